@@ -1,0 +1,206 @@
+/*
+ * maro_amd.h — C ABI of the MI355X batched rollout engine for MARO's CIM simulator.
+ *
+ * This is the drop-in boundary for the hot path named by BASELINE.json:north_star:
+ * thousands of independent CIM environments stepping on one GPU.  The reference has
+ * no FFI for this path (its native seam is the per-scalar Cython BackendAbc,
+ * maro/backends/backend.pxd:47-157, which is the wrong granularity for a batch engine),
+ * so every entry point below cites the reference *Python* interface it replaces.
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in signatures (`void* stream` is a hipStream_t);
+ *  - every `d_*` pointer is a CALLER-OWNED DEVICE pointer (e.g. torch tensor data_ptr());
+ *    the engine owns only its handle; all engine state lives in the caller-provided
+ *    workspace (`d_workspace`), so PyTorch stays the device allocator;
+ *  - all calls are asynchronous on `stream`, never synchronise, never throw; they
+ *    return 0 or a negative mrx_status; mrx_last_error() describes the last failure
+ *    on the calling thread;
+ *  - one handle <-> one stream at a time (thread-compatible, no internal threads).
+ */
+#ifndef MARO_AMD_H_
+#define MARO_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mrx_status {
+  MRX_OK = 0,
+  MRX_ERR_INVALID_ARG = -1,
+  MRX_ERR_UNSUPPORTED = -2, /* topology exceeds engine limits (ports/vessels > 64 ...) */
+  MRX_ERR_WORKSPACE = -3,   /* workspace too small / misaligned */
+  MRX_ERR_HIP = -4,         /* a HIP runtime call failed */
+  MRX_ERR_NO_DEVICE = -5
+} mrx_status;
+
+/* Per-environment status bits written by the kernels (mrx_cim_layout.off_status). */
+enum {
+  MRX_ENV_OK = 0,
+  MRX_ENV_INVALID_ACTION = 1, /* reference: AssertionError in _on_action_received,
+                                 cim/business_engine.py:731,736 — action skipped */
+  MRX_ENV_STOP_OVERFLOW = 2   /* route unrolling exceeded max_stops (engine limit) */
+};
+
+/* Action types, reference cim/common.py:18-22 (ActionType.LOAD / DISCHARGE). */
+enum { MRX_ACTION_LOAD = 0, MRX_ACTION_DISCHARGE = 1 };
+
+/*
+ * Flat CIM topology: everything the reference parses out of topologies/<name>/config.yml
+ * (maro/data_lib/cim/parsers.py:14-211, cim_data_generator.py:118-205).  Index order is
+ * yml order (parsers.py:27-52, 151-156).  All arrays are HOST pointers, copied at create.
+ * Numbers that the reference keeps as Python int/float and feeds into float arithmetic
+ * are doubles here (exactly representable), so device fp64 reproduces CPython bit for bit.
+ */
+typedef struct mrx_cim_topology {
+  int32_t n_ports, n_vessels, n_routes;
+  int32_t n_targets;      /* sum over ports of len(order_distribution.targets) */
+  int32_t n_route_points; /* sum over routes of len(route) */
+  int32_t past_stop_number, future_stop_number; /* stop_number: [past, future] */
+  int32_t container_volume;                     /* container_volumes[0] */
+  int32_t total_containers;
+  int32_t order_mode; /* 0 = fixed, 1 = unfixed (OrderGenerateMode, entities.py) */
+  int64_t seed;       /* topology default seed */
+
+  /* container_usage_proportion, after np.interp over one period (parsers.py:80-91) */
+  int32_t period;
+  double sample_noise;
+  const double* order_dist; /* [period] */
+
+  /* ports */
+  const int32_t* port_capacity;   /* [P] */
+  const int32_t* port_init_empty; /* [P] int(initial_container_proportion*total) parsers.py:190 */
+  const double* empty_return_base; /* [P] empty_return.buffer_ticks */
+  const double* empty_return_noise;
+  const double* full_return_base; /* [P] full_return.buffer_ticks */
+  const double* full_return_noise;
+  const double* source_base; /* [P] order_distribution.source.proportion */
+  const double* source_noise;
+  const int32_t* target_offset; /* [P+1] CSR into target_* */
+  const int32_t* target_port;   /* [n_targets] destination port index */
+  const double* target_base;    /* [n_targets] */
+  const double* target_noise;
+
+  /* routes */
+  const int32_t* route_offset; /* [R+1] CSR into route_* */
+  const int32_t* route_port;   /* [n_route_points] */
+  const double* route_dist;    /* [n_route_points] distance_to_next_port */
+
+  /* vessels */
+  const int32_t* vessel_capacity;     /* [V] */
+  const int32_t* vessel_init_empty;   /* [V] vessels.<name>.empty (default 0) */
+  const int32_t* vessel_route;        /* [V] route index */
+  const int32_t* vessel_start_offset; /* [V] position of initial_port_name in its route */
+  const double* vessel_speed;         /* [V] sailing.speed */
+  const double* vessel_speed_noise;
+  const double* vessel_duration; /* [V] parking.duration */
+  const double* vessel_duration_noise;
+} mrx_cim_topology;
+
+/* Env(...) constructor arguments, reference maro/simulator/core.py:42-56. */
+typedef struct mrx_cim_config {
+  int32_t n_envs;
+  int32_t device;              /* HIP device ordinal */
+  int32_t start_tick;          /* core.py:46 */
+  int32_t durations;           /* core.py:47; max_tick = start_tick + durations */
+  int32_t snapshot_resolution; /* core.py:48 */
+  int32_t max_snapshots;       /* core.py:49; <=0 -> ceil(durations/resolution) (abs_business_engine.py:115-129) */
+  int32_t max_actions;         /* A: actions accepted per decision event per step (>=1) */
+  int32_t max_stops;           /* <=0 -> engine computes a safe bound per vessel */
+} mrx_cim_config;
+
+/* Word (4-byte) offsets describing the engine's HBM layout inside the workspace, so the
+ * host can build zero-copy tensor views (live frames, snapshot ring, status words). */
+typedef struct mrx_cim_layout {
+  int32_t n_envs, n_ports, n_vessels;
+  int32_t frame_words;      /* FW: words per env frame */
+  int32_t ring_slots;       /* S: snapshot ring capacity per env */
+  int32_t max_stops;        /* stop-table capacity per vessel */
+  int32_t horizon;          /* H: pending-return ring depth in ticks */
+  /* within one frame (word offsets): ports are [attr][port], vessels [attr][slot][vessel] */
+  int32_t frame_off_ports;    /* 12 attrs x P */
+  int32_t frame_off_vessels;  /* 24 words x V */
+  int32_t frame_off_full_on_ports;   /* P*P, row = src, col = dst */
+  int32_t frame_off_full_on_vessels; /* V*P */
+  int32_t frame_off_vessel_plans;    /* V*P */
+  /* byte offsets of the big arrays inside the workspace */
+  int64_t off_live;    /* int32 [n_envs][FW] */
+  int64_t off_ring;    /* int32 [n_envs][S][FW] */
+  int64_t off_ring_fi; /* int32 [n_envs][S]  frame index held by each slot, -1 = empty */
+  int64_t off_status;  /* int32 [n_envs] MRX_ENV_* bits */
+  int64_t off_tick;    /* int32 [n_envs] current tick of each env */
+  int64_t off_seed;    /* int64 [n_envs] base seed in use */
+  int64_t off_stops;   /* uint32 [n_envs][V][max_stops]  (arrival<<8 | parking) */
+  int64_t off_nstops;  /* int32 [n_envs][V] */
+  int64_t off_order_prop; /* int32 [n_envs or 1][max_tick] */
+  int64_t off_vessel_period; /* int32 [V] vessel_period_without_noise */
+  int64_t workspace_bytes;
+} mrx_cim_layout;
+
+typedef struct mrx_cim_engine* mrx_handle;
+
+/* Bytes of device workspace the caller must allocate (256-byte aligned). */
+int64_t mrx_cim_workspace_bytes(const mrx_cim_topology* topo, const mrx_cim_config* cfg);
+
+/* Replaces Env.__init__ for N envs (core.py:42-90, cim/business_engine.py:40-105).
+ * Does not generate data: call mrx_cim_reset before the first step. */
+int mrx_cim_create(const mrx_cim_topology* topo, const mrx_cim_config* cfg, void* d_workspace,
+                   int64_t workspace_bytes, mrx_handle* out);
+int mrx_cim_destroy(mrx_handle h);
+int mrx_cim_get_layout(mrx_handle h, mrx_cim_layout* out);
+
+/*
+ * Replaces Env.reset / Env.set_seed (core.py:143-170,219-229;
+ * cim_data_container_helpers.py:56-73; cim/business_engine.py:226-245) for every env whose
+ * d_env_mask byte is non-zero (NULL = all).  d_seed_cmd[e] (NULL = all -1):
+ *    >= 0 : set_seed(s) + reset(keep_seed=True)   -> regenerate with base seed s
+ *    -1   : reset(keep_seed=True)                  -> same data, RNG streams rewound
+ *    -2   : reset(keep_seed=False)                 -> new seed = route_init.randint(0,4095)
+ * Route unrolling (cim_data_generator.py:18-115), order proportion (parsers.py:57-106),
+ * MT19937 seeding (sim_random.py:35-63) and frame initialisation all run on the device.
+ */
+int mrx_cim_reset(mrx_handle h, const int64_t* d_seed_cmd, const uint8_t* d_env_mask, void* stream);
+
+/*
+ * Replaces Env.step(action) in Sequential decision mode (core.py:92-133, 317-381) for every
+ * env whose d_env_mask byte is non-zero (NULL = all): applies the actions to the pending
+ * decision event (cim/business_engine.py:708-748), then advances ticks (…:122-224 and the
+ * handlers :448-706) until the next decision event or the end of the episode.
+ *   d_actions   int32 [n_envs][A][4] = (vessel_idx, port_idx, quantity, MRX_ACTION_*)
+ *   d_n_actions int32 [n_envs] number of valid actions per env (NULL = 0: action=None)
+ *   d_decisions int32 [n_envs][8] = (tick, port_idx, vessel_idx, scope.load, scope.discharge,
+ *               early_discharge, frame_index, valid)   valid=0 -> no decision (episode done)
+ *   d_metrics   int64 [n_envs][3] = (order_requirements, container_shortage, operation_number)
+ *   d_done      uint8 [n_envs]
+ * Outputs of masked-out envs are left untouched.
+ */
+int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_actions,
+                 const uint8_t* d_env_mask, int32_t* d_decisions, int64_t* d_metrics,
+                 uint8_t* d_done, void* stream);
+
+/*
+ * Replaces snapshot_list[node][ticks:nodes:attrs] (frame.pyx:754-801, np_backend.pyx:520-549).
+ *   node_type 0 = ports, 1 = vessels, 2 = matrices
+ *   d_ticks   int32 frame indices, [nt] shared by all envs (ticks_per_env = 0) or [n_envs][nt]
+ *   d_nodes   int32 [nn] node indices;  d_attrs int32 [na] attribute ids (mrx_cim_attr_id)
+ *   d_out     float64 [n_envs][nt][nn][sum(slots)] — flat order tick -> node -> attr -> slot,
+ *             zeros for frame indices not held by the ring (np_backend.pyx:541-545).
+ */
+int mrx_cim_query(mrx_handle h, int node_type, const int32_t* d_ticks, int nt, int ticks_per_env,
+                  const int32_t* d_nodes, int nn, const int32_t* d_attrs, int na, double* d_out,
+                  void* stream);
+
+/* Attribute name -> id and slot count for a node type; returns -1 for an unknown attribute
+ * (reference raises BackendsInvalidAttributeException, frame.pyx:786-790). */
+int mrx_cim_attr_id(int node_type, const char* name);
+int mrx_cim_attr_slots(mrx_handle h, int node_type, int attr_id);
+
+const char* mrx_last_error(void);
+const char* mrx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARO_AMD_H_ */

@@ -1,0 +1,206 @@
+"""ctypes wrapper around oracle/libcim_oracle.so  —  ORACLE, test infrastructure only.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (maro_amd/) never does.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcim_oracle.so")
+
+PORT_ATTRS = ["capacity", "empty", "full", "on_shipper", "on_consignee", "shortage", "acc_shortage", "booking",
+              "acc_booking", "fulfillment", "acc_fulfillment", "transfer_cost"]
+VESSEL_ATTRS = ["capacity", "empty", "full", "remaining_space", "early_discharge", "is_parking", "loc_port_idx",
+                "route_idx", "last_loc_idx", "next_loc_idx", "past_stop_list", "past_stop_tick_list",
+                "future_stop_list", "future_stop_tick_list"]
+MATRIX_ATTRS = ["full_on_ports", "full_on_vessels", "vessel_plans"]
+NODE_ATTRS = {"ports": PORT_ATTRS, "vessels": VESSEL_ATTRS, "matrices": MATRIX_ATTRS}
+NODE_TYPE = {"ports": 0, "vessels": 1, "matrices": 2}
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "cim_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "mt19937.h"))):
+        subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.cim_oracle_create.restype = ctypes.c_void_p
+        L.cim_oracle_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.cim_oracle_destroy.argtypes = [ctypes.c_void_p]
+        L.cim_oracle_set_seed.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+        L.cim_oracle_reset.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.cim_oracle_step.restype = ctypes.c_int
+        L.cim_oracle_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.cim_oracle_query.restype = ctypes.c_int64
+        L.cim_oracle_query.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.cim_oracle_query_live.restype = ctypes.c_int64
+        L.cim_oracle_query_live.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        for name in ("cim_oracle_tick", "cim_oracle_error", "cim_oracle_num_frames"):
+            getattr(L, name).restype = ctypes.c_int
+            getattr(L, name).argtypes = [ctypes.c_void_p]
+        L.cim_oracle_data_seed.restype = ctypes.c_int64
+        L.cim_oracle_data_seed.argtypes = [ctypes.c_void_p]
+        L.cim_oracle_frame_indices.restype = ctypes.c_int
+        L.cim_oracle_frame_indices.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.cim_oracle_num_stops.restype = ctypes.c_int
+        L.cim_oracle_num_stops.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.cim_oracle_get_stops.restype = ctypes.c_int
+        L.cim_oracle_get_stops.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_int]
+        L.cim_oracle_get_order_proportion.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.cim_oracle_get_vessel_period.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.cim_oracle_stream_seeds.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.cim_oracle_mt_selftest.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _i32(xs) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(xs, dtype=np.int32))
+
+
+class CimOracle:
+    """One reference-equivalent CIM ``Env`` (Sequential decision mode), fresh-process semantics."""
+
+    def __init__(self, topology, start_tick: int = 0, durations: int = 100, snapshot_resolution: int = 1,
+                 max_snapshots: Optional[int] = None):
+        from maro_amd.cim.topology import CimTopology, load_topology  # host-side parser (no device code)
+
+        self.topo: CimTopology = topology if isinstance(topology, CimTopology) else load_topology(topology)
+        self._cs = self.topo.c_struct()
+        self.max_tick = start_tick + durations
+        self._h = lib().cim_oracle_create(ctypes.byref(self._cs), start_tick, durations, snapshot_resolution,
+                                          max_snapshots or 0)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().cim_oracle_destroy(self._h)
+            self._h = None
+
+    def set_seed(self, seed: int):
+        lib().cim_oracle_set_seed(self._h, int(seed))
+
+    def reset(self, keep_seed: bool = False):
+        lib().cim_oracle_reset(self._h, 1 if keep_seed else 0)
+
+    def step(self, actions: Optional[Sequence[Sequence[int]]] = None) -> Tuple[np.ndarray, np.ndarray, bool]:
+        """actions: iterable of (vessel_idx, port_idx, quantity, type[0=load,1=discharge]).
+        Returns (metrics int64[3], decision int32[8], done)."""
+        acts = _i32(actions).reshape(-1, 4) if actions is not None and len(actions) else np.zeros((0, 4), np.int32)
+        dec = np.zeros(8, np.int32)
+        met = np.zeros(3, np.int64)
+        done = lib().cim_oracle_step(self._h, acts.ctypes.data, acts.shape[0], dec.ctypes.data, met.ctypes.data)
+        return met, dec, bool(done)
+
+    def query(self, node: str, ticks: Sequence[int], nodes: Sequence[int], attrs: Sequence[str]) -> np.ndarray:
+        t, n = _i32(ticks), _i32(nodes)
+        a = _i32([NODE_ATTRS[node].index(x) for x in attrs])
+        args = (self._h, NODE_TYPE[node], t.ctypes.data, len(t), n.ctypes.data, len(n), a.ctypes.data, len(a))
+        size = lib().cim_oracle_query(*args, None)
+        out = np.zeros(size, np.float64)
+        lib().cim_oracle_query(*args, out.ctypes.data)
+        return out
+
+    def query_live(self, node: str, attrs: Sequence[str]) -> np.ndarray:
+        a = _i32([NODE_ATTRS[node].index(x) for x in attrs])
+        out = np.zeros(1 << 16, np.float64)
+        n = lib().cim_oracle_query_live(self._h, NODE_TYPE[node], a.ctypes.data, len(a), out.ctypes.data)
+        return out[:n].copy()
+
+    @property
+    def tick(self) -> int:
+        return lib().cim_oracle_tick(self._h)
+
+    @property
+    def error(self) -> int:
+        return lib().cim_oracle_error(self._h)
+
+    @property
+    def data_seed(self) -> int:
+        return lib().cim_oracle_data_seed(self._h)
+
+    def frame_indices(self) -> List[int]:
+        n = lib().cim_oracle_num_frames(self._h)
+        out = np.zeros(max(n, 1), np.int32)
+        lib().cim_oracle_frame_indices(self._h, out.ctypes.data, n)
+        return out[:n].tolist()
+
+    def stops(self, vessel: int):
+        n = lib().cim_oracle_num_stops(self._h, vessel)
+        a, l, p = (np.zeros(n, np.int32) for _ in range(3))
+        lib().cim_oracle_get_stops(self._h, vessel, a.ctypes.data, l.ctypes.data, p.ctypes.data, n)
+        return a, l, p
+
+    def order_proportion(self) -> np.ndarray:
+        out = np.zeros(self.max_tick, np.int32)
+        lib().cim_oracle_get_order_proportion(self._h, out.ctypes.data)
+        return out
+
+    def vessel_period(self) -> np.ndarray:
+        out = np.zeros(self.topo.n_vessels, np.int32)
+        lib().cim_oracle_get_vessel_period(self._h, out.ctypes.data)
+        return out
+
+    def stream_seeds(self) -> np.ndarray:
+        out = np.zeros(4, np.int64)
+        lib().cim_oracle_stream_seeds(self._h, out.ctypes.data)
+        return out
+
+
+def mt_selftest(seed: int, n: int):
+    r = np.zeros(n, np.float64)
+    b = np.zeros(n, np.uint32)
+    lib().cim_oracle_mt_selftest(int(seed), n, r.ctypes.data, b.ctypes.data)
+    return r, b
+
+
+# ---- deterministic test policies shared by the oracle, the golden generator and the GPU tests ----
+class Rand0Policy:
+    """SURVEY §8c `rand0`: rng=random.Random(seed); per decision
+    `if rng.random()<0.5 and scope.load>0: LOAD rng.randint(0,scope.load) else: DISCHARGE rng.randint(0,scope.discharge)`."""
+
+    def __init__(self, seed: int = 0):
+        import random
+
+        self.rng = random.Random(seed)
+
+    def __call__(self, dec) -> List[Tuple[int, int, int, int]]:
+        tick, port, vessel, load, discharge = (int(x) for x in dec[:5])
+        if self.rng.random() < 0.5 and load > 0:
+            return [(vessel, port, self.rng.randint(0, load), 0)]
+        return [(vessel, port, self.rng.randint(0, discharge), 1)]
+
+
+def hash_policy_action(env_seed: int, step: int, dec) -> Tuple[int, int, int, int]:
+    """Counter-based legal random action, identical on host and device (bench/parity at scale):
+    h = splitmix-style hash of (env_seed, step); even -> LOAD h % (load+1) if load>0 else DISCHARGE."""
+    m = (1 << 64) - 1
+    x = (int(env_seed) * 0x9E3779B97F4A7C15 + int(step) * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) & m
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & m
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & m
+    x ^= x >> 31
+    tick, port, vessel, load, discharge = (int(v) for v in dec[:5])
+    r = x >> 1
+    if (x & 1) == 0 and load > 0:
+        return (vessel, port, r % (load + 1), 0)
+    return (vessel, port, r % (discharge + 1), 1)
