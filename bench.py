@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the batched CIM rollout engine on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
+    CIM global_trade.22p_l0.8, 16384 envs per GPU, durations 1120, device-side random legal agent,
+    snapshot_list["ports"][frame::7 attrs] sliced for every env every step.
+One "step" = one pass of the hot path over the whole batch:
+    random-policy kernel -> mrx_cim_step (action + ticks until the next decision) -> snapshot query.
+value = decision events resolved per second, whole job (all ranks), state resident in HBM.
+
+    python bench.py --gpus 1 --steps 400 --warmup 100
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+# reference-dtype frame bytes per env and targets per topology family
+FRAME_BYTES = {"global_trade.22p": 15412, "toy.4p_ssdd": 886}
+QUERY_ATTRS = ["empty", "full", "on_shipper", "on_consignee", "booking", "shortage", "fulfillment"]
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def frame_bytes(topo):
+    for k, v in FRAME_BYTES.items():
+        if topo.name.startswith(k):
+            return v
+    P, V = topo.n_ports, topo.n_vessels
+    return P * 48 + V * (9 * 4 + 2 + (2 * topo.past_stop_number + 2 * topo.future_stop_number) * 4) + 4 * (P * P + 2 * V * P)
+
+
+def cpu_baseline(topology, durations, budget_s):
+    """The C oracle (a port of the reference algorithm) timed on ONE host core: whole episodes of the same
+    workload with the same counter-based agent, until ~budget_s seconds of CPU work."""
+    from oracle.cim_oracle import CimOracle
+
+    o = CimOracle(topology, durations=durations)
+    steps = ticks = episodes = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        o.set_seed(1000 + episodes)
+        o.reset(keep_seed=True)
+        n, tk, _ = o.rollout(1000 + episodes)
+        steps += n
+        ticks += tk
+        episodes += 1
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{episodes} full episodes of {topology} ({durations} ticks, reset+rollout in C, "
+                      f"{steps} decisions, {dt:.1f} s on 1 core; {ticks / dt:.0f} ticks/s)",
+            "note": "reference Python Env.step measured in the build container: ~311 env-steps/s (BASELINE.md §2)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, default=16384, help="environments per GPU (weak scaling)")
+    ap.add_argument("--topology", default="global_trade.22p_l0.8")
+    ap.add_argument("--durations", type=int, default=1120)
+    ap.add_argument("--ring", type=int, default=4, help="snapshot ring slots per env (max_snapshots)")
+    ap.add_argument("--no-query", action="store_true", help="skip the per-step snapshot slice")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import __graft_entry__ as ge
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        ge.build()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dist.barrier()
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    from maro_amd.cim.engine import CimBatchEngine
+
+    n = args.envs
+    seeds = torch.arange(n, dtype=torch.int64) + rank * n + 1
+    eng = CimBatchEngine(args.topology, n, durations=args.durations, max_snapshots=args.ring, max_actions=1,
+                         device=dev, seeds=seeds)
+    topo = eng.topo
+    actions = torch.zeros((n, 1, 4), dtype=torch.int32, device=dev)
+    n_actions = torch.zeros((n,), dtype=torch.int32, device=dev)
+    counter = torch.zeros((1,), dtype=torch.int64, device=dev)
+    ports = torch.arange(topo.n_ports, dtype=torch.int32, device=dev)
+    q_out = None if args.no_query else torch.empty((n, 1, topo.n_ports, len(QUERY_ATTRS)), dtype=torch.float64, device=dev)
+
+    def one_step(i):
+        if i == 0:
+            eng.step()  # first step of the episode: action=None
+            return
+        eng.random_policy(i, actions, n_actions, counter)
+        eng.step(actions, n_actions)
+        if q_out is not None:
+            eng.query("ports", eng.decisions[:, 6:7], ports, QUERY_ATTRS, out=q_out)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    step_i = 0
+    for _ in range(args.warmup):
+        one_step(step_i)
+        step_i += 1
+    sync_all()
+    counter.zero_()
+    tick0 = eng.ticks.to(torch.int64).sum().item()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(step_i)
+        step_i += 1
+    sync_all()
+    dt = time.perf_counter() - t0
+    # decisions answered inside the timed window (+1 policy call lag is exact: K policy calls in the window)
+    resolved = int(counter.item())
+    ticks_adv = eng.ticks.to(torch.int64).sum().item() - tick0
+    n_done = int(eng.done.sum().item())
+    status_bad = int((eng.status != 0).sum().item())
+
+    # ---- dominant kernel (mrx_k_cim_step) timed live with HIP events on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 100))]
+    for a, b in ev:
+        eng.random_policy(step_i, actions, n_actions, None)
+        a.record()
+        eng.step(actions, n_actions)
+        b.record()
+        step_i += 1
+    torch.cuda.synchronize(dev)
+    step_kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+
+    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(resolved), float(ticks_adv), float(n_done), float(status_bad)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt = float(t_max.item())
+    resolved, ticks_adv, n_done, status_bad = (float(x) for x in tot.tolist())
+
+    if rank == 0:
+        value = resolved / dt
+        tbar = ticks_adv / max(resolved, 1.0)  # mean ticks advanced per env-step
+        F = frame_bytes(topo)
+        b_step = (3.0 + tbar) * F + 4.0 * topo.n_targets * tbar + 40.0
+        bytes_per_launch = b_step * n
+        achieved = bytes_per_launch / (step_kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (decision events/sec), CIM global_trade.22p",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32+f64", "data": "synthetic",
+            "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {args.durations}, "
+                                   f"random legal agent on device, ports snapshot slice {'off' if args.no_query else 'every step'}",
+                       "envs_per_gpu": n, "ring_slots": args.ring, "parallelism": f"env-shard x{world} (no data-path collective)",
+                       "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
+            "roofline": {"bound": "hbm", "kernel": "mrx_k_cim_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": step_kernel_ms,
+                         "algorithmic_bytes_per_env_step": b_step, "env_steps_per_launch": n},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.topology, args.durations, args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

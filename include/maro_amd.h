@@ -135,7 +135,7 @@ typedef struct mrx_cim_layout {
   int64_t off_stops;   /* uint32 [n_envs][V][max_stops]  (arrival<<8 | parking) */
   int64_t off_nstops;  /* int32 [n_envs][V] */
   int64_t off_order_prop; /* int32 [n_envs or 1][max_tick] */
-  int64_t off_vessel_period; /* int32 [V] vessel_period_without_noise */
+  int64_t off_vessel_period; /* int32 [n_envs][V] vessel_period_without_noise */
   int64_t workspace_bytes;
 } mrx_cim_layout;
 
@@ -184,13 +184,23 @@ int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_acti
  * Replaces snapshot_list[node][ticks:nodes:attrs] (frame.pyx:754-801, np_backend.pyx:520-549).
  *   node_type 0 = ports, 1 = vessels, 2 = matrices
  *   d_ticks   int32 frame indices, [nt] shared by all envs (ticks_per_env = 0) or [n_envs][nt]
- *   d_nodes   int32 [nn] node indices;  d_attrs int32 [na] attribute ids (mrx_cim_attr_id)
+ *   d_nodes   int32 [nn] node indices (device);  attrs int32 [na<=16] attribute ids (HOST array,
+ *             mrx_cim_attr_id; copied into the kernel arguments)
  *   d_out     float64 [n_envs][nt][nn][sum(slots)] — flat order tick -> node -> attr -> slot,
  *             zeros for frame indices not held by the ring (np_backend.pyx:541-545).
  */
 int mrx_cim_query(mrx_handle h, int node_type, const int32_t* d_ticks, int nt, int ticks_per_env,
-                  const int32_t* d_nodes, int nn, const int32_t* d_attrs, int na, double* d_out,
+                  const int32_t* d_nodes, int nn, const int32_t* attrs, int na, double* d_out,
                   void* stream);
+
+/*
+ * Utility: the reference's hello-world random agent (examples/hello_world/cim/hello.py:22-37) as a
+ * counter-based device policy, so rollouts need no host round trip: for every env with a valid
+ * decision writes one legal action into d_actions[e][0] (and d_n_actions[e] = 1, else 0) from
+ * hash(seed[e], step); adds the number of valid decisions to *d_counter (may be NULL).
+ */
+int mrx_cim_random_policy(mrx_handle h, const int32_t* d_decisions, int64_t step, int32_t* d_actions,
+                          int32_t* d_n_actions, uint64_t* d_counter, void* stream);
 
 /* Attribute name -> id and slot count for a node type; returns -1 for an unknown attribute
  * (reference raises BackendsInvalidAttributeException, frame.pyx:786-790). */

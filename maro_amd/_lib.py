@@ -1,0 +1,86 @@
+"""Loader of the HIP extension (maro_amd/csrc/libmaro_amd.so) — the ONLY compute path.
+
+There is deliberately no CPU / PyTorch fallback: if the shared library is missing or cannot be
+loaded the import of any engine class fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmaro_amd.so")
+
+
+class MrxCimConfig(ctypes.Structure):
+    """ctypes mirror of ``struct mrx_cim_config`` (include/maro_amd.h)."""
+
+    _fields_ = [(n, ctypes.c_int32) for n in ("n_envs", "device", "start_tick", "durations", "snapshot_resolution",
+                                              "max_snapshots", "max_actions", "max_stops")]
+
+
+class MrxCimLayout(ctypes.Structure):
+    """ctypes mirror of ``struct mrx_cim_layout`` (include/maro_amd.h)."""
+
+    _fields_ = ([(n, ctypes.c_int32) for n in ("n_envs", "n_ports", "n_vessels", "frame_words", "ring_slots",
+                                               "max_stops", "horizon", "frame_off_ports", "frame_off_vessels",
+                                               "frame_off_full_on_ports", "frame_off_full_on_vessels",
+                                               "frame_off_vessel_plans")]
+                + [(n, ctypes.c_int64) for n in ("off_live", "off_ring", "off_ring_fi", "off_status", "off_tick",
+                                                 "off_seed", "off_stops", "off_nstops", "off_order_prop",
+                                                 "off_vessel_period", "workspace_bytes")])
+
+
+EXPORTS = ("mrx_last_error", "mrx_version", "mrx_cim_workspace_bytes", "mrx_cim_create", "mrx_cim_destroy",
+           "mrx_cim_get_layout", "mrx_cim_reset", "mrx_cim_step", "mrx_cim_query", "mrx_cim_attr_id",
+           "mrx_cim_attr_slots", "mrx_cim_random_policy")
+
+_lib = None
+
+
+class ExtensionMissingError(ImportError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libmaro_amd.so and declare every entry point of include/maro_amd.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ExtensionMissingError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c \"import __graft_entry__ as g; "
+            f"g.build()\"` (hipcc --offload-arch=gfx950). maro_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    L.mrx_last_error.restype = ctypes.c_char_p
+    L.mrx_version.restype = ctypes.c_char_p
+    L.mrx_cim_workspace_bytes.restype = i64
+    L.mrx_cim_workspace_bytes.argtypes = [vp, vp]
+    L.mrx_cim_create.restype = i32
+    L.mrx_cim_create.argtypes = [vp, vp, vp, i64, ctypes.POINTER(vp)]
+    L.mrx_cim_destroy.restype = i32
+    L.mrx_cim_destroy.argtypes = [vp]
+    L.mrx_cim_get_layout.restype = i32
+    L.mrx_cim_get_layout.argtypes = [vp, vp]
+    L.mrx_cim_reset.restype = i32
+    L.mrx_cim_reset.argtypes = [vp, vp, vp, vp]
+    L.mrx_cim_step.restype = i32
+    L.mrx_cim_step.argtypes = [vp] * 8
+    L.mrx_cim_query.restype = i32
+    L.mrx_cim_query.argtypes = [vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, vp]
+    L.mrx_cim_random_policy.restype = i32
+    L.mrx_cim_random_policy.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    L.mrx_cim_attr_id.restype = i32
+    L.mrx_cim_attr_id.argtypes = [i32, ctypes.c_char_p]
+    L.mrx_cim_attr_slots.restype = i32
+    L.mrx_cim_attr_slots.argtypes = [vp, i32, i32]
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str):
+    if rc < 0:
+        msg = load().mrx_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")
+    return rc

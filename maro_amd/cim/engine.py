@@ -1,0 +1,160 @@
+"""Batched CIM rollout engine: thin Python plumbing over the C ABI (include/maro_amd.h).
+
+PyTorch owns the device memory (one uint8 workspace tensor + caller-visible I/O tensors) and the
+stream; every state transition runs in the hand-written HIP kernels of maro_amd/csrc/.
+Tensor conventions are those of the C ABI:
+    actions   int32 [n_envs, A, 4] = (vessel_idx, port_idx, quantity, 0=LOAD | 1=DISCHARGE)
+    decisions int32 [n_envs, 8]    = (tick, port_idx, vessel_idx, scope.load, scope.discharge,
+                                      early_discharge, frame_index, valid)
+    metrics   int64 [n_envs, 3]    = (order_requirements, container_shortage, operation_number)
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .topology import CimTopology, load_topology
+
+PORT_ATTRS = ["capacity", "empty", "full", "on_shipper", "on_consignee", "shortage", "acc_shortage", "booking",
+              "acc_booking", "fulfillment", "acc_fulfillment", "transfer_cost"]
+VESSEL_ATTRS = ["capacity", "empty", "full", "remaining_space", "early_discharge", "is_parking", "loc_port_idx",
+                "route_idx", "last_loc_idx", "next_loc_idx", "past_stop_list", "past_stop_tick_list",
+                "future_stop_list", "future_stop_tick_list"]
+MATRIX_ATTRS = ["full_on_ports", "full_on_vessels", "vessel_plans"]
+NODE_ATTRS = {"ports": PORT_ATTRS, "vessels": VESSEL_ATTRS, "matrices": MATRIX_ATTRS}
+NODE_TYPE = {"ports": 0, "vessels": 1, "matrices": 2}
+
+SEED_KEEP = -1      # reset(keep_seed=True)
+SEED_REDRAW = -2    # reset(keep_seed=False): new seed = route_init.randint(0, 4095)
+
+
+class CimBatchEngine:
+    """N independent CIM environments (Sequential decision mode) resident on one MI355X."""
+
+    def __init__(self, topology: Union[str, CimTopology], n_envs: int, start_tick: int = 0, durations: int = 100,
+                 snapshot_resolution: int = 1, max_snapshots: Optional[int] = None, max_actions: int = 1,
+                 device: Union[str, torch.device] = "cuda:0", seeds: Optional[Sequence[int]] = None):
+        self._L = _lib.load()  # raises if the HIP extension is not built
+        if not torch.cuda.is_available():
+            raise RuntimeError("maro_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.topo = topology if isinstance(topology, CimTopology) else load_topology(topology)
+        self.device = torch.device(device)
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.n_envs, self.max_actions = int(n_envs), int(max_actions)
+        self.start_tick, self.durations = int(start_tick), int(durations)
+        self.max_tick = self.start_tick + self.durations
+        self.snapshot_resolution = int(snapshot_resolution)
+        self._cs = self.topo.c_struct()
+        self._cfg = _lib.MrxCimConfig(self.n_envs, dev_index, self.start_tick, self.durations,
+                                      self.snapshot_resolution, int(max_snapshots or 0), self.max_actions, 0)
+        nbytes = self._L.mrx_cim_workspace_bytes(ctypes.byref(self._cs), ctypes.byref(self._cfg))
+        _lib.check(nbytes, "mrx_cim_workspace_bytes")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize()
+            _lib.check(self._L.mrx_cim_create(ctypes.byref(self._cs), ctypes.byref(self._cfg),
+                                              self.workspace.data_ptr(), nbytes, ctypes.byref(h)), "mrx_cim_create")
+        self._h = h
+        self.layout = _lib.MrxCimLayout()
+        _lib.check(self._L.mrx_cim_get_layout(self._h, ctypes.byref(self.layout)), "mrx_cim_get_layout")
+        lay = self.layout
+        # zero-copy views of engine state
+        self.live = self._view(lay.off_live, torch.int32, (self.n_envs, lay.frame_words))
+        self.ring = self._view(lay.off_ring, torch.int32, (self.n_envs, lay.ring_slots, lay.frame_words))
+        self.ring_fi = self._view(lay.off_ring_fi, torch.int32, (self.n_envs, lay.ring_slots))
+        self.status = self._view(lay.off_status, torch.int32, (self.n_envs,))
+        self.ticks = self._view(lay.off_tick, torch.int32, (self.n_envs,))
+        self.seeds = self._view(lay.off_seed, torch.int64, (self.n_envs,))
+        # persistent outputs
+        self.decisions = torch.zeros((self.n_envs, 8), dtype=torch.int32, device=self.device)
+        self.metrics = torch.zeros((self.n_envs, 3), dtype=torch.int64, device=self.device)
+        self.done = torch.zeros((self.n_envs,), dtype=torch.uint8, device=self.device)
+        if seeds is not None:
+            self.reset(seeds)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.mrx_cim_destroy(h)
+            self._h = None
+
+    # ------------------------------------------------------------------ helpers
+    def _view(self, off: int, dtype: torch.dtype, shape) -> torch.Tensor:
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        return self.workspace[off:off + n].view(dtype).view(*shape)
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _dev(self, x, dtype) -> Optional[torch.Tensor]:
+        if x is None:
+            return None
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.asarray(x), dtype=dtype)
+        return x.to(device=self.device, dtype=dtype).contiguous()
+
+    @staticmethod
+    def _p(t: Optional[torch.Tensor]):
+        return None if t is None else t.data_ptr()
+
+    # ------------------------------------------------------------------ C ABI calls
+    def reset(self, seed_cmd=None, mask=None) -> None:
+        """seed_cmd[e]: >=0 explicit seed (set_seed + reset(keep_seed=True)); -1 keep; -2 redraw."""
+        sc = self._dev(seed_cmd, torch.int64)
+        mk = self._dev(mask, torch.uint8)
+        _lib.check(self._L.mrx_cim_reset(self._h, self._p(sc), self._p(mk), self._stream()), "mrx_cim_reset")
+        self._keep = (sc, mk)
+
+    def step(self, actions=None, n_actions=None, mask=None):
+        a = self._dev(actions, torch.int32)
+        na = self._dev(n_actions, torch.int32)
+        mk = self._dev(mask, torch.uint8)
+        if a is not None:
+            assert a.numel() == self.n_envs * self.max_actions * 4, "actions must be [n_envs, max_actions, 4]"
+            if na is None:
+                na = torch.full((self.n_envs,), self.max_actions, dtype=torch.int32, device=self.device)
+        _lib.check(self._L.mrx_cim_step(self._h, self._p(a), self._p(na), self._p(mk), self.decisions.data_ptr(),
+                                        self.metrics.data_ptr(), self.done.data_ptr(), self._stream()), "mrx_cim_step")
+        self._keep = (a, na, mk)
+        return self.decisions, self.metrics, self.done
+
+    def random_policy(self, step: int, actions: torch.Tensor, n_actions: torch.Tensor,
+                      counter: Optional[torch.Tensor] = None) -> None:
+        """Device-side random legal agent (hello-world policy): fills actions[:,0] / n_actions from the current
+        decisions; adds the number of answered decisions to `counter` (uint64/int64 scalar tensor)."""
+        _lib.check(self._L.mrx_cim_random_policy(self._h, self.decisions.data_ptr(), int(step), actions.data_ptr(),
+                                                 n_actions.data_ptr(), self._p(counter), self._stream()),
+                   "mrx_cim_random_policy")
+
+    def attr_ids(self, node: str, attrs: Sequence[str]):
+        ids = []
+        for a in attrs:
+            i = self._L.mrx_cim_attr_id(NODE_TYPE[node], a.encode())
+            if i < 0:
+                raise KeyError(f"unknown attribute {a!r} of node {node!r}")
+            ids.append(i)
+        return ids
+
+    def row_slots(self, node: str, attr_ids: Sequence[int]) -> int:
+        return sum(self._L.mrx_cim_attr_slots(self._h, NODE_TYPE[node], int(a)) for a in attr_ids)
+
+    def query(self, node: str, ticks, nodes, attrs: Sequence[str], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """float64 [n_envs, nt, nn, sum(slots)]; `ticks` are frame indices, [nt] or [n_envs, nt]."""
+        ids = self.attr_ids(node, attrs)
+        t = self._dev(ticks, torch.int32)
+        n = self._dev(nodes, torch.int32)
+        per_env = 1 if t.dim() == 2 else 0
+        nt, nn = int(t.shape[-1]), int(n.numel())
+        slots = self.row_slots(node, ids)
+        if out is None:
+            out = torch.empty((self.n_envs, nt, nn, slots), dtype=torch.float64, device=self.device)
+        ida = (ctypes.c_int32 * len(ids))(*ids)
+        _lib.check(self._L.mrx_cim_query(self._h, NODE_TYPE[node], t.data_ptr(), nt, per_env, n.data_ptr(), nn, ida,
+                                         len(ids), out.data_ptr(), self._stream()), "mrx_cim_query")
+        self._keep_q = (t, n)
+        return out

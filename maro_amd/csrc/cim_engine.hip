@@ -1,0 +1,269 @@
+// cim_engine.hip — gfx950 kernels + the C ABI of include/maro_amd.h.
+//
+// Launch geometry: ONE environment per 64-lane wavefront, one wavefront per workgroup, so a batch
+// of N envs is a grid of N workgroups (N >> 256 CUs fills the chip; LDS use per workgroup bounds
+// residency).  Each workgroup touches only its own env's HBM rows (coalesced 16 B/lane copies
+// HBM <-> LDS), so there is no inter-workgroup traffic, no atomics and no XCD-affinity concern
+// beyond the tiny read-only topology tables that every L2 caches.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+
+#include "wave.h"
+#include "cim_device.h"
+#include "cim_layout.h"
+
+// ------------------------------------------------------------------------------------------ kernels
+extern "C" __global__ void __launch_bounds__(64)
+mrx_k_cim_reset(CimParams K, const long long* __restrict__ seed_cmd, const uint8_t* __restrict__ mask, long long default_cmd) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const int env = blockIdx.x;
+  if (mask && !mask[env]) return;
+  cim::reset_env(K, env, lds, seed_cmd ? seed_cmd[env] : default_cmd);
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+mrx_k_cim_step(CimParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions,
+               const uint8_t* __restrict__ mask, int32_t* __restrict__ decisions, long long* __restrict__ metrics,
+               uint8_t* __restrict__ done) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const int env = blockIdx.x;
+  if (mask && !mask[env]) return;
+  const int32_t* a = actions ? actions + (size_t)env * K.max_actions * 4 : nullptr;
+  const int na = (actions && n_actions) ? n_actions[env] : 0;
+  cim::step_env(K, env, lds, a, na, decisions + (size_t)env * 8, metrics + (size_t)env * 3, done + env);
+}
+
+struct AttrList { int n; int32_t id[16]; };
+
+extern "C" __global__ void __launch_bounds__(256)
+mrx_k_cim_query(CimParams K, int node_type, const int32_t* __restrict__ ticks, int nt, int ticks_per_env,
+                const int32_t* __restrict__ nodes, int nn, AttrList al, int row_slots, long long total,
+                double* __restrict__ out) {
+  const int32_t* attrs = al.id;
+  const int na = al.n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / row_slots;
+    const int col = (int)(i - row * row_slots);
+    out[i] = cim::query_elem(K, node_type, ticks, nt, ticks_per_env, nodes, nn, attrs, na, row, col);
+  }
+}
+
+// Reference random agent (examples/hello_world/cim/hello.py:22-37 style), counter-based so a CPU
+// replay can reproduce it: h = mix(seed[env], step); even -> LOAD h'%(scope.load+1) when load>0,
+// else DISCHARGE h'%(scope.discharge+1).  Also counts the valid decisions it answered.
+__device__ __forceinline__ unsigned long long mrx_mix64(unsigned long long seed, unsigned long long step) {
+  unsigned long long x = seed * 0x9E3779B97F4A7C15ull + step * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+mrx_k_cim_random_policy(CimParams K, const int32_t* __restrict__ decisions, long long step, int32_t* __restrict__ actions,
+                        int32_t* __restrict__ n_actions, unsigned long long* __restrict__ counter) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid = false;
+  if (env < K.n_envs) {
+    const int32_t* d = decisions + (size_t)env * 8;
+    valid = d[7] == 1;
+    int32_t* a = actions + (size_t)env * K.max_actions * 4;
+    if (valid) {
+      const unsigned long long x = mrx_mix64((unsigned long long)K.seed[env], (unsigned long long)step);
+      const unsigned long long r = x >> 1;
+      const int load = d[3], dis = d[4];
+      a[0] = d[2]; a[1] = d[1];
+      if ((x & 1ull) == 0 && load > 0) { a[2] = (int)(r % (unsigned long long)(load + 1)); a[3] = MRX_ACTION_LOAD; }
+      else { a[2] = (int)(r % (unsigned long long)(dis + 1)); a[3] = MRX_ACTION_DISCHARGE; }
+    }
+    n_actions[env] = valid ? 1 : 0;
+  }
+  if (counter) {
+    const unsigned long long m = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (unsigned long long)__builtin_popcountll(m));
+  }
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+struct mrx_cim_engine {
+  CimHostPlan plan;
+  int device;
+};
+
+static thread_local std::string g_err;
+static int set_err(int code, const std::string& m) { g_err = m; return code; }
+#define HIP_TRY(expr)                                                                                    \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess) return set_err(MRX_ERR_HIP, std::string(#expr ": ") + hipGetErrorString(_e)); \
+  } while (0)
+
+static int use_device(int device) {
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) return set_err(MRX_ERR_NO_DEVICE, "no HIP device available");
+  if (cur != device) HIP_TRY(hipSetDevice(device));
+  return MRX_OK;
+}
+
+extern "C" {
+
+const char* mrx_last_error(void) { return g_err.c_str(); }
+const char* mrx_version(void) { return "maro_amd 0.1 (gfx950)"; }
+
+int64_t mrx_cim_workspace_bytes(const mrx_cim_topology* topo, const mrx_cim_config* cfg) {
+  CimHostPlan pl;
+  std::string err;
+  int rc = cim_plan(topo, cfg, &pl, &err);
+  if (rc != MRX_OK) { set_err(rc, err); return rc; }
+  return pl.workspace_bytes;
+}
+
+int mrx_cim_create(const mrx_cim_topology* topo, const mrx_cim_config* cfg, void* d_workspace, int64_t workspace_bytes,
+                   mrx_handle* out) {
+  if (!out) return set_err(MRX_ERR_INVALID_ARG, "out handle is null");
+  *out = nullptr;
+  mrx_cim_engine* e = new (std::nothrow) mrx_cim_engine();
+  if (!e) return set_err(MRX_ERR_INVALID_ARG, "out of host memory");
+  std::string err;
+  int rc = cim_plan(topo, cfg, &e->plan, &err);
+  if (rc != MRX_OK) { delete e; return set_err(rc, err); }
+  if (!d_workspace || workspace_bytes < e->plan.workspace_bytes || ((uintptr_t)d_workspace & 255)) {
+    delete e;
+    return set_err(MRX_ERR_WORKSPACE, "workspace is null, smaller than mrx_cim_workspace_bytes() or not 256-byte aligned");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete e; return set_err(MRX_ERR_NO_DEVICE, "no HIP device available"); }
+  e->device = cfg->device;
+  rc = use_device(e->device);
+  if (rc != MRX_OK) { delete e; return rc; }
+  cim_plan_bind(&e->plan, d_workspace);
+  hipError_t he = hipMemcpy((uint8_t*)d_workspace + e->plan.const_off, e->plan.const_blob.data(), e->plan.const_blob.size(),
+                            hipMemcpyHostToDevice);
+  if (he != hipSuccess) { delete e; return set_err(MRX_ERR_HIP, std::string("upload of topology tables: ") + hipGetErrorString(he)); }
+  const CimParams& K = e->plan.kp;
+  if ((size_t)K.lds_words_reset * 4 > 64 * 1024) {
+    hipFuncSetAttribute((const void*)mrx_k_cim_reset, hipFuncAttributeMaxDynamicSharedMemorySize, K.lds_words_reset * 4);
+    hipFuncSetAttribute((const void*)mrx_k_cim_step, hipFuncAttributeMaxDynamicSharedMemorySize, K.lds_words * 4);
+  }
+  // Env.__init__ generates data with the topology's own seed (cim_data_generator.py:141-145)
+  hipLaunchKernelGGL(mrx_k_cim_reset, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_reset * 4, 0, K, nullptr, nullptr,
+                     (long long)topo->seed);
+  he = hipDeviceSynchronize();
+  if (he == hipSuccess) he = hipGetLastError();
+  if (he != hipSuccess) { delete e; return set_err(MRX_ERR_HIP, std::string("initial reset kernel: ") + hipGetErrorString(he)); }
+  *out = e;
+  return MRX_OK;
+}
+
+int mrx_cim_destroy(mrx_handle h) {
+  delete h;
+  return MRX_OK;
+}
+
+int mrx_cim_get_layout(mrx_handle h, mrx_cim_layout* out) {
+  if (!h || !out) return set_err(MRX_ERR_INVALID_ARG, "null handle/out");
+  *out = h->plan.layout;
+  return MRX_OK;
+}
+
+int mrx_cim_reset(mrx_handle h, const int64_t* d_seed_cmd, const uint8_t* d_env_mask, void* stream) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  int rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  const CimParams& K = h->plan.kp;
+  hipLaunchKernelGGL(mrx_k_cim_reset, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_reset * 4, (hipStream_t)stream, K,
+                     (const long long*)d_seed_cmd, d_env_mask, (long long)-1);
+  HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const uint8_t* d_env_mask,
+                 int32_t* d_decisions, int64_t* d_metrics, uint8_t* d_done, void* stream) {
+  if (!h || !d_decisions || !d_metrics || !d_done) return set_err(MRX_ERR_INVALID_ARG, "null handle/output pointer");
+  int rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  const CimParams& K = h->plan.kp;
+  hipLaunchKernelGGL(mrx_k_cim_step, dim3(K.n_envs), dim3(64), (size_t)K.lds_words * 4, (hipStream_t)stream, K, d_actions,
+                     d_n_actions, d_env_mask, d_decisions, (long long*)d_metrics, d_done);
+  HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+int mrx_cim_random_policy(mrx_handle h, const int32_t* d_decisions, int64_t step, int32_t* d_actions, int32_t* d_n_actions,
+                          uint64_t* d_counter, void* stream) {
+  if (!h || !d_decisions || !d_actions || !d_n_actions) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
+  int rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  const CimParams& K = h->plan.kp;
+  hipLaunchKernelGGL(mrx_k_cim_random_policy, dim3((K.n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, K, d_decisions,
+                     (long long)step, d_actions, d_n_actions, (unsigned long long*)d_counter);
+  HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+static int host_attr_slots(const CimParams& K, int node_type, int a) {
+  if (node_type == 0) return (a >= 0 && a < PA_COUNT) ? 1 : -1;
+  if (node_type == 1) {
+    if (a < 0 || a >= VA_COUNT) return -1;
+    if (a == VA_PAST_STOP_LIST || a == VA_PAST_STOP_TICK_LIST) return K.past_n;
+    if (a == VA_FUTURE_STOP_LIST || a == VA_FUTURE_STOP_TICK_LIST) return K.future_n;
+    return 1;
+  }
+  if (node_type == 2) {
+    if (a == MA_FULL_ON_PORTS) return K.P * K.P;
+    if (a == MA_FULL_ON_VESSELS || a == MA_VESSEL_PLANS) return K.V * K.P;
+  }
+  return -1;
+}
+
+int mrx_cim_attr_slots(mrx_handle h, int node_type, int attr_id) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  return host_attr_slots(h->plan.kp, node_type, attr_id);
+}
+
+int mrx_cim_attr_id(int node_type, const char* name) {
+  static const char* P[] = {"capacity", "empty", "full", "on_shipper", "on_consignee", "shortage", "acc_shortage", "booking",
+                            "acc_booking", "fulfillment", "acc_fulfillment", "transfer_cost"};
+  static const char* V[] = {"capacity", "empty", "full", "remaining_space", "early_discharge", "is_parking", "loc_port_idx",
+                            "route_idx", "last_loc_idx", "next_loc_idx", "past_stop_list", "past_stop_tick_list",
+                            "future_stop_list", "future_stop_tick_list"};
+  static const char* M[] = {"full_on_ports", "full_on_vessels", "vessel_plans"};
+  const char** tab = node_type == 0 ? P : node_type == 1 ? V : node_type == 2 ? M : nullptr;
+  const int n = node_type == 0 ? PA_COUNT : node_type == 1 ? VA_COUNT : node_type == 2 ? MA_COUNT : 0;
+  if (!name) return -1;
+  for (int i = 0; i < n; i++) if (!strcmp(tab[i], name)) return i;
+  return -1;
+}
+
+int mrx_cim_query(mrx_handle h, int node_type, const int32_t* d_ticks, int nt, int ticks_per_env, const int32_t* d_nodes,
+                  int nn, const int32_t* attrs, int na, double* d_out, void* stream) {
+  if (!h || !d_ticks || !d_nodes || !attrs || !d_out) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
+  if (na > 16) return set_err(MRX_ERR_INVALID_ARG, "at most 16 attributes per query");
+  if (nt <= 0 || nn <= 0 || na <= 0) return set_err(MRX_ERR_INVALID_ARG, "nt, nn and na must be positive");
+  int rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  const CimParams& K = h->plan.kp;
+  int row_slots = 0;
+  for (int i = 0; i < na; i++) {
+    const int s = host_attr_slots(K, node_type, attrs[i]);
+    if (s < 0) return set_err(MRX_ERR_INVALID_ARG, "unknown attribute id for this node type");
+    row_slots += s;
+  }
+  const long long total = (long long)K.n_envs * nt * nn * row_slots;
+  if (total == 0) return MRX_OK;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  AttrList al;
+  al.n = na;
+  for (int i = 0; i < 16; i++) al.id[i] = i < na ? attrs[i] : 0;
+  hipLaunchKernelGGL(mrx_k_cim_query, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, K, node_type, d_ticks, nt,
+                     ticks_per_env, d_nodes, nn, al, row_slots, total, d_out);
+  HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,246 @@
+// cim_layout.h — host-side planning of the engine's HBM workspace and constant tables.
+// Plain C++ (no HIP): used by the C-ABI implementation (cim_engine.hip) and by the CPU
+// emulation harness in tests/emu/.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/maro_amd.h"
+#include "cim_params.h"
+
+struct CimHostPlan {
+  CimParams kp;                 // device pointers valid after cim_plan_bind()
+  mrx_cim_layout layout;
+  std::vector<uint8_t> const_blob;  // constant tables, uploaded at workspace + const_off
+  int64_t const_off = 0;
+  int64_t workspace_bytes = 0;
+  // byte offsets of per-env arrays inside the workspace
+  int64_t o_live, o_ring, o_ring_fi, o_priv, o_rec, o_status, o_tick, o_nstops, o_order_prop, o_mt, o_stops, o_seed, o_vperiod;
+  // relative offsets of const tables inside const_blob, in the order of CimParams' const pointers
+  std::vector<int64_t> const_rel;
+};
+
+namespace cim_layout_detail {
+inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+struct Arena {
+  int64_t top = 0;
+  int64_t take(int64_t bytes) { int64_t o = align_up(top, 256); top = o + bytes; return o; }
+};
+template <class T>
+inline int64_t blob_put(std::vector<uint8_t>& blob, const T* src, size_t n) {
+  size_t off = (blob.size() + 63) / 64 * 64;
+  blob.resize(off + sizeof(T) * (n ? n : 1), 0);
+  if (n) memcpy(blob.data() + off, src, sizeof(T) * n);
+  return (int64_t)off;
+}
+}  // namespace cim_layout_detail
+
+// Safe per-vessel bound on the number of unrolled stops (cim_data_generator.py:18-115): every
+// stop advances the clock by at least max(1,ceil(duration-noise)) + ceil(dist/(speed+noise)).
+inline int cim_stop_bound(const mrx_cim_topology* t, int v, int max_tick) {
+  int r = t->vessel_route[v];
+  int L = t->route_offset[r + 1] - t->route_offset[r];
+  double cyc = 0;
+  for (int i = 0; i < L; i++) {
+    double park = ceil(t->vessel_duration[v] - t->vessel_duration_noise[v]);
+    if (park < 1) park = 1;
+    double sp = t->vessel_speed[v] + t->vessel_speed_noise[v];
+    double sail = sp > 0 ? ceil(t->route_dist[t->route_offset[r] + i] / sp) : 1;
+    if (sail < 0) sail = 0;
+    cyc += park + sail;
+  }
+  if (cyc < 1) cyc = 1;
+  double cycles = ceil((double)(max_tick + 1) / cyc) + 1;
+  return (int)(cycles * L) + t->future_stop_number + 2;
+}
+
+inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostPlan* pl, std::string* err) {
+  using namespace cim_layout_detail;
+  auto fail = [&](const char* m) { if (err) *err = m; return (int)MRX_ERR_UNSUPPORTED; };
+  if (!t || !c) { if (err) *err = "null topology/config"; return MRX_ERR_INVALID_ARG; }
+  if (c->n_envs <= 0 || c->durations <= 0 || c->snapshot_resolution <= 0) { if (err) *err = "n_envs, durations and snapshot_resolution must be positive"; return MRX_ERR_INVALID_ARG; }
+  if (t->n_ports <= 0 || t->n_ports > 64) return fail("engine limit: 1..64 ports (one lane per port)");
+  if (t->n_vessels <= 0 || t->n_vessels > 64) return fail("engine limit: 1..64 vessels (one lane per vessel)");
+  if (t->container_volume <= 0) return fail("container_volume must be positive");
+  CimParams& k = pl->kp;
+  memset(&k, 0, sizeof(k));
+  const int P = t->n_ports, V = t->n_vessels, R = t->n_routes, NT = t->n_targets, NRP = t->n_route_points;
+  k.n_envs = c->n_envs; k.P = P; k.V = V; k.R = R; k.NT = NT; k.NRP = NRP;
+  k.past_n = t->past_stop_number; k.future_n = t->future_stop_number;
+  if (k.past_n < 0 || k.future_n < 0 || k.past_n > 16 || k.future_n > 16) return fail("stop_number out of range (0..16)");
+  k.vrows = 10 + 2 * k.past_n + 2 * k.future_n;
+  k.start_tick = c->start_tick; k.T = c->start_tick + c->durations; k.resolution = c->snapshot_resolution;
+  k.max_actions = c->max_actions > 0 ? c->max_actions : 1;
+  k.period = t->period; k.vol = t->container_volume; k.total_containers = t->total_containers; k.order_mode = t->order_mode;
+  k.sample_noise = t->sample_noise;
+  int total_frames = (int)ceil((double)c->durations / (double)c->snapshot_resolution);
+  k.S = c->max_snapshots > 0 ? c->max_snapshots : total_frames;
+  // frame layout
+  k.f_ports = 0; k.f_vessels = PA_COUNT * P; k.f_fop = k.f_vessels + k.vrows * V; k.f_fov = k.f_fop + P * P;
+  k.f_plans = k.f_fov + V * P; k.FW = k.f_plans + V * P;
+  k.FW = (k.FW + 3) / 4 * 4;  // 16-byte rows for vector copies
+  // RNG usage (draws with zero noise cannot influence any value)
+  bool on = false, bn = false;
+  for (int p = 0; p < P; p++) { on |= t->source_noise[p] != 0; bn |= t->empty_return_noise[p] != 0 || t->full_return_noise[p] != 0; }
+  for (int i = 0; i < NT; i++) on |= t->target_noise[i] != 0;
+  k.use_order_rng = on; k.use_buffer_rng = bn;
+  bool oi = false;
+  if (t->sample_noise != 0) for (int tk = 0; tk < k.T; tk++) oi |= t->order_dist[tk % t->period] != 0;
+  k.has_order_init = oi;
+  k.idx_order_init = oi ? 0 : -1; k.idx_route = oi ? 1 : 0; k.idx_order_num = k.idx_route + 1; k.idx_buffer = k.idx_route + 2;
+  // pending-return horizon
+  int H = 1;
+  for (int p = 0; p < P; p++) {
+    int a = (int)ceil(t->empty_return_base[p] + fabs(t->empty_return_noise[p])) + 1;
+    int b = (int)ceil(t->full_return_base[p] + fabs(t->full_return_noise[p])) + 1;
+    if (a > H) H = a;
+    if (b > H) H = b;
+  }
+  if (H > 64) return fail("engine limit: return buffer ticks must be < 64");
+  k.H = H;
+  // stop-table capacity
+  int smax = 0;
+  for (int v = 0; v < V; v++) {
+    int b = cim_stop_bound(t, v, k.T);
+    if (b > smax) smax = b;
+    if (ceil(t->vessel_duration[v] + fabs(t->vessel_duration_noise[v])) > 255) return fail("engine limit: parking duration must be <= 255 ticks");
+    if (t->vessel_speed[v] - fabs(t->vessel_speed_noise[v]) <= 0) return fail("sailing speed minus noise must stay positive");
+  }
+  if (c->max_stops > 0) smax = c->max_stops;
+  k.SMAX = (smax + 3) / 4 * 4;
+  if (k.T >= (1 << 23)) return fail("engine limit: max_tick < 2^23");
+  // private state
+  k.pv_evt = PH_COUNT; k.pv_arr = k.pv_evt + V; k.pv_rfull = k.pv_arr + V; k.pv_rempty = k.pv_rfull + H * NT;
+  k.PW = (k.pv_rempty + H * P + 3) / 4 * 4;
+  // derived integer tables
+  std::vector<int32_t> pair_src(NT ? NT : 1), v_route_base(V), v_route_len(V), v_total_space(V), leg_off(V + 1), leg_time,
+      v_period(V), er_delay(P), fr_delay(P), rec_off(V + 1);
+  for (int p = 0; p < P; p++) {
+    for (int j = t->target_offset[p]; j < t->target_offset[p + 1]; j++) pair_src[j] = p;
+    er_delay[p] = (int)ceil(t->empty_return_base[p]);  // apply_noise(base, 0) == base
+    fr_delay[p] = (int)ceil(t->full_return_base[p]);
+  }
+  int rec_w = 0;
+  for (int v = 0; v < V; v++) {
+    int r = t->vessel_route[v];
+    int L = t->route_offset[r + 1] - t->route_offset[r];
+    if (L <= 0 || L > 62) return fail("engine limit: route length 1..62");
+    v_route_base[v] = t->route_offset[r]; v_route_len[v] = L;
+    v_total_space[v] = (int)floor((double)t->vessel_capacity[v] / (double)t->container_volume);  // vessel.py:69
+    leg_off[v] = (int)leg_time.size();
+    int per = 0;
+    for (int i = 0; i < L; i++) {
+      // vessel_future_stops_prediction.py:72 / cim_data_generator.py:92: duration + ceil(dist / speed)
+      int leg = (int)(t->vessel_duration[v] + ceil(t->route_dist[t->route_offset[r] + i] / t->vessel_speed[v]));
+      leg_time.push_back(leg);
+      per += leg;
+    }
+    v_period[v] = per;  // cim_data_generator.py:93-101: sum over the first route_length stops = one full cycle
+    rec_off[v] = rec_w;
+    rec_w += (L + 1) * (L + 1);
+  }
+  leg_off[V] = (int)leg_time.size(); rec_off[V] = rec_w;
+  k.REC_W = (rec_w + 3) / 4 * 4;
+  // LDS plan (word offsets; doubles 8-byte aligned)
+  int w = 0;
+  k.l_frame = w; w += k.FW;
+  k.l_priv = w; w += k.PW;
+  k.l_mt0 = w; w += MT_WORDS;
+  k.l_mt1 = w; w += MT_WORDS;
+  w = (w + 1) / 2 * 2;
+  k.l_dsrc = w; w += 2 * ((P + 1) / 2 * 2);
+  k.l_dtgt = w; w += 2 * (NT + 1);
+  k.l_oq = w; w += NT + 1;
+  k.l_odelay = w; w += NT + 1;
+  k.l_srcn = w; w += P;
+  w = (w + 1) / 2 * 2;
+  k.l_misc = w; w += 3 * 64 * 2;  // discharge-record merge list: (key, v, q) x up to 128
+  k.lds_words = (w + 3) / 4 * 4;
+  w = k.lds_words;
+  k.l_mt2 = w; w += MT_WORDS;
+  k.l_mt3 = w; w += MT_WORDS;
+  k.lds_words_reset = (w + 3) / 4 * 4;
+  if ((int64_t)k.lds_words_reset * 4 > 160 * 1024) return fail("engine limit: per-env state exceeds 160 KiB of LDS");
+
+  // ---- constant blob
+  std::vector<uint8_t>& B = pl->const_blob;
+  B.clear();
+  std::vector<int64_t>& rel = pl->const_rel;
+  rel.clear();
+  rel.push_back(blob_put(B, t->source_base, P)); rel.push_back(blob_put(B, t->source_noise, P));
+  rel.push_back(blob_put(B, t->target_base, NT)); rel.push_back(blob_put(B, t->target_noise, NT));
+  rel.push_back(blob_put(B, t->empty_return_base, P)); rel.push_back(blob_put(B, t->empty_return_noise, P));
+  rel.push_back(blob_put(B, t->full_return_base, P)); rel.push_back(blob_put(B, t->full_return_noise, P));
+  rel.push_back(blob_put(B, t->vessel_speed, V)); rel.push_back(blob_put(B, t->vessel_speed_noise, V));
+  rel.push_back(blob_put(B, t->vessel_duration, V)); rel.push_back(blob_put(B, t->vessel_duration_noise, V));
+  rel.push_back(blob_put(B, t->route_dist, NRP)); rel.push_back(blob_put(B, t->order_dist, t->period));
+  // int tables, in the order of CimParams: tgt_off, tgt_port, pair_src, route_port, v_route_base, v_route_len, v_start,
+  // v_cap, v_init_empty, v_total_space, p_cap, p_init_empty, leg_off, leg_time, v_period, er_delay, fr_delay, rec_off, v_route
+  rel.push_back(blob_put(B, t->target_offset, P + 1)); rel.push_back(blob_put(B, t->target_port, NT));
+  rel.push_back(blob_put(B, pair_src.data(), NT)); rel.push_back(blob_put(B, t->route_port, NRP));
+  rel.push_back(blob_put(B, v_route_base.data(), V)); rel.push_back(blob_put(B, v_route_len.data(), V));
+  rel.push_back(blob_put(B, t->vessel_start_offset, V)); rel.push_back(blob_put(B, t->vessel_capacity, V));
+  rel.push_back(blob_put(B, t->vessel_init_empty, V)); rel.push_back(blob_put(B, v_total_space.data(), V));
+  rel.push_back(blob_put(B, t->port_capacity, P)); rel.push_back(blob_put(B, t->port_init_empty, P));
+  rel.push_back(blob_put(B, leg_off.data(), V + 1)); rel.push_back(blob_put(B, leg_time.data(), leg_time.size()));
+  rel.push_back(blob_put(B, v_period.data(), V)); rel.push_back(blob_put(B, er_delay.data(), P));
+  rel.push_back(blob_put(B, fr_delay.data(), P)); rel.push_back(blob_put(B, rec_off.data(), V + 1));
+  rel.push_back(blob_put(B, t->vessel_route, V));
+
+  // ---- workspace carve-up
+  Arena A;
+  const int64_t N = c->n_envs;
+  pl->const_off = A.take((int64_t)B.size());
+  pl->o_live = A.take(N * k.FW * 4);
+  pl->o_ring = A.take(N * (int64_t)k.S * k.FW * 4);
+  pl->o_ring_fi = A.take(N * k.S * 4);
+  pl->o_priv = A.take(N * k.PW * 4);
+  pl->o_rec = A.take(N * (int64_t)k.REC_W * 4);
+  pl->o_status = A.take(N * 4);
+  pl->o_tick = A.take(N * 4);
+  pl->o_nstops = A.take(N * V * 4);
+  pl->o_order_prop = A.take(N * (int64_t)k.T * 4);
+  pl->o_mt = A.take(N * MTS_COUNT * MT_WORDS * 4);
+  pl->o_stops = A.take(N * (int64_t)V * k.SMAX * 4);
+  pl->o_seed = A.take(N * 8);
+  pl->o_vperiod = A.take(N * V * 4);
+  pl->workspace_bytes = align_up(A.top, 256);
+
+  mrx_cim_layout& Lo = pl->layout;
+  memset(&Lo, 0, sizeof(Lo));
+  Lo.n_envs = c->n_envs; Lo.n_ports = P; Lo.n_vessels = V; Lo.frame_words = k.FW; Lo.ring_slots = k.S;
+  Lo.max_stops = k.SMAX; Lo.horizon = k.H;
+  Lo.frame_off_ports = k.f_ports; Lo.frame_off_vessels = k.f_vessels; Lo.frame_off_full_on_ports = k.f_fop;
+  Lo.frame_off_full_on_vessels = k.f_fov; Lo.frame_off_vessel_plans = k.f_plans;
+  Lo.off_live = pl->o_live; Lo.off_ring = pl->o_ring; Lo.off_ring_fi = pl->o_ring_fi; Lo.off_status = pl->o_status;
+  Lo.off_tick = pl->o_tick; Lo.off_seed = pl->o_seed; Lo.off_stops = pl->o_stops; Lo.off_nstops = pl->o_nstops;
+  Lo.off_order_prop = pl->o_order_prop; Lo.off_vessel_period = pl->o_vperiod;  // per env: depends on how many stops were unrolled
+  Lo.workspace_bytes = pl->workspace_bytes;
+  return MRX_OK;
+}
+
+// Resolve device pointers once the workspace base address is known.
+inline void cim_plan_bind(CimHostPlan* pl, void* base_) {
+  uint8_t* base = (uint8_t*)base_;
+  CimParams& k = pl->kp;
+  uint8_t* cb = base + pl->const_off;
+  const std::vector<int64_t>& r = pl->const_rel;
+  int i = 0;
+  const double** dptr[] = {&k.src_base, &k.src_noise, &k.tgt_base, &k.tgt_noise, &k.er_base, &k.er_noise, &k.fr_base,
+                           &k.fr_noise, &k.v_speed, &k.v_speed_noise, &k.v_dur, &k.v_dur_noise, &k.route_dist, &k.order_dist};
+  for (auto p : dptr) *p = (const double*)(cb + r[i++]);
+  const int32_t** iptr[] = {&k.tgt_off, &k.tgt_port, &k.pair_src, &k.route_port, &k.v_route_base, &k.v_route_len, &k.v_start,
+                            &k.v_cap, &k.v_init_empty, &k.v_total_space, &k.p_cap, &k.p_init_empty, &k.leg_off, &k.leg_time,
+                            &k.v_period, &k.er_delay, &k.fr_delay, &k.rec_off, &k.v_route};
+  for (auto p : iptr) *p = (const int32_t*)(cb + r[i++]);
+  k.live = (int32_t*)(base + pl->o_live); k.ring = (int32_t*)(base + pl->o_ring); k.ring_fi = (int32_t*)(base + pl->o_ring_fi);
+  k.priv = (int32_t*)(base + pl->o_priv); k.rec = (int32_t*)(base + pl->o_rec); k.status = (int32_t*)(base + pl->o_status);
+  k.tick = (int32_t*)(base + pl->o_tick); k.nstops = (int32_t*)(base + pl->o_nstops);
+  k.order_prop = (int32_t*)(base + pl->o_order_prop); k.mt = (uint32_t*)(base + pl->o_mt);
+  k.stops = (uint32_t*)(base + pl->o_stops); k.seed = (int64_t*)(base + pl->o_seed);
+  k.vperiod = (int32_t*)(base + pl->o_vperiod);
+}

@@ -1,0 +1,48 @@
+// cim_params.h — POD kernel-argument block shared by host (layout/C-ABI) and device code.
+#pragma once
+#include <stdint.h>
+
+// Frame attribute ids (also the ids of mrx_cim_attr_id); names follow the reference schema
+// (cim/port.py:9-46, cim/vessel.py:14-45, cim/matrix.py:24-28).
+enum { PA_CAPACITY, PA_EMPTY, PA_FULL, PA_ON_SHIPPER, PA_ON_CONSIGNEE, PA_SHORTAGE, PA_ACC_SHORTAGE,
+       PA_BOOKING, PA_ACC_BOOKING, PA_FULFILLMENT, PA_ACC_FULFILLMENT, PA_TRANSFER_COST, PA_COUNT };
+enum { VA_CAPACITY, VA_EMPTY, VA_FULL, VA_REMAINING_SPACE, VA_EARLY_DISCHARGE, VA_IS_PARKING, VA_LOC_PORT_IDX,
+       VA_ROUTE_IDX, VA_LAST_LOC_IDX, VA_NEXT_LOC_IDX, VA_PAST_STOP_LIST, VA_PAST_STOP_TICK_LIST,
+       VA_FUTURE_STOP_LIST, VA_FUTURE_STOP_TICK_LIST, VA_COUNT };
+enum { MA_FULL_ON_PORTS, MA_FULL_ON_VESSELS, MA_VESSEL_PLANS, MA_COUNT };
+
+// private per-env header words (priv[0..PH))
+enum { PH_TICK, PH_FLAGS, PH_PEND_LO, PH_PEND_HI, PH_CUR_VESSEL, PH_OPNUM_LO, PH_OPNUM_HI, PH_IDX_ORDER,
+       PH_IDX_BUFFER, PH_IDX_ROUTE, PH_RESERVED0, PH_RESERVED1, PH_COUNT = 16 };
+enum { FL_FRESH = 1, FL_FINISHED = 2 };
+
+#define MT_WORDS 624
+enum { MTS_ORDER = 0, MTS_BUFFER = 1, MTS_ROUTE = 2, MTS_COUNT = 3 };
+
+struct CimParams {
+  // ---- dimensions
+  int n_envs, P, V, R, NT, NRP, past_n, future_n, vrows, FW, S, H, SMAX, T, start_tick, resolution,
+      max_actions, period;
+  int vol, total_containers, order_mode;
+  int use_order_rng, use_buffer_rng, has_order_init;
+  int idx_order_init, idx_route, idx_order_num, idx_buffer;  // SimRandom creation indices
+  double sample_noise;
+  // ---- frame offsets (words inside one frame)
+  int f_ports, f_vessels, f_fop, f_fov, f_plans;
+  // ---- private-state layout (words)
+  int PW, pv_evt, pv_arr, pv_rfull, pv_rempty;
+  int REC_W;
+  // ---- LDS layout (word offsets)
+  int l_frame, l_priv, l_mt0, l_mt1, l_dsrc, l_dtgt, l_oq, l_odelay, l_srcn, l_misc, lds_words;
+  int l_mt2, l_mt3, lds_words_reset;  // reset kernel only (placed after the step kernel's LDS)
+  // ---- constant tables (device)
+  const double *src_base, *src_noise, *tgt_base, *tgt_noise, *er_base, *er_noise, *fr_base, *fr_noise,
+      *v_speed, *v_speed_noise, *v_dur, *v_dur_noise, *route_dist, *order_dist;
+  const int32_t *tgt_off, *tgt_port, *pair_src, *route_port, *v_route_base, *v_route_len, *v_start, *v_cap,
+      *v_init_empty, *v_total_space, *p_cap, *p_init_empty, *leg_off, *leg_time, *v_period, *er_delay,
+      *fr_delay, *rec_off, *v_route;
+  // ---- per-env state (device)
+  int32_t *live, *ring, *ring_fi, *priv, *rec, *status, *tick, *nstops, *order_prop, *vperiod;
+  uint32_t *mt, *stops;
+  int64_t* seed;
+};

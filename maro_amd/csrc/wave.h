@@ -1,0 +1,47 @@
+// wave.h — wavefront-level collectives for gfx950 (CDNA4, wave64).
+//
+// The engine runs ONE environment per 64-lane wavefront (one wave per workgroup), so every
+// cross-lane exchange is a wave collective: no s_barrier, no inter-workgroup traffic.
+// All functions must be called from wave-uniform control flow.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MRX_DEV __device__ __forceinline__
+#define MRX_WAVE 64
+
+namespace wave {
+
+MRX_DEV int lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// LDS visibility point inside one wave: orders this lane's LDS writes before other lanes'
+// subsequent reads (s_waitcnt lgkmcnt(0)) and stops the compiler from moving LDS accesses
+// across it.  A one-wave workgroup needs no s_barrier.
+MRX_DEV void sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+MRX_DEV uint64_t ballot(bool pred) { return __ballot(pred); }
+
+MRX_DEV int shfl(int v, int src) { return __shfl(v, src, 64); }
+MRX_DEV long long shfl(long long v, int src) {
+  int lo = __shfl((int)(v & 0xffffffffll), src, 64), hi = __shfl((int)(v >> 32), src, 64);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// butterfly all-reduce (sum) over the 64 lanes; every lane gets the total
+MRX_DEV long long reduce_add(long long v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    int lo = __shfl_xor((int)(v & 0xffffffffll), m, 64), hi = __shfl_xor((int)(v >> 32), m, 64);
+    v += ((long long)hi << 32) | (unsigned int)lo;
+  }
+  return v;
+}
+
+// make a wave-uniform value provably uniform (scalar register)
+MRX_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+}  // namespace wave

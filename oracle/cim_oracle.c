@@ -780,6 +780,32 @@ void cim_oracle_get_order_proportion(const cim_oracle* o, int32_t* out) { memcpy
 void cim_oracle_get_vessel_period(const cim_oracle* o, int32_t* out) { for (int v = 0; v < o->V; v++) out[v] = o->vessel_period[v]; }
 void cim_oracle_stream_seeds(const cim_oracle* o, int64_t out[4]) { for (int k = 0; k < K_COUNT; k++) out[k] = o->rnd.created[k] >= 0 ? o->rnd.seed_of[k] : -1; }
 
+/* Whole-rollout driver used by bench.py's cpu_baseline leg (keeps the timed loop in C): steps the env
+ * with the counter-based random agent of oracle/cim_oracle.py::hash_policy_action until done or
+ * max_steps decisions; returns the number of decisions answered, *ticks_out = ticks advanced. */
+static uint64_t mix64(uint64_t seed, uint64_t step) {
+  uint64_t x = seed * 0x9E3779B97F4A7C15ull + step * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+int64_t cim_oracle_rollout(cim_oracle* o, int64_t env_seed, int64_t max_steps, int64_t* ticks_out, int64_t metrics[3]) {
+  int32_t dec[8], act[4]; int64_t n = 0;
+  int t0 = o->tick;
+  int done = cim_oracle_step(o, NULL, 0, dec, metrics);
+  while (!done && (max_steps < 0 || n < max_steps)) {
+    uint64_t x = mix64((uint64_t)env_seed, (uint64_t)n), r = x >> 1;
+    act[0] = dec[2]; act[1] = dec[1];
+    if ((x & 1ull) == 0 && dec[3] > 0) { act[2] = (int32_t)(r % (uint64_t)(dec[3] + 1)); act[3] = MRX_ACTION_LOAD; }
+    else { act[2] = (int32_t)(r % (uint64_t)(dec[4] + 1)); act[3] = MRX_ACTION_DISCHARGE; }
+    done = cim_oracle_step(o, act, 1, dec, metrics);
+    n++;
+  }
+  if (ticks_out) *ticks_out = o->tick - t0 + (done ? 1 : 0);
+  return n;
+}
+
 /* CPython random pinning hooks (tests/test_oracle_mt.py) */
 void cim_oracle_mt_selftest(int64_t seed, int n, double* out_random, uint32_t* out_randbelow4096) {
   mt_state s; mt_seed_int(&s, seed);

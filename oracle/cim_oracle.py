@@ -68,6 +68,8 @@ def lib():
         L.cim_oracle_get_order_proportion.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.cim_oracle_get_vessel_period.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.cim_oracle_stream_seeds.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.cim_oracle_rollout.restype = ctypes.c_int64
+        L.cim_oracle_rollout.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
         L.cim_oracle_mt_selftest.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
@@ -158,6 +160,14 @@ class CimOracle:
         out = np.zeros(self.topo.n_vessels, np.int32)
         lib().cim_oracle_get_vessel_period(self._h, out.ctypes.data)
         return out
+
+    def rollout(self, env_seed: int, max_steps: int = -1):
+        """Run (the rest of) an episode in C with the counter-based random agent; returns
+        (decisions answered, ticks advanced, final metrics)."""
+        ticks = ctypes.c_int64(0)
+        met = np.zeros(3, np.int64)
+        n = lib().cim_oracle_rollout(self._h, int(env_seed), int(max_steps), ctypes.byref(ticks), met.ctypes.data)
+        return int(n), int(ticks.value), met
 
     def stream_seeds(self) -> np.ndarray:
         out = np.zeros(4, np.int64)

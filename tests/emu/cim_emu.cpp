@@ -1,0 +1,90 @@
+// cim_emu.cpp — TEST INFRASTRUCTURE ONLY.  Compiles the engine's device source
+// (maro_amd/csrc/cim_device.h) for the host on top of the fiber wave emulator, so the
+// `-m "not gpu"` suite can compare the real kernel logic with the CPU oracle.  The product
+// (maro_amd/, libmaro_amd.so) never loads this library.
+#include "wave_emu.h"
+
+struct int4 { int x, y, z, w; };
+
+#include "../../maro_amd/csrc/cim_device.h"
+#include "../../maro_amd/csrc/cim_layout.h"
+
+struct Emu {
+  CimHostPlan plan;
+  uint8_t* ws = nullptr;
+  int32_t* lds = nullptr;
+  wave::EmuWave wave;
+};
+
+extern "C" {
+
+void* emu_create(const mrx_cim_topology* t, const mrx_cim_config* c, char* errbuf, int errlen) {
+  Emu* e = new Emu();
+  std::string err;
+  if (cim_plan(t, c, &e->plan, &err) != MRX_OK) {
+    snprintf(errbuf, errlen, "%s", err.c_str());
+    delete e;
+    return nullptr;
+  }
+  e->ws = (uint8_t*)aligned_alloc(256, (size_t)e->plan.workspace_bytes);
+  memset(e->ws, 0xCD, (size_t)e->plan.workspace_bytes);  // poison: nothing may rely on zeroed HBM
+  memcpy(e->ws + e->plan.const_off, e->plan.const_blob.data(), e->plan.const_blob.size());
+  cim_plan_bind(&e->plan, e->ws);
+  e->lds = (int32_t*)aligned_alloc(256, (size_t)e->plan.kp.lds_words_reset * 4 + 256);
+  return e;
+}
+
+void emu_destroy(void* h) {
+  Emu* e = (Emu*)h;
+  wave::free_wave(e->wave);
+  free(e->ws);
+  free(e->lds);
+  delete e;
+}
+
+void emu_get_layout(void* h, mrx_cim_layout* out) { *out = ((Emu*)h)->plan.layout; }
+void* emu_workspace(void* h) { return ((Emu*)h)->ws; }
+int emu_lds_words(void* h) { return ((Emu*)h)->plan.kp.lds_words; }
+
+void emu_reset(void* h, const int64_t* seed_cmd, const uint8_t* mask, int reverse) {
+  Emu* e = (Emu*)h;
+  const CimParams& K = e->plan.kp;
+  e->wave.reverse = reverse != 0;
+  for (int env = 0; env < K.n_envs; env++) {
+    if (mask && !mask[env]) continue;
+    memset(e->lds, 0xAB, (size_t)K.lds_words_reset * 4);
+    long long cmd = seed_cmd ? (long long)seed_cmd[env] : -1;
+    wave::run_wave(e->wave, [&]() { cim::reset_env(K, env, e->lds, cmd); });
+  }
+}
+
+void emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const uint8_t* mask, int32_t* dec,
+              int64_t* met, uint8_t* done, int reverse) {
+  Emu* e = (Emu*)h;
+  const CimParams& K = e->plan.kp;
+  e->wave.reverse = reverse != 0;
+  for (int env = 0; env < K.n_envs; env++) {
+    if (mask && !mask[env]) continue;
+    memset(e->lds, 0xAB, (size_t)K.lds_words * 4);
+    const int32_t* a = actions ? actions + (size_t)env * K.max_actions * 4 : nullptr;
+    int na = (actions && n_actions) ? n_actions[env] : 0;
+    wave::run_wave(e->wave, [&]() {
+      cim::step_env(K, env, e->lds, a, na, dec + (size_t)env * 8, (long long*)(met + (size_t)env * 3), done + env);
+    });
+  }
+}
+
+void emu_query(void* h, int node_type, const int32_t* ticks, int nt, int per_env, const int32_t* nodes, int nn,
+               const int32_t* attrs, int na, double* out) {
+  Emu* e = (Emu*)h;
+  const CimParams& K = e->plan.kp;
+  int row_slots = 0;
+  for (int i = 0; i < na; i++) row_slots += cim::attr_slots(K, node_type, attrs[i]);
+  long long rows = (long long)K.n_envs * nt * nn;
+  for (long long r = 0; r < rows; r++)
+    for (int c = 0; c < row_slots; c++)
+      out[r * row_slots + c] = cim::query_elem(K, node_type, ticks, nt, per_env, nodes, nn, attrs, na, r, c);
+}
+
+long emu_rounds(void* h) { return ((Emu*)h)->wave.rounds; }
+}

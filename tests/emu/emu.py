@@ -1,0 +1,118 @@
+"""Python binding of tests/emu/libcim_emu.so — TEST INFRASTRUCTURE ONLY (CPU emulation of the
+device code; the product never loads it)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, "libcim_emu.so")
+
+
+class MrxCimConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("n_envs", "device", "start_tick", "durations", "snapshot_resolution",
+                                              "max_snapshots", "max_actions", "max_stops")]
+
+
+class MrxCimLayout(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_int32) for n in ("n_envs", "n_ports", "n_vessels", "frame_words", "ring_slots",
+                                               "max_stops", "horizon", "frame_off_ports", "frame_off_vessels",
+                                               "frame_off_full_on_ports", "frame_off_full_on_vessels",
+                                               "frame_off_vessel_plans")]
+                + [(n, ctypes.c_int64) for n in ("off_live", "off_ring", "off_ring_fi", "off_status", "off_tick",
+                                                 "off_seed", "off_stops", "off_nstops", "off_order_prop",
+                                                 "off_vessel_period", "workspace_bytes")])
+
+
+def build():
+    srcs = [os.path.join(HERE, "cim_emu.cpp"), os.path.join(HERE, "wave_emu.h")] + [
+        os.path.join(REPO, "maro_amd", "csrc", f) for f in ("cim_device.h", "cim_layout.h", "cim_params.h")]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-g", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
+                               "-Wno-unused-function", "-shared", "-o", LIB, srcs[0]])
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        L.emu_create.restype = ctypes.c_void_p
+        L.emu_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+        L.emu_destroy.argtypes = [ctypes.c_void_p]
+        L.emu_get_layout.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.emu_workspace.restype = ctypes.c_void_p
+        L.emu_workspace.argtypes = [ctypes.c_void_p]
+        L.emu_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.emu_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
+        L.emu_query.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class EmuBackend:
+    """Batch backend with the same numpy-facing surface as the tests' GPU backend wrapper."""
+
+    def __init__(self, topo, n_envs=1, start_tick=0, durations=100, snapshot_resolution=1, max_snapshots=None,
+                 max_actions=2, reverse=False):
+        self.topo = topo
+        self._cs = topo.c_struct()
+        self.cfg = MrxCimConfig(n_envs, 0, start_tick, durations, snapshot_resolution, max_snapshots or 0,
+                                max_actions, 0)
+        err = ctypes.create_string_buffer(256)
+        self._h = lib().emu_create(ctypes.byref(self._cs), ctypes.byref(self.cfg), err, 256)
+        if not self._h:
+            raise RuntimeError(err.value.decode())
+        self.layout = MrxCimLayout()
+        lib().emu_get_layout(self._h, ctypes.byref(self.layout))
+        self.n_envs, self.max_actions, self.reverse = n_envs, max_actions, reverse
+        self.max_tick = start_tick + durations
+        base = lib().emu_workspace(self._h)
+        self._ws = (ctypes.c_uint8 * self.layout.workspace_bytes).from_address(base)
+        self.ws = np.frombuffer(self._ws, dtype=np.uint8)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().emu_destroy(self._h)
+            self._h = None
+
+    def view(self, off, dtype, shape):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return self.ws[off:off + n].view(dtype).reshape(shape)
+
+    def reset(self, seed_cmd=None, mask=None):
+        sc = None if seed_cmd is None else np.ascontiguousarray(seed_cmd, np.int64)
+        mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().emu_reset(self._h, _ptr(sc), _ptr(mk), int(self.reverse))
+
+    def step(self, actions=None, n_actions=None, mask=None):
+        a = None if actions is None else np.ascontiguousarray(actions, np.int32).reshape(self.n_envs, self.max_actions, 4)
+        na = None if n_actions is None else np.ascontiguousarray(n_actions, np.int32)
+        mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        if not hasattr(self, "_dec"):
+            self._dec = np.zeros((self.n_envs, 8), np.int32)
+            self._met = np.zeros((self.n_envs, 3), np.int64)
+            self._done = np.zeros(self.n_envs, np.uint8)
+        lib().emu_step(self._h, _ptr(a), _ptr(na), _ptr(mk), _ptr(self._dec), _ptr(self._met), _ptr(self._done),
+                       int(self.reverse))
+        return self._dec.copy(), self._met.copy(), self._done.copy()
+
+    def query(self, node_type, ticks, nodes, attrs, row_slots):
+        t = np.ascontiguousarray(ticks, np.int32)
+        per_env = 1 if t.ndim == 2 else 0
+        nt = t.shape[-1]
+        n = np.ascontiguousarray(nodes, np.int32)
+        a = np.ascontiguousarray(attrs, np.int32)
+        out = np.zeros((self.n_envs, nt, len(n), row_slots), np.float64)
+        lib().emu_query(self._h, node_type, _ptr(t), nt, per_env, _ptr(n), len(n), _ptr(a), len(a), _ptr(out))
+        return out

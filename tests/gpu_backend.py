@@ -1,0 +1,38 @@
+"""numpy-facing wrapper over maro_amd.cim.engine.CimBatchEngine with the same surface as
+tests/emu/emu.py::EmuBackend, so the golden replay drives the real HIP kernels through the C ABI."""
+import numpy as np
+import torch
+
+from maro_amd.cim.engine import CimBatchEngine
+
+
+class GpuBackend:
+    def __init__(self, topo, n_envs=1, start_tick=0, durations=100, snapshot_resolution=1, max_snapshots=None,
+                 max_actions=2):
+        self.eng = CimBatchEngine(topo, n_envs, start_tick=start_tick, durations=durations,
+                                  snapshot_resolution=snapshot_resolution, max_snapshots=max_snapshots,
+                                  max_actions=max_actions)
+        self.topo = self.eng.topo
+        self.layout = self.eng.layout
+        self.n_envs, self.max_actions, self.max_tick = n_envs, max_actions, start_tick + durations
+
+    def view(self, off, dtype, shape):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        torch.cuda.synchronize()
+        return self.eng.workspace[off:off + n].cpu().numpy().view(dtype).reshape(shape)
+
+    def reset(self, seed_cmd=None, mask=None):
+        self.eng.reset(seed_cmd, mask)
+
+    def step(self, actions=None, n_actions=None, mask=None):
+        d, m, dn = self.eng.step(actions, n_actions, mask)
+        torch.cuda.synchronize()
+        return d.cpu().numpy(), m.cpu().numpy(), dn.cpu().numpy()
+
+    def query(self, node_type, ticks, nodes, attrs, row_slots):
+        node = ["ports", "vessels", "matrices"][node_type]
+        from maro_amd.cim.engine import NODE_ATTRS
+        out = self.eng.query(node, np.asarray(ticks, np.int32), np.asarray(nodes, np.int32),
+                             [NODE_ATTRS[node][a] for a in attrs])
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
