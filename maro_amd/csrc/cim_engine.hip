@@ -13,6 +13,20 @@
 #include <string>
 
 #include "wave.h"
+#ifdef MRX_PROFILE_PHASES
+// tools-only build (libmaro_amd_prof.so): wave cycles (s_memtime) attributed to the phases of mrx_k_cim_step
+__device__ unsigned long long g_mrx_prof[16];
+namespace cim {
+struct Prof {
+  long long last, acc[12];
+  __device__ __forceinline__ Prof() { for (int i = 0; i < 12; i++) acc[i] = 0; last = clock64(); }
+  __device__ __forceinline__ void mark(int i) { long long c = clock64(); acc[i] += c - last; last = c; }
+  __device__ __forceinline__ void flush() {
+    if (wave::lane() == 0) for (int i = 0; i < 12; i++) if (acc[i]) atomicAdd(&g_mrx_prof[i], (unsigned long long)acc[i]);
+  }
+};
+}  // namespace cim
+#endif
 #include "cim_device.h"
 #include "cim_layout.h"
 
@@ -110,6 +124,14 @@ static int use_device(int device) {
 }
 
 extern "C" {
+
+#ifdef MRX_PROFILE_PHASES
+int mrx_prof_read(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mrx_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mrx_prof), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 const char* mrx_last_error(void) { return g_err.c_str(); }
 const char* mrx_version(void) { return "maro_amd 0.1 (gfx950)"; }

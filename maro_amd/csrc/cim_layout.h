@@ -80,7 +80,8 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   int total_frames = (int)ceil((double)c->durations / (double)c->snapshot_resolution);
   k.S = c->max_snapshots > 0 ? c->max_snapshots : total_frames;
   // frame layout
-  k.f_ports = 0; k.f_vessels = PA_COUNT * P; k.f_fop = k.f_vessels + k.vrows * V; k.f_fov = k.f_fop + P * P;
+  k.f_ports = 0; k.f_vessels = PA_COUNT * P; k.f_fop = k.f_vessels + k.vrows * V; k.f_fov = (k.f_fop + P * P + 3) / 4 * 4;
+  k.HW = k.f_fov;
   k.f_plans = k.f_fov + V * P; k.FW = k.f_plans + V * P;
   k.FW = (k.FW + 3) / 4 * 4;  // 16-byte rows for vector copies
   // RNG usage (draws with zero noise cannot influence any value)
@@ -114,7 +115,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   k.SMAX = (smax + 3) / 4 * 4;
   if (k.T >= (1 << 23)) return fail("engine limit: max_tick < 2^23");
   // private state
-  k.pv_evt = PH_COUNT; k.pv_arr = k.pv_evt + V; k.pv_rfull = k.pv_arr + V; k.pv_rempty = k.pv_rfull + H * NT;
+  k.pv_evt = PH_COUNT; k.pv_arr = k.pv_evt + V; k.pv_next = k.pv_arr + V; k.pv_pos = k.pv_next + V; k.pv_krl = k.pv_pos + V; k.pv_rfull = k.pv_krl + V; k.pv_rempty = k.pv_rfull + H * NT;
   k.PW = (k.pv_rempty + H * P + 3) / 4 * 4;
   // derived integer tables
   std::vector<int32_t> pair_src(NT ? NT : 1), v_route_base(V), v_route_len(V), v_total_space(V), leg_off(V + 1), leg_time,
@@ -147,18 +148,18 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   k.REC_W = (rec_w + 3) / 4 * 4;
   // LDS plan (word offsets; doubles 8-byte aligned)
   int w = 0;
-  k.l_frame = w; w += k.FW;
+  k.l_frame = w; w += k.HW;
   k.l_priv = w; w += k.PW;
   k.l_mt0 = w; w += MT_WORDS;
   k.l_mt1 = w; w += MT_WORDS;
   w = (w + 1) / 2 * 2;
   k.l_dsrc = w; w += 2 * ((P + 1) / 2 * 2);
-  k.l_dtgt = w; w += 2 * (NT + 1);
+  k.l_dtgt = w; w += (2 * (NT + 1) > 3 * 128 ? 2 * (NT + 1) : 3 * 128);  // also the discharge-record merge list (l_misc)
   k.l_oq = w; w += NT + 1;
   k.l_odelay = w; w += NT + 1;
   k.l_srcn = w; w += P;
   w = (w + 1) / 2 * 2;
-  k.l_misc = w; w += 3 * 64 * 2;  // discharge-record merge list: (key, v, q) x up to 128
+  k.l_misc = k.l_dtgt;  // (key, v, q) x up to 128, live only in phase B2 when dtgt is dead
   k.lds_words = (w + 3) / 4 * 4;
   w = k.lds_words;
   k.l_mt2 = w; w += MT_WORDS;
@@ -178,18 +179,28 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   rel.push_back(blob_put(B, t->vessel_speed, V)); rel.push_back(blob_put(B, t->vessel_speed_noise, V));
   rel.push_back(blob_put(B, t->vessel_duration, V)); rel.push_back(blob_put(B, t->vessel_duration_noise, V));
   rel.push_back(blob_put(B, t->route_dist, NRP)); rel.push_back(blob_put(B, t->order_dist, t->period));
-  // int tables, in the order of CimParams: tgt_off, tgt_port, pair_src, route_port, v_route_base, v_route_len, v_start,
-  // v_cap, v_init_empty, v_total_space, p_cap, p_init_empty, leg_off, leg_time, v_period, er_delay, fr_delay, rec_off, v_route
+  // int tables.  The first 13 (tgt_off .. rec_off) are read inside serial per-vessel / per-target loops, so the
+  // step kernel stages them in LDS as one contiguous block ("ctab"); blob_put pads each table to 64 B.
+  const int64_t ctab_begin = (int64_t)((B.size() + 63) / 64 * 64);
   rel.push_back(blob_put(B, t->target_offset, P + 1)); rel.push_back(blob_put(B, t->target_port, NT));
-  rel.push_back(blob_put(B, pair_src.data(), NT)); rel.push_back(blob_put(B, t->route_port, NRP));
+  rel.push_back(blob_put(B, t->route_port, NRP));
   rel.push_back(blob_put(B, v_route_base.data(), V)); rel.push_back(blob_put(B, v_route_len.data(), V));
-  rel.push_back(blob_put(B, t->vessel_start_offset, V)); rel.push_back(blob_put(B, t->vessel_capacity, V));
-  rel.push_back(blob_put(B, t->vessel_init_empty, V)); rel.push_back(blob_put(B, v_total_space.data(), V));
-  rel.push_back(blob_put(B, t->port_capacity, P)); rel.push_back(blob_put(B, t->port_init_empty, P));
+  rel.push_back(blob_put(B, t->vessel_start_offset, V)); rel.push_back(blob_put(B, v_total_space.data(), V));
   rel.push_back(blob_put(B, leg_off.data(), V + 1)); rel.push_back(blob_put(B, leg_time.data(), leg_time.size()));
-  rel.push_back(blob_put(B, v_period.data(), V)); rel.push_back(blob_put(B, er_delay.data(), P));
-  rel.push_back(blob_put(B, fr_delay.data(), P)); rel.push_back(blob_put(B, rec_off.data(), V + 1));
-  rel.push_back(blob_put(B, t->vessel_route, V));
+  rel.push_back(blob_put(B, er_delay.data(), P)); rel.push_back(blob_put(B, fr_delay.data(), P));
+  rel.push_back(blob_put(B, rec_off.data(), V + 1));
+  B.resize((B.size() + 63) / 64 * 64, 0);
+  const int64_t ctab_end = (int64_t)B.size();
+  rel.push_back(blob_put(B, t->vessel_capacity, V)); rel.push_back(blob_put(B, t->vessel_init_empty, V));
+  rel.push_back(blob_put(B, t->port_capacity, P)); rel.push_back(blob_put(B, t->port_init_empty, P));
+  rel.push_back(blob_put(B, v_period.data(), V)); rel.push_back(blob_put(B, t->vessel_route, V));
+  rel.push_back(blob_put(B, pair_src.data(), NT));
+  rel.push_back(ctab_begin);
+  k.ctab_words = (int)((ctab_end - ctab_begin) / 4);
+  k.l_ctab = k.lds_words;
+  k.lds_words += k.ctab_words;
+  k.l_mt2 += k.ctab_words; k.l_mt3 += k.ctab_words; k.lds_words_reset += k.ctab_words;
+  if ((int64_t)k.lds_words_reset * 4 > 160 * 1024) return fail("engine limit: per-env state exceeds 160 KiB of LDS");
 
   // ---- workspace carve-up
   Arena A;
@@ -233,9 +244,9 @@ inline void cim_plan_bind(CimHostPlan* pl, void* base_) {
   const double** dptr[] = {&k.src_base, &k.src_noise, &k.tgt_base, &k.tgt_noise, &k.er_base, &k.er_noise, &k.fr_base,
                            &k.fr_noise, &k.v_speed, &k.v_speed_noise, &k.v_dur, &k.v_dur_noise, &k.route_dist, &k.order_dist};
   for (auto p : dptr) *p = (const double*)(cb + r[i++]);
-  const int32_t** iptr[] = {&k.tgt_off, &k.tgt_port, &k.pair_src, &k.route_port, &k.v_route_base, &k.v_route_len, &k.v_start,
-                            &k.v_cap, &k.v_init_empty, &k.v_total_space, &k.p_cap, &k.p_init_empty, &k.leg_off, &k.leg_time,
-                            &k.v_period, &k.er_delay, &k.fr_delay, &k.rec_off, &k.v_route};
+  const int32_t** iptr[] = {&k.tgt_off, &k.tgt_port, &k.route_port, &k.v_route_base, &k.v_route_len, &k.v_start,
+                            &k.v_total_space, &k.leg_off, &k.leg_time, &k.er_delay, &k.fr_delay, &k.rec_off,
+                            &k.v_cap, &k.v_init_empty, &k.p_cap, &k.p_init_empty, &k.v_period, &k.v_route, &k.pair_src, &k.ctab};
   for (auto p : iptr) *p = (const int32_t*)(cb + r[i++]);
   k.live = (int32_t*)(base + pl->o_live); k.ring = (int32_t*)(base + pl->o_ring); k.ring_fi = (int32_t*)(base + pl->o_ring_fi);
   k.priv = (int32_t*)(base + pl->o_priv); k.rec = (int32_t*)(base + pl->o_rec); k.status = (int32_t*)(base + pl->o_status);

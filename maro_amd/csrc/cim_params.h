@@ -29,11 +29,13 @@ struct CimParams {
   double sample_noise;
   // ---- frame offsets (words inside one frame)
   int f_ports, f_vessels, f_fop, f_fov, f_plans;
+  int HW;  // hot words [0,HW): ports, vessels, full_on_ports (staged in LDS); cold [HW,FW): full_on_vessels, vessel_plans (HBM only)
   // ---- private-state layout (words)
-  int PW, pv_evt, pv_arr, pv_rfull, pv_rempty;
+  int PW, pv_evt, pv_arr, pv_next, pv_pos, pv_krl, pv_rfull, pv_rempty;
   int REC_W;
   // ---- LDS layout (word offsets)
   int l_frame, l_priv, l_mt0, l_mt1, l_dsrc, l_dtgt, l_oq, l_odelay, l_srcn, l_misc, lds_words;
+  int l_ctab, ctab_words;  // serial-access int tables staged in LDS by the step kernel
   int l_mt2, l_mt3, lds_words_reset;  // reset kernel only (placed after the step kernel's LDS)
   // ---- constant tables (device)
   const double *src_base, *src_noise, *tgt_base, *tgt_noise, *er_base, *er_noise, *fr_base, *fr_noise,
@@ -41,6 +43,7 @@ struct CimParams {
   const int32_t *tgt_off, *tgt_port, *pair_src, *route_port, *v_route_base, *v_route_len, *v_start, *v_cap,
       *v_init_empty, *v_total_space, *p_cap, *p_init_empty, *leg_off, *leg_time, *v_period, *er_delay,
       *fr_delay, *rec_off, *v_route;
+  const int32_t* ctab;  // start of the contiguous block holding tgt_off .. rec_off (ctab_words words)
   // ---- per-env state (device)
   int32_t *live, *ring, *ring_fi, *priv, *rec, *status, *tick, *nstops, *order_prop, *vperiod;
   uint32_t *mt, *stops;

@@ -13,6 +13,7 @@ class SingleEnvAdapter:
         self.lay = backend.layout
         cmd = np.full(backend.n_envs, self.topo.seed if seed is None else seed, np.int64)
         backend.reset(cmd)
+        self._paused = False
 
     # ---- reference-shaped control (core.py:143-170, 219-229; cim_data_container_helpers.py:56-73)
     def set_seed(self, s):
@@ -26,6 +27,7 @@ class SingleEnvAdapter:
         else:
             cmd = -1
         self._pending_seed = None
+        self._paused = False
         self.b.reset(np.full(self.b.n_envs, cmd, np.int64))
 
     def step(self, actions=None):
@@ -38,6 +40,8 @@ class SingleEnvAdapter:
                 acts[:, i] = a
             na[:] = len(actions)
         dec, met, done = self.b.step(acts, na)
+        self._paused = int(dec[self.e][7]) == 1
+        self._cur_fi = int(dec[self.e][6])
         return met[self.e], dec[self.e], bool(done[self.e])
 
     # ---- introspection
@@ -77,7 +81,11 @@ class SingleEnvAdapter:
 
     def frame_indices(self):
         fi = self._v(self.lay.off_ring_fi, np.int32, (self.b.n_envs, self.lay.ring_slots))[self.e]
-        return sorted(int(x) for x in fi if x >= 0)
+        S = self.lay.ring_slots
+        out = [int(x) for i, x in enumerate(fi) if x >= 0 and not (self._paused and i == self._cur_fi % S)]
+        if self._paused:  # the current frame of a paused env is its live frame (aliased pre-decision snapshot)
+            out.append(self._cur_fi)
+        return sorted(out)
 
     def _row_slots(self, node, attrs):
         t = self.topo

@@ -102,6 +102,8 @@ inline void rendezvous(int opcode, long long v) {
   swapcontext(&w->ctx[w->cur], &w->sched);
 }
 
+inline int first_live_lane() { EmuWave* w = cur_wave(); for (int l = 0; l < 64; l++) if (!w->done[l]) return l; return 0; }
+
 inline void sync() { rendezvous(1, 0); }
 
 inline uint64_t ballot(bool pred) {
@@ -123,6 +125,17 @@ inline long long reduce_add(long long v) {
   return s;
 }
 
-inline int uniform(int v) { return v; }
+// readfirstlane: modelled as a rendezvous so that wave-uniform read-modify-write code (every lane reads,
+// then every lane writes the same value) behaves as it does in lockstep on the GPU
+inline int uniform(int v) { rendezvous(6, v); return (int)cur_wave()->snap[first_live_lane()]; }
+
+inline void lds_dma_16(int32_t* lds_chunk, const int32_t* gsrc_lane) { memcpy(lds_chunk + 4 * lane(), gsrc_lane, 16); }
+inline void lds_dma_wait() { sync(); }
+
+inline void atomic_add_noret(int32_t* p, int v) { *p += v; }
+inline void mem_wait() {}
+struct mrx_v4i { int x, y, z, w; };
+inline mrx_v4i load16_l2(const int32_t* p) { mrx_v4i r; memcpy(&r, p, 16); return r; }
+inline void store16(int32_t* p, mrx_v4i v) { memcpy(p, &v, 16); }
 
 }  // namespace wave

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Attribute mrx_k_cim_step wave cycles to phases using the -DMRX_PROFILE_PHASES build
+(maro_amd/csrc/libmaro_amd_prof.so; built by `hipcc ... -DMRX_PROFILE_PHASES`).  Tooling only."""
+import argparse
+import ctypes
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+PHASES = ["load", "action", "post_step+snapshot", "mt_load", "A order_gen", "B1/B2 depart+returns", "B3 orders",
+          "B4 arrivals", "output+predecision snapshot", "store"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=16384)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--topology", default="global_trade.22p_l0.8")
+    args = ap.parse_args()
+    import maro_amd._lib as L
+    L.LIB_PATH = os.path.join(REPO, "maro_amd", "csrc", "libmaro_amd_prof.so")
+    import torch
+    from maro_amd.cim.engine import CimBatchEngine
+    lib = L.load()
+    n = args.envs
+    eng = CimBatchEngine(args.topology, n, durations=1120, max_snapshots=4, seeds=torch.arange(n) + 1)
+    actions = torch.zeros((n, 1, 4), dtype=torch.int32, device="cuda")
+    nact = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    eng.step()
+    for i in range(1, args.warmup):
+        eng.random_policy(i, actions, nact)
+        eng.step(actions, nact)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 16)()
+    lib.mrx_prof_read(buf, 1)
+    t0 = eng.ticks.sum().item()
+    for i in range(args.warmup, args.warmup + args.steps):
+        eng.random_policy(i, actions, nact)
+        eng.step(actions, nact)
+    torch.cuda.synchronize()
+    lib.mrx_prof_read(buf, 0)
+    tot = sum(buf[:10])
+    waves = n * args.steps
+    print(f"{args.topology}: {waves} env-steps, {eng.ticks.sum().item() - t0} ticks; mean {tot / waves:.0f} cycles per env-step")
+    for name, c in zip(PHASES, buf[:10]):
+        print(f"  {name:32s} {c / waves:10.0f} cyc/env-step  {100 * c / tot:5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
