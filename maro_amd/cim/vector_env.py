@@ -1,0 +1,305 @@
+"""Reference-shaped object API over the batched engine.
+
+``GpuVectorEnv`` mirrors ``maro.vector_env.VectorEnv`` (vector_env.py:95-217): ``step(action)`` with a
+scalar / list / dict action, ``reset()``, ``snapshot_list[node][ticks:nodes:attrs]`` (a list of flat float64
+numpy arrays, one per env), ``tick``, ``frame_index``.  ``env_view(i)`` gives an ``AbsEnv``-shaped single-env
+handle (core.py:92-260) so code written against ``Env`` — e.g. a ``maro.rl`` ``AbsEnvSampler`` — can drive
+env ``i`` of the batch unchanged.  This layer creates Python objects per env and synchronises with the
+device every call; high-throughput rollouts use the tensor API of ``CimBatchEngine`` directly.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from .engine import NODE_ATTRS, SEED_KEEP, SEED_REDRAW, CimBatchEngine
+from .payloads import encode_action, make_decision_event
+
+
+class InvalidActionError(AssertionError):
+    """The reference asserts inside ``_on_action_received`` (cim/business_engine.py:731,736)."""
+
+
+class BackendsInvalidAttributeException(Exception):
+    """Error code 2110 of the reference (maro/utils/exception/backends_exception.py)."""
+
+    def __init__(self, msg="Attribute not exist"):
+        super().__init__(2110, msg)
+
+
+def _as_list(x) -> list:
+    if x is None:
+        return []
+    if isinstance(x, (list, tuple)):
+        return list(x)
+    return [x]
+
+
+class _SnapshotNode:
+    """``snapshot_list[node]`` — slice grammar of frame.pyx:754-801."""
+
+    def __init__(self, owner: "GpuVectorEnv", node: str, envs: Optional[Sequence[int]]):
+        self._o, self._node, self._envs = owner, node, envs
+
+    def __len__(self):
+        t = self._o.engine.topo
+        return {"ports": t.n_ports, "vessels": t.n_vessels, "matrices": 1}[self._node]
+
+    def __getitem__(self, key: slice):
+        if key.step is None:  # querying needs at least one attribute
+            return None
+        attrs = _as_list(key.step)
+        for a in attrs:
+            if a not in NODE_ATTRS[self._node]:
+                raise BackendsInvalidAttributeException()
+        out = self._o._query(self._node, _as_list(key.start), _as_list(key.stop), attrs)
+        if self._envs is None:
+            return out
+        return out[self._envs[0]] if len(self._envs) == 1 else [out[e] for e in self._envs]
+
+
+class _SnapshotList:
+    def __init__(self, owner: "GpuVectorEnv", envs: Optional[Sequence[int]] = None):
+        self._o, self._envs = owner, envs
+
+    def __getitem__(self, name: str):
+        return _SnapshotNode(self._o, name, self._envs) if name in NODE_ATTRS else None
+
+    def get_frame_index_list(self):
+        lists = self._o._frame_index_lists()
+        if self._envs is None:
+            return lists
+        return lists[self._envs[0]] if len(self._envs) == 1 else [lists[e] for e in self._envs]
+
+    def __len__(self):
+        lists = self._o._frame_index_lists()
+        return len(lists[self._envs[0]]) if self._envs else max(len(x) for x in lists)
+
+
+class GpuVectorEnv:
+    """``batch_num`` CIM environments on one GPU, VectorEnv-shaped."""
+
+    def __init__(self, batch_num: int, scenario: str = "cim", topology: str = None, start_tick: int = 0,
+                 durations: int = 100, snapshot_resolution: int = 1, max_snapshots: int = None, decision_mode=0,
+                 options: Optional[dict] = None, seeds: Optional[Sequence[int]] = None, device="cuda:0",
+                 max_actions: int = 4, _engine=None):
+        if scenario != "cim":
+            raise NotImplementedError("the GPU engine implements the 'cim' scenario; use maro.simulator.Env for others")
+        if int(decision_mode) != 0:
+            raise NotImplementedError("only DecisionMode.Sequential is implemented on the GPU engine")
+        self.engine = _engine if _engine is not None else CimBatchEngine(
+            topology, batch_num, start_tick=start_tick, durations=durations, snapshot_resolution=snapshot_resolution,
+            max_snapshots=max_snapshots, max_actions=max_actions, device=device, seeds=seeds)
+        self._n = batch_num
+        self._started = np.zeros(batch_num, bool)
+        self._paused = np.zeros(batch_num, bool)
+        self._finished = np.zeros(batch_num, bool)     # (metrics, None, True) already returned
+        self._pending_seed: Dict[int, int] = {}
+        self._last_dec = np.zeros((batch_num, 8), np.int32)
+        self._last_met = np.zeros((batch_num, 3), np.int64)
+        self._snapshots = _SnapshotList(self)
+
+    # ------------------------------------------------------------------ VectorEnv surface
+    @property
+    def batch_number(self) -> int:
+        return self._n
+
+    @property
+    def snapshot_list(self) -> _SnapshotList:
+        return self._snapshots
+
+    @property
+    def tick(self) -> List[int]:
+        return self.engine.ticks.cpu().tolist()
+
+    @property
+    def frame_index(self) -> List[int]:
+        e = self.engine
+        return [(t - e.start_tick) // e.snapshot_resolution for t in self.tick]
+
+    def step(self, action=None):
+        """vector_env.py:116-144.  Returns (metrics list, decision_event list, all_done)."""
+        if isinstance(action, dict):
+            envs = sorted(action.keys())
+            per_env = {e: action[e] for e in envs}
+        elif isinstance(action, list):
+            assert len(action) == self._n
+            envs = list(range(self._n))
+            per_env = dict(enumerate(action))
+        else:
+            envs = list(range(self._n))
+            per_env = {e: action for e in envs}
+        res = self._step_envs(envs, per_env)
+        return [r[0] for r in res], [r[1] for r in res], bool(self._finished.all())
+
+    def reset(self, keep_seed: bool = False, envs: Optional[Sequence[int]] = None):
+        """VectorEnv.reset resets every env with Env.reset() (keep_seed=False, env_process.py:43-50)."""
+        envs = list(range(self._n)) if envs is None else list(envs)
+        cmd = np.full(self._n, SEED_KEEP, np.int64)
+        mask = np.zeros(self._n, np.uint8)
+        for e in envs:
+            mask[e] = 1
+            if not keep_seed:
+                cmd[e] = SEED_REDRAW       # set_seed is overridden by the redraw (cim_data_container_helpers.py:58-60)
+            elif e in self._pending_seed:
+                cmd[e] = self._pending_seed[e]
+            self._pending_seed.pop(e, None)
+            self._started[e] = self._paused[e] = self._finished[e] = False
+        self.engine.reset(cmd, mask)
+
+    def set_seed(self, seed: int, envs: Optional[Sequence[int]] = None):
+        """Takes effect at the next reset (cim_data_container_helpers.py:68-70)."""
+        for e in (range(self._n) if envs is None else envs):
+            self._pending_seed[e] = int(seed)
+
+    def env_view(self, index: int) -> "GpuEnvView":
+        return GpuEnvView(self, index)
+
+    def stop(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.stop()
+
+    # ------------------------------------------------------------------ internals
+    def _step_envs(self, envs: Sequence[int], per_env: Dict[int, object]):
+        eng = self.engine
+        A = eng.max_actions
+        acts = np.zeros((self._n, A, 4), np.int32)
+        nact = np.zeros(self._n, np.int32)
+        mask = np.zeros(self._n, np.uint8)
+        out = {}
+        for e in envs:
+            if self._finished[e]:
+                out[e] = (None, None, True)          # core.py:128-133
+                continue
+            mask[e] = 1
+            alist = _as_list(per_env.get(e))
+            if len(alist) > A:
+                raise ValueError(f"{len(alist)} actions for one decision event; engine was built with max_actions={A}")
+            for i, a in enumerate(alist):
+                acts[e, i] = encode_action(a)
+            nact[e] = len(alist)
+        if mask.any():
+            dec, met, done = eng.step(acts, nact, mask)
+            dec, met, done = dec.cpu().numpy(), met.cpu().numpy(), done.cpu().numpy()
+            status = eng.status.cpu().numpy()
+            for e in envs:
+                if not mask[e]:
+                    continue
+                if status[e] & 1:
+                    eng.status[e] = 0
+                    raise InvalidActionError(f"env {e}: action outside its scope (business_engine.py:731,736)")
+                self._started[e] = True
+                self._last_dec[e], self._last_met[e] = dec[e], met[e]
+                metrics = {"order_requirements": int(met[e, 0]), "container_shortage": int(met[e, 1]),
+                           "operation_number": int(met[e, 2])}
+                if done[e]:
+                    self._paused[e], self._finished[e] = False, True
+                    out[e] = (metrics, None, True)
+                else:
+                    self._paused[e] = True
+                    out[e] = (metrics, make_decision_event(dec[e], _SnapshotList(self, [e])), False)
+        return [out[e] for e in envs]
+
+    def _frame_index_lists(self) -> List[List[int]]:
+        eng = self.engine
+        fi = eng.ring_fi.cpu().numpy()
+        S = fi.shape[1]
+        ticks = eng.ticks.cpu().numpy()
+        res = []
+        for e in range(self._n):
+            cur = (int(ticks[e]) - eng.start_tick) // eng.snapshot_resolution
+            held = [int(x) for i, x in enumerate(fi[e]) if x >= 0 and not (self._paused[e] and i == cur % S)]
+            if self._paused[e]:
+                held.append(cur)     # the pre-decision snapshot (core.py:345) is the live frame
+            res.append(sorted(held))
+        return res
+
+    def _query(self, node: str, ticks: list, nodes: list, attrs: list) -> List[np.ndarray]:
+        eng = self.engine
+        n_nodes = {"ports": eng.topo.n_ports, "vessels": eng.topo.n_vessels, "matrices": 1}[node]
+        nodes = list(range(n_nodes)) if not nodes else [int(x) for x in nodes]
+        for x in nodes:
+            if not -n_nodes <= x < n_nodes:
+                raise IndexError(f"node index {x} out of range for {node}")
+        nodes = [x % n_nodes for x in nodes]
+        if ticks:
+            t = np.tile(np.asarray(ticks, np.int32), (self._n, 1))
+            counts = [len(ticks)] * self._n
+        else:  # all stored frames of each env (np_backend.pyx:530-531) — ragged across envs
+            lists = self._frame_index_lists()
+            counts = [len(x) for x in lists]
+            width = max(counts + [1])
+            t = np.full((self._n, width), -1, np.int32)
+            for e, x in enumerate(lists):
+                t[e, :len(x)] = x
+        out = eng.query(node, t, np.asarray(nodes, np.int32), attrs).cpu().numpy()
+        return [out[e, :counts[e]].reshape(-1) for e in range(self._n)]
+
+
+class GpuEnvView:
+    """``AbsEnv``-shaped handle on one env of a ``GpuVectorEnv`` (core.py:92-260)."""
+
+    def __init__(self, owner: GpuVectorEnv, index: int):
+        self._o, self._i = owner, index
+        self._snapshots = _SnapshotList(owner, [index])
+
+    def step(self, action=None):
+        return self._o._step_envs([self._i], {self._i: action})[0]
+
+    def reset(self, keep_seed: bool = False):
+        self._o.reset(keep_seed, [self._i])
+
+    def set_seed(self, seed: int):
+        assert seed is not None and isinstance(seed, int)
+        self._o.set_seed(seed, [self._i])
+
+    @property
+    def tick(self) -> int:
+        return int(self._o.engine.ticks[self._i].item())
+
+    @property
+    def frame_index(self) -> int:
+        e = self._o.engine
+        return (self.tick - e.start_tick) // e.snapshot_resolution
+
+    @property
+    def snapshot_list(self):
+        return self._snapshots
+
+    @property
+    def agent_idx_list(self) -> List[int]:
+        return list(range(self._o.engine.topo.n_ports))
+
+    @property
+    def metrics(self) -> dict:
+        m = self._o._last_met[self._i]
+        return {"order_requirements": int(m[0]), "container_shortage": int(m[1]), "operation_number": int(m[2])}
+
+    @property
+    def configs(self) -> dict:
+        return self._o.engine.topo.raw_config
+
+    @property
+    def name(self) -> str:
+        return f"cim:{self._o.engine.topo.name}"
+
+    @property
+    def summary(self) -> dict:
+        t = self._o.engine.topo
+        return {"node_mapping": {"ports": t.port_mapping, "vessels": t.vessel_mapping},
+                "node_detail": {"ports": {"number": t.n_ports}, "vessels": {"number": t.n_vessels},
+                                "matrices": {"number": 1}},
+                "event_payload": {}}
+
+    def get_finished_events(self):
+        return []
+
+    def get_pending_events(self, tick):
+        return []

@@ -1,0 +1,49 @@
+"""CimBatchEngine look-alike on top of the CPU wave emulator — lets the `-m "not gpu"` suite exercise the
+host-side object API (maro_amd/cim/vector_env.py) without a GPU.  Test infrastructure only."""
+import numpy as np
+import torch
+
+from maro_amd.cim.engine import NODE_ATTRS, NODE_TYPE
+from maro_amd.cim.topology import load_topology
+from tests.emu.emu import EmuBackend
+
+
+class EmuEngine:
+    def __init__(self, topology, n_envs, start_tick=0, durations=100, snapshot_resolution=1, max_snapshots=None,
+                 max_actions=1, seeds=None):
+        self.topo = topology if not isinstance(topology, str) else load_topology(topology)
+        self.b = EmuBackend(self.topo, n_envs, start_tick, durations, snapshot_resolution, max_snapshots, max_actions)
+        self.n_envs, self.max_actions = n_envs, max_actions
+        self.start_tick, self.durations, self.snapshot_resolution = start_tick, durations, snapshot_resolution
+        self.max_tick = start_tick + durations
+        lay = self.layout = self.b.layout
+        self.ticks = torch.from_numpy(self.b.view(lay.off_tick, np.int32, (n_envs,)))
+        self.status = torch.from_numpy(self.b.view(lay.off_status, np.int32, (n_envs,)))
+        self.seeds = torch.from_numpy(self.b.view(lay.off_seed, np.int64, (n_envs,)))
+        self.ring_fi = torch.from_numpy(self.b.view(lay.off_ring_fi, np.int32, (n_envs, lay.ring_slots)))
+        self.b.reset(np.full(n_envs, self.topo.seed, np.int64) if seeds is None else np.asarray(seeds, np.int64))
+
+    def reset(self, seed_cmd=None, mask=None):
+        self.b.reset(None if seed_cmd is None else np.asarray(seed_cmd), None if mask is None else np.asarray(mask))
+
+    def step(self, actions=None, n_actions=None, mask=None):
+        d, m, dn = self.b.step(None if actions is None else np.asarray(actions),
+                               None if n_actions is None else np.asarray(n_actions),
+                               None if mask is None else np.asarray(mask))
+        self.decisions, self.metrics, self.done = torch.from_numpy(d), torch.from_numpy(m), torch.from_numpy(dn)
+        return self.decisions, self.metrics, self.done
+
+    def query(self, node, ticks, nodes, attrs, out=None):
+        ids = [NODE_ATTRS[node].index(a) for a in attrs]
+        t = self.topo
+        slots = 0
+        for a in attrs:
+            if node == "vessels" and a.startswith("past_stop"):
+                slots += t.past_stop_number
+            elif node == "vessels" and a.startswith("future_stop"):
+                slots += t.future_stop_number
+            elif node == "matrices":
+                slots += t.n_ports * t.n_ports if a == "full_on_ports" else t.n_vessels * t.n_ports
+            else:
+                slots += 1
+        return torch.from_numpy(self.b.query(NODE_TYPE[node], np.asarray(ticks, np.int32), np.asarray(nodes, np.int32), ids, slots))
