@@ -37,6 +37,7 @@ enum { PF_LOAD, PF_ACTION, PF_POST_STEP, PF_MT_LOAD, PF_ORDER_GEN, PF_DEPART_RET
 struct Tabs {
   const int32_t *tgt_off, *tgt_port, *route_port, *v_route_base, *v_route_len, *v_start, *v_total_space,
       *leg_off, *leg_time, *er_delay, *fr_delay, *rec_off;
+  const double *src_base, *src_noise, *er_base, *er_noise, *fr_base, *fr_noise;
 };
 
 // LDS view of one env
@@ -71,6 +72,8 @@ MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
   L.tab.v_route_base = K.v_route_base; L.tab.v_route_len = K.v_route_len; L.tab.v_start = K.v_start;
   L.tab.v_total_space = K.v_total_space; L.tab.leg_off = K.leg_off; L.tab.leg_time = K.leg_time;
   L.tab.er_delay = K.er_delay; L.tab.fr_delay = K.fr_delay; L.tab.rec_off = K.rec_off;
+  L.tab.src_base = K.src_base; L.tab.src_noise = K.src_noise; L.tab.er_base = K.er_base; L.tab.er_noise = K.er_noise;
+  L.tab.fr_base = K.fr_base; L.tab.fr_noise = K.fr_noise;
   return L;
 }
 
@@ -88,6 +91,7 @@ MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
 #define V_NEXT(v) L.priv[K.pv_next + (v)]
 #define V_POS(v) L.priv[K.pv_pos + (v)]  /* (start + next_loc) mod route_len */
 #define V_KRL(v) L.priv[K.pv_krl + (v)]  /* next_loc mod (route_len + 1) */
+#define V_PERIOD(v) L.priv[K.pv_period + (v)]  /* vessel_period_without_noise of this env's data */
 #define U(x) wave::uniform(x)
 #define RING_FULL(slot, k) L.priv[K.pv_rfull + (slot) * K.NT + (k)]
 #define RING_EMPTY(slot, p) L.priv[K.pv_rempty + (slot) * K.P + (p)]
@@ -109,6 +113,9 @@ MRX_DEV void stage_tables(const CimParams& K, Lds& L, int32_t* lds) {
   L.tab.leg_off = c + (K.leg_off - K.ctab); L.tab.leg_time = c + (K.leg_time - K.ctab);
   L.tab.er_delay = c + (K.er_delay - K.ctab); L.tab.fr_delay = c + (K.fr_delay - K.ctab);
   L.tab.rec_off = c + (K.rec_off - K.ctab);
+#define MRX_DTAB(f) L.tab.f = (const double*)(c + ((const int32_t*)K.f - K.ctab))
+  MRX_DTAB(src_base); MRX_DTAB(src_noise); MRX_DTAB(er_base); MRX_DTAB(er_noise); MRX_DTAB(fr_base); MRX_DTAB(fr_noise);
+#undef MRX_DTAB
 }
 
 MRX_DEV uint32_t mt_temper(uint32_t y) {
@@ -366,6 +373,7 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
     V_ARR(v) = 0;
     V_POS(v) = K.v_start[v];
     V_KRL(v) = 0;
+    V_PERIOD(v) = K.vperiod[(size_t)env * V + v];
     V_NEXT(v) = K.nstops[(size_t)env * V + v] > 1 ? stop_arrival(g_stops[(size_t)v * K.SMAX + 1]) : 0x7fffffff;
   }
   if (lane == 0) {
@@ -388,14 +396,60 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
 
 // ==========================================================================================
 // One tick, phases A..B4.  Returns the mask of vessels that arrived (their decisions follow).
-MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int& idx_ord, int& idx_buf, int& status, Prof& prof) {
+MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int otg_in, int& idx_ord, int& idx_buf, int& status, Prof& prof) {
   const int lane = wave::lane();
   const int P = K.P, V = K.V, NT = K.NT, H = K.H;
   const Tabs& T = L.tab;
   int32_t* g_live = L.g_live;
 
+  // ---------------- prefetch: everything this tick will need from HBM/L2 is requested now, so the round trips
+  // overlap with phase A instead of stalling the serial sections later (a wave issues in order).
+  //  * per-pair fp64 noise tables and source-port ids for the first 3 x 64 pairs (lane k holds pair k0+lane)
+  double pf_tb[3], pf_tn[3];
+  int pf_src[3];
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    const int k = b * 64 + lane;
+    pf_tb[b] = 0.0; pf_tn[b] = 0.0; pf_src[b] = 0;
+    if (k < NT) { pf_tb[b] = K.tgt_base[k]; pf_tn[b] = K.tgt_noise[k]; pf_src[b] = K.pair_src[k]; }
+  }
+  //  * vessels arriving this tick are known up front (departures of this tick cannot arrive this tick): their
+  //    discharge records (lane j = j-th candidate load stop) and stop-table entries (lane a = a-th vessel)
+  const bool arr = lane < V && !FV(VA_IS_PARKING, lane) && FV(VA_NEXT_LOC_IDX, lane) > 0 && V_EVT(lane) == t;
+  const uint64_t arr_mask = wave::ballot(arr);
+  int32_t* g_rec = K.rec + (size_t)env * K.REC_W;
+  int pf_q[4], pf_key[4];
+  int pf_ns = 0;
+  uint32_t pf_stk = 0, pf_stk1 = 0;
+  {
+    uint64_t m = arr_mask;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      pf_q[a] = 0; pf_key[a] = 0;
+      if (m) {  // wave-uniform
+        const int v = __builtin_ctzll(m);
+        m &= m - 1;
+        const int k = U(FV(VA_NEXT_LOC_IDX, v));
+        const int Lr = T.v_route_len[v], RL = Lr + 1, krl = U(V_KRL(v));
+        const int sidx = k - Lr + lane;
+        int col = krl + 1 + lane;
+        if (col >= RL) col -= RL;
+        const size_t srow = ((size_t)env * V + v) * K.SMAX;
+        if (lane < Lr && sidx >= 0) {
+          pf_q[a] = g_rec[T.rec_off[v] + krl * RL + col];
+          pf_key[a] = stop_arrival(K.stops[srow + sidx]);
+        }
+        if (lane == a) {
+          pf_ns = K.nstops[(size_t)env * V + v];
+          pf_stk = K.stops[srow + k];
+          pf_stk1 = K.stops[srow + (k + 1 < K.SMAX ? k + 1 : k)];
+        }
+      }
+    }
+  }
+
   // ---------------- A. order generation (cim_data_container.py:309-398) -> L.oq[pair]
-  long long otg = (long long)K.order_prop[(size_t)env * K.T + t];
+  long long otg = (long long)otg_in;
   bool gen = true;
   if (K.order_mode == 1) {  // UNFIXED :327-333 (total_empty_number from business_engine.py:134-136)
     long long mine = 0;
@@ -409,9 +463,9 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int& idx_o
     double ns = 0.0;
     if (K.use_order_rng) {
       const double r = mt_draw_batch(L.mt_ord, idx_ord, lane < P ? lane : -1, P);
-      if (lane < P) ns = apply_noise(K.src_base[lane], K.src_noise[lane], r);
+      if (lane < P) ns = apply_noise(T.src_base[lane], T.src_noise[lane], r);
     } else if (lane < P) {
-      ns = K.src_base[lane] + 0.0;
+      ns = T.src_base[lane] + 0.0;
     }
     if (lane < P) L.dsrc[lane] = ns;
     wave::sync();
@@ -429,16 +483,22 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int& idx_o
       if (lane == 0) L.srcn[p] = (int32_t)c;
     }
     const int NTb = T.tgt_off[brk];
-    for (int k0 = 0; k0 < NTb; k0 += 64) {
-      const int k = k0 + lane;
-      const int n = (NTb - k0) < 64 ? (NTb - k0) : 64;
-      if (K.use_order_rng) {
-        const double r = mt_draw_batch(L.mt_ord, idx_ord, k < NTb ? lane : -1, n);
-        if (k < NTb) L.dtgt[k] = apply_noise(K.tgt_base[k], K.tgt_noise[k], r);
-      } else if (k < NTb) {
-        L.dtgt[k] = K.tgt_base[k] + 0.0;
-      }
+#define MRX_TGT_BATCH(k0, TB, TN)                                                              \
+    {                                                                                          \
+      const int k = (k0) + lane;                                                               \
+      const int n = (NTb - (k0)) < 64 ? (NTb - (k0)) : 64;                                      \
+      if (K.use_order_rng) {                                                                   \
+        const double r = mt_draw_batch(L.mt_ord, idx_ord, k < NTb ? lane : -1, n);             \
+        if (k < NTb) L.dtgt[k] = apply_noise(TB, TN, r);                                       \
+      } else if (k < NTb) {                                                                    \
+        L.dtgt[k] = (TB) + 0.0;                                                                \
+      }                                                                                        \
     }
+    if (NTb > 0) MRX_TGT_BATCH(0, pf_tb[0], pf_tn[0])
+    if (NTb > 64) MRX_TGT_BATCH(64, pf_tb[1], pf_tn[1])
+    if (NTb > 128) MRX_TGT_BATCH(128, pf_tb[2], pf_tn[2])
+    for (int k0 = 192; k0 < NTb; k0 += 64) MRX_TGT_BATCH(k0, K.tgt_base[k0 + lane < NT ? k0 + lane : 0], K.tgt_noise[k0 + lane < NT ? k0 + lane : 0])
+#undef MRX_TGT_BATCH
     wave::sync();
     if (lane < brk) {
       const long long n_p = L.srcn[lane];
@@ -492,12 +552,9 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int& idx_o
     FP(PA_FULL, lane) += sum;
   }
   wave::sync();
-  const bool arr = lane < V && !FV(VA_IS_PARKING, lane) && FV(VA_NEXT_LOC_IDX, lane) > 0 && V_EVT(lane) == t;
-  const uint64_t arr_mask = wave::ballot(arr);
   if (arr_mask) {
     // DISCHARGE_FULL :658-693.  One BUFFER draw per original event, in the order the events were scheduled:
     // (tick of the load, vessel index) — SURVEY.md §9.2.  Records: rec[v][dst_stop % RL][load_stop % RL].
-    int32_t* g_rec = K.rec + (size_t)env * K.REC_W;
     int32_t* ent = L.misc;  // (key, v, q) triples
     int n_ent = 0, n_ves = 0;
     for (uint64_t m = arr_mask; m; m &= m - 1) {  // wave-uniform
@@ -510,7 +567,10 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int& idx_o
       int col = krl + 1 + lane;  // (k - Lr + lane) mod RL
       if (col >= RL) col -= RL;
       int32_t* cell = g_rec + T.rec_off[v] + krl * RL + (lane < Lr ? col : 0);
-      if (lane < Lr && sidx >= 0) {
+      if (n_ves < 4) {  // prefetched at the top of the tick
+        q = n_ves == 0 ? pf_q[0] : n_ves == 1 ? pf_q[1] : n_ves == 2 ? pf_q[2] : pf_q[3];
+        key = n_ves == 0 ? pf_key[0] : n_ves == 1 ? pf_key[1] : n_ves == 2 ? pf_key[2] : pf_key[3];
+      } else if (lane < Lr && sidx >= 0) {
         q = *cell;
         key = stop_arrival(K.stops[((size_t)env * V + v) * K.SMAX + sidx]);
       }
@@ -545,7 +605,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int& idx_o
       FV(VA_FULL, v) = vf - q;
       FV(VA_REMAINING_SPACE, v) = vr + q;
       if (lane == 0) wave::atomic_add_noret(&GFOV(v, p), -q);
-      const int b = K.use_buffer_rng ? (int)ceil(apply_noise(K.er_base[p], K.er_noise[p], r)) : T.er_delay[p];
+      const int b = K.use_buffer_rng ? (int)ceil(apply_noise(T.er_base[p], T.er_noise[p], r)) : T.er_delay[p];
       if (b == 0) {  // immediate RETURN_EMPTY
         const int pe = U(FP(PA_EMPTY, p));
         FP(PA_EMPTY, p) = pe + q;
@@ -581,8 +641,9 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int& idx_o
       const int rank = has ? __builtin_popcountll(m & ((1ull << lane) - 1ull)) : -1;
       const double r = mt_draw_batch(L.mt_buf, idx_buf, rank, __builtin_popcountll(m));
       if (has) {
-        const int src = K.pair_src[k];
-        L.odelay[k] = (int)ceil(apply_noise(K.fr_base[src], K.fr_noise[src], r));
+        const int bi = k0 >> 6;
+        const int src = bi == 0 ? pf_src[0] : bi == 1 ? pf_src[1] : bi == 2 ? pf_src[2] : K.pair_src[k];
+        L.odelay[k] = (int)ceil(apply_noise(T.fr_base[src], T.fr_noise[src], r));
       }
     }
     wave::sync();
@@ -616,17 +677,25 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int& idx_o
 
   // ---------------- B4. arrivals + full loading, in vessel order (:600-632, :524-598)
   if (arr_mask) {
-    int32_t* g_rec = K.rec + (size_t)env * K.REC_W;
-    for (uint64_t m = arr_mask; m; m &= m - 1) {  // wave-uniform: all lanes compute/store identical values
+    int a_idx = 0;
+    for (uint64_t m = arr_mask; m; m &= m - 1, a_idx++) {  // wave-uniform: all lanes compute/store identical values
       const int v = __builtin_ctzll(m);
       const int k = U(FV(VA_NEXT_LOC_IDX, v));
       const int Lr = T.v_route_len[v], rb = T.v_route_base[v], RL = Lr + 1;
       const int pos = U(V_POS(v)), krl = U(V_KRL(v));
       const int p = T.route_port[rb + pos];
-      const size_t srow = ((size_t)env * V + v) * K.SMAX;
-      const int ns = K.nstops[(size_t)env * V + v];
-      const uint32_t st_k = K.stops[srow + k];
-      const uint32_t st_k1 = K.stops[srow + (k + 1 < K.SMAX ? k + 1 : k)];
+      int ns;
+      uint32_t st_k, st_k1;
+      if (a_idx < 4) {  // prefetched at the top of the tick by lane a_idx
+        ns = wave::shfl(pf_ns, a_idx);
+        st_k = (uint32_t)wave::shfl((int)pf_stk, a_idx);
+        st_k1 = (uint32_t)wave::shfl((int)pf_stk1, a_idx);
+      } else {
+        const size_t srow = ((size_t)env * V + v) * K.SMAX;
+        ns = K.nstops[(size_t)env * V + v];
+        st_k = K.stops[srow + k];
+        st_k1 = K.stops[srow + (k + 1 < K.SMAX ? k + 1 : k)];
+      }
       FV(VA_LAST_LOC_IDX, v) = k;
       FV(VA_IS_PARKING, v) = 1;
       FV(VA_LOC_PORT_IDX, v) = p;
@@ -685,7 +754,13 @@ MRX_DEV void take_snapshot(const CimParams& K, int env, Lds& L, int fi) {
   const int l = wave::lane();
   wave::mem_wait();
   const int c4 = (K.FW - K.HW) >> 2;
-  for (int i = l; i < c4; i += 64) wave::store16(dst + K.HW + 4 * i, wave::load16_l2(L.g_live + K.HW + 4 * i));
+  for (int i0 = 0; i0 < c4; i0 += 64 * 8) {  // 8 loads in flight per lane, then 8 stores
+    wave::mrx_v4i r[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + l; if (i < c4) r[u] = wave::load16_l2(L.g_live + K.HW + 4 * i); }
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + l; if (i < c4) wave::store16(dst + K.HW + 4 * i, r[u]); }
+  }
   copy_words(dst, L.frame, K.HW);
   if (l == 0) K.ring_fi[(size_t)env * K.S + s] = fi;
 }
@@ -703,19 +778,24 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   int32_t* g_live = K.live + (size_t)env * K.FW;
   uint32_t* g_mt = K.mt + (size_t)env * MTS_COUNT * MT_WORDS;
 
-  const int flags0 = g_priv[PH_FLAGS];
+  // Everything this step needs from HBM is requested before the first wait: hot frame, private state and
+  // topology tables by LDS-DMA, the action words into registers.
+  L.g_live = g_live;
+  copy_in_async(L.frame, g_live, K.HW);
+  copy_in_async(L.priv, g_priv, K.PW);
+  stage_tables(K, L, lds);
+  const Tabs& T = L.tab;
+  if (n_act > K.max_actions) n_act = K.max_actions;
+  int a0v = 0, a0p = 0, a0q = 0, a0t = 0;
+  if (n_act > 0) { a0v = actions[0]; a0p = actions[1]; a0q = actions[2]; a0t = actions[3]; }
+  wave::lds_dma_wait();
+  const int flags0 = U(L.priv[PH_FLAGS]);
   if (flags0 & FL_FINISHED) {  // reference: (None, None, True) once the generator is exhausted
     if (lane < 8) dec_out[lane] = lane == 7 ? -1 : 0;
     if (lane < 3) met_out[lane] = 0;
     if (lane == 0) *done_out = 1;
     return;
   }
-  L.g_live = g_live;
-  copy_in_async(L.frame, g_live, K.HW);
-  copy_in_async(L.priv, g_priv, K.PW);
-  stage_tables(K, L, lds);
-  const Tabs& T = L.tab;
-  wave::lds_dma_wait();
   prof.mark(PF_LOAD);
 
   int t = L.priv[PH_TICK];
@@ -729,10 +809,9 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
 
   // ---- actions for the pending decision (core.py:301-315 -> business_engine.py:708-748)
   if (!fresh) {
-    if (n_act > K.max_actions) n_act = K.max_actions;
     for (int i = 0; i < n_act; i++) {  // wave-uniform
       const int32_t* a = actions + 4 * i;
-      const int v = U(a[0]), p = U(a[1]), q = U(a[2]), ty = U(a[3]);
+      const int v = U(i == 0 ? a0v : a[0]), p = U(i == 0 ? a0p : a[1]), q = U(i == 0 ? a0q : a[2]), ty = U(i == 0 ? a0t : a[3]);
       if (v < 0 || v >= V || p < 0 || p >= P || q < 0 || (ty != 0 && ty != 1)) { status |= 1; continue; }
       const int pe = U(FP(PA_EMPTY, p)), ve = U(FV(VA_EMPTY, v));
       int npe, nve;
@@ -749,7 +828,7 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
       FV(VA_REMAINING_SPACE, v) = T.v_total_space[v] - U(FV(VA_FULL, v)) - nve;
       opnum += q;
       FP(PA_TRANSFER_COST, p) = f_bits((float)((double)bits_f(U(FP(PA_TRANSFER_COST, p))) + (double)q));
-      if (lane == 0) wave::atomic_add_noret(&GPLAN(v, p), K.vperiod[(size_t)env * V + v]);
+      if (lane == 0) wave::atomic_add_noret(&GPLAN(v, p), V_PERIOD(v));
     }
     const int cur = L.priv[PH_CUR_VESSEL];
     pend &= ~(1ull << cur);
@@ -758,6 +837,16 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   prof.mark(PF_ACTION);
 
   // ---- advance to the next decision event or the end of the episode (core.py:329-381)
+  const int32_t* g_prop = K.order_prop + (size_t)env * K.T;
+  int otg_next = 0;  // order count of the tick the loop would run next, requested one iteration ahead
+  if (!pend) {
+    const int tn = fresh ? t : t + 1;
+    if (tn < K.T) otg_next = g_prop[tn];
+    if (K.use_order_rng) copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(g_mt + MTS_ORDER * MT_WORDS), MT_WORDS);
+    if (K.use_buffer_rng) copy_in_async((int32_t*)L.mt_buf, (const int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), MT_WORDS);
+    mt_loaded = true;
+  }
+  bool mt_waited = false;
   for (;;) {
     if (pend) {
       dec_v = __builtin_ctzll(pend);
@@ -782,14 +871,14 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
     }
     prof.mark(PF_POST_STEP);
     fresh = false;
-    if (!mt_loaded) {
-      if (K.use_order_rng) copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(g_mt + MTS_ORDER * MT_WORDS), MT_WORDS);
-      if (K.use_buffer_rng) copy_in_async((int32_t*)L.mt_buf, (const int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), MT_WORDS);
-      mt_loaded = true;
+    if (!mt_waited) {
       wave::lds_dma_wait();
+      mt_waited = true;
       prof.mark(PF_MT_LOAD);
     }
-    pend = run_tick(K, env, L, t, idx_ord, idx_buf, status, prof);
+    const int otg_cur = otg_next;
+    if (t + 1 < K.T) otg_next = g_prop[t + 1];
+    pend = run_tick(K, env, L, t, otg_cur, idx_ord, idx_buf, status, prof);
   }
 
   // ---- outputs
@@ -833,7 +922,8 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   prof.mark(PF_OUTPUT);
   copy_words(g_live, L.frame, K.HW);
   copy_words(g_priv, L.priv, K.PW);
-  if (mt_loaded) {
+  if (mt_loaded && !mt_waited) wave::lds_dma_wait();  // never leave LDS-DMA in flight (episode ended before a tick ran)
+  if (mt_waited) {
     if (K.use_order_rng) copy_words((int32_t*)(g_mt + MTS_ORDER * MT_WORDS), (const int32_t*)L.mt_ord, MT_WORDS);
     if (K.use_buffer_rng) copy_words((int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), (const int32_t*)L.mt_buf, MT_WORDS);
   }
@@ -909,6 +999,7 @@ MRX_DEV double query_elem(const CimParams& K, int node_type, const int32_t* tick
 #undef V_NEXT
 #undef V_POS
 #undef V_KRL
+#undef V_PERIOD
 #undef U
 #undef RING_FULL
 #undef RING_EMPTY

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/maro_amd.h"
@@ -21,7 +22,8 @@ struct CimHostPlan {
   // byte offsets of per-env arrays inside the workspace
   int64_t o_live, o_ring, o_ring_fi, o_priv, o_rec, o_status, o_tick, o_nstops, o_order_prop, o_mt, o_stops, o_seed, o_vperiod;
   // relative offsets of const tables inside const_blob, in the order of CimParams' const pointers
-  std::vector<int64_t> const_rel;
+  std::vector<std::pair<size_t, int64_t>> binds;  // (byte offset of a pointer field inside kp, offset in const_blob)
+  int64_t ctab_rel = 0;
 };
 
 namespace cim_layout_detail {
@@ -115,7 +117,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   k.SMAX = (smax + 3) / 4 * 4;
   if (k.T >= (1 << 23)) return fail("engine limit: max_tick < 2^23");
   // private state
-  k.pv_evt = PH_COUNT; k.pv_arr = k.pv_evt + V; k.pv_next = k.pv_arr + V; k.pv_pos = k.pv_next + V; k.pv_krl = k.pv_pos + V; k.pv_rfull = k.pv_krl + V; k.pv_rempty = k.pv_rfull + H * NT;
+  k.pv_evt = PH_COUNT; k.pv_arr = k.pv_evt + V; k.pv_next = k.pv_arr + V; k.pv_pos = k.pv_next + V; k.pv_krl = k.pv_pos + V; k.pv_period = k.pv_krl + V; k.pv_rfull = k.pv_period + V; k.pv_rempty = k.pv_rfull + H * NT;
   k.PW = (k.pv_rempty + H * P + 3) / 4 * 4;
   // derived integer tables
   std::vector<int32_t> pair_src(NT ? NT : 1), v_route_base(V), v_route_len(V), v_total_space(V), leg_off(V + 1), leg_time,
@@ -161,45 +163,47 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   w = (w + 1) / 2 * 2;
   k.l_misc = k.l_dtgt;  // (key, v, q) x up to 128, live only in phase B2 when dtgt is dead
   k.lds_words = (w + 3) / 4 * 4;
-  w = k.lds_words;
-  k.l_mt2 = w; w += MT_WORDS;
-  k.l_mt3 = w; w += MT_WORDS;
-  k.lds_words_reset = (w + 3) / 4 * 4;
-  if ((int64_t)k.lds_words_reset * 4 > 160 * 1024) return fail("engine limit: per-env state exceeds 160 KiB of LDS");
 
   // ---- constant blob
   std::vector<uint8_t>& B = pl->const_blob;
   B.clear();
-  std::vector<int64_t>& rel = pl->const_rel;
-  rel.clear();
-  rel.push_back(blob_put(B, t->source_base, P)); rel.push_back(blob_put(B, t->source_noise, P));
-  rel.push_back(blob_put(B, t->target_base, NT)); rel.push_back(blob_put(B, t->target_noise, NT));
-  rel.push_back(blob_put(B, t->empty_return_base, P)); rel.push_back(blob_put(B, t->empty_return_noise, P));
-  rel.push_back(blob_put(B, t->full_return_base, P)); rel.push_back(blob_put(B, t->full_return_noise, P));
-  rel.push_back(blob_put(B, t->vessel_speed, V)); rel.push_back(blob_put(B, t->vessel_speed_noise, V));
-  rel.push_back(blob_put(B, t->vessel_duration, V)); rel.push_back(blob_put(B, t->vessel_duration_noise, V));
-  rel.push_back(blob_put(B, t->route_dist, NRP)); rel.push_back(blob_put(B, t->order_dist, t->period));
-  // int tables.  The first 13 (tgt_off .. rec_off) are read inside serial per-vessel / per-target loops, so the
-  // step kernel stages them in LDS as one contiguous block ("ctab"); blob_put pads each table to 64 B.
+  // Each table is appended to the blob and remembered as (field of kp, relative offset); cim_plan_bind()
+  // turns them into device pointers.  "ctab" = the contiguous block the step kernel stages in LDS: the six
+  // per-port fp64 tables and the int tables that are read inside serial (wave-uniform) loops.
+  std::vector<std::pair<size_t, int64_t>>& binds = pl->binds;
+  binds.clear();
+  auto put_d = [&](const double* CimParams::*f, const double* src, size_t n) {
+    binds.push_back({(size_t)((char*)&(k.*f) - (char*)&k), blob_put(B, src, n)});
+  };
+  auto put_i = [&](const int32_t* CimParams::*f, const int32_t* src, size_t n) {
+    binds.push_back({(size_t)((char*)&(k.*f) - (char*)&k), blob_put(B, src, n)});
+  };
+  put_d(&CimParams::tgt_base, t->target_base, NT); put_d(&CimParams::tgt_noise, t->target_noise, NT);
+  put_d(&CimParams::v_speed, t->vessel_speed, V); put_d(&CimParams::v_speed_noise, t->vessel_speed_noise, V);
+  put_d(&CimParams::v_dur, t->vessel_duration, V); put_d(&CimParams::v_dur_noise, t->vessel_duration_noise, V);
+  put_d(&CimParams::route_dist, t->route_dist, NRP); put_d(&CimParams::order_dist, t->order_dist, t->period);
   const int64_t ctab_begin = (int64_t)((B.size() + 63) / 64 * 64);
-  rel.push_back(blob_put(B, t->target_offset, P + 1)); rel.push_back(blob_put(B, t->target_port, NT));
-  rel.push_back(blob_put(B, t->route_port, NRP));
-  rel.push_back(blob_put(B, v_route_base.data(), V)); rel.push_back(blob_put(B, v_route_len.data(), V));
-  rel.push_back(blob_put(B, t->vessel_start_offset, V)); rel.push_back(blob_put(B, v_total_space.data(), V));
-  rel.push_back(blob_put(B, leg_off.data(), V + 1)); rel.push_back(blob_put(B, leg_time.data(), leg_time.size()));
-  rel.push_back(blob_put(B, er_delay.data(), P)); rel.push_back(blob_put(B, fr_delay.data(), P));
-  rel.push_back(blob_put(B, rec_off.data(), V + 1));
+  put_d(&CimParams::src_base, t->source_base, P); put_d(&CimParams::src_noise, t->source_noise, P);
+  put_d(&CimParams::er_base, t->empty_return_base, P); put_d(&CimParams::er_noise, t->empty_return_noise, P);
+  put_d(&CimParams::fr_base, t->full_return_base, P); put_d(&CimParams::fr_noise, t->full_return_noise, P);
+  put_i(&CimParams::tgt_off, t->target_offset, P + 1); put_i(&CimParams::tgt_port, t->target_port, NT);
+  put_i(&CimParams::route_port, t->route_port, NRP);
+  put_i(&CimParams::v_route_base, v_route_base.data(), V); put_i(&CimParams::v_route_len, v_route_len.data(), V);
+  put_i(&CimParams::v_start, t->vessel_start_offset, V); put_i(&CimParams::v_total_space, v_total_space.data(), V);
+  put_i(&CimParams::leg_off, leg_off.data(), V + 1); put_i(&CimParams::leg_time, leg_time.data(), leg_time.size());
+  put_i(&CimParams::er_delay, er_delay.data(), P); put_i(&CimParams::fr_delay, fr_delay.data(), P);
+  put_i(&CimParams::rec_off, rec_off.data(), V + 1);
   B.resize((B.size() + 63) / 64 * 64, 0);
   const int64_t ctab_end = (int64_t)B.size();
-  rel.push_back(blob_put(B, t->vessel_capacity, V)); rel.push_back(blob_put(B, t->vessel_init_empty, V));
-  rel.push_back(blob_put(B, t->port_capacity, P)); rel.push_back(blob_put(B, t->port_init_empty, P));
-  rel.push_back(blob_put(B, v_period.data(), V)); rel.push_back(blob_put(B, t->vessel_route, V));
-  rel.push_back(blob_put(B, pair_src.data(), NT));
-  rel.push_back(ctab_begin);
+  put_i(&CimParams::v_cap, t->vessel_capacity, V); put_i(&CimParams::v_init_empty, t->vessel_init_empty, V);
+  put_i(&CimParams::p_cap, t->port_capacity, P); put_i(&CimParams::p_init_empty, t->port_init_empty, P);
+  put_i(&CimParams::v_period, v_period.data(), V); put_i(&CimParams::v_route, t->vessel_route, V);
+  put_i(&CimParams::pair_src, pair_src.data(), NT);
+  pl->ctab_rel = ctab_begin;
   k.ctab_words = (int)((ctab_end - ctab_begin) / 4);
-  k.l_ctab = k.lds_words;
-  k.lds_words += k.ctab_words;
-  k.l_mt2 += k.ctab_words; k.l_mt3 += k.ctab_words; k.lds_words_reset += k.ctab_words;
+  k.l_ctab = (k.lds_words + 1) / 2 * 2;
+  k.lds_words = (k.l_ctab + k.ctab_words + 3) / 4 * 4;
+  k.l_mt2 = k.lds_words; k.l_mt3 = k.l_mt2 + MT_WORDS; k.lds_words_reset = k.l_mt3 + MT_WORDS;
   if ((int64_t)k.lds_words_reset * 4 > 160 * 1024) return fail("engine limit: per-env state exceeds 160 KiB of LDS");
 
   // ---- workspace carve-up
@@ -239,15 +243,8 @@ inline void cim_plan_bind(CimHostPlan* pl, void* base_) {
   uint8_t* base = (uint8_t*)base_;
   CimParams& k = pl->kp;
   uint8_t* cb = base + pl->const_off;
-  const std::vector<int64_t>& r = pl->const_rel;
-  int i = 0;
-  const double** dptr[] = {&k.src_base, &k.src_noise, &k.tgt_base, &k.tgt_noise, &k.er_base, &k.er_noise, &k.fr_base,
-                           &k.fr_noise, &k.v_speed, &k.v_speed_noise, &k.v_dur, &k.v_dur_noise, &k.route_dist, &k.order_dist};
-  for (auto p : dptr) *p = (const double*)(cb + r[i++]);
-  const int32_t** iptr[] = {&k.tgt_off, &k.tgt_port, &k.route_port, &k.v_route_base, &k.v_route_len, &k.v_start,
-                            &k.v_total_space, &k.leg_off, &k.leg_time, &k.er_delay, &k.fr_delay, &k.rec_off,
-                            &k.v_cap, &k.v_init_empty, &k.p_cap, &k.p_init_empty, &k.v_period, &k.v_route, &k.pair_src, &k.ctab};
-  for (auto p : iptr) *p = (const int32_t*)(cb + r[i++]);
+  for (auto& bd : pl->binds) *(const void**)((char*)&k + bd.first) = cb + bd.second;
+  k.ctab = (const int32_t*)(cb + pl->ctab_rel);
   k.live = (int32_t*)(base + pl->o_live); k.ring = (int32_t*)(base + pl->o_ring); k.ring_fi = (int32_t*)(base + pl->o_ring_fi);
   k.priv = (int32_t*)(base + pl->o_priv); k.rec = (int32_t*)(base + pl->o_rec); k.status = (int32_t*)(base + pl->o_status);
   k.tick = (int32_t*)(base + pl->o_tick); k.nstops = (int32_t*)(base + pl->o_nstops);

@@ -31,7 +31,7 @@ struct CimParams {
   int f_ports, f_vessels, f_fop, f_fov, f_plans;
   int HW;  // hot words [0,HW): ports, vessels, full_on_ports (staged in LDS); cold [HW,FW): full_on_vessels, vessel_plans (HBM only)
   // ---- private-state layout (words)
-  int PW, pv_evt, pv_arr, pv_next, pv_pos, pv_krl, pv_rfull, pv_rempty;
+  int PW, pv_evt, pv_arr, pv_next, pv_pos, pv_krl, pv_period, pv_rfull, pv_rempty;
   int REC_W;
   // ---- LDS layout (word offsets)
   int l_frame, l_priv, l_mt0, l_mt1, l_dsrc, l_dtgt, l_oq, l_odelay, l_srcn, l_misc, lds_words;
