@@ -41,7 +41,9 @@ enum {
   MRX_ENV_OK = 0,
   MRX_ENV_INVALID_ACTION = 1, /* reference: AssertionError in _on_action_received,
                                  cim/business_engine.py:731,736 — action skipped */
-  MRX_ENV_STOP_OVERFLOW = 2   /* route unrolling exceeded max_stops (engine limit) */
+  MRX_ENV_STOP_OVERFLOW = 2,  /* route unrolling exceeded max_stops (engine limit) */
+  MRX_ENV_OFFROUTE_ACTION = 32 /* an Action named a port that is not on the vessel's route: containers are moved
+                                  as in the reference but the vessel_plans[v,p] += period update is not representable */
 };
 
 /* Action types, reference cim/common.py:18-22 (ActionType.LOAD / DISCHARGE). */
@@ -123,8 +125,8 @@ typedef struct mrx_cim_layout {
   int32_t frame_off_ports;    /* 12 attrs x P */
   int32_t frame_off_vessels;  /* 24 words x V */
   int32_t frame_off_full_on_ports;   /* P*P, row = src, col = dst */
-  int32_t frame_off_full_on_vessels; /* V*P */
-  int32_t frame_off_vessel_plans;    /* V*P */
+  int32_t frame_off_full_on_vessels; /* compact: one cell per (vessel, distinct port of its route); all other */
+  int32_t frame_off_vessel_plans;    /* cells of the dense V*P matrices are constant (0 / -1); mrx_cim_query expands */
   /* byte offsets of the big arrays inside the workspace */
   int64_t off_live;    /* int32 [n_envs][FW] */
   int64_t off_ring;    /* int32 [n_envs][S][FW] */

@@ -36,14 +36,13 @@ enum { PF_LOAD, PF_ACTION, PF_POST_STEP, PF_MT_LOAD, PF_ORDER_GEN, PF_DEPART_RET
 // serial-access topology tables: global (L2) by default, re-pointed at the LDS copy by the step kernel
 struct Tabs {
   const int32_t *tgt_off, *tgt_port, *route_port, *v_route_base, *v_route_len, *v_start, *v_total_space,
-      *leg_off, *leg_time, *er_delay, *fr_delay, *rec_off;
+      *leg_off, *leg_time, *er_delay, *fr_delay, *rec_off, *v_cbase, *route_cidx;
   const double *src_base, *src_noise, *er_base, *er_noise, *fr_base, *fr_noise;
 };
 
 // LDS view of one env
 struct Lds {
   Tabs tab;
-  int32_t* g_live;  // this env's live frame in HBM (cold part is only ever accessed there)
   int32_t* frame;
   int32_t* priv;
   uint32_t* mt_ord;
@@ -72,6 +71,7 @@ MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
   L.tab.v_route_base = K.v_route_base; L.tab.v_route_len = K.v_route_len; L.tab.v_start = K.v_start;
   L.tab.v_total_space = K.v_total_space; L.tab.leg_off = K.leg_off; L.tab.leg_time = K.leg_time;
   L.tab.er_delay = K.er_delay; L.tab.fr_delay = K.fr_delay; L.tab.rec_off = K.rec_off;
+  L.tab.v_cbase = K.v_cbase; L.tab.route_cidx = K.route_cidx;
   L.tab.src_base = K.src_base; L.tab.src_noise = K.src_noise; L.tab.er_base = K.er_base; L.tab.er_noise = K.er_noise;
   L.tab.fr_base = K.fr_base; L.tab.fr_noise = K.fr_noise;
   return L;
@@ -84,8 +84,8 @@ MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
 #define FV_FUT(s, v) L.frame[K.f_vessels + (10 + 2 * K.past_n + (s)) * K.V + (v)]
 #define FV_FUTT(s, v) L.frame[K.f_vessels + (10 + 2 * K.past_n + K.future_n + (s)) * K.V + (v)]
 #define FOP(s, d) L.frame[K.f_fop + (s) * K.P + (d)]
-#define GFOV(v, p) g_live[K.f_fov + (v) * K.P + (p)]   /* cold: HBM only */
-#define GPLAN(v, p) g_live[K.f_plans + (v) * K.P + (p)] /* cold: HBM only */
+#define FOVC(v, c) L.frame[K.f_fov + T.v_cbase[v] + (c)]   /* full_on_vessels[v][c-th distinct route port] */
+#define PLANC(v, c) L.frame[K.f_plans + T.v_cbase[v] + (c)] /* vessel_plans, same indexing */
 #define V_EVT(v) L.priv[K.pv_evt + (v)]
 #define V_ARR(v) L.priv[K.pv_arr + (v)]
 #define V_NEXT(v) L.priv[K.pv_next + (v)]
@@ -113,6 +113,7 @@ MRX_DEV void stage_tables(const CimParams& K, Lds& L, int32_t* lds) {
   L.tab.leg_off = c + (K.leg_off - K.ctab); L.tab.leg_time = c + (K.leg_time - K.ctab);
   L.tab.er_delay = c + (K.er_delay - K.ctab); L.tab.fr_delay = c + (K.fr_delay - K.ctab);
   L.tab.rec_off = c + (K.rec_off - K.ctab);
+  L.tab.v_cbase = c + (K.v_cbase - K.ctab); L.tab.route_cidx = c + (K.route_cidx - K.ctab);
 #define MRX_DTAB(f) L.tab.f = (const double*)(c + ((const int32_t*)K.f - K.ctab))
   MRX_DTAB(src_base); MRX_DTAB(src_noise); MRX_DTAB(er_base); MRX_DTAB(er_noise); MRX_DTAB(fr_base); MRX_DTAB(fr_noise);
 #undef MRX_DTAB
@@ -234,9 +235,8 @@ MRX_DEV int stop_parking(uint32_t s) { return (int)(s & 0xffu); }
 // ------------------------------------------------------------------------------------------
 // predicted stops (vessel_future_stops_prediction.py:49-85): noise-free legs from `arrival`
 // at route position `pos`
-MRX_DEV void write_future_and_plans(const CimParams& K, Lds& L, int v, int pos, int arrival, bool store_cold) {
+MRX_DEV void write_future_and_plans(const CimParams& K, Lds& L, int v, int pos, int arrival) {
   const Tabs& T = L.tab;
-  int32_t* g_live = L.g_live;
   const int Lr = T.v_route_len[v], rb = T.v_route_base[v], lo = T.leg_off[v];
   int tick = arrival, x = pos;  // x walks the route cyclically
   for (int i = 0; i < Lr || i < K.future_n; i++) {
@@ -244,7 +244,7 @@ MRX_DEV void write_future_and_plans(const CimParams& K, Lds& L, int v, int pos, 
     x = (x + 1 == Lr) ? 0 : x + 1;
     const int port = T.route_port[rb + x];
     if (i < K.future_n) { FV_FUT(i, v) = port; FV_FUTT(i, v) = tick; }
-    if (i < Lr && store_cold) GPLAN(v, port) = tick;  // vessel_sailing_plan_wrapper.py:24-28 (later stops overwrite earlier)
+    if (i < Lr) PLANC(v, T.route_cidx[rb + x]) = tick;  // vessel_sailing_plan_wrapper.py:24-28 (later stops overwrite earlier)
   }
 }
 
@@ -257,11 +257,11 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   uint32_t* mt_route = (uint32_t*)(lds + K.l_mt2);
   uint32_t* mt_oinit = (uint32_t*)(lds + K.l_mt3);
   const int lane = wave::lane();
-  const int P = K.P, V = K.V, T = K.T;
+  const int P = K.P, V = K.V, TT = K.T;
   uint32_t* g_mt = K.mt + (size_t)env * MTS_COUNT * MT_WORDS;
   int32_t* g_priv = K.priv + (size_t)env * K.PW;
   int32_t* g_live = K.live + (size_t)env * K.FW;
-  L.g_live = g_live;
+  const Tabs& T = L.tab;
 
   // ---- base seed
   long long base;
@@ -291,18 +291,18 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   int idx_route = MT_WORDS, idx_oi = MT_WORDS;
 
   // ---- order proportion (parsers.py:57-106)
-  int32_t* g_prop = K.order_prop + (size_t)env * T;
-  for (int t0 = 0; t0 < T; t0 += 64) {
+  int32_t* g_prop = K.order_prop + (size_t)env * TT;
+  for (int t0 = 0; t0 < TT; t0 += 64) {
     const int t = t0 + lane;
-    double orders = t < T ? K.order_dist[t % K.period] : 0.0;
-    const bool nz = t < T && orders != 0.0;
+    double orders = t < TT ? K.order_dist[t % K.period] : 0.0;
+    const bool nz = t < TT && orders != 0.0;
     if (K.has_order_init) {
       const uint64_t m = wave::ballot(nz);
       const int rank = nz ? __builtin_popcountll(m & ((1ull << lane) - 1ull)) : -1;
       const double r = mt_draw_batch(mt_oinit, idx_oi, rank, __builtin_popcountll(m));
       if (nz) orders = apply_noise(orders, K.sample_noise, r);
     }
-    if (t < T) {
+    if (t < TT) {
       int32_t val = 0;
       if (nz) {
         double c = orders < 1.0 ? orders : 1.0;
@@ -336,7 +336,7 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
       if (k < Lr) period += K.leg_time[K.leg_off[v] + loc];  // cim_data_generator.py:93-101
       tick += parking + sailing;
       loc = (loc + 1 == Lr) ? 0 : loc + 1;
-      extra += (tick > T) ? 1 : 0;
+      extra += (tick > TT) ? 1 : 0;
       k++;
       if (k > 4 * K.SMAX) { status |= 2; break; }
     }
@@ -350,9 +350,7 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   copy_words((int32_t*)(g_mt + MTS_ROUTE * MT_WORDS), (const int32_t*)mt_route, MT_WORDS);
 
   // ---- frame (business_engine.py:321-356, 381-398) and private state
-  for (int i = lane; i < K.HW; i += 64) L.frame[i] = 0;
-  for (int i = K.HW + lane; i < K.FW; i += 64) g_live[i] = (i >= K.f_plans && i < K.f_plans + V * P) ? -1 : 0;  // cold part
-  wave::mem_wait();
+  for (int i = lane; i < K.FW; i += 64) L.frame[i] = (i >= K.f_plans && i < K.f_plans + K.NC) ? -1 : 0;
   for (int i = lane; i < K.PW; i += 64) L.priv[i] = 0;
   wave::sync();
   if (lane < P) {
@@ -368,7 +366,7 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
     FV(VA_IS_PARKING, v) = 1;
     FV(VA_LOC_PORT_IDX, v) = K.route_port[K.v_route_base[v] + K.v_start[v]];
     for (int s = 0; s < K.past_n; s++) { FV_PAST(s, v) = -1; FV_PASTT(s, v) = -1; }
-    write_future_and_plans(K, L, v, K.v_start[v], 0, true);
+    write_future_and_plans(K, L, v, K.v_start[v], 0);
     V_EVT(v) = stop_parking(g_stops[(size_t)v * K.SMAX]);  // leave tick of stop 0 (arrival 0)
     V_ARR(v) = 0;
     V_POS(v) = K.v_start[v];
@@ -387,7 +385,7 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
     K.tick[env] = K.start_tick;
   }
   wave::sync();
-  copy_words(g_live, L.frame, K.HW);
+  copy_words(g_live, L.frame, K.FW);
   copy_words(g_priv, L.priv, K.PW);
   for (int i = lane; i < K.S; i += 64) K.ring_fi[(size_t)env * K.S + i] = -1;
   int32_t* g_rec0 = K.rec + (size_t)env * K.REC_W;
@@ -400,7 +398,6 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int otg_in
   const int lane = wave::lane();
   const int P = K.P, V = K.V, NT = K.NT, H = K.H;
   const Tabs& T = L.tab;
-  int32_t* g_live = L.g_live;
 
   // ---------------- prefetch: everything this tick will need from HBM/L2 is requested now, so the round trips
   // overlap with phase A instead of stalling the serial sections later (a wave issues in order).
@@ -600,11 +597,12 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int otg_in
     for (int i = 0; i < n_ent; i++) {  // wave-uniform; every lane computes and stores the same values
       const double r = K.use_buffer_rng ? mt_draw_uniform(L.mt_buf, idx_buf) : 0.0;
       const int v = U(ent[3 * i + 1]), q = U(ent[3 * i + 2]);
-      const int p = T.route_port[T.v_route_base[v] + U(V_POS(v))];
-      const int vf = U(FV(VA_FULL, v)), vr = U(FV(VA_REMAINING_SPACE, v));
+      const int rpi = T.v_route_base[v] + U(V_POS(v));
+      const int p = T.route_port[rpi], pc = T.route_cidx[rpi];
+      const int vf = U(FV(VA_FULL, v)), vr = U(FV(VA_REMAINING_SPACE, v)), fv = U(FOVC(v, pc));
       FV(VA_FULL, v) = vf - q;
       FV(VA_REMAINING_SPACE, v) = vr + q;
-      if (lane == 0) wave::atomic_add_noret(&GFOV(v, p), -q);
+      FOVC(v, pc) = fv - q;
       const int b = K.use_buffer_rng ? (int)ceil(apply_noise(T.er_base[p], T.er_noise[p], r)) : T.er_delay[p];
       if (b == 0) {  // immediate RETURN_EMPTY
         const int pe = U(FP(PA_EMPTY, p));
@@ -700,7 +698,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int otg_in
       FV(VA_IS_PARKING, v) = 1;
       FV(VA_LOC_PORT_IDX, v) = p;
       V_ARR(v) = t;
-      write_future_and_plans(K, L, v, pos, t, lane == 0);
+      write_future_and_plans(K, L, v, pos, t);
       // load full
       const int cap = U(FV(VA_CAPACITY, v));
       int full = U(FV(VA_FULL, v));
@@ -717,10 +715,12 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int otg_in
         if (acceptable > 0 && pend > 0) {
           const int l = pend < acceptable ? pend : acceptable;
           FOP(p, dst) = pend - l;
-          if (lane == 0) wave::atomic_add_noret(&GFOV(v, dst), l);
+          const int dc = T.route_cidx[rb + x];
+          const int fv = U(FOVC(v, dc));
+          FOVC(v, dc) = fv + l;
           loaded_total += l;
           acceptable -= l;
-          if (lane == 0) g_rec[T.rec_off[v] + row * RL + krl] += l;
+          if (lane == 0) g_rec[T.rec_off[v] + row * RL + krl] = l;  // cell is empty: (dst stop, load stop) pairs are unique
         }
       }
       full += loaded_total;
@@ -746,23 +746,11 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int otg_in
   return arr_mask;
 }
 
-// snapshot into the env's ring (np_backend.pyx:481-518: slot = fi mod S): hot words from LDS, cold words
-// HBM -> HBM (read through L2 so this wave's own fire-and-forget updates are observed)
+// snapshot of the LDS frame into the env's ring (np_backend.pyx:481-518: slot = fi mod S)
 MRX_DEV void take_snapshot(const CimParams& K, int env, Lds& L, int fi) {
   const int s = fi % K.S;
-  int32_t* dst = K.ring + ((size_t)env * K.S + s) * K.FW;
-  const int l = wave::lane();
-  wave::mem_wait();
-  const int c4 = (K.FW - K.HW) >> 2;
-  for (int i0 = 0; i0 < c4; i0 += 64 * 8) {  // 8 loads in flight per lane, then 8 stores
-    wave::mrx_v4i r[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + l; if (i < c4) r[u] = wave::load16_l2(L.g_live + K.HW + 4 * i); }
-#pragma unroll
-    for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + l; if (i < c4) wave::store16(dst + K.HW + 4 * i, r[u]); }
-  }
-  copy_words(dst, L.frame, K.HW);
-  if (l == 0) K.ring_fi[(size_t)env * K.S + s] = fi;
+  copy_words(K.ring + ((size_t)env * K.S + s) * K.FW, L.frame, K.FW);
+  if (wave::lane() == 0) K.ring_fi[(size_t)env * K.S + s] = fi;
 }
 
 // ==========================================================================================
@@ -780,8 +768,7 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
 
   // Everything this step needs from HBM is requested before the first wait: hot frame, private state and
   // topology tables by LDS-DMA, the action words into registers.
-  L.g_live = g_live;
-  copy_in_async(L.frame, g_live, K.HW);
+  copy_in_async(L.frame, g_live, K.FW);
   copy_in_async(L.priv, g_priv, K.PW);
   stage_tables(K, L, lds);
   const Tabs& T = L.tab;
@@ -828,7 +815,13 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
       FV(VA_REMAINING_SPACE, v) = T.v_total_space[v] - U(FV(VA_FULL, v)) - nve;
       opnum += q;
       FP(PA_TRANSFER_COST, p) = f_bits((float)((double)bits_f(U(FP(PA_TRANSFER_COST, p))) + (double)q));
-      if (lane == 0) wave::atomic_add_noret(&GPLAN(v, p), V_PERIOD(v));
+      {  // vessel_plans[v, p] += period (:748): find p among the vessel's route ports
+        const int Lr = T.v_route_len[v], rb = T.v_route_base[v];
+        int c = -1;
+        for (int x = 0; x < Lr; x++) if (T.route_port[rb + x] == p) c = T.route_cidx[rb + x];
+        if (c >= 0) { const int pl = U(PLANC(v, c)); PLANC(v, c) = pl + U(V_PERIOD(v)); }
+        else status |= 32;  // MRX_ENV_OFFROUTE_ACTION
+      }
     }
     const int cur = L.priv[PH_CUR_VESSEL];
     pend &= ~(1ull << cur);
@@ -920,7 +913,7 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   }
   wave::sync();
   prof.mark(PF_OUTPUT);
-  copy_words(g_live, L.frame, K.HW);
+  copy_words(g_live, L.frame, K.FW);
   copy_words(g_priv, L.priv, K.PW);
   if (mt_loaded && !mt_waited) wave::lds_dma_wait();  // never leave LDS-DMA in flight (episode ended before a tick ran)
   if (mt_waited) {
@@ -953,7 +946,10 @@ MRX_DEV int frame_word(const CimParams& K, int node_type, int a, int node, int s
     else if (a == VA_FUTURE_STOP_TICK_LIST) row = 10 + 2 * K.past_n + K.future_n + s;
     return K.f_vessels + row * K.V + node;
   }
-  return (a == MA_FULL_ON_PORTS ? K.f_fop : a == MA_FULL_ON_VESSELS ? K.f_fov : K.f_plans) + s;
+  if (a == MA_FULL_ON_PORTS) return K.f_fop + s;
+  const int c = K.cidx_dense[s];  // dense cell s = vessel * P + port
+  if (c < 0) return -1;          // port not on the vessel's route: constant cell
+  return (a == MA_FULL_ON_VESSELS ? K.f_fov : K.f_plans) + c;
 }
 
 // one output element; `row` = env*nt*nn + ti*nn + ni, `col` in [0, row_slots)
@@ -981,7 +977,9 @@ MRX_DEV double query_elem(const CimParams& K, int node_type, const int32_t* tick
     if (slot < ns) { a = attrs[i]; break; }
     slot -= ns;
   }
-  const int32_t raw = frame[frame_word(K, node_type, a, nodes[ni], slot)];
+  const int w = frame_word(K, node_type, a, nodes[ni], slot);
+  if (w < 0) return a == MA_VESSEL_PLANS ? -1.0 : 0.0;  // never-written cells: plans are initialised to -1 (business_engine.py:344)
+  const int32_t raw = frame[w];
   return (node_type == 0 && a == PA_TRANSFER_COST) ? (double)bits_f(raw) : (double)raw;
 }
 
@@ -992,8 +990,8 @@ MRX_DEV double query_elem(const CimParams& K, int node_type, const int32_t* tick
 #undef FV_FUT
 #undef FV_FUTT
 #undef FOP
-#undef GFOV
-#undef GPLAN
+#undef FOVC
+#undef PLANC
 #undef V_EVT
 #undef V_ARR
 #undef V_NEXT

@@ -82,9 +82,31 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   int total_frames = (int)ceil((double)c->durations / (double)c->snapshot_resolution);
   k.S = c->max_snapshots > 0 ? c->max_snapshots : total_frames;
   // frame layout
-  k.f_ports = 0; k.f_vessels = PA_COUNT * P; k.f_fop = k.f_vessels + k.vrows * V; k.f_fov = (k.f_fop + P * P + 3) / 4 * 4;
-  k.HW = k.f_fov;
-  k.f_plans = k.f_fov + V * P; k.FW = k.f_plans + V * P;
+  k.f_ports = 0; k.f_vessels = PA_COUNT * P; k.f_fop = k.f_vessels + k.vrows * V; k.f_fov = k.f_fop + P * P;
+  // compact full_on_vessels / vessel_plans: one cell per (vessel, distinct port on its route)
+  std::vector<int32_t> v_cbase(V), route_cidx(NRP ? NRP : 1), cidx_dense((size_t)V * P, -1);
+  {
+    std::vector<int> route_nd(R, 0);
+    for (int r = 0; r < R; r++) {
+      std::vector<int> seen;
+      for (int i = t->route_offset[r]; i < t->route_offset[r + 1]; i++) {
+        int c = -1;
+        for (size_t j = 0; j < seen.size(); j++) if (seen[j] == t->route_port[i]) c = (int)j;
+        if (c < 0) { c = (int)seen.size(); seen.push_back(t->route_port[i]); }
+        route_cidx[i] = c;
+      }
+      route_nd[r] = (int)seen.size();
+    }
+    int nc = 0;
+    for (int v = 0; v < V; v++) {
+      const int r = t->vessel_route[v];
+      v_cbase[v] = nc;
+      for (int i = t->route_offset[r]; i < t->route_offset[r + 1]; i++) cidx_dense[(size_t)v * P + t->route_port[i]] = nc + route_cidx[i];
+      nc += route_nd[r];
+    }
+    k.NC = nc;
+  }
+  k.f_plans = k.f_fov + k.NC; k.FW = k.f_plans + k.NC;
   k.FW = (k.FW + 3) / 4 * 4;  // 16-byte rows for vector copies
   // RNG usage (draws with zero noise cannot influence any value)
   bool on = false, bn = false;
@@ -116,6 +138,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   if (c->max_stops > 0) smax = c->max_stops;
   k.SMAX = (smax + 3) / 4 * 4;
   if (k.T >= (1 << 23)) return fail("engine limit: max_tick < 2^23");
+  if (t->total_containers >= (1 << 24)) return fail("engine limit: total_containers < 2^24");
   // private state
   k.pv_evt = PH_COUNT; k.pv_arr = k.pv_evt + V; k.pv_next = k.pv_arr + V; k.pv_pos = k.pv_next + V; k.pv_krl = k.pv_pos + V; k.pv_period = k.pv_krl + V; k.pv_rfull = k.pv_period + V; k.pv_rempty = k.pv_rfull + H * NT;
   k.PW = (k.pv_rempty + H * P + 3) / 4 * 4;
@@ -150,7 +173,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   k.REC_W = (rec_w + 3) / 4 * 4;
   // LDS plan (word offsets; doubles 8-byte aligned)
   int w = 0;
-  k.l_frame = w; w += k.HW;
+  k.l_frame = w; w += k.FW;
   k.l_priv = w; w += k.PW;
   k.l_mt0 = w; w += MT_WORDS;
   k.l_mt1 = w; w += MT_WORDS;
@@ -193,12 +216,14 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   put_i(&CimParams::leg_off, leg_off.data(), V + 1); put_i(&CimParams::leg_time, leg_time.data(), leg_time.size());
   put_i(&CimParams::er_delay, er_delay.data(), P); put_i(&CimParams::fr_delay, fr_delay.data(), P);
   put_i(&CimParams::rec_off, rec_off.data(), V + 1);
+  put_i(&CimParams::v_cbase, v_cbase.data(), V); put_i(&CimParams::route_cidx, route_cidx.data(), NRP);
   B.resize((B.size() + 63) / 64 * 64, 0);
   const int64_t ctab_end = (int64_t)B.size();
   put_i(&CimParams::v_cap, t->vessel_capacity, V); put_i(&CimParams::v_init_empty, t->vessel_init_empty, V);
   put_i(&CimParams::p_cap, t->port_capacity, P); put_i(&CimParams::p_init_empty, t->port_init_empty, P);
   put_i(&CimParams::v_period, v_period.data(), V); put_i(&CimParams::v_route, t->vessel_route, V);
   put_i(&CimParams::pair_src, pair_src.data(), NT);
+  put_i(&CimParams::cidx_dense, cidx_dense.data(), (size_t)V * P);
   pl->ctab_rel = ctab_begin;
   k.ctab_words = (int)((ctab_end - ctab_begin) / 4);
   k.l_ctab = (k.lds_words + 1) / 2 * 2;

@@ -52,16 +52,6 @@ MRX_DEV void lds_dma_wait() {
   sync();
 }
 
-// --- HBM-resident ("cold") state touched sparsely from wave-uniform code -------------------------------
-// fire-and-forget add performed at L2 (no return value -> the wave does not wait for memory)
-MRX_DEV void atomic_add_noret(int32_t* p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// all of this wave's earlier global stores/atomics have reached L2
-MRX_DEV void mem_wait() { __builtin_amdgcn_s_waitcnt(0); }
-// 16-byte global load that bypasses the (non-coherent) per-CU L1, so it observes atomics done at L2
-typedef int mrx_v4i __attribute__((ext_vector_type(4)));
-MRX_DEV mrx_v4i load16_l2(const int32_t* p) { return __builtin_nontemporal_load((const mrx_v4i*)p); }
-MRX_DEV void store16(int32_t* p, mrx_v4i v) { *(mrx_v4i*)p = v; }
-
 // make a wave-uniform value provably uniform (scalar register)
 MRX_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

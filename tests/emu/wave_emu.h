@@ -132,10 +132,4 @@ inline int uniform(int v) { rendezvous(6, v); return (int)cur_wave()->snap[first
 inline void lds_dma_16(int32_t* lds_chunk, const int32_t* gsrc_lane) { memcpy(lds_chunk + 4 * lane(), gsrc_lane, 16); }
 inline void lds_dma_wait() { sync(); }
 
-inline void atomic_add_noret(int32_t* p, int v) { *p += v; }
-inline void mem_wait() {}
-struct mrx_v4i { int x, y, z, w; };
-inline mrx_v4i load16_l2(const int32_t* p) { mrx_v4i r; memcpy(&r, p, 16); return r; }
-inline void store16(int32_t* p, mrx_v4i v) { memcpy(p, &v, 16); }
-
 }  // namespace wave
