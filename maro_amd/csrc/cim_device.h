@@ -392,61 +392,78 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   for (int i = lane; i < K.REC_W; i += 64) g_rec0[i] = 0;
 }
 
+// Everything a tick needs from HBM/L2, requested one memory round trip ahead of its use (a wave issues in
+// order, so un-hidden loads stall the serial sections):
+//  * per-pair fp64 noise tables and source-port ids for the first 3 x 64 pairs (lane k holds pair k0+lane),
+//  * the tick's order count,
+//  * for the vessels that will arrive in that tick (known before the tick starts: a vessel departing in tick t
+//    cannot arrive in tick t): their discharge records (lane j = j-th candidate load stop) and stop-table
+//    entries (lane a = a-th arriving vessel).
+struct TickPf {
+  double tb[3], tn[3];
+  int src[3];
+  int q[4], key[4];
+  int ns, otg;
+  uint32_t stk, stk1;
+  uint64_t arr_mask;
+};
+
+MRX_DEV void tick_prefetch_static(const CimParams& K, TickPf& pf) {
+  const int lane = wave::lane();
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    const int k = b * 64 + lane;
+    pf.tb[b] = 0.0; pf.tn[b] = 0.0; pf.src[b] = 0;
+    if (k < K.NT) { pf.tb[b] = K.tgt_base[k]; pf.tn[b] = K.tgt_noise[k]; pf.src[b] = K.pair_src[k]; }
+  }
+}
+
+MRX_DEV void tick_prefetch(const CimParams& K, int env, Lds& L, int t, TickPf& pf) {
+  const int lane = wave::lane();
+  const int V = K.V;
+  const Tabs& T = L.tab;
+  pf.otg = K.order_prop[(size_t)env * K.T + t];
+  const bool arr = lane < V && !FV(VA_IS_PARKING, lane) && FV(VA_NEXT_LOC_IDX, lane) > 0 && V_EVT(lane) == t;
+  pf.arr_mask = wave::ballot(arr);
+  const int32_t* g_rec = K.rec + (size_t)env * K.REC_W;
+  pf.ns = 0; pf.stk = 0; pf.stk1 = 0;
+  uint64_t m = pf.arr_mask;
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    pf.q[a] = 0; pf.key[a] = 0;
+    if (m) {  // wave-uniform
+      const int v = __builtin_ctzll(m);
+      m &= m - 1;
+      const int k = U(FV(VA_NEXT_LOC_IDX, v));
+      const int Lr = T.v_route_len[v], RL = Lr + 1, krl = U(V_KRL(v));
+      const int sidx = k - Lr + lane;
+      int col = krl + 1 + lane;
+      if (col >= RL) col -= RL;
+      const size_t srow = ((size_t)env * V + v) * K.SMAX;
+      if (lane < Lr && sidx >= 0) {
+        pf.q[a] = g_rec[T.rec_off[v] + krl * RL + col];
+        pf.key[a] = stop_arrival(K.stops[srow + sidx]);
+      }
+      if (lane == a) {
+        pf.ns = K.nstops[(size_t)env * V + v];
+        pf.stk = K.stops[srow + k];
+        pf.stk1 = K.stops[srow + (k + 1 < K.SMAX ? k + 1 : k)];
+      }
+    }
+  }
+}
+
 // ==========================================================================================
 // One tick, phases A..B4.  Returns the mask of vessels that arrived (their decisions follow).
-MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int otg_in, int& idx_ord, int& idx_buf, int& status, Prof& prof) {
+MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, const TickPf& pf, int& idx_ord, int& idx_buf, int& status, Prof& prof) {
   const int lane = wave::lane();
   const int P = K.P, V = K.V, NT = K.NT, H = K.H;
   const Tabs& T = L.tab;
 
-  // ---------------- prefetch: everything this tick will need from HBM/L2 is requested now, so the round trips
-  // overlap with phase A instead of stalling the serial sections later (a wave issues in order).
-  //  * per-pair fp64 noise tables and source-port ids for the first 3 x 64 pairs (lane k holds pair k0+lane)
-  double pf_tb[3], pf_tn[3];
-  int pf_src[3];
-#pragma unroll
-  for (int b = 0; b < 3; b++) {
-    const int k = b * 64 + lane;
-    pf_tb[b] = 0.0; pf_tn[b] = 0.0; pf_src[b] = 0;
-    if (k < NT) { pf_tb[b] = K.tgt_base[k]; pf_tn[b] = K.tgt_noise[k]; pf_src[b] = K.pair_src[k]; }
-  }
-  //  * vessels arriving this tick are known up front (departures of this tick cannot arrive this tick): their
-  //    discharge records (lane j = j-th candidate load stop) and stop-table entries (lane a = a-th vessel)
-  const bool arr = lane < V && !FV(VA_IS_PARKING, lane) && FV(VA_NEXT_LOC_IDX, lane) > 0 && V_EVT(lane) == t;
-  const uint64_t arr_mask = wave::ballot(arr);
-  int32_t* g_rec = K.rec + (size_t)env * K.REC_W;
-  int pf_q[4], pf_key[4];
-  int pf_ns = 0;
-  uint32_t pf_stk = 0, pf_stk1 = 0;
-  {
-    uint64_t m = arr_mask;
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-      pf_q[a] = 0; pf_key[a] = 0;
-      if (m) {  // wave-uniform
-        const int v = __builtin_ctzll(m);
-        m &= m - 1;
-        const int k = U(FV(VA_NEXT_LOC_IDX, v));
-        const int Lr = T.v_route_len[v], RL = Lr + 1, krl = U(V_KRL(v));
-        const int sidx = k - Lr + lane;
-        int col = krl + 1 + lane;
-        if (col >= RL) col -= RL;
-        const size_t srow = ((size_t)env * V + v) * K.SMAX;
-        if (lane < Lr && sidx >= 0) {
-          pf_q[a] = g_rec[T.rec_off[v] + krl * RL + col];
-          pf_key[a] = stop_arrival(K.stops[srow + sidx]);
-        }
-        if (lane == a) {
-          pf_ns = K.nstops[(size_t)env * V + v];
-          pf_stk = K.stops[srow + k];
-          pf_stk1 = K.stops[srow + (k + 1 < K.SMAX ? k + 1 : k)];
-        }
-      }
-    }
-  }
-
   // ---------------- A. order generation (cim_data_container.py:309-398) -> L.oq[pair]
-  long long otg = (long long)otg_in;
+  const uint64_t arr_mask = pf.arr_mask;
+  int32_t* g_rec = K.rec + (size_t)env * K.REC_W;
+  long long otg = (long long)pf.otg;
   bool gen = true;
   if (K.order_mode == 1) {  // UNFIXED :327-333 (total_empty_number from business_engine.py:134-136)
     long long mine = 0;
@@ -491,9 +508,9 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int otg_in
         L.dtgt[k] = (TB) + 0.0;                                                                \
       }                                                                                        \
     }
-    if (NTb > 0) MRX_TGT_BATCH(0, pf_tb[0], pf_tn[0])
-    if (NTb > 64) MRX_TGT_BATCH(64, pf_tb[1], pf_tn[1])
-    if (NTb > 128) MRX_TGT_BATCH(128, pf_tb[2], pf_tn[2])
+    if (NTb > 0) MRX_TGT_BATCH(0, pf.tb[0], pf.tn[0])
+    if (NTb > 64) MRX_TGT_BATCH(64, pf.tb[1], pf.tn[1])
+    if (NTb > 128) MRX_TGT_BATCH(128, pf.tb[2], pf.tn[2])
     for (int k0 = 192; k0 < NTb; k0 += 64) MRX_TGT_BATCH(k0, K.tgt_base[k0 + lane < NT ? k0 + lane : 0], K.tgt_noise[k0 + lane < NT ? k0 + lane : 0])
 #undef MRX_TGT_BATCH
     wave::sync();
@@ -565,8 +582,8 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int otg_in
       if (col >= RL) col -= RL;
       int32_t* cell = g_rec + T.rec_off[v] + krl * RL + (lane < Lr ? col : 0);
       if (n_ves < 4) {  // prefetched at the top of the tick
-        q = n_ves == 0 ? pf_q[0] : n_ves == 1 ? pf_q[1] : n_ves == 2 ? pf_q[2] : pf_q[3];
-        key = n_ves == 0 ? pf_key[0] : n_ves == 1 ? pf_key[1] : n_ves == 2 ? pf_key[2] : pf_key[3];
+        q = n_ves == 0 ? pf.q[0] : n_ves == 1 ? pf.q[1] : n_ves == 2 ? pf.q[2] : pf.q[3];
+        key = n_ves == 0 ? pf.key[0] : n_ves == 1 ? pf.key[1] : n_ves == 2 ? pf.key[2] : pf.key[3];
       } else if (lane < Lr && sidx >= 0) {
         q = *cell;
         key = stop_arrival(K.stops[((size_t)env * V + v) * K.SMAX + sidx]);
@@ -640,7 +657,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int otg_in
       const double r = mt_draw_batch(L.mt_buf, idx_buf, rank, __builtin_popcountll(m));
       if (has) {
         const int bi = k0 >> 6;
-        const int src = bi == 0 ? pf_src[0] : bi == 1 ? pf_src[1] : bi == 2 ? pf_src[2] : K.pair_src[k];
+        const int src = bi == 0 ? pf.src[0] : bi == 1 ? pf.src[1] : bi == 2 ? pf.src[2] : K.pair_src[k];
         L.odelay[k] = (int)ceil(apply_noise(T.fr_base[src], T.fr_noise[src], r));
       }
     }
@@ -685,9 +702,9 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, int otg_in
       int ns;
       uint32_t st_k, st_k1;
       if (a_idx < 4) {  // prefetched at the top of the tick by lane a_idx
-        ns = wave::shfl(pf_ns, a_idx);
-        st_k = (uint32_t)wave::shfl((int)pf_stk, a_idx);
-        st_k1 = (uint32_t)wave::shfl((int)pf_stk1, a_idx);
+        ns = wave::shfl(pf.ns, a_idx);
+        st_k = (uint32_t)wave::shfl((int)pf.stk, a_idx);
+        st_k1 = (uint32_t)wave::shfl((int)pf.stk1, a_idx);
       } else {
         const size_t srow = ((size_t)env * V + v) * K.SMAX;
         ns = K.nstops[(size_t)env * V + v];
@@ -791,8 +808,25 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   int idx_ord = L.priv[PH_IDX_ORDER], idx_buf = L.priv[PH_IDX_BUFFER];
   long long opnum = ((long long)L.priv[PH_OPNUM_HI] << 32) | (uint32_t)L.priv[PH_OPNUM_LO];
   int status = 0;
-  bool finished = false, mt_loaded = false;
+  bool finished = false;
   int dec_v = -1;
+
+  // A tick will run in this step iff no other vessel of the current tick is still waiting for its decision.
+  // Its inputs (RNG states by LDS-DMA, order count, arrival records, noise tables) are requested NOW, so that
+  // second memory round trip overlaps with the action handling and post_step below.
+  TickPf pf;
+  bool mt_loaded = false;
+  {
+    const uint64_t pend_after = fresh ? 0ull : (pend & ~(1ull << (L.priv[PH_CUR_VESSEL] & 63)));
+    const int tn = fresh ? t : t + 1;
+    if (!pend_after && tn < K.T) {
+      if (K.use_order_rng) copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(g_mt + MTS_ORDER * MT_WORDS), MT_WORDS);
+      if (K.use_buffer_rng) copy_in_async((int32_t*)L.mt_buf, (const int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), MT_WORDS);
+      mt_loaded = true;
+      tick_prefetch_static(K, pf);
+      tick_prefetch(K, env, L, tn, pf);
+    }
+  }
 
   // ---- actions for the pending decision (core.py:301-315 -> business_engine.py:708-748)
   if (!fresh) {
@@ -830,15 +864,6 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   prof.mark(PF_ACTION);
 
   // ---- advance to the next decision event or the end of the episode (core.py:329-381)
-  const int32_t* g_prop = K.order_prop + (size_t)env * K.T;
-  int otg_next = 0;  // order count of the tick the loop would run next, requested one iteration ahead
-  if (!pend) {
-    const int tn = fresh ? t : t + 1;
-    if (tn < K.T) otg_next = g_prop[tn];
-    if (K.use_order_rng) copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(g_mt + MTS_ORDER * MT_WORDS), MT_WORDS);
-    if (K.use_buffer_rng) copy_in_async((int32_t*)L.mt_buf, (const int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), MT_WORDS);
-    mt_loaded = true;
-  }
   bool mt_waited = false;
   for (;;) {
     if (pend) {
@@ -865,13 +890,12 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
     prof.mark(PF_POST_STEP);
     fresh = false;
     if (!mt_waited) {
-      wave::lds_dma_wait();
+      wave::lds_dma_wait();  // RNG states + the prefetched loads issued right after the kernel-start wait
       mt_waited = true;
       prof.mark(PF_MT_LOAD);
     }
-    const int otg_cur = otg_next;
-    if (t + 1 < K.T) otg_next = g_prop[t + 1];
-    pend = run_tick(K, env, L, t, otg_cur, idx_ord, idx_buf, status, prof);
+    pend = run_tick(K, env, L, t, pf, idx_ord, idx_buf, status, prof);
+    if (!pend && t + 1 < K.T) tick_prefetch(K, env, L, t + 1, pf);  // another tick follows: request its inputs now
   }
 
   // ---- outputs
