@@ -408,13 +408,16 @@ struct TickPf {
   uint64_t arr_mask;
 };
 
+// All prefetch loads are branch-free (addresses clamped to valid memory, validity re-derived at the point of
+// use), so the compiler has no control-flow merge that would force an early s_waitcnt.
 MRX_DEV void tick_prefetch_static(const CimParams& K, TickPf& pf) {
   const int lane = wave::lane();
+  const int last = K.NT > 0 ? K.NT - 1 : 0;
 #pragma unroll
   for (int b = 0; b < 3; b++) {
-    const int k = b * 64 + lane;
-    pf.tb[b] = 0.0; pf.tn[b] = 0.0; pf.src[b] = 0;
-    if (k < K.NT) { pf.tb[b] = K.tgt_base[k]; pf.tn[b] = K.tgt_noise[k]; pf.src[b] = K.pair_src[k]; }
+    int k = b * 64 + lane;
+    k = k < last ? k : last;
+    pf.tb[b] = K.tgt_base[k]; pf.tn[b] = K.tgt_noise[k]; pf.src[b] = K.pair_src[k];
   }
 }
 
@@ -426,30 +429,35 @@ MRX_DEV void tick_prefetch(const CimParams& K, int env, Lds& L, int t, TickPf& p
   const bool arr = lane < V && !FV(VA_IS_PARKING, lane) && FV(VA_NEXT_LOC_IDX, lane) > 0 && V_EVT(lane) == t;
   pf.arr_mask = wave::ballot(arr);
   const int32_t* g_rec = K.rec + (size_t)env * K.REC_W;
-  pf.ns = 0; pf.stk = 0; pf.stk1 = 0;
+  // lane a (< 4) fetches the stop-table entries of the a-th arriving vessel
+  {
+    uint64_t m = pf.arr_mask;
+    int v = 0;
+    for (int a = 0; a < 4; a++) {
+      const int va = m ? __builtin_ctzll(m) : 0;
+      if (m) m &= m - 1;
+      if (lane == a) v = va;
+    }
+    const int k = FV(VA_NEXT_LOC_IDX, lane < 4 ? v : 0);
+    const size_t srow = ((size_t)env * V + v) * K.SMAX;
+    pf.ns = K.nstops[(size_t)env * V + v];
+    pf.stk = K.stops[srow + (k < K.SMAX ? k : 0)];
+    pf.stk1 = K.stops[srow + (k + 1 < K.SMAX ? k + 1 : 0)];
+  }
+  // lane j fetches the j-th candidate discharge record (and its load tick) of each of the first 4 vessels
   uint64_t m = pf.arr_mask;
 #pragma unroll
   for (int a = 0; a < 4; a++) {
-    pf.q[a] = 0; pf.key[a] = 0;
-    if (m) {  // wave-uniform
-      const int v = __builtin_ctzll(m);
-      m &= m - 1;
-      const int k = U(FV(VA_NEXT_LOC_IDX, v));
-      const int Lr = T.v_route_len[v], RL = Lr + 1, krl = U(V_KRL(v));
-      const int sidx = k - Lr + lane;
-      int col = krl + 1 + lane;
-      if (col >= RL) col -= RL;
-      const size_t srow = ((size_t)env * V + v) * K.SMAX;
-      if (lane < Lr && sidx >= 0) {
-        pf.q[a] = g_rec[T.rec_off[v] + krl * RL + col];
-        pf.key[a] = stop_arrival(K.stops[srow + sidx]);
-      }
-      if (lane == a) {
-        pf.ns = K.nstops[(size_t)env * V + v];
-        pf.stk = K.stops[srow + k];
-        pf.stk1 = K.stops[srow + (k + 1 < K.SMAX ? k + 1 : k)];
-      }
-    }
+    const int v = m ? __builtin_ctzll(m) : 0;  // wave-uniform; vessel 0 is a harmless stand-in when fewer arrive
+    if (m) m &= m - 1;
+    const int k = U(FV(VA_NEXT_LOC_IDX, v));
+    const int Lr = T.v_route_len[v], RL = Lr + 1, krl = U(V_KRL(v));
+    const int sidx = k - Lr + lane;
+    int col = krl + 1 + lane;
+    if (col >= RL) col -= RL;
+    const bool ok = lane < Lr && sidx >= 0;
+    pf.q[a] = g_rec[T.rec_off[v] + krl * RL + (ok ? col : 0)];
+    pf.key[a] = (int)K.stops[((size_t)env * V + v) * K.SMAX + (ok ? sidx : 0)];
   }
 }
 
@@ -483,18 +491,36 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, const Tick
     }
     if (lane < P) L.dsrc[lane] = ns;
     wave::sync();
-    // list_sum_normalize + sequential split with early break (:351-375), wave-uniform
+    // list_sum_normalize (utils.py:44-56): left-to-right fp64 sum, then one division per port (lane-parallel)
     double tot = 0.0;
     for (int p = 0; p < P; p++) tot += L.dsrc[p];
-    long long remaining = otg;
+    long long c = 0;
+    if (lane < P) {
+      const double ratio = (tot == 0.0) ? ns : ns / tot;
+      c = (long long)ceil((double)otg * ratio);
+      if (c > 0x7fffffffll) c = 0x7fffffffll;
+      if (c < -0x7fffffffll) c = -0x7fffffffll;
+    }
+    // sequential split with early break (:354-375): n_p = min(c_p, remaining), remaining -= n_p, stop at remaining == 0
     int brk = P;
-    for (int p = 0; p < P; p++) {
-      if (remaining == 0) { brk = p; break; }
-      const double ratio = (tot == 0.0) ? L.dsrc[p] : L.dsrc[p] / tot;
-      long long c = (long long)ceil((double)otg * ratio);
-      if (c > remaining) c = remaining;
-      remaining -= c;
-      if (lane == 0) L.srcn[p] = (int32_t)c;
+    const uint64_t negm = wave::ballot(lane < P && c < 0);
+    if (!negm) {  // usual case: a clamped prefix sum
+      const long long incl = (long long)wave::scan_incl_add((int)(lane < P ? (c < otg ? c : otg) : 0));  // terms capped at otg: no overflow
+      const long long rem_top = otg - (incl - (c < otg ? c : otg));  // remaining orders when port `lane` is reached
+      const uint64_t zm = wave::ballot(lane < P && rem_top <= 0);
+      if (zm) brk = __builtin_ctzll(zm);
+      if (lane < P) L.srcn[lane] = (int32_t)(rem_top <= 0 ? 0 : (c < rem_top ? c : rem_top));
+    } else {  // a negative noised ratio makes `remaining` grow: replay the reference loop literally
+      if (lane < P) L.srcn[lane] = (int32_t)c;
+      wave::sync();
+      long long remaining = otg;
+      for (int p = 0; p < P; p++) {
+        if (remaining == 0) { brk = p; break; }
+        long long cp = (long long)U(L.srcn[p]);
+        if (cp > remaining) cp = remaining;
+        remaining -= cp;
+        if (lane == 0) L.srcn[p] = (int32_t)cp;
+      }
     }
     const int NTb = T.tgt_off[brk];
 #define MRX_TGT_BATCH(k0, TB, TN)                                                              \
@@ -514,17 +540,45 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, const Tick
     for (int k0 = 192; k0 < NTb; k0 += 64) MRX_TGT_BATCH(k0, K.tgt_base[k0 + lane < NT ? k0 + lane : 0], K.tgt_noise[k0 + lane < NT ? k0 + lane : 0])
 #undef MRX_TGT_BATCH
     wave::sync();
+    // per-port normaliser: left-to-right sum of its noised target ratios (:361-366)
+    if (lane < brk) {
+      const int off = T.tgt_off[lane], cnt = T.tgt_off[lane + 1] - off;
+      double ts = 0.0;
+      for (int j = 0; j < cnt; j++) ts += L.dtgt[off + j];
+      L.dsrc[lane] = ts;
+    }
+    wave::sync();
+    // one division per (src, dst) pair, lane-parallel: raw ceil(n_src * ratio) (:380)
+#define MRX_PAIR_BATCH(k0, SRC)                                                                     \
+    {                                                                                               \
+      const int k = (k0) + lane;                                                                    \
+      if (k < NTb) {                                                                                \
+        const int sp = (SRC);                                                                       \
+        const long long n_p = L.srcn[sp];                                                           \
+        long long cur = 0;                                                                          \
+        if (n_p > 0) {                                                                              \
+          const double ts = L.dsrc[sp], x = L.dtgt[k];                                              \
+          cur = (long long)ceil((double)n_p * ((ts == 0.0) ? x : x / ts));                          \
+          if (cur > 0x7fffffffll) cur = 0x7fffffffll;                                               \
+          if (cur < -0x7fffffffll) cur = -0x7fffffffll;                                             \
+        }                                                                                           \
+        L.oq[k] = (int32_t)cur;                                                                     \
+      }                                                                                             \
+    }
+    if (NTb > 0) MRX_PAIR_BATCH(0, pf.src[0])
+    if (NTb > 64) MRX_PAIR_BATCH(64, pf.src[1])
+    if (NTb > 128) MRX_PAIR_BATCH(128, pf.src[2])
+    for (int k0 = 192; k0 < NTb; k0 += 64) MRX_PAIR_BATCH(k0, K.pair_src[k0 + lane < NT ? k0 + lane : 0])
+#undef MRX_PAIR_BATCH
+    wave::sync();
+    // sequential hand-out per source port (:381-393): cur = min(cur, remaining); only positive orders exist
     if (lane < brk) {
       const long long n_p = L.srcn[lane];
       if (n_p > 0) {
         const int off = T.tgt_off[lane], cnt = T.tgt_off[lane + 1] - off;
-        double ts = 0.0;
-        for (int j = 0; j < cnt; j++) ts += L.dtgt[off + j];
         long long rem = n_p;
         for (int j = 0; j < cnt; j++) {
-          const double x = L.dtgt[off + j];
-          const double ratio = (ts == 0.0) ? x : x / ts;
-          long long cur = (long long)ceil((double)n_p * ratio);
+          long long cur = L.oq[off + j];
           if (cur > rem) cur = rem;
           rem -= cur;
           L.oq[off + j] = cur > 0 ? (int32_t)cur : 0;
@@ -581,9 +635,11 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, const Tick
       int col = krl + 1 + lane;  // (k - Lr + lane) mod RL
       if (col >= RL) col -= RL;
       int32_t* cell = g_rec + T.rec_off[v] + krl * RL + (lane < Lr ? col : 0);
-      if (n_ves < 4) {  // prefetched at the top of the tick
-        q = n_ves == 0 ? pf.q[0] : n_ves == 1 ? pf.q[1] : n_ves == 2 ? pf.q[2] : pf.q[3];
-        key = n_ves == 0 ? pf.key[0] : n_ves == 1 ? pf.key[1] : n_ves == 2 ? pf.key[2] : pf.key[3];
+      if (n_ves < 4) {  // prefetched one round trip earlier (tick_prefetch)
+        if (lane < Lr && sidx >= 0) {
+          q = n_ves == 0 ? pf.q[0] : n_ves == 1 ? pf.q[1] : n_ves == 2 ? pf.q[2] : pf.q[3];
+          key = stop_arrival((uint32_t)(n_ves == 0 ? pf.key[0] : n_ves == 1 ? pf.key[1] : n_ves == 2 ? pf.key[2] : pf.key[3]));
+        }
       } else if (lane < Lr && sidx >= 0) {
         q = *cell;
         key = stop_arrival(K.stops[((size_t)env * V + v) * K.SMAX + sidx]);
@@ -789,9 +845,13 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   copy_in_async(L.priv, g_priv, K.PW);
   stage_tables(K, L, lds);
   const Tabs& T = L.tab;
+  // The RNG states are requested unconditionally: whether a tick will run is only known once the private
+  // state has arrived, and a second LDS-DMA round trip would serialise behind every later LDS access.
+  if (K.use_order_rng) copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(g_mt + MTS_ORDER * MT_WORDS), MT_WORDS);
+  if (K.use_buffer_rng) copy_in_async((int32_t*)L.mt_buf, (const int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), MT_WORDS);
   if (n_act > K.max_actions) n_act = K.max_actions;
   int a0v = 0, a0p = 0, a0q = 0, a0t = 0;
-  if (n_act > 0) { a0v = actions[0]; a0p = actions[1]; a0q = actions[2]; a0t = actions[3]; }
+  if (actions) { a0v = actions[0]; a0p = actions[1]; a0q = actions[2]; a0t = actions[3]; }
   wave::lds_dma_wait();
   const int flags0 = U(L.priv[PH_FLAGS]);
   if (flags0 & FL_FINISHED) {  // reference: (None, None, True) once the generator is exhausted
@@ -815,14 +875,10 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   // Its inputs (RNG states by LDS-DMA, order count, arrival records, noise tables) are requested NOW, so that
   // second memory round trip overlaps with the action handling and post_step below.
   TickPf pf;
-  bool mt_loaded = false;
   {
     const uint64_t pend_after = fresh ? 0ull : (pend & ~(1ull << (L.priv[PH_CUR_VESSEL] & 63)));
     const int tn = fresh ? t : t + 1;
     if (!pend_after && tn < K.T) {
-      if (K.use_order_rng) copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(g_mt + MTS_ORDER * MT_WORDS), MT_WORDS);
-      if (K.use_buffer_rng) copy_in_async((int32_t*)L.mt_buf, (const int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), MT_WORDS);
-      mt_loaded = true;
       tick_prefetch_static(K, pf);
       tick_prefetch(K, env, L, tn, pf);
     }
@@ -889,11 +945,7 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
     }
     prof.mark(PF_POST_STEP);
     fresh = false;
-    if (!mt_waited) {
-      wave::lds_dma_wait();  // RNG states + the prefetched loads issued right after the kernel-start wait
-      mt_waited = true;
-      prof.mark(PF_MT_LOAD);
-    }
+    mt_waited = true;  // RNG states are modified from here on
     pend = run_tick(K, env, L, t, pf, idx_ord, idx_buf, status, prof);
     if (!pend && t + 1 < K.T) tick_prefetch(K, env, L, t + 1, pf);  // another tick follows: request its inputs now
   }
@@ -939,7 +991,6 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   prof.mark(PF_OUTPUT);
   copy_words(g_live, L.frame, K.FW);
   copy_words(g_priv, L.priv, K.PW);
-  if (mt_loaded && !mt_waited) wave::lds_dma_wait();  // never leave LDS-DMA in flight (episode ended before a tick ran)
   if (mt_waited) {
     if (K.use_order_rng) copy_words((int32_t*)(g_mt + MTS_ORDER * MT_WORDS), (const int32_t*)L.mt_ord, MT_WORDS);
     if (K.use_buffer_rng) copy_words((int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), (const int32_t*)L.mt_buf, MT_WORDS);

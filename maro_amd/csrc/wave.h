@@ -52,6 +52,17 @@ MRX_DEV void lds_dma_wait() {
   sync();
 }
 
+// inclusive prefix sum over the lanes (lane i gets v_0 + ... + v_i)
+MRX_DEV int scan_incl_add(int v) {
+  const int l = lane();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_up(v, d, 64);
+    if (l >= d) v += u;
+  }
+  return v;
+}
+
 // make a wave-uniform value provably uniform (scalar register)
 MRX_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

@@ -63,6 +63,10 @@ CASES = {
     "toy4p_l00_full": ("toy.4p_ssdd_l0.0", dict(durations=1120), [("run", "none", None)]),
     "gt22p_l00_full": ("global_trade.22p_l0.0", dict(durations=1120), [("run", "none", None)]),
 }
+# synthetic topologies (tests/test_emu_synthetic.py::VARIANTS) exercising branches no shipped topology reaches;
+# written to a temp folder as config.yml and run through the real reference
+for _syn in ("immediate_returns", "unfixed_mode", "repeated_ports_noisy", "volume3_stops_2_5"):  # (negative_ratios trips the reference's own assert, cim_data_container.py:396)
+    CASES[f"syn_{_syn}"] = (f"#{_syn}", dict(durations=90), [("run", "rand0", None)])
 LIGHT = {"toy4p_l00_full", "gt22p_l00_full"}  # only decisions/metrics kept (size)
 
 
@@ -80,6 +84,16 @@ def worker(maro_root, case_name, out_path):
     topology, kwargs, script = CASES[case_name]
     if topology.startswith("@"):
         topology = os.path.join(maro_root, topology[1:])
+    if topology.startswith("#"):
+        import tempfile
+
+        import yaml
+        sys.path.insert(0, REPO)
+        from tests.test_emu_synthetic import VARIANTS
+        folder = tempfile.mkdtemp(prefix="syn_topo_")
+        with open(os.path.join(folder, "config.yml"), "w") as fp:
+            yaml.safe_dump(VARIANTS[topology[1:]], fp, sort_keys=False)
+        topology = folder
     env = Env(scenario="cim", topology=topology, start_tick=0, **kwargs)
     be = env.business_engine
     light = case_name in LIGHT

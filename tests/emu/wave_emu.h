@@ -125,6 +125,14 @@ inline long long reduce_add(long long v) {
   return s;
 }
 
+inline int scan_incl_add(int v) {
+  rendezvous(7, v);
+  EmuWave* w = cur_wave();
+  long long s = 0;
+  for (int l = 0; l <= w->cur; l++) s += w->snap[l];
+  return (int)s;
+}
+
 // readfirstlane: modelled as a rendezvous so that wave-uniform read-modify-write code (every lane reads,
 // then every lane writes the same value) behaves as it does in lockstep on the GPU
 inline int uniform(int v) { rendezvous(6, v); return (int)cur_wave()->snap[first_live_lane()]; }

@@ -28,6 +28,11 @@ def load_case(name):
 
 def case_topology(meta) -> CimTopology:
     topo = meta["topology"]
+    if topo.startswith("#"):
+        from maro_amd.cim.topology import parse_config
+        from tests.test_emu_synthetic import VARIANTS
+        import copy
+        return parse_config(copy.deepcopy(VARIANTS[topo[1:]]), name="syn_" + topo[1:])
     if topo.startswith("@"):
         with open(os.path.join(GOLDEN_DIR, "topology_case_config_folder.json")) as fp:
             return CimTopology.from_json(fp.read())
