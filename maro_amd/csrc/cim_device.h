@@ -603,21 +603,21 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, const Tick
     }
   }
 
-  // ---------------- B2. returns / discharges scheduled for this tick (all additive)
+  // ---------------- B2. returns / discharges scheduled for this tick (all additive -> lane-parallel + LDS adds)
   const int slot = t % H;
-  if (lane < P) {  // RETURN_FULL :499-522
-    const int off = T.tgt_off[lane], cnt = T.tgt_off[lane + 1] - off;
-    int sum = 0;
-    for (int j = 0; j < cnt; j++) {
-      const int q = RING_FULL(slot, off + j);
+#define MRX_PAIR_SRC(k0, k) ((k0) == 0 ? pf.src[0] : (k0) == 64 ? pf.src[1] : (k0) == 128 ? pf.src[2] : K.pair_src[(k) < NT ? (k) : 0])
+  for (int k0 = 0; k0 < NT; k0 += 64) {  // RETURN_FULL :499-522, one lane per (src, dst) pair
+    const int k = k0 + lane;
+    if (k < NT) {
+      const int q = RING_FULL(slot, k);
       if (q) {
-        sum += q;
-        FOP(lane, T.tgt_port[off + j]) += q;
-        RING_FULL(slot, off + j) = 0;
+        const int src = MRX_PAIR_SRC(k0, k);
+        RING_FULL(slot, k) = 0;
+        FOP(src, T.tgt_port[k]) += q;  // the pair owns this cell
+        wave::lds_add(&FP(PA_ON_SHIPPER, src), -q);
+        wave::lds_add(&FP(PA_FULL, src), q);
       }
     }
-    FP(PA_ON_SHIPPER, lane) -= sum;
-    FP(PA_FULL, lane) += sum;
   }
   wave::sync();
   if (arr_mask) {
@@ -656,7 +656,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, const Tick
     }
     if (n_ent > 128) { status |= 16; n_ent = 128; }
     wave::sync();
-    if (n_ves > 1 && n_ent > 1) {  // merge by load tick, stable (rare: several vessels arriving in one tick)
+    if (n_ves > 1 && n_ent > 1) {  // merge by load tick, stable (several vessels arriving in one tick)
       if (lane == 0) {
         for (int i = 1; i < n_ent; i++) {
           const int key = ent[3 * i], vv = ent[3 * i + 1], qq = ent[3 * i + 2];
@@ -667,26 +667,24 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, const Tick
       }
       wave::sync();
     }
-    for (int i = 0; i < n_ent; i++) {  // wave-uniform; every lane computes and stores the same values
-      const double r = K.use_buffer_rng ? mt_draw_uniform(L.mt_buf, idx_buf) : 0.0;
-      const int v = U(ent[3 * i + 1]), q = U(ent[3 * i + 2]);
-      const int rpi = T.v_route_base[v] + U(V_POS(v));
-      const int p = T.route_port[rpi], pc = T.route_cidx[rpi];
-      const int vf = U(FV(VA_FULL, v)), vr = U(FV(VA_REMAINING_SPACE, v)), fv = U(FOVC(v, pc));
-      FV(VA_FULL, v) = vf - q;
-      FV(VA_REMAINING_SPACE, v) = vr + q;
-      FOVC(v, pc) = fv - q;
-      const int b = K.use_buffer_rng ? (int)ceil(apply_noise(T.er_base[p], T.er_noise[p], r)) : T.er_delay[p];
-      if (b == 0) {  // immediate RETURN_EMPTY
-        const int pe = U(FP(PA_EMPTY, p));
-        FP(PA_EMPTY, p) = pe + q;
-      } else {
-        const int oc = U(FP(PA_ON_CONSIGNEE, p));
-        FP(PA_ON_CONSIGNEE, p) = oc + q;
-        if (b > 0) {
-          const int sl = slot + b >= H ? slot + b - H : slot + b;
-          const int re = U(RING_EMPTY(sl, p));
-          RING_EMPTY(sl, p) = re + q;
+    for (int i0 = 0; i0 < n_ent; i0 += 64) {  // one lane per record; every effect is an addition
+      const int i = i0 + lane;
+      const bool has = i < n_ent;
+      const int nb = (n_ent - i0) < 64 ? (n_ent - i0) : 64;
+      const double r = K.use_buffer_rng ? mt_draw_batch(L.mt_buf, idx_buf, has ? lane : -1, nb) : 0.0;
+      if (has) {
+        const int v = ent[3 * i + 1], q = ent[3 * i + 2];
+        const int rpi = T.v_route_base[v] + V_POS(v);
+        const int p = T.route_port[rpi], pc = T.route_cidx[rpi];
+        wave::lds_add(&FV(VA_FULL, v), -q);
+        wave::lds_add(&FV(VA_REMAINING_SPACE, v), q);
+        wave::lds_add(&FOVC(v, pc), -q);
+        const int b = K.use_buffer_rng ? (int)ceil(apply_noise(T.er_base[p], T.er_noise[p], r)) : T.er_delay[p];
+        if (b == 0) {  // immediate RETURN_EMPTY
+          wave::lds_add(&FP(PA_EMPTY, p), q);
+        } else {
+          wave::lds_add(&FP(PA_ON_CONSIGNEE, p), q);
+          if (b > 0) { const int sl = slot + b >= H ? slot + b - H : slot + b; wave::lds_add(&RING_EMPTY(sl, p), q); }
         }
       }
     }
@@ -703,61 +701,85 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, const Tick
   wave::sync();
   prof.mark(PF_DEPART_RETURNS);
 
-  // ---------------- B3. orders (:448-497) — one BUFFER draw per order, in generation order
-  if (K.use_buffer_rng) {
+  // ---------------- B3. orders (:448-497) — one BUFFER draw per order, in generation order; one lane per pair
+  {
+    int32_t* pre = L.misc;  // inclusive prefix of the order quantities over all pairs (ent[] is dead by now)
+    int carry = 0;
+    bool any_imm = false;
+    if (lane < P) L.srcn[lane] = 0;  // per-port sum of immediately returned containers
     for (int k0 = 0; k0 < NT; k0 += 64) {
       const int k = k0 + lane;
-      const bool has = k < NT && L.oq[k] > 0;
-      const uint64_t m = wave::ballot(has);
-      const int rank = has ? __builtin_popcountll(m & ((1ull << lane) - 1ull)) : -1;
-      const double r = mt_draw_batch(L.mt_buf, idx_buf, rank, __builtin_popcountll(m));
-      if (has) {
-        const int bi = k0 >> 6;
-        const int src = bi == 0 ? pf.src[0] : bi == 1 ? pf.src[1] : bi == 2 ? pf.src[2] : K.pair_src[k];
-        L.odelay[k] = (int)ceil(apply_noise(T.fr_base[src], T.fr_noise[src], r));
+      const int q = k < NT ? L.oq[k] : 0;
+      const bool has = q > 0;
+      int b = 0;
+      if (K.use_buffer_rng) {
+        const uint64_t m = wave::ballot(has);
+        const int rank = has ? __builtin_popcountll(m & ((1ull << lane) - 1ull)) : -1;
+        const double r = mt_draw_batch(L.mt_buf, idx_buf, rank, __builtin_popcountll(m));
+        if (has) { const int src = MRX_PAIR_SRC(k0, k); b = (int)ceil(apply_noise(T.fr_base[src], T.fr_noise[src], r)); }
+      } else if (has) {
+        b = T.fr_delay[MRX_PAIR_SRC(k0, k)];
+      }
+      const int incl = wave::scan_incl_add(q) + carry;
+      carry = wave::shfl(incl, 63);
+      if (k < NT) { pre[k] = incl; L.odelay[k] = b; }
+      any_imm = any_imm || (wave::ballot(has && b == 0) != 0);
+    }
+    wave::sync();
+    // exec_j = min(q_j, max(0, empty0 - sum of the port's earlier orders)): the sequential hand-out of :462-478
+    for (int k0 = 0; k0 < NT; k0 += 64) {
+      const int k = k0 + lane;
+      const int q = k < NT ? L.oq[k] : 0;
+      if (q > 0) {
+        const int src = MRX_PAIR_SRC(k0, k);
+        const int off = T.tgt_off[src];
+        const int excl = pre[k] - q - (off > 0 ? pre[off - 1] : 0);
+        const int avail = FP(PA_EMPTY, src) - excl;
+        const int exec = avail <= 0 ? 0 : (q < avail ? q : avail);
+        const int b = L.odelay[k];
+        if (b == 0) { FOP(src, T.tgt_port[k]) += exec; wave::lds_add(&L.srcn[src], exec); }  // RETURN_FULL right away (:494-497)
+        else if (b > 0) { const int sl = slot + b; RING_FULL(sl >= H ? sl - H : sl, k) += exec; }
       }
     }
     wave::sync();
-  }
-  if (lane < P) {
-    const int p = lane;
-    const int off = T.tgt_off[p], cnt = T.tgt_off[p + 1] - off;
-    int empty = FP(PA_EMPTY, p), booking = FP(PA_BOOKING, p), acc_booking = FP(PA_ACC_BOOKING, p);
-    int shortage = FP(PA_SHORTAGE, p), acc_shortage = FP(PA_ACC_SHORTAGE, p);
-    int on_shipper = FP(PA_ON_SHIPPER, p), full = FP(PA_FULL, p);
-    for (int j = 0; j < cnt; j++) {
-      const int q = L.oq[off + j];
-      if (q > 0) {
-        int exec = q;
-        booking += q; acc_booking += q;
-        if (empty < q) { const int s = q - empty; shortage += s; acc_shortage += s; exec = empty; }
-        empty -= exec;
-        on_shipper += exec;
-        const int b = K.use_buffer_rng ? L.odelay[off + j] : T.fr_delay[p];
-        if (b == 0) { on_shipper -= exec; full += exec; FOP(p, T.tgt_port[off + j]) += exec; }
-        else if (b > 0) { const int sl = slot + b; RING_FULL(sl >= H ? sl - H : sl, off + j) += exec; }
+    if (lane < P) {  // port totals in closed form
+      const int p = lane;
+      const int off = T.tgt_off[p], cnt = T.tgt_off[p + 1] - off;
+      if (cnt > 0) {
+        const int sumq = pre[off + cnt - 1] - (off > 0 ? pre[off - 1] : 0);
+        if (sumq > 0) {
+          const int empty0 = FP(PA_EMPTY, p);
+          const int short_ = sumq > empty0 ? sumq - empty0 : 0;
+          const int exec = sumq - short_;
+          const int imm = any_imm ? L.srcn[p] : 0;
+          const int booking = FP(PA_BOOKING, p) + sumq, shortage = FP(PA_SHORTAGE, p) + short_;
+          FP(PA_BOOKING, p) = booking; FP(PA_ACC_BOOKING, p) += sumq;
+          FP(PA_SHORTAGE, p) = shortage; FP(PA_ACC_SHORTAGE, p) += short_;
+          FP(PA_FULFILLMENT, p) = booking - shortage;  // port.py:88-97
+          FP(PA_EMPTY, p) = empty0 - exec;
+          FP(PA_ON_SHIPPER, p) += exec - imm;
+          FP(PA_FULL, p) += imm;
+        }
       }
     }
-    FP(PA_EMPTY, p) = empty; FP(PA_BOOKING, p) = booking; FP(PA_ACC_BOOKING, p) = acc_booking;
-    FP(PA_SHORTAGE, p) = shortage; FP(PA_ACC_SHORTAGE, p) = acc_shortage;
-    FP(PA_FULFILLMENT, p) = booking - shortage;  // port.py:88-97
-    FP(PA_ON_SHIPPER, p) = on_shipper; FP(PA_FULL, p) = full;
   }
+#undef MRX_PAIR_SRC
   wave::sync();
   prof.mark(PF_ORDERS);
 
-  // ---------------- B4. arrivals + full loading, in vessel order (:600-632, :524-598)
+  // ---------------- B4. arrivals + full loading, in vessel order (:600-632, :524-598); lane i = i-th next stop
   if (arr_mask) {
     int a_idx = 0;
-    for (uint64_t m = arr_mask; m; m &= m - 1, a_idx++) {  // wave-uniform: all lanes compute/store identical values
+    for (uint64_t m = arr_mask; m; m &= m - 1, a_idx++) {  // wave-uniform over the arriving vessels
       const int v = __builtin_ctzll(m);
-      const int k = U(FV(VA_NEXT_LOC_IDX, v));
+      int k = FV(VA_NEXT_LOC_IDX, v), pos = V_POS(v), krl = V_KRL(v), cap = FV(VA_CAPACITY, v), full = FV(VA_FULL, v),
+          empty = FV(VA_EMPTY, v);
+      k = U(k); pos = U(pos); krl = U(krl); cap = U(cap); full = U(full); empty = U(empty);
       const int Lr = T.v_route_len[v], rb = T.v_route_base[v], RL = Lr + 1;
-      const int pos = U(V_POS(v)), krl = U(V_KRL(v));
       const int p = T.route_port[rb + pos];
       int ns;
       uint32_t st_k, st_k1;
-      if (a_idx < 4) {  // prefetched at the top of the tick by lane a_idx
+      if (a_idx < 4) {  // prefetched by lane a_idx (tick_prefetch)
         ns = wave::shfl(pf.ns, a_idx);
         st_k = (uint32_t)wave::shfl((int)pf.stk, a_idx);
         st_k1 = (uint32_t)wave::shfl((int)pf.stk1, a_idx);
@@ -767,53 +789,61 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, const Tick
         st_k = K.stops[srow + k];
         st_k1 = K.stops[srow + (k + 1 < K.SMAX ? k + 1 : k)];
       }
-      FV(VA_LAST_LOC_IDX, v) = k;
-      FV(VA_IS_PARKING, v) = 1;
-      FV(VA_LOC_PORT_IDX, v) = p;
-      V_ARR(v) = t;
-      write_future_and_plans(K, L, v, pos, t);
-      // load full
-      const int cap = U(FV(VA_CAPACITY, v));
-      int full = U(FV(VA_FULL, v));
-      int acceptable = (int)floor((double)(cap - full * K.vol) / (double)K.vol);
-      int loaded_total = 0;
-      int x = pos, row = krl;  // x: route position of stop kd; row: kd mod RL
+      // lane i: the i-th stop after this one — route position, port, compact matrix column, predicted tick
+      const int nlan = Lr > K.future_n ? Lr : K.future_n;
+      const bool act = lane < nlan;
+      int xi = pos + lane, xn = pos + 1 + lane;  // leg out of stop i-1, position of stop i
+      xi %= Lr; xn %= Lr;
+      const int leg = act ? T.leg_time[T.leg_off[v] + xi] : 0;
+      const int tick_i = t + wave::scan_incl_add(leg);  // vessel_future_stops_prediction.py:49-85
+      const int port_i = T.route_port[rb + xn], c_i = T.route_cidx[rb + xn];
+      bool dup_later = false, dup_earlier = false;  // the route may visit a port twice
       for (int j = 0; j < Lr; j++) {
-        const int kd = k + 1 + j;
-        if (kd >= ns) break;  // python slice truncation (vessel_reachable_stops_wrapper.py:27)
-        x = (x + 1 == Lr) ? 0 : x + 1;
-        row = (row + 1 == RL) ? 0 : row + 1;
-        const int dst = T.route_port[rb + x];
-        const int pend = U(FOP(p, dst));
-        if (acceptable > 0 && pend > 0) {
-          const int l = pend < acceptable ? pend : acceptable;
-          FOP(p, dst) = pend - l;
-          const int dc = T.route_cidx[rb + x];
-          const int fv = U(FOVC(v, dc));
-          FOVC(v, dc) = fv + l;
-          loaded_total += l;
-          acceptable -= l;
-          if (lane == 0) g_rec[T.rec_off[v] + row * RL + krl] = l;  // cell is empty: (dst stop, load stop) pairs are unique
-        }
+        const int cj = wave::shfl(c_i, j);
+        dup_later = dup_later || (j > lane && cj == c_i);
+        dup_earlier = dup_earlier || (j < lane && cj == c_i);
+      }
+      if (lane < K.future_n) { FV_FUT(lane, v) = port_i; FV_FUTT(lane, v) = tick_i; }
+      if (lane < Lr && !dup_later) PLANC(v, c_i) = tick_i;  // vessel_sailing_plan_wrapper.py:24-28 (later stops overwrite)
+      // load full (:551-587): the sequential hand-out of `acceptable` over the next Lr stops is a clamped prefix sum;
+      // a second visit of the same port within the window gets nothing (first visit took all, or space ran out)
+      const int acceptable = (int)floor((double)(cap - full * K.vol) / (double)K.vol);
+      const bool lv = lane < Lr && (k + 1 + lane) < ns && !dup_earlier;  // python slice truncation at the end of the stop list
+      const int pend = lv ? FOP(p, port_i) : 0;
+      const int incl = wave::scan_incl_add(pend);
+      int l = 0;
+      if (acceptable > 0 && pend > 0) { const int room = acceptable - (incl - pend); l = room <= 0 ? 0 : (pend < room ? pend : room); }
+      const int loaded_total = wave::shfl(incl < acceptable ? incl : (acceptable > 0 ? acceptable : 0), 63);
+      if (l > 0) {
+        FOP(p, port_i) = pend - l;
+        FOVC(v, c_i) += l;
+        int row = krl + 1 + lane;  // (k + 1 + lane) mod RL
+        if (row >= RL) row -= RL;
+        g_rec[T.rec_off[v] + row * RL + krl] = l;  // cell is empty: (dst stop, load stop) pairs are unique
       }
       full += loaded_total;
-      int empty = U(FV(VA_EMPTY, v));
       int early = 0;
       if ((long long)(full + empty) * K.vol > (long long)cap) {
         early = (full + empty) - (int)ceil((double)cap / (double)K.vol);
         empty -= early;
       }
-      const int pf = U(FP(PA_FULL, p)), pe = U(FP(PA_EMPTY, p));
-      FP(PA_FULL, p) = pf - loaded_total;
-      FP(PA_EMPTY, p) = pe + early;
-      FV(VA_FULL, v) = full;
-      FV(VA_EMPTY, v) = empty;
-      FV(VA_EARLY_DISCHARGE, v) = early;
-      FV(VA_REMAINING_SPACE, v) = T.v_total_space[v] - full - empty;  // vessel.py:113-120
-      V_EVT(v) = t + stop_parking(st_k);
-      V_NEXT(v) = k + 1 < ns ? stop_arrival(st_k1) : 0x7fffffff;
+      wave::sync();
+      if (lane == 0) {
+        FV(VA_LAST_LOC_IDX, v) = k;
+        FV(VA_IS_PARKING, v) = 1;
+        FV(VA_LOC_PORT_IDX, v) = p;
+        V_ARR(v) = t;
+        FP(PA_FULL, p) -= loaded_total;
+        FP(PA_EMPTY, p) += early;
+        FV(VA_FULL, v) = full;
+        FV(VA_EMPTY, v) = empty;
+        FV(VA_EARLY_DISCHARGE, v) = early;
+        FV(VA_REMAINING_SPACE, v) = T.v_total_space[v] - full - empty;  // vessel.py:113-120
+        V_EVT(v) = t + stop_parking(st_k);
+        V_NEXT(v) = k + 1 < ns ? stop_arrival(st_k1) : 0x7fffffff;
+      }
+      wave::sync();
     }
-    wave::sync();
   }
   prof.mark(PF_ARRIVALS);
   return arr_mask;

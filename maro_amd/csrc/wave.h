@@ -52,6 +52,9 @@ MRX_DEV void lds_dma_wait() {
   sync();
 }
 
+// fire-and-forget LDS add (ds_add_u32): concurrent lanes may target the same word
+MRX_DEV void lds_add(int32_t* p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 // inclusive prefix sum over the lanes (lane i gets v_0 + ... + v_i)
 MRX_DEV int scan_incl_add(int v) {
   const int l = lane();

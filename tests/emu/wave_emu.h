@@ -125,6 +125,8 @@ inline long long reduce_add(long long v) {
   return s;
 }
 
+inline void lds_add(int32_t* p, int v) { *p += v; }
+
 inline int scan_incl_add(int v) {
   rendezvous(7, v);
   EmuWave* w = cur_wave();
