@@ -410,6 +410,15 @@ struct TickPf {
 
 // All prefetch loads are branch-free (addresses clamped to valid memory, validity re-derived at the point of
 // use), so the compiler has no control-flow merge that would force an early s_waitcnt.
+// consume every prefetched register in one straight-line place (see wave::touch)
+MRX_DEV void tick_prefetch_land(TickPf& pf) {
+#pragma unroll
+  for (int b = 0; b < 3; b++) { wave::touch(pf.tb[b]); wave::touch(pf.tn[b]); wave::touch(pf.src[b]); }
+#pragma unroll
+  for (int a = 0; a < 4; a++) { wave::touch(pf.q[a]); wave::touch(pf.key[a]); }
+  wave::touch(pf.ns); wave::touch(pf.otg); wave::touch(pf.stk); wave::touch(pf.stk1);
+}
+
 MRX_DEV void tick_prefetch_static(const CimParams& K, TickPf& pf) {
   const int lane = wave::lane();
   const int last = K.NT > 0 ? K.NT - 1 : 0;
@@ -421,17 +430,15 @@ MRX_DEV void tick_prefetch_static(const CimParams& K, TickPf& pf) {
   }
 }
 
-MRX_DEV void tick_prefetch(const CimParams& K, int env, Lds& L, int t, TickPf& pf) {
+// stop-table entries and discharge records of the first (up to) four vessels of `mask`
+MRX_DEV void tick_prefetch_arrivals(const CimParams& K, int env, Lds& L, uint64_t mask, TickPf& pf) {
   const int lane = wave::lane();
   const int V = K.V;
   const Tabs& T = L.tab;
-  pf.otg = K.order_prop[(size_t)env * K.T + t];
-  const bool arr = lane < V && !FV(VA_IS_PARKING, lane) && FV(VA_NEXT_LOC_IDX, lane) > 0 && V_EVT(lane) == t;
-  pf.arr_mask = wave::ballot(arr);
   const int32_t* g_rec = K.rec + (size_t)env * K.REC_W;
   // lane a (< 4) fetches the stop-table entries of the a-th arriving vessel
   {
-    uint64_t m = pf.arr_mask;
+    uint64_t m = mask;
     int v = 0;
     for (int a = 0; a < 4; a++) {
       const int va = m ? __builtin_ctzll(m) : 0;
@@ -444,8 +451,8 @@ MRX_DEV void tick_prefetch(const CimParams& K, int env, Lds& L, int t, TickPf& p
     pf.stk = K.stops[srow + (k < K.SMAX ? k : 0)];
     pf.stk1 = K.stops[srow + (k + 1 < K.SMAX ? k + 1 : 0)];
   }
-  // lane j fetches the j-th candidate discharge record (and its load tick) of each of the first 4 vessels
-  uint64_t m = pf.arr_mask;
+  // lane j fetches the j-th candidate discharge record (and its load tick) of each of those vessels
+  uint64_t m = mask;
 #pragma unroll
   for (int a = 0; a < 4; a++) {
     const int v = m ? __builtin_ctzll(m) : 0;  // wave-uniform; vessel 0 is a harmless stand-in when fewer arrive
@@ -461,9 +468,17 @@ MRX_DEV void tick_prefetch(const CimParams& K, int env, Lds& L, int t, TickPf& p
   }
 }
 
+MRX_DEV void tick_prefetch(const CimParams& K, int env, Lds& L, int t, TickPf& pf) {
+  const int lane = wave::lane();
+  pf.otg = K.order_prop[(size_t)env * K.T + t];
+  const bool arr = lane < K.V && !FV(VA_IS_PARKING, lane) && FV(VA_NEXT_LOC_IDX, lane) > 0 && V_EVT(lane) == t;
+  pf.arr_mask = wave::ballot(arr);
+  tick_prefetch_arrivals(K, env, L, pf.arr_mask, pf);
+}
+
 // ==========================================================================================
 // One tick, phases A..B4.  Returns the mask of vessels that arrived (their decisions follow).
-MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, const TickPf& pf, int& idx_ord, int& idx_buf, int& status, Prof& prof) {
+MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf, int& idx_ord, int& idx_buf, int& status, Prof& prof) {
   const int lane = wave::lane();
   const int P = K.P, V = K.V, NT = K.NT, H = K.H;
   const Tabs& T = L.tab;
@@ -625,7 +640,13 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, const Tick
     // (tick of the load, vessel index) — SURVEY.md §9.2.  Records: rec[v][dst_stop % RL][load_stop % RL].
     int32_t* ent = L.misc;  // (key, v, q) triples
     int n_ent = 0, n_ves = 0;
-    for (uint64_t m = arr_mask; m; m &= m - 1) {  // wave-uniform
+    int slot4 = 0;
+    for (uint64_t m = arr_mask; m; m &= m - 1, slot4++) {  // wave-uniform
+      if (slot4 == 4) {  // more than four arrivals in one tick (rare): fetch the next four now
+        tick_prefetch_arrivals(K, env, L, m, pf);
+        tick_prefetch_land(pf);
+        slot4 = 0;
+      }
       const int v = __builtin_ctzll(m);
       const int k = U(FV(VA_NEXT_LOC_IDX, v));
       const int Lr = T.v_route_len[v], RL = Lr + 1;
@@ -635,14 +656,9 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, const Tick
       int col = krl + 1 + lane;  // (k - Lr + lane) mod RL
       if (col >= RL) col -= RL;
       int32_t* cell = g_rec + T.rec_off[v] + krl * RL + (lane < Lr ? col : 0);
-      if (n_ves < 4) {  // prefetched one round trip earlier (tick_prefetch)
-        if (lane < Lr && sidx >= 0) {
-          q = n_ves == 0 ? pf.q[0] : n_ves == 1 ? pf.q[1] : n_ves == 2 ? pf.q[2] : pf.q[3];
-          key = stop_arrival((uint32_t)(n_ves == 0 ? pf.key[0] : n_ves == 1 ? pf.key[1] : n_ves == 2 ? pf.key[2] : pf.key[3]));
-        }
-      } else if (lane < Lr && sidx >= 0) {
-        q = *cell;
-        key = stop_arrival(K.stops[((size_t)env * V + v) * K.SMAX + sidx]);
+      if (lane < Lr && sidx >= 0) {  // prefetched (tick_prefetch_arrivals)
+        q = slot4 == 0 ? pf.q[0] : slot4 == 1 ? pf.q[1] : slot4 == 2 ? pf.q[2] : pf.q[3];
+        key = stop_arrival((uint32_t)(slot4 == 0 ? pf.key[0] : slot4 == 1 ? pf.key[1] : slot4 == 2 ? pf.key[2] : pf.key[3]));
       }
       const bool has = q > 0;
       const uint64_t hm = wave::ballot(has);
@@ -770,25 +786,26 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, const Tick
   // ---------------- B4. arrivals + full loading, in vessel order (:600-632, :524-598); lane i = i-th next stop
   if (arr_mask) {
     int a_idx = 0;
+    if (__builtin_popcountll(arr_mask) > 4) {  // the discharge pass re-used the prefetch registers: fetch group 0 again
+      tick_prefetch_arrivals(K, env, L, arr_mask, pf);
+      tick_prefetch_land(pf);
+    }
     for (uint64_t m = arr_mask; m; m &= m - 1, a_idx++) {  // wave-uniform over the arriving vessels
+      if (a_idx == 4) {
+        tick_prefetch_arrivals(K, env, L, m, pf);
+        tick_prefetch_land(pf);
+        a_idx = 0;
+      }
       const int v = __builtin_ctzll(m);
       int k = FV(VA_NEXT_LOC_IDX, v), pos = V_POS(v), krl = V_KRL(v), cap = FV(VA_CAPACITY, v), full = FV(VA_FULL, v),
           empty = FV(VA_EMPTY, v);
       k = U(k); pos = U(pos); krl = U(krl); cap = U(cap); full = U(full); empty = U(empty);
       const int Lr = T.v_route_len[v], rb = T.v_route_base[v], RL = Lr + 1;
       const int p = T.route_port[rb + pos];
-      int ns;
-      uint32_t st_k, st_k1;
-      if (a_idx < 4) {  // prefetched by lane a_idx (tick_prefetch)
-        ns = wave::shfl(pf.ns, a_idx);
-        st_k = (uint32_t)wave::shfl((int)pf.stk, a_idx);
-        st_k1 = (uint32_t)wave::shfl((int)pf.stk1, a_idx);
-      } else {
-        const size_t srow = ((size_t)env * V + v) * K.SMAX;
-        ns = K.nstops[(size_t)env * V + v];
-        st_k = K.stops[srow + k];
-        st_k1 = K.stops[srow + (k + 1 < K.SMAX ? k + 1 : k)];
-      }
+      const int ns = wave::shfl(pf.ns, a_idx);  // prefetched by lane a_idx (tick_prefetch_arrivals)
+      const uint32_t st_k = (uint32_t)wave::shfl((int)pf.stk, a_idx);
+      const uint32_t st_k1 = (uint32_t)wave::shfl((int)pf.stk1, a_idx);
+      prof.mark(10);
       // lane i: the i-th stop after this one — route position, port, compact matrix column, predicted tick
       const int nlan = Lr > K.future_n ? Lr : K.future_n;
       const bool act = lane < nlan;
@@ -805,6 +822,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, const Tick
       }
       if (lane < K.future_n) { FV_FUT(lane, v) = port_i; FV_FUTT(lane, v) = tick_i; }
       if (lane < Lr && !dup_later) PLANC(v, c_i) = tick_i;  // vessel_sailing_plan_wrapper.py:24-28 (later stops overwrite)
+      prof.mark(11);
       // load full (:551-587): the sequential hand-out of `acceptable` over the next Lr stops is a clamped prefix sum;
       // a second visit of the same port within the window gets nothing (first visit took all, or space ran out)
       const int acceptable = (int)floor((double)(cap - full * K.vol) / (double)K.vol);
@@ -904,7 +922,7 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   // A tick will run in this step iff no other vessel of the current tick is still waiting for its decision.
   // Its inputs (RNG states by LDS-DMA, order count, arrival records, noise tables) are requested NOW, so that
   // second memory round trip overlaps with the action handling and post_step below.
-  TickPf pf;
+  TickPf pf = {};
   {
     const uint64_t pend_after = fresh ? 0ull : (pend & ~(1ull << (L.priv[PH_CUR_VESSEL] & 63)));
     const int tn = fresh ? t : t + 1;
@@ -956,6 +974,7 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
       dec_v = __builtin_ctzll(pend);
       break;
     }
+    tick_prefetch_land(pf);  // before the snapshot stores below, so that nothing later waits behind them
     if (!fresh) {
       // C. post_step (business_engine.py:201-224)
       if ((t + 1) % K.resolution == 0) {

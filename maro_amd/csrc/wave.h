@@ -18,9 +18,11 @@ MRX_DEV int lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn
 // subsequent reads (s_waitcnt lgkmcnt(0)) and stops the compiler from moving LDS accesses
 // across it.  A one-wave workgroup needs no s_barrier.
 MRX_DEV void sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  // LDS only: wait for this wave's outstanding LDS operations and stop the compiler from moving memory accesses
+  // across this point.  Deliberately NOT a workgroup-scope fence: that would also drain vmcnt, i.e. stall on every
+  // in-flight global load/store (prefetches, fire-and-forget stores) at each of the many syncs per tick.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 MRX_DEV uint64_t ballot(bool pred) { return __ballot(pred); }
@@ -65,6 +67,13 @@ MRX_DEV int scan_incl_add(int v) {
   }
   return v;
 }
+
+// "Use" a prefetched value here: forces the compiler's s_waitcnt for its load to this (straight-line) point, so
+// that no conservative vmcnt(0) — which would also wait for every store issued since — is needed at later uses
+// inside loops.
+MRX_DEV void touch(int& x) { asm volatile("" : "+v"(x)); }
+MRX_DEV void touch(uint32_t& x) { asm volatile("" : "+v"(x)); }
+MRX_DEV void touch(double& x) { asm volatile("" : "+v"(x)); }
 
 // make a wave-uniform value provably uniform (scalar register)
 MRX_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

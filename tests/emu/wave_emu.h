@@ -126,6 +126,9 @@ inline long long reduce_add(long long v) {
 }
 
 inline void lds_add(int32_t* p, int v) { *p += v; }
+inline void touch(int&) {}
+inline void touch(uint32_t&) {}
+inline void touch(double&) {}
 
 inline int scan_incl_add(int v) {
   rendezvous(7, v);

@@ -9,7 +9,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 PHASES = ["load", "action", "post_step+snapshot", "mt_load", "A order_gen", "B1/B2 depart+returns", "B3 orders",
-          "B4 arrivals", "output+predecision snapshot", "store"]
+          "B4 arrivals (load+commit)", "output+predecision snapshot", "store", "B4.a per-vessel reads", "B4.b positions/plans"]
 
 
 def main():
@@ -41,10 +41,10 @@ def main():
         eng.step(actions, nact)
     torch.cuda.synchronize()
     lib.mrx_prof_read(buf, 0)
-    tot = sum(buf[:10])
+    tot = sum(buf[:12])
     waves = n * args.steps
     print(f"{args.topology}: {waves} env-steps, {eng.ticks.sum().item() - t0} ticks; mean {tot / waves:.0f} cycles per env-step")
-    for name, c in zip(PHASES, buf[:10]):
+    for name, c in zip(PHASES, buf[:12]):
         print(f"  {name:32s} {c / waves:10.0f} cyc/env-step  {100 * c / tot:5.1f} %")
 
 
