@@ -163,6 +163,14 @@ def main():
         b_step = (3.0 + tbar) * F + 4.0 * topo.n_targets * tbar + 40.0
         bytes_per_launch = b_step * n
         achieved = bytes_per_launch / (step_kernel_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the committed PMC passes of this same workload (profiles/)
+        try:
+            with open(os.path.join(REPO, "profiles", "latest_pmc.json")) as fp:
+                pmc = json.load(fp)
+            if pmc["topology"] == args.topology and pmc["envs_per_launch"] == n:
+                traffic = (2.0 * pmc["fetch_size_kib"] + pmc["write_size_kib"]) * 1024.0
+        except Exception:
+            pass
         out = {
             "metric": "env-steps/sec (decision events/sec), CIM global_trade.22p",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -173,7 +181,8 @@ def main():
                        "envs_per_gpu": n, "ring_slots": args.ring, "parallelism": f"env-shard x{world} (no data-path collective)",
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
             "roofline": {"bound": "hbm", "kernel": "mrx_k_cim_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": step_kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": "profiles/latest_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": step_kernel_ms,
                          "algorithmic_bytes_per_env_step": b_step, "env_steps_per_launch": n},
         }
         if world == 1 and not args.no_cpu:
