@@ -1,0 +1,65 @@
+"""Sharded rollouts: independent env batches per GPU, trajectories gathered to the learner rank.
+
+Envs never interact (separate ``Env`` objects / processes in the reference: vector_env/env_process.py:32), so the
+env index range is split contiguously across ranks — one process per GPU, its own engine and stream — and the
+data path needs NO collective.  The only exchange is the per-rollout gather of trajectory tensors to the
+learner (``torch.distributed.gather``: RCCL over xGMI on GPUs, gloo in the CPU tests).  This replaces the
+reference's process-per-env ``VectorEnv`` + ``multiprocessing.Pipe`` pickling (vector_env.py:186-217) and the
+zmq fan-out of ``BatchEnvSampler`` (rl/rollout/batch_env_sampler.py:53-97).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+
+def shard_range(total_envs: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) slice of the global env index range owned by `rank` (sizes differ by at most 1)."""
+    base, rem = divmod(total_envs, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def rollout(engine, n_steps: int, policy: Callable[[int, torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor]],
+            first_step: bool = True) -> Dict[str, torch.Tensor]:
+    """Run `n_steps` batched env-steps.  `policy(step, decisions, done) -> (actions [n,A,4], n_actions [n])` works on
+    device tensors.  Returns the trajectory: decisions [T,n,8], actions [T,n,A,4], metrics [T,n,3], done [T,n]."""
+    dec, met, done = engine.step() if first_step else (engine.decisions, engine.metrics, engine.done)
+    D, A, M, Dn = [], [], [], []
+    for t in range(n_steps):
+        actions, n_actions = policy(t, dec, done)
+        D.append(dec.clone())
+        A.append(actions.clone())
+        dec, met, done = engine.step(actions, n_actions, mask=(done == 0).to(torch.uint8))
+        M.append(met.clone())
+        Dn.append(done.clone())
+    return {"decisions": torch.stack(D), "actions": torch.stack(A), "metrics": torch.stack(M), "done": torch.stack(Dn)}
+
+
+def gather_to_learner(traj: Dict[str, torch.Tensor], dst: int = 0, group=None) -> Optional[Dict[str, torch.Tensor]]:
+    """Concatenate every rank's trajectory along the env axis (dim 1) on rank `dst`.  Shards may differ in size by
+    one env, so sizes are exchanged first and the payload is padded to the largest shard."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return traj
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    any_t = next(iter(traj.values()))
+    n_local = torch.tensor([any_t.shape[1]], dtype=torch.int64, device=any_t.device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    n_max = max(sizes)
+    out = {} if rank == dst else None
+    for key in sorted(traj):
+        t = traj[key]
+        pad_shape = list(t.shape)
+        pad_shape[1] = n_max
+        buf = torch.zeros(pad_shape, dtype=t.dtype, device=t.device)
+        buf[:, :t.shape[1]] = t
+        recv = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, recv, dst=dst, group=group)
+        if rank == dst:
+            out[key] = torch.cat([r[:, :sizes[i]] for i, r in enumerate(recv)], dim=1)
+    return out
