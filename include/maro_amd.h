@@ -124,7 +124,7 @@ typedef struct mrx_cim_layout {
   /* within one frame (word offsets): ports are [attr][port], vessels [attr][slot][vessel] */
   int32_t frame_off_ports;    /* 12 attrs x P */
   int32_t frame_off_vessels;  /* 24 words x V */
-  int32_t frame_off_full_on_ports;   /* P*P, row = src, col = dst */
+  int32_t frame_off_full_on_ports;   /* compact: one cell per (src, dst) order pair (target_offset CSR order) */
   int32_t frame_off_full_on_vessels; /* compact: one cell per (vessel, distinct port of its route); all other */
   int32_t frame_off_vessel_plans;    /* cells of the dense V*P matrices are constant (0 / -1); mrx_cim_query expands */
   /* byte offsets of the big arrays inside the workspace */

@@ -7,6 +7,7 @@
 // beyond the tiny read-only topology tables that every L2 caches.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -209,7 +210,8 @@ int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_acti
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
   const CimParams& K = h->plan.kp;
-  hipLaunchKernelGGL(mrx_k_cim_step, dim3(K.n_envs), dim3(64), (size_t)K.lds_words * 4, (hipStream_t)stream, K, d_actions,
+  static const size_t lds_pad = getenv("MRX_DEBUG_LDS_PAD_BYTES") ? (size_t)atoi(getenv("MRX_DEBUG_LDS_PAD_BYTES")) : 0;  // occupancy experiments
+  hipLaunchKernelGGL(mrx_k_cim_step, dim3(K.n_envs), dim3(64), (size_t)K.lds_words * 4 + lds_pad, (hipStream_t)stream, K, d_actions,
                      d_n_actions, d_env_mask, d_decisions, (long long*)d_metrics, d_done);
   HIP_TRY(hipGetLastError());
   return MRX_OK;

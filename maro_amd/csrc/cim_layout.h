@@ -33,8 +33,8 @@ struct Arena {
   int64_t take(int64_t bytes) { int64_t o = align_up(top, 256); top = o + bytes; return o; }
 };
 template <class T>
-inline int64_t blob_put(std::vector<uint8_t>& blob, const T* src, size_t n) {
-  size_t off = (blob.size() + 63) / 64 * 64;
+inline int64_t blob_put(std::vector<uint8_t>& blob, const T* src, size_t n, size_t align = 64) {
+  size_t off = (blob.size() + align - 1) / align * align;
   blob.resize(off + sizeof(T) * (n ? n : 1), 0);
   if (n) memcpy(blob.data() + off, src, sizeof(T) * n);
   return (int64_t)off;
@@ -82,7 +82,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   int total_frames = (int)ceil((double)c->durations / (double)c->snapshot_resolution);
   k.S = c->max_snapshots > 0 ? c->max_snapshots : total_frames;
   // frame layout
-  k.f_ports = 0; k.f_vessels = PA_COUNT * P; k.f_fop = k.f_vessels + k.vrows * V; k.f_fov = k.f_fop + P * P;
+  k.f_ports = 0; k.f_vessels = PA_COUNT * P; k.f_fop = k.f_vessels + k.vrows * V; k.f_fov = k.f_fop + NT;  // full_on_ports is stored per (src, dst) order pair: every other cell of the P x P matrix is always 0
   // compact full_on_vessels / vessel_plans: one cell per (vessel, distinct port on its route)
   std::vector<int32_t> v_cbase(V), route_cidx(NRP ? NRP : 1), cidx_dense((size_t)V * P, -1);
   {
@@ -179,9 +179,9 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   k.l_mt1 = w; w += MT_WORDS;
   w = (w + 1) / 2 * 2;
   k.l_dsrc = w; w += 2 * ((P + 1) / 2 * 2);
-  k.l_dtgt = w; w += (2 * (NT + 1) > 3 * 128 ? 2 * (NT + 1) : 3 * 128);  // also the discharge-record merge list (l_misc)
-  k.l_oq = w; w += NT + 1;
-  k.l_odelay = w; w += NT + 1;
+  { const int dw = 2 * (NT + 1) > 3 * 64 ? 2 * (NT + 1) : 3 * 64; k.l_dtgt = w; w += dw; k.misc_cap = dw / 3; }  // also the discharge-record merge list (l_misc)
+  k.l_oq = w; w += NT + 1;  // order quantity | (buffer ticks + 1) << 24
+  k.l_odelay = k.l_oq;
   k.l_srcn = w; w += P;
   w = (w + 1) / 2 * 2;
   k.l_misc = k.l_dtgt;  // (key, v, q) x up to 128, live only in phase B2 when dtgt is dead
@@ -195,35 +195,46 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   // per-port fp64 tables and the int tables that are read inside serial (wave-uniform) loops.
   std::vector<std::pair<size_t, int64_t>>& binds = pl->binds;
   binds.clear();
+  size_t align = 64;  // tables outside the LDS-staged block are padded to cache-line-ish boundaries, inside it packed
   auto put_d = [&](const double* CimParams::*f, const double* src, size_t n) {
-    binds.push_back({(size_t)((char*)&(k.*f) - (char*)&k), blob_put(B, src, n)});
+    binds.push_back({(size_t)((char*)&(k.*f) - (char*)&k), blob_put(B, src, n, align < 8 ? 8 : align)});
   };
   auto put_i = [&](const int32_t* CimParams::*f, const int32_t* src, size_t n) {
-    binds.push_back({(size_t)((char*)&(k.*f) - (char*)&k), blob_put(B, src, n)});
+    binds.push_back({(size_t)((char*)&(k.*f) - (char*)&k), blob_put(B, src, n, align)});
   };
   put_d(&CimParams::tgt_base, t->target_base, NT); put_d(&CimParams::tgt_noise, t->target_noise, NT);
   put_d(&CimParams::v_speed, t->vessel_speed, V); put_d(&CimParams::v_speed_noise, t->vessel_speed_noise, V);
   put_d(&CimParams::v_dur, t->vessel_duration, V); put_d(&CimParams::v_dur_noise, t->vessel_duration_noise, V);
   put_d(&CimParams::route_dist, t->route_dist, NRP); put_d(&CimParams::order_dist, t->order_dist, t->period);
   const int64_t ctab_begin = (int64_t)((B.size() + 63) / 64 * 64);
+  B.resize((size_t)ctab_begin, 0);
+  align = 4;
   put_d(&CimParams::src_base, t->source_base, P); put_d(&CimParams::src_noise, t->source_noise, P);
   put_d(&CimParams::er_base, t->empty_return_base, P); put_d(&CimParams::er_noise, t->empty_return_noise, P);
   put_d(&CimParams::fr_base, t->full_return_base, P); put_d(&CimParams::fr_noise, t->full_return_noise, P);
   put_i(&CimParams::tgt_off, t->target_offset, P + 1); put_i(&CimParams::tgt_port, t->target_port, NT);
   put_i(&CimParams::route_port, t->route_port, NRP);
   put_i(&CimParams::v_route_base, v_route_base.data(), V); put_i(&CimParams::v_route_len, v_route_len.data(), V);
-  put_i(&CimParams::v_start, t->vessel_start_offset, V); put_i(&CimParams::v_total_space, v_total_space.data(), V);
   put_i(&CimParams::leg_off, leg_off.data(), V + 1); put_i(&CimParams::leg_time, leg_time.data(), leg_time.size());
-  put_i(&CimParams::er_delay, er_delay.data(), P); put_i(&CimParams::fr_delay, fr_delay.data(), P);
+  if (!k.use_buffer_rng) { put_i(&CimParams::er_delay, er_delay.data(), P); put_i(&CimParams::fr_delay, fr_delay.data(), P); }
   put_i(&CimParams::rec_off, rec_off.data(), V + 1);
   put_i(&CimParams::v_cbase, v_cbase.data(), V); put_i(&CimParams::route_cidx, route_cidx.data(), NRP);
   B.resize((B.size() + 63) / 64 * 64, 0);
   const int64_t ctab_end = (int64_t)B.size();
+  align = 64;
+  if (k.use_buffer_rng) { put_i(&CimParams::er_delay, er_delay.data(), P); put_i(&CimParams::fr_delay, fr_delay.data(), P); }
   put_i(&CimParams::v_cap, t->vessel_capacity, V); put_i(&CimParams::v_init_empty, t->vessel_init_empty, V);
   put_i(&CimParams::p_cap, t->port_capacity, P); put_i(&CimParams::p_init_empty, t->port_init_empty, P);
   put_i(&CimParams::v_period, v_period.data(), V); put_i(&CimParams::v_route, t->vessel_route, V);
   put_i(&CimParams::pair_src, pair_src.data(), NT);
+  put_i(&CimParams::v_start, t->vessel_start_offset, V); put_i(&CimParams::v_total_space, v_total_space.data(), V);
   put_i(&CimParams::cidx_dense, cidx_dense.data(), (size_t)V * P);
+  {
+    std::vector<int32_t> pair_dense((size_t)P * P, -1);
+    for (int p = 0; p < P; p++)
+      for (int j = t->target_offset[p]; j < t->target_offset[p + 1]; j++) pair_dense[(size_t)p * P + t->target_port[j]] = j;
+    put_i(&CimParams::pair_dense, pair_dense.data(), (size_t)P * P);
+  }
   pl->ctab_rel = ctab_begin;
   k.ctab_words = (int)((ctab_end - ctab_begin) / 4);
   k.l_ctab = (k.lds_words + 1) / 2 * 2;

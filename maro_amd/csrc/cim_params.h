@@ -29,6 +29,7 @@ struct CimParams {
   double sample_noise;
   // ---- frame offsets (words inside one frame)
   int f_ports, f_vessels, f_fop, f_fov, f_plans;
+  int misc_cap;  // capacity (entries) of the discharge-record merge list
   int NC;  // compact matrix cells: sum over vessels of the distinct ports on its route (full_on_vessels / vessel_plans
            // are stored [vessel][route port] — every other cell of the dense V x P matrices is constant 0 / -1)
   // ---- private-state layout (words)
@@ -43,7 +44,7 @@ struct CimParams {
       *v_speed, *v_speed_noise, *v_dur, *v_dur_noise, *route_dist, *order_dist;
   const int32_t *tgt_off, *tgt_port, *pair_src, *route_port, *v_route_base, *v_route_len, *v_start, *v_cap,
       *v_init_empty, *v_total_space, *p_cap, *p_init_empty, *leg_off, *leg_time, *v_period, *er_delay,
-      *fr_delay, *rec_off, *v_route, *v_cbase, *route_cidx, *cidx_dense;
+      *fr_delay, *rec_off, *v_route, *v_cbase, *route_cidx, *cidx_dense, *pair_dense;
   const int32_t* ctab;  // start of the contiguous block holding tgt_off .. rec_off (ctab_words words)
   // ---- per-env state (device)
   int32_t *live, *ring, *ring_fi, *priv, *rec, *status, *tick, *nstops, *order_prop, *vperiod;
