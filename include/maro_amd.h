@@ -185,7 +185,9 @@ int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_acti
 /*
  * Replaces snapshot_list[node][ticks:nodes:attrs] (frame.pyx:754-801, np_backend.pyx:520-549).
  *   node_type 0 = ports, 1 = vessels, 2 = matrices
- *   d_ticks   int32 frame indices, [nt] shared by all envs (ticks_per_env = 0) or [n_envs][nt]
+ *   d_ticks   int32 frame indices: one row [nt] shared by all envs (ticks_per_env = 0), or one row per env with a
+ *             row stride of `ticks_per_env` int32 elements (= nt for a dense [n_envs][nt] array; 8 with d_ticks =
+ *             d_decisions + 6 slices "the frame of my pending decision" straight out of mrx_cim_step's output)
  *   d_nodes   int32 [nn] node indices (device);  attrs int32 [na<=16] attribute ids (HOST array,
  *             mrx_cim_attr_id; copied into the kernel arguments)
  *   d_out     float64 [n_envs][nt][nn][sum(slots)] — flat order tick -> node -> attr -> slot,

@@ -146,9 +146,15 @@ class CimBatchEngine:
     def query(self, node: str, ticks, nodes, attrs: Sequence[str], out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """float64 [n_envs, nt, nn, sum(slots)]; `ticks` are frame indices, [nt] or [n_envs, nt]."""
         ids = self.attr_ids(node, attrs)
-        t = self._dev(ticks, torch.int32)
+        if isinstance(ticks, torch.Tensor) and ticks.dim() == 2 and ticks.dtype == torch.int32 and ticks.is_cuda \
+                and ticks.stride(1) == 1:
+            t = ticks                      # strided per-env rows (e.g. decisions[:, 6:7]) are passed through without a copy
+        else:
+            t = self._dev(ticks, torch.int32)
         n = self._dev(nodes, torch.int32)
-        per_env = 1 if t.dim() == 2 else 0
+        per_env = int(t.stride(0)) if t.dim() == 2 else 0
+        if t.dim() == 2 and per_env == 0:
+            t, per_env = t.contiguous(), int(t.shape[1])
         nt, nn = int(t.shape[-1]), int(n.numel())
         slots = self.row_slots(node, ids)
         if out is None:

@@ -58,12 +58,13 @@ extern "C" __global__ void __launch_bounds__(256)
 mrx_k_cim_query(CimParams K, int node_type, const int32_t* __restrict__ ticks, int nt, int ticks_per_env,
                 const int32_t* __restrict__ nodes, int nn, AttrList al, int row_slots, long long total,
                 double* __restrict__ out) {
-  const int32_t* attrs = al.id;
-  const int na = al.n;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long row = i / row_slots;
-    const int col = (int)(i - row * row_slots);
-    out[i] = cim::query_elem(K, node_type, ticks, nt, ticks_per_env, nodes, nn, attrs, na, row, col);
+  // one workgroup per (env, tick) row group: the frame lookup (ring slot / aliased live frame / missing) is resolved
+  // once, then the threads stream the nn x row_slots elements
+  const long long rt = blockIdx.x;  // env * nt + ti
+  const int per_row = nn * row_slots;
+  for (int j = threadIdx.x; j < per_row; j += blockDim.x) {
+    const int ni = j / row_slots;
+    out[rt * per_row + j] = cim::query_elem(K, node_type, ticks, nt, ticks_per_env, nodes, nn, al.id, al.n, rt * nn + ni, j - ni * row_slots);
   }
 }
 
@@ -279,12 +280,11 @@ int mrx_cim_query(mrx_handle h, int node_type, const int32_t* d_ticks, int nt, i
   }
   const long long total = (long long)K.n_envs * nt * nn * row_slots;
   if (total == 0) return MRX_OK;
-  long long blocks = (total + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
+  const long long blocks = (long long)K.n_envs * nt;
   AttrList al;
   al.n = na;
   for (int i = 0; i < 16; i++) al.id[i] = i < na ? attrs[i] : 0;
-  hipLaunchKernelGGL(mrx_k_cim_query, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, K, node_type, d_ticks, nt,
+  hipLaunchKernelGGL(mrx_k_cim_query, dim3((unsigned)blocks), dim3(nn * row_slots >= 192 ? 256 : (nn * row_slots >= 96 ? 128 : 64)), 0, (hipStream_t)stream, K, node_type, d_ticks, nt,
                      ticks_per_env, d_nodes, nn, al, row_slots, total, d_out);
   HIP_TRY(hipGetLastError());
   return MRX_OK;

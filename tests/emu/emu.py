@@ -109,8 +109,8 @@ class EmuBackend:
 
     def query(self, node_type, ticks, nodes, attrs, row_slots):
         t = np.ascontiguousarray(ticks, np.int32)
-        per_env = 1 if t.ndim == 2 else 0
         nt = t.shape[-1]
+        per_env = nt if t.ndim == 2 else 0
         n = np.ascontiguousarray(nodes, np.int32)
         a = np.ascontiguousarray(attrs, np.int32)
         out = np.zeros((self.n_envs, nt, len(n), row_slots), np.float64)
