@@ -188,13 +188,14 @@ int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_acti
  *   d_ticks   int32 frame indices: one row [nt] shared by all envs (ticks_per_env = 0), or one row per env with a
  *             row stride of `ticks_per_env` int32 elements (= nt for a dense [n_envs][nt] array; 8 with d_ticks =
  *             d_decisions + 6 slices "the frame of my pending decision" straight out of mrx_cim_step's output)
- *   d_nodes   int32 [nn] node indices (device);  attrs int32 [na<=16] attribute ids (HOST array,
+ *   d_nodes   int32 node indices (device): one row [nn] shared by all envs (nodes_per_env = 0) or one row per env
+ *             with a row stride of `nodes_per_env` elements;  attrs int32 [na<=16] attribute ids (HOST array,
  *             mrx_cim_attr_id; copied into the kernel arguments)
  *   d_out     float64 [n_envs][nt][nn][sum(slots)] — flat order tick -> node -> attr -> slot,
  *             zeros for frame indices not held by the ring (np_backend.pyx:541-545).
  */
 int mrx_cim_query(mrx_handle h, int node_type, const int32_t* d_ticks, int nt, int ticks_per_env,
-                  const int32_t* d_nodes, int nn, const int32_t* attrs, int na, double* d_out,
+                  const int32_t* d_nodes, int nn, int nodes_per_env, const int32_t* attrs, int na, double* d_out,
                   void* stream);
 
 /*

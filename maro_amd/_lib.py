@@ -68,7 +68,7 @@ def load() -> ctypes.CDLL:
     L.mrx_cim_step.restype = i32
     L.mrx_cim_step.argtypes = [vp] * 8
     L.mrx_cim_query.restype = i32
-    L.mrx_cim_query.argtypes = [vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, vp]
+    L.mrx_cim_query.argtypes = [vp, i32, vp, i32, i32, vp, i32, i32, vp, i32, vp, vp]
     L.mrx_cim_random_policy.restype = i32
     L.mrx_cim_random_policy.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     L.mrx_cim_attr_id.restype = i32

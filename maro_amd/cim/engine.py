@@ -144,23 +144,31 @@ class CimBatchEngine:
         return sum(self._L.mrx_cim_attr_slots(self._h, NODE_TYPE[node], int(a)) for a in attr_ids)
 
     def query(self, node: str, ticks, nodes, attrs: Sequence[str], out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """float64 [n_envs, nt, nn, sum(slots)]; `ticks` are frame indices, [nt] or [n_envs, nt]."""
+        """float64 [n_envs, nt, nn, sum(slots)]; `ticks` are frame indices, [nt] or [n_envs, nt]; `nodes` [nn] or
+        per-env [n_envs, nn] (out-of-range node indices, e.g. the -1 padding of stop lists, give zeros)."""
         ids = self.attr_ids(node, attrs)
         if isinstance(ticks, torch.Tensor) and ticks.dim() == 2 and ticks.dtype == torch.int32 and ticks.is_cuda \
                 and ticks.stride(1) == 1:
             t = ticks                      # strided per-env rows (e.g. decisions[:, 6:7]) are passed through without a copy
         else:
             t = self._dev(ticks, torch.int32)
-        n = self._dev(nodes, torch.int32)
+        if isinstance(nodes, torch.Tensor) and nodes.dim() == 2 and nodes.dtype == torch.int32 and nodes.is_cuda \
+                and nodes.stride(1) == 1:
+            n = nodes
+        else:
+            n = self._dev(nodes, torch.int32)
+        nodes_per_env = int(n.stride(0)) if n.dim() == 2 else 0
+        if n.dim() == 2 and nodes_per_env == 0:
+            n, nodes_per_env = n.contiguous(), int(n.shape[1])
         per_env = int(t.stride(0)) if t.dim() == 2 else 0
         if t.dim() == 2 and per_env == 0:
             t, per_env = t.contiguous(), int(t.shape[1])
-        nt, nn = int(t.shape[-1]), int(n.numel())
+        nt, nn = int(t.shape[-1]), int(n.shape[-1])
         slots = self.row_slots(node, ids)
         if out is None:
             out = torch.empty((self.n_envs, nt, nn, slots), dtype=torch.float64, device=self.device)
         ida = (ctypes.c_int32 * len(ids))(*ids)
-        _lib.check(self._L.mrx_cim_query(self._h, NODE_TYPE[node], t.data_ptr(), nt, per_env, n.data_ptr(), nn, ida,
+        _lib.check(self._L.mrx_cim_query(self._h, NODE_TYPE[node], t.data_ptr(), nt, per_env, n.data_ptr(), nn, nodes_per_env, ida,
                                          len(ids), out.data_ptr(), self._stream()), "mrx_cim_query")
         self._keep_q = (t, n)
         return out

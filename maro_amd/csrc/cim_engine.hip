@@ -56,7 +56,7 @@ struct AttrList { int n; int32_t id[16]; };
 
 extern "C" __global__ void __launch_bounds__(256)
 mrx_k_cim_query(CimParams K, int node_type, const int32_t* __restrict__ ticks, int nt, int ticks_per_env,
-                const int32_t* __restrict__ nodes, int nn, AttrList al, int row_slots, long long total,
+                const int32_t* __restrict__ nodes, int nn, int nodes_per_env, AttrList al, int row_slots, long long total,
                 double* __restrict__ out) {
   // one workgroup per (env, tick) row group: the frame lookup (ring slot / aliased live frame / missing) is resolved
   // once, then the threads stream the nn x row_slots elements
@@ -64,7 +64,7 @@ mrx_k_cim_query(CimParams K, int node_type, const int32_t* __restrict__ ticks, i
   const int per_row = nn * row_slots;
   for (int j = threadIdx.x; j < per_row; j += blockDim.x) {
     const int ni = j / row_slots;
-    out[rt * per_row + j] = cim::query_elem(K, node_type, ticks, nt, ticks_per_env, nodes, nn, al.id, al.n, rt * nn + ni, j - ni * row_slots);
+    out[rt * per_row + j] = cim::query_elem(K, node_type, ticks, nt, ticks_per_env, nodes, nn, nodes_per_env, al.id, al.n, rt * nn + ni, j - ni * row_slots);
   }
 }
 
@@ -265,7 +265,7 @@ int mrx_cim_attr_id(int node_type, const char* name) {
 }
 
 int mrx_cim_query(mrx_handle h, int node_type, const int32_t* d_ticks, int nt, int ticks_per_env, const int32_t* d_nodes,
-                  int nn, const int32_t* attrs, int na, double* d_out, void* stream) {
+                  int nn, int nodes_per_env, const int32_t* attrs, int na, double* d_out, void* stream) {
   if (!h || !d_ticks || !d_nodes || !attrs || !d_out) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
   if (na > 16) return set_err(MRX_ERR_INVALID_ARG, "at most 16 attributes per query");
   if (nt <= 0 || nn <= 0 || na <= 0) return set_err(MRX_ERR_INVALID_ARG, "nt, nn and na must be positive");
@@ -285,7 +285,7 @@ int mrx_cim_query(mrx_handle h, int node_type, const int32_t* d_ticks, int nt, i
   al.n = na;
   for (int i = 0; i < 16; i++) al.id[i] = i < na ? attrs[i] : 0;
   hipLaunchKernelGGL(mrx_k_cim_query, dim3((unsigned)blocks), dim3(nn * row_slots >= 192 ? 256 : (nn * row_slots >= 96 ? 128 : 64)), 0, (hipStream_t)stream, K, node_type, d_ticks, nt,
-                     ticks_per_env, d_nodes, nn, al, row_slots, total, d_out);
+                     ticks_per_env, d_nodes, nn, nodes_per_env, al, row_slots, total, d_out);
   HIP_TRY(hipGetLastError());
   return MRX_OK;
 }

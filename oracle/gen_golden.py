@@ -67,6 +67,7 @@ CASES = {
 # written to a temp folder as config.yml and run through the real reference
 for _syn in ("immediate_returns", "unfixed_mode", "repeated_ports_noisy", "volume3_stops_2_5"):  # (negative_ratios trips the reference's own assert, cim_data_container.py:396)
     CASES[f"syn_{_syn}"] = (f"#{_syn}", dict(durations=90), [("run", "rand0", None)])
+CASES["toy5p_l05_sampler"] = ("toy.5p_ssddd_l0.5", dict(durations=160), [("run", "rand0", None)])  # + CIMEnvSampler state/reward
 LIGHT = {"toy4p_l00_full", "gt22p_l00_full"}  # only decisions/metrics kept (size)
 
 
@@ -140,6 +141,7 @@ def worker(maro_root, case_name, out_path):
             _, policy, max_steps = op
             rng = pyrandom.Random(0)
             decs, mets, acts = [], [], []
+            sampler_states = []
             nsteps = 0
             if not started:
                 m, de, done = env.step(None)
@@ -148,6 +150,14 @@ def worker(maro_root, case_name, out_path):
                 scope = de.action_scope
                 decs.append([de.tick, de.port_idx, de.vessel_idx, scope.load, scope.discharge, de.early_discharge,
                              env.frame_index, 1])
+                if case_name.endswith("_sampler"):  # examples/cim/rl/env_sampler.py:21-31 (look_back 7, config.py:13-18)
+                    vs, ps = env.snapshot_list["vessels"], env.snapshot_list["ports"]
+                    tk = env.tick
+                    s_ticks = [max(0, tk - rt) for rt in range(7 - 1)]
+                    fut = vs[tk:de.vessel_idx:"future_stop_list"].astype("int")
+                    sampler_states.append(np.concatenate([
+                        ps[s_ticks:[de.port_idx] + list(fut):["empty", "full", "on_shipper", "on_consignee", "booking", "shortage", "fulfillment"]],
+                        vs[tk:de.vessel_idx:["empty", "full", "remaining_space"]]]))
                 mets.append([m["order_requirements"], m["container_shortage"], m["operation_number"]])
                 if policy == "none":
                     action, enc = None, []
@@ -185,6 +195,17 @@ def worker(maro_root, case_name, out_path):
             out[f"{tag}/final_tick"] = np.array([env.tick], np.int32)
             if not light:
                 record_snapshots(tag)
+            if case_name.endswith("_sampler"):  # env_sampler.py:65-80 with config.py:24-29
+                out[f"{tag}/sampler_state"] = np.array(sampler_states, np.float64)
+                ps = env.snapshot_list["ports"]
+                decay = [0.97 ** i for i in range(99)]
+                rew = []
+                for dd in decs:
+                    tks = list(range(dd[0] + 1, dd[0] + 1 + 99))
+                    ff = ps[tks:[dd[1]]:"fulfillment"].reshape(99, -1)
+                    sh = ps[tks:[dd[1]]:"shortage"].reshape(99, -1)
+                    rew.append(np.float32(1.0 * np.dot(ff.T, decay) - 1.0 * np.dot(sh.T, decay))[0])
+                out[f"{tag}/sampler_reward"] = np.array(rew, np.float32)
     out["meta"] = np.frombuffer(json.dumps(dict(case=case_name, topology=CASES[case_name][0], kwargs=kwargs,
                                                 script=script, n_segments=seg + 1)).encode(), np.uint8)
     np.savez_compressed(out_path, **out)

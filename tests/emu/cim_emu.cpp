@@ -74,7 +74,7 @@ void emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const u
   }
 }
 
-void emu_query(void* h, int node_type, const int32_t* ticks, int nt, int per_env, const int32_t* nodes, int nn,
+void emu_query(void* h, int node_type, const int32_t* ticks, int nt, int per_env, const int32_t* nodes, int nn, int nodes_per_env,
                const int32_t* attrs, int na, double* out) {
   Emu* e = (Emu*)h;
   const CimParams& K = e->plan.kp;
@@ -83,7 +83,7 @@ void emu_query(void* h, int node_type, const int32_t* ticks, int nt, int per_env
   long long rows = (long long)K.n_envs * nt * nn;
   for (long long r = 0; r < rows; r++)
     for (int c = 0; c < row_slots; c++)
-      out[r * row_slots + c] = cim::query_elem(K, node_type, ticks, nt, per_env, nodes, nn, attrs, na, r, c);
+      out[r * row_slots + c] = cim::query_elem(K, node_type, ticks, nt, per_env, nodes, nn, nodes_per_env, attrs, na, r, c);
 }
 
 long emu_rounds(void* h) { return ((Emu*)h)->wave.rounds; }

@@ -51,7 +51,7 @@ def lib():
         L.emu_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.emu_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
         L.emu_query.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                                ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+                                ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -112,7 +112,9 @@ class EmuBackend:
         nt = t.shape[-1]
         per_env = nt if t.ndim == 2 else 0
         n = np.ascontiguousarray(nodes, np.int32)
+        nn = n.shape[-1]
+        npe = nn if n.ndim == 2 else 0
         a = np.ascontiguousarray(attrs, np.int32)
-        out = np.zeros((self.n_envs, nt, len(n), row_slots), np.float64)
-        lib().emu_query(self._h, node_type, _ptr(t), nt, per_env, _ptr(n), len(n), _ptr(a), len(a), _ptr(out))
+        out = np.zeros((self.n_envs, nt, nn, row_slots), np.float64)
+        lib().emu_query(self._h, node_type, _ptr(t), nt, per_env, _ptr(n), nn, npe, _ptr(a), len(a), _ptr(out))
         return out

@@ -22,6 +22,9 @@ class EmuEngine:
         self.seeds = torch.from_numpy(self.b.view(lay.off_seed, np.int64, (n_envs,)))
         self.ring_fi = torch.from_numpy(self.b.view(lay.off_ring_fi, np.int32, (n_envs, lay.ring_slots)))
         self.b.reset(np.full(n_envs, self.topo.seed, np.int64) if seeds is None else np.asarray(seeds, np.int64))
+        self.decisions = torch.zeros((n_envs, 8), dtype=torch.int32)
+        self.metrics = torch.zeros((n_envs, 3), dtype=torch.int64)
+        self.done = torch.zeros((n_envs,), dtype=torch.uint8)
 
     def reset(self, seed_cmd=None, mask=None):
         self.b.reset(None if seed_cmd is None else np.asarray(seed_cmd), None if mask is None else np.asarray(mask))
