@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Golden vectors for the citi_bike path from the REAL reference — ORACLE tooling.
+
+Needs the reference built as for gen_golden.py, plus two stub modules on sys.path (the real packages are not
+installed here): `holidays` (US() that contains nothing) and `geopy.distance` (haversine) — see SURVEY.md §8c.
+The toy data (trips.bin etc.) is generated ONCE by the reference's own pipeline
+(`CitiBikeProcess(is_temp=False).topologies[name].download/clean/build`, unseeded random) and compiled with
+tools/import_maro_citi_bike.py; the goldens and the packaged .npz must come from the same build folder.
+
+    python oracle/gen_golden_citi_bike.py --maro /tmp/oracle/maro_src --stubs /tmp/oracle/stubs --out tests/golden
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+STATION_ATTRS = ["bikes", "shortage", "trip_requirement", "fulfillment", "capacity", "id", "weekday", "temperature",
+                 "weather", "holiday", "extra_cost", "transfer_cost", "failed_return", "min_bikes"]
+CASES = {
+    "cb_toy3s4t_d1440_r10": ("toy.3s_4t", dict(durations=1440, snapshot_resolution=10), "half"),
+    "cb_toy3s4t_d600_r1": ("toy.3s_4t", dict(durations=600, snapshot_resolution=1), "half"),
+    "cb_toy3s4t_d2000_r7_ring12": ("toy.3s_4t", dict(durations=2000, snapshot_resolution=7, max_snapshots=12), "all"),
+    "cb_toy3s4t_d900_r10_none": ("toy.3s_4t", dict(durations=900, snapshot_resolution=10), "none"),
+}
+
+
+def worker(maro_root, stubs, case, out_path):
+    os.environ["HOME"] = os.environ.get("MARO_ORACLE_HOME", "/tmp/oracle/home")  # where the built toy data lives (~/.maro)
+    sys.path.insert(0, stubs)
+    sys.path.insert(0, maro_root)
+    import numpy as np
+    from maro.simulator import Env
+    from maro.simulator.scenarios.citi_bike.common import Action, DecisionType
+
+    topology, kwargs, policy = CASES[case]
+    np.random.seed(0)
+    env = Env("citi_bike", topology, start_tick=0, **kwargs)
+    decs, scopes, mets, acts = [], [], [], []
+    m, de, done = env.step(None)
+    while not done:
+        scope = de.action_scope                      # reading it is what updates the trip-window cache
+        items = [(int(k), int(v)) for k, v in scope.items()]
+        decs.append([de.tick, de.station_idx, 0 if de.type == DecisionType.Supply else 1, de.frame_index, len(items)])
+        scopes.append(items + [(-1, -1)] * (8 - len(items)))
+        mets.append([m["trip_requirements"], m["bike_shortage"], m["operation_number"]])
+        action, enc = None, (-1, -1, -1)
+        others = [k for k, _ in items if k != de.station_idx]
+        if policy != "none" and others:
+            to = others[0]
+            n = min(scope[de.station_idx], scope[to])
+            n = n // 2 if policy == "half" else n
+            frm, dst = (de.station_idx, to) if de.type == DecisionType.Supply else (to, de.station_idx)
+            action, enc = Action(frm, dst, int(n)), (frm, dst, int(n))
+        acts.append(enc)
+        m, de, done = env.step(action)
+    sl = env.snapshot_list
+    out = dict(decisions=np.array(decs, np.int32).reshape(-1, 5), scopes=np.array(scopes, np.int32).reshape(-1, 8, 2),
+               metrics=np.array(mets, np.int64).reshape(-1, 3), actions=np.array(acts, np.int32).reshape(-1, 3),
+               final_metrics=np.array([m["trip_requirements"], m["bike_shortage"], m["operation_number"]], np.int64),
+               frame_indices=np.array(sl.get_frame_index_list(), np.int32),
+               snap_stations=sl["stations"][::STATION_ATTRS], snap_matrices=sl["matrices"][::"trips_adj"],
+               final_tick=np.array([env.tick], np.int32),
+               meta=np.frombuffer(json.dumps(dict(case=case, topology=topology, kwargs=kwargs, policy=policy, np_seed=0)).encode(), np.uint8))
+    np.savez_compressed(out_path, **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--maro", default="/tmp/oracle/maro_src")
+    ap.add_argument("--stubs", default="/tmp/oracle/stubs")
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--case")
+    ap.add_argument("--worker", action="store_true")
+    a = ap.parse_args()
+    if a.worker:
+        worker(a.maro, a.stubs, a.case, os.path.join(a.out, f"{a.case}.npz"))
+        return
+    for name in ([a.case] if a.case else CASES):
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--maro", a.maro, "--stubs", a.stubs, "--out", a.out,
+                               "--case", name, "--worker"])
+        print("golden:", name, os.path.getsize(os.path.join(a.out, f"{name}.npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
