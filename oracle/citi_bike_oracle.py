@@ -194,6 +194,10 @@ class CitiBikeOracle:
         if self._pending is not None:
             # TAKE_ACTION is an immediate event of the decision: it runs right after it (:521-559)
             self._cursor += 1
+            # Reference quirk (event_linked_list.py:86-108): popping a finished cascade event that was the LAST element
+            # of the tick's list leaves `_tail` pointing at it, so events appended to this same tick afterwards
+            # (a DeliverBike with transfer time 0) hang off the removed node and are never executed.
+            tail_stale = self._cursor == len(self.events.get(self.tick, []))
             for frm, to, number in (actions or []):
                 if frm < 0 or to < 0:
                     continue
@@ -203,7 +207,8 @@ class CitiBikeOracle:
                     self._set_bikes(frm, b - ex)
                     tt = int(self._transfer_times[self._tt_pos])
                     self._tt_pos += 1
-                    self._insert(self.tick + tt, (EV_DELIVER, frm, to, ex))
+                    if not (tt == 0 and tail_stale):
+                        self._insert(self.tick + tt, (EV_DELIVER, frm, to, ex))
             self._pending = None
         elif self._fresh:
             self._fresh = False

@@ -24,6 +24,11 @@ CASES = {
     "cb_toy3s4t_d600_r1": ("toy.3s_4t", dict(durations=600, snapshot_resolution=1), "half"),
     "cb_toy3s4t_d2000_r7_ring12": ("toy.3s_4t", dict(durations=2000, snapshot_resolution=7, max_snapshots=12), "all"),
     "cb_toy3s4t_d900_r10_none": ("toy.3s_4t", dict(durations=900, snapshot_resolution=10), "none"),
+    # toy.3s_tight: toy.3s_4t trips with small, nearly full stations (overflow -> move_to_neighbor, failed returns,
+    # Supply decisions), extra_cost_mode target, transfer time N(3, 2) (zero / negative transfer times)
+    "cb_tight_d1500_r10_all": ("toy.3s_tight", dict(durations=1500, snapshot_resolution=10), "all"),
+    "cb_tight_d700_r3_half": ("toy.3s_tight", dict(durations=700, snapshot_resolution=3), "half"),
+    "cb_tight_d800_r20_none": ("toy.3s_tight", dict(durations=800, snapshot_resolution=20, max_snapshots=6), "none"),
 }
 
 

@@ -82,7 +82,7 @@ def main():
         resolution=int(dec["resolution"]), time_mean=float(dec["effective_time_mean"]), time_std=float(dec["effective_time_std"]),
         supply_water_mark_ratio=float(dec["supply_water_mark_ratio"]), demand_water_mark_ratio=float(dec["demand_water_mark_ratio"]),
         scope_low_ratio=float(dec["action_scope"]["low"]), scope_high_ratio=float(dec["action_scope"]["high"]),
-        extra_cost_mode={"source": 0, "target": 1, "target_neighbors": 2}[dec["extra_cost_mode"]],
+        extra_cost_mode={"source": 0, "target": 1}[dec["extra_cost_mode"]],  # common.py:155-160 (target_neighbors is commented out there)
         filters=[dict(type=ftype[f["type"]], num=int(f["num"]), windows=int(f.get("windows", 0))) for f in dec["action_scope"]["filters"]])
     os.makedirs(args.out, exist_ok=True)
     path = os.path.join(args.out, args.topology + ".npz")
