@@ -1,0 +1,132 @@
+/*
+ * maro_amd_citi_bike.h — C ABI of the MI355X batched rollout engine for MARO's citi_bike simulator
+ * (SURVEY.md §8 row a20).  Same conventions as maro_amd.h: plain C, caller-owned device pointers,
+ * all engine state inside the caller's workspace, asynchronous on `stream`, status codes, no throws.
+ *
+ * The reference has no FFI for this path; each entry point cites the Python interface it replaces.
+ */
+#ifndef MARO_AMD_CITI_BIKE_H_
+#define MARO_AMD_CITI_BIKE_H_
+
+#include "maro_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Extra per-environment status bits (same status word convention as MRX_ENV_*). */
+enum {
+  MRX_CB_ENV_INVALID_ACTION = 1,     /* station index out of range — action skipped */
+  MRX_CB_ENV_DELIVERY_OVERFLOW = 2,  /* more in-flight DeliverBike events than delivery_capacity */
+  MRX_CB_ENV_TRANSFER_TIMES_OUT = 4, /* the env consumed more transfer times than were supplied */
+  MRX_CB_ENV_TRANSFER_TOO_LONG = 8   /* (unused: any positive transfer time is representable) */
+};
+
+enum { MRX_CB_SUPPLY = 0, MRX_CB_DEMAND = 1 }; /* DecisionType, citi_bike/common.py:57-65 */
+enum { MRX_CB_FILTER_DISTANCE = 0, MRX_CB_FILTER_REQUIREMENTS = 1, MRX_CB_FILTER_TRIP_WINDOW = 2 };
+enum { MRX_CB_MAX_FILTERS = 4 };
+
+/*
+ * Flat citi_bike topology: what CitibikeBusinessEngine reads from a topology folder
+ * (citi_bike/business_engine.py:205-260): trips.bin through BinaryReader/ItemTickPicker
+ * (data_lib/binary_reader.py:80-112), station_meta.csv, distance_adj.csv, KNYC_daily.bin, config.yml.
+ * All arrays are HOST pointers, copied at create.  Trips must be sorted by tick (file order inside a tick).
+ */
+typedef struct mrx_cb_topology {
+  int32_t n_stations, n_trips, n_ticks, n_days;
+  const int32_t* trip_tick;     /* [n_trips] minutes from the data start */
+  const int32_t* trip_src;      /* [n_trips] station index */
+  const int32_t* trip_dst;      /* [n_trips] */
+  const int32_t* trip_duration; /* [n_trips] ticks */
+  const int32_t* capacity;      /* [S] */
+  const int32_t* init_bikes;    /* [S] */
+  const int32_t* station_id;    /* [S] */
+  const double* distance;       /* [S][S]; 0.0 = not a neighbour (decision_strategy.py:381-391) */
+  const int32_t* tick_day;      /* [n_ticks] day index of each tick (business_engine.py:367-369) */
+  const int16_t* day_weekday;   /* [n_days] values as the int16 frame attributes store them */
+  const int16_t* day_holiday;
+  const int16_t* day_weather;
+  const int16_t* day_temperature;
+  /* decision strategy options (decision_strategy.py:181-211) */
+  int32_t resolution;
+  double supply_water_mark_ratio, demand_water_mark_ratio, scope_low_ratio, scope_high_ratio;
+  int32_t extra_cost_mode; /* 0 source, 1 target, 2 target_neighbors (ExtraCostMode) */
+  int32_t n_filters;
+  int32_t filter_type[MRX_CB_MAX_FILTERS], filter_num[MRX_CB_MAX_FILTERS], filter_windows[MRX_CB_MAX_FILTERS];
+} mrx_cb_topology;
+
+/* Env(...) constructor arguments (core.py:42-56) plus engine capacities. */
+typedef struct mrx_cb_config {
+  int32_t n_envs, device, start_tick, durations, snapshot_resolution;
+  int32_t max_snapshots;      /* <=0 -> ceil(durations/resolution) */
+  int32_t max_actions;        /* A: actions accepted per decision per step (>=1) */
+  int32_t delivery_capacity;  /* in-flight DeliverBike events per env; <=0 -> 4*S+4 */
+  int32_t transfer_times_cap; /* transfer times per env; <=0 -> S*(durations/resolution+1) */
+} mrx_cb_config;
+
+/* Layout of the per-env arrays inside the workspace.  Every per-env array is struct-of-arrays
+ * `int32 [words][env_stride]` (word-major, env-minor) so a wave's 64 envs touch 256 contiguous bytes. */
+typedef struct mrx_cb_layout {
+  int32_t n_envs, env_stride, n_stations, frame_words, ring_slots, scope_cap, delivery_capacity, transfer_times_cap;
+  int64_t off_hdr;     /* int32 [16][stride]: tick, flags, ..., status (MRX_CB_HDR_*) */
+  int64_t off_live;    /* int32 [frame_words][stride]: 8 attrs x S (attr-major) then trips_adj S*S */
+  int64_t off_ring;    /* int32 [ring_slots][frame_words + 1][stride] (last word: tick of the snapshot) */
+  int64_t off_ring_fi; /* int32 [ring_slots][stride] frame index held by each slot, -1 = empty */
+  int64_t off_transfer_times; /* int32 [transfer_times_cap][stride] */
+  int64_t workspace_bytes;
+} mrx_cb_layout;
+enum { MRX_CB_HDR_TICK = 0, MRX_CB_HDR_FLAGS = 1, MRX_CB_HDR_STATUS = 13, MRX_CB_HDR_WORDS = 16 };
+
+typedef struct mrx_cb_engine* mrx_cb_handle;
+
+int64_t mrx_cb_workspace_bytes(const mrx_cb_topology* topo, const mrx_cb_config* cfg);
+/* Replaces Env.__init__ for N envs (core.py:42-90, citi_bike/business_engine.py:40-99, 205-366). */
+int mrx_cb_create(const mrx_cb_topology* topo, const mrx_cb_config* cfg, void* d_workspace, int64_t workspace_bytes,
+                  mrx_cb_handle* out);
+int mrx_cb_destroy(mrx_cb_handle h);
+int mrx_cb_get_layout(mrx_cb_handle h, mrx_cb_layout* out);
+
+/*
+ * Replaces Env.reset (core.py:143-170, citi_bike/business_engine.py:164-190) for every env whose mask byte is
+ * non-zero (NULL = all).  d_transfer_times int32 [n_envs][n_times] (NULL = keep what the workspace holds) is the
+ * sequence BikeDecisionStrategy.transfer_time would yield for that env (`round(np.random.normal(mean, std))`,
+ * global numpy RNG in the reference, decision_strategy.py:213-216; SURVEY.md §8c: pre-drawn, fed to the device).
+ */
+int mrx_cb_reset(mrx_cb_handle h, const int32_t* d_transfer_times, int32_t n_times, const uint8_t* d_env_mask,
+                 void* stream);
+
+/*
+ * Replaces Env.step(action) in Sequential decision mode (core.py:92-133, 317-381) for every unmasked env:
+ * applies the actions to the pending RebalanceBike decision (business_engine.py:521-559), then runs ticks
+ * (…:101-147 and the handlers :398-519) until the next decision or the end of the episode.
+ *   d_actions   int32 [n_envs][A][3] = (from_station_idx, to_station_idx, number); d_n_actions int32 [n_envs] (NULL = 0)
+ *   d_decisions int32 [n_envs][8] = (tick, station_idx, MRX_CB_SUPPLY|DEMAND, frame_index, n_scope, valid, 0, 0)
+ *   d_scope     int32 [n_envs][scope_cap][2] = the decision's action_scope as ordered (station, max) pairs,
+ *               the deciding station last (decision_strategy.py:253-293); unused rows are (-1, -1)
+ *   d_metrics   int64 [n_envs][3] = (trip_requirements, bike_shortage, operation_number)
+ */
+int mrx_cb_step(mrx_cb_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const uint8_t* d_env_mask,
+                int32_t* d_decisions, int32_t* d_scope, int64_t* d_metrics, uint8_t* d_done, void* stream);
+
+/*
+ * Replaces snapshot_list["stations" | "matrices"][ticks:nodes:attrs] (frame.pyx:754-801, np_backend.pyx:520-549).
+ * node_type 0 = stations, 1 = matrices; arguments as mrx_cim_query.  trips_adj has S*S slots, every other attr 1.
+ */
+int mrx_cb_query(mrx_cb_handle h, int node_type, const int32_t* d_ticks, int nt, int ticks_per_env, const int32_t* d_nodes,
+                 int nn, int nodes_per_env, const int32_t* attrs, int na, double* d_out, void* stream);
+
+/*
+ * Utility device policy (counter-based, replayed by the tests' oracle): for every env with a valid decision pick
+ * the first other station of the scope and move hash-chosen 0..min(scope[self], scope[other]) bikes
+ * (Supply: self -> other, Demand: other -> self).  Adds the number of valid decisions to *d_counter (may be NULL).
+ */
+int mrx_cb_random_policy(mrx_cb_handle h, const int32_t* d_decisions, const int32_t* d_scope, int64_t step,
+                         int32_t* d_actions, int32_t* d_n_actions, uint64_t* d_counter, void* stream);
+
+int mrx_cb_attr_id(int node_type, const char* name);
+int mrx_cb_attr_slots(mrx_cb_handle h, int node_type, int attr_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARO_AMD_CITI_BIKE_H_ */

@@ -33,7 +33,10 @@ class MrxCimLayout(ctypes.Structure):
 
 EXPORTS = ("mrx_last_error", "mrx_version", "mrx_cim_workspace_bytes", "mrx_cim_create", "mrx_cim_destroy",
            "mrx_cim_get_layout", "mrx_cim_reset", "mrx_cim_step", "mrx_cim_query", "mrx_cim_attr_id",
-           "mrx_cim_attr_slots", "mrx_cim_random_policy")
+           "mrx_cim_attr_slots", "mrx_cim_random_policy",
+           # include/maro_amd_citi_bike.h
+           "mrx_cb_workspace_bytes", "mrx_cb_create", "mrx_cb_destroy", "mrx_cb_get_layout", "mrx_cb_reset", "mrx_cb_step",
+           "mrx_cb_query", "mrx_cb_random_policy", "mrx_cb_attr_id", "mrx_cb_attr_slots")
 
 _lib = None
 
@@ -75,6 +78,27 @@ def load() -> ctypes.CDLL:
     L.mrx_cim_attr_id.argtypes = [i32, ctypes.c_char_p]
     L.mrx_cim_attr_slots.restype = i32
     L.mrx_cim_attr_slots.argtypes = [vp, i32, i32]
+    # ---- include/maro_amd_citi_bike.h
+    L.mrx_cb_workspace_bytes.restype = i64
+    L.mrx_cb_workspace_bytes.argtypes = [vp, vp]
+    L.mrx_cb_create.restype = i32
+    L.mrx_cb_create.argtypes = [vp, vp, vp, i64, ctypes.POINTER(vp)]
+    L.mrx_cb_destroy.restype = i32
+    L.mrx_cb_destroy.argtypes = [vp]
+    L.mrx_cb_get_layout.restype = i32
+    L.mrx_cb_get_layout.argtypes = [vp, vp]
+    L.mrx_cb_reset.restype = i32
+    L.mrx_cb_reset.argtypes = [vp, vp, i32, vp, vp]
+    L.mrx_cb_step.restype = i32
+    L.mrx_cb_step.argtypes = [vp] * 9
+    L.mrx_cb_query.restype = i32
+    L.mrx_cb_query.argtypes = [vp, i32, vp, i32, i32, vp, i32, i32, vp, i32, vp, vp]
+    L.mrx_cb_random_policy.restype = i32
+    L.mrx_cb_random_policy.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
+    L.mrx_cb_attr_id.restype = i32
+    L.mrx_cb_attr_id.argtypes = [i32, ctypes.c_char_p]
+    L.mrx_cb_attr_slots.restype = i32
+    L.mrx_cb_attr_slots.argtypes = [vp, i32, i32]
     _lib = L
     return L
 

@@ -1,0 +1,157 @@
+"""Batched citi_bike rollout engine: thin Python plumbing over the C ABI (include/maro_amd_citi_bike.h).
+
+PyTorch owns the device memory and the stream; every state transition runs in the HIP kernels of
+maro_amd/csrc/cb_engine.hip.  Tensor conventions are those of the C ABI:
+    actions   int32 [n_envs, A, 3] = (from_station_idx, to_station_idx, number)
+    decisions int32 [n_envs, 8]    = (tick, station_idx, 0=Supply | 1=Demand, frame_index, n_scope, valid, 0, 0)
+    scope     int32 [n_envs, K, 2] = ordered (station, max) pairs of the decision's action_scope, the deciding station last
+    metrics   int64 [n_envs, 3]    = (trip_requirements, bike_shortage, operation_number)
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .abi import (HDR_STATUS, HDR_TICK, HDR_WORDS, NODE_ATTRS, NODE_TYPE, MrxCbConfig, MrxCbLayout, draw_transfer_times,
+                  topology_struct)
+from .data import CitiBikeData, load_topology
+
+
+class CitiBikeBatchEngine:
+    """N independent citi_bike environments (Sequential decision mode) resident on one MI355X."""
+
+    def __init__(self, topology: Union[str, CitiBikeData], n_envs: int, start_tick: int = 0, durations: int = 1440,
+                 snapshot_resolution: int = 1, max_snapshots: Optional[int] = None, max_actions: int = 1,
+                 device: Union[str, torch.device] = "cuda:0", seeds: Optional[Sequence[int]] = None,
+                 delivery_capacity: int = 0, transfer_times_cap: int = 0):
+        self._L = _lib.load()  # raises if the HIP extension is not built
+        if not torch.cuda.is_available():
+            raise RuntimeError("maro_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.data = topology if isinstance(topology, CitiBikeData) else load_topology(topology)
+        self.device = torch.device(device)
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.n_envs, self.max_actions = int(n_envs), int(max_actions)
+        self.start_tick, self.durations = int(start_tick), int(durations)
+        self.max_tick = self.start_tick + self.durations
+        self.snapshot_resolution = int(snapshot_resolution)
+        self._ts, self._keep_topo = topology_struct(self.data)
+        self._cfg = MrxCbConfig(self.n_envs, dev_index, self.start_tick, self.durations, self.snapshot_resolution,
+                                int(max_snapshots or 0), self.max_actions, int(delivery_capacity), int(transfer_times_cap))
+        nbytes = self._L.mrx_cb_workspace_bytes(ctypes.byref(self._ts), ctypes.byref(self._cfg))
+        _lib.check(nbytes, "mrx_cb_workspace_bytes")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize()
+            _lib.check(self._L.mrx_cb_create(ctypes.byref(self._ts), ctypes.byref(self._cfg), self.workspace.data_ptr(), nbytes,
+                                             ctypes.byref(h)), "mrx_cb_create")
+        self._h = h
+        self.layout = MrxCbLayout()
+        _lib.check(self._L.mrx_cb_get_layout(self._h, ctypes.byref(self.layout)), "mrx_cb_get_layout")
+        lay = self.layout
+        st = lay.env_stride
+        # zero-copy views of engine state: struct-of-arrays [word, env]
+        self.hdr = self._view(lay.off_hdr, (HDR_WORDS, st))[:, :self.n_envs]
+        self.live = self._view(lay.off_live, (lay.frame_words, st))[:, :self.n_envs]
+        self.ring = self._view(lay.off_ring, (lay.ring_slots, lay.frame_words + 1, st))[:, :, :self.n_envs]
+        self.ring_fi = self._view(lay.off_ring_fi, (lay.ring_slots, st))[:, :self.n_envs]
+        self.ticks, self.status = self.hdr[HDR_TICK], self.hdr[HDR_STATUS]
+        self.decisions = torch.zeros((self.n_envs, 8), dtype=torch.int32, device=self.device)
+        self.scope = torch.full((self.n_envs, lay.scope_cap, 2), -1, dtype=torch.int32, device=self.device)
+        self.metrics = torch.zeros((self.n_envs, 3), dtype=torch.int64, device=self.device)
+        self.done = torch.zeros((self.n_envs,), dtype=torch.uint8, device=self.device)
+        if seeds is not None:
+            self.reset(seeds=seeds)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.mrx_cb_destroy(h)
+            self._h = None
+
+    def _view(self, off: int, shape) -> torch.Tensor:
+        n = int(np.prod(shape)) * 4
+        return self.workspace[off:off + n].view(torch.int32).view(*shape)
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _dev(self, x, dtype) -> Optional[torch.Tensor]:
+        if x is None:
+            return None
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.asarray(x), dtype=dtype)
+        return x.to(device=self.device, dtype=dtype).contiguous()
+
+    @staticmethod
+    def _p(t: Optional[torch.Tensor]):
+        return None if t is None else t.data_ptr()
+
+    # ------------------------------------------------------------------ C ABI calls
+    def reset(self, seeds: Optional[Sequence[int]] = None, transfer_times=None, mask=None) -> None:
+        """`seeds`: one numpy seed per env — env e replays what `np.random.seed(seeds[e])` gives the reference's
+        transfer times; or pass the `transfer_times` [n_envs, k] directly; neither = keep the streams in place."""
+        if seeds is not None:
+            transfer_times = draw_transfer_times(self.data, seeds, self.layout.transfer_times_cap)
+        tt = self._dev(transfer_times, torch.int32)
+        mk = self._dev(mask, torch.uint8)
+        if tt is not None:
+            assert tt.dim() == 2 and tt.shape[0] == self.n_envs, "transfer_times must be [n_envs, k]"
+        _lib.check(self._L.mrx_cb_reset(self._h, self._p(tt), 0 if tt is None else int(tt.shape[1]), self._p(mk), self._stream()),
+                   "mrx_cb_reset")
+        self._keep = (tt, mk)
+
+    def step(self, actions=None, n_actions=None, mask=None):
+        a = self._dev(actions, torch.int32)
+        na = self._dev(n_actions, torch.int32)
+        mk = self._dev(mask, torch.uint8)
+        if a is not None:
+            assert a.numel() == self.n_envs * self.max_actions * 3, "actions must be [n_envs, max_actions, 3]"
+            if na is None:
+                na = torch.full((self.n_envs,), self.max_actions, dtype=torch.int32, device=self.device)
+        _lib.check(self._L.mrx_cb_step(self._h, self._p(a), self._p(na), self._p(mk), self.decisions.data_ptr(), self.scope.data_ptr(),
+                                       self.metrics.data_ptr(), self.done.data_ptr(), self._stream()), "mrx_cb_step")
+        self._keep = (a, na, mk)
+        return self.decisions, self.scope, self.metrics, self.done
+
+    def random_policy(self, step: int, actions: torch.Tensor, n_actions: torch.Tensor, counter: Optional[torch.Tensor] = None) -> None:
+        _lib.check(self._L.mrx_cb_random_policy(self._h, self.decisions.data_ptr(), self.scope.data_ptr(), int(step), actions.data_ptr(),
+                                                n_actions.data_ptr(), self._p(counter), self._stream()), "mrx_cb_random_policy")
+
+    def attr_ids(self, node: str, attrs: Sequence[str]):
+        ids = []
+        for a in attrs:
+            i = self._L.mrx_cb_attr_id(NODE_TYPE[node], a.encode())
+            if i < 0:
+                raise KeyError(f"unknown attribute {a!r} of node {node!r}")
+            ids.append(i)
+        return ids
+
+    def row_slots(self, node: str, attr_ids: Sequence[int]) -> int:
+        return sum(self._L.mrx_cb_attr_slots(self._h, NODE_TYPE[node], int(a)) for a in attr_ids)
+
+    def query(self, node: str, ticks, nodes, attrs: Sequence[str], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """float64 [n_envs, nt, nn, sum(slots)]; `ticks` are frame indices [nt] or [n_envs, nt]; `nodes` [nn] or [n_envs, nn]."""
+        ids = self.attr_ids(node, attrs)
+
+        def rows(x):
+            if isinstance(x, torch.Tensor) and x.dim() == 2 and x.dtype == torch.int32 and x.is_cuda and x.stride(1) == 1 and x.stride(0) > 0:
+                return x, int(x.stride(0))
+            x = self._dev(x, torch.int32)
+            return x, (int(x.shape[1]) if x.dim() == 2 else 0)
+
+        t, per_env = rows(ticks)
+        n, nodes_per_env = rows(nodes)
+        nt, nn = int(t.shape[-1]), int(n.shape[-1])
+        slots = self.row_slots(node, ids)
+        if out is None:
+            out = torch.empty((self.n_envs, nt, nn, slots), dtype=torch.float64, device=self.device)
+        ida = (ctypes.c_int32 * len(ids))(*ids)
+        _lib.check(self._L.mrx_cb_query(self._h, NODE_TYPE[node], t.data_ptr(), nt, per_env, n.data_ptr(), nn, nodes_per_env, ida, len(ids),
+                                        out.data_ptr(), self._stream()), "mrx_cb_query")
+        self._keep_q = (t, n)
+        return out

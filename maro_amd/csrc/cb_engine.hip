@@ -1,0 +1,224 @@
+// cb_engine.hip — gfx950 kernels + the C ABI of include/maro_amd_citi_bike.h.
+//
+// Launch geometry: ONE environment per LANE (cb_device.h explains why), 64 envs per wavefront, one wavefront per
+// workgroup so that a batch spreads over as many CUs as it has waves.  State is struct-of-arrays [word][env]: the
+// 64 lanes of a wave read/write 256 contiguous bytes whenever they agree on the word, which is the common case
+// (every env replays the same trip table).  No LDS, no cross-lane traffic, no atomics.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+
+#define MRX_DEV __device__ __forceinline__
+#include "cb_layout.h"
+#include "cb_device.h"
+
+int mrx_set_error_(int code, const std::string& m);  // cim_engine.hip (thread-local message behind mrx_last_error)
+
+// ------------------------------------------------------------------------------------------ kernels
+extern "C" __global__ void __launch_bounds__(64)
+mrx_k_cb_reset(CbParams K, const int32_t* __restrict__ tt, int n_times, const uint8_t* __restrict__ mask) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= K.n_envs || (mask && !mask[e])) return;
+  if (tt)
+    for (int i = 0; i < K.tt_cap; i++) K.tt[(size_t)i * K.stride + e] = i < n_times ? tt[(size_t)e * n_times + i] : 1;
+  cb::reset_env(K, e);
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions, const uint8_t* __restrict__ mask,
+              int32_t* __restrict__ decisions, int32_t* __restrict__ scope, long long* __restrict__ metrics, uint8_t* __restrict__ done) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= K.n_envs || (mask && !mask[e])) return;
+  int na = (actions && n_actions) ? n_actions[e] : 0;
+  if (na > K.max_actions) na = K.max_actions;
+  cb::step_env(K, e, actions ? actions + (size_t)e * K.max_actions * 3 : nullptr, na, decisions + (size_t)e * 8,
+               scope + (size_t)e * K.scope_cap * 2, (int64_t*)metrics + (size_t)e * 3, done + e);
+}
+
+struct CbAttrList { int n; int32_t id[16]; };
+
+extern "C" __global__ void __launch_bounds__(256)
+mrx_k_cb_query(CbParams K, int node_type, const int32_t* __restrict__ ticks, int nt, int ticks_per_env, const int32_t* __restrict__ nodes,
+               int nn, int nodes_per_env, CbAttrList al, int row_slots, long long total, double* __restrict__ out) {
+  // consecutive threads take consecutive ENVS of one (tick, node, column) so the SoA state reads coalesce
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int e = (int)(i % K.n_envs);
+  long long r = i / K.n_envs;
+  const int col = (int)(r % row_slots); r /= row_slots;
+  const int ni = (int)(r % nn);
+  const int ti = (int)(r / nn);
+  const long long row = ((long long)e * nt + ti) * nn + ni;
+  out[row * row_slots + col] = cb::query_elem(K, node_type, ticks, nt, ticks_per_env, nodes, nn, nodes_per_env, al.id, al.n, row, col);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+mrx_k_cb_random_policy(CbParams K, const int32_t* __restrict__ decisions, const int32_t* __restrict__ scope, long long step,
+                       int32_t* __restrict__ actions, int32_t* __restrict__ n_actions, unsigned long long* __restrict__ counter) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid = false;
+  if (e < K.n_envs)
+    valid = cb::random_policy_env(K, e, decisions + (size_t)e * 8, scope + (size_t)e * K.scope_cap * 2, step,
+                                  actions + (size_t)e * K.max_actions * 3, n_actions + e) != 0;
+  if (counter) {
+    const unsigned long long m = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (unsigned long long)__builtin_popcountll(m));
+  }
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+struct mrx_cb_engine {
+  CbHostPlan plan;
+  int device;
+};
+
+static int set_err(int code, const std::string& m) { return mrx_set_error_(code, m); }
+#define HIP_TRY(expr)                                                                                    \
+  do {                                                                                                   \
+    hipError_t _e = (expr);                                                                              \
+    if (_e != hipSuccess) return set_err(MRX_ERR_HIP, std::string(#expr ": ") + hipGetErrorString(_e)); \
+  } while (0)
+
+static int use_device(int device) {
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) return set_err(MRX_ERR_NO_DEVICE, "no HIP device available");
+  if (cur != device) HIP_TRY(hipSetDevice(device));
+  return MRX_OK;
+}
+
+extern "C" {
+
+int64_t mrx_cb_workspace_bytes(const mrx_cb_topology* topo, const mrx_cb_config* cfg) {
+  CbHostPlan pl;
+  std::string err;
+  int rc = cb_plan(topo, cfg, &pl, &err);
+  if (rc != MRX_OK) { set_err(rc, err); return rc; }
+  return pl.workspace_bytes;
+}
+
+int mrx_cb_create(const mrx_cb_topology* topo, const mrx_cb_config* cfg, void* d_workspace, int64_t workspace_bytes, mrx_cb_handle* out) {
+  if (!out) return set_err(MRX_ERR_INVALID_ARG, "out handle is null");
+  *out = nullptr;
+  mrx_cb_engine* e = new (std::nothrow) mrx_cb_engine();
+  if (!e) return set_err(MRX_ERR_INVALID_ARG, "out of host memory");
+  std::string err;
+  int rc = cb_plan(topo, cfg, &e->plan, &err);
+  if (rc != MRX_OK) { delete e; return set_err(rc, err); }
+  if (!d_workspace || workspace_bytes < e->plan.workspace_bytes || ((uintptr_t)d_workspace & 255)) {
+    delete e;
+    return set_err(MRX_ERR_WORKSPACE, "workspace is null, smaller than mrx_cb_workspace_bytes() or not 256-byte aligned");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete e; return set_err(MRX_ERR_NO_DEVICE, "no HIP device available"); }
+  e->device = cfg->device;
+  rc = use_device(e->device);
+  if (rc != MRX_OK) { delete e; return rc; }
+  cb_plan_bind(&e->plan, d_workspace);
+  hipError_t he = hipMemcpy((uint8_t*)d_workspace + e->plan.const_off, e->plan.const_blob.data(), e->plan.const_blob.size(), hipMemcpyHostToDevice);
+  if (he != hipSuccess) { delete e; return set_err(MRX_ERR_HIP, std::string("upload of the trip tables: ") + hipGetErrorString(he)); }
+  const CbParams& K = e->plan.kp;
+  // default transfer times: the distribution mean is not known here, so 1 tick until mrx_cb_reset supplies them
+  he = hipMemsetD32((hipDeviceptr_t)K.tt, 1, (size_t)K.tt_cap * K.stride);
+  if (he == hipSuccess) {
+    hipLaunchKernelGGL(mrx_k_cb_reset, dim3((K.n_envs + 63) / 64), dim3(64), 0, 0, K, nullptr, 0, nullptr);
+    he = hipDeviceSynchronize();
+  }
+  if (he == hipSuccess) he = hipGetLastError();
+  if (he != hipSuccess) { delete e; return set_err(MRX_ERR_HIP, std::string("initial reset kernel: ") + hipGetErrorString(he)); }
+  *out = e;
+  return MRX_OK;
+}
+
+int mrx_cb_destroy(mrx_cb_handle h) {
+  delete h;
+  return MRX_OK;
+}
+
+int mrx_cb_get_layout(mrx_cb_handle h, mrx_cb_layout* out) {
+  if (!h || !out) return set_err(MRX_ERR_INVALID_ARG, "null handle/out");
+  *out = h->plan.layout;
+  return MRX_OK;
+}
+
+int mrx_cb_reset(mrx_cb_handle h, const int32_t* d_transfer_times, int32_t n_times, const uint8_t* d_env_mask, void* stream) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  if (d_transfer_times && n_times <= 0) return set_err(MRX_ERR_INVALID_ARG, "n_times must be positive when transfer times are given");
+  int rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  const CbParams& K = h->plan.kp;
+  hipLaunchKernelGGL(mrx_k_cb_reset, dim3((K.n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, K, d_transfer_times, (int)n_times, d_env_mask);
+  HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+int mrx_cb_step(mrx_cb_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const uint8_t* d_env_mask, int32_t* d_decisions,
+                int32_t* d_scope, int64_t* d_metrics, uint8_t* d_done, void* stream) {
+  if (!h || !d_decisions || !d_scope || !d_metrics || !d_done) return set_err(MRX_ERR_INVALID_ARG, "null handle/output pointer");
+  int rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  const CbParams& K = h->plan.kp;
+  hipLaunchKernelGGL(mrx_k_cb_step, dim3((K.n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, K, d_actions, d_n_actions, d_env_mask,
+                     d_decisions, d_scope, (long long*)d_metrics, d_done);
+  HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+int mrx_cb_random_policy(mrx_cb_handle h, const int32_t* d_decisions, const int32_t* d_scope, int64_t step, int32_t* d_actions,
+                         int32_t* d_n_actions, uint64_t* d_counter, void* stream) {
+  if (!h || !d_decisions || !d_scope || !d_actions || !d_n_actions) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
+  int rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  const CbParams& K = h->plan.kp;
+  hipLaunchKernelGGL(mrx_k_cb_random_policy, dim3((K.n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, K, d_decisions, d_scope,
+                     (long long)step, d_actions, d_n_actions, (unsigned long long*)d_counter);
+  HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+int mrx_cb_attr_slots(mrx_cb_handle h, int node_type, int attr_id) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  const CbParams& K = h->plan.kp;
+  if (node_type == 0) return (attr_id >= 0 && attr_id < SA_COUNT) ? 1 : -1;
+  if (node_type == 1) return attr_id == CB_MA_TRIPS_ADJ ? K.S * K.S : -1;
+  return -1;
+}
+
+int mrx_cb_attr_id(int node_type, const char* name) {
+  static const char* ST[] = {"bikes", "shortage", "trip_requirement", "fulfillment", "capacity", "id", "weekday", "temperature",
+                             "weather", "holiday", "extra_cost", "transfer_cost", "failed_return", "min_bikes"};
+  static const char* M[] = {"trips_adj"};
+  const char** tab = node_type == 0 ? ST : node_type == 1 ? M : nullptr;
+  const int n = node_type == 0 ? SA_COUNT : node_type == 1 ? CB_MA_COUNT : 0;
+  if (!name) return -1;
+  for (int i = 0; i < n; i++) if (!strcmp(tab[i], name)) return i;
+  return -1;
+}
+
+int mrx_cb_query(mrx_cb_handle h, int node_type, const int32_t* d_ticks, int nt, int ticks_per_env, const int32_t* d_nodes, int nn,
+                 int nodes_per_env, const int32_t* attrs, int na, double* d_out, void* stream) {
+  if (!h || !d_ticks || !d_nodes || !attrs || !d_out) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
+  if (na > 16) return set_err(MRX_ERR_INVALID_ARG, "at most 16 attributes per query");
+  if (nt <= 0 || nn <= 0 || na <= 0) return set_err(MRX_ERR_INVALID_ARG, "nt, nn and na must be positive");
+  int rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  const CbParams& K = h->plan.kp;
+  int row_slots = 0;
+  for (int i = 0; i < na; i++) {
+    const int s = mrx_cb_attr_slots(h, node_type, attrs[i]);
+    if (s < 0) return set_err(MRX_ERR_INVALID_ARG, "unknown attribute id for this node type");
+    row_slots += s;
+  }
+  const long long total = (long long)K.n_envs * nt * nn * row_slots;
+  CbAttrList al;
+  al.n = na;
+  for (int i = 0; i < 16; i++) al.id[i] = i < na ? attrs[i] : 0;
+  hipLaunchKernelGGL(mrx_k_cb_query, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K, node_type, d_ticks, nt,
+                     ticks_per_env, d_nodes, nn, nodes_per_env, al, row_slots, total, d_out);
+  HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// cb_params.h — POD kernel-argument block of the citi_bike engine, shared by host (layout / C-ABI) and device code.
+#pragma once
+#include <stdint.h>
+
+// Station attribute ids (the ids of mrx_cb_attr_id), in the reference's schema order (citi_bike/station.py:8-39).
+enum { SA_BIKES, SA_SHORTAGE, SA_TRIP_REQUIREMENT, SA_FULFILLMENT, SA_CAPACITY, SA_ID, SA_WEEKDAY, SA_TEMPERATURE,
+       SA_WEATHER, SA_HOLIDAY, SA_EXTRA_COST, SA_TRANSFER_COST, SA_FAILED_RETURN, SA_MIN_BIKES, SA_COUNT };
+enum { CB_MA_TRIPS_ADJ, CB_MA_COUNT };
+
+// Live-frame rows (what actually varies per env); capacity / id / calendar attributes are shared tables.
+enum { LV_BIKES, LV_SHORTAGE, LV_TRIP_REQUIREMENT, LV_FULFILLMENT, LV_EXTRA_COST, LV_TRANSFER_COST, LV_FAILED_RETURN,
+       LV_MIN_BIKES, LV_COUNT };
+
+// Per-env header words (hdr[w][env]).
+enum { CH_TICK, CH_FLAGS, CH_CUR_STATION, CH_CUR_TYPE, CH_TT_POS, CH_TRIPS, CH_SHORT, CH_OPER, CH_POOL_HEAD, CH_POOL_TAIL,
+       CH_POOL_MINLAND, CH_LATE, CH_NDEC, CH_STATUS, CH_RES0, CH_RES1, CH_WORDS };
+enum { CFL_FRESH = 1, CFL_FINISHED = 2, CFL_PENDING = 4 };
+enum { CB_POOL_WORDS = 5 };  // land tick, scheduling tick, from, to, number (<0: executed)
+#define CB_NO_LAND 0x7fffffff
+
+struct CbParams {
+  // ---- dimensions / options
+  int32_t n_envs, stride, S, start_tick, max_tick, res, ring_slots, max_actions;
+  int32_t dres, extra_cost_mode, n_filters, f_type[4], f_num[4], f_win[4];
+  int32_t FW, w_mask, w_words, pool_cap, tt_cap, scope_cap, mask_words, nb_stride;
+  double supply_wm, demand_wm, scope_low_keep, scope_high;
+  // ---- per-env struct-of-arrays state: X[word][stride]
+  int32_t* hdr;       // [CH_WORDS]
+  int32_t* live;      // [FW]  LV_* x S (attr-major), then trips_adj S x S
+  int32_t* ring;      // [ring_slots][FW + 1]  (+1: tick the snapshot was taken at)
+  int32_t* ring_fi;   // [ring_slots]
+  int32_t* twc;       // [ring_slots][S]   TripsWindowFilter cache of trip_requirement
+  int32_t* twc_fi;    // [ring_slots]
+  int32_t* pool;      // [pool_cap][CB_POOL_WORDS]  in-flight DeliverBike events, insertion order
+  int32_t* tt;        // [tt_cap] transfer times
+  int32_t* scratch;   // [3 * S] action-scope work arrays
+  uint32_t* fulfilled;  // [w_words]  bit ring over trip index: RequireBike got a bike
+  uint32_t* decmask;    // [2 * mask_words] stations with a pending Supply / Demand decision this tick
+  // ---- shared tables (trips restricted to [start_tick, max_tick), re-indexed from 0)
+  const int32_t *trip_off, *trip_tick, *trip_src, *trip_dst;  // trip_off [durations + 1]
+  const int32_t *ret_off, *ret_mid, *ret_trip;                // returns landing at each tick, insertion order
+  const int32_t *capacity, *init_bikes, *station_id, *nb, *nb_cnt;
+  const int32_t *tick_day, *cal;  // tick_day [durations] (relative to start_tick) -> cal [n_days][4] weekday, temperature, weather, holiday
+};

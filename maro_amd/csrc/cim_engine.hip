@@ -111,7 +111,8 @@ struct mrx_cim_engine {
 };
 
 static thread_local std::string g_err;
-static int set_err(int code, const std::string& m) { g_err = m; return code; }
+int mrx_set_error_(int code, const std::string& m) { g_err = m; return code; }  // shared with cb_engine.hip
+static int set_err(int code, const std::string& m) { return mrx_set_error_(code, m); }
 #define HIP_TRY(expr)                                                                                    \
   do {                                                                                                   \
     hipError_t _e = (expr);                                                                              \

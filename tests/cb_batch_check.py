@@ -1,0 +1,69 @@
+"""Shared body of the citi_bike batch-vs-oracle parity tests (CPU harness and GPU): every env of a batch gets its
+own transfer-time stream and its own counter-based actions; each is replayed through the pure-Python oracle."""
+import numpy as np
+
+from maro_amd.citi_bike.abi import NODE_TYPE, STATION_ATTRS, draw_transfer_times
+from oracle.citi_bike_oracle import CitiBikeOracle
+
+M64 = (1 << 64) - 1
+
+
+def mix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M64
+    return x ^ (x >> 31)
+
+
+def policy_action(step, env, de):
+    """Python twin of cb::random_policy_env (maro_amd/csrc/cb_device.h)."""
+    scope = de["action_scope"]
+    if len(scope) < 2:
+        return None
+    (self_s, self_max), (other, other_max) = scope[-1], scope[0]
+    m = max(min(self_max, other_max), 0)
+    number = mix64(mix64(step) ^ env) % (m + 1)
+    return (self_s, other, number) if de["type"] == 0 else (other, self_s, number)
+
+
+def run_batch_vs_oracle(backend, data, kwargs, seeds, episodes=1, check_envs=None):
+    n = backend.n_envs
+    tts = draw_transfer_times(data, seeds, backend.layout.transfer_times_cap)
+    check_envs = list(range(n)) if check_envs is None else check_envs
+    for ep in range(episodes):
+        backend.reset(transfer_times=tts if ep == 0 else None)
+        oracles = {e: CitiBikeOracle(data, transfer_times=tts[e], **kwargs) for e in check_envs}
+        o_out = {e: o.step(None) for e, o in oracles.items()}
+        dec, scope, met, done = backend.step()
+        step = 0
+        while True:
+            for e in check_envs:
+                m, de, od = o_out[e]
+                assert bool(done[e]) == od, (e, step)
+                assert met[e].tolist() == [m["trip_requirements"], m["bike_shortage"], m["operation_number"]], (e, step)
+                if not od:
+                    assert dec[e, :6].tolist() == [de["tick"], de["station_idx"], de["type"], de["frame_index"], len(de["action_scope"]), 1], (e, step, de, dec[e])
+                    assert [tuple(x) for x in scope[e, : dec[e, 4]].tolist()] == [tuple(x) for x in de["action_scope"]], (e, step)
+            if done.all():
+                break
+            step += 1
+            a, na = backend.random_policy(dec, scope, step)
+            for e in check_envs:
+                m, de, od = o_out[e]
+                if od:
+                    continue
+                act = policy_action(step, e, de)
+                assert (act is None and na[e] == 0) or (na[e] == 1 and a[e, 0].tolist() == list(act)), (e, step, act, a[e])
+                o_out[e] = oracles[e].step([act] if act else None)
+            dec, scope, met, done = backend.step(a, na)
+        # full-history snapshot tensors
+        for e in check_envs:
+            o = oracles[e]
+            fis = o.frame_indices()
+            S = data.n_stations
+            got = backend.query(NODE_TYPE["stations"], fis, list(range(S)), list(range(len(STATION_ATTRS))), len(STATION_ATTRS))[e].reshape(-1)
+            assert np.array_equal(got, o.query("stations", fis, [], STATION_ATTRS)), e
+            got = backend.query(NODE_TYPE["matrices"], fis, [0], [0], S * S)[e].reshape(-1)
+            assert np.array_equal(got, o.query("matrices", fis, [], ["trips_adj"])), e
+        assert (backend.hdr()[13, :n] == 0).all(), backend.hdr()[13, :n]
+    return step

@@ -1,0 +1,83 @@
+// cb_emu.cpp — TEST INFRASTRUCTURE ONLY.  Compiles the citi_bike engine's device source
+// (maro_amd/csrc/cb_device.h, one env per lane, no cross-lane operations) for the host, one call per env, so the
+// `-m "not gpu"` suite can compare the real kernel logic with the CPU oracle.  The product never loads this.
+#include <stdio.h>
+#include <stdlib.h>
+
+#define MRX_DEV static inline
+#include "../../maro_amd/csrc/cb_layout.h"
+#include "../../maro_amd/csrc/cb_device.h"
+
+struct CbEmu {
+  CbHostPlan plan;
+  uint8_t* ws = nullptr;
+};
+
+extern "C" {
+
+void* cb_emu_create(const mrx_cb_topology* t, const mrx_cb_config* c, char* errbuf, int errlen) {
+  CbEmu* e = new CbEmu();
+  std::string err;
+  if (cb_plan(t, c, &e->plan, &err) != MRX_OK) {
+    snprintf(errbuf, errlen, "%s", err.c_str());
+    delete e;
+    return nullptr;
+  }
+  e->ws = (uint8_t*)aligned_alloc(256, (size_t)e->plan.workspace_bytes);
+  memset(e->ws, 0xCD, (size_t)e->plan.workspace_bytes);  // poison: nothing may rely on zeroed HBM
+  memcpy(e->ws + e->plan.const_off, e->plan.const_blob.data(), e->plan.const_blob.size());
+  cb_plan_bind(&e->plan, e->ws);
+  return e;
+}
+
+void cb_emu_destroy(void* h) {
+  CbEmu* e = (CbEmu*)h;
+  free(e->ws);
+  delete e;
+}
+
+void cb_emu_get_layout(void* h, mrx_cb_layout* out) { *out = ((CbEmu*)h)->plan.layout; }
+void* cb_emu_workspace(void* h) { return ((CbEmu*)h)->ws; }
+
+void cb_emu_reset(void* h, const int32_t* tt, int n_times, const uint8_t* mask) {
+  CbEmu* e = (CbEmu*)h;
+  const CbParams& K = e->plan.kp;
+  for (int env = 0; env < K.n_envs; env++) {
+    if (mask && !mask[env]) continue;
+    if (tt) for (int i = 0; i < K.tt_cap; i++) K.tt[(size_t)i * K.stride + env] = i < n_times ? tt[(size_t)env * n_times + i] : 1;
+    cb::reset_env(K, env);
+  }
+}
+
+void cb_emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const uint8_t* mask, int32_t* dec, int32_t* scope,
+                 int64_t* met, uint8_t* done) {
+  CbEmu* e = (CbEmu*)h;
+  const CbParams& K = e->plan.kp;
+  for (int env = 0; env < K.n_envs; env++) {
+    if (mask && !mask[env]) continue;
+    const int na = n_actions ? n_actions[env] : 0;
+    cb::step_env(K, env, actions ? actions + (size_t)env * K.max_actions * 3 : nullptr, na < K.max_actions ? na : K.max_actions,
+                 dec + (size_t)env * 8, scope + (size_t)env * K.scope_cap * 2, met + (size_t)env * 3, done + env);
+  }
+}
+
+void cb_emu_query(void* h, int node_type, const int32_t* ticks, int nt, int ticks_per_env, const int32_t* nodes, int nn,
+                  int nodes_per_env, const int32_t* attrs, int na, double* out) {
+  CbEmu* e = (CbEmu*)h;
+  const CbParams& K = e->plan.kp;
+  int row_slots = 0;
+  for (int i = 0; i < na; i++) row_slots += cb::attr_slots(K, node_type, attrs[i]);
+  const long long rows = (long long)K.n_envs * nt * nn;
+  for (long long r = 0; r < rows; r++)
+    for (int c = 0; c < row_slots; c++)
+      out[r * row_slots + c] = cb::query_elem(K, node_type, ticks, nt, ticks_per_env, nodes, nn, nodes_per_env, attrs, na, r, c);
+}
+
+void cb_emu_random_policy(void* h, const int32_t* dec, const int32_t* scope, int64_t step, int32_t* actions, int32_t* n_actions) {
+  CbEmu* e = (CbEmu*)h;
+  const CbParams& K = e->plan.kp;
+  for (int env = 0; env < K.n_envs; env++)
+    cb::random_policy_env(K, env, dec + (size_t)env * 8, scope + (size_t)env * K.scope_cap * 2, step,
+                          actions + (size_t)env * K.max_actions * 3, n_actions + env);
+}
+}

@@ -1,0 +1,120 @@
+"""Python binding of tests/emu/libcb_emu.so — TEST INFRASTRUCTURE ONLY (the citi_bike device code compiled for
+the host; the product never loads it)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from maro_amd.citi_bike.abi import MrxCbConfig, MrxCbLayout, topology_struct
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, "libcb_emu.so")
+
+
+def build():
+    srcs = [os.path.join(HERE, "cb_emu.cpp")] + [os.path.join(REPO, "maro_amd", "csrc", f) for f in
+                                                 ("cb_device.h", "cb_layout.h", "cb_params.h")] + [
+        os.path.join(REPO, "include", "maro_amd_citi_bike.h")]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-g", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
+                               "-Wno-unused-function", "-shared", "-o", LIB, srcs[0]])
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        vp, i32 = ctypes.c_void_p, ctypes.c_int
+        L.cb_emu_create.restype = vp
+        L.cb_emu_create.argtypes = [vp, vp, ctypes.c_char_p, i32]
+        L.cb_emu_destroy.argtypes = [vp]
+        L.cb_emu_get_layout.argtypes = [vp, vp]
+        L.cb_emu_workspace.restype = vp
+        L.cb_emu_workspace.argtypes = [vp]
+        L.cb_emu_reset.argtypes = [vp, vp, i32, vp]
+        L.cb_emu_step.argtypes = [vp] * 8
+        L.cb_emu_query.argtypes = [vp, i32, vp, i32, i32, vp, i32, i32, vp, i32, vp]
+        L.cb_emu_random_policy.argtypes = [vp, vp, vp, ctypes.c_int64, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class CbEmuBackend:
+    """numpy-facing batch backend; tests/cb_backend_adapter.py gives the GPU engine the same surface."""
+
+    def __init__(self, data, n_envs=1, start_tick=0, durations=100, snapshot_resolution=1, max_snapshots=None, max_actions=1,
+                 delivery_capacity=0, transfer_times_cap=0):
+        self.data = data
+        self._ts, self._keep = topology_struct(data)
+        self.cfg = MrxCbConfig(n_envs, 0, start_tick, durations, snapshot_resolution, max_snapshots or 0, max_actions,
+                               delivery_capacity, transfer_times_cap)
+        err = ctypes.create_string_buffer(256)
+        self._h = lib().cb_emu_create(ctypes.byref(self._ts), ctypes.byref(self.cfg), err, 256)
+        if not self._h:
+            raise RuntimeError(err.value.decode())
+        self.layout = MrxCbLayout()
+        lib().cb_emu_get_layout(self._h, ctypes.byref(self.layout))
+        self.n_envs, self.max_actions = n_envs, max_actions
+        self.start_tick, self.max_tick, self.res = start_tick, start_tick + durations, snapshot_resolution
+        base = lib().cb_emu_workspace(self._h)
+        self._ws = (ctypes.c_uint8 * self.layout.workspace_bytes).from_address(base)
+        self.ws = np.frombuffer(self._ws, dtype=np.uint8)
+        self._dec = np.zeros((n_envs, 8), np.int32)
+        self._scope = np.zeros((n_envs, self.layout.scope_cap, 2), np.int32)
+        self._met = np.zeros((n_envs, 3), np.int64)
+        self._done = np.zeros(n_envs, np.uint8)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().cb_emu_destroy(self._h)
+            self._h = None
+
+    def view(self, off, words):
+        """int32 [words, n_envs] view of a per-env SoA array."""
+        st = self.layout.env_stride
+        return self.ws[off:off + words * st * 4].view(np.int32).reshape(words, st)[:, :self.n_envs]
+
+    def reset(self, transfer_times=None, mask=None):
+        tt = None if transfer_times is None else np.ascontiguousarray(transfer_times, np.int32).reshape(self.n_envs, -1)
+        mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().cb_emu_reset(self._h, _ptr(tt), 0 if tt is None else tt.shape[1], _ptr(mk))
+
+    def step(self, actions=None, n_actions=None, mask=None):
+        a = None if actions is None else np.ascontiguousarray(actions, np.int32).reshape(self.n_envs, self.max_actions, 3)
+        na = None if n_actions is None else np.ascontiguousarray(n_actions, np.int32)
+        mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        lib().cb_emu_step(self._h, _ptr(a), _ptr(na), _ptr(mk), _ptr(self._dec), _ptr(self._scope), _ptr(self._met), _ptr(self._done))
+        return self._dec.copy(), self._scope.copy(), self._met.copy(), self._done.copy()
+
+    def random_policy(self, dec, scope, step):
+        a = np.zeros((self.n_envs, self.max_actions, 3), np.int32)
+        na = np.zeros(self.n_envs, np.int32)
+        lib().cb_emu_random_policy(self._h, _ptr(np.ascontiguousarray(dec, np.int32)), _ptr(np.ascontiguousarray(scope, np.int32)),
+                                   int(step), _ptr(a), _ptr(na))
+        return a, na
+
+    def query(self, node_type, ticks, nodes, attrs, row_slots):
+        t = np.ascontiguousarray(ticks, np.int32)
+        nt, per_env = t.shape[-1], (t.shape[-1] if t.ndim == 2 else 0)
+        n = np.ascontiguousarray(nodes, np.int32)
+        nn, npe = n.shape[-1], (n.shape[-1] if n.ndim == 2 else 0)
+        a = np.ascontiguousarray(attrs, np.int32)
+        out = np.zeros((self.n_envs, nt, nn, row_slots), np.float64)
+        lib().cb_emu_query(self._h, node_type, _ptr(t), nt, per_env, _ptr(n), nn, npe, _ptr(a), len(a), _ptr(out))
+        return out
+
+    def hdr(self):
+        return self.view(self.layout.off_hdr, 16)
+
+    def ring_fi(self):
+        return self.view(self.layout.off_ring_fi, self.layout.ring_slots)

@@ -1,0 +1,31 @@
+"""citi_bike device code on the CPU harness: batches with per-env actions and transfer times vs the oracle."""
+import numpy as np
+import pytest
+
+from maro_amd.citi_bike.data import load_topology
+from tests.cb_batch_check import run_batch_vs_oracle
+from tests.emu.cb_emu import CbEmuBackend
+
+
+@pytest.mark.parametrize("topology,kwargs,n", [
+    ("toy.3s_4t", dict(durations=1440, snapshot_resolution=10), 12),
+    ("toy.3s_tight", dict(durations=1100, snapshot_resolution=7, max_snapshots=9), 12),
+    ("toy.3s_tight", dict(start_tick=300, durations=500, snapshot_resolution=1), 6),
+])
+def test_batch_matches_oracle(topology, kwargs, n):
+    data = load_topology(topology)
+    b = CbEmuBackend(data, n_envs=n, max_actions=1, **kwargs)
+    steps = run_batch_vs_oracle(b, data, kwargs, seeds=np.arange(n) + 11, episodes=2)
+    assert steps > 20
+
+
+def test_masked_envs_do_not_move():
+    data = load_topology("toy.3s_4t")
+    b = CbEmuBackend(data, n_envs=4, durations=200)
+    b.reset(transfer_times=np.full((4, 8), 20))
+    mask = np.array([1, 0, 1, 0], np.uint8)
+    d0, _, _, _ = b.step()
+    t0 = b.hdr()[0].copy()
+    b.step(mask=mask)
+    t1 = b.hdr()[0]
+    assert (t1[[1, 3]] == t0[[1, 3]]).all()
