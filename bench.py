@@ -57,8 +57,151 @@ def cpu_baseline(topology, durations, budget_s):
             "note": "reference Python Env.step measured in the build container: ~311 env-steps/s (BASELINE.md §2)"}
 
 
+def cpu_baseline_citi_bike(topology, durations, res, budget_s):
+    """The pure-Python oracle (a port of the reference algorithm) timed on ONE host core, same agent."""
+    import numpy as np
+
+    from maro_amd.citi_bike.abi import draw_transfer_times
+    from maro_amd.citi_bike.data import load_topology
+    from oracle.citi_bike_oracle import CitiBikeOracle
+    from tests.cb_batch_check import policy_action
+
+    data = load_topology(topology)
+    steps = episodes = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        tt = draw_transfer_times(data, [episodes], 3 * (durations // data.resolution + 1))[0]
+        o = CitiBikeOracle(data, durations=durations, snapshot_resolution=res, max_snapshots=16, transfer_times=tt)
+        m, de, done = o.step(None)
+        k = 0
+        while not done and time.perf_counter() - t0 < budget_s:
+            k += 1
+            act = policy_action(k, episodes, de)
+            m, de, done = o.step([act] if act else None)
+            steps += 1
+        episodes += 1
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} decisions of {topology} ({episodes} episode(s), pure-Python oracle, {dt:.1f} s on 1 core)"}
+
+
+def bench_citi_bike(args):
+    """BASELINE.json configs[3]: citi_bike toy.3s_4t, 4096 envs per GPU, shared trip table, per-env action seeds.
+    One step = device policy -> mrx_cb_step (action + ticks until the next decision) -> stations snapshot slice."""
+    import torch
+
+    import __graft_entry__ as ge
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        ge.build()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dist.barrier()
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    import numpy as np
+
+    from maro_amd.citi_bike.engine import CitiBikeBatchEngine
+
+    n, res = args.envs, 10
+    topology = args.topology if args.topology != "global_trade.22p_l0.8" else "toy.3s_4t"
+    durations = args.durations if args.durations != 1120 else 44000
+    eng = CitiBikeBatchEngine(topology, n, durations=durations, snapshot_resolution=res, max_snapshots=16, max_actions=1, device=dev,
+                              seeds=np.arange(n) + rank * n + 1)
+    S = eng.data.n_stations
+    actions = torch.zeros((n, 1, 3), dtype=torch.int32, device=dev)
+    n_actions = torch.zeros((n,), dtype=torch.int32, device=dev)
+    counter = torch.zeros((1,), dtype=torch.int64, device=dev)
+    stations = torch.arange(S, dtype=torch.int32, device=dev)
+    q_attrs = ["bikes", "shortage", "trip_requirement", "fulfillment", "capacity", "extra_cost", "min_bikes"]
+    q_out = None if args.no_query else torch.empty((n, 1, S, len(q_attrs)), dtype=torch.float64, device=dev)
+
+    def one_step(i):
+        if i == 0:
+            eng.step()
+            return
+        eng.random_policy(i, actions, n_actions, counter)
+        eng.step(actions, n_actions)
+        if q_out is not None:
+            eng.query("stations", eng.decisions[:, 3:4], stations, q_attrs, out=q_out)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    step_i = 0
+    for _ in range(args.warmup):
+        one_step(step_i)
+        step_i += 1
+    sync_all()
+    counter.zero_()
+    tick0 = eng.ticks.to(torch.int64).sum().item()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(step_i)
+        step_i += 1
+    sync_all()
+    dt = time.perf_counter() - t0
+    resolved = int(counter.item())
+    ticks_adv = eng.ticks.to(torch.int64).sum().item() - tick0
+    n_done = int(eng.done.sum().item())
+    status_bad = int((eng.status != 0).sum().item())
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 100))]
+    for a, b in ev:
+        eng.random_policy(step_i, actions, n_actions, None)
+        a.record()
+        eng.step(actions, n_actions)
+        b.record()
+        step_i += 1
+    torch.cuda.synchronize(dev)
+    step_kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(resolved), float(ticks_adv), float(n_done), float(status_bad)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt = float(t_max.item())
+    resolved, ticks_adv, n_done, status_bad = (float(x) for x in tot.tolist())
+    if rank == 0:
+        tbar = ticks_adv / max(resolved, 1.0)
+        F = S * 48 + 4 * S * S                       # SURVEY.md §8(a20): reference-dtype frame bytes (180 B for 3 stations)
+        n_trips = float((eng.data.trip_tick < durations).sum())
+        b_step = (3.0 + tbar / res) * F + 20.0 * (n_trips / durations) * tbar + 40.0   # SURVEY.md §8(d) general form
+        achieved = b_step * n / (step_kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec (decision events/sec), citi_bike toy.3s_4t",
+            "value": resolved / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32+f64", "data": "synthetic",
+            "config": {"workload": f"citi_bike {topology}, {n} envs/GPU x {world} GPU, durations {durations}, resolution {res}, "
+                                   f"device policy, stations snapshot slice {'off' if args.no_query else 'every step'}",
+                       "envs_per_gpu": n, "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective)",
+                       "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
+            "roofline": {"bound": "hbm", "kernel": "mrx_k_cb_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": step_kernel_ms,
+                         "algorithmic_bytes_per_env_step": b_step, "env_steps_per_launch": n,
+                         "note": "latency-bound by construction (SURVEY.md §8d: ~1 KB per env-step); the roofline fraction is judged on the CIM 22p workload"},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline_citi_bike(topology, min(durations, 1440), res, args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--scenario", default="cim", choices=["cim", "citi_bike"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=100)
@@ -70,6 +213,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+    if args.scenario == "citi_bike":
+        return bench_citi_bike(args)
 
     import torch
 

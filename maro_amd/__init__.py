@@ -1,8 +1,8 @@
-"""maro_amd — MI355X-native batched rollout engine for MARO's CIM simulator.
+"""maro_amd — MI355X-native batched rollout engines for MARO's CIM and citi_bike simulators.
 
-    from maro_amd import CimBatchEngine, GpuVectorEnv
+    from maro_amd import CimBatchEngine, CitiBikeBatchEngine, GpuVectorEnv
 
-The compute path is the HIP library maro_amd/csrc/libmaro_amd.so (C ABI: include/maro_amd.h); there is no
+The compute path is the HIP library maro_amd/csrc/libmaro_amd.so (C ABI: include/maro_amd.h, include/maro_amd_citi_bike.h); there is no
 CPU fallback.  Importing this package does not load the library; constructing an engine does.
 """
 __version__ = "0.1.0"
@@ -18,6 +18,9 @@ def __getattr__(name):
     if name in ("Action", "ActionType", "ActionScope", "DecisionEvent"):
         from .cim import payloads
         return getattr(payloads, name)
+    if name in ("CitiBikeBatchEngine",):
+        from .citi_bike.engine import CitiBikeBatchEngine
+        return CitiBikeBatchEngine
     if name in ("load_topology", "CimTopology"):
         from .cim import topology
         return getattr(topology, name)

@@ -1,0 +1,97 @@
+"""citi_bike host-side object API (GpuVectorEnv(scenario="citi_bike") / env views / payloads / snapshot slicing)
+against the oracle.  Runs on the host-compiled device code here; test_gpu_citi_bike_api.py runs it on the HIP engine."""
+import pickle
+
+import numpy as np
+import pytest
+
+from maro_amd.cim.vector_env import BackendsInvalidAttributeException, GpuVectorEnv
+from maro_amd.citi_bike.abi import STATION_ATTRS, draw_transfer_times
+from maro_amd.citi_bike.data import load_topology
+from maro_amd.citi_bike.payloads import Action, DecisionEvent, DecisionType
+from maro_amd.citi_bike.vector_env import CitiBikeVectorEnv
+from oracle.citi_bike_oracle import CitiBikeOracle
+
+TOPO = "toy.3s_tight"
+KW = dict(durations=400, snapshot_resolution=5)
+
+
+def emu_factory(topology, n, **kw):
+    from tests.emu.cb_emu_engine import CbEmuEngine
+    return CbEmuEngine(topology, n, **kw)
+
+
+def check_vector_env(engine_factory):
+    seeds = [5, 6, 7]
+    eng = engine_factory(TOPO, 3, max_actions=2, seeds=seeds, **KW)
+    env = GpuVectorEnv(3, "citi_bike", TOPO, _engine=eng, **KW)
+    assert isinstance(env, CitiBikeVectorEnv) and env.batch_number == 3
+    data = load_topology(TOPO)
+    tts = draw_transfer_times(data, seeds, eng.layout.transfer_times_cap)
+    oracles = [CitiBikeOracle(data, transfer_times=tts[e], **KW) for e in range(3)]
+    ost = [o.step(None) for o in oracles]
+    metrics, events, all_done = env.step(None)
+    step = 0
+    while not all_done:
+        actions = []
+        for e, (ev, (om, od, odone)) in enumerate(zip(events, ost)):
+            if ev is None:
+                assert odone and (metrics[e] is None or metrics[e] == om)
+                actions.append(None)
+                continue
+            assert isinstance(ev, DecisionEvent)
+            assert (ev.tick, ev.station_idx, ev.frame_index) == (od["tick"], od["station_idx"], od["frame_index"])
+            assert ev.type == (DecisionType.Supply if od["type"] == 0 else DecisionType.Demand)
+            assert list(ev.action_scope.items()) == [tuple(x) for x in od["action_scope"]]
+            assert metrics[e] == om
+            others = [k for k in ev.action_scope if k != ev.station_idx]
+            n = min(ev.action_scope[ev.station_idx], ev.action_scope[others[0]])
+            frm, to = (ev.station_idx, others[0]) if ev.type == DecisionType.Supply else (others[0], ev.station_idx)
+            if step == 4 and e == 1:
+                ev2 = pickle.loads(pickle.dumps(ev))
+                assert ev2.action_scope == ev.action_scope and ev2.type == ev.type
+                # slicing while paused: the decision's frame is the live state; missing frames are zero padded
+                view = env.env_view(e)
+                sl = view.snapshot_list
+                assert len(sl["stations"]) == 3 and sl["nope"] is None and sl["stations"][0::] is None
+                fis = sl.get_frame_index_list()
+                assert fis == oracles[e].frame_indices() and fis[-1] == ev.frame_index
+                got = sl["stations"][::STATION_ATTRS]
+                assert np.array_equal(got, oracles[e].query("stations", [], [], STATION_ATTRS))
+                got = sl["stations"][[ev.frame_index, 999]:[2, 0]:["bikes", "capacity", "weekday"]]
+                assert np.array_equal(got, oracles[e].query("stations", [ev.frame_index, 999], [2, 0], ["bikes", "capacity", "weekday"]))
+                assert np.array_equal(sl["matrices"][ev.frame_index::"trips_adj"], oracles[e].query("matrices", [ev.frame_index], [], ["trips_adj"]))
+                with pytest.raises(BackendsInvalidAttributeException):
+                    sl["stations"][0:0:"no_such_attr"]
+                assert view.tick == ev.tick and view.frame_index == ev.frame_index and view.agent_idx_list == [0, 1, 2]
+                assert view.metrics == om
+            if e == 0:      # no action
+                actions.append(None)
+                ost[e] = oracles[e].step(None)
+            elif e == 1:    # one Action object
+                actions.append(Action(frm, to, n))
+                ost[e] = oracles[e].step([(frm, to, n)])
+            else:           # a list of two actions, one of them with an ignored negative station index
+                actions.append([Action(frm, to, n // 2), Action(-1, to, 3)])
+                ost[e] = oracles[e].step([(frm, to, n // 2), (-1, to, 3)])
+        metrics, events, all_done = env.step(actions)
+        step += 1
+    for e in range(3):
+        assert ost[e][2] and metrics[e] in (None, ost[e][0]) and env.env_view(e).metrics == ost[e][0]
+    assert env.step(None) == ([None] * 3, [None] * 3, True)
+    # full-history tensors, per env (ragged list API) after the episode
+    got = env.snapshot_list["stations"][::["bikes", "shortage", "min_bikes", "failed_return", "extra_cost"]]
+    for e in range(3):
+        assert np.array_equal(got[e], oracles[e].query("stations", [], [], ["bikes", "shortage", "min_bikes", "failed_return", "extra_cost"]))
+    # reset one env through its view: same transfer-time stream again -> same trajectory
+    v = env.env_view(1)
+    v.reset()
+    o = CitiBikeOracle(data, transfer_times=tts[1], **KW)
+    m, ev, done = v.step(None)
+    om, od, _ = o.step(None)
+    assert m == om and ev.tick == od["tick"] and ev.station_idx == od["station_idx"]
+    return step
+
+
+def test_vector_env_on_host_compiled_device_code():
+    assert check_vector_env(emu_factory) > 10
