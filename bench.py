@@ -3,7 +3,7 @@
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
     CIM global_trade.22p_l0.8, 16384 envs per GPU, durations 1120, device-side random legal agent,
-    snapshot_list["ports"][frame::7 attrs] sliced for every env every step.
+    snapshot_list["ports"][frame::7 attrs] and ["vessels"][frame:vessel:3 attrs] sliced for every env every step.
 One "step" = one pass of the hot path over the whole batch:
     random-policy kernel -> mrx_cim_step (action + ticks until the next decision) -> snapshot query.
 value = decision events resolved per second, whole job (all ranks), state resident in HBM.
@@ -24,6 +24,7 @@ sys.path.insert(0, REPO)
 # reference-dtype frame bytes per env and targets per topology family
 FRAME_BYTES = {"global_trade.22p": 15412, "toy.4p_ssdd": 886}
 QUERY_ATTRS = ["empty", "full", "on_shipper", "on_consignee", "booking", "shortage", "fulfillment"]
+VESSEL_QUERY_ATTRS = ["empty", "full", "remaining_space"]
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -205,7 +206,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--envs", type=int, default=16384, help="environments per GPU (weak scaling)")
+    ap.add_argument("--envs", type=int, default=None, help="environments per GPU (weak scaling); default 16384 (cim) / 4096 (citi_bike)")
+    ap.add_argument("--groups", type=int, default=2, help="independent env groups per GPU, each on its own HIP stream (cim)")
     ap.add_argument("--topology", default="global_trade.22p_l0.8")
     ap.add_argument("--durations", type=int, default=1120)
     ap.add_argument("--ring", type=int, default=4, help="snapshot ring slots per env (max_snapshots)")
@@ -213,6 +215,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+    if args.envs is None:
+        args.envs = 16384 if args.scenario == "cim" else 4096
     if args.scenario == "citi_bike":
         return bench_citi_bike(args)
 
@@ -236,25 +240,43 @@ def main():
 
     from maro_amd.cim.engine import CimBatchEngine
 
-    n = args.envs
-    seeds = torch.arange(n, dtype=torch.int64) + rank * n + 1
-    eng = CimBatchEngine(args.topology, n, durations=args.durations, max_snapshots=args.ring, max_actions=1,
-                         device=dev, seeds=seeds)
-    topo = eng.topo
-    actions = torch.zeros((n, 1, 4), dtype=torch.int32, device=dev)
-    n_actions = torch.zeros((n,), dtype=torch.int32, device=dev)
-    counter = torch.zeros((1,), dtype=torch.int64, device=dev)
+    # The per-GPU batch is split into G independent groups, each with its own engine and HIP stream: a step kernel
+    # ends with a tail of long (ticking) waves while most of the chip is already idle, and the next group's kernel
+    # fills exactly that tail.  Envs never interact, so this is pure scheduling.
+    n, G = args.envs, max(1, args.groups)
+    assert n % G == 0, "--envs must be divisible by --groups"
+    ng = n // G
+    engines, streams, bufs = [], [], []
+    for g in range(G):
+        seeds = torch.arange(ng, dtype=torch.int64) + rank * n + g * ng + 1
+        eng = CimBatchEngine(args.topology, ng, durations=args.durations, max_snapshots=args.ring, max_actions=1, device=dev, seeds=seeds)
+        engines.append(eng)
+        streams.append(torch.cuda.Stream(device=dev) if G > 1 else torch.cuda.current_stream(dev))
+        bufs.append(dict(actions=torch.zeros((ng, 1, 4), dtype=torch.int32, device=dev),
+                         n_actions=torch.zeros((ng,), dtype=torch.int32, device=dev),
+                         counter=torch.zeros((1,), dtype=torch.int64, device=dev),
+                         q_ports=None if args.no_query else torch.empty((ng, 1, engines[0].topo.n_ports, len(QUERY_ATTRS)), dtype=torch.float64, device=dev),
+                         q_vessel=None if args.no_query else torch.empty((ng, 1, 1, len(VESSEL_QUERY_ATTRS)), dtype=torch.float64, device=dev)))
+    topo = engines[0].topo
     ports = torch.arange(topo.n_ports, dtype=torch.int32, device=dev)
-    q_out = None if args.no_query else torch.empty((n, 1, topo.n_ports, len(QUERY_ATTRS)), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize(dev)
 
-    def one_step(i):
-        if i == 0:
-            eng.step()  # first step of the episode: action=None
-            return
-        eng.random_policy(i, actions, n_actions, counter)
-        eng.step(actions, n_actions)
-        if q_out is not None:
-            eng.query("ports", eng.decisions[:, 6:7], ports, QUERY_ATTRS, out=q_out)
+    def one_step(i, g, timing=None):
+        eng, b = engines[g], bufs[g]
+        with torch.cuda.stream(streams[g]):
+            if i == 0:
+                eng.step()  # first step of the episode: action=None
+                return
+            eng.random_policy(i, b["actions"], b["n_actions"], b["counter"] if timing is None else None)
+            if timing is not None:
+                timing[0].record()
+            eng.step(b["actions"], b["n_actions"])
+            if timing is not None:
+                timing[1].record()
+            if b["q_ports"] is not None:
+                # ports[frame::7 attrs] and vessels[frame:vessel:3 attrs] of the pending decision
+                eng.query("ports", eng.decisions[:, 6:7], ports, QUERY_ATTRS, out=b["q_ports"])
+                eng.query("vessels", eng.decisions[:, 6:7], eng.decisions[:, 2:3], VESSEL_QUERY_ATTRS, out=b["q_vessel"])
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -262,36 +284,46 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    def total_ticks():
+        return sum(e.ticks.to(torch.int64).sum().item() for e in engines)
+
     step_i = 0
     for _ in range(args.warmup):
-        one_step(step_i)
+        for g in range(G):
+            one_step(step_i, g)
         step_i += 1
     sync_all()
-    counter.zero_()
-    tick0 = eng.ticks.to(torch.int64).sum().item()
+    for b in bufs:
+        b["counter"].zero_()
+    tick0 = total_ticks()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step(step_i)
+        for g in range(G):
+            one_step(step_i, g)
         step_i += 1
     sync_all()
     dt = time.perf_counter() - t0
-    # decisions answered inside the timed window (+1 policy call lag is exact: K policy calls in the window)
-    resolved = int(counter.item())
-    ticks_adv = eng.ticks.to(torch.int64).sum().item() - tick0
-    n_done = int(eng.done.sum().item())
-    status_bad = int((eng.status != 0).sum().item())
+    # decisions answered inside the timed window (K policy calls per group in the window)
+    resolved = sum(int(b["counter"].item()) for b in bufs)
+    ticks_adv = total_ticks() - tick0
+    n_done = sum(int(e.done.sum().item()) for e in engines)
+    status_bad = sum(int((e.status != 0).sum().item()) for e in engines)
 
-    # ---- dominant kernel (mrx_k_cim_step) timed live with HIP events on the launch stream
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 100))]
-    for a, b in ev:
-        eng.random_policy(step_i, actions, n_actions, None)
-        a.record()
-        eng.step(actions, n_actions)
-        b.record()
+    # ---- dominant kernel (mrx_k_cim_step) timed live with HIP events, each pair on the stream of its launch, in
+    # the same interleaved schedule as the timed loop
+    reps = min(args.steps, 100)
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(G)] for _ in range(reps)]
+    sync_all()
+    for r in range(reps):
+        for g in range(G):
+            one_step(step_i, g, timing=ev[r][g])
         step_i += 1
     torch.cuda.synchronize(dev)
-    step_kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    durs = [a.elapsed_time(b) for row in ev for a, b in row]
+    step_kernel_ms = sum(durs) / len(durs)                      # mean duration of one launch (ng envs)
+    span_ms = max([ev[0][g][0].elapsed_time(ev[-1][g2][1]) for g in range(G) for g2 in range(G)]) if G > 1 else sum(durs)
+    in_flight = max(1.0, sum(durs) / span_ms) if G > 1 else 1.0    # mean number of step kernels running concurrently
 
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(resolved), float(ticks_adv), float(n_done), float(status_bad)], dtype=torch.float64, device=dev)
@@ -306,13 +338,14 @@ def main():
         tbar = ticks_adv / max(resolved, 1.0)  # mean ticks advanced per env-step
         F = frame_bytes(topo)
         b_step = (3.0 + tbar) * F + 4.0 * topo.n_targets * tbar + 40.0
-        bytes_per_launch = b_step * n
-        achieved = bytes_per_launch / (step_kernel_ms * 1e-3) / 1e9
+        bytes_per_launch = b_step * ng
+        # one launch moves bytes_per_launch in step_kernel_ms, and `in_flight` launches (one per group/stream) overlap
+        achieved = bytes_per_launch / (step_kernel_ms * 1e-3) / 1e9 * in_flight
         traffic = None  # HBM bytes per launch from the committed PMC passes of this same workload (profiles/)
         try:
             with open(os.path.join(REPO, "profiles", "latest_pmc.json")) as fp:
                 pmc = json.load(fp)
-            if pmc["topology"] == args.topology and pmc["envs_per_launch"] == n:
+            if pmc["topology"] == args.topology and pmc["envs_per_launch"] == ng:
                 traffic = (2.0 * pmc["fetch_size_kib"] + pmc["write_size_kib"]) * 1024.0
         except Exception:
             pass
@@ -322,13 +355,15 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {args.durations}, "
-                                   f"random legal agent on device, ports snapshot slice {'off' if args.no_query else 'every step'}",
-                       "envs_per_gpu": n, "ring_slots": args.ring, "parallelism": f"env-shard x{world} (no data-path collective)",
+                                   f"random legal agent on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step'}",
+                       "envs_per_gpu": n, "groups_per_gpu": G, "envs_per_launch": ng, "ring_slots": args.ring,
+                       "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
             "roofline": {"bound": "hbm", "kernel": "mrx_k_cim_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": "profiles/latest_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": step_kernel_ms,
-                         "algorithmic_bytes_per_env_step": b_step, "env_steps_per_launch": n},
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": step_kernel_ms, "launches_in_flight": in_flight,
+                         "definition": "achieved = algorithmic_bytes_per_launch / kernel_ms x launches_in_flight (mean number of overlapping step kernels, one per group stream)",
+                         "algorithmic_bytes_per_env_step": b_step, "env_steps_per_launch": ng},
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.topology, args.durations, args.cpu_seconds)

@@ -111,6 +111,11 @@ typedef struct mrx_cim_config {
   int32_t max_snapshots;       /* core.py:49; <=0 -> ceil(durations/resolution) (abs_business_engine.py:115-129) */
   int32_t max_actions;         /* A: actions accepted per decision event per step (>=1) */
   int32_t max_stops;           /* <=0 -> engine computes a safe bound per vessel */
+  int32_t order_table;         /* 0 = auto, 1 = on, -1 = off.  In `fixed` order mode the orders of a tick are a pure
+                                  function of (seed, tick) (cim_data_container.py:309-398), so mrx_cim_reset can draw
+                                  the whole episode's order table ahead of time (int32 [durations][n_targets] per env)
+                                  and the step kernel reads its tick's row instead of generating it.  auto = on
+                                  whenever the topology allows it. */
 } mrx_cim_config;
 
 /* Word (4-byte) offsets describing the engine's HBM layout inside the workspace, so the
@@ -138,6 +143,9 @@ typedef struct mrx_cim_layout {
   int64_t off_nstops;  /* int32 [n_envs][V] */
   int64_t off_order_prop; /* int32 [n_envs or 1][max_tick] */
   int64_t off_vessel_period; /* int32 [n_envs][V] vessel_period_without_noise */
+  int64_t off_orders;        /* int32 [n_envs][durations][order_row_words] pre-generated order quantities per
+                                (src, dst) pair in target_offset CSR order; 0 when the order table is off */
+  int32_t order_row_words, order_table_on;
   int64_t workspace_bytes;
 } mrx_cim_layout;
 

@@ -16,7 +16,7 @@ class MrxCimConfig(ctypes.Structure):
     """ctypes mirror of ``struct mrx_cim_config`` (include/maro_amd.h)."""
 
     _fields_ = [(n, ctypes.c_int32) for n in ("n_envs", "device", "start_tick", "durations", "snapshot_resolution",
-                                              "max_snapshots", "max_actions", "max_stops")]
+                                              "max_snapshots", "max_actions", "max_stops", "order_table")]
 
 
 class MrxCimLayout(ctypes.Structure):
@@ -28,7 +28,9 @@ class MrxCimLayout(ctypes.Structure):
                                                "frame_off_vessel_plans")]
                 + [(n, ctypes.c_int64) for n in ("off_live", "off_ring", "off_ring_fi", "off_status", "off_tick",
                                                  "off_seed", "off_stops", "off_nstops", "off_order_prop",
-                                                 "off_vessel_period", "workspace_bytes")])
+                                                 "off_vessel_period", "off_orders")]
+                + [(n, ctypes.c_int32) for n in ("order_row_words", "order_table_on")]
+                + [("workspace_bytes", ctypes.c_int64)])
 
 
 EXPORTS = ("mrx_last_error", "mrx_version", "mrx_cim_workspace_bytes", "mrx_cim_create", "mrx_cim_destroy",

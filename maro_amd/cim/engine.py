@@ -37,7 +37,7 @@ class CimBatchEngine:
 
     def __init__(self, topology: Union[str, CimTopology], n_envs: int, start_tick: int = 0, durations: int = 100,
                  snapshot_resolution: int = 1, max_snapshots: Optional[int] = None, max_actions: int = 1,
-                 device: Union[str, torch.device] = "cuda:0", seeds: Optional[Sequence[int]] = None):
+                 device: Union[str, torch.device] = "cuda:0", seeds: Optional[Sequence[int]] = None, order_table: int = 0):
         self._L = _lib.load()  # raises if the HIP extension is not built
         if not torch.cuda.is_available():
             raise RuntimeError("maro_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
@@ -50,7 +50,7 @@ class CimBatchEngine:
         self.snapshot_resolution = int(snapshot_resolution)
         self._cs = self.topo.c_struct()
         self._cfg = _lib.MrxCimConfig(self.n_envs, dev_index, self.start_tick, self.durations,
-                                      self.snapshot_resolution, int(max_snapshots or 0), self.max_actions, 0)
+                                      self.snapshot_resolution, int(max_snapshots or 0), self.max_actions, 0, int(order_table))
         nbytes = self._L.mrx_cim_workspace_bytes(ctypes.byref(self._cs), ctypes.byref(self._cfg))
         _lib.check(nbytes, "mrx_cim_workspace_bytes")
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)

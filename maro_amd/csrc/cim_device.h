@@ -26,6 +26,7 @@ namespace cim {
 #ifndef MRX_PROFILE_PHASES
 struct Prof {
   MRX_DEV void mark(int) {}
+  MRX_DEV void mark(int, long long) {}
   MRX_DEV void flush() {}
 };
 #endif
@@ -245,6 +246,221 @@ MRX_DEV void write_future_and_plans(const CimParams& K, Lds& L, int v, int pos, 
   }
 }
 
+
+// Everything a tick needs from HBM/L2, requested one memory round trip ahead of its use (a wave issues in
+// order, so un-hidden loads stall the serial sections):
+//  * per-pair fp64 noise tables and source-port ids for the first 3 x 64 pairs (lane k holds pair k0+lane),
+//  * the tick's order count,
+//  * for the vessels that will arrive in that tick (known before the tick starts: a vessel departing in tick t
+//    cannot arrive in tick t): their discharge records (lane j = j-th candidate load stop) and stop-table
+//    entries (lane a = a-th arriving vessel).
+struct TickPf {
+  double tb[3], tn[3];
+  int src[3];
+  int q[4], key[4];
+  int ns, otg;
+  int oqr[3];  // order table: quantities of pairs lane + 64 b of the coming tick
+  uint32_t stk, stk1;
+  uint64_t arr_mask;
+};
+
+// All prefetch loads are branch-free (addresses clamped to valid memory, validity re-derived at the point of
+// use), so the compiler has no control-flow merge that would force an early s_waitcnt.
+// consume every prefetched register in one straight-line place (see wave::touch)
+MRX_DEV void tick_prefetch_land(TickPf& pf) {
+#pragma unroll
+  for (int b = 0; b < 3; b++) { wave::touch(pf.tb[b]); wave::touch(pf.tn[b]); wave::touch(pf.src[b]); }
+#pragma unroll
+  for (int a = 0; a < 4; a++) { wave::touch(pf.q[a]); wave::touch(pf.key[a]); }
+  wave::touch(pf.ns); wave::touch(pf.otg); wave::touch(pf.stk); wave::touch(pf.stk1);
+#pragma unroll
+  for (int b = 0; b < 3; b++) wave::touch(pf.oqr[b]);
+}
+
+// static per-pair tables of pairs lane + 64 b: source port (phases B2/B3) and, for the order generator, the
+// target ratios
+MRX_DEV void tick_prefetch_static(const CimParams& K, TickPf& pf, bool generator) {
+  const int lane = wave::lane();
+  const int last = K.NT > 0 ? K.NT - 1 : 0;
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    int k = b * 64 + lane;
+    k = k < last ? k : last;
+    pf.src[b] = K.pair_src[k];
+    if (generator) { pf.tb[b] = K.tgt_base[k]; pf.tn[b] = K.tgt_noise[k]; }
+  }
+}
+
+// stop-table entries and discharge records of the first (up to) four vessels of `mask`
+MRX_DEV void tick_prefetch_arrivals(const CimParams& K, int env, Lds& L, uint64_t mask, TickPf& pf) {
+  const int lane = wave::lane();
+  const int V = K.V;
+  const Tabs& T = L.tab;
+  const int32_t* g_rec = K.rec + (size_t)env * K.REC_W;
+  // lane a (< 4) fetches the stop-table entries of the a-th arriving vessel
+  {
+    uint64_t m = mask;
+    int v = 0;
+    for (int a = 0; a < 4; a++) {
+      const int va = m ? __builtin_ctzll(m) : 0;
+      if (m) m &= m - 1;
+      if (lane == a) v = va;
+    }
+    const int k = FV(VA_NEXT_LOC_IDX, lane < 4 ? v : 0);
+    const size_t srow = ((size_t)env * V + v) * K.SMAX;
+    pf.ns = K.nstops[(size_t)env * V + v];
+    pf.stk = K.stops[srow + (k < K.SMAX ? k : 0)];
+    pf.stk1 = K.stops[srow + (k + 1 < K.SMAX ? k + 1 : 0)];
+  }
+  // lane j fetches the j-th candidate discharge record (and its load tick) of each of those vessels
+  uint64_t m = mask;
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    const int v = m ? __builtin_ctzll(m) : 0;  // wave-uniform; vessel 0 is a harmless stand-in when fewer arrive
+    if (m) m &= m - 1;
+    const int k = U(FV(VA_NEXT_LOC_IDX, v));
+    const int Lr = T.v_route_len[v], RL = Lr + 1, krl = U(V_KRL(v));
+    const int sidx = k - Lr + lane;
+    int col = krl + 1 + lane;
+    if (col >= RL) col -= RL;
+    const bool ok = lane < Lr && sidx >= 0;
+    pf.q[a] = g_rec[T.rec_off[v] + krl * RL + (ok ? col : 0)];
+    pf.key[a] = (int)K.stops[((size_t)env * V + v) * K.SMAX + (ok ? sidx : 0)];
+  }
+}
+
+// PG = the episode's orders were drawn by mrx_cim_reset (CimParams::pregen): the tick's row of the order table
+// replaces the order count and the generator's inputs.
+template <bool PG>
+MRX_DEV void tick_prefetch(const CimParams& K, int env, Lds& L, int t, TickPf& pf) {
+  const int lane = wave::lane();
+  if constexpr (PG) {
+    const int32_t* row = K.orders + ((size_t)env * (K.T - K.start_tick) + (size_t)(t - K.start_tick)) * K.NTP;
+#pragma unroll
+    for (int b = 0; b < 3; b++) pf.oqr[b] = row[b * 64 + lane < K.NTP ? b * 64 + lane : 0];
+    pf.otg = 0;
+  } else {
+    pf.otg = K.order_prop[(size_t)env * K.T + t];
+  }
+  const bool arr = lane < K.V && !FV(VA_IS_PARKING, lane) && FV(VA_NEXT_LOC_IDX, lane) > 0 && V_EVT(lane) == t;
+  pf.arr_mask = wave::ballot(arr);
+  tick_prefetch_arrivals(K, env, L, pf.arr_mask, pf);
+}
+
+// ==========================================================================================
+// Order generation of one tick (cim_data_container.py:309-398): `otg` orders -> L.oq[pair].  Used by the step kernel
+// (online generation) and by the reset kernel (order table).  pf.tb / tn / src hold the target tables of pairs
+// lane + 64 b (tick_prefetch_static).
+MRX_DEV void gen_orders(const CimParams& K, Lds& L, long long otg, int& idx_ord, const TickPf& pf) {
+  const int lane = wave::lane();
+  const int P = K.P, NT = K.NT;
+  const Tabs& T = L.tab;
+  for (int k = lane; k < NT; k += 64) L.oq[k] = 0;
+  double ns = 0.0;
+  if (K.use_order_rng) {
+    const double r = mt_draw_batch(L.mt_ord, idx_ord, lane < P ? lane : -1, P);
+    if (lane < P) ns = apply_noise(T.src_base[lane], T.src_noise[lane], r);
+  } else if (lane < P) {
+    ns = T.src_base[lane] + 0.0;
+  }
+  if (lane < P) L.dsrc[lane] = ns;
+  wave::sync();
+  // list_sum_normalize (utils.py:44-56): left-to-right fp64 sum, then one division per port (lane-parallel)
+  double tot = 0.0;
+  for (int p = 0; p < P; p++) tot += L.dsrc[p];
+  long long c = 0;
+  if (lane < P) {
+    const double ratio = (tot == 0.0) ? ns : ns / tot;
+    c = (long long)ceil((double)otg * ratio);
+    if (c > 0x7fffffffll) c = 0x7fffffffll;
+    if (c < -0x7fffffffll) c = -0x7fffffffll;
+  }
+  // sequential split with early break (:354-375): n_p = min(c_p, remaining), remaining -= n_p, stop at remaining == 0
+  int brk = P;
+  const uint64_t negm = wave::ballot(lane < P && c < 0);
+  if (!negm) {  // usual case: a clamped prefix sum
+    const long long incl = (long long)wave::scan_incl_add((int)(lane < P ? (c < otg ? c : otg) : 0));  // terms capped at otg: no overflow
+    const long long rem_top = otg - (incl - (c < otg ? c : otg));  // remaining orders when port `lane` is reached
+    const uint64_t zm = wave::ballot(lane < P && rem_top <= 0);
+    if (zm) brk = __builtin_ctzll(zm);
+    if (lane < P) L.srcn[lane] = (int32_t)(rem_top <= 0 ? 0 : (c < rem_top ? c : rem_top));
+  } else {  // a negative noised ratio makes `remaining` grow: replay the reference loop literally
+    if (lane < P) L.srcn[lane] = (int32_t)c;
+    wave::sync();
+    long long remaining = otg;
+    for (int p = 0; p < P; p++) {
+      if (remaining == 0) { brk = p; break; }
+      long long cp = (long long)U(L.srcn[p]);
+      if (cp > remaining) cp = remaining;
+      remaining -= cp;
+      if (lane == 0) L.srcn[p] = (int32_t)cp;
+    }
+  }
+  const int NTb = T.tgt_off[brk];
+#define MRX_TGT_BATCH(k0, TB, TN)                                                              \
+  {                                                                                          \
+    const int k = (k0) + lane;                                                               \
+    const int n = (NTb - (k0)) < 64 ? (NTb - (k0)) : 64;                                      \
+    if (K.use_order_rng) {                                                                   \
+      const double r = mt_draw_batch(L.mt_ord, idx_ord, k < NTb ? lane : -1, n);             \
+      if (k < NTb) L.dtgt[k] = apply_noise(TB, TN, r);                                       \
+    } else if (k < NTb) {                                                                    \
+      L.dtgt[k] = (TB) + 0.0;                                                                \
+    }                                                                                        \
+  }
+  if (NTb > 0) MRX_TGT_BATCH(0, pf.tb[0], pf.tn[0])
+  if (NTb > 64) MRX_TGT_BATCH(64, pf.tb[1], pf.tn[1])
+  if (NTb > 128) MRX_TGT_BATCH(128, pf.tb[2], pf.tn[2])
+  for (int k0 = 192; k0 < NTb; k0 += 64) MRX_TGT_BATCH(k0, K.tgt_base[k0 + lane < NT ? k0 + lane : 0], K.tgt_noise[k0 + lane < NT ? k0 + lane : 0])
+#undef MRX_TGT_BATCH
+  wave::sync();
+  // per-port normaliser: left-to-right sum of its noised target ratios (:361-366)
+  if (lane < brk) {
+    const int off = T.tgt_off[lane], cnt = T.tgt_off[lane + 1] - off;
+    double ts = 0.0;
+    for (int j = 0; j < cnt; j++) ts += L.dtgt[off + j];
+    L.dsrc[lane] = ts;
+  }
+  wave::sync();
+  // one division per (src, dst) pair, lane-parallel: raw ceil(n_src * ratio) (:380)
+#define MRX_PAIR_BATCH(k0, SRC)                                                                     \
+  {                                                                                               \
+    const int k = (k0) + lane;                                                                    \
+    if (k < NTb) {                                                                                \
+      const int sp = (SRC);                                                                       \
+      const long long n_p = L.srcn[sp];                                                           \
+      long long cur = 0;                                                                          \
+      if (n_p > 0) {                                                                              \
+        const double ts = L.dsrc[sp], x = L.dtgt[k];                                              \
+        cur = (long long)ceil((double)n_p * ((ts == 0.0) ? x : x / ts));                          \
+        if (cur > 0x7fffffffll) cur = 0x7fffffffll;                                               \
+        if (cur < -0x7fffffffll) cur = -0x7fffffffll;                                             \
+      }                                                                                           \
+      L.oq[k] = (int32_t)cur;                                                                     \
+    }                                                                                             \
+  }
+  if (NTb > 0) MRX_PAIR_BATCH(0, pf.src[0])
+  if (NTb > 64) MRX_PAIR_BATCH(64, pf.src[1])
+  if (NTb > 128) MRX_PAIR_BATCH(128, pf.src[2])
+  for (int k0 = 192; k0 < NTb; k0 += 64) MRX_PAIR_BATCH(k0, K.pair_src[k0 + lane < NT ? k0 + lane : 0])
+#undef MRX_PAIR_BATCH
+  wave::sync();
+  // sequential hand-out per source port (:381-393): cur = min(cur, remaining); only positive orders exist
+  if (lane < brk) {
+    const long long n_p = L.srcn[lane];
+    if (n_p > 0) {
+      const int off = T.tgt_off[lane], cnt = T.tgt_off[lane + 1] - off;
+      long long rem = n_p;
+      for (int j = 0; j < cnt; j++) {
+        long long cur = L.oq[off + j];
+        if (cur > rem) cur = rem;
+        rem -= cur;
+        L.oq[off + j] = cur > 0 ? (int32_t)cur : 0;
+      }
+    }
+  }
+}
+
 // ==========================================================================================
 // RESET: Env.reset / set_seed + data generation + frame initialisation, all on the device
 // (core.py:143-170; cim/business_engine.py:226-242, 321-398; cim_data_container_helpers.py:56-73;
@@ -287,8 +503,17 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   wave::sync();
   int idx_route = MT_WORDS, idx_oi = MT_WORDS;
 
-  // ---- order proportion (parsers.py:57-106)
+  // ---- order proportion (parsers.py:57-106) and, tick by tick, the order table (CimParams::pregen): in `fixed`
+  // order mode the orders of tick t are a function of order_proportion[t] and the order_number stream alone
+  // (cim_data_container.py:309-398), drawn here in tick order exactly as the reference would while stepping.
   int32_t* g_prop = K.order_prop + (size_t)env * TT;
+  TickPf gpf = {};
+  int idx_ord = MT_WORDS;
+  if (K.pregen) {
+    stage_tables(K, L, lds);
+    tick_prefetch_static(K, gpf, true);
+    wave::lds_dma_wait();
+  }
   for (int t0 = 0; t0 < TT; t0 += 64) {
     const int t = t0 + lane;
     double orders = t < TT ? K.order_dist[t % K.period] : 0.0;
@@ -307,6 +532,25 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
         val = (int32_t)floor(c * (double)K.total_containers);
       }
       g_prop[t] = val;
+    }
+    if (K.pregen) {
+      int val = 0;  // order_proportion of tick t0 + lane, recomputed as stored above
+      if (nz) {
+        double c = orders < 1.0 ? orders : 1.0;
+        if (c < 0.0) c = 0.0;
+        val = (int32_t)floor(c * (double)K.total_containers);
+      }
+      const int n_here = TT - t0 < 64 ? TT - t0 : 64;
+      for (int j = 0; j < n_here; j++) {  // wave-uniform
+        const int tj = t0 + j;
+        const long long otg = (long long)wave::shfl(val, j);
+        if (tj < K.start_tick) continue;
+        gen_orders(K, L, otg, idx_ord, gpf);
+        wave::sync();
+        int32_t* row = K.orders + ((size_t)env * (TT - K.start_tick) + (size_t)(tj - K.start_tick)) * K.NTP;
+        for (int k = lane; k < K.NTP; k += 64) row[k] = k < K.NT ? L.oq[k] : 0;
+        wave::sync();
+      }
     }
   }
 
@@ -389,214 +633,36 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   for (int i = lane; i < K.REC_W; i += 64) g_rec0[i] = 0;
 }
 
-// Everything a tick needs from HBM/L2, requested one memory round trip ahead of its use (a wave issues in
-// order, so un-hidden loads stall the serial sections):
-//  * per-pair fp64 noise tables and source-port ids for the first 3 x 64 pairs (lane k holds pair k0+lane),
-//  * the tick's order count,
-//  * for the vessels that will arrive in that tick (known before the tick starts: a vessel departing in tick t
-//    cannot arrive in tick t): their discharge records (lane j = j-th candidate load stop) and stop-table
-//    entries (lane a = a-th arriving vessel).
-struct TickPf {
-  double tb[3], tn[3];
-  int src[3];
-  int q[4], key[4];
-  int ns, otg;
-  uint32_t stk, stk1;
-  uint64_t arr_mask;
-};
-
-// All prefetch loads are branch-free (addresses clamped to valid memory, validity re-derived at the point of
-// use), so the compiler has no control-flow merge that would force an early s_waitcnt.
-// consume every prefetched register in one straight-line place (see wave::touch)
-MRX_DEV void tick_prefetch_land(TickPf& pf) {
-#pragma unroll
-  for (int b = 0; b < 3; b++) { wave::touch(pf.tb[b]); wave::touch(pf.tn[b]); wave::touch(pf.src[b]); }
-#pragma unroll
-  for (int a = 0; a < 4; a++) { wave::touch(pf.q[a]); wave::touch(pf.key[a]); }
-  wave::touch(pf.ns); wave::touch(pf.otg); wave::touch(pf.stk); wave::touch(pf.stk1);
-}
-
-MRX_DEV void tick_prefetch_static(const CimParams& K, TickPf& pf) {
-  const int lane = wave::lane();
-  const int last = K.NT > 0 ? K.NT - 1 : 0;
-#pragma unroll
-  for (int b = 0; b < 3; b++) {
-    int k = b * 64 + lane;
-    k = k < last ? k : last;
-    pf.tb[b] = K.tgt_base[k]; pf.tn[b] = K.tgt_noise[k]; pf.src[b] = K.pair_src[k];
-  }
-}
-
-// stop-table entries and discharge records of the first (up to) four vessels of `mask`
-MRX_DEV void tick_prefetch_arrivals(const CimParams& K, int env, Lds& L, uint64_t mask, TickPf& pf) {
-  const int lane = wave::lane();
-  const int V = K.V;
-  const Tabs& T = L.tab;
-  const int32_t* g_rec = K.rec + (size_t)env * K.REC_W;
-  // lane a (< 4) fetches the stop-table entries of the a-th arriving vessel
-  {
-    uint64_t m = mask;
-    int v = 0;
-    for (int a = 0; a < 4; a++) {
-      const int va = m ? __builtin_ctzll(m) : 0;
-      if (m) m &= m - 1;
-      if (lane == a) v = va;
-    }
-    const int k = FV(VA_NEXT_LOC_IDX, lane < 4 ? v : 0);
-    const size_t srow = ((size_t)env * V + v) * K.SMAX;
-    pf.ns = K.nstops[(size_t)env * V + v];
-    pf.stk = K.stops[srow + (k < K.SMAX ? k : 0)];
-    pf.stk1 = K.stops[srow + (k + 1 < K.SMAX ? k + 1 : 0)];
-  }
-  // lane j fetches the j-th candidate discharge record (and its load tick) of each of those vessels
-  uint64_t m = mask;
-#pragma unroll
-  for (int a = 0; a < 4; a++) {
-    const int v = m ? __builtin_ctzll(m) : 0;  // wave-uniform; vessel 0 is a harmless stand-in when fewer arrive
-    if (m) m &= m - 1;
-    const int k = U(FV(VA_NEXT_LOC_IDX, v));
-    const int Lr = T.v_route_len[v], RL = Lr + 1, krl = U(V_KRL(v));
-    const int sidx = k - Lr + lane;
-    int col = krl + 1 + lane;
-    if (col >= RL) col -= RL;
-    const bool ok = lane < Lr && sidx >= 0;
-    pf.q[a] = g_rec[T.rec_off[v] + krl * RL + (ok ? col : 0)];
-    pf.key[a] = (int)K.stops[((size_t)env * V + v) * K.SMAX + (ok ? sidx : 0)];
-  }
-}
-
-MRX_DEV void tick_prefetch(const CimParams& K, int env, Lds& L, int t, TickPf& pf) {
-  const int lane = wave::lane();
-  pf.otg = K.order_prop[(size_t)env * K.T + t];
-  const bool arr = lane < K.V && !FV(VA_IS_PARKING, lane) && FV(VA_NEXT_LOC_IDX, lane) > 0 && V_EVT(lane) == t;
-  pf.arr_mask = wave::ballot(arr);
-  tick_prefetch_arrivals(K, env, L, pf.arr_mask, pf);
-}
-
-// ==========================================================================================
 // One tick, phases A..B4.  Returns the mask of vessels that arrived (their decisions follow).
+template <bool PG>
 MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf, int& idx_ord, int& idx_buf, int& status, Prof& prof) {
   const int lane = wave::lane();
   const int P = K.P, V = K.V, NT = K.NT, H = K.H;
   const Tabs& T = L.tab;
 
-  // ---------------- A. order generation (cim_data_container.py:309-398) -> L.oq[pair]
+  // ---------------- A. orders of this tick -> L.oq[pair]
   const uint64_t arr_mask = pf.arr_mask;
   int32_t* g_rec = K.rec + (size_t)env * K.REC_W;
-  long long otg = (long long)pf.otg;
-  bool gen = true;
-  if (K.order_mode == 1) {  // UNFIXED :327-333 (total_empty_number from business_engine.py:134-136)
-    long long mine = 0;
-    if (lane < P) mine += FP(PA_EMPTY, lane);
-    if (lane < V) mine += FV(VA_EMPTY, lane);
-    const long long delta = (long long)K.total_containers - wave::reduce_add(mine);
-    if (otg <= delta) gen = false; else otg -= delta;
-  }
-  for (int k = lane; k < NT; k += 64) L.oq[k] = 0;
-  if (gen) {
-    double ns = 0.0;
-    if (K.use_order_rng) {
-      const double r = mt_draw_batch(L.mt_ord, idx_ord, lane < P ? lane : -1, P);
-      if (lane < P) ns = apply_noise(T.src_base[lane], T.src_noise[lane], r);
-    } else if (lane < P) {
-      ns = T.src_base[lane] + 0.0;
+  if constexpr (PG) {
+    // drawn at reset (order table): the row was requested one round trip ago (tick_prefetch)
+#pragma unroll
+    for (int b = 0; b < 3; b++) { const int k = b * 64 + lane; if (k < NT) L.oq[k] = pf.oqr[b]; }
+    if (NT > 192) {
+      const int32_t* row = K.orders + ((size_t)env * (K.T - K.start_tick) + (size_t)(t - K.start_tick)) * K.NTP;
+      for (int k = 192 + lane; k < NT; k += 64) L.oq[k] = row[k];
     }
-    if (lane < P) L.dsrc[lane] = ns;
-    wave::sync();
-    // list_sum_normalize (utils.py:44-56): left-to-right fp64 sum, then one division per port (lane-parallel)
-    double tot = 0.0;
-    for (int p = 0; p < P; p++) tot += L.dsrc[p];
-    long long c = 0;
-    if (lane < P) {
-      const double ratio = (tot == 0.0) ? ns : ns / tot;
-      c = (long long)ceil((double)otg * ratio);
-      if (c > 0x7fffffffll) c = 0x7fffffffll;
-      if (c < -0x7fffffffll) c = -0x7fffffffll;
+  } else {
+    long long otg = (long long)pf.otg;
+    bool gen = true;
+    if (K.order_mode == 1) {  // UNFIXED :327-333 (total_empty_number from business_engine.py:134-136)
+      long long mine = 0;
+      if (lane < P) mine += FP(PA_EMPTY, lane);
+      if (lane < V) mine += FV(VA_EMPTY, lane);
+      const long long delta = (long long)K.total_containers - wave::reduce_add(mine);
+      if (otg <= delta) gen = false; else otg -= delta;
     }
-    // sequential split with early break (:354-375): n_p = min(c_p, remaining), remaining -= n_p, stop at remaining == 0
-    int brk = P;
-    const uint64_t negm = wave::ballot(lane < P && c < 0);
-    if (!negm) {  // usual case: a clamped prefix sum
-      const long long incl = (long long)wave::scan_incl_add((int)(lane < P ? (c < otg ? c : otg) : 0));  // terms capped at otg: no overflow
-      const long long rem_top = otg - (incl - (c < otg ? c : otg));  // remaining orders when port `lane` is reached
-      const uint64_t zm = wave::ballot(lane < P && rem_top <= 0);
-      if (zm) brk = __builtin_ctzll(zm);
-      if (lane < P) L.srcn[lane] = (int32_t)(rem_top <= 0 ? 0 : (c < rem_top ? c : rem_top));
-    } else {  // a negative noised ratio makes `remaining` grow: replay the reference loop literally
-      if (lane < P) L.srcn[lane] = (int32_t)c;
-      wave::sync();
-      long long remaining = otg;
-      for (int p = 0; p < P; p++) {
-        if (remaining == 0) { brk = p; break; }
-        long long cp = (long long)U(L.srcn[p]);
-        if (cp > remaining) cp = remaining;
-        remaining -= cp;
-        if (lane == 0) L.srcn[p] = (int32_t)cp;
-      }
-    }
-    const int NTb = T.tgt_off[brk];
-#define MRX_TGT_BATCH(k0, TB, TN)                                                              \
-    {                                                                                          \
-      const int k = (k0) + lane;                                                               \
-      const int n = (NTb - (k0)) < 64 ? (NTb - (k0)) : 64;                                      \
-      if (K.use_order_rng) {                                                                   \
-        const double r = mt_draw_batch(L.mt_ord, idx_ord, k < NTb ? lane : -1, n);             \
-        if (k < NTb) L.dtgt[k] = apply_noise(TB, TN, r);                                       \
-      } else if (k < NTb) {                                                                    \
-        L.dtgt[k] = (TB) + 0.0;                                                                \
-      }                                                                                        \
-    }
-    if (NTb > 0) MRX_TGT_BATCH(0, pf.tb[0], pf.tn[0])
-    if (NTb > 64) MRX_TGT_BATCH(64, pf.tb[1], pf.tn[1])
-    if (NTb > 128) MRX_TGT_BATCH(128, pf.tb[2], pf.tn[2])
-    for (int k0 = 192; k0 < NTb; k0 += 64) MRX_TGT_BATCH(k0, K.tgt_base[k0 + lane < NT ? k0 + lane : 0], K.tgt_noise[k0 + lane < NT ? k0 + lane : 0])
-#undef MRX_TGT_BATCH
-    wave::sync();
-    // per-port normaliser: left-to-right sum of its noised target ratios (:361-366)
-    if (lane < brk) {
-      const int off = T.tgt_off[lane], cnt = T.tgt_off[lane + 1] - off;
-      double ts = 0.0;
-      for (int j = 0; j < cnt; j++) ts += L.dtgt[off + j];
-      L.dsrc[lane] = ts;
-    }
-    wave::sync();
-    // one division per (src, dst) pair, lane-parallel: raw ceil(n_src * ratio) (:380)
-#define MRX_PAIR_BATCH(k0, SRC)                                                                     \
-    {                                                                                               \
-      const int k = (k0) + lane;                                                                    \
-      if (k < NTb) {                                                                                \
-        const int sp = (SRC);                                                                       \
-        const long long n_p = L.srcn[sp];                                                           \
-        long long cur = 0;                                                                          \
-        if (n_p > 0) {                                                                              \
-          const double ts = L.dsrc[sp], x = L.dtgt[k];                                              \
-          cur = (long long)ceil((double)n_p * ((ts == 0.0) ? x : x / ts));                          \
-          if (cur > 0x7fffffffll) cur = 0x7fffffffll;                                               \
-          if (cur < -0x7fffffffll) cur = -0x7fffffffll;                                             \
-        }                                                                                           \
-        L.oq[k] = (int32_t)cur;                                                                     \
-      }                                                                                             \
-    }
-    if (NTb > 0) MRX_PAIR_BATCH(0, pf.src[0])
-    if (NTb > 64) MRX_PAIR_BATCH(64, pf.src[1])
-    if (NTb > 128) MRX_PAIR_BATCH(128, pf.src[2])
-    for (int k0 = 192; k0 < NTb; k0 += 64) MRX_PAIR_BATCH(k0, K.pair_src[k0 + lane < NT ? k0 + lane : 0])
-#undef MRX_PAIR_BATCH
-    wave::sync();
-    // sequential hand-out per source port (:381-393): cur = min(cur, remaining); only positive orders exist
-    if (lane < brk) {
-      const long long n_p = L.srcn[lane];
-      if (n_p > 0) {
-        const int off = T.tgt_off[lane], cnt = T.tgt_off[lane + 1] - off;
-        long long rem = n_p;
-        for (int j = 0; j < cnt; j++) {
-          long long cur = L.oq[off + j];
-          if (cur > rem) cur = rem;
-          rem -= cur;
-          L.oq[off + j] = cur > 0 ? (int32_t)cur : 0;
-        }
-      }
-    }
+    if (gen) gen_orders(K, L, otg, idx_ord, pf);
+    else for (int k = lane; k < NT; k += 64) L.oq[k] = 0;
   }
   wave::sync();
   prof.mark(PF_ORDER_GEN);
@@ -881,13 +947,40 @@ MRX_DEV void take_snapshot(const CimParams& K, int env, Lds& L, int fi) {
 // ==========================================================================================
 // FAST PATH of a step that cannot advance time: another vessel of the current tick is still waiting for its
 // decision (2.2 vessels arrive per tick on global_trade.22p, so this is more than half of all env-steps).
-// Such a step touches a dozen words — the acting port / vessel, one plan cell, the next vessel — so it works
-// directly on HBM in three dependent round trips instead of staging the whole env in LDS.
-// `hdr` = private header word PH_<lane> held by lane < 16.  Returns false if the step needs the full path.
-MRX_DEV bool fast_step(const CimParams& K, int env, int hdr, const int32_t* actions, int n_act, int a0v, int a0p, int a0q,
-                       int a0t, int32_t* dec_out, long long* met_out, uint8_t* done_out) {
+// Such a step touches a dozen words — the acting port / vessel, one plan cell, the next vessel.  It never stages
+// the env in LDS, and it needs ONE trip to HBM: the rows those words live in (FastRows, ~1.5 KB, lane = node) are
+// requested together with the private header at kernel entry, before it is known which path the step takes; the
+// words themselves are then picked out of registers (readlane).  Only the (vessel, port) -> plan-cell table lookup
+// follows, and that table is a few KB shared by every env (L1/L2 resident).
+struct FastRows {
+  int hdr;                  // private header word PH_<lane> (lane < 16)
+  int pe, tc;               // ports:   empty, transfer_cost            (lane = port)
+  int ve, rs, ed, lp, per;  // vessels: empty, remaining_space, early_discharge, loc_port_idx, vessel period (lane = vessel)
+  int pl[4];                // vessel_plans cells lane + 64 k (only when the compact plan block has <= 256 cells)
+};
+
+MRX_DEV void fast_rows_request(const CimParams& K, int env, FastRows& R) {
+  const int lane = wave::lane();
+  const int32_t* g_live = K.live + (size_t)env * K.FW;
+  const int32_t* g_priv = K.priv + (size_t)env * K.PW;
+  const int p = lane < K.P ? lane : 0, v = lane < K.V ? lane : 0;
+  R.hdr = lane < PH_COUNT ? g_priv[lane] : 0;
+  R.pe = g_live[K.f_ports + PA_EMPTY * K.P + p];
+  R.tc = g_live[K.f_ports + PA_TRANSFER_COST * K.P + p];
+  R.ve = g_live[K.f_vessels + VA_EMPTY * K.V + v];
+  R.rs = g_live[K.f_vessels + VA_REMAINING_SPACE * K.V + v];
+  R.ed = g_live[K.f_vessels + VA_EARLY_DISCHARGE * K.V + v];
+  R.lp = g_live[K.f_vessels + VA_LOC_PORT_IDX * K.V + v];
+  R.per = g_priv[K.pv_period + v];
+  for (int k = 0; k < 4; k++) R.pl[k] = (K.NC <= 256 && lane + 64 * k < K.NC) ? g_live[K.f_plans + lane + 64 * k] : 0;
+}
+
+// Returns false if the step needs the full path.
+MRX_DEV bool fast_step(const CimParams& K, int env, const FastRows& R, int n_act, int a0v, int a0p, int a0q, int a0t,
+                       int32_t* dec_out, long long* met_out, uint8_t* done_out) {
   const int lane = wave::lane();
   const int P = K.P, V = K.V;
+  const int hdr = R.hdr;
   const int flags = wave::shfl(hdr, PH_FLAGS);
   if (flags & (FL_FRESH | FL_FINISHED)) return false;
   const uint64_t pend = ((uint64_t)(uint32_t)wave::shfl(hdr, PH_PEND_HI) << 32) | (uint32_t)wave::shfl(hdr, PH_PEND_LO);
@@ -904,21 +997,26 @@ MRX_DEV bool fast_step(const CimParams& K, int env, int hdr, const int32_t* acti
   const int v2 = __builtin_ctzll(pend_after);  // the vessel whose decision comes next
 #define GP(a, p) g_live[K.f_ports + (a) * P + (p)]
 #define GV(a, v) g_live[K.f_vessels + (a) * V + (v)]
-  // ---- round trip 2: everything addressable from the header and the action
   bool act = n_act == 1;
   const int av = a0v, ap = a0p, q = a0q, ty = a0t;
   if (act && (av < 0 || av >= V || ap < 0 || ap >= P || q < 0 || (ty != 0 && ty != 1))) { status |= 1; act = false; }
-  const int sv = act ? av : 0, sp = act ? ap : 0;  // safe addresses when there is no (valid) action
-  const int pe = GP(PA_EMPTY, sp), tc = GP(PA_TRANSFER_COST, sp);
-  const int ve = GV(VA_EMPTY, sv), rs = GV(VA_REMAINING_SPACE, sv);
-  const int c = K.cidx_dense[sv * P + sp];
-  const int period = g_priv[K.pv_period + sv];
-  const int lp2 = GV(VA_LOC_PORT_IDX, v2);
-  int ve2 = GV(VA_EMPTY, v2), rs2 = GV(VA_REMAINING_SPACE, v2);
-  const int ed2 = GV(VA_EARLY_DISCHARGE, v2);
-  // ---- round trip 3
-  int pe2 = GP(PA_EMPTY, lp2);
-  const int pl = g_live[K.f_plans + (c >= 0 ? c : 0)];
+  const int sv = act ? av : 0, sp = act ? ap : 0;  // safe lanes when there is no (valid) action
+  const int c = act ? K.cidx_dense[sv * P + sp] : -1;
+  const int pe = wave::shfl(R.pe, sp), tc = wave::shfl(R.tc, sp);
+  const int ve = wave::shfl(R.ve, sv), rs = wave::shfl(R.rs, sv);
+  const int period = wave::shfl(R.per, sv);
+  const int lp2 = wave::shfl(R.lp, v2);
+  int ve2 = wave::shfl(R.ve, v2), rs2 = wave::shfl(R.rs, v2);
+  const int ed2 = wave::shfl(R.ed, v2);
+  int pe2 = wave::shfl(R.pe, lp2);
+  int pl;
+  {
+    const int cc = c >= 0 ? c : 0;
+    const int p0 = wave::shfl(R.pl[0], cc & 63), p1 = wave::shfl(R.pl[1], cc & 63), p2 = wave::shfl(R.pl[2], cc & 63),
+              p3 = wave::shfl(R.pl[3], cc & 63);
+    pl = cc < 64 ? p0 : cc < 128 ? p1 : cc < 192 ? p2 : p3;
+    if (K.NC > 256) pl = g_live[K.f_plans + cc];  // large plan blocks: a second, dependent trip
+  }
   // ---- the action (business_engine.py:708-748)
   if (act) {
     int npe = pe, nve = ve;
@@ -964,6 +1062,7 @@ MRX_DEV bool fast_step(const CimParams& K, int env, int hdr, const int32_t* acti
 // ==========================================================================================
 // STEP: Env.step(action) in Sequential mode
 //   decision[8] = (tick, port, vessel, scope.load, scope.discharge, early_discharge, frame_index, valid)
+template <bool PG>
 MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* actions, int n_act,
                       int32_t* dec_out, long long* met_out, uint8_t* done_out) {
   Lds L = make_lds(K, lds);
@@ -977,10 +1076,16 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   // The 64-byte private header and the first action decide which path this step takes.
   if (n_act > K.max_actions) n_act = K.max_actions;
   {
-    const int hdr = lane < PH_COUNT ? g_priv[lane] : 0;
+    FastRows rows;
+    fast_rows_request(K, env, rows);
     int f0v = 0, f0p = 0, f0q = 0, f0t = 0;
     if (actions) { f0v = actions[0]; f0p = actions[1]; f0q = actions[2]; f0t = actions[3]; }
-    if (fast_step(K, env, hdr, actions, n_act, f0v, f0p, f0q, f0t, dec_out, met_out, done_out)) return;
+    if (fast_step(K, env, rows, n_act, f0v, f0p, f0q, f0t, dec_out, met_out, done_out)) {
+      prof.mark(13); prof.mark(14, 1);  // tools build: fast-path cycles and count
+      prof.flush();
+      return;
+    }
+    prof.mark(12);  // header round trip of the full path
   }
 
   // Everything this step needs from HBM is requested before the first wait: hot frame, private state and
@@ -991,7 +1096,7 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   const Tabs& T = L.tab;
   // The RNG states are requested unconditionally: whether a tick will run is only known once the private
   // state has arrived, and a second LDS-DMA round trip would serialise behind every later LDS access.
-  if (K.use_order_rng) copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(g_mt + MTS_ORDER * MT_WORDS), MT_WORDS);
+  if (!PG && K.use_order_rng) copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(g_mt + MTS_ORDER * MT_WORDS), MT_WORDS);
   if (K.use_buffer_rng) copy_in_async((int32_t*)L.mt_buf, (const int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), MT_WORDS);
   if (n_act > K.max_actions) n_act = K.max_actions;
   int a0v = 0, a0p = 0, a0q = 0, a0t = 0;
@@ -1023,8 +1128,8 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
     const uint64_t pend_after = fresh ? 0ull : (pend & ~(1ull << (L.priv[PH_CUR_VESSEL] & 63)));
     const int tn = fresh ? t : t + 1;
     if (!pend_after && tn < K.T) {
-      tick_prefetch_static(K, pf);
-      tick_prefetch(K, env, L, tn, pf);
+      tick_prefetch_static(K, pf, !PG);
+      tick_prefetch<PG>(K, env, L, tn, pf);
     }
   }
 
@@ -1091,8 +1196,8 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
     prof.mark(PF_POST_STEP);
     fresh = false;
     mt_waited = true;  // RNG states are modified from here on
-    pend = run_tick(K, env, L, t, pf, idx_ord, idx_buf, status, prof);
-    if (!pend && t + 1 < K.T) tick_prefetch(K, env, L, t + 1, pf);  // another tick follows: request its inputs now
+    pend = run_tick<PG>(K, env, L, t, pf, idx_ord, idx_buf, status, prof);
+    if (!pend && t + 1 < K.T) tick_prefetch<PG>(K, env, L, t + 1, pf);  // another tick follows: request its inputs now
   }
 
   // ---- outputs
@@ -1139,7 +1244,7 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   copy_words(g_live, L.frame, K.FW);
   copy_words(g_priv, L.priv, K.PW);
   if (mt_waited) {
-    if (K.use_order_rng) copy_words((int32_t*)(g_mt + MTS_ORDER * MT_WORDS), (const int32_t*)L.mt_ord, MT_WORDS);
+    if (!PG && K.use_order_rng) copy_words((int32_t*)(g_mt + MTS_ORDER * MT_WORDS), (const int32_t*)L.mt_ord, MT_WORDS);
     if (K.use_buffer_rng) copy_words((int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), (const int32_t*)L.mt_buf, MT_WORDS);
   }
   prof.mark(PF_STORE);

@@ -19,11 +19,12 @@
 __device__ unsigned long long g_mrx_prof[16];
 namespace cim {
 struct Prof {
-  long long last, acc[12];
-  __device__ __forceinline__ Prof() { for (int i = 0; i < 12; i++) acc[i] = 0; last = clock64(); }
+  long long last, acc[16];
+  __device__ __forceinline__ Prof() { for (int i = 0; i < 16; i++) acc[i] = 0; last = clock64(); }
   __device__ __forceinline__ void mark(int i) { long long c = clock64(); acc[i] += c - last; last = c; }
+  __device__ __forceinline__ void mark(int i, long long add) { acc[i] += add; }
   __device__ __forceinline__ void flush() {
-    if (wave::lane() == 0) for (int i = 0; i < 12; i++) if (acc[i]) atomicAdd(&g_mrx_prof[i], (unsigned long long)acc[i]);
+    if (wave::lane() == 0) for (int i = 0; i < 16; i++) if (acc[i]) atomicAdd(&g_mrx_prof[i], (unsigned long long)acc[i]);
   }
 };
 }  // namespace cim
@@ -40,17 +41,24 @@ mrx_k_cim_reset(CimParams K, const long long* __restrict__ seed_cmd, const uint8
   cim::reset_env(K, env, lds, seed_cmd ? seed_cmd[env] : default_cmd);
 }
 
-extern "C" __global__ void __launch_bounds__(64)
-mrx_k_cim_step(CimParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions,
-               const uint8_t* __restrict__ mask, int32_t* __restrict__ decisions, long long* __restrict__ metrics,
-               uint8_t* __restrict__ done) {
-  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-  const int env = blockIdx.x;
-  if (mask && !mask[env]) return;
-  const int32_t* a = actions ? actions + (size_t)env * K.max_actions * 4 : nullptr;
-  const int na = (actions && n_actions) ? n_actions[env] : 0;
-  cim::step_env(K, env, lds, a, na, decisions + (size_t)env * 8, metrics + (size_t)env * 3, done + env);
-}
+// Two builds of the step kernel: mrx_k_cim_step generates the tick's orders itself (any order mode);
+// mrx_k_cim_step_tab reads them from the order table drawn at reset (CimParams::pregen) and carries neither the
+// generator's code nor its LDS (order RNG state, fp64 scratch).
+#define MRX_STEP_KERNEL(NAME, PG)                                                                                  \
+  extern "C" __global__ void __launch_bounds__(64)                                                                  \
+  NAME(CimParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions,                     \
+       const uint8_t* __restrict__ mask, int32_t* __restrict__ decisions, long long* __restrict__ metrics,          \
+       uint8_t* __restrict__ done) {                                                                                \
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];                                                   \
+    const int env = blockIdx.x;                                                                                     \
+    if (mask && !mask[env]) return;                                                                                 \
+    const int32_t* a = actions ? actions + (size_t)env * K.max_actions * 4 : nullptr;                               \
+    const int na = (actions && n_actions) ? n_actions[env] : 0;                                                     \
+    cim::step_env<PG>(K, env, lds, a, na, decisions + (size_t)env * 8, metrics + (size_t)env * 3, done + env);      \
+  }
+MRX_STEP_KERNEL(mrx_k_cim_step, false)
+MRX_STEP_KERNEL(mrx_k_cim_step_tab, true)
+#undef MRX_STEP_KERNEL
 
 struct AttrList { int n; int32_t id[16]; };
 
@@ -173,6 +181,7 @@ int mrx_cim_create(const mrx_cim_topology* topo, const mrx_cim_config* cfg, void
   if ((size_t)K.lds_words_reset * 4 > 64 * 1024) {
     hipFuncSetAttribute((const void*)mrx_k_cim_reset, hipFuncAttributeMaxDynamicSharedMemorySize, K.lds_words_reset * 4);
     hipFuncSetAttribute((const void*)mrx_k_cim_step, hipFuncAttributeMaxDynamicSharedMemorySize, K.lds_words * 4);
+    hipFuncSetAttribute((const void*)mrx_k_cim_step_tab, hipFuncAttributeMaxDynamicSharedMemorySize, K.lds_words * 4);
   }
   // Env.__init__ generates data with the topology's own seed (cim_data_generator.py:141-145)
   hipLaunchKernelGGL(mrx_k_cim_reset, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_reset * 4, 0, K, nullptr, nullptr,
@@ -213,8 +222,12 @@ int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_acti
   if (rc != MRX_OK) return rc;
   const CimParams& K = h->plan.kp;
   static const size_t lds_pad = getenv("MRX_DEBUG_LDS_PAD_BYTES") ? (size_t)atoi(getenv("MRX_DEBUG_LDS_PAD_BYTES")) : 0;  // occupancy experiments
-  hipLaunchKernelGGL(mrx_k_cim_step, dim3(K.n_envs), dim3(64), (size_t)K.lds_words * 4 + lds_pad, (hipStream_t)stream, K, d_actions,
-                     d_n_actions, d_env_mask, d_decisions, (long long*)d_metrics, d_done);
+  if (K.pregen)
+    hipLaunchKernelGGL(mrx_k_cim_step_tab, dim3(K.n_envs), dim3(64), (size_t)K.lds_words * 4 + lds_pad, (hipStream_t)stream, K, d_actions,
+                       d_n_actions, d_env_mask, d_decisions, (long long*)d_metrics, d_done);
+  else
+    hipLaunchKernelGGL(mrx_k_cim_step, dim3(K.n_envs), dim3(64), (size_t)K.lds_words * 4 + lds_pad, (hipStream_t)stream, K, d_actions,
+                       d_n_actions, d_env_mask, d_decisions, (long long*)d_metrics, d_done);
   HIP_TRY(hipGetLastError());
   return MRX_OK;
 }

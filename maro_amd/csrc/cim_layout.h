@@ -20,7 +20,7 @@ struct CimHostPlan {
   int64_t const_off = 0;
   int64_t workspace_bytes = 0;
   // byte offsets of per-env arrays inside the workspace
-  int64_t o_live, o_ring, o_ring_fi, o_priv, o_rec, o_status, o_tick, o_nstops, o_order_prop, o_mt, o_stops, o_seed, o_vperiod;
+  int64_t o_live, o_ring, o_ring_fi, o_priv, o_rec, o_status, o_tick, o_nstops, o_order_prop, o_mt, o_stops, o_seed, o_vperiod, o_orders;
   // relative offsets of const tables inside const_blob, in the order of CimParams' const pointers
   std::vector<std::pair<size_t, int64_t>> binds;  // (byte offset of a pointer field inside kp, offset in const_blob)
   int64_t ctab_rel = 0;
@@ -172,19 +172,25 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   leg_off[V] = (int)leg_time.size(); rec_off[V] = rec_w;
   k.REC_W = (rec_w + 3) / 4 * 4;
   // LDS plan (word offsets; doubles 8-byte aligned)
+  // Order table (mrx_cim_config.order_table): only `fixed` order mode is state independent
+  k.pregen = (t->order_mode == 0 && NT > 0 && c->order_table >= 0) ? 1 : 0;
+  k.NTP = (NT + 3) / 4 * 4;
+  const int dsrc_w = 2 * ((P + 1) / 2 * 2);
+  const int dtgt_w = 2 * (NT + 1) > 3 * 64 ? 2 * (NT + 1) : 3 * 64;
   int w = 0;
   k.l_frame = w; w += k.FW;
   k.l_priv = w; w += k.PW;
-  k.l_mt0 = w; w += MT_WORDS;
-  k.l_mt1 = w; w += MT_WORDS;
+  if (!k.pregen) { k.l_mt0 = w; w += MT_WORDS; }  // with the order table the order stream and the generator's fp64
+  k.l_mt1 = w; w += MT_WORDS;                    // scratch live in the reset kernel's LDS only (see below)
   w = (w + 1) / 2 * 2;
-  k.l_dsrc = w; w += 2 * ((P + 1) / 2 * 2);
-  { const int dw = 2 * (NT + 1) > 3 * 64 ? 2 * (NT + 1) : 3 * 64; k.l_dtgt = w; w += dw; k.misc_cap = dw / 3; }  // also the discharge-record merge list (l_misc)
+  if (!k.pregen) { k.l_dsrc = w; w += dsrc_w; }
+  k.misc_cap = dtgt_w / 3;
+  if (!k.pregen) { k.l_dtgt = w; w += dtgt_w; k.l_misc = k.l_dtgt; }  // dtgt doubles as the discharge-record merge list:
+  else { k.l_misc = w; w += dtgt_w; }                                  // (key, v, q) x misc_cap, live only in phase B2
   k.l_oq = w; w += NT + 1;  // order quantity | (buffer ticks + 1) << 24
   k.l_odelay = k.l_oq;
   k.l_srcn = w; w += P;
   w = (w + 1) / 2 * 2;
-  k.l_misc = k.l_dtgt;  // (key, v, q) x up to 128, live only in phase B2 when dtgt is dead
   k.lds_words = (w + 3) / 4 * 4;
 
   // ---- constant blob
@@ -240,6 +246,10 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   k.l_ctab = (k.lds_words + 1) / 2 * 2;
   k.lds_words = (k.l_ctab + k.ctab_words + 3) / 4 * 4;
   k.l_mt2 = k.lds_words; k.l_mt3 = k.l_mt2 + MT_WORDS; k.lds_words_reset = k.l_mt3 + MT_WORDS;
+  if (k.pregen) {  // the order generator runs inside the reset kernel
+    k.l_mt0 = k.lds_words_reset; k.l_dsrc = k.l_mt0 + MT_WORDS; k.l_dtgt = k.l_dsrc + dsrc_w;
+    k.lds_words_reset = (k.l_dtgt + dtgt_w + 3) / 4 * 4;
+  }
   if ((int64_t)k.lds_words_reset * 4 > 160 * 1024) return fail("engine limit: per-env state exceeds 160 KiB of LDS");
 
   // ---- workspace carve-up
@@ -259,6 +269,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   pl->o_stops = A.take(N * (int64_t)V * k.SMAX * 4);
   pl->o_seed = A.take(N * 8);
   pl->o_vperiod = A.take(N * V * 4);
+  pl->o_orders = k.pregen ? A.take(N * (int64_t)c->durations * k.NTP * 4) : 0;
   pl->workspace_bytes = align_up(A.top, 256);
 
   mrx_cim_layout& Lo = pl->layout;
@@ -270,6 +281,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   Lo.off_live = pl->o_live; Lo.off_ring = pl->o_ring; Lo.off_ring_fi = pl->o_ring_fi; Lo.off_status = pl->o_status;
   Lo.off_tick = pl->o_tick; Lo.off_seed = pl->o_seed; Lo.off_stops = pl->o_stops; Lo.off_nstops = pl->o_nstops;
   Lo.off_order_prop = pl->o_order_prop; Lo.off_vessel_period = pl->o_vperiod;  // per env: depends on how many stops were unrolled
+  Lo.off_orders = pl->o_orders; Lo.order_row_words = k.NTP; Lo.order_table_on = k.pregen;
   Lo.workspace_bytes = pl->workspace_bytes;
   return MRX_OK;
 }
@@ -287,4 +299,5 @@ inline void cim_plan_bind(CimHostPlan* pl, void* base_) {
   k.order_prop = (int32_t*)(base + pl->o_order_prop); k.mt = (uint32_t*)(base + pl->o_mt);
   k.stops = (uint32_t*)(base + pl->o_stops); k.seed = (int64_t*)(base + pl->o_seed);
   k.vperiod = (int32_t*)(base + pl->o_vperiod);
+  k.orders = k.pregen ? (int32_t*)(base + pl->o_orders) : nullptr;
 }

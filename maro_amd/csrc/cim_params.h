@@ -40,6 +40,7 @@ struct CimParams {
   int l_frame, l_priv, l_mt0, l_mt1, l_dsrc, l_dtgt, l_oq, l_odelay, l_srcn, l_misc, lds_words;
   int l_ctab, ctab_words;  // serial-access int tables staged in LDS by the step kernel
   int l_mt2, l_mt3, lds_words_reset;  // reset kernel only (placed after the step kernel's LDS)
+  int pregen, NTP;  // order table: rows of NTP (= NT rounded up to 4) words, one per tick of the episode
   // ---- constant tables (device)
   const double *src_base, *src_noise, *tgt_base, *tgt_noise, *er_base, *er_noise, *fr_base, *fr_noise,
       *v_speed, *v_speed_noise, *v_dur, *v_dur_noise, *route_dist, *order_dist;
@@ -48,7 +49,7 @@ struct CimParams {
       *fr_delay, *rec_off, *v_route, *v_cbase, *route_cidx, *cidx_dense, *pair_dense;
   const int32_t* ctab;  // start of the contiguous block holding tgt_off .. rec_off (ctab_words words)
   // ---- per-env state (device)
-  int32_t *live, *ring, *ring_fi, *priv, *rec, *status, *tick, *nstops, *order_prop, *vperiod;
+  int32_t *live, *ring, *ring_fi, *priv, *rec, *status, *tick, *nstops, *order_prop, *vperiod, *orders;
   uint32_t *mt, *stops;
   int64_t* seed;
 };

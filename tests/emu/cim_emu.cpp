@@ -69,7 +69,8 @@ void emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const u
     const int32_t* a = actions ? actions + (size_t)env * K.max_actions * 4 : nullptr;
     int na = (actions && n_actions) ? n_actions[env] : 0;
     wave::run_wave(e->wave, [&]() {
-      cim::step_env(K, env, e->lds, a, na, dec + (size_t)env * 8, (long long*)(met + (size_t)env * 3), done + env);
+      if (K.pregen) cim::step_env<true>(K, env, e->lds, a, na, dec + (size_t)env * 8, (long long*)(met + (size_t)env * 3), done + env);
+      else cim::step_env<false>(K, env, e->lds, a, na, dec + (size_t)env * 8, (long long*)(met + (size_t)env * 3), done + env);
     });
   }
 }

@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, "libcim_emu.so")
 
 class MrxCimConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("n_envs", "device", "start_tick", "durations", "snapshot_resolution",
-                                              "max_snapshots", "max_actions", "max_stops")]
+                                              "max_snapshots", "max_actions", "max_stops", "order_table")]
 
 
 class MrxCimLayout(ctypes.Structure):
@@ -23,7 +23,9 @@ class MrxCimLayout(ctypes.Structure):
                                                "frame_off_vessel_plans")]
                 + [(n, ctypes.c_int64) for n in ("off_live", "off_ring", "off_ring_fi", "off_status", "off_tick",
                                                  "off_seed", "off_stops", "off_nstops", "off_order_prop",
-                                                 "off_vessel_period", "workspace_bytes")])
+                                                 "off_vessel_period", "off_orders")]
+                + [(n, ctypes.c_int32) for n in ("order_row_words", "order_table_on")]
+                + [("workspace_bytes", ctypes.c_int64)])
 
 
 def build():
@@ -64,11 +66,11 @@ class EmuBackend:
     """Batch backend with the same numpy-facing surface as the tests' GPU backend wrapper."""
 
     def __init__(self, topo, n_envs=1, start_tick=0, durations=100, snapshot_resolution=1, max_snapshots=None,
-                 max_actions=2, reverse=False):
+                 max_actions=2, reverse=False, order_table=0):
         self.topo = topo
         self._cs = topo.c_struct()
         self.cfg = MrxCimConfig(n_envs, 0, start_tick, durations, snapshot_resolution, max_snapshots or 0,
-                                max_actions, 0)
+                                max_actions, 0, order_table)
         err = ctypes.create_string_buffer(256)
         self._h = lib().emu_create(ctypes.byref(self._cs), ctypes.byref(self.cfg), err, 256)
         if not self._h:

@@ -12,11 +12,12 @@ from tests.test_oracle_golden import replay_case
 FAST = [c for c in golden_cases() if not c.endswith("_full")]
 
 
-def _make(reverse):
+def _make(reverse, order_table=0):
     def make(topo, kwargs):
         kw = dict(kwargs)
         b = EmuBackend(topo, n_envs=1, durations=kw["durations"], snapshot_resolution=kw.get("snapshot_resolution", 1),
-                       max_snapshots=kw.get("max_snapshots"), max_actions=2, reverse=reverse)
+                       max_snapshots=kw.get("max_snapshots"), max_actions=2, reverse=reverse, order_table=order_table)
+        assert b.layout.order_table_on == (1 if order_table >= 0 and topo.order_mode == 0 else 0)
         return SingleEnvAdapter(b)
     return make
 
@@ -29,3 +30,11 @@ def test_emulated_kernels_reproduce_reference(name):
 @pytest.mark.parametrize("name", ["toy4p_l00_rand0", "gt22p_l08_res3", "toy6p_l08_rand0"])
 def test_emulated_kernels_lane_order_independent(name):
     replay_case(_make(True), name)
+
+
+@pytest.mark.parametrize("name", ["toy4p_l00_rand0", "gt22p_l08_rand0", "toy6p_l08_rand0", "gt22p_l08_reset_chain"])
+def test_online_order_generation_path(name):
+    """order_table = -1: the step kernel draws each tick's orders itself (the only path for `unfixed` order mode)."""
+    if name not in FAST:
+        pytest.skip("golden not present")
+    replay_case(_make(False, order_table=-1), name)

@@ -9,7 +9,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 PHASES = ["load", "action", "post_step+snapshot", "mt_load", "A order_gen", "B1/B2 depart+returns", "B3 orders",
-          "B4 arrivals (load+commit)", "output+predecision snapshot", "store", "B4.a per-vessel reads", "B4.b positions/plans"]
+          "B4 arrivals (load+commit)", "output+predecision snapshot", "store", "B4.a per-vessel reads", "B4.b positions/plans", "header round trip (full path)", "FAST PATH total", "(fast-path step count)"]
 
 
 def main():
@@ -41,10 +41,12 @@ def main():
         eng.step(actions, nact)
     torch.cuda.synchronize()
     lib.mrx_prof_read(buf, 0)
-    tot = sum(buf[:12])
+    tot = sum(buf[:14])
     waves = n * args.steps
     print(f"{args.topology}: {waves} env-steps, {eng.ticks.sum().item() - t0} ticks; mean {tot / waves:.0f} cycles per env-step")
-    for name, c in zip(PHASES, buf[:12]):
+    nfast = buf[14]
+    print(f'  fast-path steps: {nfast} ({100*nfast/waves:.1f} %), {buf[13]/max(nfast,1):.0f} cycles each; full-path steps: {(tot-buf[13])/max(waves-nfast,1):.0f} cycles each')
+    for name, c in zip(PHASES, buf[:14]):
         print(f"  {name:32s} {c / waves:10.0f} cyc/env-step  {100 * c / tot:5.1f} %")
 
 
