@@ -186,6 +186,7 @@ def bench_citi_bike(args):
             "config": {"workload": f"citi_bike {topology}, {n} envs/GPU x {world} GPU, durations {durations}, resolution {res}, "
                                    f"device policy, stations snapshot slice {'off' if args.no_query else 'every step'}",
                        "envs_per_gpu": n, "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective)",
+                       "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms,
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
             "roofline": {"bound": "hbm", "kernel": "mrx_k_cb_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": step_kernel_ms,
@@ -260,6 +261,14 @@ def main():
     topo = engines[0].topo
     ports = torch.arange(topo.n_ports, dtype=torch.int32, device=dev)
     torch.cuda.synchronize(dev)
+    # Env.reset for the whole batch (route unrolling, order proportion and — with the order table — every order of the
+    # episode are generated on the device here, outside the timed step loop): reported next to the step rate
+    t_r = time.perf_counter()
+    for g, eng in enumerate(engines):
+        with torch.cuda.stream(streams[g]):
+            eng.reset(torch.arange(ng, dtype=torch.int64) + rank * n + g * ng + 1)
+    torch.cuda.synchronize(dev)
+    reset_ms = (time.perf_counter() - t_r) * 1e3
 
     def one_step(i, g, timing=None):
         eng, b = engines[g], bufs[g]
@@ -358,6 +367,7 @@ def main():
                                    f"random legal agent on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step'}",
                        "envs_per_gpu": n, "groups_per_gpu": G, "envs_per_launch": ng, "ring_slots": args.ring,
                        "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
+                       "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms,
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
             "roofline": {"bound": "hbm", "kernel": "mrx_k_cim_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": "profiles/latest_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",

@@ -102,8 +102,7 @@ MRX_DEV int32_t f_bits(float f) { union { int32_t i; float f; } u; u.f = f; retu
 // MT19937 == CPython random.Random, state (624 words) in LDS, regenerated by the whole wave.
 // stage the serial-access tables in LDS and re-point L.tab at the copy (complete with lds_dma_wait)
 MRX_DEV void copy_in_async(int32_t* lds_dst, const int32_t* gsrc, int n_words);
-MRX_DEV void stage_tables(const CimParams& K, Lds& L, int32_t* lds) {
-  int32_t* c = lds + K.l_ctab;
+MRX_DEV void stage_tables(const CimParams& K, Lds& L, int32_t* c) {
   copy_in_async(c, K.ctab, K.ctab_words);
   L.tab.tgt_off = c + (K.tgt_off - K.ctab); L.tab.tgt_port = c + (K.tgt_port - K.ctab);
   L.tab.route_port = c + (K.route_port - K.ctab);
@@ -503,17 +502,8 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   wave::sync();
   int idx_route = MT_WORDS, idx_oi = MT_WORDS;
 
-  // ---- order proportion (parsers.py:57-106) and, tick by tick, the order table (CimParams::pregen): in `fixed`
-  // order mode the orders of tick t are a function of order_proportion[t] and the order_number stream alone
-  // (cim_data_container.py:309-398), drawn here in tick order exactly as the reference would while stepping.
+  // ---- order proportion (parsers.py:57-106)
   int32_t* g_prop = K.order_prop + (size_t)env * TT;
-  TickPf gpf = {};
-  int idx_ord = MT_WORDS;
-  if (K.pregen) {
-    stage_tables(K, L, lds);
-    tick_prefetch_static(K, gpf, true);
-    wave::lds_dma_wait();
-  }
   for (int t0 = 0; t0 < TT; t0 += 64) {
     const int t = t0 + lane;
     double orders = t < TT ? K.order_dist[t % K.period] : 0.0;
@@ -532,25 +522,6 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
         val = (int32_t)floor(c * (double)K.total_containers);
       }
       g_prop[t] = val;
-    }
-    if (K.pregen) {
-      int val = 0;  // order_proportion of tick t0 + lane, recomputed as stored above
-      if (nz) {
-        double c = orders < 1.0 ? orders : 1.0;
-        if (c < 0.0) c = 0.0;
-        val = (int32_t)floor(c * (double)K.total_containers);
-      }
-      const int n_here = TT - t0 < 64 ? TT - t0 : 64;
-      for (int j = 0; j < n_here; j++) {  // wave-uniform
-        const int tj = t0 + j;
-        const long long otg = (long long)wave::shfl(val, j);
-        if (tj < K.start_tick) continue;
-        gen_orders(K, L, otg, idx_ord, gpf);
-        wave::sync();
-        int32_t* row = K.orders + ((size_t)env * (TT - K.start_tick) + (size_t)(tj - K.start_tick)) * K.NTP;
-        for (int k = lane; k < K.NTP; k += 64) row[k] = k < K.NT ? L.oq[k] : 0;
-        wave::sync();
-      }
     }
   }
 
@@ -631,6 +602,40 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   for (int i = lane; i < K.S; i += 64) K.ring_fi[(size_t)env * K.S + i] = -1;
   int32_t* g_rec0 = K.rec + (size_t)env * K.REC_W;
   for (int i = lane; i < K.REC_W; i += 64) g_rec0[i] = 0;
+}
+
+// ==========================================================================================
+// ORDER TABLE (CimParams::pregen): in `fixed` order mode the orders of tick t are a function of
+// order_proportion[t] and the order_number stream alone (cim_data_container.py:309-398), so the whole episode is
+// drawn right after reset_env, in tick order, exactly as the reference would while stepping.  Runs as its own
+// kernel with a small LDS footprint (RNG state, generator scratch, tables: ~9 KB) so many envs are resident per CU.
+MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {
+  const int lane = wave::lane();
+  Lds L = make_lds(K, lds);
+  L.mt_ord = (uint32_t*)(lds + K.g_mt0);
+  L.dsrc = (double*)(lds + K.g_dsrc);
+  L.dtgt = (double*)(lds + K.g_dtgt);
+  L.oq = lds + K.g_oq;
+  L.srcn = lds + K.g_srcn;
+  stage_tables(K, L, lds + K.g_ctab);
+  copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(K.mt + ((size_t)env * MTS_COUNT + MTS_ORDER) * MT_WORDS), MT_WORDS);
+  TickPf pf = {};
+  tick_prefetch_static(K, pf, true);
+  const int32_t* g_prop = K.order_prop + (size_t)env * K.T;
+  const int D = K.T - K.start_tick;
+  int idx_ord = MT_WORDS;  // the stream as reset_env seeded it
+  wave::lds_dma_wait();
+  for (int t0 = 0; t0 < D; t0 += 64) {
+    const int mine = t0 + lane < D ? g_prop[K.start_tick + t0 + lane] : 0;  // 64 ticks of order_proportion per load
+    const int n_here = D - t0 < 64 ? D - t0 : 64;
+    for (int j = 0; j < n_here; j++) {  // wave-uniform
+      gen_orders(K, L, (long long)wave::shfl(mine, j), idx_ord, pf);
+      wave::sync();
+      int32_t* row = K.orders + ((size_t)env * D + (size_t)(t0 + j)) * K.NTP;
+      for (int k = lane; k < K.NTP; k += 64) row[k] = k < K.NT ? L.oq[k] : 0;
+      wave::sync();
+    }
+  }
 }
 
 // One tick, phases A..B4.  Returns the mask of vessels that arrived (their decisions follow).
@@ -1092,7 +1097,7 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   // topology tables by LDS-DMA, the action words into registers.
   copy_in_async(L.frame, g_live, K.FW);
   copy_in_async(L.priv, g_priv, K.PW);
-  stage_tables(K, L, lds);
+  stage_tables(K, L, lds + K.l_ctab);
   const Tabs& T = L.tab;
   // The RNG states are requested unconditionally: whether a tick will run is only known once the private
   // state has arrived, and a second LDS-DMA round trip would serialise behind every later LDS access.

@@ -41,6 +41,15 @@ mrx_k_cim_reset(CimParams K, const long long* __restrict__ seed_cmd, const uint8
   cim::reset_env(K, env, lds, seed_cmd ? seed_cmd[env] : default_cmd);
 }
 
+extern "C" __global__ void __launch_bounds__(64)
+mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const uint8_t* __restrict__ mask, long long default_cmd) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const int env = blockIdx.x;
+  if (mask && !mask[env]) return;
+  if ((seed_cmd ? seed_cmd[env] : default_cmd) == -1) return;  // reset(keep_seed=True): same seed, same table
+  cim::gen_order_table(K, env, lds);
+}
+
 // Two builds of the step kernel: mrx_k_cim_step generates the tick's orders itself (any order mode);
 // mrx_k_cim_step_tab reads them from the order table drawn at reset (CimParams::pregen) and carries neither the
 // generator's code nor its LDS (order RNG state, fp64 scratch).
@@ -186,6 +195,9 @@ int mrx_cim_create(const mrx_cim_topology* topo, const mrx_cim_config* cfg, void
   // Env.__init__ generates data with the topology's own seed (cim_data_generator.py:141-145)
   hipLaunchKernelGGL(mrx_k_cim_reset, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_reset * 4, 0, K, nullptr, nullptr,
                      (long long)topo->seed);
+  if (K.pregen)
+    hipLaunchKernelGGL(mrx_k_cim_order_table, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_gen * 4, 0, K, nullptr, nullptr,
+                       (long long)topo->seed);
   he = hipDeviceSynchronize();
   if (he == hipSuccess) he = hipGetLastError();
   if (he != hipSuccess) { delete e; return set_err(MRX_ERR_HIP, std::string("initial reset kernel: ") + hipGetErrorString(he)); }
@@ -211,6 +223,9 @@ int mrx_cim_reset(mrx_handle h, const int64_t* d_seed_cmd, const uint8_t* d_env_
   const CimParams& K = h->plan.kp;
   hipLaunchKernelGGL(mrx_k_cim_reset, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_reset * 4, (hipStream_t)stream, K,
                      (const long long*)d_seed_cmd, d_env_mask, (long long)-1);
+  if (K.pregen && d_seed_cmd)  // without seed commands every env keeps its seed, hence its order table
+    hipLaunchKernelGGL(mrx_k_cim_order_table, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_gen * 4, (hipStream_t)stream, K,
+                       (const long long*)d_seed_cmd, d_env_mask, (long long)-1);
   HIP_TRY(hipGetLastError());
   return MRX_OK;
 }

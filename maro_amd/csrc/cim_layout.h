@@ -246,9 +246,17 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   k.l_ctab = (k.lds_words + 1) / 2 * 2;
   k.lds_words = (k.l_ctab + k.ctab_words + 3) / 4 * 4;
   k.l_mt2 = k.lds_words; k.l_mt3 = k.l_mt2 + MT_WORDS; k.lds_words_reset = k.l_mt3 + MT_WORDS;
-  if (k.pregen) {  // the order generator runs inside the reset kernel
-    k.l_mt0 = k.lds_words_reset; k.l_dsrc = k.l_mt0 + MT_WORDS; k.l_dtgt = k.l_dsrc + dsrc_w;
-    k.lds_words_reset = (k.l_dtgt + dtgt_w + 3) / 4 * 4;
+  if (k.pregen) {
+    k.l_mt0 = k.lds_words_reset; k.lds_words_reset += MT_WORDS;  // reset_env seeds the order stream here
+    // the order-table kernel: order RNG state, generator scratch, staged tables
+    int g = 0;
+    k.g_mt0 = g; g += MT_WORDS;
+    k.g_dsrc = g; g += dsrc_w;
+    k.g_dtgt = g; g += dtgt_w;
+    k.g_oq = g; g += NT + 1;
+    k.g_srcn = g; g += P;
+    k.g_ctab = (g + 3) / 4 * 4;
+    k.lds_words_gen = (k.g_ctab + k.ctab_words + 3) / 4 * 4;
   }
   if ((int64_t)k.lds_words_reset * 4 > 160 * 1024) return fail("engine limit: per-env state exceeds 160 KiB of LDS");
 

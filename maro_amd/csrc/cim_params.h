@@ -41,6 +41,7 @@ struct CimParams {
   int l_ctab, ctab_words;  // serial-access int tables staged in LDS by the step kernel
   int l_mt2, l_mt3, lds_words_reset;  // reset kernel only (placed after the step kernel's LDS)
   int pregen, NTP;  // order table: rows of NTP (= NT rounded up to 4) words, one per tick of the episode
+  int g_mt0, g_dsrc, g_dtgt, g_oq, g_srcn, g_ctab, lds_words_gen;  // LDS layout of the order-table kernel
   // ---- constant tables (device)
   const double *src_base, *src_noise, *tgt_base, *tgt_noise, *er_base, *er_noise, *fr_base, *fr_noise,
       *v_speed, *v_speed_noise, *v_dur, *v_dur_noise, *route_dist, *order_dist;
