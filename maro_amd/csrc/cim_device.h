@@ -36,8 +36,9 @@ enum { PF_LOAD, PF_ACTION, PF_POST_STEP, PF_MT_LOAD, PF_ORDER_GEN, PF_DEPART_RET
 // ------------------------------------------------------------------------------------------
 // serial-access topology tables: global (L2) by default, re-pointed at the LDS copy by the step kernel
 struct Tabs {
-  const int32_t *tgt_off, *tgt_port, *route_port, *v_route_base, *v_route_len,
-      *leg_off, *leg_time, *er_delay, *fr_delay, *rec_off, *v_cbase, *route_cidx;
+  const uint16_t *tgt_off, *tgt_port, *route_port, *v_route_base, *v_route_len, *leg_off, *leg_time, *rec_off, *v_cbase,
+      *route_cidx;  // 16-bit copies (cim_plan checks the ranges)
+  const int32_t *er_delay, *fr_delay;
   const double *src_base, *src_noise, *er_base, *er_noise, *fr_base, *fr_noise;
 };
 
@@ -66,11 +67,11 @@ MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
   L.oq = b + K.l_oq;
   L.srcn = b + K.l_srcn;
   L.misc = b + K.l_misc;
-  L.tab.tgt_off = K.tgt_off; L.tab.tgt_port = K.tgt_port; L.tab.route_port = K.route_port;
-  L.tab.v_route_base = K.v_route_base; L.tab.v_route_len = K.v_route_len;
-  L.tab.leg_off = K.leg_off; L.tab.leg_time = K.leg_time;
-  L.tab.er_delay = K.er_delay; L.tab.fr_delay = K.fr_delay; L.tab.rec_off = K.rec_off;
-  L.tab.v_cbase = K.v_cbase; L.tab.route_cidx = K.route_cidx;
+  L.tab.tgt_off = K.h_tgt_off; L.tab.tgt_port = K.h_tgt_port; L.tab.route_port = K.h_route_port;
+  L.tab.v_route_base = K.h_v_route_base; L.tab.v_route_len = K.h_v_route_len;
+  L.tab.leg_off = K.h_leg_off; L.tab.leg_time = K.h_leg_time;
+  L.tab.er_delay = K.er_delay; L.tab.fr_delay = K.fr_delay; L.tab.rec_off = K.h_rec_off;
+  L.tab.v_cbase = K.h_v_cbase; L.tab.route_cidx = K.h_route_cidx;
   L.tab.src_base = K.src_base; L.tab.src_noise = K.src_noise; L.tab.er_base = K.er_base; L.tab.er_noise = K.er_noise;
   L.tab.fr_base = K.fr_base; L.tab.fr_noise = K.fr_noise;
   return L;
@@ -104,15 +105,14 @@ MRX_DEV int32_t f_bits(float f) { union { int32_t i; float f; } u; u.f = f; retu
 MRX_DEV void copy_in_async(int32_t* lds_dst, const int32_t* gsrc, int n_words);
 MRX_DEV void stage_tables(const CimParams& K, Lds& L, int32_t* c) {
   copy_in_async(c, K.ctab, K.ctab_words);
-  L.tab.tgt_off = c + (K.tgt_off - K.ctab); L.tab.tgt_port = c + (K.tgt_port - K.ctab);
-  L.tab.route_port = c + (K.route_port - K.ctab);
-  L.tab.v_route_base = c + (K.v_route_base - K.ctab); L.tab.v_route_len = c + (K.v_route_len - K.ctab);
-  L.tab.leg_off = c + (K.leg_off - K.ctab); L.tab.leg_time = c + (K.leg_time - K.ctab);
+#define MRX_HTAB(f) L.tab.f = (const uint16_t*)c + (K.h_##f - (const uint16_t*)K.ctab)
+  MRX_HTAB(tgt_off); MRX_HTAB(tgt_port); MRX_HTAB(route_port); MRX_HTAB(v_route_base); MRX_HTAB(v_route_len);
+  MRX_HTAB(leg_off); MRX_HTAB(leg_time); MRX_HTAB(rec_off); MRX_HTAB(v_cbase); MRX_HTAB(route_cidx);
+#undef MRX_HTAB
   L.tab.er_delay = c + (K.er_delay - K.ctab); L.tab.fr_delay = c + (K.fr_delay - K.ctab);
-  L.tab.rec_off = c + (K.rec_off - K.ctab);
-  L.tab.v_cbase = c + (K.v_cbase - K.ctab); L.tab.route_cidx = c + (K.route_cidx - K.ctab);
 #define MRX_DTAB(f) L.tab.f = (const double*)(c + ((const int32_t*)K.f - K.ctab))
-  MRX_DTAB(src_base); MRX_DTAB(src_noise); MRX_DTAB(er_base); MRX_DTAB(er_noise); MRX_DTAB(fr_base); MRX_DTAB(fr_noise);
+  if (!K.pregen) { MRX_DTAB(src_base); MRX_DTAB(src_noise); }  // with the order table they stay in global memory
+  MRX_DTAB(er_base); MRX_DTAB(er_noise); MRX_DTAB(fr_base); MRX_DTAB(fr_noise);
 #undef MRX_DTAB
 }
 

@@ -186,7 +186,10 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   if (!k.pregen) { k.l_dsrc = w; w += dsrc_w; }
   k.misc_cap = dtgt_w / 3;
   if (!k.pregen) { k.l_dtgt = w; w += dtgt_w; k.l_misc = k.l_dtgt; }  // dtgt doubles as the discharge-record merge list:
-  else { k.l_misc = w; w += dtgt_w; }                                  // (key, v, q) x misc_cap, live only in phase B2
+  else {  // (key, v, q) x misc_cap in phase B2, then the NT-entry prefix array of phase B3
+    const int mw = NT + 1 > 3 * 64 ? (NT + 2) / 2 * 2 : 3 * 64;
+    k.l_misc = w; w += mw; k.misc_cap = mw / 3;
+  }
   k.l_oq = w; w += NT + 1;  // order quantity | (buffer ticks + 1) << 24
   k.l_odelay = k.l_oq;
   k.l_srcn = w; w += P;
@@ -212,19 +215,37 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   put_d(&CimParams::v_speed, t->vessel_speed, V); put_d(&CimParams::v_speed_noise, t->vessel_speed_noise, V);
   put_d(&CimParams::v_dur, t->vessel_duration, V); put_d(&CimParams::v_dur_noise, t->vessel_duration_noise, V);
   put_d(&CimParams::route_dist, t->route_dist, NRP); put_d(&CimParams::order_dist, t->order_dist, t->period);
-  const int64_t ctab_begin = (int64_t)((B.size() + 63) / 64 * 64);
-  B.resize((size_t)ctab_begin, 0);
-  align = 4;
-  put_d(&CimParams::src_base, t->source_base, P); put_d(&CimParams::src_noise, t->source_noise, P);
-  put_d(&CimParams::er_base, t->empty_return_base, P); put_d(&CimParams::er_noise, t->empty_return_noise, P);
-  put_d(&CimParams::fr_base, t->full_return_base, P); put_d(&CimParams::fr_noise, t->full_return_noise, P);
+  // int32 originals (global-memory users: reset kernel, fast path, query)
   put_i(&CimParams::tgt_off, t->target_offset, P + 1); put_i(&CimParams::tgt_port, t->target_port, NT);
   put_i(&CimParams::route_port, t->route_port, NRP);
   put_i(&CimParams::v_route_base, v_route_base.data(), V); put_i(&CimParams::v_route_len, v_route_len.data(), V);
   put_i(&CimParams::leg_off, leg_off.data(), V + 1); put_i(&CimParams::leg_time, leg_time.data(), leg_time.size());
-  if (!k.use_buffer_rng) { put_i(&CimParams::er_delay, er_delay.data(), P); put_i(&CimParams::fr_delay, fr_delay.data(), P); }
   put_i(&CimParams::rec_off, rec_off.data(), V + 1);
   put_i(&CimParams::v_cbase, v_cbase.data(), V); put_i(&CimParams::route_cidx, route_cidx.data(), NRP);
+  if (k.pregen) { put_d(&CimParams::src_base, t->source_base, P); put_d(&CimParams::src_noise, t->source_noise, P); }
+  const int64_t ctab_begin = (int64_t)((B.size() + 63) / 64 * 64);
+  B.resize((size_t)ctab_begin, 0);
+  align = 4;
+  // with the order table the source ratios are read by the order-table kernel only (from global memory)
+  if (!k.pregen) { put_d(&CimParams::src_base, t->source_base, P); put_d(&CimParams::src_noise, t->source_noise, P); }
+  put_d(&CimParams::er_base, t->empty_return_base, P); put_d(&CimParams::er_noise, t->empty_return_noise, P);
+  put_d(&CimParams::fr_base, t->full_return_base, P); put_d(&CimParams::fr_noise, t->full_return_noise, P);
+  if (!k.use_buffer_rng) { put_i(&CimParams::er_delay, er_delay.data(), P); put_i(&CimParams::fr_delay, fr_delay.data(), P); }
+  {
+    bool fits = true;
+    auto put_h = [&](const uint16_t* CimParams::*f, const int32_t* src, size_t n) {
+      std::vector<uint16_t> h(n ? n : 1, 0);
+      for (size_t i = 0; i < n; i++) { if (src[i] < 0 || src[i] > 65535) fits = false; h[i] = (uint16_t)src[i]; }
+      binds.push_back({(size_t)((char*)&(k.*f) - (char*)&k), blob_put(B, h.data(), h.size(), 2)});
+    };
+    put_h(&CimParams::h_tgt_off, t->target_offset, P + 1); put_h(&CimParams::h_tgt_port, t->target_port, NT);
+    put_h(&CimParams::h_route_port, t->route_port, NRP);
+    put_h(&CimParams::h_v_route_base, v_route_base.data(), V); put_h(&CimParams::h_v_route_len, v_route_len.data(), V);
+    put_h(&CimParams::h_leg_off, leg_off.data(), V + 1); put_h(&CimParams::h_leg_time, leg_time.data(), leg_time.size());
+    put_h(&CimParams::h_rec_off, rec_off.data(), V + 1);
+    put_h(&CimParams::h_v_cbase, v_cbase.data(), V); put_h(&CimParams::h_route_cidx, route_cidx.data(), NRP);
+    if (!fits) return fail("engine limit: a topology table entry (offsets, leg times) exceeds 65535");
+  }
   B.resize((B.size() + 63) / 64 * 64, 0);
   const int64_t ctab_end = (int64_t)B.size();
   align = 64;

@@ -48,7 +48,10 @@ struct CimParams {
   const int32_t *tgt_off, *tgt_port, *pair_src, *route_port, *v_route_base, *v_route_len, *v_start, *v_cap,
       *v_init_empty, *v_total_space, *p_cap, *p_init_empty, *leg_off, *leg_time, *v_period, *er_delay,
       *fr_delay, *rec_off, *v_route, *v_cbase, *route_cidx, *cidx_dense, *pair_dense;
-  const int32_t* ctab;  // start of the contiguous block holding tgt_off .. rec_off (ctab_words words)
+  const int32_t* ctab;  // start of the contiguous block staged in LDS by the step kernel (ctab_words words):
+                        // per-port fp64 tables, er/fr_delay, and 16-bit copies of the serial-access int tables
+  const uint16_t *h_tgt_off, *h_tgt_port, *h_route_port, *h_v_route_base, *h_v_route_len, *h_leg_off, *h_leg_time,
+      *h_rec_off, *h_v_cbase, *h_route_cidx;
   // ---- per-env state (device)
   int32_t *live, *ring, *ring_fi, *priv, *rec, *status, *tick, *nstops, *order_prop, *vperiod, *orders;
   uint32_t *mt, *stops;
