@@ -369,7 +369,7 @@ def main():
                        "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
                        "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms,
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
-            "roofline": {"bound": "hbm", "kernel": "mrx_k_cim_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "mrx_k_cim_step_tab" if engines[0].layout.order_table_on else "mrx_k_cim_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": "profiles/latest_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
                          "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": step_kernel_ms, "launches_in_flight": in_flight,
                          "definition": "achieved = algorithmic_bytes_per_launch / kernel_ms x launches_in_flight (mean number of overlapping step kernels, one per group stream)",

@@ -32,6 +32,21 @@ def summarise(path):
         a["mx"] = max(a["mx"], d)
         for k, v in pmc.get(ev, {}).items():
             a["pmc"][k] = a["pmc"].get(k, 0.0) + v
+    # overlap of dispatches of the same kernel (several streams): sum of durations / union of their intervals
+    spans = {}
+    for kid, ev, st, en, gx, wx, lds in rows:
+        spans.setdefault(names.get(kid, str(kid)), []).append((st, en))
+    for name, iv in spans.items():
+        iv.sort()
+        union, cs, ce = 0, iv[0][0], iv[0][1]
+        for st, en in iv[1:]:
+            if st > ce:
+                union += ce - cs
+                cs, ce = st, en
+            else:
+                ce = max(ce, en)
+        union += ce - cs
+        agg[name]["in_flight"] = agg[name]["tot"] / max(union, 1)
     total = sum(a["tot"] for a in agg.values()) or 1
     print(f"### {path}\n")
     print("| kernel | calls | total ms | mean us | min us | max us | % | grid | wg | LDS B | counters (mean per dispatch) |")
@@ -46,6 +61,8 @@ def summarise(path):
                 ctr.append(f"WRITE_SIZE {m:.1f} KiB ({m * 1024 / 1e6:.2f} MB)")
             else:
                 ctr.append(f"{k} {m:.4g}")
+        if a.get("in_flight", 1.0) > 1.05:
+            ctr.append("in flight %.2f" % a["in_flight"])
         print(f"| {name.replace('.kd', '')} | {a['n']} | {a['tot'] / 1e6:.3f} | {a['tot'] / a['n'] / 1e3:.1f} | "
               f"{a['mn'] / 1e3:.1f} | {a['mx'] / 1e3:.1f} | {100 * a['tot'] / total:.1f} | {a['grid']} | {a['wg']} | "
               f"{a['lds']} | {'; '.join(ctr)} |")
