@@ -111,6 +111,8 @@ typedef struct mrx_cim_config {
   int32_t max_snapshots;       /* core.py:49; <=0 -> ceil(durations/resolution) (abs_business_engine.py:115-129) */
   int32_t max_actions;         /* A: actions accepted per decision event per step (>=1) */
   int32_t max_stops;           /* <=0 -> engine computes a safe bound per vessel */
+  int32_t decision_mode;       /* DecisionMode, maro/simulator/abs_core.py:14-22: 0 Sequential (mrx_cim_step),
+                                  1 Joint, 2 JointWithSequentialAction (mrx_cim_step_joint) */
   int32_t order_table;         /* 0 = auto, 1 = on, -1 = off.  In `fixed` order mode the orders of a tick are a pure
                                   function of (seed, tick) (cim_data_container.py:309-398), so mrx_cim_reset can draw
                                   the whole episode's order table ahead of time (int32 [durations][n_targets] per env)
@@ -189,6 +191,22 @@ int mrx_cim_reset(mrx_handle h, const int64_t* d_seed_cmd, const uint8_t* d_env_
 int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_actions,
                  const uint8_t* d_env_mask, int32_t* d_decisions, int64_t* d_metrics,
                  uint8_t* d_done, void* stream);
+
+/*
+ * Env.step in DecisionMode.Joint / JointWithSequentialAction (core.py:354-366; engines created with
+ * mrx_cim_config.decision_mode 1 / 2): every pending decision event of the tick is reported at once.
+ *   d_decisions  int32 [n_envs][n_vessels][8]: one row per pending event in event (= vessel index) order, same columns as
+ *                mrx_cim_step; unused rows have valid = 0 (row 0 still carries tick and frame_index).  Rows are always
+ *                evaluated on the live state; the reference re-yields the same DecisionEvent objects, which cache
+ *                action_scope at their first read — keep the first row seen per (tick, vessel) to reproduce that.
+ *   d_actions    int32 [n_envs][A][4]: the answered events' actions, flattened in event order (they are applied in this order,
+ *                exactly as the reference runs each event's action list when the event is popped); d_n_actions int32 [n_envs]
+ *   d_n_answered int32 [n_envs] (JointWithSequentialAction): how many of the pending events were answered; the others
+ *                stay pending and are reported again.  NULL / negative = all.  In Joint mode unanswered events are
+ *                finished without an action (core.py:364-366), so the value is ignored.
+ */
+int mrx_cim_step_joint(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const int32_t* d_n_answered,
+                       const uint8_t* d_env_mask, int32_t* d_decisions, int64_t* d_metrics, uint8_t* d_done, void* stream);
 
 /*
  * Replaces snapshot_list[node][ticks:nodes:attrs] (frame.pyx:754-801, np_backend.pyx:520-549).

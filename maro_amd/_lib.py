@@ -16,7 +16,7 @@ class MrxCimConfig(ctypes.Structure):
     """ctypes mirror of ``struct mrx_cim_config`` (include/maro_amd.h)."""
 
     _fields_ = [(n, ctypes.c_int32) for n in ("n_envs", "device", "start_tick", "durations", "snapshot_resolution",
-                                              "max_snapshots", "max_actions", "max_stops", "order_table")]
+                                              "max_snapshots", "max_actions", "max_stops", "decision_mode", "order_table")]
 
 
 class MrxCimLayout(ctypes.Structure):
@@ -34,7 +34,7 @@ class MrxCimLayout(ctypes.Structure):
 
 
 EXPORTS = ("mrx_last_error", "mrx_version", "mrx_cim_workspace_bytes", "mrx_cim_create", "mrx_cim_destroy",
-           "mrx_cim_get_layout", "mrx_cim_reset", "mrx_cim_step", "mrx_cim_query", "mrx_cim_attr_id",
+           "mrx_cim_get_layout", "mrx_cim_reset", "mrx_cim_step", "mrx_cim_step_joint", "mrx_cim_query", "mrx_cim_attr_id",
            "mrx_cim_attr_slots", "mrx_cim_random_policy",
            # include/maro_amd_citi_bike.h
            "mrx_cb_workspace_bytes", "mrx_cb_create", "mrx_cb_destroy", "mrx_cb_get_layout", "mrx_cb_reset", "mrx_cb_step",
@@ -72,6 +72,8 @@ def load() -> ctypes.CDLL:
     L.mrx_cim_reset.argtypes = [vp, vp, vp, vp]
     L.mrx_cim_step.restype = i32
     L.mrx_cim_step.argtypes = [vp] * 8
+    L.mrx_cim_step_joint.restype = i32
+    L.mrx_cim_step_joint.argtypes = [vp] * 9
     L.mrx_cim_query.restype = i32
     L.mrx_cim_query.argtypes = [vp, i32, vp, i32, i32, vp, i32, i32, vp, i32, vp, vp]
     L.mrx_cim_random_policy.restype = i32

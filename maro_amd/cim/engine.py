@@ -37,7 +37,8 @@ class CimBatchEngine:
 
     def __init__(self, topology: Union[str, CimTopology], n_envs: int, start_tick: int = 0, durations: int = 100,
                  snapshot_resolution: int = 1, max_snapshots: Optional[int] = None, max_actions: int = 1,
-                 device: Union[str, torch.device] = "cuda:0", seeds: Optional[Sequence[int]] = None, order_table: int = 0):
+                 device: Union[str, torch.device] = "cuda:0", seeds: Optional[Sequence[int]] = None, order_table: int = 0,
+                 decision_mode: int = 0):
         self._L = _lib.load()  # raises if the HIP extension is not built
         if not torch.cuda.is_available():
             raise RuntimeError("maro_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
@@ -50,7 +51,9 @@ class CimBatchEngine:
         self.snapshot_resolution = int(snapshot_resolution)
         self._cs = self.topo.c_struct()
         self._cfg = _lib.MrxCimConfig(self.n_envs, dev_index, self.start_tick, self.durations,
-                                      self.snapshot_resolution, int(max_snapshots or 0), self.max_actions, 0, int(order_table))
+                                      self.snapshot_resolution, int(max_snapshots or 0), self.max_actions, 0, int(decision_mode),
+                                      int(order_table))
+        self.decision_mode = int(decision_mode)
         nbytes = self._L.mrx_cim_workspace_bytes(ctypes.byref(self._cs), ctypes.byref(self._cfg))
         _lib.check(nbytes, "mrx_cim_workspace_bytes")
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -71,7 +74,8 @@ class CimBatchEngine:
         self.ticks = self._view(lay.off_tick, torch.int32, (self.n_envs,))
         self.seeds = self._view(lay.off_seed, torch.int64, (self.n_envs,))
         # persistent outputs
-        self.decisions = torch.zeros((self.n_envs, 8), dtype=torch.int32, device=self.device)
+        dshape = (self.n_envs, 8) if self.decision_mode == 0 else (self.n_envs, lay.n_vessels, 8)  # Joint: a row per vessel
+        self.decisions = torch.zeros(dshape, dtype=torch.int32, device=self.device)
         self.metrics = torch.zeros((self.n_envs, 3), dtype=torch.int64, device=self.device)
         self.done = torch.zeros((self.n_envs,), dtype=torch.uint8, device=self.device)
         if seeds is not None:
@@ -110,7 +114,10 @@ class CimBatchEngine:
         _lib.check(self._L.mrx_cim_reset(self._h, self._p(sc), self._p(mk), self._stream()), "mrx_cim_reset")
         self._keep = (sc, mk)
 
-    def step(self, actions=None, n_actions=None, mask=None):
+    def step(self, actions=None, n_actions=None, mask=None, n_answered=None):
+        """Sequential mode: decisions [n, 8].  Joint modes (decision_mode 1 / 2): decisions [n, V, 8], one row per pending
+        event; `actions` is the flat list of the answered events' actions and `n_answered` (mode 2) how many events
+        they answer (None = all)."""
         a = self._dev(actions, torch.int32)
         na = self._dev(n_actions, torch.int32)
         mk = self._dev(mask, torch.uint8)
@@ -118,9 +125,15 @@ class CimBatchEngine:
             assert a.numel() == self.n_envs * self.max_actions * 4, "actions must be [n_envs, max_actions, 4]"
             if na is None:
                 na = torch.full((self.n_envs,), self.max_actions, dtype=torch.int32, device=self.device)
-        _lib.check(self._L.mrx_cim_step(self._h, self._p(a), self._p(na), self._p(mk), self.decisions.data_ptr(),
-                                        self.metrics.data_ptr(), self.done.data_ptr(), self._stream()), "mrx_cim_step")
-        self._keep = (a, na, mk)
+        if self.decision_mode == 0:
+            _lib.check(self._L.mrx_cim_step(self._h, self._p(a), self._p(na), self._p(mk), self.decisions.data_ptr(),
+                                            self.metrics.data_ptr(), self.done.data_ptr(), self._stream()), "mrx_cim_step")
+            self._keep = (a, na, mk)
+        else:
+            nans = self._dev(n_answered, torch.int32)
+            _lib.check(self._L.mrx_cim_step_joint(self._h, self._p(a), self._p(na), self._p(nans), self._p(mk), self.decisions.data_ptr(),
+                                                  self.metrics.data_ptr(), self.done.data_ptr(), self._stream()), "mrx_cim_step_joint")
+            self._keep = (a, na, mk, nans)
         return self.decisions, self.metrics, self.done
 
     def random_policy(self, step: int, actions: torch.Tensor, n_actions: torch.Tensor,

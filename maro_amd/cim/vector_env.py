@@ -98,11 +98,13 @@ class GpuVectorEnv:
         if scenario != "cim":
             raise NotImplementedError("the GPU engine implements the 'cim' and 'citi_bike' scenarios; use "
                                       "maro.simulator.Env for others")
-        if int(getattr(decision_mode, "value", decision_mode)) != 0:
-            raise NotImplementedError("only DecisionMode.Sequential is implemented on the GPU engine")
+        mode = int(getattr(decision_mode, "value", decision_mode))
+        if mode not in (0, 1, 2):
+            raise ValueError("decision_mode must be Sequential (0), Joint (1) or JointWithSequentialAction (2)")
         self.engine = _engine if _engine is not None else CimBatchEngine(
             topology, batch_num, start_tick=start_tick, durations=durations, snapshot_resolution=snapshot_resolution,
-            max_snapshots=max_snapshots, max_actions=max_actions, device=device, seeds=seeds)
+            max_snapshots=max_snapshots, max_actions=max_actions, device=device, seeds=seeds, decision_mode=mode)
+        self._mode = int(getattr(self.engine, "decision_mode", mode))
         self._init_state(batch_num)
 
     def _init_state(self, batch_num: int):
@@ -111,7 +113,9 @@ class GpuVectorEnv:
         self._paused = np.zeros(batch_num, bool)
         self._finished = np.zeros(batch_num, bool)     # (metrics, None, True) already returned
         self._pending_seed: Dict[int, int] = {}
-        self._last_dec = np.zeros((batch_num, 8), np.int32)
+        self._last_dec = [None] * batch_num
+        self._joint_events: Dict[int, dict] = {}   # env -> {(tick, vessel): DecisionEvent} (JointWithSequentialAction)
+        self._n_pending = np.zeros(batch_num, np.int32)
         self._last_met = np.zeros((batch_num, 3), np.int64)
         self._snapshots = _SnapshotList(self)
 
@@ -161,6 +165,7 @@ class GpuVectorEnv:
                 cmd[e] = self._pending_seed[e]
             self._pending_seed.pop(e, None)
             self._started[e] = self._paused[e] = self._finished[e] = False
+            self._joint_events.pop(e, None)
         self.engine.reset(cmd, mask)
 
     def set_seed(self, seed: int, envs: Optional[Sequence[int]] = None):
@@ -186,21 +191,31 @@ class GpuVectorEnv:
         A = eng.max_actions
         acts = np.zeros((self._n, A, self.ACTION_WIDTH), np.int32)
         nact = np.zeros(self._n, np.int32)
+        nans = np.full(self._n, -1, np.int32)
         mask = np.zeros(self._n, np.uint8)
+        joint = getattr(self, "_mode", 0) != 0
         out = {}
         for e in envs:
             if self._finished[e]:
                 out[e] = (None, None, True)          # core.py:128-133
                 continue
             mask[e] = 1
-            alist = _as_list(per_env.get(e))
+            if joint:
+                # core.py:354-366: one entry (Action / list / None) per pending event, zipped in event order
+                per_event = per_env.get(e)
+                per_event = [] if per_event is None else list(per_event) if isinstance(per_event, (list, tuple)) else [per_event]
+                per_event = per_event[:int(self._n_pending[e])]
+                nans[e] = len(per_event)
+                alist = [a for entry in per_event for a in _as_list(entry)]
+            else:
+                alist = _as_list(per_env.get(e))
             if len(alist) > A:
                 raise ValueError(f"{len(alist)} actions for one decision event; engine was built with max_actions={A}")
             for i, a in enumerate(alist):
                 acts[e, i] = self._encode_action(a)
             nact[e] = len(alist)
         if mask.any():
-            dec, met, done, extra = self._engine_step(acts, nact, mask)
+            dec, met, done, extra = self._engine_step(acts, nact, mask, nans if joint else None)
             status = eng.status.cpu().numpy()
             for e in envs:
                 if not mask[e]:
@@ -216,15 +231,34 @@ class GpuVectorEnv:
                     out[e] = (metrics, None, True)
                 else:
                     self._paused[e] = True
-                    out[e] = (metrics, self._make_event(e, dec[e], extra), False)
+                    out[e] = (metrics, self._make_joint_events(e, dec[e]) if joint else self._make_event(e, dec[e], extra), False)
         return [out[e] for e in envs]
+
+    def _make_joint_events(self, e: int, rows) -> list:
+        """Joint modes: every pending event of the tick.  An event that stayed pending is re-yielded as the SAME object
+        (its action scope cached at the first read, cim/common.py:107-123), like the reference does."""
+        cache = self._joint_events.setdefault(e, {})
+        events, keep = [], {}
+        for row in rows:
+            if row[7] != 1:
+                continue
+            key = (int(row[0]), int(row[2]))
+            ev = cache.get(key) or make_decision_event(row, _SnapshotList(self, [e]))
+            keep[key] = ev
+            events.append(ev)
+        self._joint_events[e] = keep
+        self._n_pending[e] = len(events)
+        return events
 
     # ---- scenario hooks (overridden by CitiBikeVectorEnv)
     def _encode_action(self, a) -> tuple:
         return encode_action(a)
 
-    def _engine_step(self, acts, nact, mask):
-        dec, met, done = self.engine.step(acts, nact, mask)
+    def _engine_step(self, acts, nact, mask, n_answered=None):
+        if n_answered is None:
+            dec, met, done = self.engine.step(acts, nact, mask)
+        else:
+            dec, met, done = self.engine.step(acts, nact, mask, n_answered=n_answered)
         return dec.cpu().numpy(), met.cpu().numpy(), done.cpu().numpy(), None
 
     def _make_event(self, e: int, row, extra):

@@ -51,7 +51,7 @@ class CitiBikeVectorEnv(GpuVectorEnv):
     def _encode_action(self, a) -> tuple:
         return encode_action(a)
 
-    def _engine_step(self, acts, nact, mask):
+    def _engine_step(self, acts, nact, mask, n_answered=None):
         dec, scope, met, done = self.engine.step(acts, nact, mask)
         return dec.cpu().numpy(), met.cpu().numpy(), done.cpu().numpy(), scope.cpu().numpy()
 

@@ -1067,8 +1067,17 @@ MRX_DEV bool fast_step(const CimParams& K, int env, const FastRows& R, int n_act
 // ==========================================================================================
 // STEP: Env.step(action) in Sequential mode
 //   decision[8] = (tick, port, vessel, scope.load, scope.discharge, early_discharge, frame_index, valid)
+// Decision events consumed by a step (core.py:349-366): Sequential answers the current vessel's event; Joint finishes
+// every pending event of the tick (answered or not); JointWithSequentialAction the first n_answered in event order.
+MRX_DEV uint64_t consume_decisions(const CimParams& K, uint64_t pend, int cur, int n_answered) {
+  if (K.decision_mode == 0) return pend & ~(1ull << (cur & 63));
+  if (K.decision_mode == 1 || n_answered < 0) return 0ull;
+  for (int k = 0; k < n_answered && pend; k++) pend &= pend - 1;
+  return pend;
+}
+
 template <bool PG>
-MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* actions, int n_act,
+MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* actions, int n_act, int n_answered,
                       int32_t* dec_out, long long* met_out, uint8_t* done_out) {
   Lds L = make_lds(K, lds);
   Prof prof;
@@ -1080,7 +1089,7 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
 
   // The 64-byte private header and the first action decide which path this step takes.
   if (n_act > K.max_actions) n_act = K.max_actions;
-  {
+  if (K.decision_mode == 0) {  // Sequential
     FastRows rows;
     fast_rows_request(K, env, rows);
     int f0v = 0, f0p = 0, f0q = 0, f0t = 0;
@@ -1130,7 +1139,7 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   // second memory round trip overlaps with the action handling and post_step below.
   TickPf pf = {};
   {
-    const uint64_t pend_after = fresh ? 0ull : (pend & ~(1ull << (L.priv[PH_CUR_VESSEL] & 63)));
+    const uint64_t pend_after = fresh ? 0ull : consume_decisions(K, pend, L.priv[PH_CUR_VESSEL], n_answered);
     const int tn = fresh ? t : t + 1;
     if (!pend_after && tn < K.T) {
       tick_prefetch_static(K, pf, !PG);
@@ -1167,8 +1176,7 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
         else status |= 32;  // MRX_ENV_OFFROUTE_ACTION
       }
     }
-    const int cur = L.priv[PH_CUR_VESSEL];
-    pend &= ~(1ull << cur);
+    pend = consume_decisions(K, pend, L.priv[PH_CUR_VESSEL], n_answered);
     wave::sync();
   }
   prof.mark(PF_ACTION);
@@ -1211,7 +1219,25 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   acc_b = wave::reduce_add(acc_b);
   acc_s = wave::reduce_add(acc_s);
   const int fi = (t - K.start_tick) / K.resolution;
-  if (!finished) {
+  if (K.decision_mode != 0) {
+    // Joint modes: one row per pending decision event, in event (= vessel) order; dec_out is [V][8]
+    const uint64_t pm = finished ? 0ull : pend;
+    const bool mine = lane < V && ((pm >> lane) & 1ull);
+    if (mine) {
+      const int r = __builtin_popcountll(pm & ((1ull << lane) - 1ull));
+      const int v = lane, p = FV(VA_LOC_PORT_IDX, v);
+      const int pe = FP(PA_EMPTY, p), rs = FV(VA_REMAINING_SPACE, v);
+      int32_t* d = dec_out + 8 * r;
+      d[0] = t; d[1] = p; d[2] = v; d[3] = pe < rs ? pe : rs; d[4] = FV(VA_EMPTY, v); d[5] = FV(VA_EARLY_DISCHARGE, v);
+      d[6] = fi; d[7] = 1;
+    }
+    const int cnt = __builtin_popcountll(pm);
+    if (lane < V && lane >= cnt) {
+      int32_t* d = dec_out + 8 * lane;
+      for (int j = 0; j < 8; j++) d[j] = 0;
+      if (lane == 0) { d[0] = t; d[6] = fi; }
+    }
+  } else if (!finished) {
     // The pre-decision snapshot (core.py:345) is ALIASED, not copied: while an env is paused, frame index
     // fi(t) of its snapshot list is its live frame (mrx_cim_query resolves it); see DESIGN.md.
     if (lane == 0) {

@@ -56,14 +56,16 @@ mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const
 #define MRX_STEP_KERNEL(NAME, PG)                                                                                  \
   extern "C" __global__ void __launch_bounds__(64)                                                                  \
   NAME(CimParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions,                     \
-       const uint8_t* __restrict__ mask, int32_t* __restrict__ decisions, long long* __restrict__ metrics,          \
-       uint8_t* __restrict__ done) {                                                                                \
+       const int32_t* __restrict__ n_answered, const uint8_t* __restrict__ mask, int32_t* __restrict__ decisions,   \
+       long long* __restrict__ metrics, uint8_t* __restrict__ done) {                                               \
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];                                                   \
     const int env = blockIdx.x;                                                                                     \
     if (mask && !mask[env]) return;                                                                                 \
     const int32_t* a = actions ? actions + (size_t)env * K.max_actions * 4 : nullptr;                               \
     const int na = (actions && n_actions) ? n_actions[env] : 0;                                                     \
-    cim::step_env<PG>(K, env, lds, a, na, decisions + (size_t)env * 8, metrics + (size_t)env * 3, done + env);      \
+    const size_t drow = K.decision_mode ? (size_t)K.V * 8 : 8; /* Joint modes: one row per vessel */                \
+    cim::step_env<PG>(K, env, lds, a, na, n_answered ? n_answered[env] : -1, decisions + (size_t)env * drow,        \
+                      metrics + (size_t)env * 3, done + env);                                                       \
   }
 MRX_STEP_KERNEL(mrx_k_cim_step, false)
 MRX_STEP_KERNEL(mrx_k_cim_step_tab, true)
@@ -230,8 +232,23 @@ int mrx_cim_reset(mrx_handle h, const int64_t* d_seed_cmd, const uint8_t* d_env_
   return MRX_OK;
 }
 
+static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const int32_t* d_n_answered,
+                       const uint8_t* d_env_mask, int32_t* d_decisions, int64_t* d_metrics, uint8_t* d_done, void* stream);
+
 int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const uint8_t* d_env_mask,
                  int32_t* d_decisions, int64_t* d_metrics, uint8_t* d_done, void* stream) {
+  if (h && h->plan.kp.decision_mode != 0) return set_err(MRX_ERR_INVALID_ARG, "engine was created in a Joint decision mode: use mrx_cim_step_joint");
+  return launch_step(h, d_actions, d_n_actions, nullptr, d_env_mask, d_decisions, d_metrics, d_done, stream);
+}
+
+int mrx_cim_step_joint(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const int32_t* d_n_answered,
+                       const uint8_t* d_env_mask, int32_t* d_decisions, int64_t* d_metrics, uint8_t* d_done, void* stream) {
+  if (h && h->plan.kp.decision_mode == 0) return set_err(MRX_ERR_INVALID_ARG, "engine was created in Sequential decision mode: use mrx_cim_step");
+  return launch_step(h, d_actions, d_n_actions, d_n_answered, d_env_mask, d_decisions, d_metrics, d_done, stream);
+}
+
+static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const int32_t* d_n_answered,
+                       const uint8_t* d_env_mask, int32_t* d_decisions, int64_t* d_metrics, uint8_t* d_done, void* stream) {
   if (!h || !d_decisions || !d_metrics || !d_done) return set_err(MRX_ERR_INVALID_ARG, "null handle/output pointer");
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
@@ -239,10 +256,10 @@ int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_acti
   static const size_t lds_pad = getenv("MRX_DEBUG_LDS_PAD_BYTES") ? (size_t)atoi(getenv("MRX_DEBUG_LDS_PAD_BYTES")) : 0;  // occupancy experiments
   if (K.pregen)
     hipLaunchKernelGGL(mrx_k_cim_step_tab, dim3(K.n_envs), dim3(64), (size_t)K.lds_words * 4 + lds_pad, (hipStream_t)stream, K, d_actions,
-                       d_n_actions, d_env_mask, d_decisions, (long long*)d_metrics, d_done);
+                       d_n_actions, d_n_answered, d_env_mask, d_decisions, (long long*)d_metrics, d_done);
   else
     hipLaunchKernelGGL(mrx_k_cim_step, dim3(K.n_envs), dim3(64), (size_t)K.lds_words * 4 + lds_pad, (hipStream_t)stream, K, d_actions,
-                       d_n_actions, d_env_mask, d_decisions, (long long*)d_metrics, d_done);
+                       d_n_actions, d_n_answered, d_env_mask, d_decisions, (long long*)d_metrics, d_done);
   HIP_TRY(hipGetLastError());
   return MRX_OK;
 }

@@ -77,6 +77,8 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   k.vrows = 10 + 2 * k.past_n + 2 * k.future_n;
   k.start_tick = c->start_tick; k.T = c->start_tick + c->durations; k.resolution = c->snapshot_resolution;
   k.max_actions = c->max_actions > 0 ? c->max_actions : 1;
+  if (c->decision_mode < 0 || c->decision_mode > 2) { if (err) *err = "decision_mode must be 0, 1 or 2"; return MRX_ERR_INVALID_ARG; }
+  k.decision_mode = c->decision_mode;
   k.period = t->period; k.vol = t->container_volume; k.total_containers = t->total_containers; k.order_mode = t->order_mode;
   k.sample_noise = t->sample_noise;
   int total_frames = (int)ceil((double)c->durations / (double)c->snapshot_resolution);

@@ -40,6 +40,7 @@ struct CimParams {
   int l_frame, l_priv, l_mt0, l_mt1, l_dsrc, l_dtgt, l_oq, l_odelay, l_srcn, l_misc, lds_words;
   int l_ctab, ctab_words;  // serial-access int tables staged in LDS by the step kernel
   int l_mt2, l_mt3, lds_words_reset;  // reset kernel only (placed after the step kernel's LDS)
+  int decision_mode;  // 0 Sequential, 1 Joint, 2 JointWithSequentialAction (core.py:349-366)
   int pregen, NTP;  // order table: rows of NTP (= NT rounded up to 4) words, one per tick of the episode
   int g_mt0, g_dsrc, g_dtgt, g_oq, g_srcn, g_ctab, lds_words_gen;  // LDS layout of the order-table kernel
   // ---- constant tables (device)

@@ -697,6 +697,63 @@ int cim_oracle_step(cim_oracle* o, const int32_t* actions, int n_actions, int32_
   return 1;
 }
 
+/* Env.step in DecisionMode.Joint (mode 1) / JointWithSequentialAction (mode 2), core.py:354-366: every pending
+ * decision event of the tick is reported (EventLinkedList._collect_pending_decision_events, event_linked_list.py:108-115);
+ * the first `n_answered` get their actions, the others are FINISHED (mode 1) or stay pending (mode 2).  The flat
+ * `actions` list is attached to the first answered event: pending-decision events have no handlers, so running all
+ * actions when the first event is popped is the order the reference executes them in.
+ * decisions: [V][8] rows (valid flag in column 7).  Returns 1 when the episode is over. */
+int cim_oracle_step_joint(cim_oracle* o, int mode, const int32_t* actions, int n_actions, int n_answered, int32_t* decisions,
+                          int64_t metrics[3]) {
+  memset(decisions, 0, sizeof(int32_t) * 8 * (size_t)o->V);
+  if (o->finished) { decisions[7] = -1; metrics[0] = metrics[1] = metrics[2] = 0; return 1; }
+  if (o->waiting_action) {
+    int i = 0;
+    for (event* de = o->pending0; de && de->type == EV_PENDING_DECISION; de = de->next, i++) {
+      if (i < n_answered) {
+        de->state = ST_EXECUTING; /* _assign_action core.py:301-315 */
+        event* ae = ev_new(o->tick, EV_TAKE_ACTION, 0, 0, 0, 0);
+        const int n = i == 0 ? n_actions : 0;
+        ae->n_actions = n;
+        ae->actions = (int32_t*)malloc(sizeof(int32_t) * 4 * (size_t)(n > 0 ? n : 1));
+        if (n > 0) memcpy(ae->actions, actions, sizeof(int32_t) * 4 * (size_t)n);
+        ev_add_immediate(de, ae, 1);
+      } else if (mode == 1) {
+        de->state = ST_FINISHED; /* core.py:364-366 */
+      }
+    }
+    o->waiting_action = 0;
+  } else {
+    be_step(o, o->tick);
+  }
+  for (;;) {
+    event* pend = eb_execute(o, o->tick);
+    if (pend) {
+      int fi = frame_index(o, o->tick);
+      take_snapshot(o, fi); /* core.py:345 */
+      int r = 0;
+      for (event* de = pend; de && de->type == EV_PENDING_DECISION; de = de->next, r++) {
+        int port = de->a, v = de->b;
+        int pe = PORT(o, port, PA_EMPTY), rs = VES(o, v, VA_REMAINING_SPACE);
+        int32_t* d = decisions + 8 * r;
+        d[0] = o->tick; d[1] = port; d[2] = v; d[3] = pe < rs ? pe : rs; d[4] = VES(o, v, VA_EMPTY);
+        d[5] = VES(o, v, VA_EARLY_DISCHARGE); d[6] = fi; d[7] = 1;
+      }
+      get_metrics(o, metrics);
+      o->pending0 = pend; o->waiting_action = 1;
+      return 0;
+    }
+    if (post_step(o, o->tick)) break;
+    o->tick += 1;
+    be_step(o, o->tick);
+  }
+  if ((o->tick + 1) % o->resolution != 0) take_snapshot(o, frame_index(o, o->tick));
+  get_metrics(o, metrics);
+  decisions[0] = o->tick; decisions[6] = frame_index(o, o->tick); decisions[7] = 0;
+  o->finished = 1;
+  return 1;
+}
+
 static int attr_slots(const cim_oracle* o, int node_type, int attr) {
   if (node_type == 0) return attr >= 0 && attr < PA_COUNT ? 1 : -1;
   if (node_type == 1) {

@@ -48,6 +48,9 @@ def lib():
         L.cim_oracle_reset.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.cim_oracle_step.restype = ctypes.c_int
         L.cim_oracle_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.cim_oracle_step_joint.restype = ctypes.c_int
+        L.cim_oracle_step_joint.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_void_p]
         L.cim_oracle_query.restype = ctypes.c_int64
         L.cim_oracle_query.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
@@ -110,6 +113,16 @@ class CimOracle:
         dec = np.zeros(8, np.int32)
         met = np.zeros(3, np.int64)
         done = lib().cim_oracle_step(self._h, acts.ctypes.data, acts.shape[0], dec.ctypes.data, met.ctypes.data)
+        return met, dec, bool(done)
+
+    def step_joint(self, mode: int, actions: Optional[Sequence[Sequence[int]]] = None, n_answered: int = 1 << 20):
+        """DecisionMode.Joint (mode 1) / JointWithSequentialAction (mode 2): `actions` is the flat list of the answered
+        events' actions.  Returns (metrics int64[3], decisions int32[V, 8] with a valid flag in column 7, done)."""
+        acts = _i32(actions).reshape(-1, 4) if actions is not None and len(actions) else np.zeros((0, 4), np.int32)
+        dec = np.zeros((self.topo.n_vessels, 8), np.int32)
+        met = np.zeros(3, np.int64)
+        done = lib().cim_oracle_step_joint(self._h, int(mode), acts.ctypes.data, acts.shape[0], int(n_answered), dec.ctypes.data,
+                                           met.ctypes.data)
         return met, dec, bool(done)
 
     def query(self, node: str, ticks: Sequence[int], nodes: Sequence[int], attrs: Sequence[str]) -> np.ndarray:

@@ -63,7 +63,7 @@ void emu_reset(void* h, const int64_t* seed_cmd, const uint8_t* mask, int revers
 }
 
 void emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const uint8_t* mask, int32_t* dec,
-              int64_t* met, uint8_t* done, int reverse) {
+              int64_t* met, uint8_t* done, int reverse, const int32_t* n_answered) {
   Emu* e = (Emu*)h;
   const CimParams& K = e->plan.kp;
   e->wave.reverse = reverse != 0;
@@ -73,8 +73,10 @@ void emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const u
     const int32_t* a = actions ? actions + (size_t)env * K.max_actions * 4 : nullptr;
     int na = (actions && n_actions) ? n_actions[env] : 0;
     wave::run_wave(e->wave, [&]() {
-      if (K.pregen) cim::step_env<true>(K, env, e->lds, a, na, dec + (size_t)env * 8, (long long*)(met + (size_t)env * 3), done + env);
-      else cim::step_env<false>(K, env, e->lds, a, na, dec + (size_t)env * 8, (long long*)(met + (size_t)env * 3), done + env);
+      const size_t drow = K.decision_mode ? (size_t)K.V * 8 : 8;
+      const int nans = n_answered ? n_answered[env] : -1;
+      if (K.pregen) cim::step_env<true>(K, env, e->lds, a, na, nans, dec + (size_t)env * drow, (long long*)(met + (size_t)env * 3), done + env);
+      else cim::step_env<false>(K, env, e->lds, a, na, nans, dec + (size_t)env * drow, (long long*)(met + (size_t)env * 3), done + env);
     });
   }
 }

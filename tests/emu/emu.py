@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, "libcim_emu.so")
 
 class MrxCimConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("n_envs", "device", "start_tick", "durations", "snapshot_resolution",
-                                              "max_snapshots", "max_actions", "max_stops", "order_table")]
+                                              "max_snapshots", "max_actions", "max_stops", "decision_mode", "order_table")]
 
 
 class MrxCimLayout(ctypes.Structure):
@@ -51,7 +51,7 @@ def lib():
         L.emu_workspace.restype = ctypes.c_void_p
         L.emu_workspace.argtypes = [ctypes.c_void_p]
         L.emu_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-        L.emu_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6 + [ctypes.c_int]
+        L.emu_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_void_p]
         L.emu_query.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         _lib = L
@@ -66,11 +66,11 @@ class EmuBackend:
     """Batch backend with the same numpy-facing surface as the tests' GPU backend wrapper."""
 
     def __init__(self, topo, n_envs=1, start_tick=0, durations=100, snapshot_resolution=1, max_snapshots=None,
-                 max_actions=2, reverse=False, order_table=0):
+                 max_actions=2, reverse=False, order_table=0, decision_mode=0):
         self.topo = topo
         self._cs = topo.c_struct()
         self.cfg = MrxCimConfig(n_envs, 0, start_tick, durations, snapshot_resolution, max_snapshots or 0,
-                                max_actions, 0, order_table)
+                                max_actions, 0, decision_mode, order_table)
         err = ctypes.create_string_buffer(256)
         self._h = lib().emu_create(ctypes.byref(self._cs), ctypes.byref(self.cfg), err, 256)
         if not self._h:
@@ -97,16 +97,17 @@ class EmuBackend:
         mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         lib().emu_reset(self._h, _ptr(sc), _ptr(mk), int(self.reverse))
 
-    def step(self, actions=None, n_actions=None, mask=None):
+    def step(self, actions=None, n_actions=None, mask=None, n_answered=None):
         a = None if actions is None else np.ascontiguousarray(actions, np.int32).reshape(self.n_envs, self.max_actions, 4)
         na = None if n_actions is None else np.ascontiguousarray(n_actions, np.int32)
         mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        nans = None if n_answered is None else np.ascontiguousarray(n_answered, np.int32)
         if not hasattr(self, "_dec"):
-            self._dec = np.zeros((self.n_envs, 8), np.int32)
+            self._dec = np.zeros((self.n_envs, 8) if self.cfg.decision_mode == 0 else (self.n_envs, self.layout.n_vessels, 8), np.int32)
             self._met = np.zeros((self.n_envs, 3), np.int64)
             self._done = np.zeros(self.n_envs, np.uint8)
         lib().emu_step(self._h, _ptr(a), _ptr(na), _ptr(mk), _ptr(self._dec), _ptr(self._met), _ptr(self._done),
-                       int(self.reverse))
+                       int(self.reverse), _ptr(nans))
         return self._dec.copy(), self._met.copy(), self._done.copy()
 
     def query(self, node_type, ticks, nodes, attrs, row_slots):

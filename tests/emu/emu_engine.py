@@ -10,9 +10,11 @@ from tests.emu.emu import EmuBackend
 
 class EmuEngine:
     def __init__(self, topology, n_envs, start_tick=0, durations=100, snapshot_resolution=1, max_snapshots=None,
-                 max_actions=1, seeds=None):
+                 max_actions=1, seeds=None, decision_mode=0):
         self.topo = topology if not isinstance(topology, str) else load_topology(topology)
-        self.b = EmuBackend(self.topo, n_envs, start_tick, durations, snapshot_resolution, max_snapshots, max_actions)
+        self.b = EmuBackend(self.topo, n_envs, start_tick, durations, snapshot_resolution, max_snapshots, max_actions,
+                            decision_mode=decision_mode)
+        self.decision_mode = decision_mode
         self.n_envs, self.max_actions = n_envs, max_actions
         self.start_tick, self.durations, self.snapshot_resolution = start_tick, durations, snapshot_resolution
         self.max_tick = start_tick + durations
@@ -29,10 +31,11 @@ class EmuEngine:
     def reset(self, seed_cmd=None, mask=None):
         self.b.reset(None if seed_cmd is None else np.asarray(seed_cmd), None if mask is None else np.asarray(mask))
 
-    def step(self, actions=None, n_actions=None, mask=None):
+    def step(self, actions=None, n_actions=None, mask=None, n_answered=None):
         d, m, dn = self.b.step(None if actions is None else np.asarray(actions),
                                None if n_actions is None else np.asarray(n_actions),
-                               None if mask is None else np.asarray(mask))
+                               None if mask is None else np.asarray(mask),
+                               n_answered=None if n_answered is None else np.asarray(n_answered))
         self.decisions, self.metrics, self.done = torch.from_numpy(d), torch.from_numpy(m), torch.from_numpy(dn)
         return self.decisions, self.metrics, self.done
 

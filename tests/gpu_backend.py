@@ -8,10 +8,10 @@ from maro_amd.cim.engine import CimBatchEngine
 
 class GpuBackend:
     def __init__(self, topo, n_envs=1, start_tick=0, durations=100, snapshot_resolution=1, max_snapshots=None,
-                 max_actions=2):
+                 max_actions=2, decision_mode=0, order_table=0):
         self.eng = CimBatchEngine(topo, n_envs, start_tick=start_tick, durations=durations,
                                   snapshot_resolution=snapshot_resolution, max_snapshots=max_snapshots,
-                                  max_actions=max_actions)
+                                  max_actions=max_actions, decision_mode=decision_mode, order_table=order_table)
         self.topo = self.eng.topo
         self.layout = self.eng.layout
         self.n_envs, self.max_actions, self.max_tick = n_envs, max_actions, start_tick + durations
@@ -24,8 +24,8 @@ class GpuBackend:
     def reset(self, seed_cmd=None, mask=None):
         self.eng.reset(seed_cmd, mask)
 
-    def step(self, actions=None, n_actions=None, mask=None):
-        d, m, dn = self.eng.step(actions, n_actions, mask)
+    def step(self, actions=None, n_actions=None, mask=None, n_answered=None):
+        d, m, dn = self.eng.step(actions, n_actions, mask, n_answered=n_answered)
         torch.cuda.synchronize()
         return d.cpu().numpy(), m.cpu().numpy(), dn.cpu().numpy()
 

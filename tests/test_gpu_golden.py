@@ -4,7 +4,7 @@ the stochastic order generator is reproduced exactly, so no tolerance is needed)
 import numpy as np
 import pytest
 
-from tests.golden_util import MATRIX_ATTRS, PORT_ATTRS, VESSEL_ATTRS, golden_cases
+from tests.golden_util import MATRIX_ATTRS, PORT_ATTRS, VESSEL_ATTRS, golden_cases, joint_golden_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -21,6 +21,20 @@ def _make(topo, kwargs):
 def test_hip_engine_reproduces_reference(name):
     from tests.test_oracle_golden import replay_case
     replay_case(_make, name)
+
+
+@pytest.mark.parametrize("name", joint_golden_cases())
+def test_hip_engine_joint_decision_modes(name):
+    """DecisionMode.Joint / JointWithSequentialAction through mrx_cim_step_joint."""
+    from tests.gpu_backend import GpuBackend
+    from tests.golden_util import replay_joint_case
+    from tests.test_emu_joint import JointAdapter
+
+    def make(topo, kwargs, mode):
+        b = GpuBackend(topo, n_envs=3, durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
+                       max_snapshots=kwargs.get("max_snapshots"), max_actions=topo.n_vessels, decision_mode=mode)
+        return JointAdapter(b, env=2)
+    replay_joint_case(make, name)
 
 
 def test_extension_is_loaded_not_a_fallback():

@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 
 from oracle.cim_oracle import CimOracle, mt_selftest
-from tests.golden_util import MATRIX_ATTRS, PORT_ATTRS, VESSEL_ATTRS, case_topology, golden_cases, load_case, segment_actions
+from tests.golden_util import (MATRIX_ATTRS, PORT_ATTRS, VESSEL_ATTRS, case_topology, golden_cases, joint_golden_cases, load_case,
+                               replay_joint_case, segment_actions)
 
 
 def test_mt19937_matches_cpython_random():
@@ -125,3 +126,20 @@ def test_reference_known_answers():
         while not done:
             met, dec, done = env.step(None)
         assert tuple(met.tolist()) == expect
+
+
+class _OracleJoint:
+    def __init__(self, topo, kwargs, mode):
+        self.o, self.mode = CimOracle(topo, **kwargs), mode
+
+    def step_joint(self, actions, n_answered):
+        return self.o.step_joint(self.mode, actions, n_answered)
+
+    def __getattr__(self, name):
+        return getattr(self.o, name)
+
+
+@pytest.mark.parametrize("name", joint_golden_cases())
+def test_oracle_joint_decision_modes(name):
+    """DecisionMode.Joint / JointWithSequentialAction (core.py:354-366) against the real reference."""
+    replay_joint_case(_OracleJoint, name)

@@ -120,3 +120,40 @@ def test_vector_env_on_emulator():
 
 def test_env_view_on_emulator():
     check_env_view(emu_factory)
+
+
+def check_joint_object_api(engine_factory, case):
+    """DecisionMode.Joint / JointWithSequentialAction through GpuVectorEnv: lists of DecisionEvents in, lists of Actions
+    out, replaying what the real reference did (tests/golden/cimjoint_*.npz)."""
+    from tests.golden_util import case_topology, load_joint_case
+    z, meta = load_joint_case(case)
+    topo = case_topology(meta)
+    kw = meta["kwargs"]
+    mode = meta["decision_mode"]
+    eng = engine_factory(topo, 2, max_actions=topo.n_vessels, decision_mode=mode, **kw)
+    env = GpuVectorEnv(2, "cim", topo, decision_mode=mode, _engine=eng, **kw)
+    gd, ga, gn, gm = z["decisions"], z["actions"], z["n_answered"], z["metrics"]
+    metrics, events, all_done = env.step(None)
+    i = 0
+    while not all_done:
+        for e in range(2):
+            evs = events[e]
+            want = gd[i][gd[i][:, 7] == 1]
+            assert isinstance(evs, list) and len(evs) == len(want)
+            got = [[ev.tick, ev.port_idx, ev.vessel_idx, ev.action_scope.load, ev.action_scope.discharge, ev.early_discharge] for ev in evs]
+            assert got == want[:, :6].tolist(), (case, i, e)
+            assert [metrics[e][k] for k in ("order_requirements", "container_shortage", "operation_number")] == gm[i].tolist()
+        k = int(gn[i])
+        acts = [Action(int(a[0]), int(a[1]), int(a[2]), ActionType.LOAD if a[3] == 0 else ActionType.DISCHARGE) for a in ga[i][:k]]
+        # env 0: one Action per event; env 1: the same wrapped in single-element lists (both forms are accepted, core.py:301-313)
+        metrics, events, all_done = env.step([acts, [[a] for a in acts]])
+        i += 1
+    assert i == len(gd)
+    assert [metrics[0][k] for k in ("order_requirements", "container_shortage", "operation_number")] == z["final_metrics"].tolist()
+    snap = env.snapshot_list["ports"][::["empty", "full", "shortage", "booking"]]
+    assert np.array_equal(snap[0], snap[1])
+
+
+@pytest.mark.parametrize("case", ["jointseq_toy5p_l05_some", "joint_toy6p_l08_all"])
+def test_joint_decision_modes_object_api(case):
+    check_joint_object_api(emu_factory, case)
