@@ -56,6 +56,9 @@ def load() -> ctypes.CDLL:
         raise ExtensionMissingError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c \"import __graft_entry__ as g; "
             f"g.build()\"` (hipcc --offload-arch=gfx950). maro_amd has no CPU fallback.")
+    # PyTorch wheels bundle their own libamdhip64; it must be the one this process binds (device memory and streams
+    # come from torch), so torch is imported before the extension pulls in a second copy from /opt/rocm.
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
     L.mrx_last_error.restype = ctypes.c_char_p
