@@ -99,6 +99,22 @@ typedef struct mrx_cim_topology {
   const double* vessel_speed_noise;
   const double* vessel_duration; /* [V] parking.duration */
   const double* vessel_duration_noise;
+
+  /* ---- data read from files instead of generated at reset (maro/data_lib/cim/cim_data_loader.py:360-450):
+   * 1 = dump folder (data_from_dumps: stops.csv|bin, global_order_proportion.txt, vessel periods; orders are still
+   *     drawn by the synthetic generator), 2 = real data files (data_from_files: stops + orders.csv|bin; no order
+   *     generator, ports carry no order distribution).  In both modes every reset re-seeds the RNG registry with the
+   *     data set's own seed (cim_data_container_helpers.py:79-85, 118-123), so seed commands are ignored. */
+  int32_t data_mode;       /* 0 = generated from config.yml (everything above) */
+  int32_t data_max_tick;   /* misc.yml max_tick: ticks covered by fixed_order_prop / fixed_orders */
+  int32_t fixed_max_stops; /* row length of fixed_stops_* */
+  const int32_t* fixed_n_stops;       /* [V] */
+  const int32_t* fixed_stops_arrival; /* [V][fixed_max_stops]; stop k of a vessel is at route position (start + k) mod len */
+  const int32_t* fixed_stops_leave;   /* [V][fixed_max_stops] */
+  const int32_t* fixed_vessel_period; /* [V] */
+  const int32_t* fixed_order_prop;    /* [data_max_tick] order_proportion (mode 1) */
+  const int32_t* fixed_orders;        /* [data_max_tick][n_targets] quantity per order pair (mode 2), target_offset CSR
+                                         order = the order the file lists a tick's orders in */
 } mrx_cim_topology;
 
 /* Env(...) constructor arguments, reference maro/simulator/core.py:42-56. */

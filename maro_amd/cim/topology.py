@@ -25,6 +25,9 @@ _F64 = ("order_dist", "empty_return_base", "empty_return_noise", "full_return_ba
         "vessel_speed_noise", "vessel_duration", "vessel_duration_noise")
 _I32 = ("port_capacity", "port_init_empty", "target_offset", "target_port", "route_offset", "route_port",
         "vessel_capacity", "vessel_init_empty", "vessel_route", "vessel_start_offset")
+_FIXED_I32 = ("fixed_n_stops", "fixed_stops_arrival", "fixed_stops_leave", "fixed_vessel_period", "fixed_order_prop",
+              "fixed_orders")
+_FIXED_SCALARS = ("data_mode", "data_max_tick", "fixed_max_stops")
 _SCALARS = ("n_ports", "n_vessels", "n_routes", "n_targets", "n_route_points", "past_stop_number",
             "future_stop_number", "container_volume", "total_containers", "order_mode", "seed", "period",
             "sample_noise")
@@ -51,6 +54,8 @@ class MrxCimTopology(ctypes.Structure):
                                                           "vessel_start_offset")]
         + [(n, ctypes.POINTER(ctypes.c_double)) for n in ("vessel_speed", "vessel_speed_noise",
                                                            "vessel_duration", "vessel_duration_noise")]
+        + [(n, ctypes.c_int32) for n in ("data_mode", "data_max_tick", "fixed_max_stops")]
+        + [(n, ctypes.POINTER(ctypes.c_int32)) for n in _FIXED_I32]
     )
 
 
@@ -102,6 +107,16 @@ class CimTopology:
     load_cost_factor: float = 0.0
     dsch_cost_factor: float = 0.0
     raw_config: dict = field(default_factory=dict, repr=False)
+    # data read from files (dump folder / real data files) instead of generated at reset — include/maro_amd.h
+    data_mode: int = 0
+    data_max_tick: int = 0
+    fixed_max_stops: int = 0
+    fixed_n_stops: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    fixed_stops_arrival: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    fixed_stops_leave: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    fixed_vessel_period: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    fixed_order_prop: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    fixed_orders: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
 
     # ---- reference-compatible views -------------------------------------------------
     @property
@@ -131,6 +146,12 @@ class CimTopology:
             a = np.ascontiguousarray(getattr(self, n), dtype=np.int32)
             keep.append(a)
             setattr(s, n, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        for n in _FIXED_SCALARS:
+            setattr(s, n, int(getattr(self, n)))
+        for n in _FIXED_I32:
+            a = np.ascontiguousarray(getattr(self, n), dtype=np.int32).reshape(-1)
+            keep.append(a)
+            setattr(s, n, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)) if a.size else None)
         s._keepalive = keep
         return s
 
@@ -146,6 +167,11 @@ class CimTopology:
         d["sample_noise"] = repr(float(self.sample_noise))
         d.update(port_names=self.port_names, vessel_names=self.vessel_names, route_names=self.route_names,
                  load_cost_factor=self.load_cost_factor, dsch_cost_factor=self.dsch_cost_factor)
+        if self.data_mode:
+            for n in _FIXED_SCALARS:
+                d[n] = int(getattr(self, n))
+            for n in _FIXED_I32:
+                d[n] = np.asarray(getattr(self, n), np.int32).reshape(-1).tolist()
         return json.dumps(d, separators=(",", ":"))
 
     @staticmethod
@@ -157,6 +183,9 @@ class CimTopology:
             kw[n] = np.array([float(x) for x in d[n]], dtype=np.float64)
         for n in _I32:
             kw[n] = np.array(d[n], dtype=np.int32)
+        for n in _FIXED_I32:
+            if n in d:
+                kw[n] = np.array(d[n], dtype=np.int32)
         return CimTopology(**kw)
 
 

@@ -334,7 +334,7 @@ template <bool PG>
 MRX_DEV void tick_prefetch(const CimParams& K, int env, Lds& L, int t, TickPf& pf) {
   const int lane = wave::lane();
   if constexpr (PG) {
-    const int32_t* row = K.orders + ((size_t)env * (K.T - K.start_tick) + (size_t)(t - K.start_tick)) * K.NTP;
+    const int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t - K.start_tick) * K.NTP;
 #pragma unroll
     for (int b = 0; b < 3; b++) pf.oqr[b] = row[b * 64 + lane < K.NTP ? b * 64 + lane : 0];
     pf.otg = 0;
@@ -477,7 +477,11 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
 
   // ---- base seed
   long long base;
-  if (cmd >= 0) {
+  if (K.data_mode) {
+    // dump folder / real data files: every (re)load re-seeds the registry with the data set's own seed
+    // (cim_data_container_helpers.py:79-85, 118-123), whatever set_seed / the redraw say
+    base = K.data_seed;
+  } else if (cmd >= 0) {
     base = cmd;
   } else if (cmd == -1) {
     base = K.seed[env];
@@ -504,6 +508,17 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
 
   // ---- order proportion (parsers.py:57-106)
   int32_t* g_prop = K.order_prop + (size_t)env * TT;
+  int status = 0;
+  uint32_t* g_stops = K.stops + (size_t)env * V * K.SMAX;
+  if (K.data_mode) {
+    // stop tables, vessel periods and the order proportion come from files (cim_data_loader.py:360-450)
+    for (int t = lane; t < TT; t += 64) g_prop[t] = (K.data_mode == 1 && t < K.data_T) ? K.fx_order_prop[t] : 0;
+    for (int i = lane; i < V * K.SMAX; i += 64) g_stops[i] = K.fx_stops[i];
+    if (lane < V) { K.nstops[(size_t)env * V + lane] = K.fx_nstops[lane]; K.vperiod[(size_t)env * V + lane] = K.fx_vperiod[lane]; }
+    // the frame initialisation below reads the stop table back through global memory
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    wave::sync();
+  } else {
   for (int t0 = 0; t0 < TT; t0 += 64) {
     const int t = t0 + lane;
     double orders = t < TT ? K.order_dist[t % K.period] : 0.0;
@@ -527,8 +542,6 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
 
   // ---- route unrolling (cim_data_generator.py:18-115): one sequential stream across vessels, two
   // draws per stop; executed wave-uniformly (every lane computes the same values, lane 0 stores)
-  int status = 0;
-  uint32_t* g_stops = K.stops + (size_t)env * V * K.SMAX;
   for (int v = 0; v < V; v++) {
     const int Lr = K.v_route_len[v], rb = K.v_route_base[v];
     const double speed = K.v_speed[v], sn = K.v_speed_noise[v], dur = K.v_dur[v], dn = K.v_dur_noise[v];
@@ -554,6 +567,7 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
     }
     if (lane == 0) { K.nstops[(size_t)env * V + v] = k < K.SMAX ? k : K.SMAX; K.vperiod[(size_t)env * V + v] = period; }
   }
+  }  // generated data
   wave::sync();
 
   // ---- persist RNG streams
@@ -631,7 +645,7 @@ MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {
     for (int j = 0; j < n_here; j++) {  // wave-uniform
       gen_orders(K, L, (long long)wave::shfl(mine, j), idx_ord, pf);
       wave::sync();
-      int32_t* row = K.orders + ((size_t)env * D + (size_t)(t0 + j)) * K.NTP;
+      int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t0 + j) * K.NTP;
       for (int k = lane; k < K.NTP; k += 64) row[k] = k < K.NT ? L.oq[k] : 0;
       wave::sync();
     }
@@ -653,7 +667,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
 #pragma unroll
     for (int b = 0; b < 3; b++) { const int k = b * 64 + lane; if (k < NT) L.oq[k] = pf.oqr[b]; }
     if (NT > 192) {
-      const int32_t* row = K.orders + ((size_t)env * (K.T - K.start_tick) + (size_t)(t - K.start_tick)) * K.NTP;
+      const int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t - K.start_tick) * K.NTP;
       for (int k = 192 + lane; k < NT; k += 64) L.oq[k] = row[k];
     }
   } else {

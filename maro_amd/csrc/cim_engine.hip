@@ -197,7 +197,7 @@ int mrx_cim_create(const mrx_cim_topology* topo, const mrx_cim_config* cfg, void
   // Env.__init__ generates data with the topology's own seed (cim_data_generator.py:141-145)
   hipLaunchKernelGGL(mrx_k_cim_reset, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_reset * 4, 0, K, nullptr, nullptr,
                      (long long)topo->seed);
-  if (K.pregen)
+  if (K.pregen && K.orders_stride)  // (real data files: the table is an input, uploaded with the constant tables)
     hipLaunchKernelGGL(mrx_k_cim_order_table, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_gen * 4, 0, K, nullptr, nullptr,
                        (long long)topo->seed);
   he = hipDeviceSynchronize();
@@ -225,7 +225,7 @@ int mrx_cim_reset(mrx_handle h, const int64_t* d_seed_cmd, const uint8_t* d_env_
   const CimParams& K = h->plan.kp;
   hipLaunchKernelGGL(mrx_k_cim_reset, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_reset * 4, (hipStream_t)stream, K,
                      (const long long*)d_seed_cmd, d_env_mask, (long long)-1);
-  if (K.pregen && d_seed_cmd)  // without seed commands every env keeps its seed, hence its order table
+  if (K.pregen && K.orders_stride && d_seed_cmd && !K.data_mode)  // envs that keep their seed keep their order table
     hipLaunchKernelGGL(mrx_k_cim_order_table, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_gen * 4, (hipStream_t)stream, K,
                        (const long long*)d_seed_cmd, d_env_mask, (long long)-1);
   HIP_TRY(hipGetLastError());

@@ -24,6 +24,7 @@ struct CimHostPlan {
   // relative offsets of const tables inside const_blob, in the order of CimParams' const pointers
   std::vector<std::pair<size_t, int64_t>> binds;  // (byte offset of a pointer field inside kp, offset in const_blob)
   int64_t ctab_rel = 0;
+  int64_t shared_orders_rel = -1;  // real data files: the order table inside const_blob, shared by every env
 };
 
 namespace cim_layout_detail {
@@ -119,6 +120,19 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   if (t->sample_noise != 0) for (int tk = 0; tk < k.T; tk++) oi |= t->order_dist[tk % t->period] != 0;
   k.has_order_init = oi;
   k.idx_order_init = oi ? 0 : -1; k.idx_route = oi ? 1 : 0; k.idx_order_num = k.idx_route + 1; k.idx_buffer = k.idx_route + 2;
+  // data read from files (dump folder / real data files): nothing is generated, so the streams are created lazily by
+  // the first episode in this order (fresh process): order_number at the first get_orders, buffer_time at the first
+  // buffer draw; the real-data container never touches order_number (cim_data_container.py:250-252, 304-307, 422-443)
+  k.data_mode = t->data_mode; k.data_T = t->data_max_tick; k.data_seed = t->seed;
+  if (t->data_mode) {
+    if (t->data_mode != 1 && t->data_mode != 2) return fail("data_mode must be 0, 1 or 2");
+    if (!t->fixed_n_stops || !t->fixed_stops_arrival || !t->fixed_stops_leave || !t->fixed_vessel_period || t->fixed_max_stops <= 0)
+      return fail("data_mode != 0 needs the fixed stop tables");
+    if (k.T > t->data_max_tick) return fail("start_tick + durations exceeds the data set's max_tick");
+    k.has_order_init = 0; k.idx_order_init = -1;
+    if (t->data_mode == 1) { if (!t->fixed_order_prop) return fail("dump data needs fixed_order_prop"); k.idx_order_num = 0; k.idx_buffer = 1; k.idx_route = 2; }
+    else { if (!t->fixed_orders) return fail("real data needs fixed_orders"); k.idx_buffer = 0; k.idx_order_num = 1; k.idx_route = 2; k.use_order_rng = 0; }
+  }
   // pending-return horizon
   int H = 1;
   for (int p = 0; p < P; p++) {
@@ -138,6 +152,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
     if (t->vessel_speed[v] - fabs(t->vessel_speed_noise[v]) <= 0) return fail("sailing speed minus noise must stay positive");
   }
   if (c->max_stops > 0) smax = c->max_stops;
+  if (t->data_mode) smax = t->fixed_max_stops;
   k.SMAX = (smax + 3) / 4 * 4;
   if (k.T >= (1 << 23)) return fail("engine limit: max_tick < 2^23");
   if (t->total_containers >= (1 << 24)) return fail("engine limit: total_containers < 2^24");
@@ -176,6 +191,10 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   // LDS plan (word offsets; doubles 8-byte aligned)
   // Order table (mrx_cim_config.order_table): only `fixed` order mode is state independent
   k.pregen = (t->order_mode == 0 && NT > 0 && c->order_table >= 0) ? 1 : 0;
+  if (t->data_mode == 2) {  // orders come from a file: the table is the input format (one copy shared by every env)
+    if (c->order_table < 0) return fail("real data files need the order table (order_table >= 0)");
+    k.pregen = NT > 0 ? 1 : 0;
+  }
   k.NTP = (NT + 3) / 4 * 4;
   const int dsrc_w = 2 * ((P + 1) / 2 * 2);
   const int dtgt_w = 2 * (NT + 1) > 3 * 64 ? 2 * (NT + 1) : 3 * 64;
@@ -264,6 +283,30 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
       for (int j = t->target_offset[p]; j < t->target_offset[p + 1]; j++) pair_dense[(size_t)p * P + t->target_port[j]] = j;
     put_i(&CimParams::pair_dense, pair_dense.data(), (size_t)P * P);
   }
+  int64_t shared_orders_rel = -1;
+  if (t->data_mode) {
+    std::vector<uint32_t> fx((size_t)V * k.SMAX, 0);
+    for (int v = 0; v < V; v++) {
+      if (t->fixed_n_stops[v] < 2 || t->fixed_n_stops[v] > t->fixed_max_stops) return fail("every vessel needs at least two stops in the data set");
+      for (int i = 0; i < t->fixed_n_stops[v]; i++) {
+        const int a = t->fixed_stops_arrival[(size_t)v * t->fixed_max_stops + i], l = t->fixed_stops_leave[(size_t)v * t->fixed_max_stops + i];
+        if (a < 0 || a >= (1 << 23) || l - a <= 0 || l - a > 255) return fail("engine limit: stop arrival < 2^23 and parking 1..255 ticks");
+        fx[(size_t)v * k.SMAX + i] = ((uint32_t)a << 8) | (uint32_t)(l - a);
+      }
+    }
+    auto put_u = [&](const uint32_t* CimParams::*f, const uint32_t* src, size_t n) {
+      binds.push_back({(size_t)((char*)&(k.*f) - (char*)&k), blob_put(B, src, n, 64)});
+    };
+    put_u(&CimParams::fx_stops, fx.data(), fx.size());
+    put_i(&CimParams::fx_nstops, t->fixed_n_stops, V); put_i(&CimParams::fx_vperiod, t->fixed_vessel_period, V);
+    if (t->data_mode == 1) put_i(&CimParams::fx_order_prop, t->fixed_order_prop, t->data_max_tick);
+    if (t->data_mode == 2 && k.pregen) {
+      std::vector<int32_t> tab((size_t)c->durations * k.NTP, 0);
+      for (int d = 0; d < c->durations; d++)
+        for (int j = 0; j < NT; j++) tab[(size_t)d * k.NTP + j] = t->fixed_orders[(size_t)(c->start_tick + d) * NT + j];
+      shared_orders_rel = blob_put(B, tab.data(), tab.size(), 256);
+    }
+  }
   pl->ctab_rel = ctab_begin;
   k.ctab_words = (int)((ctab_end - ctab_begin) / 4);
   k.l_ctab = (k.lds_words + 1) / 2 * 2;
@@ -300,7 +343,9 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   pl->o_stops = A.take(N * (int64_t)V * k.SMAX * 4);
   pl->o_seed = A.take(N * 8);
   pl->o_vperiod = A.take(N * V * 4);
-  pl->o_orders = k.pregen ? A.take(N * (int64_t)c->durations * k.NTP * 4) : 0;
+  pl->shared_orders_rel = shared_orders_rel;
+  k.orders_stride = shared_orders_rel >= 0 ? 0 : (long long)c->durations * k.NTP;
+  pl->o_orders = (k.pregen && shared_orders_rel < 0) ? A.take(N * (int64_t)c->durations * k.NTP * 4) : 0;
   pl->workspace_bytes = align_up(A.top, 256);
 
   mrx_cim_layout& Lo = pl->layout;
@@ -312,7 +357,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   Lo.off_live = pl->o_live; Lo.off_ring = pl->o_ring; Lo.off_ring_fi = pl->o_ring_fi; Lo.off_status = pl->o_status;
   Lo.off_tick = pl->o_tick; Lo.off_seed = pl->o_seed; Lo.off_stops = pl->o_stops; Lo.off_nstops = pl->o_nstops;
   Lo.off_order_prop = pl->o_order_prop; Lo.off_vessel_period = pl->o_vperiod;  // per env: depends on how many stops were unrolled
-  Lo.off_orders = pl->o_orders; Lo.order_row_words = k.NTP; Lo.order_table_on = k.pregen;
+  Lo.off_orders = shared_orders_rel >= 0 ? pl->const_off + shared_orders_rel : pl->o_orders; Lo.order_row_words = k.NTP; Lo.order_table_on = k.pregen;
   Lo.workspace_bytes = pl->workspace_bytes;
   return MRX_OK;
 }
@@ -330,5 +375,5 @@ inline void cim_plan_bind(CimHostPlan* pl, void* base_) {
   k.order_prop = (int32_t*)(base + pl->o_order_prop); k.mt = (uint32_t*)(base + pl->o_mt);
   k.stops = (uint32_t*)(base + pl->o_stops); k.seed = (int64_t*)(base + pl->o_seed);
   k.vperiod = (int32_t*)(base + pl->o_vperiod);
-  k.orders = k.pregen ? (int32_t*)(base + pl->o_orders) : nullptr;
+  k.orders = !k.pregen ? nullptr : pl->shared_orders_rel >= 0 ? (int32_t*)(cb + pl->shared_orders_rel) : (int32_t*)(base + pl->o_orders);
 }

@@ -41,6 +41,12 @@ struct CimParams {
   int l_ctab, ctab_words;  // serial-access int tables staged in LDS by the step kernel
   int l_mt2, l_mt3, lds_words_reset;  // reset kernel only (placed after the step kernel's LDS)
   int decision_mode;  // 0 Sequential, 1 Joint, 2 JointWithSequentialAction (core.py:349-366)
+  int data_mode;      // 0 generated at reset, 1 dump folder, 2 real data files (mrx_cim_topology.data_mode)
+  int data_T;         // ticks covered by the fixed order proportion
+  long long data_seed;
+  long long orders_stride;  // words between two envs' order tables (0: one table shared by every env)
+  const uint32_t* fx_stops;  // [V][SMAX] (arrival << 8 | parking)
+  const int32_t *fx_nstops, *fx_vperiod, *fx_order_prop;
   int pregen, NTP;  // order table: rows of NTP (= NT rounded up to 4) words, one per tick of the episode
   int g_mt0, g_dsrc, g_dtgt, g_oq, g_srcn, g_ctab, lds_words_gen;  // LDS layout of the order-table kernel
   // ---- constant tables (device)

@@ -160,6 +160,12 @@ static void topo_copy(cim_oracle* o, const mrx_cim_topology* s) {
   DUP(route_offset, R + 1, int32_t); DUP(route_port, NR, int32_t); DUP(route_dist, NR, double);
   DUP(vessel_capacity, V, int32_t); DUP(vessel_init_empty, V, int32_t); DUP(vessel_route, V, int32_t); DUP(vessel_start_offset, V, int32_t);
   DUP(vessel_speed, V, double); DUP(vessel_speed_noise, V, double); DUP(vessel_duration, V, double); DUP(vessel_duration_noise, V, double);
+  if (s->data_mode) { /* dump folder / real data files: cim_data_loader.py:360-450 */
+    DUP(fixed_n_stops, V, int32_t); DUP(fixed_vessel_period, V, int32_t);
+    DUP(fixed_stops_arrival, (size_t)V * s->fixed_max_stops, int32_t); DUP(fixed_stops_leave, (size_t)V * s->fixed_max_stops, int32_t);
+    if (s->data_mode == 1) DUP(fixed_order_prop, s->data_max_tick, int32_t);
+    if (s->data_mode == 2) DUP(fixed_orders, (size_t)s->data_max_tick * NT, int32_t);
+  }
 #undef DUP
 }
 static int route_len(const cim_oracle* o, int v) { int r = o->t.vessel_route[v]; return o->t.route_offset[r + 1] - o->t.route_offset[r]; }
@@ -219,6 +225,27 @@ static void extend_route(cim_oracle* o) {
 
 /* cim_data_generator.py:118-205 gen_cim_data (+ data_from_generator) */
 static void gen_cim_data(cim_oracle* o, int64_t topology_seed) {
+  if (o->t.data_mode) {
+    /* data_from_dumps / data_from_files (cim_data_container_helpers.py:79-85, 118-123): the data set is (re)loaded from
+     * its folder whatever the wrapper's seed says, then seed(data_collection.seed) re-seeds the registry */
+    const mrx_cim_topology* t = &o->t;
+    simrand_seed(&o->rnd, t->seed);
+    o->data_seed = t->seed;
+    for (int tk = 0; tk < o->max_tick; tk++) o->order_proportion[tk] = (t->data_mode == 1 && tk < t->data_max_tick) ? t->fixed_order_prop[tk] : 0;
+    for (int v = 0; v < o->V; v++) {
+      const int n = t->fixed_n_stops[v], L = route_len(o, v);
+      if (o->stops_cap[v] < n) { o->stops_cap[v] = n; o->stops[v] = (stop_t*)realloc(o->stops[v], sizeof(stop_t) * (size_t)n); }
+      for (int k = 0; k < n; k++) {
+        stop_t st = {k, t->fixed_stops_arrival[(size_t)v * t->fixed_max_stops + k], t->fixed_stops_leave[(size_t)v * t->fixed_max_stops + k],
+                     route_port_at(o, v, (t->vessel_start_offset[v] + k) % L), v};
+        o->stops[v][k] = st;
+      }
+      o->n_stops[v] = n;
+      o->vessel_period[v] = t->fixed_vessel_period[v];
+    }
+    o->is_need_reset_seed = 0;
+    return;
+  }
   simrand_seed(&o->rnd, topology_seed); /* :145 */
   o->data_seed = topology_seed;
   gen_order_proportion(o);              /* :157-162 */
@@ -362,12 +389,21 @@ static void reset_nodes(cim_oracle* o) {
 /* cim_data_container.py:309-398 _gen_orders; emits ORDER events (business_engine.py:138-143) */
 static void gen_orders(cim_oracle* o, int tick, int64_t total_empty) {
   const mrx_cim_topology* t = &o->t;
-  if (o->is_need_reset_seed) { /* cim_data_container.py:292-296, 304-307 */
+  if (o->is_need_reset_seed) { /* cim_data_container.py:292-296, 304-307; the real-data container only has the base :250-252 */
     simrand_reset_seed(&o->rnd, K_BUFFER_TICK);
-    simrand_reset_seed(&o->rnd, K_ORDER_NUM);
+    if (t->data_mode != 2) simrand_reset_seed(&o->rnd, K_ORDER_NUM);
     o->is_need_reset_seed = 0;
   }
-  if (tick >= o->max_tick) return;
+  if (t->data_mode == 2) { /* CimRealDataContainer.get_orders :422-443: the tick's orders as listed in the file */
+    if (tick >= t->data_max_tick) return;
+    for (int p = 0; p < o->P; p++)
+      for (int j = t->target_offset[p]; j < t->target_offset[p + 1]; j++) {
+        const int q = t->fixed_orders[(size_t)tick * t->n_targets + j];
+        if (q > 0) eb_insert(o, ev_new(tick, EV_ORDER, p, t->target_port[j], q, 0));
+      }
+    return;
+  }
+  if (tick >= (t->data_mode ? t->data_max_tick : o->max_tick)) return;
   int64_t orders_to_gen = (int64_t)o->order_proportion[tick];
   if (t->order_mode == 1) { /* UNFIXED :327-333 */
     int64_t delta = (int64_t)t->total_containers - total_empty;

@@ -67,6 +67,16 @@ CASES = {
 # written to a temp folder as config.yml and run through the real reference
 for _syn in ("immediate_returns", "unfixed_mode", "repeated_ports_noisy", "volume3_stops_2_5"):  # (negative_ratios trips the reference's own assert, cim_data_container.py:396)
     CASES[f"syn_{_syn}"] = (f"#{_syn}", dict(durations=90), [("run", "rand0", None)])
+# data read from files: a dump of the fixture topology made with the reference's dump_from_config (200 ticks), and the
+# reference's real-data fixture (tests/cim/test_cim_scenario.py:111-150); "=<name>:<folder>", compiled to
+# tests/golden/topology_<name>.json by tools/import_maro_cim_data.py
+CASES["dump_case_config_kat"] = ("=dump_case_config:/tmp/oracle/dump_case_config_200", dict(durations=200),
+                                 [("run", "early_discharge_script", None), ("reset", False), ("run", "rand0", 60),
+                                  ("reset", True), ("run", "none", None)])
+CASES["real_csv_rand0"] = ("=real_folder_csv:@tests/data/cim/case_data/real_folder_csv", dict(durations=224),
+                           [("run", "rand0", None), ("reset", True), ("run", "none", 40), ("set_seed", 5), ("reset", False),
+                            ("run", "rand0", None)])
+CASES["real_bin_none"] = ("=real_folder_bin:@tests/data/cim/case_data/real_folder_bin", dict(durations=100), [("run", "none", None)])
 CASES["toy5p_l05_sampler"] = ("toy.5p_ssddd_l0.5", dict(durations=160), [("run", "rand0", None)])  # + CIMEnvSampler state/reward
 LIGHT = {"toy4p_l00_full", "gt22p_l00_full"}  # only decisions/metrics kept (size)
 
@@ -83,6 +93,8 @@ def worker(maro_root, case_name, out_path):
     from maro.simulator.utils import random as sim_random
 
     topology, kwargs, script = CASES[case_name]
+    if topology.startswith("="):
+        topology = topology.split(":", 1)[1]
     if topology.startswith("@"):
         topology = os.path.join(maro_root, topology[1:])
     if topology.startswith("#"):
@@ -111,7 +123,7 @@ def worker(maro_root, case_name, out_path):
             for k, s in enumerate(ss):
                 arr[v, k], lea[v, k], prt[v, k] = s.arrival_tick, s.leave_tick, s.port_idx
         out[f"{tag}/stops_arrival"], out[f"{tag}/stops_leave"], out[f"{tag}/stops_port"] = arr, lea, prt
-        out[f"{tag}/order_proportion"] = np.asarray(dc._data_collection.order_proportion, np.int32)
+        out[f"{tag}/order_proportion"] = np.asarray(getattr(dc._data_collection, "order_proportion", np.zeros(0)), np.int32)
         out[f"{tag}/vessel_period"] = np.asarray(dc.vessel_period, np.int32)
         out[f"{tag}/stream_seeds"] = np.array([sim_random._seed_dict.get(k, -1) for k in
                                                ("order_init", "route_init", "order_number", "buffer_time")], np.int64)

@@ -55,7 +55,7 @@ void emu_reset(void* h, const int64_t* seed_cmd, const uint8_t* mask, int revers
     memset(e->lds, 0xAB, (size_t)K.lds_words_reset * 4);
     long long cmd = seed_cmd ? (long long)seed_cmd[env] : -1;
     wave::run_wave(e->wave, [&]() { cim::reset_env(K, env, e->lds, cmd); });
-    if (K.pregen && cmd != -1) {
+    if (K.pregen && K.orders_stride && cmd != -1) {
       memset(e->lds, 0xAB, (size_t)K.lds_words_reset * 4);
       wave::run_wave(e->wave, [&]() { cim::gen_order_table(K, env, e->lds); });
     }

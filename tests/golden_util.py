@@ -33,6 +33,9 @@ def case_topology(meta) -> CimTopology:
         from tests.test_emu_synthetic import VARIANTS
         import copy
         return parse_config(copy.deepcopy(VARIANTS[topo[1:]]), name="syn_" + topo[1:])
+    if topo.startswith("="):   # "=<name>:<folder>": a dump / real data folder compiled by tools/import_maro_cim_data.py
+        with open(os.path.join(GOLDEN_DIR, f"topology_{topo[1:].split(':')[0]}.json")) as fp:
+            return CimTopology.from_json(fp.read())
     if topo.startswith("@"):
         with open(os.path.join(GOLDEN_DIR, "topology_case_config_folder.json")) as fp:
             return CimTopology.from_json(fp.read())

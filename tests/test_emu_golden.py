@@ -32,9 +32,17 @@ def test_emulated_kernels_lane_order_independent(name):
     replay_case(_make(True), name)
 
 
-@pytest.mark.parametrize("name", ["toy4p_l00_rand0", "gt22p_l08_rand0", "toy6p_l08_rand0", "gt22p_l08_reset_chain"])
+@pytest.mark.parametrize("name", ["toy4p_l00_rand0", "gt22p_l08_rand0", "toy6p_l08_rand0", "gt22p_l08_reset_chain",
+                                  "dump_case_config_kat"])
 def test_online_order_generation_path(name):
     """order_table = -1: the step kernel draws each tick's orders itself (the only path for `unfixed` order mode)."""
     if name not in FAST:
         pytest.skip("golden not present")
     replay_case(_make(False, order_table=-1), name)
+
+
+def test_real_data_needs_the_order_table():
+    from tests.golden_util import case_topology, load_case
+    _, meta = load_case("real_csv_rand0")
+    with pytest.raises(RuntimeError, match="order table"):
+        EmuBackend(case_topology(meta), n_envs=1, durations=50, order_table=-1)
