@@ -208,7 +208,10 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=None, help="environments per GPU (weak scaling); default 16384 (cim) / 4096 (citi_bike)")
-    ap.add_argument("--groups", type=int, default=2, help="independent env groups per GPU, each on its own HIP stream (cim)")
+    ap.add_argument("--obs", default="fused", choices=["fused", "query"],
+                    help="how the per-step ports / deciding-vessel snapshot slices are produced: fused into the step kernel, or by mrx_cim_query")
+    ap.add_argument("--graphs", type=int, default=0, help="1: capture one step per group in a hipGraph and replay it (cim)")
+    ap.add_argument("--groups", type=int, default=3, help="independent env groups per GPU, each on its own HIP stream (cim)")
     ap.add_argument("--topology", default="global_trade.22p_l0.8")
     ap.add_argument("--durations", type=int, default=1120)
     ap.add_argument("--ring", type=int, default=4, help="snapshot ring slots per env (max_snapshots)")
@@ -245,19 +248,23 @@ def main():
     # ends with a tail of long (ticking) waves while most of the chip is already idle, and the next group's kernel
     # fills exactly that tail.  Envs never interact, so this is pure scheduling.
     n, G = args.envs, max(1, args.groups)
-    assert n % G == 0, "--envs must be divisible by --groups"
-    ng = n // G
+    sizes = [n // G + (1 if g < n % G else 0) for g in range(G)]   # group sizes differ by at most one env
+    offs = [sum(sizes[:g]) for g in range(G)]
     engines, streams, bufs = [], [], []
     for g in range(G):
-        seeds = torch.arange(ng, dtype=torch.int64) + rank * n + g * ng + 1
+        ng = sizes[g]
+        seeds = torch.arange(ng, dtype=torch.int64) + rank * n + offs[g] + 1
         eng = CimBatchEngine(args.topology, ng, durations=args.durations, max_snapshots=args.ring, max_actions=1, device=dev, seeds=seeds)
         engines.append(eng)
         streams.append(torch.cuda.Stream(device=dev) if G > 1 else torch.cuda.current_stream(dev))
         bufs.append(dict(actions=torch.zeros((ng, 1, 4), dtype=torch.int32, device=dev),
                          n_actions=torch.zeros((ng,), dtype=torch.int32, device=dev),
                          counter=torch.zeros((1,), dtype=torch.int64, device=dev),
-                         q_ports=None if args.no_query else torch.empty((ng, 1, engines[0].topo.n_ports, len(QUERY_ATTRS)), dtype=torch.float64, device=dev),
-                         q_vessel=None if args.no_query else torch.empty((ng, 1, 1, len(VESSEL_QUERY_ATTRS)), dtype=torch.float64, device=dev)))
+                         q_ports=None if (args.no_query or args.obs == "fused") else torch.empty((ng, 1, engines[0].topo.n_ports, len(QUERY_ATTRS)), dtype=torch.float64, device=dev),
+                         q_vessel=None if (args.no_query or args.obs == "fused") else torch.empty((ng, 1, 1, len(VESSEL_QUERY_ATTRS)), dtype=torch.float64, device=dev)))
+        if args.obs == "fused" and not args.no_query:
+            # the same two slices, written by the step kernel itself (mrx_cim_set_observation) instead of two more launches
+            bufs[-1]["obs"] = eng.set_observation(QUERY_ATTRS, VESSEL_QUERY_ATTRS)
     topo = engines[0].topo
     ports = torch.arange(topo.n_ports, dtype=torch.int32, device=dev)
     torch.cuda.synchronize(dev)
@@ -266,9 +273,11 @@ def main():
     t_r = time.perf_counter()
     for g, eng in enumerate(engines):
         with torch.cuda.stream(streams[g]):
-            eng.reset(torch.arange(ng, dtype=torch.int64) + rank * n + g * ng + 1)
+            eng.reset(torch.arange(sizes[g], dtype=torch.int64) + rank * n + offs[g] + 1)
     torch.cuda.synchronize(dev)
     reset_ms = (time.perf_counter() - t_r) * 1e3
+
+    graphs = [None] * G
 
     def one_step(i, g, timing=None):
         eng, b = engines[g], bufs[g]
@@ -276,7 +285,10 @@ def main():
             if i == 0:
                 eng.step()  # first step of the episode: action=None
                 return
-            eng.random_policy(i, b["actions"], b["n_actions"], b["counter"] if timing is None else None)
+            if graphs[g] is not None and timing is None:
+                graphs[g].replay()  # policy -> step -> snapshot slices, captured once (hipGraph)
+                return
+            eng.random_policy(-1 if args.graphs else i, b["actions"], b["n_actions"], b["counter"] if timing is None else None)
             if timing is not None:
                 timing[0].record()
             eng.step(b["actions"], b["n_actions"])
@@ -302,6 +314,24 @@ def main():
             one_step(step_i, g)
         step_i += 1
     sync_all()
+    if args.graphs:
+        # the launch-bound inner loop (4 small launches per group and step) is captured once per group and replayed
+        for g in range(G):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=streams[g]):
+                eng, b = engines[g], bufs[g]
+                eng.random_policy(-1, b["actions"], b["n_actions"], b["counter"])
+                eng.step(b["actions"], b["n_actions"])
+                if b["q_ports"] is not None:
+                    eng.query("ports", eng.decisions[:, 6:7], ports, QUERY_ATTRS, out=b["q_ports"])
+                    eng.query("vessels", eng.decisions[:, 6:7], eng.decisions[:, 2:3], VESSEL_QUERY_ATTRS, out=b["q_vessel"])
+            graphs[g] = gr
+        sync_all()
+        for _ in range(10):
+            for g in range(G):
+                one_step(step_i, g)
+            step_i += 1
+        sync_all()
     for b in bufs:
         b["counter"].zero_()
     tick0 = total_ticks()
@@ -347,6 +377,7 @@ def main():
         tbar = ticks_adv / max(resolved, 1.0)  # mean ticks advanced per env-step
         F = frame_bytes(topo)
         b_step = (3.0 + tbar) * F + 4.0 * topo.n_targets * tbar + 40.0
+        ng = n / G                                  # mean env-steps per launch
         bytes_per_launch = b_step * ng
         # one launch moves bytes_per_launch in step_kernel_ms, and `in_flight` launches (one per group/stream) overlap
         achieved = bytes_per_launch / (step_kernel_ms * 1e-3) / 1e9 * in_flight
@@ -354,7 +385,7 @@ def main():
         try:
             with open(os.path.join(REPO, "profiles", "latest_pmc.json")) as fp:
                 pmc = json.load(fp)
-            if pmc["topology"] == args.topology and pmc["envs_per_launch"] == ng:
+            if pmc["topology"] == args.topology and abs(pmc["envs_per_launch"] - ng) <= 1:
                 traffic = (2.0 * pmc["fetch_size_kib"] + pmc["write_size_kib"]) * 1024.0
         except Exception:
             pass
@@ -364,8 +395,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {args.durations}, "
-                                   f"random legal agent on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step'}",
-                       "envs_per_gpu": n, "groups_per_gpu": G, "envs_per_launch": ng, "ring_slots": args.ring,
+                                   f"random legal agent on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step (' + args.obs + ')'}",
+                       "envs_per_gpu": n, "groups_per_gpu": G, "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,
                        "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
                        "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms,
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},

@@ -209,6 +209,22 @@ int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_acti
                  uint8_t* d_done, void* stream);
 
 /*
+ * Fuses an agent's per-decision snapshot slices into mrx_cim_step (Sequential mode): after this call every step also writes,
+ * for each stepped env that pauses at a new decision,
+ *   d_obs_ports  float64 [n_envs][n_ports][n_port_attrs] = snapshot_list["ports"][decision frame :: port_attrs]
+ *   d_obs_vessel float64 [n_envs][n_vessel_attrs]        = snapshot_list["vessels"][decision frame : decision vessel : vessel_attrs]
+ * i.e. what examples/cim/rl/env_sampler.py:21-31 and examples/hello_world read through frame.pyx:754-801 right after
+ * Env.step returns — values identical to mrx_cim_query on decisions[:, 6] (the decision's frame is the live frame).
+ * Attribute ids as mrx_cim_attr_id; single-slot attributes only, at most 8 each; HOST arrays (copied).  Rows of envs
+ * that did not get a new decision (episode over, masked out) are left untouched.  n = 0 switches a part off.
+ * The two buffers are engine state between steps: a step that stays inside the current tick (another vessel's decision)
+ * only patches the cells its action changed — so call this before the reset / first step of an episode, and do not
+ * write to the buffers.
+ */
+int mrx_cim_set_observation(mrx_handle h, const int32_t* port_attrs, int n_port_attrs, const int32_t* vessel_attrs,
+                            int n_vessel_attrs, double* d_obs_ports, double* d_obs_vessel);
+
+/*
  * Env.step in DecisionMode.Joint / JointWithSequentialAction (core.py:354-366; engines created with
  * mrx_cim_config.decision_mode 1 / 2): every pending decision event of the tick is reported at once.
  *   d_decisions  int32 [n_envs][n_vessels][8]: one row per pending event in event (= vessel index) order, same columns as
@@ -244,7 +260,8 @@ int mrx_cim_query(mrx_handle h, int node_type, const int32_t* d_ticks, int nt, i
  * Utility: the reference's hello-world random agent (examples/hello_world/cim/hello.py:22-37) as a
  * counter-based device policy, so rollouts need no host round trip: for every env with a valid
  * decision writes one legal action into d_actions[e][0] (and d_n_actions[e] = 1, else 0) from
- * hash(seed[e], step); adds the number of valid decisions to *d_counter (may be NULL).
+ * hash(seed[e], step) — or, with step < 0, from hash(seed[e], tick, vessel) of the decision itself, so the call can
+ * sit in a captured hipGraph; adds the number of valid decisions to *d_counter (may be NULL).
  */
 int mrx_cim_random_policy(mrx_handle h, const int32_t* d_decisions, int64_t step, int32_t* d_actions,
                           int32_t* d_n_actions, uint64_t* d_counter, void* stream);

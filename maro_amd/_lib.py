@@ -35,7 +35,7 @@ class MrxCimLayout(ctypes.Structure):
 
 EXPORTS = ("mrx_last_error", "mrx_version", "mrx_cim_workspace_bytes", "mrx_cim_create", "mrx_cim_destroy",
            "mrx_cim_get_layout", "mrx_cim_reset", "mrx_cim_step", "mrx_cim_step_joint", "mrx_cim_query", "mrx_cim_attr_id",
-           "mrx_cim_attr_slots", "mrx_cim_random_policy",
+           "mrx_cim_attr_slots", "mrx_cim_random_policy", "mrx_cim_set_observation",
            # include/maro_amd_citi_bike.h
            "mrx_cb_workspace_bytes", "mrx_cb_create", "mrx_cb_destroy", "mrx_cb_get_layout", "mrx_cb_reset", "mrx_cb_step",
            "mrx_cb_query", "mrx_cb_random_policy", "mrx_cb_attr_id", "mrx_cb_attr_slots")
@@ -81,6 +81,8 @@ def load() -> ctypes.CDLL:
     L.mrx_cim_query.argtypes = [vp, i32, vp, i32, i32, vp, i32, i32, vp, i32, vp, vp]
     L.mrx_cim_random_policy.restype = i32
     L.mrx_cim_random_policy.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    L.mrx_cim_set_observation.restype = i32
+    L.mrx_cim_set_observation.argtypes = [vp, vp, i32, vp, i32, vp, vp]
     L.mrx_cim_attr_id.restype = i32
     L.mrx_cim_attr_id.argtypes = [i32, ctypes.c_char_p]
     L.mrx_cim_attr_slots.restype = i32

@@ -144,6 +144,19 @@ class CimBatchEngine:
                                                  n_actions.data_ptr(), self._p(counter), self._stream()),
                    "mrx_cim_random_policy")
 
+    def set_observation(self, port_attrs: Sequence[str] = (), vessel_attrs: Sequence[str] = ()):
+        """Fuse an agent's per-decision snapshot slices into step(): returns (obs_ports float64 [n, P, len(port_attrs)],
+        obs_vessel float64 [n, len(vessel_attrs)]), rewritten by every step() for the envs that pause at a new decision —
+        the values `query("ports", decisions[:, 6:7], all ports, port_attrs)` and
+        `query("vessels", decisions[:, 6:7], decisions[:, 2:3], vessel_attrs)` would return, without the extra launches."""
+        pa, va = self.attr_ids("ports", port_attrs), self.attr_ids("vessels", vessel_attrs)
+        self.obs_ports = torch.zeros((self.n_envs, self.layout.n_ports, len(pa)), dtype=torch.float64, device=self.device)
+        self.obs_vessel = torch.zeros((self.n_envs, len(va)), dtype=torch.float64, device=self.device)
+        pa_c, va_c = (ctypes.c_int32 * max(len(pa), 1))(*pa), (ctypes.c_int32 * max(len(va), 1))(*va)
+        _lib.check(self._L.mrx_cim_set_observation(self._h, pa_c, len(pa), va_c, len(va), self.obs_ports.data_ptr(),
+                                                   self.obs_vessel.data_ptr()), "mrx_cim_set_observation")
+        return self.obs_ports, self.obs_vessel
+
     def attr_ids(self, node: str, attrs: Sequence[str]):
         ids = []
         for a in attrs:

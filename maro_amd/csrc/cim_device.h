@@ -976,9 +976,11 @@ struct FastRows {
   int pe, tc;               // ports:   empty, transfer_cost            (lane = port)
   int ve, rs, ed, lp, per;  // vessels: empty, remaining_space, early_discharge, loc_port_idx, vessel period (lane = vessel)
   int pl[4];                // vessel_plans cells lane + 64 k (only when the compact plan block has <= 256 cells)
+  int vo[8];                // fused observation (CimObs): rows of the requested vessel attributes
 };
 
-MRX_DEV void fast_rows_request(const CimParams& K, int env, FastRows& R) {
+template <bool OBS>
+MRX_DEV void fast_rows_request(const CimParams& K, const CimObs& O, int env, FastRows& R) {
   const int lane = wave::lane();
   const int32_t* g_live = K.live + (size_t)env * K.FW;
   const int32_t* g_priv = K.priv + (size_t)env * K.PW;
@@ -992,10 +994,17 @@ MRX_DEV void fast_rows_request(const CimParams& K, int env, FastRows& R) {
   R.lp = g_live[K.f_vessels + VA_LOC_PORT_IDX * K.V + v];
   R.per = g_priv[K.pv_period + v];
   for (int k = 0; k < 4; k++) R.pl[k] = (K.NC <= 256 && lane + 64 * k < K.NC) ? g_live[K.f_plans + lane + 64 * k] : 0;
+  if constexpr (OBS) {
+#pragma unroll
+    for (int a = 0; a < 8; a++) R.vo[a] = a < O.nv ? g_live[K.f_vessels + O.va[a] * K.V + v] : 0;
+  }
 }
 
+MRX_DEV double port_attr_value(int attr, int raw) { return attr == PA_TRANSFER_COST ? (double)bits_f(raw) : (double)raw; }
+
 // Returns false if the step needs the full path.
-MRX_DEV bool fast_step(const CimParams& K, int env, const FastRows& R, int n_act, int a0v, int a0p, int a0q, int a0t,
+template <bool OBS>
+MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastRows& R, int n_act, int a0v, int a0p, int a0q, int a0t,
                        int32_t* dec_out, long long* met_out, uint8_t* done_out) {
   const int lane = wave::lane();
   const int P = K.P, V = K.V;
@@ -1037,6 +1046,8 @@ MRX_DEV bool fast_step(const CimParams& K, int env, const FastRows& R, int n_act
     if (K.NC > 256) pl = g_live[K.f_plans + cc];  // large plan blocks: a second, dependent trip
   }
   // ---- the action (business_engine.py:708-748)
+  bool applied = false;
+  int o_pe = 0, o_tc = 0, o_ve = 0, o_rs = 0;  // new values of the acting port / vessel (fused observation)
   if (act) {
     int npe = pe, nve = ve;
     bool ok = true;
@@ -1045,6 +1056,7 @@ MRX_DEV bool fast_step(const CimParams& K, int env, const FastRows& R, int n_act
     if (!ok) status |= 1;
     else {
       const int nrs = rs - (nve - ve);
+      applied = true; o_pe = npe; o_tc = f_bits((float)((double)bits_f(tc) + (double)q)); o_ve = nve; o_rs = nrs;
       if (lane == 0) {
         GP(PA_EMPTY, ap) = npe;
         GP(PA_TRANSFER_COST, ap) = f_bits((float)((double)bits_f(tc) + (double)q));
@@ -1060,6 +1072,22 @@ MRX_DEV bool fast_step(const CimParams& K, int env, const FastRows& R, int n_act
   }
 #undef GP
 #undef GV
+  // ---- fused observation of the next decision (vessel v2).  The ports block was written by the previous step of
+  // this env, which paused at the same tick; since then only this action changed anything, so it is patched in place.
+  if constexpr (OBS) {
+    if (applied && lane == 0) {
+      if (O.i_empty >= 0) O.ports[((size_t)env * P + ap) * O.np + O.i_empty] = (double)o_pe;
+      if (O.i_tc >= 0) O.ports[((size_t)env * P + ap) * O.np + O.i_tc] = (double)bits_f(o_tc);
+    }
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+      if (a < O.nv) {
+        int raw = wave::shfl(R.vo[a], v2);
+        if (applied && av == v2) { if (O.va[a] == VA_EMPTY) raw = o_ve; else if (O.va[a] == VA_REMAINING_SPACE) raw = o_rs; }
+        if (lane == 0) O.vessel[(size_t)env * O.nv + a] = (double)raw;
+      }
+    }
+  }
   // ---- next decision of the same tick (action_scope :247-260; metrics unchanged since the last tick)
   if (lane == 0) {
     dec_out[0] = t; dec_out[1] = lp2; dec_out[2] = v2;
@@ -1090,8 +1118,8 @@ MRX_DEV uint64_t consume_decisions(const CimParams& K, uint64_t pend, int cur, i
   return pend;
 }
 
-template <bool PG>
-MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* actions, int n_act, int n_answered,
+template <bool PG, bool OBS>
+MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds, const int32_t* actions, int n_act, int n_answered,
                       int32_t* dec_out, long long* met_out, uint8_t* done_out) {
   Lds L = make_lds(K, lds);
   Prof prof;
@@ -1105,10 +1133,10 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
   if (n_act > K.max_actions) n_act = K.max_actions;
   if (K.decision_mode == 0) {  // Sequential
     FastRows rows;
-    fast_rows_request(K, env, rows);
+    fast_rows_request<OBS>(K, O, env, rows);
     int f0v = 0, f0p = 0, f0q = 0, f0t = 0;
     if (actions) { f0v = actions[0]; f0p = actions[1]; f0q = actions[2]; f0t = actions[3]; }
-    if (fast_step(K, env, rows, n_act, f0v, f0p, f0q, f0t, dec_out, met_out, done_out)) {
+    if (fast_step<OBS>(K, O, env, rows, n_act, f0v, f0p, f0q, f0t, dec_out, met_out, done_out)) {
       prof.mark(13); prof.mark(14, 1);  // tools build: fast-path cycles and count
       prof.flush();
       return;
@@ -1262,6 +1290,20 @@ MRX_DEV void step_env(const CimParams& K, int env, int32_t* lds, const int32_t* 
       dec_out[4] = FV(VA_EMPTY, v);
       dec_out[5] = FV(VA_EARLY_DISCHARGE, v);
       dec_out[6] = fi; dec_out[7] = 1;
+    }
+    // fused observation: the decision's frame is the live frame (aliased pre-decision snapshot); consecutive lanes
+    // write consecutive doubles of the [P][np] block
+    if constexpr (OBS) {
+      const int tot = P * O.np;
+      double* op = O.ports + (size_t)env * tot;
+      for (int i = lane; i < tot; i += 64) {
+        const int p = i / O.np, a = i - p * O.np;
+        const int attr = (int)((O.pa_packed >> (4 * a)) & 15u);
+        op[i] = port_attr_value(attr, FP(attr, p));
+      }
+#pragma unroll
+      for (int a = 0; a < 8; a++)
+        if (a < O.nv && lane == 0) O.vessel[(size_t)env * O.nv + a] = (double)FV(O.va[a], dec_v);
     }
   } else if (lane == 0) {
     dec_out[0] = t; dec_out[1] = 0; dec_out[2] = 0; dec_out[3] = 0; dec_out[4] = 0; dec_out[5] = 0;

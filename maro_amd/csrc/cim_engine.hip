@@ -53,9 +53,9 @@ mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const
 // Two builds of the step kernel: mrx_k_cim_step generates the tick's orders itself (any order mode);
 // mrx_k_cim_step_tab reads them from the order table drawn at reset (CimParams::pregen) and carries neither the
 // generator's code nor its LDS (order RNG state, fp64 scratch).
-#define MRX_STEP_KERNEL(NAME, PG)                                                                                  \
-  extern "C" __global__ void __launch_bounds__(64)                                                                  \
-  NAME(CimParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions,                     \
+#define MRX_STEP_KERNEL(NAME, PG, OBS, WAVES)                                                                                  \
+  extern "C" __global__ void __launch_bounds__(64, WAVES)                                                           \
+  NAME(CimParams K, CimObs O, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions,           \
        const int32_t* __restrict__ n_answered, const uint8_t* __restrict__ mask, int32_t* __restrict__ decisions,   \
        long long* __restrict__ metrics, uint8_t* __restrict__ done) {                                               \
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];                                                   \
@@ -64,11 +64,13 @@ mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const
     const int32_t* a = actions ? actions + (size_t)env * K.max_actions * 4 : nullptr;                               \
     const int na = (actions && n_actions) ? n_actions[env] : 0;                                                     \
     const size_t drow = K.decision_mode ? (size_t)K.V * 8 : 8; /* Joint modes: one row per vessel */                \
-    cim::step_env<PG>(K, env, lds, a, na, n_answered ? n_answered[env] : -1, decisions + (size_t)env * drow,        \
+    cim::step_env<PG, OBS>(K, O, env, lds, a, na, n_answered ? n_answered[env] : -1, decisions + (size_t)env * drow,     \
                       metrics + (size_t)env * 3, done + env);                                                       \
   }
-MRX_STEP_KERNEL(mrx_k_cim_step, false)
-MRX_STEP_KERNEL(mrx_k_cim_step_tab, true)
+MRX_STEP_KERNEL(mrx_k_cim_step, false, false, 2)
+MRX_STEP_KERNEL(mrx_k_cim_step_tab, true, false, 3)  // 3 waves/SIMD: <= 168 VGPRs, so LDS (9 waves/CU) is the limit
+MRX_STEP_KERNEL(mrx_k_cim_step_obs, false, true, 2)      // + fused observation (mrx_cim_set_observation)
+MRX_STEP_KERNEL(mrx_k_cim_step_tab_obs, true, true, 3)
 #undef MRX_STEP_KERNEL
 
 struct AttrList { int n; int32_t id[16]; };
@@ -108,7 +110,9 @@ mrx_k_cim_random_policy(CimParams K, const int32_t* __restrict__ decisions, long
     valid = d[7] == 1;
     int32_t* a = actions + (size_t)env * K.max_actions * 4;
     if (valid) {
-      const unsigned long long x = mrx_mix64((unsigned long long)K.seed[env], (unsigned long long)step);
+      // step < 0: key the draw on the decision itself (tick, vessel) so a captured hipGraph needs no per-step scalar
+      const unsigned long long key = step >= 0 ? (unsigned long long)step : (((unsigned long long)(unsigned)d[0] << 8) | (unsigned)d[2]) + 0x100000000ull;
+      const unsigned long long x = mrx_mix64((unsigned long long)K.seed[env], key);
       const unsigned long long r = x >> 1;
       const int load = d[3], dis = d[4];
       a[0] = d[2]; a[1] = d[1];
@@ -127,6 +131,7 @@ mrx_k_cim_random_policy(CimParams K, const int32_t* __restrict__ decisions, long
 struct mrx_cim_engine {
   CimHostPlan plan;
   int device;
+  CimObs obs;  // fused observation (all zero = off)
 };
 
 static thread_local std::string g_err;
@@ -182,6 +187,7 @@ int mrx_cim_create(const mrx_cim_topology* topo, const mrx_cim_config* cfg, void
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { delete e; return set_err(MRX_ERR_NO_DEVICE, "no HIP device available"); }
   e->device = cfg->device;
+  memset(&e->obs, 0, sizeof(e->obs));
   rc = use_device(e->device);
   if (rc != MRX_OK) { delete e; return rc; }
   cim_plan_bind(&e->plan, d_workspace);
@@ -193,6 +199,8 @@ int mrx_cim_create(const mrx_cim_topology* topo, const mrx_cim_config* cfg, void
     hipFuncSetAttribute((const void*)mrx_k_cim_reset, hipFuncAttributeMaxDynamicSharedMemorySize, K.lds_words_reset * 4);
     hipFuncSetAttribute((const void*)mrx_k_cim_step, hipFuncAttributeMaxDynamicSharedMemorySize, K.lds_words * 4);
     hipFuncSetAttribute((const void*)mrx_k_cim_step_tab, hipFuncAttributeMaxDynamicSharedMemorySize, K.lds_words * 4);
+    hipFuncSetAttribute((const void*)mrx_k_cim_step_obs, hipFuncAttributeMaxDynamicSharedMemorySize, K.lds_words * 4);
+    hipFuncSetAttribute((const void*)mrx_k_cim_step_tab_obs, hipFuncAttributeMaxDynamicSharedMemorySize, K.lds_words * 4);
   }
   // Env.__init__ generates data with the topology's own seed (cim_data_generator.py:141-145)
   hipLaunchKernelGGL(mrx_k_cim_reset, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_reset * 4, 0, K, nullptr, nullptr,
@@ -254,13 +262,38 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
   if (rc != MRX_OK) return rc;
   const CimParams& K = h->plan.kp;
   static const size_t lds_pad = getenv("MRX_DEBUG_LDS_PAD_BYTES") ? (size_t)atoi(getenv("MRX_DEBUG_LDS_PAD_BYTES")) : 0;  // occupancy experiments
-  if (K.pregen)
-    hipLaunchKernelGGL(mrx_k_cim_step_tab, dim3(K.n_envs), dim3(64), (size_t)K.lds_words * 4 + lds_pad, (hipStream_t)stream, K, d_actions,
-                       d_n_actions, d_n_answered, d_env_mask, d_decisions, (long long*)d_metrics, d_done);
-  else
-    hipLaunchKernelGGL(mrx_k_cim_step, dim3(K.n_envs), dim3(64), (size_t)K.lds_words * 4 + lds_pad, (hipStream_t)stream, K, d_actions,
-                       d_n_actions, d_n_answered, d_env_mask, d_decisions, (long long*)d_metrics, d_done);
+  const bool obs = h->obs.np > 0 || h->obs.nv > 0;
+  auto kern = K.pregen ? (obs ? mrx_k_cim_step_tab_obs : mrx_k_cim_step_tab) : (obs ? mrx_k_cim_step_obs : mrx_k_cim_step);
+  hipLaunchKernelGGL(kern, dim3(K.n_envs), dim3(64), (size_t)K.lds_words * 4 + lds_pad, (hipStream_t)stream, K, h->obs, d_actions,
+                     d_n_actions, d_n_answered, d_env_mask, d_decisions, (long long*)d_metrics, d_done);
   HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+int mrx_cim_set_observation(mrx_handle h, const int32_t* port_attrs, int n_port_attrs, const int32_t* vessel_attrs, int n_vessel_attrs,
+                            double* d_obs_ports, double* d_obs_vessel) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  if (h->plan.kp.decision_mode != 0) return set_err(MRX_ERR_UNSUPPORTED, "the fused observation is defined for Sequential decision mode");
+  if (n_port_attrs < 0 || n_port_attrs > 8 || n_vessel_attrs < 0 || n_vessel_attrs > 8) return set_err(MRX_ERR_INVALID_ARG, "at most 8 port and 8 vessel attributes");
+  if ((n_port_attrs && (!port_attrs || !d_obs_ports)) || (n_vessel_attrs && (!vessel_attrs || !d_obs_vessel))) return set_err(MRX_ERR_INVALID_ARG, "null attribute list / output");
+  CimObs o;
+  memset(&o, 0, sizeof(o));
+  for (int i = 0; i < n_port_attrs; i++) {
+    if (port_attrs[i] < 0 || port_attrs[i] >= PA_COUNT) return set_err(MRX_ERR_INVALID_ARG, "unknown port attribute id");
+    o.pa[i] = port_attrs[i];
+  }
+  for (int i = 0; i < n_vessel_attrs; i++) {
+    if (vessel_attrs[i] < 0 || vessel_attrs[i] >= VA_PAST_STOP_LIST) return set_err(MRX_ERR_INVALID_ARG, "vessel attribute must be a single-slot attribute");
+    o.va[i] = vessel_attrs[i];
+  }
+  o.np = n_port_attrs; o.nv = n_vessel_attrs; o.ports = d_obs_ports; o.vessel = d_obs_vessel;
+  o.i_empty = o.i_tc = -1;
+  for (int i = 0; i < n_port_attrs; i++) {
+    o.pa_packed |= (unsigned)o.pa[i] << (4 * i);
+    if (o.pa[i] == PA_EMPTY) o.i_empty = i;
+    if (o.pa[i] == PA_TRANSFER_COST) o.i_tc = i;
+  }
+  h->obs = o;
   return MRX_OK;
 }
 

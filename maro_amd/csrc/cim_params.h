@@ -64,3 +64,14 @@ struct CimParams {
   uint32_t *mt, *stops;
   int64_t* seed;
 };
+
+// Observation fused into the step kernel (mrx_cim_set_observation): per stepped env with a new decision,
+//   ports  [n_envs][P][np] = snapshot_list["ports"][decision frame :: port attrs]
+//   vessel [n_envs][nv]    = snapshot_list["vessels"][decision frame : decision vessel : vessel attrs]
+struct CimObs {
+  int np, nv;
+  int pa[8], va[8];
+  unsigned pa_packed;  // pa[] as 4-bit codes (lane-varying attribute index without indexing a kernel argument)
+  int i_empty, i_tc;   // position of `empty` / `transfer_cost` in pa[] (-1: not requested)
+  double *ports, *vessel;
+};

@@ -10,6 +10,7 @@ struct int4 { int x, y, z, w; };
 #include "../../maro_amd/csrc/cim_layout.h"
 
 struct Emu {
+  CimObs obs = {};
   CimHostPlan plan;
   uint8_t* ws = nullptr;
   int32_t* lds = nullptr;
@@ -75,9 +76,26 @@ void emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const u
     wave::run_wave(e->wave, [&]() {
       const size_t drow = K.decision_mode ? (size_t)K.V * 8 : 8;
       const int nans = n_answered ? n_answered[env] : -1;
-      if (K.pregen) cim::step_env<true>(K, env, e->lds, a, na, nans, dec + (size_t)env * drow, (long long*)(met + (size_t)env * 3), done + env);
-      else cim::step_env<false>(K, env, e->lds, a, na, nans, dec + (size_t)env * drow, (long long*)(met + (size_t)env * 3), done + env);
+      const bool obs = e->obs.np > 0 || e->obs.nv > 0;
+#define EMU_STEP(PG, OBS) cim::step_env<PG, OBS>(K, e->obs, env, e->lds, a, na, nans, dec + (size_t)env * drow, (long long*)(met + (size_t)env * 3), done + env)
+      if (K.pregen) { if (obs) EMU_STEP(true, true); else EMU_STEP(true, false); }
+      else { if (obs) EMU_STEP(false, true); else EMU_STEP(false, false); }
+#undef EMU_STEP
     });
+  }
+}
+
+void emu_set_observation(void* h, const int32_t* pa, int np, const int32_t* va, int nv, double* ports, double* vessel) {
+  Emu* e = (Emu*)h;
+  memset(&e->obs, 0, sizeof(e->obs));
+  for (int i = 0; i < np; i++) e->obs.pa[i] = pa[i];
+  for (int i = 0; i < nv; i++) e->obs.va[i] = va[i];
+  e->obs.np = np; e->obs.nv = nv; e->obs.ports = ports; e->obs.vessel = vessel;
+  e->obs.i_empty = e->obs.i_tc = -1;
+  for (int i = 0; i < np; i++) {
+    e->obs.pa_packed |= (unsigned)pa[i] << (4 * i);
+    if (pa[i] == PA_EMPTY) e->obs.i_empty = i;
+    if (pa[i] == PA_TRANSFER_COST) e->obs.i_tc = i;
   }
 }
 

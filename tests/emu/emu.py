@@ -54,6 +54,8 @@ def lib():
         L.emu_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_void_p]
         L.emu_query.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.emu_set_observation.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -109,6 +111,14 @@ class EmuBackend:
         lib().emu_step(self._h, _ptr(a), _ptr(na), _ptr(mk), _ptr(self._dec), _ptr(self._met), _ptr(self._done),
                        int(self.reverse), _ptr(nans))
         return self._dec.copy(), self._met.copy(), self._done.copy()
+
+    def set_observation(self, port_attr_ids, vessel_attr_ids):
+        """Fused observation (mrx_cim_set_observation): returns (obs_ports [n, P, np], obs_vessel [n, nv]) written by step()."""
+        pa, va = np.ascontiguousarray(port_attr_ids, np.int32), np.ascontiguousarray(vessel_attr_ids, np.int32)
+        self.obs_ports = np.zeros((self.n_envs, self.layout.n_ports, len(pa)), np.float64)
+        self.obs_vessel = np.zeros((self.n_envs, len(va)), np.float64)
+        lib().emu_set_observation(self._h, _ptr(pa), len(pa), _ptr(va), len(va), _ptr(self.obs_ports), _ptr(self.obs_vessel))
+        return self.obs_ports, self.obs_vessel
 
     def query(self, node_type, ticks, nodes, attrs, row_slots):
         t = np.ascontiguousarray(ticks, np.int32)

@@ -36,3 +36,20 @@ class GpuBackend:
                              [NODE_ATTRS[node][a] for a in attrs])
         torch.cuda.synchronize()
         return out.cpu().numpy()
+
+
+    def set_observation(self, port_attr_ids, vessel_attr_ids):
+        from maro_amd.cim.engine import PORT_ATTRS, VESSEL_ATTRS
+        op, ov = self.eng.set_observation([PORT_ATTRS[a] for a in port_attr_ids], [VESSEL_ATTRS[a] for a in vessel_attr_ids])
+        return _Live(op), _Live(ov)
+
+
+class _Live:
+    """np.array(x) gives the current content of a device tensor."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def __array__(self, dtype=None, copy=None):
+        torch.cuda.synchronize()
+        return self.t.cpu().numpy()

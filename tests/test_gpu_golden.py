@@ -178,3 +178,12 @@ def test_full_size_bench_workload_properties():
         o.reset(keep_seed=True)
         _, _, om = o.rollout(int(seeds[e]))
         assert np.array_equal(met[e], om), (e, met[e], om)
+
+
+@pytest.mark.parametrize("topology,n", [("global_trade.22p_l0.8", 130), ("toy.5p_ssddd_l0.5", 70)])
+def test_fused_observation_matches_snapshot_slices(topology, n):
+    from maro_amd.cim.topology import load_topology
+    from tests.gpu_backend import GpuBackend
+    from tests.test_emu_observation import check_fused_observation
+    b = GpuBackend(load_topology(topology), n_envs=n, durations=80, max_actions=1)
+    check_fused_observation(b, seeds=np.arange(n) + 5)
