@@ -186,7 +186,6 @@ def bench_citi_bike(args):
             "config": {"workload": f"citi_bike {topology}, {n} envs/GPU x {world} GPU, durations {durations}, resolution {res}, "
                                    f"device policy, stations snapshot slice {'off' if args.no_query else 'every step'}",
                        "envs_per_gpu": n, "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective)",
-                       "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms,
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
             "roofline": {"bound": "hbm", "kernel": "mrx_k_cb_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": step_kernel_ms,
