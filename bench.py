@@ -207,6 +207,9 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs", type=int, default=None, help="environments per GPU (weak scaling); default 16384 (cim) / 4096 (citi_bike)")
+    ap.add_argument("--policy", default="random", choices=["random", "dqn"],
+                    help="random: the device random legal agent (headline); dqn: CIMEnvSampler state + 22 per-port dueling DQNs "
+                         "+ action translation, all on the device (SURVEY.md 8d config 5; use --ring 8 or more)")
     ap.add_argument("--obs", default="fused", choices=["fused", "query"],
                     help="how the per-step ports / deciding-vessel snapshot slices are produced: fused into the step kernel, or by mrx_cim_query")
     ap.add_argument("--graphs", type=int, default=0, help="1: capture one step per group in a hipGraph and replay it (cim)")
@@ -261,11 +264,22 @@ def main():
                          counter=torch.zeros((1,), dtype=torch.int64, device=dev),
                          q_ports=None if (args.no_query or args.obs == "fused") else torch.empty((ng, 1, engines[0].topo.n_ports, len(QUERY_ATTRS)), dtype=torch.float64, device=dev),
                          q_vessel=None if (args.no_query or args.obs == "fused") else torch.empty((ng, 1, 1, len(VESSEL_QUERY_ATTRS)), dtype=torch.float64, device=dev)))
-        if args.obs == "fused" and not args.no_query:
+        if args.obs == "fused" and not args.no_query and args.policy != "dqn":
             # the same two slices, written by the step kernel itself (mrx_cim_set_observation) instead of two more launches
             bufs[-1]["obs"] = eng.set_observation(QUERY_ATTRS, VESSEL_QUERY_ATTRS)
     topo = engines[0].topo
     ports = torch.arange(topo.n_ports, dtype=torch.int32, device=dev)
+    samplers, qnet = [], None
+    if args.policy == "dqn":
+        # the CIM RL example's rollout path entirely on the device — CIMEnvSampler state
+        # (look-back snapshot slices, maro_amd/cim/sampler.py), 22 per-port dueling DQNs (random-init weights, bf16 GEMMs),
+        # greedy action, env_sampler.py action translation (maro_amd/cim/policy.py)
+        from maro_amd.cim.policy import PerPortDuelingQNet, translate_actions
+        from maro_amd.cim.sampler import CimBatchSampler
+        samplers = [CimBatchSampler(e) for e in engines]
+        qnet = PerPortDuelingQNet(topo.n_ports, samplers[0].state_dim).to(dev)
+        for e, b in zip(engines, bufs):
+            b["vobs"] = e.set_observation([], ["remaining_space", "early_discharge"])[1]
     torch.cuda.synchronize(dev)
     # Env.reset for the whole batch (route unrolling, order proportion and — with the order table — every order of the
     # episode are generated on the device here, outside the timed step loop): reported next to the step rate
@@ -287,7 +301,15 @@ def main():
             if graphs[g] is not None and timing is None:
                 graphs[g].replay()  # policy -> step -> snapshot slices, captured once (hipGraph)
                 return
-            eng.random_policy(-1 if args.graphs else i, b["actions"], b["n_actions"], b["counter"] if timing is None else None)
+            if qnet is not None:
+                d = eng.decisions
+                q = qnet(samplers[g].state(d), d[:, 1])
+                translate_actions(q.argmax(dim=1), d, b["vobs"][:, 0], b["vobs"][:, 1], out=b["actions"])
+                b["n_actions"].copy_(d[:, 7])
+                if timing is None:
+                    b["counter"] += d[:, 7].sum()
+            else:
+                eng.random_policy(-1 if args.graphs else i, b["actions"], b["n_actions"], b["counter"] if timing is None else None)
             if timing is not None:
                 timing[0].record()
             eng.step(b["actions"], b["n_actions"])
@@ -394,7 +416,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {args.durations}, "
-                                   f"random legal agent on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step (' + args.obs + ')'}",
+                                   f"{'random legal agent' if args.policy == 'random' else 'per-port dueling DQN (bf16, greedy) + CIMEnvSampler state shaping'} on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step (' + args.obs + ')'}",
                        "envs_per_gpu": n, "groups_per_gpu": G, "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,
                        "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
                        "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms,
