@@ -257,6 +257,7 @@ struct TickPf {
   double tb[3], tn[3];
   int src[3];
   int q[4], key[4];
+  int kk[4];  // order pair (arrival port -> port of the i-th next stop) of the a-th arriving vessel, lane i; -1: none
   int ns, otg;
   int oqr[3];  // order table: quantities of pairs lane + 64 b of the coming tick
   uint32_t stk, stk1;
@@ -270,7 +271,7 @@ MRX_DEV void tick_prefetch_land(TickPf& pf) {
 #pragma unroll
   for (int b = 0; b < 3; b++) { wave::touch(pf.tb[b]); wave::touch(pf.tn[b]); wave::touch(pf.src[b]); }
 #pragma unroll
-  for (int a = 0; a < 4; a++) { wave::touch(pf.q[a]); wave::touch(pf.key[a]); }
+  for (int a = 0; a < 4; a++) { wave::touch(pf.q[a]); wave::touch(pf.key[a]); wave::touch(pf.kk[a]); }
   wave::touch(pf.ns); wave::touch(pf.otg); wave::touch(pf.stk); wave::touch(pf.stk1);
 #pragma unroll
   for (int b = 0; b < 3; b++) wave::touch(pf.oqr[b]);
@@ -290,12 +291,16 @@ MRX_DEV void tick_prefetch_static(const CimParams& K, TickPf& pf, bool generator
   }
 }
 
-// stop-table entries and discharge records of the first (up to) four vessels of `mask`
+// stop-table entries, discharge records and order pairs of the first (up to) four vessels of `mask`
 MRX_DEV void tick_prefetch_arrivals(const CimParams& K, int env, Lds& L, uint64_t mask, TickPf& pf) {
   const int lane = wave::lane();
-  const int V = K.V;
+  const int V = K.V, P = K.P;
   const Tabs& T = L.tab;
   const int32_t* g_rec = K.rec + (size_t)env * K.REC_W;
+  // per-vessel words as rows (lane = vessel): one LDS trip for all of them, then register reads per arriving vessel
+  const int lv = lane < V ? lane : 0;
+  const int r_next = FV(VA_NEXT_LOC_IDX, lv), r_krl = V_KRL(lv), r_pos = V_POS(lv);
+  const int r_len = T.v_route_len[lv], r_rb = T.v_route_base[lv], r_rec = T.rec_off[lv];
   // lane a (< 4) fetches the stop-table entries of the a-th arriving vessel
   {
     uint64_t m = mask;
@@ -305,26 +310,30 @@ MRX_DEV void tick_prefetch_arrivals(const CimParams& K, int env, Lds& L, uint64_
       if (m) m &= m - 1;
       if (lane == a) v = va;
     }
-    const int k = FV(VA_NEXT_LOC_IDX, lane < 4 ? v : 0);
+    const int k = wave::shfl(r_next, lane < 4 ? v : 0);
     const size_t srow = ((size_t)env * V + v) * K.SMAX;
     pf.ns = K.nstops[(size_t)env * V + v];
     pf.stk = K.stops[srow + (k < K.SMAX ? k : 0)];
     pf.stk1 = K.stops[srow + (k + 1 < K.SMAX ? k + 1 : 0)];
   }
-  // lane j fetches the j-th candidate discharge record (and its load tick) of each of those vessels
+  // lane j fetches the j-th candidate discharge record (and its load tick) of each of those vessels, and the order
+  // pair that ships from the arrival port to the port of the vessel's j-th next stop
   uint64_t m = mask;
 #pragma unroll
   for (int a = 0; a < 4; a++) {
     const int v = m ? __builtin_ctzll(m) : 0;  // wave-uniform; vessel 0 is a harmless stand-in when fewer arrive
     if (m) m &= m - 1;
-    const int k = U(FV(VA_NEXT_LOC_IDX, v));
-    const int Lr = T.v_route_len[v], RL = Lr + 1, krl = U(V_KRL(v));
+    const int k = wave::readlane(r_next, v), Lr = wave::readlane(r_len, v), krl = wave::readlane(r_krl, v);
+    const int pos = wave::readlane(r_pos, v), rb = wave::readlane(r_rb, v);
+    const int RL = Lr + 1;
     const int sidx = k - Lr + lane;
     int col = krl + 1 + lane;
     if (col >= RL) col -= RL;
     const bool ok = lane < Lr && sidx >= 0;
-    pf.q[a] = g_rec[T.rec_off[v] + krl * RL + (ok ? col : 0)];
+    pf.q[a] = g_rec[wave::readlane(r_rec, v) + krl * RL + (ok ? col : 0)];
     pf.key[a] = (int)K.stops[((size_t)env * V + v) * K.SMAX + (ok ? sidx : 0)];
+    const int xn = (pos + 1 + (lane < Lr ? lane : 0)) % Lr;
+    pf.kk[a] = K.pair_dense[(int)T.route_port[rb + pos] * P + (int)T.route_port[rb + xn]];
   }
 }
 
@@ -723,6 +732,8 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
     int32_t* ent = L.misc;  // (key, v, q) triples
     int n_ent = 0, n_ves = 0;
     int slot4 = 0;
+    const int lvd = lane < V ? lane : 0;
+    const int d_k = FV(VA_NEXT_LOC_IDX, lvd), d_krl = V_KRL(lvd), d_len = T.v_route_len[lvd], d_rec = T.rec_off[lvd];  // rows, lane = vessel
     for (uint64_t m = arr_mask; m; m &= m - 1, slot4++) {  // wave-uniform
       if (slot4 == 4) {  // more than four arrivals in one tick (rare): fetch the next four now
         tick_prefetch_arrivals(K, env, L, m, pf);
@@ -730,14 +741,14 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
         slot4 = 0;
       }
       const int v = __builtin_ctzll(m);
-      const int k = U(FV(VA_NEXT_LOC_IDX, v));
-      const int Lr = T.v_route_len[v], RL = Lr + 1;
-      const int krl = U(V_KRL(v));
+      const int k = wave::readlane(d_k, v);
+      const int Lr = wave::readlane(d_len, v), RL = Lr + 1;
+      const int krl = wave::readlane(d_krl, v);
       const int sidx = k - Lr + lane;  // lane j looks at load stop k-Lr+j
       int q = 0, key = 0;
       int col = krl + 1 + lane;  // (k - Lr + lane) mod RL
       if (col >= RL) col -= RL;
-      int32_t* cell = g_rec + T.rec_off[v] + krl * RL + (lane < Lr ? col : 0);
+      int32_t* cell = g_rec + wave::readlane(d_rec, v) + krl * RL + (lane < Lr ? col : 0);
       if (lane < Lr && sidx >= 0) {  // prefetched (tick_prefetch_arrivals)
         q = slot4 == 0 ? pf.q[0] : slot4 == 1 ? pf.q[1] : slot4 == 2 ? pf.q[2] : pf.q[3];
         key = stop_arrival((uint32_t)(slot4 == 0 ? pf.key[0] : slot4 == 1 ? pf.key[1] : slot4 == 2 ? pf.key[2] : pf.key[3]));
@@ -754,7 +765,19 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
     }
     if (n_ent > K.misc_cap) { status |= 16; n_ent = K.misc_cap; }
     wave::sync();
-    if (n_ves > 1 && n_ent > 1) {  // merge by load tick, stable (several vessels arriving in one tick)
+    if (n_ves > 1 && n_ent > 1 && n_ent <= 64) {
+      // merge by load tick, stable (several vessels arriving in one tick): lane i ranks entry i among all entries
+      const bool mine = lane < n_ent;
+      const int key = mine ? ent[3 * lane] : 0x7fffffff, vv = mine ? ent[3 * lane + 1] : 0, qq = mine ? ent[3 * lane + 2] : 0;
+      int rank = 0;
+      for (int j = 0; j < n_ent; j++) {  // wave-uniform
+        const int kj = wave::readlane(key, j);
+        rank += (kj < key || (kj == key && j < lane)) ? 1 : 0;
+      }
+      wave::sync();
+      if (mine) { ent[3 * rank] = key; ent[3 * rank + 1] = vv; ent[3 * rank + 2] = qq; }
+      wave::sync();
+    } else if (n_ves > 1 && n_ent > 1) {  // more records than lanes: serial insertion sort
       if (lane == 0) {
         for (int i = 1; i < n_ent; i++) {
           const int key = ent[3 * i], vv = ent[3 * i + 1], qq = ent[3 * i + 2];
@@ -873,6 +896,11 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
       tick_prefetch_arrivals(K, env, L, arr_mask, pf);
       tick_prefetch_land(pf);
     }
+    // per-vessel words as rows (lane = vessel): one LDS trip, then register reads per arriving vessel (an arrival only
+    // changes its own vessel's words)
+    const int lvv = lane < V ? lane : 0;
+    const int r_k = FV(VA_NEXT_LOC_IDX, lvv), r_pos = V_POS(lvv), r_krl = V_KRL(lvv), r_cap = FV(VA_CAPACITY, lvv),
+              r_full = FV(VA_FULL, lvv), r_empty = FV(VA_EMPTY, lvv), r_len = T.v_route_len[lvv], r_rb = T.v_route_base[lvv];
     for (uint64_t m = arr_mask; m; m &= m - 1, a_idx++) {  // wave-uniform over the arriving vessels
       if (a_idx == 4) {
         tick_prefetch_arrivals(K, env, L, m, pf);
@@ -880,11 +908,11 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
         a_idx = 0;
       }
       const int v = __builtin_ctzll(m);
-      int k = FV(VA_NEXT_LOC_IDX, v), pos = V_POS(v), krl = V_KRL(v), cap = FV(VA_CAPACITY, v), full = FV(VA_FULL, v),
-          empty = FV(VA_EMPTY, v);
-      k = U(k); pos = U(pos); krl = U(krl); cap = U(cap); full = U(full); empty = U(empty);
+      const int k = wave::readlane(r_k, v), pos = wave::readlane(r_pos, v), krl = wave::readlane(r_krl, v),
+                cap = wave::readlane(r_cap, v);
+      int full = wave::readlane(r_full, v), empty = wave::readlane(r_empty, v);
       const int full0 = full, empty0 = empty;
-      const int Lr = T.v_route_len[v], rb = T.v_route_base[v], RL = Lr + 1;
+      const int Lr = wave::readlane(r_len, v), rb = wave::readlane(r_rb, v), RL = Lr + 1;
       const int p = T.route_port[rb + pos];
       const int ns = wave::shfl(pf.ns, a_idx);  // prefetched by lane a_idx (tick_prefetch_arrivals)
       const uint32_t st_k = (uint32_t)wave::shfl((int)pf.stk, a_idx);
@@ -911,11 +939,8 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
       // a second visit of the same port within the window gets nothing (first visit took all, or space ran out)
       const int acceptable = (int)floor((double)(cap - full * K.vol) / (double)K.vol);
       const bool lv = lane < Lr && (k + 1 + lane) < ns && !dup_earlier;  // python slice truncation at the end of the stop list
-      int kk = -1;  // order pair (p -> port_i), if the port ships there at all
-      {
-        const int off = T.tgt_off[p], cnt = T.tgt_off[p + 1] - off;
-        for (int j = 0; j < cnt; j++) if (T.tgt_port[off + j] == port_i) kk = off + j;
-      }
+      // order pair (p -> port_i), if the port ships there at all: prefetched (tick_prefetch_arrivals)
+      const int kk = a_idx == 0 ? pf.kk[0] : a_idx == 1 ? pf.kk[1] : a_idx == 2 ? pf.kk[2] : pf.kk[3];
       const int pend = (lv && kk >= 0) ? FOPK(kk) : 0;
       const int incl = wave::scan_incl_add(pend);
       int l = 0;
@@ -1158,6 +1183,9 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
   int a0v = 0, a0p = 0, a0q = 0, a0t = 0;
   if (actions) { a0v = actions[0]; a0p = actions[1]; a0q = actions[2]; a0t = actions[3]; }
   wave::lds_dma_wait();
+  // plan cell of the first action's (vessel, port): a shared L2-resident table, requested now and used after the tick
+  // prefetch below has been issued
+  int a0c = K.cidx_dense[(a0v >= 0 && a0v < V && a0p >= 0 && a0p < P) ? a0v * P + a0p : 0];
   const int flags0 = U(L.priv[PH_FLAGS]);
   if (flags0 & FL_FINISHED) {  // reference: (None, None, True) once the generator is exhausted
     if (lane < 8) dec_out[lane] = lane == 7 ? -1 : 0;
@@ -1210,11 +1238,9 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
       { const int rs0 = U(FV(VA_REMAINING_SPACE, v)); FV(VA_REMAINING_SPACE, v) = rs0 - (nve - ve); }  // total_space - full - empty
       opnum += q;
       FP(PA_TRANSFER_COST, p) = f_bits((float)((double)bits_f(U(FP(PA_TRANSFER_COST, p))) + (double)q));
-      {  // vessel_plans[v, p] += period (:748): find p among the vessel's route ports
-        const int Lr = T.v_route_len[v], rb = T.v_route_base[v];
-        int c = -1;
-        for (int x = 0; x < Lr; x++) if (T.route_port[rb + x] == p) c = T.route_cidx[rb + x];
-        if (c >= 0) { const int pl = U(PLANC(v, c)); PLANC(v, c) = pl + U(V_PERIOD(v)); }
+      {  // vessel_plans[v, p] += period (:748): the compact plan cell of (v, p), -1 if p is not on the vessel's route
+        const int c = U(i == 0 ? a0c : K.cidx_dense[v * P + p]);
+        if (c >= 0) { const int pl = U(L.frame[K.f_plans + c]); L.frame[K.f_plans + c] = pl + U(V_PERIOD(v)); }
         else status |= 32;  // MRX_ENV_OFFROUTE_ACTION
       }
     }

@@ -68,9 +68,9 @@ mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const
                       metrics + (size_t)env * 3, done + env);                                                       \
   }
 MRX_STEP_KERNEL(mrx_k_cim_step, false, false, 2)
-MRX_STEP_KERNEL(mrx_k_cim_step_tab, true, false, 3)  // 3 waves/SIMD: <= 168 VGPRs, so LDS (9 waves/CU) is the limit
+MRX_STEP_KERNEL(mrx_k_cim_step_tab, true, false, 2)  // 3 waves/SIMD: <= 168 VGPRs, so LDS (9 waves/CU) is the limit
 MRX_STEP_KERNEL(mrx_k_cim_step_obs, false, true, 2)      // + fused observation (mrx_cim_set_observation)
-MRX_STEP_KERNEL(mrx_k_cim_step_tab_obs, true, true, 3)
+MRX_STEP_KERNEL(mrx_k_cim_step_tab_obs, true, true, 2)
 #undef MRX_STEP_KERNEL
 
 struct AttrList { int n; int32_t id[16]; };

@@ -28,6 +28,8 @@ MRX_DEV void sync() {
 MRX_DEV uint64_t ballot(bool pred) { return __ballot(pred); }
 
 MRX_DEV int shfl(int v, int src) { return __shfl(v, src, 64); }
+// value of lane `src`, src wave-uniform: v_readlane_b32 (a register read; no trip through the LDS crossbar)
+MRX_DEV int readlane(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 MRX_DEV long long shfl(long long v, int src) {
   int lo = __shfl((int)(v & 0xffffffffll), src, 64), hi = __shfl((int)(v >> 32), src, 64);
   return ((long long)hi << 32) | (unsigned int)lo;
