@@ -25,7 +25,8 @@
 
 namespace cb {
 
-#define HDR(w) K.hdr[(size_t)(w) * K.stride + e]
+#define GHDR(w) K.hdr[(size_t)(w) * K.stride + e] /* header word in HBM */
+#define HDR(w) hd[(w)]                           /* header word of the env being stepped: a register copy (step_env) */
 #define ST(a, s) K.live[((size_t)(a) * K.S + (size_t)(s)) * K.stride + e]
 #define ADJ(i, j) K.live[((size_t)LV_COUNT * K.S + (size_t)(i) * K.S + (size_t)(j)) * K.stride + e]
 #define POOL(i, w) K.pool[((size_t)(i) * CB_POOL_WORDS + (w)) * K.stride + e]
@@ -52,7 +53,7 @@ MRX_DEV void move_to_neighbor(const CbParams& K, int e, int src, int cur, int nu
 }
 
 // _on_bike_returned :439-466 (deliver = false) and _on_bike_deliver :494-519 (deliver = true)
-MRX_DEV void land_bikes(const CbParams& K, int e, bool deliver, int frm, int to, int n) {
+MRX_DEV void land_bikes(const CbParams& K, int e, int32_t* hd, bool deliver, int frm, int to, int n) {
   const int b = ST(LV_BIKES, to);
   int accept = K.capacity[to] - b;
   if (accept > n) accept = n;
@@ -69,19 +70,19 @@ MRX_DEV void land_bikes(const CbParams& K, int e, bool deliver, int frm, int to,
 
 // Executes, in insertion order, the pool's deliveries landing at tick `t` whose scheduling tick is < sched_lt.
 // `p` is the scan position (monotonic counter); entries are appended in scheduling order.
-MRX_DEV void pool_exec_until(const CbParams& K, int e, int t, int sched_lt, int& p, int tail) {
+MRX_DEV void pool_exec_until(const CbParams& K, int e, int32_t* hd, int t, int sched_lt, int& p, int tail) {
   while (p != tail) {
     const int idx = p % K.pool_cap;
     if (POOL(idx, 0) == t && POOL(idx, 4) >= 0) {
       if (POOL(idx, 1) >= sched_lt) return;
-      land_bikes(K, e, true, POOL(idx, 2), POOL(idx, 3), POOL(idx, 4));
+      land_bikes(K, e, hd, true, POOL(idx, 2), POOL(idx, 3), POOL(idx, 4));
       POOL(idx, 4) = -1;
     }
     p++;
   }
 }
 
-MRX_DEV void pool_compact(const CbParams& K, int e) {
+MRX_DEV void pool_compact(const CbParams& K, int e, int32_t* hd) {
   int head = HDR(CH_POOL_HEAD);
   const int tail = HDR(CH_POOL_TAIL);
   while (head != tail && POOL(head % K.pool_cap, 4) < 0) head++;
@@ -94,7 +95,7 @@ MRX_DEV void pool_compact(const CbParams& K, int e) {
   HDR(CH_POOL_MINLAND) = m;
 }
 
-MRX_DEV void pool_push(const CbParams& K, int e, int land, int sched, int frm, int to, int n) {
+MRX_DEV void pool_push(const CbParams& K, int e, int32_t* hd, int land, int sched, int frm, int to, int n) {
   const int head = HDR(CH_POOL_HEAD), tail = HDR(CH_POOL_TAIL);
   if (tail - head >= K.pool_cap) {
     HDR(CH_STATUS) |= MRX_CB_ENV_DELIVERY_OVERFLOW;
@@ -107,7 +108,7 @@ MRX_DEV void pool_push(const CbParams& K, int e, int land, int sched, int frm, i
 }
 
 // phases 1-3 of tick t
-MRX_DEV void begin_tick(const CbParams& K, int e, int t) {
+MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t) {
   const int d = t - K.start_tick;
   // ---- 1: events queued by earlier ticks, by (scheduling tick, ReturnBike before DeliverBike, insertion order)
   const bool deliveries = HDR(CH_POOL_MINLAND) == t;
@@ -116,12 +117,12 @@ MRX_DEV void begin_tick(const CbParams& K, int e, int t) {
   const int r_mid = K.ret_mid[d], r_end = K.ret_off[d + 1];
   for (int r = K.ret_off[d]; r < r_mid; r++) {
     const int i = K.ret_trip[r];
-    if (deliveries) pool_exec_until(K, e, t, K.trip_tick[i], p, tail);
-    if (K.fulfilled[(size_t)((i & K.w_mask) >> 5) * K.stride + e] >> (i & 31) & 1u) land_bikes(K, e, false, K.trip_src[i], K.trip_dst[i], 1);
+    if (deliveries) pool_exec_until(K, e, hd, t, K.trip_tick[i], p, tail);
+    if (K.fulfilled[(size_t)((i & K.w_mask) >> 5) * K.stride + e] >> (i & 31) & 1u) land_bikes(K, e, hd, false, K.trip_src[i], K.trip_dst[i], 1);
   }
   if (deliveries) {
-    pool_exec_until(K, e, t, CB_NO_LAND, p, tail);
-    pool_compact(K, e);
+    pool_exec_until(K, e, hd, t, CB_NO_LAND, p, tail);
+    pool_compact(K, e, hd);
   }
   // ---- 2: RequireBike :398-437
   const int q_end = K.trip_off[d + 1];
@@ -160,7 +161,7 @@ MRX_DEV void begin_tick(const CbParams& K, int e, int t) {
   }
   for (int r = r_mid; r < r_end; r++) {
     const int i = K.ret_trip[r];
-    if (K.fulfilled[(size_t)((i & K.w_mask) >> 5) * K.stride + e] >> (i & 31) & 1u) land_bikes(K, e, false, K.trip_src[i], K.trip_dst[i], 1);
+    if (K.fulfilled[(size_t)((i & K.w_mask) >> 5) * K.stride + e] >> (i & 31) & 1u) land_bikes(K, e, hd, false, K.trip_src[i], K.trip_dst[i], 1);
   }
   HDR(CH_LATE) = 0;
 }
@@ -176,11 +177,11 @@ MRX_DEV void take_snapshot(const CbParams& K, int e, int t) {
 }
 
 // phases 5-6 of tick t; returns true when the episode is over
-MRX_DEV bool end_tick(const CbParams& K, int e, int t) {
+MRX_DEV bool end_tick(const CbParams& K, int e, int32_t* hd, int t) {
   if (HDR(CH_LATE) > 0) {  // DeliverBike appended to this very tick (transfer time 0)
     int p = HDR(CH_POOL_HEAD);
-    pool_exec_until(K, e, t, CB_NO_LAND, p, HDR(CH_POOL_TAIL));
-    pool_compact(K, e);
+    pool_exec_until(K, e, hd, t, CB_NO_LAND, p, HDR(CH_POOL_TAIL));
+    pool_compact(K, e, hd);
   }
   const bool frame_end = (t + 1) % K.res == 0;  // post_step :130-147
   if (frame_end) {
@@ -285,7 +286,7 @@ MRX_DEV int action_scope(const CbParams& K, int e, int s, int type, int t, int32
 }
 
 // _on_action_received :521-559 for the pending decision of station `s` at tick t
-MRX_DEV void apply_actions(const CbParams& K, int e, int t, int s, const int32_t* actions, int n_actions) {
+MRX_DEV void apply_actions(const CbParams& K, int e, int32_t* hd, int t, int s, const int32_t* actions, int n_actions) {
   // pop the decision from the tick's list
   K.decmask[(size_t)(s >> 5) * K.stride + e] &= ~(1u << (s & 31));
   K.decmask[(size_t)(K.mask_words + (s >> 5)) * K.stride + e] &= ~(1u << (s & 31));
@@ -313,23 +314,26 @@ MRX_DEV void apply_actions(const CbParams& K, int e, int t, int s, const int32_t
       if (tail_stale) continue;
       HDR(CH_LATE) += 1;
     }
-    pool_push(K, e, t + tt, t, frm, to, ex);
+    pool_push(K, e, hd, t + tt, t, frm, to, ex);
   }
 }
 
 // Env.step for one env.  dec[8], scope[scope_cap][2], met[3]
 MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_actions, int32_t* dec, int32_t* scope, int64_t* met,
                       uint8_t* done) {
+  int32_t hd[CH_WORDS];  // the env's header lives in registers for the whole step
+#pragma unroll
+  for (int w = 0; w < CH_WORDS; w++) hd[w] = GHDR(w);
   int flags = HDR(CH_FLAGS);
   int t = HDR(CH_TICK);
   bool finished = (flags & CFL_FINISHED) != 0;
   if (!finished) {
     if (flags & CFL_PENDING) {
-      apply_actions(K, e, t, HDR(CH_CUR_STATION), actions, n_actions);
+      apply_actions(K, e, hd, t, HDR(CH_CUR_STATION), actions, n_actions);
       flags &= ~CFL_PENDING;
     } else if (flags & CFL_FRESH) {
       flags &= ~CFL_FRESH;
-      begin_tick(K, e, t);
+      begin_tick(K, e, hd, t);
     }
     for (;;) {
       int type;
@@ -345,16 +349,18 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
         dec[5] = 1; dec[6] = 0; dec[7] = 0;
         break;
       }
-      if (end_tick(K, e, t)) {
+      if (end_tick(K, e, hd, t)) {
         flags |= CFL_FINISHED;
         finished = true;
         break;
       }
       t++;
-      begin_tick(K, e, t);
+      begin_tick(K, e, hd, t);
     }
     HDR(CH_TICK) = t;
     HDR(CH_FLAGS) = flags;
+#pragma unroll
+    for (int w = 0; w < CH_WORDS; w++) GHDR(w) = hd[w];
   }
   if (finished) {
     dec[0] = t; dec[1] = -1; dec[2] = -1; dec[3] = (t - K.start_tick) / K.res; dec[4] = 0; dec[5] = 0; dec[6] = 0; dec[7] = 0;
@@ -366,10 +372,10 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
 
 // Env.reset: citi_bike/business_engine.py:164-190, station.py:63-69
 MRX_DEV void reset_env(const CbParams& K, int e) {
-  for (int w = 0; w < CH_WORDS; w++) HDR(w) = 0;
-  HDR(CH_TICK) = K.start_tick;
-  HDR(CH_FLAGS) = CFL_FRESH;
-  HDR(CH_POOL_MINLAND) = CB_NO_LAND;
+  for (int w = 0; w < CH_WORDS; w++) GHDR(w) = 0;
+  GHDR(CH_TICK) = K.start_tick;
+  GHDR(CH_FLAGS) = CFL_FRESH;
+  GHDR(CH_POOL_MINLAND) = CB_NO_LAND;
   for (int w = 0; w < K.FW; w++) K.live[(size_t)w * K.stride + e] = 0;
   for (int s = 0; s < K.S; s++) { ST(LV_BIKES, s) = K.init_bikes[s]; ST(LV_MIN_BIKES, s) = K.init_bikes[s]; }
   for (int i = 0; i < K.ring_slots; i++) { K.ring_fi[(size_t)i * K.stride + e] = -1; K.twc_fi[(size_t)i * K.stride + e] = -1; }
@@ -393,9 +399,9 @@ MRX_DEV double query_elem(const CbParams& K, int node_type, const int32_t* ticks
   const int slot = fi % K.ring_slots;
   // while an env is paused at a decision its current frame is the live frame (core.py:345), which also evicts
   // whatever the slot held
-  const int flags = HDR(CH_FLAGS);
+  const int flags = GHDR(CH_FLAGS);
   const bool paused = (flags & (CFL_FRESH | CFL_FINISHED)) == 0;
-  const int t_cur = HDR(CH_TICK);
+  const int t_cur = GHDR(CH_TICK);
   const int cur_fi = (t_cur - K.start_tick) / K.res;
   const int32_t* frame;
   int t_frame;
@@ -458,6 +464,7 @@ MRX_DEV int random_policy_env(const CbParams& K, int e, const int32_t* dec, cons
 }
 
 #undef HDR
+#undef GHDR
 #undef ST
 #undef ADJ
 #undef POOL
