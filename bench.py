@@ -165,6 +165,27 @@ def bench_citi_bike(args):
         step_i += 1
     torch.cuda.synchronize(dev)
     step_kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    # the one exchange step of a sharded rollout: 32 steps of (decision, action, metrics, done) per env gathered to the
+    # learner rank over RCCL (maro_amd/cim/rollout.py::gather_to_learner); outside the timed env-step window
+    gather_ms = None
+    if dist is not None:
+        from maro_amd.cim.rollout import gather_to_learner
+        T = 32
+        traj = {"decisions": torch.zeros((T, n, 8), dtype=torch.int32, device=dev), "actions": torch.zeros((T, n, 1, 3), dtype=torch.int32, device=dev),
+                "metrics": torch.zeros((T, n, 3), dtype=torch.int64, device=dev), "done": torch.zeros((T, n), dtype=torch.uint8, device=dev)}
+        for k in range(T):
+            eng.random_policy(step_i, actions, n_actions, None)
+            traj["decisions"][k], traj["actions"][k] = eng.decisions, actions
+            eng.step(actions, n_actions)
+            traj["metrics"][k], traj["done"][k] = eng.metrics, eng.done
+            step_i += 1
+        sync_all()
+        tg = time.perf_counter()
+        out = gather_to_learner(traj, dst=0)
+        sync_all()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        if rank == 0:
+            assert out["decisions"].shape[1] == n * world
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(resolved), float(ticks_adv), float(n_done), float(status_bad)], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -186,7 +207,7 @@ def bench_citi_bike(args):
             "config": {"workload": f"citi_bike {topology}, {n} envs/GPU x {world} GPU, durations {durations}, resolution {res}, "
                                    f"device policy, stations snapshot slice {'off' if args.no_query else 'every step'}",
                        "envs_per_gpu": n, "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective)",
-                       "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
+                       "trajectory_gather_ms_32_steps": gather_ms, "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
             "roofline": {"bound": "hbm", "kernel": "mrx_k_cb_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": step_kernel_ms,
                          "algorithmic_bytes_per_env_step": b_step, "env_steps_per_launch": n,
