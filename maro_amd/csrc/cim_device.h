@@ -37,7 +37,7 @@ enum { PF_LOAD, PF_ACTION, PF_POST_STEP, PF_MT_LOAD, PF_ORDER_GEN, PF_DEPART_RET
 // serial-access topology tables: global (L2) by default, re-pointed at the LDS copy by the step kernel
 struct Tabs {
   const uint16_t *tgt_off, *tgt_port, *route_port, *v_route_base, *v_route_len, *leg_off, *leg_time, *rec_off, *v_cbase,
-      *route_cidx;  // 16-bit copies (cim_plan checks the ranges)
+      *route_cidx, *pair_src;  // 16-bit copies (cim_plan checks the ranges)
   const int32_t *er_delay, *fr_delay;
   const double *src_base, *src_noise, *er_base, *er_noise, *fr_base, *fr_noise;
 };
@@ -71,7 +71,7 @@ MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
   L.tab.v_route_base = K.h_v_route_base; L.tab.v_route_len = K.h_v_route_len;
   L.tab.leg_off = K.h_leg_off; L.tab.leg_time = K.h_leg_time;
   L.tab.er_delay = K.er_delay; L.tab.fr_delay = K.fr_delay; L.tab.rec_off = K.h_rec_off;
-  L.tab.v_cbase = K.h_v_cbase; L.tab.route_cidx = K.h_route_cidx;
+  L.tab.v_cbase = K.h_v_cbase; L.tab.route_cidx = K.h_route_cidx; L.tab.pair_src = K.h_pair_src;
   L.tab.src_base = K.src_base; L.tab.src_noise = K.src_noise; L.tab.er_base = K.er_base; L.tab.er_noise = K.er_noise;
   L.tab.fr_base = K.fr_base; L.tab.fr_noise = K.fr_noise;
   return L;
@@ -107,7 +107,7 @@ MRX_DEV void stage_tables(const CimParams& K, Lds& L, int32_t* c) {
   copy_in_async(c, K.ctab, K.ctab_words);
 #define MRX_HTAB(f) L.tab.f = (const uint16_t*)c + (K.h_##f - (const uint16_t*)K.ctab)
   MRX_HTAB(tgt_off); MRX_HTAB(tgt_port); MRX_HTAB(route_port); MRX_HTAB(v_route_base); MRX_HTAB(v_route_len);
-  MRX_HTAB(leg_off); MRX_HTAB(leg_time); MRX_HTAB(rec_off); MRX_HTAB(v_cbase); MRX_HTAB(route_cidx);
+  MRX_HTAB(leg_off); MRX_HTAB(leg_time); MRX_HTAB(rec_off); MRX_HTAB(v_cbase); MRX_HTAB(route_cidx); MRX_HTAB(pair_src);
 #undef MRX_HTAB
   L.tab.er_delay = c + (K.er_delay - K.ctab); L.tab.fr_delay = c + (K.fr_delay - K.ctab);
 #define MRX_DTAB(f) L.tab.f = (const double*)(c + ((const int32_t*)K.f - K.ctab))
@@ -711,7 +711,9 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
 
   // ---------------- B2. returns / discharges scheduled for this tick (all additive -> lane-parallel + LDS adds)
   const int slot = t % H;
-#define MRX_PAIR_SRC(k0, k) ((k0) == 0 ? pf.src[0] : (k0) == 64 ? pf.src[1] : (k0) == 128 ? pf.src[2] : K.pair_src[(k) < NT ? (k) : 0])
+  // source port of pair k from the staged table: no global load inside these loops (its s_waitcnt would land behind a
+  // control-flow merge as vmcnt(0), which on gfx950 also drains the snapshot stores issued just before)
+#define MRX_PAIR_SRC(k0, k) ((int)T.pair_src[(k)])
   for (int k0 = 0; k0 < NT; k0 += 64) {  // RETURN_FULL :499-522, one lane per (src, dst) pair
     const int k = k0 + lane;
     if (k < NT) {
@@ -1126,7 +1128,7 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
     g_priv[PH_CUR_VESSEL] = v2;
     g_priv[PH_OPNUM_LO] = (int32_t)(uint32_t)((unsigned long long)opnum & 0xffffffffull);
     g_priv[PH_OPNUM_HI] = (int32_t)(opnum >> 32);
-    if (status) K.status[env] |= status;
+    if (status) wave::global_or(&K.status[env], status);  // fire-and-forget: a read-modify-write would wait for every store in flight
   }
   return true;
 }
@@ -1162,8 +1164,10 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
     int f0v = 0, f0p = 0, f0q = 0, f0t = 0;
     if (actions) { f0v = actions[0]; f0p = actions[1]; f0q = actions[2]; f0t = actions[3]; }
     if (fast_step<OBS>(K, O, env, rows, n_act, f0v, f0p, f0q, f0t, dec_out, met_out, done_out)) {
-      prof.mark(13); prof.mark(14, 1);  // tools build: fast-path cycles and count
+#ifdef MRX_PROFILE_FAST_PATH  // tools build: fast-path cycles and count (its atomics perturb the full-path numbers)
+      prof.mark(13); prof.mark(14, 1);
       prof.flush();
+#endif
       return;
     }
     prof.mark(12);  // header round trip of the full path
@@ -1212,7 +1216,7 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
     const uint64_t pend_after = fresh ? 0ull : consume_decisions(K, pend, L.priv[PH_CUR_VESSEL], n_answered);
     const int tn = fresh ? t : t + 1;
     if (!pend_after && tn < K.T) {
-      tick_prefetch_static(K, pf, !PG);
+      if constexpr (!PG) tick_prefetch_static(K, pf, true);
       tick_prefetch<PG>(K, env, L, tn, pf);
     }
   }
@@ -1350,7 +1354,7 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
     L.priv[PH_ACCB_LO] = (int32_t)(uint32_t)((unsigned long long)acc_b & 0xffffffffull); L.priv[PH_ACCB_HI] = (int32_t)(acc_b >> 32);
     L.priv[PH_ACCS_LO] = (int32_t)(uint32_t)((unsigned long long)acc_s & 0xffffffffull); L.priv[PH_ACCS_HI] = (int32_t)(acc_s >> 32);
     K.tick[env] = t;
-    if (status) K.status[env] |= status;
+    if (status) wave::global_or(&K.status[env], status);  // fire-and-forget: a read-modify-write would wait for every store in flight
   }
   wave::sync();
   prof.mark(PF_OUTPUT);

@@ -265,6 +265,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
     put_h(&CimParams::h_leg_off, leg_off.data(), V + 1); put_h(&CimParams::h_leg_time, leg_time.data(), leg_time.size());
     put_h(&CimParams::h_rec_off, rec_off.data(), V + 1);
     put_h(&CimParams::h_v_cbase, v_cbase.data(), V); put_h(&CimParams::h_route_cidx, route_cidx.data(), NRP);
+    put_h(&CimParams::h_pair_src, pair_src.data(), NT);
     if (!fits) return fail("engine limit: a topology table entry (offsets, leg times) exceeds 65535");
   }
   B.resize((B.size() + 63) / 64 * 64, 0);

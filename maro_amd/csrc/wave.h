@@ -59,6 +59,9 @@ MRX_DEV void lds_dma_wait() {
 // fire-and-forget LDS add (ds_add_u32): concurrent lanes may target the same word
 MRX_DEV void lds_add(int32_t* p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// fire-and-forget OR into global memory (no return value, hence no s_waitcnt)
+MRX_DEV void global_or(int32_t* p, int v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // inclusive prefix sum over the lanes (lane i gets v_0 + ... + v_i)
 MRX_DEV int scan_incl_add(int v) {
   const int l = lane();
