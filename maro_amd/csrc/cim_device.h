@@ -644,12 +644,21 @@ MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {
   copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(K.mt + ((size_t)env * MTS_COUNT + MTS_ORDER) * MT_WORDS), MT_WORDS);
   TickPf pf = {};
   tick_prefetch_static(K, pf, true);
+  // the source ratio tables into LDS: a global load inside the tick loop would wait (vmcnt) for the previous tick's
+  // row stores every time
+  {
+    double* sb = (double*)(lds + K.g_srctab);
+    if (lane < K.P) { sb[lane] = K.src_base[lane]; sb[K.P + lane] = K.src_noise[lane]; }
+    L.tab.src_base = sb; L.tab.src_noise = sb + K.P;
+  }
   const int32_t* g_prop = K.order_prop + (size_t)env * K.T;
   const int D = K.T - K.start_tick;
   int idx_ord = MT_WORDS;  // the stream as reset_env seeded it
   wave::lds_dma_wait();
+  tick_prefetch_land(pf);  // no load may still be pending inside the tick loop (its wait would also drain the row stores)
   for (int t0 = 0; t0 < D; t0 += 64) {
-    const int mine = t0 + lane < D ? g_prop[K.start_tick + t0 + lane] : 0;  // 64 ticks of order_proportion per load
+    int mine = t0 + lane < D ? g_prop[K.start_tick + t0 + lane] : 0;  // 64 ticks of order_proportion per load
+    wave::touch(mine);  // wait for it HERE: inside the tick loop the same wait would also drain the previous tick's row stores
     const int n_here = D - t0 < 64 ? D - t0 : 64;
     for (int j = 0; j < n_here; j++) {  // wave-uniform
       gen_orders(K, L, (long long)wave::shfl(mine, j), idx_ord, pf);

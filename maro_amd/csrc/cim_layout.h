@@ -322,6 +322,8 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
     k.g_dtgt = g; g += dtgt_w;
     k.g_oq = g; g += NT + 1;
     k.g_srcn = g; g += P;
+    g = (g + 1) / 2 * 2;
+    k.g_srctab = g; g += 4 * P;  // source ratio tables (base, noise) as doubles
     k.g_ctab = (g + 3) / 4 * 4;
     k.lds_words_gen = (k.g_ctab + k.ctab_words + 3) / 4 * 4;
   }

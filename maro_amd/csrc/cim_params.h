@@ -48,7 +48,7 @@ struct CimParams {
   const uint32_t* fx_stops;  // [V][SMAX] (arrival << 8 | parking)
   const int32_t *fx_nstops, *fx_vperiod, *fx_order_prop;
   int pregen, NTP;  // order table: rows of NTP (= NT rounded up to 4) words, one per tick of the episode
-  int g_mt0, g_dsrc, g_dtgt, g_oq, g_srcn, g_ctab, lds_words_gen;  // LDS layout of the order-table kernel
+  int g_mt0, g_dsrc, g_dtgt, g_oq, g_srcn, g_srctab, g_ctab, lds_words_gen;  // LDS layout of the order-table kernel
   // ---- constant tables (device)
   const double *src_base, *src_noise, *tgt_base, *tgt_noise, *er_base, *er_noise, *fr_base, *fr_noise,
       *v_speed, *v_speed_noise, *v_dur, *v_dur_noise, *route_dist, *order_dist;
