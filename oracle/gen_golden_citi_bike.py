@@ -28,6 +28,10 @@ CASES = {
     # Supply decisions), extra_cost_mode target, transfer time N(3, 2) (zero / negative transfer times)
     "cb_tight_d1500_r10_all": ("toy.3s_tight", dict(durations=1500, snapshot_resolution=10), "all"),
     "cb_tight_d700_r3_half": ("toy.3s_tight", dict(durations=700, snapshot_resolution=3), "half"),
+    # the reference's larger toy topologies (4 and 5 stations: more neighbours for the filters to choose from)
+    "cb_toy4s4t_d1500_r10_all": ("toy.4s_4t", dict(durations=1500, snapshot_resolution=10), "all"),
+    "cb_toy5s6t_d1200_r5_half": ("toy.5s_6t", dict(durations=1200, snapshot_resolution=5, max_snapshots=40), "half"),
+    "cb_toy5s6t_d2000_r10_all": ("toy.5s_6t", dict(durations=2000, snapshot_resolution=10), "all"),
     "cb_tight_d800_r20_none": ("toy.3s_tight", dict(durations=800, snapshot_resolution=20, max_snapshots=6), "none"),
 }
 
