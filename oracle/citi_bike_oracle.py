@@ -172,7 +172,7 @@ class CitiBikeOracle:
             else:                   # TripsWindowFilter :88-163 (caches frames the first time it sees them)
                 fis = list(self.snap_order)
                 windows = min(f["windows"], len(fis))
-                fis = fis[-windows:] if windows > 0 else []
+                fis = fis[-windows:]   # NB `lst[-0:]` is the whole list: windows == 0 means every stored frame (:123-129)
                 trips: Dict[int, int] = {}
                 for i, fi in enumerate(fis):
                     if i == windows - 1 or fi not in self.window_cache:

@@ -32,6 +32,11 @@ CASES = {
     "cb_toy4s4t_d1500_r10_all": ("toy.4s_4t", dict(durations=1500, snapshot_resolution=10), "all"),
     "cb_toy5s6t_d1200_r5_half": ("toy.5s_6t", dict(durations=1200, snapshot_resolution=5, max_snapshots=40), "half"),
     "cb_toy5s6t_d2000_r10_all": ("toy.5s_6t", dict(durations=2000, snapshot_resolution=10), "all"),
+    # toy.5s_6t data with filters that really cut the neighbour list (distance 3 -> requirements 2 -> trip window 1 of 4
+    # frames), scope ratios 0.2 / 0.7, water marks 0.7 / 0.3; and a `windows: 0` trip-window filter (Python's lst[-0:])
+    "cb_filters_d1600_r10_all": ("toy.5s_filters", dict(durations=1600, snapshot_resolution=10), "all"),
+    "cb_filters_d1000_r3_half": ("toy.5s_filters", dict(durations=1000, snapshot_resolution=3, max_snapshots=7), "half"),
+    "cb_win0_d1400_r10_all": ("toy.5s_win0", dict(durations=1400, snapshot_resolution=10), "all"),
     "cb_tight_d800_r20_none": ("toy.3s_tight", dict(durations=800, snapshot_resolution=20, max_snapshots=6), "none"),
 }
 
