@@ -60,7 +60,9 @@ typedef struct mrx_cb_config {
   int32_t n_envs, device, start_tick, durations, snapshot_resolution;
   int32_t max_snapshots;      /* <=0 -> ceil(durations/resolution) */
   int32_t max_actions;        /* A: actions accepted per decision per step (>=1) */
-  int32_t delivery_capacity;  /* in-flight DeliverBike events per env; <=0 -> 4*S+4 */
+  int32_t delivery_capacity;  /* in-flight DeliverBike events per env; <=0 -> 4*S+4.  Size it as
+                                 S * (ceil(longest transfer time / decision resolution) + 2): overflow is flagged
+                                 (MRX_CB_ENV_DELIVERY_OVERFLOW) and the delivery dropped */
   int32_t transfer_times_cap; /* transfer times per env; <=0 -> S*(durations/resolution+1) */
 } mrx_cb_config;
 

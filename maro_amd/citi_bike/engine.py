@@ -38,6 +38,10 @@ class CitiBikeBatchEngine:
         self.start_tick, self.durations = int(start_tick), int(durations)
         self.max_tick = self.start_tick + self.durations
         self.snapshot_resolution = int(snapshot_resolution)
+        if not delivery_capacity:
+            # every decision tick can put one DeliverBike per station in flight for up to ~mean + 6 std ticks
+            d = self.data
+            delivery_capacity = d.n_stations * (int((d.time_mean + 6 * d.time_std) / max(d.resolution, 1)) + 2) + 4
         self._ts, self._keep_topo = topology_struct(self.data)
         self._cfg = MrxCbConfig(self.n_envs, dev_index, self.start_tick, self.durations, self.snapshot_resolution,
                                 int(max_snapshots or 0), self.max_actions, int(delivery_capacity), int(transfer_times_cap))

@@ -55,6 +55,8 @@ class CbEmuBackend:
     def __init__(self, data, n_envs=1, start_tick=0, durations=100, snapshot_resolution=1, max_snapshots=None, max_actions=1,
                  delivery_capacity=0, transfer_times_cap=0):
         self.data = data
+        if not delivery_capacity:   # same default as maro_amd.citi_bike.engine.CitiBikeBatchEngine
+            delivery_capacity = data.n_stations * (int((data.time_mean + 6 * data.time_std) / max(data.resolution, 1)) + 2) + 4
         self._ts, self._keep = topology_struct(data)
         self.cfg = MrxCbConfig(n_envs, 0, start_tick, durations, snapshot_resolution, max_snapshots or 0, max_actions,
                                delivery_capacity, transfer_times_cap)
