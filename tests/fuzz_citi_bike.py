@@ -35,9 +35,10 @@ def random_data(rng):
         scope_high_ratio=float(rng.choice([1, 0.85, 0.5])), extra_cost_mode=int(rng.randint(0, 2)), filters=filters)
 
 
-def run_case(case_seed):
+def run_case(case_seed, backend=None):
     from tests.cb_batch_check import run_batch_vs_oracle
     from tests.emu.cb_emu import CbEmuBackend
+    CbEmuBackend = backend or CbEmuBackend
     rng = np.random.RandomState(case_seed)
     data = random_data(rng)
     kw = dict(durations=int(rng.choice([150, 400])), snapshot_resolution=int(rng.choice([1, 4, 10])))

@@ -60,13 +60,14 @@ def random_conf(rng):
             "ports": ports, "routes": routes, "vessels": vessels}
 
 
-def run_case(case_seed, durations=70):
+def run_case(case_seed, durations=70, backend=None):
+    from tests.emu.emu import EmuBackend
     from tests.test_emu_synthetic import run_pair
     rng = np.random.RandomState(case_seed)
     conf = random_conf(rng)
     try:
         return run_pair(copy.deepcopy(conf), durations=durations, resolution=int(rng.choice([1, 1, 3])), seed=int(rng.randint(0, 10**6)),
-                        min_steps=0)
+                        min_steps=0, backend=backend or EmuBackend)
     except Exception:
         import json
         print("FAILING CASE seed", case_seed, json.dumps(conf)[:2000])
