@@ -270,6 +270,9 @@ def main():
     # The per-GPU batch is split into G independent groups, each with its own engine and HIP stream: a step kernel
     # ends with a tail of long (ticking) waves while most of the chip is already idle, and the next group's kernel
     # fills exactly that tail.  Envs never interact, so this is pure scheduling.
+    # the episode must outlast the run (finished envs would idle): ~0.45 ticks per env-step on 22p, so only very long runs
+    # (more than ~2300 steps in total) stretch the nominal 1120 ticks
+    sim_durations = max(args.durations, int(0.55 * (args.warmup + args.steps + min(args.steps, 100) + 10)) + 64)
     n, G = args.envs, max(1, args.groups)
     sizes = [n // G + (1 if g < n % G else 0) for g in range(G)]   # group sizes differ by at most one env
     offs = [sum(sizes[:g]) for g in range(G)]
@@ -277,7 +280,7 @@ def main():
     for g in range(G):
         ng = sizes[g]
         seeds = torch.arange(ng, dtype=torch.int64) + rank * n + offs[g] + 1
-        eng = CimBatchEngine(args.topology, ng, durations=args.durations, max_snapshots=args.ring, max_actions=1, device=dev, seeds=seeds)
+        eng = CimBatchEngine(args.topology, ng, durations=sim_durations, max_snapshots=args.ring, max_actions=1, device=dev, seeds=seeds)
         engines.append(eng)
         streams.append(torch.cuda.Stream(device=dev) if G > 1 else torch.cuda.current_stream(dev))
         bufs.append(dict(actions=torch.zeros((ng, 1, 4), dtype=torch.int32, device=dev),
@@ -436,7 +439,7 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
-            "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {args.durations}, "
+            "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {sim_durations}, "
                                    f"{'random legal agent' if args.policy == 'random' else 'per-port dueling DQN (bf16, greedy) + CIMEnvSampler state shaping'} on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step (' + args.obs + ')'}",
                        "envs_per_gpu": n, "groups_per_gpu": G, "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,
                        "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
