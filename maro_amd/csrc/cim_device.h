@@ -208,13 +208,13 @@ MRX_DEV double apply_noise(double value, double noise, double r) {
 
 // ------------------------------------------------------------------------------------------
 // coalesced wave copies (16 B per lane)
+// n_words is a multiple of 4 for every row the engine copies (cim_plan rounds FW / PW; MT_WORDS = 624)
 MRX_DEV void copy_words(int32_t* dst, const int32_t* src, int n_words) {
   const int l = wave::lane();
   const int n4 = n_words >> 2;
   const int4* s4 = (const int4*)src;
   int4* d4 = (int4*)dst;
   for (int i = l; i < n4; i += 64) d4[i] = s4[i];
-  for (int i = (n4 << 2) + l; i < n_words; i += 64) dst[i] = src[i];
 }
 
 // HBM -> LDS through LDS-DMA (all chunks in flight at once); rows are multiples of 4 words.
@@ -332,7 +332,8 @@ MRX_DEV void tick_prefetch_arrivals(const CimParams& K, int env, Lds& L, uint64_
     const bool ok = lane < Lr && sidx >= 0;
     pf.q[a] = g_rec[wave::readlane(r_rec, v) + krl * RL + (ok ? col : 0)];
     pf.key[a] = (int)K.stops[((size_t)env * V + v) * K.SMAX + (ok ? sidx : 0)];
-    const int xn = (pos + 1 + (lane < Lr ? lane : 0)) % Lr;
+    int xn = pos + 1 + (lane < Lr ? lane : 0);  // < 2 Lr: one conditional subtraction instead of an integer modulo
+    if (xn >= Lr) xn -= Lr;
     pf.kk[a] = K.pair_dense[(int)T.route_port[rb + pos] * P + (int)T.route_port[rb + xn]];
   }
 }
