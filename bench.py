@@ -280,7 +280,7 @@ def main():
     for g in range(G):
         ng = sizes[g]
         seeds = torch.arange(ng, dtype=torch.int64) + rank * n + offs[g] + 1
-        eng = CimBatchEngine(args.topology, ng, durations=sim_durations, max_snapshots=args.ring, max_actions=1, device=dev, seeds=seeds)
+        eng = CimBatchEngine(args.topology, ng, durations=sim_durations, max_snapshots=max(args.ring, 8) if args.policy == "dqn" else args.ring, max_actions=1, device=dev, seeds=seeds)  # dqn: the look-back window must fit the ring
         engines.append(eng)
         streams.append(torch.cuda.Stream(device=dev) if G > 1 else torch.cuda.current_stream(dev))
         bufs.append(dict(actions=torch.zeros((ng, 1, 4), dtype=torch.int32, device=dev),
@@ -296,14 +296,12 @@ def main():
     samplers, qnet = [], None
     if args.policy == "dqn":
         # the CIM RL example's rollout path entirely on the device — CIMEnvSampler state
-        # (look-back snapshot slices, maro_amd/cim/sampler.py), 22 per-port dueling DQNs (random-init weights, bf16 GEMMs),
-        # greedy action, env_sampler.py action translation (maro_amd/cim/policy.py)
-        from maro_amd.cim.policy import PerPortDuelingQNet, translate_actions
+        # (look-back snapshot slices), 22 per-port dueling DQNs (random-init weights, exact-f32 MFMA), greedy action and the
+        # env_sampler.py action translation, fused in mrx_cim_dqn_act (maro_amd/csrc/cim_dqn.h)
+        from maro_amd.cim.policy import ACTION_SPACE, FusedPerPortDQN, random_chains
         from maro_amd.cim.sampler import CimBatchSampler
-        samplers = [CimBatchSampler(e) for e in engines]
-        qnet = PerPortDuelingQNet(topo.n_ports, samplers[0].state_dim).to(dev)
-        for e, b in zip(engines, bufs):
-            b["vobs"] = e.set_observation([], ["remaining_space", "early_discharge"])[1]
+        chains = random_chains(topo.n_ports, CimBatchSampler(engines[0]).state_dim, len(ACTION_SPACE), seed=0)
+        qnet = [FusedPerPortDQN(e, chains) for e in engines]
     torch.cuda.synchronize(dev)
     # Env.reset for the whole batch (route unrolling, order proportion and — with the order table — every order of the
     # episode are generated on the device here, outside the timed step loop): reported next to the step rate
@@ -326,12 +324,9 @@ def main():
                 graphs[g].replay()  # policy -> step -> snapshot slices, captured once (hipGraph)
                 return
             if qnet is not None:
-                d = eng.decisions
-                q = qnet(samplers[g].state(d), d[:, 1])
-                translate_actions(q.argmax(dim=1), d, b["vobs"][:, 0], b["vobs"][:, 1], out=b["actions"])
-                b["n_actions"].copy_(d[:, 7])
+                qnet[g].act(b["actions"], b["n_actions"])     # mrx_cim_dqn_act: state gather + MFMA MLP + argmax + translation
                 if timing is None:
-                    b["counter"] += d[:, 7].sum()
+                    b["counter"] += b["n_actions"].sum()
             else:
                 eng.random_policy(-1 if args.graphs else i, b["actions"], b["n_actions"], b["counter"] if timing is None else None)
             if timing is not None:
@@ -440,7 +435,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {sim_durations}, "
-                                   f"{'random legal agent' if args.policy == 'random' else 'per-port dueling DQN (bf16, greedy) + CIMEnvSampler state shaping'} on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step (' + args.obs + ')'}",
+                                   f"{'random legal agent' if args.policy == 'random' else 'per-port dueling DQN (f32 MFMA, greedy) + CIMEnvSampler state shaping (mrx_cim_dqn_act)'} on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step (' + args.obs + ')'}",
                        "envs_per_gpu": n, "groups_per_gpu": G, "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,
                        "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
                        "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms,

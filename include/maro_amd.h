@@ -266,6 +266,50 @@ int mrx_cim_query(mrx_handle h, int node_type, const int32_t* d_ticks, int nt, i
 int mrx_cim_random_policy(mrx_handle h, const int32_t* d_decisions, int64_t step, int32_t* d_actions,
                           int32_t* d_n_actions, uint64_t* d_counter, void* stream);
 
+/*
+ * On-device action selection of the CIM RL example — for every env with a valid decision:
+ *   state   = CIMEnvSampler._get_global_and_agent_state_impl (examples/cim/rl/env_sampler.py:15-31):
+ *             ports[ticks : [port] + future_stop_list : port_attrs] over ticks max(0, tick - rt), rt in range(look_back - 1),
+ *             then vessels[tick : vessel : vessel_attrs], float32
+ *   q       = the deciding port's own network, MyQNet (examples/cim/rl/algorithms/dqn.py:13-52) built from FullyConnected
+ *             blocks (maro/rl/model/fc_block.py:72-133) in eval mode: BatchNorm folded into the linear maps, LeakyReLU
+ *             between layers, no activation on the top layers (head=True), q = adv - mean(adv) + v; exact-f32 MFMA
+ *   action  = argmax q (first maximum), translated as CIMEnvSampler._translate_to_env_action (env_sampler.py:33-64)
+ * The network is a chain of dense layers dims[0] -> ... -> dims[n_layers]; a dueling net folds its two heads into the last
+ * two layers (hidden layers side by side, top layers block-diagonal) so dims[n_layers] = n_actions + 1 (advantages, then V).
+ */
+enum { MRX_DQN_MAX_LAYERS = 8, MRX_DQN_MAX_WIDTH = 256, MRX_DQN_MAX_ACTIONS = 32 };
+typedef struct mrx_cim_dqn_model {
+  int32_t n_nets;                       /* one network per port: must equal n_ports */
+  int32_t n_layers;                     /* 1..MRX_DQN_MAX_LAYERS dense layers */
+  int32_t dims[MRX_DQN_MAX_LAYERS + 1]; /* dims[0] = state_dim; every width <= MRX_DQN_MAX_WIDTH */
+  int32_t dueling;                      /* 1: dims[n_layers] = n_actions + 1, 0: = n_actions */
+  int32_t n_actions;                    /* <= MRX_DQN_MAX_ACTIONS */
+  float negative_slope;                 /* LeakyReLU slope (torch default 0.01) applied after every layer but the last */
+  float epsilon;                        /* > 0: epsilon-greedy, counter-based on (env seed, tick, vessel); 0 = greedy */
+  int32_t look_back;                    /* state_shaping_conf["look_back"] (examples/cim/rl/config.py) */
+  int32_t n_port_attrs, port_attrs[8];  /* attribute ids as mrx_cim_attr_id */
+  int32_t n_vessel_attrs, vessel_attrs[8];
+  double action_space[MRX_DQN_MAX_ACTIONS]; /* examples/cim/rl/config.py:20-24: fraction per action index, negative = load */
+  const float* d_weights;               /* device: n_nets consecutive blobs of mrx_cim_dqn_net_floats() floats */
+} mrx_cim_dqn_model;
+
+/* Floats in one network's packed blob (weights padded and permuted for the MFMA operand loads, then biases); < 0 on error. */
+int64_t mrx_cim_dqn_net_floats(const mrx_cim_dqn_model* m);
+/* HOST helper: packs one network.  weights[l] row-major float32 [dims[l]][dims[l+1]] (= torch Linear.weight transposed),
+ * biases[l] float32 [dims[l+1]]; out = host buffer of mrx_cim_dqn_net_floats(m) floats (copy it to d_weights + net * that). */
+int mrx_cim_dqn_pack_net(const mrx_cim_dqn_model* m, const float* const* weights, const float* const* biases, float* out);
+/* Bytes of device scratch mrx_cim_dqn_act needs (env ids sorted by port + the tile table). */
+int64_t mrx_cim_dqn_scratch_bytes(mrx_handle h);
+/*
+ *   d_decisions  int32 [n_envs][8] as written by mrx_cim_step (Sequential mode)
+ *   d_actions    int32 [n_envs][A][4], d_n_actions int32 [n_envs]: ready for the next mrx_cim_step
+ *   d_q          float32 [n_envs][n_actions] or NULL; d_state float32 [n_envs][state_dim] or NULL; d_choice int32 [n_envs]
+ *                or NULL (the chosen action index) — rows of envs without a valid decision are left untouched
+ */
+int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_decisions, void* d_scratch, int32_t* d_actions,
+                    int32_t* d_n_actions, float* d_q, float* d_state, int32_t* d_choice, void* stream);
+
 /* Attribute name -> id and slot count for a node type; returns -1 for an unknown attribute
  * (reference raises BackendsInvalidAttributeException, frame.pyx:786-790). */
 int mrx_cim_attr_id(int node_type, const char* name);

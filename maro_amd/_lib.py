@@ -33,9 +33,20 @@ class MrxCimLayout(ctypes.Structure):
                 + [("workspace_bytes", ctypes.c_int64)])
 
 
+class MrxCimDqnModel(ctypes.Structure):
+    """ctypes mirror of ``struct mrx_cim_dqn_model`` (include/maro_amd.h)."""
+
+    _fields_ = [("n_nets", ctypes.c_int32), ("n_layers", ctypes.c_int32), ("dims", ctypes.c_int32 * 9),
+                ("dueling", ctypes.c_int32), ("n_actions", ctypes.c_int32), ("negative_slope", ctypes.c_float),
+                ("epsilon", ctypes.c_float), ("look_back", ctypes.c_int32), ("n_port_attrs", ctypes.c_int32),
+                ("port_attrs", ctypes.c_int32 * 8), ("n_vessel_attrs", ctypes.c_int32), ("vessel_attrs", ctypes.c_int32 * 8),
+                ("action_space", ctypes.c_double * 32), ("d_weights", ctypes.c_void_p)]
+
+
 EXPORTS = ("mrx_last_error", "mrx_version", "mrx_cim_workspace_bytes", "mrx_cim_create", "mrx_cim_destroy",
            "mrx_cim_get_layout", "mrx_cim_reset", "mrx_cim_step", "mrx_cim_step_joint", "mrx_cim_query", "mrx_cim_attr_id",
-           "mrx_cim_attr_slots", "mrx_cim_random_policy", "mrx_cim_set_observation",
+           "mrx_cim_attr_slots", "mrx_cim_random_policy", "mrx_cim_set_observation", "mrx_cim_dqn_net_floats",
+           "mrx_cim_dqn_pack_net", "mrx_cim_dqn_scratch_bytes", "mrx_cim_dqn_act",
            # include/maro_amd_citi_bike.h
            "mrx_cb_workspace_bytes", "mrx_cb_create", "mrx_cb_destroy", "mrx_cb_get_layout", "mrx_cb_reset", "mrx_cb_step",
            "mrx_cb_query", "mrx_cb_random_policy", "mrx_cb_attr_id", "mrx_cb_attr_slots")
@@ -83,6 +94,14 @@ def load() -> ctypes.CDLL:
     L.mrx_cim_random_policy.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     L.mrx_cim_set_observation.restype = i32
     L.mrx_cim_set_observation.argtypes = [vp, vp, i32, vp, i32, vp, vp]
+    L.mrx_cim_dqn_net_floats.restype = i64
+    L.mrx_cim_dqn_net_floats.argtypes = [vp]
+    L.mrx_cim_dqn_pack_net.restype = i32
+    L.mrx_cim_dqn_pack_net.argtypes = [vp, vp, vp, vp]
+    L.mrx_cim_dqn_scratch_bytes.restype = i64
+    L.mrx_cim_dqn_scratch_bytes.argtypes = [vp]
+    L.mrx_cim_dqn_act.restype = i32
+    L.mrx_cim_dqn_act.argtypes = [vp] * 10
     L.mrx_cim_attr_id.restype = i32
     L.mrx_cim_attr_id.argtypes = [i32, ctypes.c_char_p]
     L.mrx_cim_attr_slots.restype = i32

@@ -1409,6 +1409,21 @@ MRX_DEV int frame_word(const CimParams& K, int node_type, int a, int node, int s
   return (a == MA_FULL_ON_VESSELS ? K.f_fov : K.f_plans) + c;
 }
 
+// The frame a snapshot query for frame index `fi` of `env` reads, or nullptr when the ring does not hold it.
+// While an env is paused at a decision its current frame index is aliased to the live frame (the
+// reference's pre-decision take_snapshot, core.py:345), which also evicts whatever the slot held.
+MRX_DEV const int32_t* frame_of(const CimParams& K, int env, int fi) {
+  if (fi < 0) return nullptr;
+  const int s = fi % K.S;
+  const int32_t* hdr = K.priv + (size_t)env * K.PW;
+  const bool paused = (hdr[PH_FLAGS] & (FL_FRESH | FL_FINISHED)) == 0;
+  const int cur_fi = (hdr[PH_TICK] - K.start_tick) / K.resolution;
+  if (paused && fi == cur_fi) return K.live + (size_t)env * K.FW;
+  if (paused && s == cur_fi % K.S) return nullptr;
+  if (K.ring_fi[(size_t)env * K.S + s] == fi) return K.ring + ((size_t)env * K.S + s) * K.FW;
+  return nullptr;  // padding for missing frames :541-545
+}
+
 // one output element; `row` = env*nt*nn + ti*nn + ni, `col` in [0, row_slots)
 MRX_DEV double query_elem(const CimParams& K, int node_type, const int32_t* ticks, int nt, int ticks_per_env,
                           const int32_t* nodes, int nn, int nodes_per_env, const int32_t* attrs, int na, long long row, int col) {
@@ -1416,18 +1431,8 @@ MRX_DEV double query_elem(const CimParams& K, int node_type, const int32_t* tick
   const int ti = (int)((row / nn) % nt);
   const int env = (int)(row / ((long long)nn * nt));
   const int fi = ticks[(size_t)env * ticks_per_env + ti];  // ticks_per_env = row stride in int32 elements (0: one shared row)
-  if (fi < 0) return 0.0;
-  const int s = fi % K.S;
-  // While an env is paused at a decision its current frame index is aliased to the live frame (the
-  // reference's pre-decision take_snapshot, core.py:345), which also evicts whatever the slot held.
-  const int32_t* hdr = K.priv + (size_t)env * K.PW;
-  const bool paused = (hdr[PH_FLAGS] & (FL_FRESH | FL_FINISHED)) == 0;
-  const int cur_fi = (hdr[PH_TICK] - K.start_tick) / K.resolution;
-  const int32_t* frame;
-  if (paused && fi == cur_fi) frame = K.live + (size_t)env * K.FW;
-  else if (paused && s == cur_fi % K.S) return 0.0;
-  else if (K.ring_fi[(size_t)env * K.S + s] == fi) frame = K.ring + ((size_t)env * K.S + s) * K.FW;
-  else return 0.0;  // padding for missing frames :541-545
+  const int32_t* frame = frame_of(K, env, fi);
+  if (!frame) return 0.0;
   int a = 0, slot = col;
   for (int i = 0; i < na; i++) {
     const int ns = attr_slots(K, node_type, attrs[i]);

@@ -1,0 +1,262 @@
+// cim_dqn.h — on-device action selection for the CIM RL example: for every env that
+// pauses at a decision, build the CIMEnvSampler state from the snapshot ring (examples/cim/rl/env_sampler.py:15-31),
+// evaluate the deciding port's dueling DQN (examples/cim/rl/algorithms/dqn.py:13-84, maro/rl/model/fc_block.py:72-133),
+// take the greedy action and translate it into an env Action (env_sampler.py:33-64) — two launches, no host round trip.
+//
+// This is the one dense-contraction piece next to the simulator, so it runs on the matrix cores: exact-f32 MFMA
+// (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate — the reference networks are f32), envs binned by port so that a
+// workgroup multiplies a 64-env tile by ONE port's weights:
+//   mrx_k_cim_dqn_bin      one workgroup: counting sort of the deciding envs by port -> sorted env ids + tile table
+//   mrx_k_cim_dqn_forward  one workgroup (4 waves) per tile: state gather -> LDS, the dense chain layer by layer with the
+//                          activations kept in one LDS buffer (written back in place between barriers), weights streamed
+//                          from L2 as coalesced 16-B loads in the packed layout below, then argmax + action translation.
+// HIP only (not part of the CPU wave emulator build).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cim_device.h"
+
+namespace cim {
+
+enum { DQ_MAX_LAYERS = 8, DQ_MAX_WIDTH = 256, DQ_TILE = 64, DQ_LD = DQ_MAX_WIDTH + 4, DQ_MAX_TICKS = 16, DQ_MAX_NODES = 8 };
+
+struct DqnParams {
+  int n_layers, dueling, state_dim, look_back, n_nodes, n_pa, n_va, n_actions;
+  int pa[8], va[8];
+  int kpad[DQ_MAX_LAYERS], npad[DQ_MAX_LAYERS], n_out[DQ_MAX_LAYERS];
+  long long w_off[DQ_MAX_LAYERS], b_off[DQ_MAX_LAYERS], net_floats;
+  float slope, epsilon;
+  const float* weights;
+  double action_space[32];
+};
+
+// padded widths: a layer's outputs are split over the 4 waves in 16-column MFMA tiles
+__host__ __device__ inline int dq_npad(int n) { return n <= 16 ? 16 : n <= 32 ? 32 : (n + 63) / 64 * 64; }
+__host__ __device__ inline int dq_kpad(int k) { return (k + 15) / 16 * 16; }
+
+// Packed weight layout of one layer (K = kpad inputs, N = npad outputs, zero padded): 16 inputs x 1 output column are
+// stored as 4 groups g of 4 consecutive floats, Wp[((kb * N + n) * 4 + g) * 4 + s] = W[kb * 16 + g * 4 + s][n], so that
+// MFMA lane (n & 15, g) fetches its B operands of four consecutive k-steps with one 16-byte load and a wave reads
+// 1 KB contiguous.  The A operand uses the same k permutation (one ds_read_b128 per lane from the activation row).
+__host__ __device__ inline long long dq_w_index(int k, int n, int N) {
+  return (((long long)(k >> 4) * N + n) * 4 + ((k >> 2) & 3)) * 4 + (k & 3);
+}
+
+typedef float dq_f4 __attribute__((ext_vector_type(4)));
+
+template <int MT, int NT>
+__device__ __forceinline__ void dq_dense(float* X, const float* __restrict__ Wp, const float* __restrict__ bias, int Kpad, int Npad,
+                                         int m0, int nt0, int nt_step, bool act, float slope) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  dq_f4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) acc[mt][nt] = dq_f4{0.f, 0.f, 0.f, 0.f};
+  const int nkb = Kpad >> 4;
+#pragma unroll 2
+  for (int kb = 0; kb < nkb; kb++) {
+    dq_f4 a[MT], b[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+      b[nt] = *(const dq_f4*)(Wp + (((size_t)kb * Npad + (size_t)(nt0 + nt * nt_step) * 16 + r) * 4 + g) * 4);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) a[mt] = *(const dq_f4*)(X + ((m0 + mt) * 16 + r) * DQ_LD + kb * 16 + g * 4);
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+  }
+  __syncthreads();  // every wave has read the layer's input: the buffer may be overwritten with its output
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+    const int col = (nt0 + nt * nt_step) * 16 + r;
+    const float bv = bias[col];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float v = acc[mt][nt][i] + bv;  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + i
+        if (act) v = v > 0.f ? v : v * slope;
+        X[((m0 + mt) * 16 + g * 4 + i) * DQ_LD + col] = v;
+      }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void dq_layer(float* X, const float* Wp, const float* bias, int Kpad, int Npad, bool act, float slope) {
+  const int w = threadIdx.x >> 6;
+  switch (Npad) {
+    case 16: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, w, 0, 1, act, slope); break;
+    case 32: dq_dense<2, 1>(X, Wp, bias, Kpad, Npad, (w >> 1) * 2, w & 1, 1, act, slope); break;
+    case 64: dq_dense<4, 1>(X, Wp, bias, Kpad, Npad, 0, w, 4, act, slope); break;
+    case 128: dq_dense<4, 2>(X, Wp, bias, Kpad, Npad, 0, w, 4, act, slope); break;
+    case 192: dq_dense<4, 3>(X, Wp, bias, Kpad, Npad, 0, w, 4, act, slope); break;
+    default: dq_dense<4, 4>(X, Wp, bias, Kpad, Npad, 0, w, 4, act, slope); break;
+  }
+}
+
+__device__ __forceinline__ unsigned long long dq_mix64(unsigned long long seed, unsigned long long key) {
+  unsigned long long x = seed * 0x9E3779B97F4A7C15ull + key * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+}  // namespace cim
+
+// Counting sort of the envs with a pending decision by deciding port.  tiles int32 [max_tiles][3] = (port, first index
+// into sorted, rows <= 64); *n_tiles = tiles in use.  Also writes n_actions (1 for a deciding env, else 0).
+extern "C" __global__ void __launch_bounds__(1024)
+mrx_k_cim_dqn_bin(int n_envs, int P, const int32_t* __restrict__ decisions, int32_t* __restrict__ sorted, int32_t* __restrict__ tiles,
+                  int32_t* __restrict__ n_tiles, int32_t* __restrict__ n_actions) {
+  __shared__ int cnt[64], start[64], tbase[64];
+  const int t = threadIdx.x;
+  if (t < 64) cnt[t] = 0;
+  __syncthreads();
+  for (int e = t; e < n_envs; e += blockDim.x) {
+    const int32_t* d = decisions + (size_t)e * 8;
+    const bool valid = d[7] == 1 && (unsigned)d[1] < (unsigned)P;
+    if (valid) atomicAdd(&cnt[d[1]], 1);
+    n_actions[e] = valid ? 1 : 0;
+  }
+  __syncthreads();
+  if (t == 0) {
+    int s = 0, tb = 0;
+    for (int p = 0; p < P; p++) {
+      start[p] = s;
+      tbase[p] = tb;
+      s += cnt[p];
+      tb += (cnt[p] + cim::DQ_TILE - 1) / cim::DQ_TILE;
+    }
+    *n_tiles = tb;
+  }
+  __syncthreads();
+  if (t < P) {
+    const int nt = (cnt[t] + cim::DQ_TILE - 1) / cim::DQ_TILE;
+    for (int i = 0; i < nt; i++) {
+      int32_t* tr = tiles + (size_t)(tbase[t] + i) * 3;
+      tr[0] = t;
+      tr[1] = start[t] + i * cim::DQ_TILE;
+      tr[2] = min(cim::DQ_TILE, cnt[t] - i * cim::DQ_TILE);
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < n_envs; e += blockDim.x) {
+    const int32_t* d = decisions + (size_t)e * 8;
+    if (d[7] == 1 && (unsigned)d[1] < (unsigned)P) sorted[atomicAdd(&start[d[1]], 1)] = e;
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__ decisions, const int32_t* __restrict__ sorted,
+                      const int32_t* __restrict__ tiles, const int32_t* __restrict__ n_tiles, int32_t* __restrict__ actions,
+                      float* __restrict__ q_out, float* __restrict__ state_out, int32_t* __restrict__ choice_out) {
+  using namespace cim;
+  if ((int)blockIdx.x >= *n_tiles) return;
+  __shared__ __attribute__((aligned(16))) float X[DQ_TILE * DQ_LD];
+  __shared__ int r_env[DQ_TILE], r_node[DQ_TILE][DQ_MAX_NODES];
+  __shared__ const int32_t* r_frame[DQ_TILE][DQ_MAX_TICKS];
+  const int t = threadIdx.x;
+  const int port = tiles[(size_t)blockIdx.x * 3], first = tiles[(size_t)blockIdx.x * 3 + 1], rows = tiles[(size_t)blockIdx.x * 3 + 2];
+  const int n_ticks = M.look_back - 1;
+
+  // ---- per-row lookups: env, the node list [port] + future_stop_list, the frame of each look-back tick
+  if (t < DQ_TILE) {
+    const int env = t < rows ? sorted[first + t] : -1;
+    r_env[t] = env;
+    if (env >= 0) {
+      const int32_t* d = decisions + (size_t)env * 8;
+      const int32_t* now = frame_of(K, env, d[0]);  // snapshots[tick : vessel : future_stop_list]
+      r_node[t][0] = d[1];
+      for (int j = 1; j < M.n_nodes; j++) r_node[t][j] = now ? now[frame_word(K, 1, VA_FUTURE_STOP_LIST, d[2], j - 1)] : 0;
+    }
+  }
+  for (int i = t; i < DQ_TILE * n_ticks; i += blockDim.x) {
+    const int r = i / n_ticks, ti = i - r * n_ticks;
+    const int env = r < rows ? sorted[first + r] : -1;
+    const int32_t* f = nullptr;
+    if (env >= 0) {
+      const int tick = decisions[(size_t)env * 8];
+      f = frame_of(K, env, max(0, tick - ti));  // ticks = [max(0, tick - rt) for rt in range(look_back - 1)]
+    }
+    r_frame[r][ti] = f;
+  }
+  __syncthreads();
+
+  // ---- state rows (float32, as FullyConnected.forward's x.float()): ports[ticks : nodes : port_attrs] then vessels[tick : vessel : vessel_attrs]
+  const int kp0 = M.kpad[0], per_tick = M.n_nodes * M.n_pa, n_port_feats = n_ticks * per_tick;
+  for (int i = t; i < DQ_TILE * kp0; i += blockDim.x) {
+    const int r = i / kp0, c = i - r * kp0;
+    float v = 0.f;
+    const int env = r_env[r];
+    if (env >= 0 && c < M.state_dim) {
+      if (c < n_port_feats) {
+        const int ti = c / per_tick, rem = c - ti * per_tick, ni = rem / M.n_pa, ai = rem - ni * M.n_pa;
+        const int32_t* f = r_frame[r][ti];
+        const int node = r_node[r][ni], a = M.pa[ai];
+        if (f && (unsigned)node < (unsigned)K.P) {
+          const int32_t raw = f[K.f_ports + a * K.P + node];
+          v = a == PA_TRANSFER_COST ? bits_f(raw) : (float)raw;
+        }
+      } else {
+        const int32_t* f = r_frame[r][0];
+        const int vessel = decisions[(size_t)env * 8 + 2];
+        if (f) v = (float)f[frame_word(K, 1, M.va[c - n_port_feats], vessel, 0)];
+      }
+      if (state_out) state_out[(size_t)env * M.state_dim + c] = v;
+    }
+    X[r * DQ_LD + c] = v;
+  }
+  __syncthreads();
+
+  // ---- the dense chain of this port's network
+  const float* net = M.weights + (size_t)port * M.net_floats;
+  for (int l = 0; l < M.n_layers; l++)
+    dq_layer(X, net + M.w_off[l], net + M.b_off[l], M.kpad[l], M.npad[l], l + 1 < M.n_layers, M.slope);
+
+  // ---- q = adv - mean(adv) + v (dqn.py:48-52), greedy action, env_sampler.py:33-64 translation
+  if (t < rows) {
+    const int env = r_env[t];
+    const float* y = X + t * DQ_LD;
+    const int A = M.n_actions;
+    float mean = 0.f;
+    if (M.dueling) {
+      for (int a = 0; a < A; a++) mean += y[a];
+      mean = mean / (float)A - y[A];
+    }
+    int best = 0;
+    float bq = y[0] - mean;
+    for (int a = 0; a < A; a++) {
+      const float q = y[a] - mean;
+      if (q_out) q_out[(size_t)env * A + a] = q;
+      if (q > bq) { bq = q; best = a; }
+    }
+    const int32_t* d = decisions + (size_t)env * 8;
+    if (M.epsilon > 0.f) {  // counter-based epsilon-greedy keyed on (env seed, tick, vessel)
+      const unsigned long long x = dq_mix64((unsigned long long)K.seed[env], (((unsigned long long)(unsigned)d[0] << 8) | (unsigned)d[2]) + 0x200000000ull);
+      if ((double)(x >> 11) * (1.0 / 9007199254740992.0) < (double)M.epsilon) best = (int)(dq_mix64(x, 1) % (unsigned long long)A);
+    }
+    if (choice_out) choice_out[env] = best;
+    const int32_t* live = K.live + (size_t)env * K.FW;  // the decision's frame is the live frame
+    const double percent = fabs(M.action_space[best]);
+    const double load = (double)d[3], discharge = (double)d[4];
+    const bool is_load = 2 * best < A;  // model_action < len(action_space) / 2
+    double qty;
+    if (is_load) {
+      qty = fmin(rint(percent * load), (double)live[frame_word(K, 1, VA_REMAINING_SPACE, d[2], 0)]);
+    } else {
+      const double early = (double)live[frame_word(K, 1, VA_EARLY_DISCHARGE, d[2], 0)];
+      const double plan = percent * (discharge + early) - early;
+      qty = plan > 0 ? rint(plan) : rint(percent * discharge);
+    }
+    int32_t* a = actions + (size_t)env * K.max_actions * 4;
+    a[0] = d[2];
+    a[1] = d[1];
+    a[2] = (int32_t)qty;
+    a[3] = is_load ? MRX_ACTION_LOAD : MRX_ACTION_DISCHARGE;
+  }
+}

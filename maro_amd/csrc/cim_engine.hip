@@ -73,6 +73,8 @@ MRX_STEP_KERNEL(mrx_k_cim_step_obs, false, true, 2)      // + fused observation 
 MRX_STEP_KERNEL(mrx_k_cim_step_tab_obs, true, true, 2)
 #undef MRX_STEP_KERNEL
 
+#include "cim_dqn.h"
+
 struct AttrList { int n; int32_t id[16]; };
 
 extern "C" __global__ void __launch_bounds__(256)
@@ -365,6 +367,107 @@ int mrx_cim_query(mrx_handle h, int node_type, const int32_t* d_ticks, int nt, i
   for (int i = 0; i < 16; i++) al.id[i] = i < na ? attrs[i] : 0;
   hipLaunchKernelGGL(mrx_k_cim_query, dim3((unsigned)blocks), dim3(nn * row_slots >= 192 ? 256 : (nn * row_slots >= 96 ? 128 : 64)), 0, (hipStream_t)stream, K, node_type, d_ticks, nt,
                      ticks_per_env, d_nodes, nn, nodes_per_env, al, row_slots, total, d_out);
+  HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+// ---- DQN action selection (cim_dqn.h)
+static int dqn_plan(const mrx_cim_dqn_model* m, cim::DqnParams* D) {
+  using namespace cim;
+  if (!m) return set_err(MRX_ERR_INVALID_ARG, "null model");
+  if (m->n_layers < 1 || m->n_layers > MRX_DQN_MAX_LAYERS) return set_err(MRX_ERR_INVALID_ARG, "n_layers out of range");
+  if (m->n_actions < 1 || m->n_actions > MRX_DQN_MAX_ACTIONS) return set_err(MRX_ERR_INVALID_ARG, "n_actions out of range");
+  if (m->dims[m->n_layers] != m->n_actions + (m->dueling ? 1 : 0)) return set_err(MRX_ERR_INVALID_ARG, "last width must be n_actions (+ 1 when dueling)");
+  memset(D, 0, sizeof(*D));
+  D->n_layers = m->n_layers;
+  D->dueling = m->dueling ? 1 : 0;
+  D->state_dim = m->dims[0];
+  D->n_actions = m->n_actions;
+  D->slope = m->negative_slope;
+  D->epsilon = m->epsilon;
+  long long off = 0;
+  for (int l = 0; l < m->n_layers; l++) {
+    if (m->dims[l] < 1 || m->dims[l] > MRX_DQN_MAX_WIDTH || m->dims[l + 1] < 1 || m->dims[l + 1] > MRX_DQN_MAX_WIDTH)
+      return set_err(MRX_ERR_UNSUPPORTED, "layer widths must be in 1..256");
+    D->kpad[l] = l == 0 ? dq_kpad(m->dims[0]) : D->npad[l - 1];
+    D->npad[l] = dq_npad(m->dims[l + 1]);
+    D->n_out[l] = m->dims[l + 1];
+    D->w_off[l] = off;
+    off += (long long)D->kpad[l] * D->npad[l];
+    D->b_off[l] = off;
+    off += D->npad[l];
+  }
+  D->net_floats = off;
+  for (int a = 0; a < m->n_actions; a++) D->action_space[a] = m->action_space[a];
+  return MRX_OK;
+}
+
+int64_t mrx_cim_dqn_net_floats(const mrx_cim_dqn_model* m) {
+  cim::DqnParams D;
+  const int rc = dqn_plan(m, &D);
+  return rc != MRX_OK ? rc : D.net_floats;
+}
+
+int mrx_cim_dqn_pack_net(const mrx_cim_dqn_model* m, const float* const* weights, const float* const* biases, float* out) {
+  cim::DqnParams D;
+  const int rc = dqn_plan(m, &D);
+  if (rc != MRX_OK) return rc;
+  if (!weights || !biases || !out) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
+  memset(out, 0, sizeof(float) * (size_t)D.net_floats);
+  for (int l = 0; l < m->n_layers; l++) {
+    const int K = m->dims[l], N = m->dims[l + 1];
+    for (int k = 0; k < K; k++)
+      for (int n = 0; n < N; n++) out[D.w_off[l] + cim::dq_w_index(k, n, D.npad[l])] = weights[l][(size_t)k * N + n];
+    for (int n = 0; n < N; n++) out[D.b_off[l] + n] = biases[l][n];
+  }
+  return MRX_OK;
+}
+
+static long long dqn_max_tiles(const CimParams& K) { return (long long)K.n_envs / cim::DQ_TILE + K.P + 1; }
+
+int64_t mrx_cim_dqn_scratch_bytes(mrx_handle h) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  const CimParams& K = h->plan.kp;
+  return 4 * ((long long)K.n_envs + 3 * dqn_max_tiles(K) + 4);
+}
+
+int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_decisions, void* d_scratch, int32_t* d_actions,
+                    int32_t* d_n_actions, float* d_q, float* d_state, int32_t* d_choice, void* stream) {
+  using namespace cim;
+  if (!h || !m || !d_decisions || !d_scratch || !d_actions || !d_n_actions || !m->d_weights) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
+  const CimParams& K = h->plan.kp;
+  if (K.decision_mode != 0) return set_err(MRX_ERR_INVALID_ARG, "mrx_cim_dqn_act answers Sequential-mode decisions");
+  DqnParams D;
+  int rc = dqn_plan(m, &D);
+  if (rc != MRX_OK) return rc;
+  if (m->n_nets != K.P) return set_err(MRX_ERR_INVALID_ARG, "one network per port: n_nets must equal n_ports");
+  if (m->look_back < 2 || m->look_back - 1 > DQ_MAX_TICKS) return set_err(MRX_ERR_INVALID_ARG, "look_back out of range");
+  if (m->n_port_attrs < 0 || m->n_port_attrs > 8 || m->n_vessel_attrs < 0 || m->n_vessel_attrs > 8) return set_err(MRX_ERR_INVALID_ARG, "at most 8 attributes each");
+  if (1 + K.future_n > DQ_MAX_NODES) return set_err(MRX_ERR_UNSUPPORTED, "future_stop_number too large");
+  D.look_back = m->look_back;
+  D.n_nodes = 1 + K.future_n;
+  D.n_pa = m->n_port_attrs;
+  D.n_va = m->n_vessel_attrs;
+  for (int i = 0; i < D.n_pa; i++) {
+    if (host_attr_slots(K, 0, m->port_attrs[i]) != 1) return set_err(MRX_ERR_INVALID_ARG, "unknown port attribute id");
+    D.pa[i] = m->port_attrs[i];
+  }
+  for (int i = 0; i < D.n_va; i++) {
+    if (host_attr_slots(K, 1, m->vessel_attrs[i]) != 1) return set_err(MRX_ERR_INVALID_ARG, "vessel attributes must be single-slot");
+    D.va[i] = m->vessel_attrs[i];
+  }
+  if (D.state_dim != (D.look_back - 1) * D.n_nodes * D.n_pa + D.n_va)
+    return set_err(MRX_ERR_INVALID_ARG, "dims[0] must be (look_back - 1) * (1 + future_stop_number) * n_port_attrs + n_vessel_attrs");
+  D.weights = m->d_weights;
+  rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  int32_t* sorted = (int32_t*)d_scratch;
+  int32_t* tiles = sorted + K.n_envs;
+  const long long max_tiles = dqn_max_tiles(K);
+  int32_t* n_tiles = tiles + 3 * max_tiles;
+  hipLaunchKernelGGL(mrx_k_cim_dqn_bin, dim3(1), dim3(1024), 0, (hipStream_t)stream, K.n_envs, K.P, d_decisions, sorted, tiles, n_tiles, d_n_actions);
+  hipLaunchKernelGGL(mrx_k_cim_dqn_forward, dim3((unsigned)max_tiles), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, sorted, tiles,
+                     n_tiles, d_actions, d_q, d_state, d_choice);
   HIP_TRY(hipGetLastError());
   return MRX_OK;
 }

@@ -1,9 +1,15 @@
-"""Device-side policy pieces of the CIM RL example (maro_amd/cim/policy.py) against plain Python restatements of
-examples/cim/rl/env_sampler.py:33-64 and algorithms/dqn.py:13-84."""
+"""Device-side policy pieces of the CIM RL example (maro_amd/cim/policy.py): the action translation against a plain Python
+restatement of examples/cim/rl/env_sampler.py:33-64, and the BatchNorm-folded dense chain against q-values produced by the
+reference's own MyQNet (tests/golden/dqn_myqnet_small.npz, oracle/gen_golden_dqn.py)."""
+import os
+from collections import OrderedDict
+
 import numpy as np
 import torch
 
-from maro_amd.cim.policy import ACTION_SPACE, PerPortDuelingQNet, translate_actions
+from maro_amd.cim.policy import ACTION_SPACE, PerPortDuelingQNet, dueling_chain, fold_fully_connected, translate_actions
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "dqn_myqnet_small.npz")
 
 
 def ref_translate(model_action, load, discharge, vsl_space, early_discharge):
@@ -31,18 +37,66 @@ def test_translate_actions_matches_env_sampler():
         assert got[i, 0].tolist() == [dec[i, 2], dec[i, 1], q, ty], (i, ma[i], got[i], q, ty)
 
 
+def fc_like_reference(dims, top=None, head_act=False):
+    """A torch module with the structure (and state_dict keys) of maro.rl's FullyConnected (fc_block.py:72-133)."""
+    def layer(i, o, act):
+        mods = [("batch_norm", torch.nn.BatchNorm1d(i)), ("linear", torch.nn.Linear(i, o))]
+        if act:
+            mods.append(("activation", torch.nn.LeakyReLU()))
+        return torch.nn.Sequential(OrderedDict(mods))
+
+    layers = [layer(i, o, True) for i, o in zip(dims, dims[1:])]
+    if top is not None:
+        layers.append(layer(dims[-1], top, head_act))
+    m = torch.nn.Module()
+    m._net = torch.nn.Sequential(*layers)
+    return m
+
+
+def load_golden_net():
+    g = np.load(GOLDEN)
+    sd, A, hh = int(g["state_dim"]), int(g["action_num"]), int(g["head_hidden"])
+    hidden = [int(h) for h in g["hidden"]]
+    net = torch.nn.Module()
+    net._fc = fc_like_reference([sd] + hidden)
+    net._q = fc_like_reference([hidden[-1], hh], top=A)
+    net._v = fc_like_reference([hidden[-1], hh], top=1)
+    net.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd:")})
+    net.eval()
+    return g, net, A
+
+
+def test_folded_chain_reproduces_reference_myqnet():
+    g, net, A = load_golden_net()
+    chain = dueling_chain(fold_fully_connected(net._fc), fold_fully_connected(net._q), fold_fully_connected(net._v))
+    assert [w.shape for w, _ in chain] == [(45, 40), (40, 24), (24, 12), (12, 40), (40, A + 1)]
+    x = g["states"].astype(np.float64)
+    for i, (w, b) in enumerate(chain):   # numpy float64 evaluation of the folded chain
+        x = x @ w.astype(np.float64) + b
+        if i + 1 < len(chain):
+            x = np.where(x > 0, x, 0.01 * x)
+    q = x[:, :A] - x[:, :A].mean(axis=1, keepdims=True) + x[:, A:]
+    # the reference evaluates BatchNorm and Linear separately in float32; folding reorders the arithmetic
+    np.testing.assert_allclose(q, g["q"], rtol=2e-4, atol=2e-4)
+    assert (q.argmax(axis=1) == g["greedy"]).all()
+    # the torch float32 restatement used as the GPU tests' reference agrees as well
+    tq = PerPortDuelingQNet([chain, chain], A)(torch.from_numpy(g["states"]), torch.zeros(64, dtype=torch.int64)).numpy()
+    np.testing.assert_allclose(tq, g["q"], rtol=2e-4, atol=2e-4)
+
+
 def test_per_port_qnet_selects_each_ports_network():
-    net = PerPortDuelingQNet(n_ports=5, state_dim=19, action_num=21, hidden=(32, 16), head_hidden=8, dtype=torch.float32, seed=1)
+    from maro_amd.cim.policy import random_chains
+    chains = random_chains(5, 19, 21, hidden=(32, 16), head_hidden=8, seed=1)
+    net = PerPortDuelingQNet(chains, 21)
     x = torch.randn(40, 19)
     port = torch.arange(40) % 5
     q = net(x, port)
     assert q.shape == (40, 21)
-    act = torch.nn.functional.leaky_relu
     for i in (0, 7, 39):   # one env at a time through its own port's weights
-        p = int(port[i])
-        h = x[i:i + 1]
-        for k in range(0, len(net.trunk), 2):
-            h = act(h @ net.trunk[k][p] + net.trunk[k + 1][p])
-        qq = act(act(h @ net.q1[p] + net.q1b[p]) @ net.q2[p] + net.q2b[p])
-        vv = act(h @ net.v1[p] + net.v1b[p]) @ net.v2[p] + net.v2b[p]
-        assert torch.allclose(q[i], (qq - qq.mean(dim=1, keepdim=True) + vv)[0], atol=1e-5)   # fp32 GEMM reduction order only
+        h = x[i:i + 1].numpy().astype(np.float64)
+        for k, (w, b) in enumerate(chains[int(port[i])]):
+            h = h @ w + b
+            if k + 1 < len(chains[0]):
+                h = np.where(h > 0, h, 0.01 * h)
+        ref = h[:, :21] - h[:, :21].mean(axis=1, keepdims=True) + h[:, 21:]
+        np.testing.assert_allclose(q[i].numpy(), ref[0], rtol=1e-4, atol=1e-4)
