@@ -299,7 +299,8 @@ int64_t mrx_cim_dqn_net_floats(const mrx_cim_dqn_model* m);
 /* HOST helper: packs one network.  weights[l] row-major float32 [dims[l]][dims[l+1]] (= torch Linear.weight transposed),
  * biases[l] float32 [dims[l+1]]; out = host buffer of mrx_cim_dqn_net_floats(m) floats (copy it to d_weights + net * that). */
 int mrx_cim_dqn_pack_net(const mrx_cim_dqn_model* m, const float* const* weights, const float* const* biases, float* out);
-/* Bytes of device scratch mrx_cim_dqn_act needs (env ids sorted by port + the tile table). */
+/* Bytes of device scratch mrx_cim_dqn_act needs (per-port env lists and their counters).  The caller zeroes it ONCE after
+ * allocation; every call leaves the counters zero again.  One scratch per handle and stream. */
 int64_t mrx_cim_dqn_scratch_bytes(mrx_handle h);
 /*
  *   d_decisions  int32 [n_envs][8] as written by mrx_cim_step (Sequential mode)

@@ -1413,15 +1413,16 @@ MRX_DEV int frame_word(const CimParams& K, int node_type, int a, int node, int s
 // While an env is paused at a decision its current frame index is aliased to the live frame (the
 // reference's pre-decision take_snapshot, core.py:345), which also evicts whatever the slot held.
 MRX_DEV const int32_t* frame_of(const CimParams& K, int env, int fi) {
-  if (fi < 0) return nullptr;
-  const int s = fi % K.S;
+  const int s = (fi < 0 ? 0 : fi) % K.S;
   const int32_t* hdr = K.priv + (size_t)env * K.PW;
-  const bool paused = (hdr[PH_FLAGS] & (FL_FRESH | FL_FINISHED)) == 0;
-  const int cur_fi = (hdr[PH_TICK] - K.start_tick) / K.resolution;
-  if (paused && fi == cur_fi) return K.live + (size_t)env * K.FW;
-  if (paused && s == cur_fi % K.S) return nullptr;
-  if (K.ring_fi[(size_t)env * K.S + s] == fi) return K.ring + ((size_t)env * K.S + s) * K.FW;
-  return nullptr;  // padding for missing frames :541-545
+  // three independent loads, then selects: no dependent chain of memory latencies
+  const int flags = hdr[PH_FLAGS], tick = hdr[PH_TICK], held = K.ring_fi[(size_t)env * K.S + s];
+  const bool paused = (flags & (FL_FRESH | FL_FINISHED)) == 0;
+  const int cur_fi = (tick - K.start_tick) / K.resolution;
+  const int32_t* frame = nullptr;  // padding for missing frames :541-545
+  if (held == fi) frame = K.ring + ((size_t)env * K.S + s) * K.FW;
+  if (paused && s == cur_fi % K.S) frame = fi == cur_fi ? K.live + (size_t)env * K.FW : nullptr;
+  return fi < 0 ? nullptr : frame;
 }
 
 // one output element; `row` = env*nt*nn + ti*nn + ni, `col` in [0, row_slots)

@@ -5,9 +5,9 @@
 //
 // This is the one dense-contraction piece next to the simulator, so it runs on the matrix cores: exact-f32 MFMA
 // (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate — the reference networks are f32), envs binned by port so that a
-// workgroup multiplies a 64-env tile by ONE port's weights:
-//   mrx_k_cim_dqn_bin      one workgroup: counting sort of the deciding envs by port -> sorted env ids + tile table
-//   mrx_k_cim_dqn_forward  one workgroup (4 waves) per tile: state gather -> LDS, the dense chain layer by layer with the
+// workgroup multiplies a tile of envs by ONE port's weights:
+//   mrx_k_cim_dqn_bin      the deciding envs appended to their port's list (LDS histogram + one global atomic per port and workgroup)
+//   mrx_k_cim_dqn_forward  one workgroup (4 waves) per 32-env tile of one port's list: state gather -> LDS, the dense chain layer by layer with the
 //                          activations kept in one LDS buffer (written back in place between barriers), weights streamed
 //                          from L2 as coalesced 16-B loads in the packed layout below, then argmax + action translation.
 // HIP only (not part of the CPU wave emulator build).
@@ -18,7 +18,7 @@
 
 namespace cim {
 
-enum { DQ_MAX_LAYERS = 8, DQ_MAX_WIDTH = 256, DQ_TILE = 64, DQ_LD = DQ_MAX_WIDTH + 4, DQ_MAX_TICKS = 16, DQ_MAX_NODES = 8 };
+enum { DQ_MAX_LAYERS = 8, DQ_MAX_WIDTH = 256, DQ_TILE = 32, DQ_LD = DQ_MAX_WIDTH + 4, DQ_MAX_TICKS = 16, DQ_MAX_NODES = 8, DQ_PF = 4 };
 
 struct DqnParams {
   int n_layers, dueling, state_dim, look_back, n_nodes, n_pa, n_va, n_actions;
@@ -46,55 +46,92 @@ typedef float dq_f4 __attribute__((ext_vector_type(4)));
 
 template <int MT, int NT>
 __device__ __forceinline__ void dq_dense(float* X, const float* __restrict__ Wp, const float* __restrict__ bias, int Kpad, int Npad,
-                                         int m0, int nt0, int nt_step, bool act, float slope) {
+                                         int m0, int nt0, int nt_step, bool idle, bool act, float slope) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   dq_f4 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; mt++)
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) acc[mt][nt] = dq_f4{0.f, 0.f, 0.f, 0.f};
-  const int nkb = Kpad >> 4;
-#pragma unroll 2
-  for (int kb = 0; kb < nkb; kb++) {
-    dq_f4 a[MT], b[NT];
+  const int nkb = idle ? 0 : Kpad >> 4;
+  // B operands (weights, L2) are fetched DQ_PF k-blocks ahead into a rotating register buffer: a narrow layer gives a wave
+  // only a few MFMAs per k-block, far less than the L2 latency
+  dq_f4 bq[DQ_PF][NT];
+  const float* wlane = Wp + ((size_t)nt0 * 16 + r) * 16 + g * 4;
+  const float* xlane = X + (m0 * 16 + r) * DQ_LD + g * 4;
+  const int nfull = nkb / DQ_PF, rem = nkb - nfull * DQ_PF;
+  if (nkb > 0) {
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++)
-      b[nt] = *(const dq_f4*)(Wp + (((size_t)kb * Npad + (size_t)(nt0 + nt * nt_step) * 16 + r) * 4 + g) * 4);
+    for (int p = 0; p < DQ_PF; p++)
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) a[mt] = *(const dq_f4*)(X + ((m0 + mt) * 16 + r) * DQ_LD + kb * 16 + g * 4);
+      for (int nt = 0; nt < NT; nt++) bq[p][nt] = *(const dq_f4*)(wlane + ((size_t)min(p, nkb - 1) * Npad + (size_t)nt * nt_step * 16) * 16);
+  }
+  // Static register slots (a rotating buffer's moves would wait for the loads they move) and no control flow inside the
+  // loop (a branch merge makes the compiler drain every outstanding load): slot p is refilled with the block DQ_PF ahead
+  // right after it is consumed; past the end the last block is re-fetched and never used.
+  for (int i = 0; i < nfull; i++) {
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+    for (int p = 0; p < DQ_PF; p++) {
+      const int kb = i * DQ_PF + p;
+      dq_f4 a[MT], b[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        b[nt] = bq[p][nt];
+        bq[p][nt] = *(const dq_f4*)(wlane + ((size_t)min(kb + DQ_PF, nkb - 1) * Npad + (size_t)nt * nt_step * 16) * 16);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) a[mt] = *(const dq_f4*)(xlane + mt * 16 * DQ_LD + kb * 16);
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p + 1 < DQ_PF; p++)
+    if (p < rem) {  // the tail blocks are already in their slots
+      const int kb = nfull * DQ_PF + p;
+      dq_f4 a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) a[mt] = *(const dq_f4*)(xlane + mt * 16 * DQ_LD + kb * 16);
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], bq[p][nt][s], acc[mt][nt], 0, 0, 0);
+    }
+  __syncthreads();  // every wave has read the layer's input: the buffer may be overwritten with its output
+  if (!idle) {
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+      const int col = (nt0 + nt * nt_step) * 16 + r;
+      const float bv = bias[col];
 #pragma unroll
       for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
-  }
-  __syncthreads();  // every wave has read the layer's input: the buffer may be overwritten with its output
-#pragma unroll
-  for (int nt = 0; nt < NT; nt++) {
-    const int col = (nt0 + nt * nt_step) * 16 + r;
-    const float bv = bias[col];
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        float v = acc[mt][nt][i] + bv;  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + i
-        if (act) v = v > 0.f ? v : v * slope;
-        X[((m0 + mt) * 16 + g * 4 + i) * DQ_LD + col] = v;
-      }
+        for (int i = 0; i < 4; i++) {
+          float v = acc[mt][nt][i] + bv;  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + i
+          if (act) v = v > 0.f ? v : v * slope;
+          X[((m0 + mt) * 16 + g * 4 + i) * DQ_LD + col] = v;
+        }
+    }
   }
   __syncthreads();
 }
 
+// A layer for the 32-row tile (two 16-row MFMA tiles): the output columns are dealt to the 4 waves in 16-column tiles.
 __device__ __forceinline__ void dq_layer(float* X, const float* Wp, const float* bias, int Kpad, int Npad, bool act, float slope) {
   const int w = threadIdx.x >> 6;
   switch (Npad) {
-    case 16: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, w, 0, 1, act, slope); break;
-    case 32: dq_dense<2, 1>(X, Wp, bias, Kpad, Npad, (w >> 1) * 2, w & 1, 1, act, slope); break;
-    case 64: dq_dense<4, 1>(X, Wp, bias, Kpad, Npad, 0, w, 4, act, slope); break;
-    case 128: dq_dense<4, 2>(X, Wp, bias, Kpad, Npad, 0, w, 4, act, slope); break;
-    case 192: dq_dense<4, 3>(X, Wp, bias, Kpad, Npad, 0, w, 4, act, slope); break;
-    default: dq_dense<4, 4>(X, Wp, bias, Kpad, Npad, 0, w, 4, act, slope); break;
+    case 16: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, w & 1, 0, 1, w >= 2, act, slope); break;   // 2 tiles: waves 2, 3 idle
+    case 32: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, w >> 1, w & 1, 1, false, act, slope); break;
+    case 64: dq_dense<2, 1>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+    case 128: dq_dense<2, 2>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+    case 192: dq_dense<2, 3>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+    default: dq_dense<2, 4>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
   }
 }
 
@@ -108,76 +145,96 @@ __device__ __forceinline__ unsigned long long dq_mix64(unsigned long long seed, 
 
 }  // namespace cim
 
-// Counting sort of the envs with a pending decision by deciding port.  tiles int32 [max_tiles][3] = (port, first index
-// into sorted, rows <= 64); *n_tiles = tiles in use.  Also writes n_actions (1 for a deciding env, else 0).
-extern "C" __global__ void __launch_bounds__(1024)
-mrx_k_cim_dqn_bin(int n_envs, int P, const int32_t* __restrict__ decisions, int32_t* __restrict__ sorted, int32_t* __restrict__ tiles,
-                  int32_t* __restrict__ n_tiles, int32_t* __restrict__ n_actions) {
-  __shared__ int cnt[64], start[64], tbase[64];
-  const int t = threadIdx.x;
-  if (t < 64) cnt[t] = 0;
+// Bins the envs with a pending decision by deciding port: lists int32 [P][n_envs] (list p = the envs deciding for port p,
+// any order), cnt int32 [64] = list lengths (zero on entry: the forward kernel's last workgroup resets them).  Also writes
+// n_actions (1 for a deciding env, else 0).
+extern "C" __global__ void __launch_bounds__(256)
+mrx_k_cim_dqn_bin(int n_envs, int P, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt, int32_t* __restrict__ lists,
+                  int32_t* __restrict__ n_actions) {
+  __shared__ int lcnt[64], base[64];
+  const int t = threadIdx.x, e = blockIdx.x * blockDim.x + t;
+  if (t < 64) lcnt[t] = 0;
   __syncthreads();
-  for (int e = t; e < n_envs; e += blockDim.x) {
+  int port = -1, rank = 0;
+  if (e < n_envs) {
     const int32_t* d = decisions + (size_t)e * 8;
-    const bool valid = d[7] == 1 && (unsigned)d[1] < (unsigned)P;
-    if (valid) atomicAdd(&cnt[d[1]], 1);
-    n_actions[e] = valid ? 1 : 0;
-  }
-  __syncthreads();
-  if (t == 0) {
-    int s = 0, tb = 0;
-    for (int p = 0; p < P; p++) {
-      start[p] = s;
-      tbase[p] = tb;
-      s += cnt[p];
-      tb += (cnt[p] + cim::DQ_TILE - 1) / cim::DQ_TILE;
+    if (d[7] == 1 && (unsigned)d[1] < (unsigned)P) {
+      port = d[1];
+      rank = atomicAdd(&lcnt[port], 1);
     }
-    *n_tiles = tb;
+    n_actions[e] = port >= 0 ? 1 : 0;
   }
   __syncthreads();
-  if (t < P) {
-    const int nt = (cnt[t] + cim::DQ_TILE - 1) / cim::DQ_TILE;
-    for (int i = 0; i < nt; i++) {
-      int32_t* tr = tiles + (size_t)(tbase[t] + i) * 3;
-      tr[0] = t;
-      tr[1] = start[t] + i * cim::DQ_TILE;
-      tr[2] = min(cim::DQ_TILE, cnt[t] - i * cim::DQ_TILE);
-    }
-  }
+  if (t < P && lcnt[t] > 0) base[t] = atomicAdd(&cnt[t], lcnt[t]);
   __syncthreads();
-  for (int e = t; e < n_envs; e += blockDim.x) {
-    const int32_t* d = decisions + (size_t)e * 8;
-    if (d[7] == 1 && (unsigned)d[1] < (unsigned)P) sorted[atomicAdd(&start[d[1]], 1)] = e;
-  }
+  if (port >= 0) lists[(size_t)port * n_envs + base[port] + rank] = e;
 }
 
 extern "C" __global__ void __launch_bounds__(256)
-mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__ decisions, const int32_t* __restrict__ sorted,
-                      const int32_t* __restrict__ tiles, const int32_t* __restrict__ n_tiles, int32_t* __restrict__ actions,
-                      float* __restrict__ q_out, float* __restrict__ state_out, int32_t* __restrict__ choice_out) {
+mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
+                      const int32_t* __restrict__ lists, int32_t* __restrict__ actions, float* __restrict__ q_out,
+                      float* __restrict__ state_out, int32_t* __restrict__ choice_out) {
   using namespace cim;
-  if ((int)blockIdx.x >= *n_tiles) return;
   __shared__ __attribute__((aligned(16))) float X[DQ_TILE * DQ_LD];
-  __shared__ int r_env[DQ_TILE], r_node[DQ_TILE][DQ_MAX_NODES];
+  __shared__ int r_env[DQ_TILE], r_node[DQ_TILE][DQ_MAX_NODES], c_info[DQ_MAX_WIDTH], s_tile[3];
   __shared__ const int32_t* r_frame[DQ_TILE][DQ_MAX_TICKS];
   const int t = threadIdx.x;
-  const int port = tiles[(size_t)blockIdx.x * 3], first = tiles[(size_t)blockIdx.x * 3 + 1], rows = tiles[(size_t)blockIdx.x * 3 + 2];
-  const int n_ticks = M.look_back - 1;
 
-  // ---- per-row lookups: env, the node list [port] + future_stop_list, the frame of each look-back tick
+  // ---- which (port, tile) is this workgroup: prefix over the ports' tile counts (P <= 64: one wave)
+  if (t < 64) {
+    const int c = t < K.P ? cnt[t] : 0;
+    const int nt = (c + DQ_TILE - 1) / DQ_TILE;
+    int incl = nt;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o);
+      if (t >= o) incl += up;
+    }
+    if (t == 0) s_tile[0] = -1;
+    const int b = (int)blockIdx.x - (incl - nt);
+    if (b >= 0 && b < nt) {  // exactly one lane matches (or none: more workgroups than tiles)
+      s_tile[0] = t;
+      s_tile[1] = b * DQ_TILE;
+      s_tile[2] = min(DQ_TILE, c - b * DQ_TILE);
+    }
+    // every workgroup has now read the counters: the last one to say so clears them for the next call
+    if (t == 0) {
+      int32_t* done = cnt + 64;
+      if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
+        for (int p = 0; p < 64; p++) cnt[p] = 0;
+        *done = 0;
+      }
+    }
+  }
+  __syncthreads();
+  const int port = s_tile[0];
+  if (port < 0) return;
+  const int rows = s_tile[2];
+  const int32_t* list = lists + (size_t)port * K.n_envs + s_tile[1];
+  const int n_ticks = M.look_back - 1;
+#ifdef MRX_DQN_PROFILE
+  long long tm[12]; int tmi = 0;
+#define DQ_MARK() do { __syncthreads(); tm[tmi++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DQ_MARK() do {} while (0)
+#endif
+  DQ_MARK();
+
+  // ---- per-row lookups: env, the node list [port] + future_stop_list, the frame of each look-back tick;
+  //      per-column descriptors: which (tick, node, frame word) a state column reads
   if (t < DQ_TILE) {
-    const int env = t < rows ? sorted[first + t] : -1;
+    const int env = t < rows ? list[t] : -1;
     r_env[t] = env;
     if (env >= 0) {
       const int32_t* d = decisions + (size_t)env * 8;
       const int32_t* now = frame_of(K, env, d[0]);  // snapshots[tick : vessel : future_stop_list]
       r_node[t][0] = d[1];
+      r_node[t][DQ_MAX_NODES - 1] = d[2];
       for (int j = 1; j < M.n_nodes; j++) r_node[t][j] = now ? now[frame_word(K, 1, VA_FUTURE_STOP_LIST, d[2], j - 1)] : 0;
     }
   }
   for (int i = t; i < DQ_TILE * n_ticks; i += blockDim.x) {
     const int r = i / n_ticks, ti = i - r * n_ticks;
-    const int env = r < rows ? sorted[first + r] : -1;
+    const int env = r < rows ? list[r] : -1;
     const int32_t* f = nullptr;
     if (env >= 0) {
       const int tick = decisions[(size_t)env * 8];
@@ -185,38 +242,53 @@ mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__
     }
     r_frame[r][ti] = f;
   }
-  __syncthreads();
-
-  // ---- state rows (float32, as FullyConnected.forward's x.float()): ports[ticks : nodes : port_attrs] then vessels[tick : vessel : vessel_attrs]
   const int kp0 = M.kpad[0], per_tick = M.n_nodes * M.n_pa, n_port_feats = n_ticks * per_tick;
-  for (int i = t; i < DQ_TILE * kp0; i += blockDim.x) {
-    const int r = i / kp0, c = i - r * kp0;
-    float v = 0.f;
-    const int env = r_env[r];
-    if (env >= 0 && c < M.state_dim) {
-      if (c < n_port_feats) {
-        const int ti = c / per_tick, rem = c - ti * per_tick, ni = rem / M.n_pa, ai = rem - ni * M.n_pa;
-        const int32_t* f = r_frame[r][ti];
-        const int node = r_node[r][ni], a = M.pa[ai];
-        if (f && (unsigned)node < (unsigned)K.P) {
-          const int32_t raw = f[K.f_ports + a * K.P + node];
-          v = a == PA_TRANSFER_COST ? bits_f(raw) : (float)raw;
-        }
-      } else {
-        const int32_t* f = r_frame[r][0];
-        const int vessel = decisions[(size_t)env * 8 + 2];
-        if (f) v = (float)f[frame_word(K, 1, M.va[c - n_port_feats], vessel, 0)];
-      }
-      if (state_out) state_out[(size_t)env * M.state_dim + c] = v;
+  if (t < kp0) {
+    int info = -1;  // padding column
+    if (t < n_port_feats) {
+      const int ti = t / per_tick, rem = t - ti * per_tick, ni = rem / M.n_pa, a = M.pa[rem - ni * M.n_pa];
+      info = ti | (ni << 8) | ((a == PA_TRANSFER_COST ? 1 : 0) << 15) | ((K.f_ports + a * K.P) << 16);
+    } else if (t < M.state_dim) {
+      info = 0 | (0x7f << 8) | (M.va[t - n_port_feats] << 16);  // vessel attribute of the decision's frame
     }
-    X[r * DQ_LD + c] = v;
+    c_info[t] = info;
+  }
+  __syncthreads();
+  DQ_MARK();
+
+  // ---- state rows (float32, as FullyConnected.forward's x.float()): ports[ticks : nodes : port_attrs] then
+  //      vessels[tick : vessel : vessel_attrs]; thread = column, independent loads in flight per thread
+  if (t < kp0) {
+    const int info = c_info[t];
+    const int ti = info & 0xff, ni = (info >> 8) & 0x7f, word = info >> 16;
+    const bool is_f32 = (info >> 15) & 1, vessel_col = ni == 0x7f;
+    int32_t raw[DQ_TILE];
+    unsigned okm = 0;
+#pragma unroll
+    for (int r = 0; r < DQ_TILE; r++) {  // all the tile's loads of this column in flight at once
+      const int32_t* f = r_frame[r][ti];
+      const int node = vessel_col ? r_node[r][DQ_MAX_NODES - 1] : r_node[r][ni];  // last slot: the deciding vessel
+      const bool ok = r_env[r] >= 0 && info >= 0 && f != nullptr && (unsigned)node < (unsigned)(vessel_col ? K.V : K.P);
+      const int w = vessel_col ? frame_word(K, 1, word, node, 0) : word + node;
+      raw[r] = *(ok ? f + w : K.live);  // always a valid address: no branch around the load
+      okm |= (unsigned)ok << r;
+    }
+#pragma unroll
+    for (int r = 0; r < DQ_TILE; r++) {
+      const float v = !((okm >> r) & 1) ? 0.f : is_f32 ? bits_f(raw[r]) : (float)raw[r];
+      if (state_out && r_env[r] >= 0 && info >= 0) state_out[(size_t)r_env[r] * M.state_dim + t] = v;
+      X[r * DQ_LD + t] = v;
+    }
   }
   __syncthreads();
 
   // ---- the dense chain of this port's network
   const float* net = M.weights + (size_t)port * M.net_floats;
-  for (int l = 0; l < M.n_layers; l++)
+  DQ_MARK();
+  for (int l = 0; l < M.n_layers; l++) {
     dq_layer(X, net + M.w_off[l], net + M.b_off[l], M.kpad[l], M.npad[l], l + 1 < M.n_layers, M.slope);
+    DQ_MARK();
+  }
 
   // ---- q = adv - mean(adv) + v (dqn.py:48-52), greedy action, env_sampler.py:33-64 translation
   if (t < rows) {
@@ -259,4 +331,9 @@ mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__
     a[2] = (int32_t)qty;
     a[3] = is_load ? MRX_ACTION_LOAD : MRX_ACTION_DISCHARGE;
   }
+#ifdef MRX_DQN_PROFILE
+  DQ_MARK();
+  if (t == 0 && q_out) for (int i = 0; i + 1 < tmi; i++) q_out[(size_t)blockIdx.x * 16 + i] = (float)(tm[i + 1] - tm[i]);  // overwrites q rows: profiling build only
+#endif
+#undef DQ_MARK
 }

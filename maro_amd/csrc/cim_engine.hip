@@ -423,12 +423,12 @@ int mrx_cim_dqn_pack_net(const mrx_cim_dqn_model* m, const float* const* weights
   return MRX_OK;
 }
 
-static long long dqn_max_tiles(const CimParams& K) { return (long long)K.n_envs / cim::DQ_TILE + K.P + 1; }
+static long long dqn_max_tiles(const CimParams& K) { return ((long long)K.n_envs + cim::DQ_TILE - 1) / cim::DQ_TILE + K.P; }
 
 int64_t mrx_cim_dqn_scratch_bytes(mrx_handle h) {
   if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
   const CimParams& K = h->plan.kp;
-  return 4 * ((long long)K.n_envs + 3 * dqn_max_tiles(K) + 4);
+  return 4 * (128 + (long long)K.P * K.n_envs);  // counters + ticket, then one env list per port
 }
 
 int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_decisions, void* d_scratch, int32_t* d_actions,
@@ -443,7 +443,7 @@ int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_d
   if (m->n_nets != K.P) return set_err(MRX_ERR_INVALID_ARG, "one network per port: n_nets must equal n_ports");
   if (m->look_back < 2 || m->look_back - 1 > DQ_MAX_TICKS) return set_err(MRX_ERR_INVALID_ARG, "look_back out of range");
   if (m->n_port_attrs < 0 || m->n_port_attrs > 8 || m->n_vessel_attrs < 0 || m->n_vessel_attrs > 8) return set_err(MRX_ERR_INVALID_ARG, "at most 8 attributes each");
-  if (1 + K.future_n > DQ_MAX_NODES) return set_err(MRX_ERR_UNSUPPORTED, "future_stop_number too large");
+  if (1 + K.future_n > DQ_MAX_NODES - 1) return set_err(MRX_ERR_UNSUPPORTED, "future_stop_number too large");
   D.look_back = m->look_back;
   D.n_nodes = 1 + K.future_n;
   D.n_pa = m->n_port_attrs;
@@ -461,13 +461,12 @@ int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_d
   D.weights = m->d_weights;
   rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
-  int32_t* sorted = (int32_t*)d_scratch;
-  int32_t* tiles = sorted + K.n_envs;
-  const long long max_tiles = dqn_max_tiles(K);
-  int32_t* n_tiles = tiles + 3 * max_tiles;
-  hipLaunchKernelGGL(mrx_k_cim_dqn_bin, dim3(1), dim3(1024), 0, (hipStream_t)stream, K.n_envs, K.P, d_decisions, sorted, tiles, n_tiles, d_n_actions);
-  hipLaunchKernelGGL(mrx_k_cim_dqn_forward, dim3((unsigned)max_tiles), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, sorted, tiles,
-                     n_tiles, d_actions, d_q, d_state, d_choice);
+  int32_t* cnt = (int32_t*)d_scratch;
+  int32_t* lists = cnt + 128;
+  hipLaunchKernelGGL(mrx_k_cim_dqn_bin, dim3((unsigned)((K.n_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K.n_envs, K.P, d_decisions, cnt, lists,
+                     d_n_actions);
+  hipLaunchKernelGGL(mrx_k_cim_dqn_forward, dim3((unsigned)dqn_max_tiles(K)), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, cnt, lists,
+                     d_actions, d_q, d_state, d_choice);
   HIP_TRY(hipGetLastError());
   return MRX_OK;
 }
