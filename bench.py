@@ -324,9 +324,8 @@ def main():
                 graphs[g].replay()  # policy -> step -> snapshot slices, captured once (hipGraph)
                 return
             if qnet is not None:
-                qnet[g].act(b["actions"], b["n_actions"])     # mrx_cim_dqn_act: state gather + MFMA MLP + argmax + translation
-                if timing is None:
-                    b["counter"] += b["n_actions"].sum()
+                # mrx_cim_dqn_act: state gather + MFMA MLP + argmax + translation
+                qnet[g].act(b["actions"], b["n_actions"], counter=b["counter"] if timing is None else None)
             else:
                 eng.random_policy(-1 if args.graphs else i, b["actions"], b["n_actions"], b["counter"] if timing is None else None)
             if timing is not None:

@@ -307,9 +307,10 @@ int64_t mrx_cim_dqn_scratch_bytes(mrx_handle h);
  *   d_actions    int32 [n_envs][A][4], d_n_actions int32 [n_envs]: ready for the next mrx_cim_step
  *   d_q          float32 [n_envs][n_actions] or NULL; d_state float32 [n_envs][state_dim] or NULL; d_choice int32 [n_envs]
  *                or NULL (the chosen action index) — rows of envs without a valid decision are left untouched
+ *   d_counter    NULL, or a device counter the number of answered decisions is added to (as mrx_cim_random_policy)
  */
 int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_decisions, void* d_scratch, int32_t* d_actions,
-                    int32_t* d_n_actions, float* d_q, float* d_state, int32_t* d_choice, void* stream);
+                    int32_t* d_n_actions, float* d_q, float* d_state, int32_t* d_choice, uint64_t* d_counter, void* stream);
 
 /* Attribute name -> id and slot count for a node type; returns -1 for an unknown attribute
  * (reference raises BackendsInvalidAttributeException, frame.pyx:786-790). */

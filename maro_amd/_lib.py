@@ -101,7 +101,7 @@ def load() -> ctypes.CDLL:
     L.mrx_cim_dqn_scratch_bytes.restype = i64
     L.mrx_cim_dqn_scratch_bytes.argtypes = [vp]
     L.mrx_cim_dqn_act.restype = i32
-    L.mrx_cim_dqn_act.argtypes = [vp] * 10
+    L.mrx_cim_dqn_act.argtypes = [vp] * 11
     L.mrx_cim_attr_id.restype = i32
     L.mrx_cim_attr_id.argtypes = [i32, ctypes.c_char_p]
     L.mrx_cim_attr_slots.restype = i32

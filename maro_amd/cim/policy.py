@@ -125,13 +125,15 @@ class FusedPerPortDQN:
                                    dtype=torch.uint8, device=engine.device)
 
     def act(self, actions: torch.Tensor, n_actions: torch.Tensor, decisions: Optional[torch.Tensor] = None,
-            q: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None, choice: Optional[torch.Tensor] = None) -> None:
+            q: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None, choice: Optional[torch.Tensor] = None,
+            counter: Optional[torch.Tensor] = None) -> None:
         """actions int32 [n, A, 4] / n_actions int32 [n] <- the policy's answer to `decisions` (default: engine.decisions).
-        Optional outputs: q float32 [n, n_actions], state float32 [n, state_dim], choice int32 [n] (rows of deciding envs)."""
+        Optional outputs: q float32 [n, n_actions], state float32 [n, state_dim], choice int32 [n] (rows of deciding envs);
+        counter int64 [1]: the number of answered decisions is added to it."""
         d = self.eng.decisions if decisions is None else decisions
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         _lib.check(self._L.mrx_cim_dqn_act(self.eng._h, ctypes.byref(self._m), d.data_ptr(), self.scratch.data_ptr(),
-                                           actions.data_ptr(), n_actions.data_ptr(), p(q), p(state), p(choice),
+                                           actions.data_ptr(), n_actions.data_ptr(), p(q), p(state), p(choice), p(counter),
                                            self.eng._stream()), "mrx_cim_dqn_act")
 
 

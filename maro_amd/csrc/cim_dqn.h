@@ -147,10 +147,10 @@ __device__ __forceinline__ unsigned long long dq_mix64(unsigned long long seed, 
 
 // Bins the envs with a pending decision by deciding port: lists int32 [P][n_envs] (list p = the envs deciding for port p,
 // any order), cnt int32 [64] = list lengths (zero on entry: the forward kernel's last workgroup resets them).  Also writes
-// n_actions (1 for a deciding env, else 0).
+// n_actions (1 for a deciding env, else 0) and adds the number of deciding envs to *counter (may be NULL).
 extern "C" __global__ void __launch_bounds__(256)
 mrx_k_cim_dqn_bin(int n_envs, int P, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt, int32_t* __restrict__ lists,
-                  int32_t* __restrict__ n_actions) {
+                  int32_t* __restrict__ n_actions, unsigned long long* __restrict__ counter) {
   __shared__ int lcnt[64], base[64];
   const int t = threadIdx.x, e = blockIdx.x * blockDim.x + t;
   if (t < 64) lcnt[t] = 0;
@@ -165,7 +165,10 @@ mrx_k_cim_dqn_bin(int n_envs, int P, const int32_t* __restrict__ decisions, int3
     n_actions[e] = port >= 0 ? 1 : 0;
   }
   __syncthreads();
-  if (t < P && lcnt[t] > 0) base[t] = atomicAdd(&cnt[t], lcnt[t]);
+  if (t < P && lcnt[t] > 0) {
+    base[t] = atomicAdd(&cnt[t], lcnt[t]);
+    if (counter) atomicAdd(counter, (unsigned long long)lcnt[t]);
+  }
   __syncthreads();
   if (port >= 0) lists[(size_t)port * n_envs + base[port] + rank] = e;
 }

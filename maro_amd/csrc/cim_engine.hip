@@ -432,7 +432,7 @@ int64_t mrx_cim_dqn_scratch_bytes(mrx_handle h) {
 }
 
 int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_decisions, void* d_scratch, int32_t* d_actions,
-                    int32_t* d_n_actions, float* d_q, float* d_state, int32_t* d_choice, void* stream) {
+                    int32_t* d_n_actions, float* d_q, float* d_state, int32_t* d_choice, uint64_t* d_counter, void* stream) {
   using namespace cim;
   if (!h || !m || !d_decisions || !d_scratch || !d_actions || !d_n_actions || !m->d_weights) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
   const CimParams& K = h->plan.kp;
@@ -464,7 +464,7 @@ int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_d
   int32_t* cnt = (int32_t*)d_scratch;
   int32_t* lists = cnt + 128;
   hipLaunchKernelGGL(mrx_k_cim_dqn_bin, dim3((unsigned)((K.n_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K.n_envs, K.P, d_decisions, cnt, lists,
-                     d_n_actions);
+                     d_n_actions, (unsigned long long*)d_counter);
   hipLaunchKernelGGL(mrx_k_cim_dqn_forward, dim3((unsigned)dqn_max_tiles(K)), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, cnt, lists,
                      d_actions, d_q, d_state, d_choice);
   HIP_TRY(hipGetLastError());
