@@ -28,6 +28,25 @@ VESSEL_QUERY_ATTRS = ["empty", "full", "remaining_space"]
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def init_dist(world, local_rank):
+    """One process per GPU over RCCL (backend "nccl").  MRX_BENCH_BACKEND=gloo + MRX_BENCH_DEVICE=<i> are test hooks only: they
+    let a 1-GPU box run the N>1 code path with every rank on the same device (RCCL refuses two ranks per GPU)."""
+    import torch
+    dev = torch.device(f"cuda:{os.environ.get('MRX_BENCH_DEVICE', local_rank)}")
+    if world <= 1:
+        return None, dev
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(dev)
+    backend = os.environ.get("MRX_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(backend)
+    dist.barrier()
+    return dist, dev
+
+
 def frame_bytes(topo):
     for k, v in FRAME_BYTES.items():
         if topo.name.startswith(k):
@@ -97,14 +116,7 @@ def bench_citi_bike(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if rank == 0:
         ge.build()
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        dist.barrier()
-    dev = torch.device(f"cuda:{local_rank}")
+    dist, dev = init_dist(world, local_rank)
     torch.cuda.set_device(dev)
     import numpy as np
 
@@ -255,14 +267,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if rank == 0:
         ge.build()
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        dist.barrier()
-    dev = torch.device(f"cuda:{local_rank}")
+    dist, dev = init_dist(world, local_rank)
     torch.cuda.set_device(dev)
 
     from maro_amd.cim.engine import CimBatchEngine
@@ -439,7 +444,7 @@ def main():
                        "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
                        "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms,
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
-            "roofline": {"bound": "hbm", "kernel": "mrx_k_cim_step_tab" if engines[0].layout.order_table_on else "mrx_k_cim_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("mrx_k_cim_step_tab" if engines[0].layout.order_table_on else "mrx_k_cim_step") + ("_obs" if bufs[0].get("obs") is not None else ""), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_GBps": None if traffic is None else traffic / (step_kernel_ms * 1e-3) / 1e9 * in_flight,
                          "traffic_source": "profiles/latest_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
