@@ -55,25 +55,51 @@ def frame_bytes(topo):
     return P * 48 + V * (9 * 4 + 2 + (2 * topo.past_stop_number + 2 * topo.future_stop_number) * 4) + 4 * (P * P + 2 * V * P)
 
 
+def host_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a container that sees
+    256 CPUs but is limited to 16 CPU-seconds per second runs slower with 256 busy threads than with 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())       # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(topology, durations, budget_s):
-    """The C oracle (a port of the reference algorithm) timed on ONE host core: whole episodes of the same
-    workload with the same counter-based agent, until ~budget_s seconds of CPU work."""
+    """The C oracle (a port of the reference algorithm) timed on the host: whole episodes of the same workload with the
+    same counter-based agent — first on ONE core, then one independent oracle per host core (threads; the ctypes call
+    releases the GIL), ~budget_s / 2 seconds each.  `value` is the all-cores rate, `cores` the threads used."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from oracle.cim_oracle import CimOracle
 
-    o = CimOracle(topology, durations=durations)
-    steps = ticks = episodes = 0
+    def worker(o, wid, budget):
+        t0 = time.perf_counter()
+        steps, ticks, episodes = o.bench(1000 + 1000003 * wid, budget)   # the episode loop runs in C (oracle/cim_oracle.c)
+        return steps, ticks, episodes, time.perf_counter() - t0
+
+    first = CimOracle(topology, durations=durations)
+    s1, k1, e1, d1 = worker(first, 0, budget_s / 2)
+    cores = host_cores()
+    oracles = [first] + [CimOracle(first.topo, durations=durations) for _ in range(cores - 1)]  # built outside the timed window
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        o.set_seed(1000 + episodes)
-        o.reset(keep_seed=True)
-        n, tk, _ = o.rollout(1000 + episodes)
-        steps += n
-        ticks += tk
-        episodes += 1
+    with ThreadPoolExecutor(cores) as ex:
+        res = list(ex.map(lambda w: worker(oracles[w], w + 1, budget_s / 2), range(cores)))
     dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{episodes} full episodes of {topology} ({durations} ticks, reset+rollout in C, "
-                      f"{steps} decisions, {dt:.1f} s on 1 core; {ticks / dt:.0f} ticks/s)",
+    steps, ticks, episodes = (sum(r[i] for r in res) for i in range(3))
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port", "value_one_core": s1 / d1,
+            "sample": f"{episodes} full episodes of {topology} ({durations} ticks, reset+rollout in C, {steps} decisions, "
+                      f"{dt:.1f} s on {cores} threads = one oracle per usable host core (affinity capped by the cgroup CPU quota); {ticks / dt:.0f} ticks/s); "
+                      f"one core alone: {e1} episodes, {s1} decisions in {d1:.1f} s",
             "note": "reference Python Env.step measured in the build container: ~311 env-steps/s (BASELINE.md §2)"}
 
 

@@ -16,11 +16,13 @@
  * the real reference (built from /root/reference; generator: oracle/gen_golden.py) and against
  * the reference's own known answers (tests/cim/test_cim_scenario.py, docs ...rst:152-165,293-303).
  */
+#define _POSIX_C_SOURCE 199309L /* clock_gettime (cim_oracle_bench) */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../include/maro_amd.h"
 #include "mt19937.h"
@@ -897,6 +899,27 @@ int64_t cim_oracle_rollout(cim_oracle* o, int64_t env_seed, int64_t max_steps, i
   }
   if (ticks_out) *ticks_out = o->tick - t0 + (done ? 1 : 0);
   return n;
+}
+
+/* bench.py's cpu_baseline leg: whole episodes (set_seed + reset + rollout with the counter-based agent) until
+ * budget_s seconds have passed, entirely in C so that one thread per host core runs without touching the interpreter. */
+int64_t cim_oracle_bench(cim_oracle* o, int64_t first_seed, double budget_s, int64_t* ticks_out, int64_t* episodes_out) {
+  struct timespec t0, t;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  int64_t steps = 0, ticks = 0, episodes = 0, metrics[3];
+  for (;;) {
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    if ((double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec) >= budget_s) break;
+    int64_t tk = 0;
+    cim_oracle_set_seed(o, first_seed + episodes);
+    cim_oracle_reset(o, 1);
+    steps += cim_oracle_rollout(o, first_seed + episodes, -1, &tk, metrics);
+    ticks += tk;
+    episodes++;
+  }
+  if (ticks_out) *ticks_out = ticks;
+  if (episodes_out) *episodes_out = episodes;
+  return steps;
 }
 
 /* CPython random pinning hooks (tests/test_oracle_mt.py) */

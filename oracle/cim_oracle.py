@@ -73,6 +73,8 @@ def lib():
         L.cim_oracle_stream_seeds.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.cim_oracle_rollout.restype = ctypes.c_int64
         L.cim_oracle_rollout.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+        L.cim_oracle_bench.restype = ctypes.c_int64
+        L.cim_oracle_bench.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
         L.cim_oracle_mt_selftest.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
     return _lib
@@ -181,6 +183,12 @@ class CimOracle:
         met = np.zeros(3, np.int64)
         n = lib().cim_oracle_rollout(self._h, int(env_seed), int(max_steps), ctypes.byref(ticks), met.ctypes.data)
         return int(n), int(ticks.value), met
+
+    def bench(self, first_seed: int, budget_s: float):
+        """Whole episodes (set_seed + reset + rollout) in C for ~budget_s seconds: (decisions, ticks, episodes)."""
+        ticks, episodes = ctypes.c_int64(0), ctypes.c_int64(0)
+        n = lib().cim_oracle_bench(self._h, int(first_seed), float(budget_s), ctypes.byref(ticks), ctypes.byref(episodes))
+        return int(n), int(ticks.value), int(episodes.value)
 
     def stream_seeds(self) -> np.ndarray:
         out = np.zeros(4, np.int64)
