@@ -324,7 +324,7 @@ def main():
             bufs[-1]["obs"] = eng.set_observation(QUERY_ATTRS, VESSEL_QUERY_ATTRS)
     topo = engines[0].topo
     ports = torch.arange(topo.n_ports, dtype=torch.int32, device=dev)
-    samplers, qnet = [], None
+    qnet = None
     if args.policy == "dqn":
         # the CIM RL example's rollout path entirely on the device — CIMEnvSampler state
         # (look-back snapshot slices), 22 per-port dueling DQNs (random-init weights, exact-f32 MFMA), greedy action and the

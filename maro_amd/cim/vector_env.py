@@ -9,10 +9,9 @@ device every call; high-throughput rollouts use the tensor API of ``CimBatchEngi
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence, Union
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
-import torch
 
 from .engine import NODE_ATTRS, SEED_KEEP, SEED_REDRAW, CimBatchEngine
 from .payloads import encode_action, make_decision_event

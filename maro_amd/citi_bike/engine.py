@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .abi import (HDR_STATUS, HDR_TICK, HDR_WORDS, NODE_ATTRS, NODE_TYPE, MrxCbConfig, MrxCbLayout, draw_transfer_times,
+from .abi import (HDR_STATUS, HDR_TICK, HDR_WORDS, NODE_TYPE, MrxCbConfig, MrxCbLayout, draw_transfer_times,
                   topology_struct)
 from .data import CitiBikeData, load_topology
 

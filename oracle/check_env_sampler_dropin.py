@@ -40,7 +40,7 @@ def main():
     # engine (and the reference's one-process-per-env VectorEnv) has.
     Env(scenario="cim", topology=args.topology, durations=args.durations)
     from examples.cim.rl.algorithms.dqn import get_dqn_policy
-    from examples.cim.rl.config import action_shaping_conf, reward_shaping_conf, state_shaping_conf, port_attributes, vessel_attributes
+    from examples.cim.rl.config import action_shaping_conf, reward_shaping_conf
     from examples.cim.rl.env_sampler import CIMEnvSampler
 
     from maro_amd.cim.vector_env import GpuVectorEnv

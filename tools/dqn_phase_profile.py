@@ -5,7 +5,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from maro_amd.cim.engine import CimBatchEngine
-from maro_amd.cim.policy import ACTION_SPACE, FusedPerPortDQN, random_chains
+from maro_amd.cim.policy import FusedPerPortDQN, random_chains
 from maro_amd.cim.sampler import CimBatchSampler
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5461
