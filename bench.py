@@ -356,6 +356,8 @@ def main():
                 return
             if qnet is not None:
                 # mrx_cim_dqn_act: state gather + MFMA MLP + argmax + translation
+                if timing is not None:
+                    timing[2].record()
                 qnet[g].act(b["actions"], b["n_actions"], counter=b["counter"] if timing is None else None)
             else:
                 eng.random_policy(-1 if args.graphs else i, b["actions"], b["n_actions"], b["counter"] if timing is None else None)
@@ -422,14 +424,15 @@ def main():
     # ---- dominant kernel (mrx_k_cim_step) timed live with HIP events, each pair on the stream of its launch, in
     # the same interleaved schedule as the timed loop
     reps = min(args.steps, 100)
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(G)] for _ in range(reps)]
+    ev = [[tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(G)] for _ in range(reps)]
     sync_all()
     for r in range(reps):
         for g in range(G):
             one_step(step_i, g, timing=ev[r][g])
         step_i += 1
     torch.cuda.synchronize(dev)
-    durs = [a.elapsed_time(b) for row in ev for a, b in row]
+    durs = [a.elapsed_time(b) for row in ev for a, b, _ in row]
+    policy_ms = sum(c.elapsed_time(a) for row in ev for a, _, c in row) / len(durs) if qnet is not None else None
     step_kernel_ms = sum(durs) / len(durs)                      # mean duration of one launch (ng envs)
     span_ms = max([ev[0][g][0].elapsed_time(ev[-1][g2][1]) for g in range(G) for g2 in range(G)]) if G > 1 else sum(durs)
     in_flight = max(1.0, sum(durs) / span_ms) if G > 1 else 1.0    # mean number of step kernels running concurrently
@@ -480,6 +483,14 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.topology, args.durations, args.cpu_seconds)
+        if qnet is not None:
+            # the policy's own roofline: exact-f32 MFMA (MI355X_MICROARCH.md: 157.3 TFLOP/s), algorithmic flops = 2 x sum(in x out)
+            # of the example's real layer sizes x the deciding envs of one launch; mrx_cim_dqn_act = bin + forward kernels
+            fl = 2.0 * sum(a * b for a, b in ((171, 256), (256, 128), (128, 64), (64, 32), (32, 128), (32, 128), (128, 21), (128, 1)))
+            tf = fl * (resolved / max(args.steps * world * G, 1)) / (policy_ms * 1e-3) / 1e12
+            out["roofline_policy"] = {"bound": "mfma", "kernel": "mrx_k_cim_dqn_forward (+ mrx_k_cim_dqn_bin)", "achieved": tf, "peak": 157.3,
+                                      "unit": "TFLOP/s", "frac": tf / 157.3, "dtype": "f32 (v_mfma_f32_16x16x4_f32)", "kernel_ms": policy_ms,
+                                      "flops_per_env": fl, "note": "launch latency bound: ~190 32-env tiles per launch on 256 CUs, sharing them with the other groups' step kernels"}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
