@@ -15,6 +15,7 @@ value = decision events resolved per second, whole job (all ranks), state reside
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -275,6 +276,8 @@ def main():
     ap.add_argument("--groups", type=int, default=3, help="independent env groups per GPU, each on its own HIP stream (cim)")
     ap.add_argument("--topology", default="global_trade.22p_l0.8")
     ap.add_argument("--durations", type=int, default=1120)
+    ap.add_argument("--specialize", type=int, default=1, help="1: step with kernels compiled for this exact plan (maro_amd/cim/specialize.py; "
+                    "built by __graft_entry__.build() for the default workload, else ~3 s of hipcc at engine creation); 0: generic kernels")
     ap.add_argument("--ring", type=int, default=4, help="snapshot ring slots per env (max_snapshots)")
     ap.add_argument("--no-query", action="store_true", help="skip the per-step snapshot slice")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -311,7 +314,15 @@ def main():
     for g in range(G):
         ng = sizes[g]
         seeds = torch.arange(ng, dtype=torch.int64) + rank * n + offs[g] + 1
-        eng = CimBatchEngine(args.topology, ng, durations=sim_durations, max_snapshots=max(args.ring, 8) if args.policy == "dqn" else args.ring, max_actions=1, device=dev, seeds=seeds)  # dqn: the look-back window must fit the ring
+        kw = dict(durations=sim_durations, max_snapshots=max(args.ring, 8) if args.policy == "dqn" else args.ring, max_actions=1,
+                  device=dev, seeds=seeds)  # dqn: the look-back window must fit the ring
+        try:
+            eng = CimBatchEngine(args.topology, ng, specialize=bool(args.specialize), **kw)
+        except (RuntimeError, OSError, subprocess.CalledProcessError) as e:   # no hipcc and not in the cache: generic kernels
+            if not args.specialize:
+                raise
+            print(f"bench: specialised kernels unavailable ({e}); using the generic ones", file=sys.stderr)
+            eng = CimBatchEngine(args.topology, ng, specialize=False, **kw)
         engines.append(eng)
         streams.append(torch.cuda.Stream(device=dev) if G > 1 else torch.cuda.current_stream(dev))
         bufs.append(dict(actions=torch.zeros((ng, 1, 4), dtype=torch.int32, device=dev),
@@ -469,7 +480,7 @@ def main():
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {sim_durations}, "
                                    f"{'random legal agent' if args.policy == 'random' else 'per-port dueling DQN (f32 MFMA, greedy) + CIMEnvSampler state shaping (mrx_cim_dqn_act)'} on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step (' + args.obs + ')'}",
-                       "envs_per_gpu": n, "groups_per_gpu": G, "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,
+                       "envs_per_gpu": n, "groups_per_gpu": G, "specialized_kernels": bool(engines[0].specialized), "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,
                        "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
                        "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms,
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},

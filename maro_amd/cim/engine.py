@@ -11,6 +11,7 @@ Tensor conventions are those of the C ABI:
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence, Union
 
 import numpy as np
@@ -38,7 +39,13 @@ class CimBatchEngine:
     def __init__(self, topology: Union[str, CimTopology], n_envs: int, start_tick: int = 0, durations: int = 100,
                  snapshot_resolution: int = 1, max_snapshots: Optional[int] = None, max_actions: int = 1,
                  device: Union[str, torch.device] = "cuda:0", seeds: Optional[Sequence[int]] = None, order_table: int = 0,
-                 decision_mode: int = 0):
+                 decision_mode: int = 0, specialize: Union[bool, str, None] = None):
+        """specialize: True = step with kernels compiled for this exact plan (maro_amd/cim/specialize.py: ~15 s of hipcc
+        the first time a (topology, config) is seen, cached in-tree; +15-20 % env-steps/s); "cached" = use them only if the
+        code object is already in the cache; False = the generic kernels; None = $MARO_AMD_SPECIALIZE ("1" / "cached" / "0"),
+        default generic."""
+        if specialize is None:
+            specialize = {"1": True, "cached": "cached"}.get(os.environ.get("MARO_AMD_SPECIALIZE", "0"), False)
         self._L = _lib.load()  # raises if the HIP extension is not built
         if not torch.cuda.is_available():
             raise RuntimeError("maro_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
@@ -63,6 +70,14 @@ class CimBatchEngine:
             _lib.check(self._L.mrx_cim_create(ctypes.byref(self._cs), ctypes.byref(self._cfg),
                                               self.workspace.data_ptr(), nbytes, ctypes.byref(h)), "mrx_cim_create")
         self._h = h
+        self.specialized = False
+        if specialize:
+            from . import specialize as spec
+            try:
+                spec.load_into(self, spec.plan_defines(self._cs, self._cfg), build=specialize != "cached")
+                self.specialized = True
+            except KeyError:
+                pass   # "cached" and not in the cache: generic kernels
         self.layout = _lib.MrxCimLayout()
         _lib.check(self._L.mrx_cim_get_layout(self._h, ctypes.byref(self.layout)), "mrx_cim_get_layout")
         lay = self.layout

@@ -19,6 +19,16 @@
 
 #include "cim_params.h"
 
+// KD(f): an integer dimension / layout offset of the plan (CimParams::f).  The generic kernels read it from the kernel
+// arguments; a build specialised for one (topology, config) plan (cim_spec.hip, compiled at engine creation) turns every
+// one of them into a compile-time constant MRXC_f — which removes ~60 live SGPRs and their spill traffic, folds the
+// divisions / loop bounds / LDS offsets, and drops the VGPR count from ~197 to ~118.
+#ifdef MRX_SPECIALIZED
+#define KD(f) (MRXC_##f)
+#else
+#define KD(f) (K.f)
+#endif
+
 namespace cim {
 
 // Phase timer hook: a no-op in the product build; tools/profile build (-DMRX_PROFILE_PHASES) supplies a
@@ -58,15 +68,15 @@ struct Lds {
 
 MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
   Lds L;
-  L.frame = b + K.l_frame;
-  L.priv = b + K.l_priv;
-  L.mt_ord = (uint32_t*)(b + K.l_mt0);
-  L.mt_buf = (uint32_t*)(b + K.l_mt1);
-  L.dsrc = (double*)(b + K.l_dsrc);
-  L.dtgt = (double*)(b + K.l_dtgt);
-  L.oq = b + K.l_oq;
-  L.srcn = b + K.l_srcn;
-  L.misc = b + K.l_misc;
+  L.frame = b + KD(l_frame);
+  L.priv = b + KD(l_priv);
+  L.mt_ord = (uint32_t*)(b + KD(l_mt0));
+  L.mt_buf = (uint32_t*)(b + KD(l_mt1));
+  L.dsrc = (double*)(b + KD(l_dsrc));
+  L.dtgt = (double*)(b + KD(l_dtgt));
+  L.oq = b + KD(l_oq);
+  L.srcn = b + KD(l_srcn);
+  L.misc = b + KD(l_misc);
   L.tab.tgt_off = K.h_tgt_off; L.tab.tgt_port = K.h_tgt_port; L.tab.route_port = K.h_route_port;
   L.tab.v_route_base = K.h_v_route_base; L.tab.v_route_len = K.h_v_route_len;
   L.tab.leg_off = K.h_leg_off; L.tab.leg_time = K.h_leg_time;
@@ -77,24 +87,24 @@ MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
   return L;
 }
 
-#define FP(a, p) L.frame[K.f_ports + (a) * K.P + (p)]
-#define FV(a, v) L.frame[K.f_vessels + (a) * K.V + (v)]
-#define FV_PAST(s, v) L.frame[K.f_vessels + (10 + (s)) * K.V + (v)]
-#define FV_PASTT(s, v) L.frame[K.f_vessels + (10 + K.past_n + (s)) * K.V + (v)]
-#define FV_FUT(s, v) L.frame[K.f_vessels + (10 + 2 * K.past_n + (s)) * K.V + (v)]
-#define FV_FUTT(s, v) L.frame[K.f_vessels + (10 + 2 * K.past_n + K.future_n + (s)) * K.V + (v)]
-#define FOPK(k) L.frame[K.f_fop + (k)] /* full_on_ports of order pair k = (src, dst) */
-#define FOVC(v, c) L.frame[K.f_fov + T.v_cbase[v] + (c)]   /* full_on_vessels[v][c-th distinct route port] */
-#define PLANC(v, c) L.frame[K.f_plans + T.v_cbase[v] + (c)] /* vessel_plans, same indexing */
-#define V_EVT(v) L.priv[K.pv_evt + (v)]
-#define V_ARR(v) L.priv[K.pv_arr + (v)]
-#define V_NEXT(v) L.priv[K.pv_next + (v)]
-#define V_POS(v) L.priv[K.pv_pos + (v)]  /* (start + next_loc) mod route_len */
-#define V_KRL(v) L.priv[K.pv_krl + (v)]  /* next_loc mod (route_len + 1) */
-#define V_PERIOD(v) L.priv[K.pv_period + (v)]  /* vessel_period_without_noise of this env's data */
+#define FP(a, p) L.frame[KD(f_ports) + (a) * KD(P) + (p)]
+#define FV(a, v) L.frame[KD(f_vessels) + (a) * KD(V) + (v)]
+#define FV_PAST(s, v) L.frame[KD(f_vessels) + (10 + (s)) * KD(V) + (v)]
+#define FV_PASTT(s, v) L.frame[KD(f_vessels) + (10 + KD(past_n) + (s)) * KD(V) + (v)]
+#define FV_FUT(s, v) L.frame[KD(f_vessels) + (10 + 2 * KD(past_n) + (s)) * KD(V) + (v)]
+#define FV_FUTT(s, v) L.frame[KD(f_vessels) + (10 + 2 * KD(past_n) + KD(future_n) + (s)) * KD(V) + (v)]
+#define FOPK(k) L.frame[KD(f_fop) + (k)] /* full_on_ports of order pair k = (src, dst) */
+#define FOVC(v, c) L.frame[KD(f_fov) + T.v_cbase[v] + (c)]   /* full_on_vessels[v][c-th distinct route port] */
+#define PLANC(v, c) L.frame[KD(f_plans) + T.v_cbase[v] + (c)] /* vessel_plans, same indexing */
+#define V_EVT(v) L.priv[KD(pv_evt) + (v)]
+#define V_ARR(v) L.priv[KD(pv_arr) + (v)]
+#define V_NEXT(v) L.priv[KD(pv_next) + (v)]
+#define V_POS(v) L.priv[KD(pv_pos) + (v)]  /* (start + next_loc) mod route_len */
+#define V_KRL(v) L.priv[KD(pv_krl) + (v)]  /* next_loc mod (route_len + 1) */
+#define V_PERIOD(v) L.priv[KD(pv_period) + (v)]  /* vessel_period_without_noise of this env's data */
 #define U(x) wave::uniform(x)
-#define RING_FULL(slot, k) L.priv[K.pv_rfull + (slot) * K.NT + (k)]
-#define RING_EMPTY(slot, p) L.priv[K.pv_rempty + (slot) * K.P + (p)]
+#define RING_FULL(slot, k) L.priv[KD(pv_rfull) + (slot) * KD(NT) + (k)]
+#define RING_EMPTY(slot, p) L.priv[KD(pv_rempty) + (slot) * KD(P) + (p)]
 
 MRX_DEV float bits_f(int32_t x) { union { int32_t i; float f; } u; u.i = x; return u.f; }
 MRX_DEV int32_t f_bits(float f) { union { int32_t i; float f; } u; u.f = f; return u.i; }
@@ -104,14 +114,14 @@ MRX_DEV int32_t f_bits(float f) { union { int32_t i; float f; } u; u.f = f; retu
 // stage the serial-access tables in LDS and re-point L.tab at the copy (complete with lds_dma_wait)
 MRX_DEV void copy_in_async(int32_t* lds_dst, const int32_t* gsrc, int n_words);
 MRX_DEV void stage_tables(const CimParams& K, Lds& L, int32_t* c) {
-  copy_in_async(c, K.ctab, K.ctab_words);
+  copy_in_async(c, K.ctab, KD(ctab_words));
 #define MRX_HTAB(f) L.tab.f = (const uint16_t*)c + (K.h_##f - (const uint16_t*)K.ctab)
   MRX_HTAB(tgt_off); MRX_HTAB(tgt_port); MRX_HTAB(route_port); MRX_HTAB(v_route_base); MRX_HTAB(v_route_len);
   MRX_HTAB(leg_off); MRX_HTAB(leg_time); MRX_HTAB(rec_off); MRX_HTAB(v_cbase); MRX_HTAB(route_cidx); MRX_HTAB(pair_src);
 #undef MRX_HTAB
   L.tab.er_delay = c + (K.er_delay - K.ctab); L.tab.fr_delay = c + (K.fr_delay - K.ctab);
 #define MRX_DTAB(f) L.tab.f = (const double*)(c + ((const int32_t*)K.f - K.ctab))
-  if (!K.pregen) { MRX_DTAB(src_base); MRX_DTAB(src_noise); }  // with the order table they stay in global memory
+  if (!KD(pregen)) { MRX_DTAB(src_base); MRX_DTAB(src_noise); }  // with the order table they stay in global memory
   MRX_DTAB(er_base); MRX_DTAB(er_noise); MRX_DTAB(fr_base); MRX_DTAB(fr_noise);
 #undef MRX_DTAB
 }
@@ -236,11 +246,11 @@ MRX_DEV void write_future_and_plans(const CimParams& K, Lds& L, int v, int pos, 
   const Tabs& T = L.tab;
   const int Lr = T.v_route_len[v], rb = T.v_route_base[v], lo = T.leg_off[v];
   int tick = arrival, x = pos;  // x walks the route cyclically
-  for (int i = 0; i < Lr || i < K.future_n; i++) {
+  for (int i = 0; i < Lr || i < KD(future_n); i++) {
     tick += T.leg_time[lo + x];
     x = (x + 1 == Lr) ? 0 : x + 1;
     const int port = T.route_port[rb + x];
-    if (i < K.future_n) { FV_FUT(i, v) = port; FV_FUTT(i, v) = tick; }
+    if (i < KD(future_n)) { FV_FUT(i, v) = port; FV_FUTT(i, v) = tick; }
     if (i < Lr) PLANC(v, T.route_cidx[rb + x]) = tick;  // vessel_sailing_plan_wrapper.py:24-28 (later stops overwrite earlier)
   }
 }
@@ -281,7 +291,7 @@ MRX_DEV void tick_prefetch_land(TickPf& pf) {
 // target ratios
 MRX_DEV void tick_prefetch_static(const CimParams& K, TickPf& pf, bool generator) {
   const int lane = wave::lane();
-  const int last = K.NT > 0 ? K.NT - 1 : 0;
+  const int last = KD(NT) > 0 ? KD(NT) - 1 : 0;
 #pragma unroll
   for (int b = 0; b < 3; b++) {
     int k = b * 64 + lane;
@@ -294,9 +304,9 @@ MRX_DEV void tick_prefetch_static(const CimParams& K, TickPf& pf, bool generator
 // stop-table entries, discharge records and order pairs of the first (up to) four vessels of `mask`
 MRX_DEV void tick_prefetch_arrivals(const CimParams& K, int env, Lds& L, uint64_t mask, TickPf& pf) {
   const int lane = wave::lane();
-  const int V = K.V, P = K.P;
+  const int V = KD(V), P = KD(P);
   const Tabs& T = L.tab;
-  const int32_t* g_rec = K.rec + (size_t)env * K.REC_W;
+  const int32_t* g_rec = K.rec + (size_t)env * KD(REC_W);
   // per-vessel words as rows (lane = vessel): one LDS trip for all of them, then register reads per arriving vessel
   const int lv = lane < V ? lane : 0;
   const int r_next = FV(VA_NEXT_LOC_IDX, lv), r_krl = V_KRL(lv), r_pos = V_POS(lv);
@@ -311,10 +321,10 @@ MRX_DEV void tick_prefetch_arrivals(const CimParams& K, int env, Lds& L, uint64_
       if (lane == a) v = va;
     }
     const int k = wave::shfl(r_next, lane < 4 ? v : 0);
-    const size_t srow = ((size_t)env * V + v) * K.SMAX;
+    const size_t srow = ((size_t)env * V + v) * KD(SMAX);
     pf.ns = K.nstops[(size_t)env * V + v];
-    pf.stk = K.stops[srow + (k < K.SMAX ? k : 0)];
-    pf.stk1 = K.stops[srow + (k + 1 < K.SMAX ? k + 1 : 0)];
+    pf.stk = K.stops[srow + (k < KD(SMAX) ? k : 0)];
+    pf.stk1 = K.stops[srow + (k + 1 < KD(SMAX) ? k + 1 : 0)];
   }
   // lane j fetches the j-th candidate discharge record (and its load tick) of each of those vessels, and the order
   // pair that ships from the arrival port to the port of the vessel's j-th next stop
@@ -331,7 +341,7 @@ MRX_DEV void tick_prefetch_arrivals(const CimParams& K, int env, Lds& L, uint64_
     if (col >= RL) col -= RL;
     const bool ok = lane < Lr && sidx >= 0;
     pf.q[a] = g_rec[wave::readlane(r_rec, v) + krl * RL + (ok ? col : 0)];
-    pf.key[a] = (int)K.stops[((size_t)env * V + v) * K.SMAX + (ok ? sidx : 0)];
+    pf.key[a] = (int)K.stops[((size_t)env * V + v) * KD(SMAX) + (ok ? sidx : 0)];
     int xn = pos + 1 + (lane < Lr ? lane : 0);  // < 2 Lr: one conditional subtraction instead of an integer modulo
     if (xn >= Lr) xn -= Lr;
     pf.kk[a] = K.pair_dense[(int)T.route_port[rb + pos] * P + (int)T.route_port[rb + xn]];
@@ -344,14 +354,14 @@ template <bool PG>
 MRX_DEV void tick_prefetch(const CimParams& K, int env, Lds& L, int t, TickPf& pf) {
   const int lane = wave::lane();
   if constexpr (PG) {
-    const int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t - K.start_tick) * K.NTP;
+    const int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t - KD(start_tick)) * KD(NTP);
 #pragma unroll
-    for (int b = 0; b < 3; b++) pf.oqr[b] = row[b * 64 + lane < K.NTP ? b * 64 + lane : 0];
+    for (int b = 0; b < 3; b++) pf.oqr[b] = row[b * 64 + lane < KD(NTP) ? b * 64 + lane : 0];
     pf.otg = 0;
   } else {
-    pf.otg = K.order_prop[(size_t)env * K.T + t];
+    pf.otg = K.order_prop[(size_t)env * KD(T) + t];
   }
-  const bool arr = lane < K.V && !FV(VA_IS_PARKING, lane) && FV(VA_NEXT_LOC_IDX, lane) > 0 && V_EVT(lane) == t;
+  const bool arr = lane < KD(V) && !FV(VA_IS_PARKING, lane) && FV(VA_NEXT_LOC_IDX, lane) > 0 && V_EVT(lane) == t;
   pf.arr_mask = wave::ballot(arr);
   tick_prefetch_arrivals(K, env, L, pf.arr_mask, pf);
 }
@@ -362,11 +372,11 @@ MRX_DEV void tick_prefetch(const CimParams& K, int env, Lds& L, int t, TickPf& p
 // lane + 64 b (tick_prefetch_static).
 MRX_DEV void gen_orders(const CimParams& K, Lds& L, long long otg, int& idx_ord, const TickPf& pf) {
   const int lane = wave::lane();
-  const int P = K.P, NT = K.NT;
+  const int P = KD(P), NT = KD(NT);
   const Tabs& T = L.tab;
   for (int k = lane; k < NT; k += 64) L.oq[k] = 0;
   double ns = 0.0;
-  if (K.use_order_rng) {
+  if (KD(use_order_rng)) {
     const double r = mt_draw_batch(L.mt_ord, idx_ord, lane < P ? lane : -1, P);
     if (lane < P) ns = apply_noise(T.src_base[lane], T.src_noise[lane], r);
   } else if (lane < P) {
@@ -410,7 +420,7 @@ MRX_DEV void gen_orders(const CimParams& K, Lds& L, long long otg, int& idx_ord,
   {                                                                                          \
     const int k = (k0) + lane;                                                               \
     const int n = (NTb - (k0)) < 64 ? (NTb - (k0)) : 64;                                      \
-    if (K.use_order_rng) {                                                                   \
+    if (KD(use_order_rng)) {                                                                   \
       const double r = mt_draw_batch(L.mt_ord, idx_ord, k < NTb ? lane : -1, n);             \
       if (k < NTb) L.dtgt[k] = apply_noise(TB, TN, r);                                       \
     } else if (k < NTb) {                                                                    \
@@ -479,15 +489,15 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   uint32_t* mt_route = (uint32_t*)(lds + K.l_mt2);
   uint32_t* mt_oinit = (uint32_t*)(lds + K.l_mt3);
   const int lane = wave::lane();
-  const int P = K.P, V = K.V, TT = K.T;
+  const int P = KD(P), V = KD(V), TT = KD(T);
   uint32_t* g_mt = K.mt + (size_t)env * MTS_COUNT * MT_WORDS;
-  int32_t* g_priv = K.priv + (size_t)env * K.PW;
-  int32_t* g_live = K.live + (size_t)env * K.FW;
+  int32_t* g_priv = K.priv + (size_t)env * KD(PW);
+  int32_t* g_live = K.live + (size_t)env * KD(FW);
   const Tabs& T = L.tab;
 
   // ---- base seed
   long long base;
-  if (K.data_mode) {
+  if (KD(data_mode)) {
     // dump folder / real data files: every (re)load re-seeds the registry with the data set's own seed
     // (cim_data_container_helpers.py:79-85, 118-123), whatever set_seed / the redraw say
     base = K.data_seed;
@@ -510,8 +520,8 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   // ---- seed the streams: stream i of the registry gets base + i (sim_random.py:35-63)
   {
     uint32_t* arr = lane == 0 ? L.mt_ord : lane == 1 ? L.mt_buf : lane == 2 ? mt_route : mt_oinit;
-    const int sidx = lane == 0 ? K.idx_order_num : lane == 1 ? K.idx_buffer : lane == 2 ? K.idx_route : K.idx_order_init;
-    if (lane < 3 || (lane == 3 && K.has_order_init)) mt_seed_serial(arr, base + sidx);  // 4 lanes, 4 streams
+    const int sidx = lane == 0 ? KD(idx_order_num) : lane == 1 ? KD(idx_buffer) : lane == 2 ? KD(idx_route) : KD(idx_order_init);
+    if (lane < 3 || (lane == 3 && KD(has_order_init))) mt_seed_serial(arr, base + sidx);  // 4 lanes, 4 streams
   }
   wave::sync();
   int idx_route = MT_WORDS, idx_oi = MT_WORDS;
@@ -519,11 +529,11 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   // ---- order proportion (parsers.py:57-106)
   int32_t* g_prop = K.order_prop + (size_t)env * TT;
   int status = 0;
-  uint32_t* g_stops = K.stops + (size_t)env * V * K.SMAX;
-  if (K.data_mode) {
+  uint32_t* g_stops = K.stops + (size_t)env * V * KD(SMAX);
+  if (KD(data_mode)) {
     // stop tables, vessel periods and the order proportion come from files (cim_data_loader.py:360-450)
-    for (int t = lane; t < TT; t += 64) g_prop[t] = (K.data_mode == 1 && t < K.data_T) ? K.fx_order_prop[t] : 0;
-    for (int i = lane; i < V * K.SMAX; i += 64) g_stops[i] = K.fx_stops[i];
+    for (int t = lane; t < TT; t += 64) g_prop[t] = (KD(data_mode) == 1 && t < KD(data_T)) ? K.fx_order_prop[t] : 0;
+    for (int i = lane; i < V * KD(SMAX); i += 64) g_stops[i] = K.fx_stops[i];
     if (lane < V) { K.nstops[(size_t)env * V + lane] = K.fx_nstops[lane]; K.vperiod[(size_t)env * V + lane] = K.fx_vperiod[lane]; }
     // the frame initialisation below reads the stop table back through global memory
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
@@ -531,9 +541,9 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   } else {
   for (int t0 = 0; t0 < TT; t0 += 64) {
     const int t = t0 + lane;
-    double orders = t < TT ? K.order_dist[t % K.period] : 0.0;
+    double orders = t < TT ? K.order_dist[t % KD(period)] : 0.0;
     const bool nz = t < TT && orders != 0.0;
-    if (K.has_order_init) {
+    if (KD(has_order_init)) {
       const uint64_t m = wave::ballot(nz);
       const int rank = nz ? __builtin_popcountll(m & ((1ull << lane) - 1ull)) : -1;
       const double r = mt_draw_batch(mt_oinit, idx_oi, rank, __builtin_popcountll(m));
@@ -544,7 +554,7 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
       if (nz) {
         double c = orders < 1.0 ? orders : 1.0;
         if (c < 0.0) c = 0.0;
-        val = (int32_t)floor(c * (double)K.total_containers);
+        val = (int32_t)floor(c * (double)KD(total_containers));
       }
       g_prop[t] = val;
     }
@@ -556,15 +566,15 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
     const int Lr = K.v_route_len[v], rb = K.v_route_base[v];
     const double speed = K.v_speed[v], sn = K.v_speed_noise[v], dur = K.v_dur[v], dn = K.v_dur_noise[v];
     int loc = K.v_start[v], tick = 0, extra = 0, k = 0, period = 0;
-    while (extra <= K.future_n) {
+    while (extra <= KD(future_n)) {
       const double r1 = mt_draw_uniform(mt_route, idx_route);
       const int parking = (int)ceil(apply_noise(dur, dn, r1));
       const double r2 = mt_draw_uniform(mt_route, idx_route);
       const double noised_speed = apply_noise(speed, sn, r2);
       const int sailing = (int)ceil(K.route_dist[rb + loc] / noised_speed);
       if (parking <= 0 || parking > 255) status |= 8;  // reference: assert parking_duration > 0
-      if (k < K.SMAX) {
-        if (lane == 0) g_stops[(size_t)v * K.SMAX + k] = ((uint32_t)tick << 8) | (uint32_t)(parking & 0xff);
+      if (k < KD(SMAX)) {
+        if (lane == 0) g_stops[(size_t)v * KD(SMAX) + k] = ((uint32_t)tick << 8) | (uint32_t)(parking & 0xff);
       } else {
         status |= 2;  // MRX_ENV_STOP_OVERFLOW
       }
@@ -573,9 +583,9 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
       loc = (loc + 1 == Lr) ? 0 : loc + 1;
       extra += (tick > TT) ? 1 : 0;
       k++;
-      if (k > 4 * K.SMAX) { status |= 2; break; }
+      if (k > 4 * KD(SMAX)) { status |= 2; break; }
     }
-    if (lane == 0) { K.nstops[(size_t)env * V + v] = k < K.SMAX ? k : K.SMAX; K.vperiod[(size_t)env * V + v] = period; }
+    if (lane == 0) { K.nstops[(size_t)env * V + v] = k < KD(SMAX) ? k : KD(SMAX); K.vperiod[(size_t)env * V + v] = period; }
   }
   }  // generated data
   wave::sync();
@@ -586,8 +596,8 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   copy_words((int32_t*)(g_mt + MTS_ROUTE * MT_WORDS), (const int32_t*)mt_route, MT_WORDS);
 
   // ---- frame (business_engine.py:321-356, 381-398) and private state
-  for (int i = lane; i < K.FW; i += 64) L.frame[i] = (i >= K.f_plans && i < K.f_plans + K.NC) ? -1 : 0;
-  for (int i = lane; i < K.PW; i += 64) L.priv[i] = 0;
+  for (int i = lane; i < KD(FW); i += 64) L.frame[i] = (i >= KD(f_plans) && i < KD(f_plans) + KD(NC)) ? -1 : 0;
+  for (int i = lane; i < KD(PW); i += 64) L.priv[i] = 0;
   wave::sync();
   if (lane < P) {
     FP(PA_CAPACITY, lane) = K.p_cap[lane];
@@ -601,31 +611,31 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
     FV(VA_REMAINING_SPACE, v) = K.v_total_space[v] - K.v_init_empty[v];
     FV(VA_IS_PARKING, v) = 1;
     FV(VA_LOC_PORT_IDX, v) = K.route_port[K.v_route_base[v] + K.v_start[v]];
-    for (int s = 0; s < K.past_n; s++) { FV_PAST(s, v) = -1; FV_PASTT(s, v) = -1; }
+    for (int s = 0; s < KD(past_n); s++) { FV_PAST(s, v) = -1; FV_PASTT(s, v) = -1; }
     write_future_and_plans(K, L, v, K.v_start[v], 0);
-    V_EVT(v) = stop_parking(g_stops[(size_t)v * K.SMAX]);  // leave tick of stop 0 (arrival 0)
+    V_EVT(v) = stop_parking(g_stops[(size_t)v * KD(SMAX)]);  // leave tick of stop 0 (arrival 0)
     V_ARR(v) = 0;
     V_POS(v) = K.v_start[v];
     V_KRL(v) = 0;
     V_PERIOD(v) = K.vperiod[(size_t)env * V + v];
-    V_NEXT(v) = K.nstops[(size_t)env * V + v] > 1 ? stop_arrival(g_stops[(size_t)v * K.SMAX + 1]) : 0x7fffffff;
+    V_NEXT(v) = K.nstops[(size_t)env * V + v] > 1 ? stop_arrival(g_stops[(size_t)v * KD(SMAX) + 1]) : 0x7fffffff;
   }
   if (lane == 0) {
-    L.priv[PH_TICK] = K.start_tick;
+    L.priv[PH_TICK] = KD(start_tick);
     L.priv[PH_FLAGS] = FL_FRESH;
     L.priv[PH_IDX_ORDER] = MT_WORDS;
     L.priv[PH_IDX_BUFFER] = MT_WORDS;
     L.priv[PH_IDX_ROUTE] = idx_route;
     K.seed[env] = base;
     K.status[env] = status;
-    K.tick[env] = K.start_tick;
+    K.tick[env] = KD(start_tick);
   }
   wave::sync();
-  copy_words(g_live, L.frame, K.FW);
-  copy_words(g_priv, L.priv, K.PW);
-  for (int i = lane; i < K.S; i += 64) K.ring_fi[(size_t)env * K.S + i] = -1;
-  int32_t* g_rec0 = K.rec + (size_t)env * K.REC_W;
-  for (int i = lane; i < K.REC_W; i += 64) g_rec0[i] = 0;
+  copy_words(g_live, L.frame, KD(FW));
+  copy_words(g_priv, L.priv, KD(PW));
+  for (int i = lane; i < KD(S); i += 64) K.ring_fi[(size_t)env * KD(S) + i] = -1;
+  int32_t* g_rec0 = K.rec + (size_t)env * KD(REC_W);
+  for (int i = lane; i < KD(REC_W); i += 64) g_rec0[i] = 0;
 }
 
 // ==========================================================================================
@@ -649,23 +659,23 @@ MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {
   // row stores every time
   {
     double* sb = (double*)(lds + K.g_srctab);
-    if (lane < K.P) { sb[lane] = K.src_base[lane]; sb[K.P + lane] = K.src_noise[lane]; }
-    L.tab.src_base = sb; L.tab.src_noise = sb + K.P;
+    if (lane < KD(P)) { sb[lane] = K.src_base[lane]; sb[KD(P) + lane] = K.src_noise[lane]; }
+    L.tab.src_base = sb; L.tab.src_noise = sb + KD(P);
   }
-  const int32_t* g_prop = K.order_prop + (size_t)env * K.T;
-  const int D = K.T - K.start_tick;
+  const int32_t* g_prop = K.order_prop + (size_t)env * KD(T);
+  const int D = KD(T) - KD(start_tick);
   int idx_ord = MT_WORDS;  // the stream as reset_env seeded it
   wave::lds_dma_wait();
   tick_prefetch_land(pf);  // no load may still be pending inside the tick loop (its wait would also drain the row stores)
   for (int t0 = 0; t0 < D; t0 += 64) {
-    int mine = t0 + lane < D ? g_prop[K.start_tick + t0 + lane] : 0;  // 64 ticks of order_proportion per load
+    int mine = t0 + lane < D ? g_prop[KD(start_tick) + t0 + lane] : 0;  // 64 ticks of order_proportion per load
     wave::touch(mine);  // wait for it HERE: inside the tick loop the same wait would also drain the previous tick's row stores
     const int n_here = D - t0 < 64 ? D - t0 : 64;
     for (int j = 0; j < n_here; j++) {  // wave-uniform
       gen_orders(K, L, (long long)wave::shfl(mine, j), idx_ord, pf);
       wave::sync();
-      int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t0 + j) * K.NTP;
-      for (int k = lane; k < K.NTP; k += 64) row[k] = k < K.NT ? L.oq[k] : 0;
+      int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t0 + j) * KD(NTP);
+      for (int k = lane; k < KD(NTP); k += 64) row[k] = k < KD(NT) ? L.oq[k] : 0;
       wave::sync();
     }
   }
@@ -675,28 +685,28 @@ MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {
 template <bool PG>
 MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf, int& idx_ord, int& idx_buf, int& status, Prof& prof) {
   const int lane = wave::lane();
-  const int P = K.P, V = K.V, NT = K.NT, H = K.H;
+  const int P = KD(P), V = KD(V), NT = KD(NT), H = KD(H);
   const Tabs& T = L.tab;
 
   // ---------------- A. orders of this tick -> L.oq[pair]
   const uint64_t arr_mask = pf.arr_mask;
-  int32_t* g_rec = K.rec + (size_t)env * K.REC_W;
+  int32_t* g_rec = K.rec + (size_t)env * KD(REC_W);
   if constexpr (PG) {
     // drawn at reset (order table): the row was requested one round trip ago (tick_prefetch)
 #pragma unroll
     for (int b = 0; b < 3; b++) { const int k = b * 64 + lane; if (k < NT) L.oq[k] = pf.oqr[b]; }
     if (NT > 192) {
-      const int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t - K.start_tick) * K.NTP;
+      const int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t - KD(start_tick)) * KD(NTP);
       for (int k = 192 + lane; k < NT; k += 64) L.oq[k] = row[k];
     }
   } else {
     long long otg = (long long)pf.otg;
     bool gen = true;
-    if (K.order_mode == 1) {  // UNFIXED :327-333 (total_empty_number from business_engine.py:134-136)
+    if (KD(order_mode) == 1) {  // UNFIXED :327-333 (total_empty_number from business_engine.py:134-136)
       long long mine = 0;
       if (lane < P) mine += FP(PA_EMPTY, lane);
       if (lane < V) mine += FV(VA_EMPTY, lane);
-      const long long delta = (long long)K.total_containers - wave::reduce_add(mine);
+      const long long delta = (long long)KD(total_containers) - wave::reduce_add(mine);
       if (otg <= delta) gen = false; else otg -= delta;
     }
     if (gen) gen_orders(K, L, otg, idx_ord, pf);
@@ -709,8 +719,8 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
   if (lane < V) {
     const int v = lane;
     if (FV(VA_IS_PARKING, v) && V_EVT(v) == t) {
-      for (int s = 0; s + 1 < K.past_n; s++) { FV_PAST(s, v) = FV_PAST(s + 1, v); FV_PASTT(s, v) = FV_PASTT(s + 1, v); }
-      if (K.past_n > 0) { FV_PAST(K.past_n - 1, v) = FV(VA_LOC_PORT_IDX, v); FV_PASTT(K.past_n - 1, v) = V_ARR(v); }
+      for (int s = 0; s + 1 < KD(past_n); s++) { FV_PAST(s, v) = FV_PAST(s + 1, v); FV_PASTT(s, v) = FV_PASTT(s + 1, v); }
+      if (KD(past_n) > 0) { FV_PAST(KD(past_n) - 1, v) = FV(VA_LOC_PORT_IDX, v); FV_PASTT(KD(past_n) - 1, v) = V_ARR(v); }
       FV(VA_NEXT_LOC_IDX, v) += 1;
       { const int Lr = T.v_route_len[v]; const int x = V_POS(v) + 1, y = V_KRL(v) + 1; V_POS(v) = x == Lr ? 0 : x; V_KRL(v) = y == Lr + 1 ? 0 : y; }
       FV(VA_IS_PARKING, v) = 0;
@@ -770,12 +780,12 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
       if (has) {
         *cell = 0;
         const int i = n_ent + __builtin_popcountll(hm & ((1ull << lane) - 1ull));
-        if (i < K.misc_cap) { ent[3 * i] = key; ent[3 * i + 1] = v; ent[3 * i + 2] = q; }
+        if (i < KD(misc_cap)) { ent[3 * i] = key; ent[3 * i + 1] = v; ent[3 * i + 2] = q; }
       }
       n_ent += __builtin_popcountll(hm);
       n_ves++;
     }
-    if (n_ent > K.misc_cap) { status |= 16; n_ent = K.misc_cap; }
+    if (n_ent > KD(misc_cap)) { status |= 16; n_ent = KD(misc_cap); }
     wave::sync();
     if (n_ves > 1 && n_ent > 1 && n_ent <= 64) {
       // merge by load tick, stable (several vessels arriving in one tick): lane i ranks entry i among all entries
@@ -804,7 +814,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
       const int i = i0 + lane;
       const bool has = i < n_ent;
       const int nb = (n_ent - i0) < 64 ? (n_ent - i0) : 64;
-      const double r = K.use_buffer_rng ? mt_draw_batch(L.mt_buf, idx_buf, has ? lane : -1, nb) : 0.0;
+      const double r = KD(use_buffer_rng) ? mt_draw_batch(L.mt_buf, idx_buf, has ? lane : -1, nb) : 0.0;
       if (has) {
         const int v = ent[3 * i + 1], q = ent[3 * i + 2];
         const int rpi = T.v_route_base[v] + V_POS(v);
@@ -812,7 +822,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
         wave::lds_add(&FV(VA_FULL, v), -q);
         wave::lds_add(&FV(VA_REMAINING_SPACE, v), q);
         wave::lds_add(&FOVC(v, pc), -q);
-        const int b = K.use_buffer_rng ? (int)ceil(apply_noise(T.er_base[p], T.er_noise[p], r)) : T.er_delay[p];
+        const int b = KD(use_buffer_rng) ? (int)ceil(apply_noise(T.er_base[p], T.er_noise[p], r)) : T.er_delay[p];
         if (b == 0) {  // immediate RETURN_EMPTY
           wave::lds_add(&FP(PA_EMPTY, p), q);
         } else {
@@ -845,7 +855,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
       const int q = k < NT ? L.oq[k] : 0;
       const bool has = q > 0;
       int b = 0;
-      if (K.use_buffer_rng) {
+      if (KD(use_buffer_rng)) {
         const uint64_t m = wave::ballot(has);
         const int rank = has ? __builtin_popcountll(m & ((1ull << lane) - 1ull)) : -1;
         const double r = mt_draw_batch(L.mt_buf, idx_buf, rank, __builtin_popcountll(m));
@@ -931,7 +941,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
       const uint32_t st_k1 = (uint32_t)wave::shfl((int)pf.stk1, a_idx);
       prof.mark(10);
       // lane i: the i-th stop after this one — route position, port, compact matrix column, predicted tick
-      const int nlan = Lr > K.future_n ? Lr : K.future_n;
+      const int nlan = Lr > KD(future_n) ? Lr : KD(future_n);
       const bool act = lane < nlan;
       int xi = pos + lane, xn = pos + 1 + lane;  // leg out of stop i-1, position of stop i
       xi %= Lr; xn %= Lr;
@@ -944,12 +954,12 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
         dup_later = dup_later || (j > lane && cj == c_i);
         dup_earlier = dup_earlier || (j < lane && cj == c_i);
       }
-      if (lane < K.future_n) { FV_FUT(lane, v) = port_i; FV_FUTT(lane, v) = tick_i; }
+      if (lane < KD(future_n)) { FV_FUT(lane, v) = port_i; FV_FUTT(lane, v) = tick_i; }
       if (lane < Lr && !dup_later) PLANC(v, c_i) = tick_i;  // vessel_sailing_plan_wrapper.py:24-28 (later stops overwrite)
       prof.mark(11);
       // load full (:551-587): the sequential hand-out of `acceptable` over the next Lr stops is a clamped prefix sum;
       // a second visit of the same port within the window gets nothing (first visit took all, or space ran out)
-      const int acceptable = (int)floor((double)(cap - full * K.vol) / (double)K.vol);
+      const int acceptable = (int)floor((double)(cap - full * KD(vol)) / (double)KD(vol));
       const bool lv = lane < Lr && (k + 1 + lane) < ns && !dup_earlier;  // python slice truncation at the end of the stop list
       // order pair (p -> port_i), if the port ships there at all: prefetched (tick_prefetch_arrivals)
       const int kk = a_idx == 0 ? pf.kk[0] : a_idx == 1 ? pf.kk[1] : a_idx == 2 ? pf.kk[2] : pf.kk[3];
@@ -967,8 +977,8 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
       }
       full += loaded_total;
       int early = 0;
-      if ((long long)(full + empty) * K.vol > (long long)cap) {
-        early = (full + empty) - (int)ceil((double)cap / (double)K.vol);
+      if ((long long)(full + empty) * KD(vol) > (long long)cap) {
+        early = (full + empty) - (int)ceil((double)cap / (double)KD(vol));
         empty -= early;
       }
       wave::sync();
@@ -995,9 +1005,9 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
 
 // snapshot of the LDS frame into the env's ring (np_backend.pyx:481-518: slot = fi mod S)
 MRX_DEV void take_snapshot(const CimParams& K, int env, Lds& L, int fi) {
-  const int s = fi % K.S;
-  copy_words(K.ring + ((size_t)env * K.S + s) * K.FW, L.frame, K.FW);
-  if (wave::lane() == 0) K.ring_fi[(size_t)env * K.S + s] = fi;
+  const int s = fi % KD(S);
+  copy_words(K.ring + ((size_t)env * KD(S) + s) * KD(FW), L.frame, KD(FW));
+  if (wave::lane() == 0) K.ring_fi[(size_t)env * KD(S) + s] = fi;
 }
 
 // ==========================================================================================
@@ -1019,21 +1029,21 @@ struct FastRows {
 template <bool OBS>
 MRX_DEV void fast_rows_request(const CimParams& K, const CimObs& O, int env, FastRows& R) {
   const int lane = wave::lane();
-  const int32_t* g_live = K.live + (size_t)env * K.FW;
-  const int32_t* g_priv = K.priv + (size_t)env * K.PW;
-  const int p = lane < K.P ? lane : 0, v = lane < K.V ? lane : 0;
+  const int32_t* g_live = K.live + (size_t)env * KD(FW);
+  const int32_t* g_priv = K.priv + (size_t)env * KD(PW);
+  const int p = lane < KD(P) ? lane : 0, v = lane < KD(V) ? lane : 0;
   R.hdr = lane < PH_COUNT ? g_priv[lane] : 0;
-  R.pe = g_live[K.f_ports + PA_EMPTY * K.P + p];
-  R.tc = g_live[K.f_ports + PA_TRANSFER_COST * K.P + p];
-  R.ve = g_live[K.f_vessels + VA_EMPTY * K.V + v];
-  R.rs = g_live[K.f_vessels + VA_REMAINING_SPACE * K.V + v];
-  R.ed = g_live[K.f_vessels + VA_EARLY_DISCHARGE * K.V + v];
-  R.lp = g_live[K.f_vessels + VA_LOC_PORT_IDX * K.V + v];
-  R.per = g_priv[K.pv_period + v];
-  for (int k = 0; k < 4; k++) R.pl[k] = (K.NC <= 256 && lane + 64 * k < K.NC) ? g_live[K.f_plans + lane + 64 * k] : 0;
+  R.pe = g_live[KD(f_ports) + PA_EMPTY * KD(P) + p];
+  R.tc = g_live[KD(f_ports) + PA_TRANSFER_COST * KD(P) + p];
+  R.ve = g_live[KD(f_vessels) + VA_EMPTY * KD(V) + v];
+  R.rs = g_live[KD(f_vessels) + VA_REMAINING_SPACE * KD(V) + v];
+  R.ed = g_live[KD(f_vessels) + VA_EARLY_DISCHARGE * KD(V) + v];
+  R.lp = g_live[KD(f_vessels) + VA_LOC_PORT_IDX * KD(V) + v];
+  R.per = g_priv[KD(pv_period) + v];
+  for (int k = 0; k < 4; k++) R.pl[k] = (KD(NC) <= 256 && lane + 64 * k < KD(NC)) ? g_live[KD(f_plans) + lane + 64 * k] : 0;
   if constexpr (OBS) {
 #pragma unroll
-    for (int a = 0; a < 8; a++) R.vo[a] = a < O.nv ? g_live[K.f_vessels + O.va[a] * K.V + v] : 0;
+    for (int a = 0; a < 8; a++) R.vo[a] = a < O.nv ? g_live[KD(f_vessels) + O.va[a] * KD(V) + v] : 0;
   }
 }
 
@@ -1044,7 +1054,7 @@ template <bool OBS>
 MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastRows& R, int n_act, int a0v, int a0p, int a0q, int a0t,
                        int32_t* dec_out, long long* met_out, uint8_t* done_out) {
   const int lane = wave::lane();
-  const int P = K.P, V = K.V;
+  const int P = KD(P), V = KD(V);
   const int hdr = R.hdr;
   const int flags = wave::shfl(hdr, PH_FLAGS);
   if (flags & (FL_FRESH | FL_FINISHED)) return false;
@@ -1052,16 +1062,16 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
   const int cur = wave::shfl(hdr, PH_CUR_VESSEL);
   const uint64_t pend_after = pend & ~(1ull << (cur & 63));
   if (!pend_after || n_act > 1) return false;
-  int32_t* g_live = K.live + (size_t)env * K.FW;
-  int32_t* g_priv = K.priv + (size_t)env * K.PW;
+  int32_t* g_live = K.live + (size_t)env * KD(FW);
+  int32_t* g_priv = K.priv + (size_t)env * KD(PW);
   const int t = wave::shfl(hdr, PH_TICK);
   long long opnum = ((long long)wave::shfl(hdr, PH_OPNUM_HI) << 32) | (uint32_t)wave::shfl(hdr, PH_OPNUM_LO);
   const long long acc_b = ((long long)wave::shfl(hdr, PH_ACCB_HI) << 32) | (uint32_t)wave::shfl(hdr, PH_ACCB_LO);
   const long long acc_s = ((long long)wave::shfl(hdr, PH_ACCS_HI) << 32) | (uint32_t)wave::shfl(hdr, PH_ACCS_LO);
   int status = 0;
   const int v2 = __builtin_ctzll(pend_after);  // the vessel whose decision comes next
-#define GP(a, p) g_live[K.f_ports + (a) * P + (p)]
-#define GV(a, v) g_live[K.f_vessels + (a) * V + (v)]
+#define GP(a, p) g_live[KD(f_ports) + (a) * P + (p)]
+#define GV(a, v) g_live[KD(f_vessels) + (a) * V + (v)]
   bool act = n_act == 1;
   const int av = a0v, ap = a0p, q = a0q, ty = a0t;
   if (act && (av < 0 || av >= V || ap < 0 || ap >= P || q < 0 || (ty != 0 && ty != 1))) { status |= 1; act = false; }
@@ -1080,7 +1090,7 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
     const int p0 = wave::shfl(R.pl[0], cc & 63), p1 = wave::shfl(R.pl[1], cc & 63), p2 = wave::shfl(R.pl[2], cc & 63),
               p3 = wave::shfl(R.pl[3], cc & 63);
     pl = cc < 64 ? p0 : cc < 128 ? p1 : cc < 192 ? p2 : p3;
-    if (K.NC > 256) pl = g_live[K.f_plans + cc];  // large plan blocks: a second, dependent trip
+    if (KD(NC) > 256) pl = g_live[KD(f_plans) + cc];  // large plan blocks: a second, dependent trip
   }
   // ---- the action (business_engine.py:708-748)
   bool applied = false;
@@ -1099,7 +1109,7 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
         GP(PA_TRANSFER_COST, ap) = f_bits((float)((double)bits_f(tc) + (double)q));
         GV(VA_EMPTY, av) = nve;
         GV(VA_REMAINING_SPACE, av) = nrs;
-        if (c >= 0) g_live[K.f_plans + c] = pl + period;
+        if (c >= 0) g_live[KD(f_plans) + c] = pl + period;
       }
       if (c < 0) status |= 32;  // MRX_ENV_OFFROUTE_ACTION
       opnum += q;
@@ -1130,7 +1140,7 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
     dec_out[0] = t; dec_out[1] = lp2; dec_out[2] = v2;
     dec_out[3] = pe2 < rs2 ? pe2 : rs2;
     dec_out[4] = ve2; dec_out[5] = ed2;
-    dec_out[6] = (t - K.start_tick) / K.resolution; dec_out[7] = 1;
+    dec_out[6] = (t - KD(start_tick)) / KD(resolution); dec_out[7] = 1;
     met_out[0] = acc_b; met_out[1] = acc_s; met_out[2] = opnum;
     *done_out = 0;
     g_priv[PH_PEND_LO] = (int32_t)(uint32_t)(pend_after & 0xffffffffull);
@@ -1149,8 +1159,8 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
 // Decision events consumed by a step (core.py:349-366): Sequential answers the current vessel's event; Joint finishes
 // every pending event of the tick (answered or not); JointWithSequentialAction the first n_answered in event order.
 MRX_DEV uint64_t consume_decisions(const CimParams& K, uint64_t pend, int cur, int n_answered) {
-  if (K.decision_mode == 0) return pend & ~(1ull << (cur & 63));
-  if (K.decision_mode == 1 || n_answered < 0) return 0ull;
+  if (KD(decision_mode) == 0) return pend & ~(1ull << (cur & 63));
+  if (KD(decision_mode) == 1 || n_answered < 0) return 0ull;
   for (int k = 0; k < n_answered && pend; k++) pend &= pend - 1;
   return pend;
 }
@@ -1161,14 +1171,14 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
   Lds L = make_lds(K, lds);
   Prof prof;
   const int lane = wave::lane();
-  const int P = K.P, V = K.V;
-  int32_t* g_priv = K.priv + (size_t)env * K.PW;
-  int32_t* g_live = K.live + (size_t)env * K.FW;
+  const int P = KD(P), V = KD(V);
+  int32_t* g_priv = K.priv + (size_t)env * KD(PW);
+  int32_t* g_live = K.live + (size_t)env * KD(FW);
   uint32_t* g_mt = K.mt + (size_t)env * MTS_COUNT * MT_WORDS;
 
   // The 64-byte private header and the first action decide which path this step takes.
-  if (n_act > K.max_actions) n_act = K.max_actions;
-  if (K.decision_mode == 0) {  // Sequential
+  if (n_act > KD(max_actions)) n_act = KD(max_actions);
+  if (KD(decision_mode) == 0) {  // Sequential
     FastRows rows;
     fast_rows_request<OBS>(K, O, env, rows);
     int f0v = 0, f0p = 0, f0q = 0, f0t = 0;
@@ -1185,15 +1195,15 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
 
   // Everything this step needs from HBM is requested before the first wait: hot frame, private state and
   // topology tables by LDS-DMA, the action words into registers.
-  copy_in_async(L.frame, g_live, K.FW);
-  copy_in_async(L.priv, g_priv, K.PW);
-  stage_tables(K, L, lds + K.l_ctab);
+  copy_in_async(L.frame, g_live, KD(FW));
+  copy_in_async(L.priv, g_priv, KD(PW));
+  stage_tables(K, L, lds + KD(l_ctab));
   const Tabs& T = L.tab;
   // The RNG states are requested unconditionally: whether a tick will run is only known once the private
   // state has arrived, and a second LDS-DMA round trip would serialise behind every later LDS access.
-  if (!PG && K.use_order_rng) copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(g_mt + MTS_ORDER * MT_WORDS), MT_WORDS);
-  if (K.use_buffer_rng) copy_in_async((int32_t*)L.mt_buf, (const int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), MT_WORDS);
-  if (n_act > K.max_actions) n_act = K.max_actions;
+  if (!PG && KD(use_order_rng)) copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(g_mt + MTS_ORDER * MT_WORDS), MT_WORDS);
+  if (KD(use_buffer_rng)) copy_in_async((int32_t*)L.mt_buf, (const int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), MT_WORDS);
+  if (n_act > KD(max_actions)) n_act = KD(max_actions);
   int a0v = 0, a0p = 0, a0q = 0, a0t = 0;
   if (actions) { a0v = actions[0]; a0p = actions[1]; a0q = actions[2]; a0t = actions[3]; }
   wave::lds_dma_wait();
@@ -1225,7 +1235,7 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
   {
     const uint64_t pend_after = fresh ? 0ull : consume_decisions(K, pend, L.priv[PH_CUR_VESSEL], n_answered);
     const int tn = fresh ? t : t + 1;
-    if (!pend_after && tn < K.T) {
+    if (!pend_after && tn < KD(T)) {
       if constexpr (!PG) tick_prefetch_static(K, pf, true);
       tick_prefetch<PG>(K, env, L, tn, pf);
     }
@@ -1254,7 +1264,7 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
       FP(PA_TRANSFER_COST, p) = f_bits((float)((double)bits_f(U(FP(PA_TRANSFER_COST, p))) + (double)q));
       {  // vessel_plans[v, p] += period (:748): the compact plan cell of (v, p), -1 if p is not on the vessel's route
         const int c = U(i == 0 ? a0c : K.cidx_dense[v * P + p]);
-        if (c >= 0) { const int pl = U(L.frame[K.f_plans + c]); L.frame[K.f_plans + c] = pl + U(V_PERIOD(v)); }
+        if (c >= 0) { const int pl = U(L.frame[KD(f_plans) + c]); L.frame[KD(f_plans) + c] = pl + U(V_PERIOD(v)); }
         else status |= 32;  // MRX_ENV_OFFROUTE_ACTION
       }
     }
@@ -1273,16 +1283,16 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
     tick_prefetch_land(pf);  // before the snapshot stores below, so that nothing later waits behind them
     if (!fresh) {
       // C. post_step (business_engine.py:201-224)
-      if ((t + 1) % K.resolution == 0) {
+      if ((t + 1) % KD(resolution) == 0) {
         if (lane < P) FP(PA_ACC_FULFILLMENT, lane) = FP(PA_ACC_BOOKING, lane) - FP(PA_ACC_SHORTAGE, lane);
         wave::sync();
-        take_snapshot(K, env, L, (t - K.start_tick) / K.resolution);
+        take_snapshot(K, env, L, (t - KD(start_tick)) / KD(resolution));
         wave::sync();
         if (lane < P) { FP(PA_SHORTAGE, lane) = 0; FP(PA_BOOKING, lane) = 0; FP(PA_FULFILLMENT, lane) = 0; FP(PA_TRANSFER_COST, lane) = 0; }
         wave::sync();
       }
-      if (t + 1 == K.T) {
-        if ((t + 1) % K.resolution != 0) take_snapshot(K, env, L, (t - K.start_tick) / K.resolution);  // core.py:376-378
+      if (t + 1 == KD(T)) {
+        if ((t + 1) % KD(resolution) != 0) take_snapshot(K, env, L, (t - KD(start_tick)) / KD(resolution));  // core.py:376-378
         finished = true;
         break;
       }
@@ -1292,7 +1302,7 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
     fresh = false;
     mt_waited = true;  // RNG states are modified from here on
     pend = run_tick<PG>(K, env, L, t, pf, idx_ord, idx_buf, status, prof);
-    if (!pend && t + 1 < K.T) tick_prefetch<PG>(K, env, L, t + 1, pf);  // another tick follows: request its inputs now
+    if (!pend && t + 1 < KD(T)) tick_prefetch<PG>(K, env, L, t + 1, pf);  // another tick follows: request its inputs now
   }
 
   // ---- outputs
@@ -1300,8 +1310,8 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
   if (lane < P) { acc_b = FP(PA_ACC_BOOKING, lane); acc_s = FP(PA_ACC_SHORTAGE, lane); }
   acc_b = wave::reduce_add(acc_b);
   acc_s = wave::reduce_add(acc_s);
-  const int fi = (t - K.start_tick) / K.resolution;
-  if (K.decision_mode != 0) {
+  const int fi = (t - KD(start_tick)) / KD(resolution);
+  if (KD(decision_mode) != 0) {
     // Joint modes: one row per pending decision event, in event (= vessel) order; dec_out is [V][8]
     const uint64_t pm = finished ? 0ull : pend;
     const bool mine = lane < V && ((pm >> lane) & 1ull);
@@ -1368,11 +1378,11 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
   }
   wave::sync();
   prof.mark(PF_OUTPUT);
-  copy_words(g_live, L.frame, K.FW);
-  copy_words(g_priv, L.priv, K.PW);
+  copy_words(g_live, L.frame, KD(FW));
+  copy_words(g_priv, L.priv, KD(PW));
   if (mt_waited) {
-    if (!PG && K.use_order_rng) copy_words((int32_t*)(g_mt + MTS_ORDER * MT_WORDS), (const int32_t*)L.mt_ord, MT_WORDS);
-    if (K.use_buffer_rng) copy_words((int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), (const int32_t*)L.mt_buf, MT_WORDS);
+    if (!PG && KD(use_order_rng)) copy_words((int32_t*)(g_mt + MTS_ORDER * MT_WORDS), (const int32_t*)L.mt_ord, MT_WORDS);
+    if (KD(use_buffer_rng)) copy_words((int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), (const int32_t*)L.mt_buf, MT_WORDS);
   }
   prof.mark(PF_STORE);
   prof.flush();
@@ -1383,45 +1393,45 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
 MRX_DEV int attr_slots(const CimParams& K, int node_type, int a) {
   if (node_type == 0) return 1;
   if (node_type == 1) {
-    if (a == VA_PAST_STOP_LIST || a == VA_PAST_STOP_TICK_LIST) return K.past_n;
-    if (a == VA_FUTURE_STOP_LIST || a == VA_FUTURE_STOP_TICK_LIST) return K.future_n;
+    if (a == VA_PAST_STOP_LIST || a == VA_PAST_STOP_TICK_LIST) return KD(past_n);
+    if (a == VA_FUTURE_STOP_LIST || a == VA_FUTURE_STOP_TICK_LIST) return KD(future_n);
     return 1;
   }
-  return a == MA_FULL_ON_PORTS ? K.P * K.P : K.V * K.P;
+  return a == MA_FULL_ON_PORTS ? KD(P) * KD(P) : KD(V) * KD(P);
 }
 
 MRX_DEV int frame_word(const CimParams& K, int node_type, int a, int node, int s) {
-  if (node_type == 0) return K.f_ports + a * K.P + node;
+  if (node_type == 0) return KD(f_ports) + a * KD(P) + node;
   if (node_type == 1) {
     int row = a;
     if (a == VA_PAST_STOP_LIST) row = 10 + s;
-    else if (a == VA_PAST_STOP_TICK_LIST) row = 10 + K.past_n + s;
-    else if (a == VA_FUTURE_STOP_LIST) row = 10 + 2 * K.past_n + s;
-    else if (a == VA_FUTURE_STOP_TICK_LIST) row = 10 + 2 * K.past_n + K.future_n + s;
-    return K.f_vessels + row * K.V + node;
+    else if (a == VA_PAST_STOP_TICK_LIST) row = 10 + KD(past_n) + s;
+    else if (a == VA_FUTURE_STOP_LIST) row = 10 + 2 * KD(past_n) + s;
+    else if (a == VA_FUTURE_STOP_TICK_LIST) row = 10 + 2 * KD(past_n) + KD(future_n) + s;
+    return KD(f_vessels) + row * KD(V) + node;
   }
   if (a == MA_FULL_ON_PORTS) {
     const int k = K.pair_dense[s];  // dense cell s = src * P + dst
-    return k < 0 ? -1 : K.f_fop + k;
+    return k < 0 ? -1 : KD(f_fop) + k;
   }
   const int c = K.cidx_dense[s];  // dense cell s = vessel * P + port
   if (c < 0) return -1;          // port not on the vessel's route: constant cell
-  return (a == MA_FULL_ON_VESSELS ? K.f_fov : K.f_plans) + c;
+  return (a == MA_FULL_ON_VESSELS ? KD(f_fov) : KD(f_plans)) + c;
 }
 
 // The frame a snapshot query for frame index `fi` of `env` reads, or nullptr when the ring does not hold it.
 // While an env is paused at a decision its current frame index is aliased to the live frame (the
 // reference's pre-decision take_snapshot, core.py:345), which also evicts whatever the slot held.
 MRX_DEV const int32_t* frame_of(const CimParams& K, int env, int fi) {
-  const int s = (fi < 0 ? 0 : fi) % K.S;
-  const int32_t* hdr = K.priv + (size_t)env * K.PW;
+  const int s = (fi < 0 ? 0 : fi) % KD(S);
+  const int32_t* hdr = K.priv + (size_t)env * KD(PW);
   // three independent loads, then selects: no dependent chain of memory latencies
-  const int flags = hdr[PH_FLAGS], tick = hdr[PH_TICK], held = K.ring_fi[(size_t)env * K.S + s];
+  const int flags = hdr[PH_FLAGS], tick = hdr[PH_TICK], held = K.ring_fi[(size_t)env * KD(S) + s];
   const bool paused = (flags & (FL_FRESH | FL_FINISHED)) == 0;
-  const int cur_fi = (tick - K.start_tick) / K.resolution;
+  const int cur_fi = (tick - KD(start_tick)) / KD(resolution);
   const int32_t* frame = nullptr;  // padding for missing frames :541-545
-  if (held == fi) frame = K.ring + ((size_t)env * K.S + s) * K.FW;
-  if (paused && s == cur_fi % K.S) frame = fi == cur_fi ? K.live + (size_t)env * K.FW : nullptr;
+  if (held == fi) frame = K.ring + ((size_t)env * KD(S) + s) * KD(FW);
+  if (paused && s == cur_fi % KD(S)) frame = fi == cur_fi ? K.live + (size_t)env * KD(FW) : nullptr;
   return fi < 0 ? nullptr : frame;
 }
 
@@ -1441,7 +1451,7 @@ MRX_DEV double query_elem(const CimParams& K, int node_type, const int32_t* tick
     slot -= ns;
   }
   const int node = nodes[(size_t)env * nodes_per_env + ni];  // nodes_per_env = row stride (0: one shared row)
-  const int n_nodes = node_type == 0 ? K.P : node_type == 1 ? K.V : 1;
+  const int n_nodes = node_type == 0 ? KD(P) : node_type == 1 ? KD(V) : 1;
   if (node < 0 || node >= n_nodes) return 0.0;  // e.g. the -1 padding of stop lists used as a node index
   const int w = frame_word(K, node_type, a, node, slot);
   if (w < 0) return a == MA_VESSEL_PLANS ? -1.0 : 0.0;  // never-written cells: plans are initialised to -1 (business_engine.py:344)

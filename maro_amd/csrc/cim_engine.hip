@@ -53,25 +53,7 @@ mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const
 // Two builds of the step kernel: mrx_k_cim_step generates the tick's orders itself (any order mode);
 // mrx_k_cim_step_tab reads them from the order table drawn at reset (CimParams::pregen) and carries neither the
 // generator's code nor its LDS (order RNG state, fp64 scratch).
-#define MRX_STEP_KERNEL(NAME, PG, OBS, WAVES)                                                                                  \
-  extern "C" __global__ void __launch_bounds__(64, WAVES)                                                           \
-  NAME(CimParams K, CimObs O, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions,           \
-       const int32_t* __restrict__ n_answered, const uint8_t* __restrict__ mask, int32_t* __restrict__ decisions,   \
-       long long* __restrict__ metrics, uint8_t* __restrict__ done) {                                               \
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];                                                   \
-    const int env = blockIdx.x;                                                                                     \
-    if (mask && !mask[env]) return;                                                                                 \
-    const int32_t* a = actions ? actions + (size_t)env * K.max_actions * 4 : nullptr;                               \
-    const int na = (actions && n_actions) ? n_actions[env] : 0;                                                     \
-    const size_t drow = K.decision_mode ? (size_t)K.V * 8 : 8; /* Joint modes: one row per vessel */                \
-    cim::step_env<PG, OBS>(K, O, env, lds, a, na, n_answered ? n_answered[env] : -1, decisions + (size_t)env * drow,     \
-                      metrics + (size_t)env * 3, done + env);                                                       \
-  }
-MRX_STEP_KERNEL(mrx_k_cim_step, false, false, 2)
-MRX_STEP_KERNEL(mrx_k_cim_step_tab, true, false, 2)  // 3 waves/SIMD: <= 168 VGPRs, so LDS (9 waves/CU) is the limit
-MRX_STEP_KERNEL(mrx_k_cim_step_obs, false, true, 2)      // + fused observation (mrx_cim_set_observation)
-MRX_STEP_KERNEL(mrx_k_cim_step_tab_obs, true, true, 2)
-#undef MRX_STEP_KERNEL
+#include "cim_step_kernels.h"
 
 #include "cim_dqn.h"
 
@@ -134,6 +116,9 @@ struct mrx_cim_engine {
   CimHostPlan plan;
   int device;
   CimObs obs;  // fused observation (all zero = off)
+  hipModule_t spec_module = nullptr;      // plan-specialised step kernels (mrx_cim_load_step_kernels), else the generic ones
+  hipFunction_t spec_fn[4] = {nullptr, nullptr, nullptr, nullptr};  // [pregen * 2 + obs]
+  ~mrx_cim_engine() { if (spec_module) hipModuleUnload(spec_module); }
 };
 
 static thread_local std::string g_err;
@@ -265,6 +250,15 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
   const CimParams& K = h->plan.kp;
   static const size_t lds_pad = getenv("MRX_DEBUG_LDS_PAD_BYTES") ? (size_t)atoi(getenv("MRX_DEBUG_LDS_PAD_BYTES")) : 0;  // occupancy experiments
   const bool obs = h->obs.np > 0 || h->obs.nv > 0;
+  if (h->spec_module) {
+    CimParams Kc = K;
+    CimObs Oc = h->obs;
+    long long* met = (long long*)d_metrics;
+    void* params[] = {&Kc, &Oc, &d_actions, &d_n_actions, &d_n_answered, &d_env_mask, &d_decisions, &met, &d_done};
+    HIP_TRY(hipModuleLaunchKernel(h->spec_fn[(K.pregen ? 2 : 0) + (obs ? 1 : 0)], (unsigned)K.n_envs, 1, 1, 64, 1, 1,
+                                  (unsigned)((size_t)K.lds_words * 4 + lds_pad), (hipStream_t)stream, params, nullptr));
+    return MRX_OK;
+  }
   auto kern = K.pregen ? (obs ? mrx_k_cim_step_tab_obs : mrx_k_cim_step_tab) : (obs ? mrx_k_cim_step_obs : mrx_k_cim_step);
   hipLaunchKernelGGL(kern, dim3(K.n_envs), dim3(64), (size_t)K.lds_words * 4 + lds_pad, (hipStream_t)stream, K, h->obs, d_actions,
                      d_n_actions, d_n_answered, d_env_mask, d_decisions, (long long*)d_metrics, d_done);
@@ -368,6 +362,50 @@ int mrx_cim_query(mrx_handle h, int node_type, const int32_t* d_ticks, int nt, i
   hipLaunchKernelGGL(mrx_k_cim_query, dim3((unsigned)blocks), dim3(nn * row_slots >= 192 ? 256 : (nn * row_slots >= 96 ? 128 : 64)), 0, (hipStream_t)stream, K, node_type, d_ticks, nt,
                      ticks_per_env, d_nodes, nn, nodes_per_env, al, row_slots, total, d_out);
   HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+// ---- plan-specialised step kernels (cim_spec.hip)
+static std::string plan_defines(const CimParams& K) {
+  std::string o;
+#define X(f) o += std::string("#define MRXC_") + #f + " " + std::to_string((long long)K.f) + "\n";
+  MRX_CIM_DIM_FIELDS(X)
+#undef X
+  return o;
+}
+
+int64_t mrx_cim_plan_defines(const mrx_cim_topology* topo, const mrx_cim_config* cfg, char* buf, int64_t len) {
+  CimHostPlan plan;
+  std::string err;
+  const int rc = cim_plan(topo, cfg, &plan, &err);
+  if (rc != MRX_OK) return set_err(rc, err);
+  const std::string d = plan_defines(plan.kp);
+  if (buf && len > 0) {
+    if ((int64_t)d.size() + 1 > len) return set_err(MRX_ERR_INVALID_ARG, "buffer too small");
+    memcpy(buf, d.c_str(), d.size() + 1);
+  }
+  return (int64_t)d.size() + 1;
+}
+
+int mrx_cim_load_step_kernels(mrx_handle h, const void* image, int64_t bytes, const char* defines) {
+  if (!h || !image || bytes <= 0 || !defines) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
+  if (plan_defines(h->plan.kp) != defines) return set_err(MRX_ERR_INVALID_ARG, "the code object was built for a different plan (defines differ)");
+  int rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  hipModule_t mod = nullptr;
+  HIP_TRY(hipModuleLoadData(&mod, image));
+  static const char* names[4] = {"mrx_k_cim_step", "mrx_k_cim_step_obs", "mrx_k_cim_step_tab", "mrx_k_cim_step_tab_obs"};
+  hipFunction_t fn[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = h->plan.kp.pregen ? 2 : 0; i < (h->plan.kp.pregen ? 4 : 2); i++) {  // the pair for this plan's order mode
+    if (hipModuleGetFunction(&fn[i], mod, names[i]) != hipSuccess) {
+      hipModuleUnload(mod);
+      return set_err(MRX_ERR_INVALID_ARG, std::string("code object lacks kernel ") + names[i]);
+    }
+    if ((size_t)h->plan.kp.lds_words * 4 > 64 * 1024) hipFuncSetAttribute((const void*)fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, h->plan.kp.lds_words * 4);
+  }
+  if (h->spec_module) hipModuleUnload(h->spec_module);
+  h->spec_module = mod;
+  for (int i = 0; i < 4; i++) h->spec_fn[i] = fn[i];
   return MRX_OK;
 }
 

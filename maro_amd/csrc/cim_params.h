@@ -65,6 +65,72 @@ struct CimParams {
   int64_t* seed;
 };
 
+// The integer fields of CimParams that are constant for one (topology, config) plan: the set a specialised build
+// (cim_spec.hip) receives as MRXC_<field> macros (KD() in cim_device.h).
+#define MRX_CIM_DIM_FIELDS(X) \
+  X(P) \
+  X(V) \
+  X(R) \
+  X(NT) \
+  X(NRP) \
+  X(past_n) \
+  X(future_n) \
+  X(vrows) \
+  X(FW) \
+  X(S) \
+  X(H) \
+  X(SMAX) \
+  X(T) \
+  X(start_tick) \
+  X(resolution) \
+  X(max_actions) \
+  X(period) \
+  X(vol) \
+  X(total_containers) \
+  X(order_mode) \
+  X(use_order_rng) \
+  X(use_buffer_rng) \
+  X(has_order_init) \
+  X(idx_order_init) \
+  X(idx_route) \
+  X(idx_order_num) \
+  X(idx_buffer) \
+  X(f_ports) \
+  X(f_vessels) \
+  X(f_fop) \
+  X(f_fov) \
+  X(f_plans) \
+  X(misc_cap) \
+  X(NC) \
+  X(PW) \
+  X(pv_evt) \
+  X(pv_arr) \
+  X(pv_next) \
+  X(pv_pos) \
+  X(pv_krl) \
+  X(pv_period) \
+  X(pv_rfull) \
+  X(pv_rempty) \
+  X(REC_W) \
+  X(l_frame) \
+  X(l_priv) \
+  X(l_mt0) \
+  X(l_mt1) \
+  X(l_dsrc) \
+  X(l_dtgt) \
+  X(l_oq) \
+  X(l_odelay) \
+  X(l_srcn) \
+  X(l_misc) \
+  X(lds_words) \
+  X(l_ctab) \
+  X(ctab_words) \
+  X(decision_mode) \
+  X(data_mode) \
+  X(data_T) \
+  X(pregen) \
+  X(NTP)
+
 // Observation fused into the step kernel (mrx_cim_set_observation): per stepped env with a new decision,
 //   ports  [n_envs][P][np] = snapshot_list["ports"][decision frame :: port attrs]
 //   vessel [n_envs][nv]    = snapshot_list["vessels"][decision frame : decision vessel : vessel attrs]

@@ -19,6 +19,9 @@ struct Emu {
 
 extern "C" {
 
+// The plan's integer dimensions / layout offsets as "NAME value" lines (tools: kernel specialisation experiments).
+int emu_dump_dims(void* h, char* buf, int len);
+
 void* emu_create(const mrx_cim_topology* t, const mrx_cim_config* c, char* errbuf, int errlen) {
   Emu* e = new Emu();
   std::string err;
@@ -112,4 +115,20 @@ void emu_query(void* h, int node_type, const int32_t* ticks, int nt, int per_env
 }
 
 long emu_rounds(void* h) { return ((Emu*)h)->wave.rounds; }
+}
+
+extern "C" int emu_dump_dims(void* h, char* buf, int len) {
+  const CimParams& K = ((Emu*)h)->plan.kp;
+  std::string o;
+#define D(f) o += std::string(#f) + " " + std::to_string((long long)K.f) + "\n";
+  D(P) D(V) D(R) D(NT) D(NRP) D(past_n) D(future_n) D(vrows) D(FW) D(S) D(H) D(SMAX) D(T) D(start_tick) D(resolution)
+  D(max_actions) D(period) D(vol) D(total_containers) D(order_mode) D(use_order_rng) D(use_buffer_rng) D(has_order_init)
+  D(idx_order_init) D(idx_route) D(idx_order_num) D(idx_buffer) D(f_ports) D(f_vessels) D(f_fop) D(f_fov) D(f_plans)
+  D(misc_cap) D(NC) D(PW) D(pv_evt) D(pv_arr) D(pv_next) D(pv_pos) D(pv_krl) D(pv_period) D(pv_rfull) D(pv_rempty) D(REC_W)
+  D(l_frame) D(l_priv) D(l_mt0) D(l_mt1) D(l_dsrc) D(l_dtgt) D(l_oq) D(l_odelay) D(l_srcn) D(l_misc) D(lds_words) D(l_ctab)
+  D(ctab_words) D(decision_mode) D(data_mode) D(data_T) D(pregen) D(NTP)
+#undef D
+  if ((int)o.size() + 1 > len) return -1;
+  memcpy(buf, o.c_str(), o.size() + 1);
+  return (int)o.size();
 }

@@ -1,0 +1,93 @@
+"""The plan-specialised step kernels (mrx_cim_load_step_kernels) on an MI355X: same device source with the plan's dimensions
+as compile-time constants, so every parity check the generic kernels pass must pass unchanged."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests.golden_util import golden_cases, joint_golden_cases
+
+pytestmark = pytest.mark.gpu
+
+SUBSET = [c for i, c in enumerate(golden_cases()) if i % 3 == 0]
+
+
+class _Spec:
+    """GpuBackend with specialize=True (and a check that the specialised module really is in use)."""
+
+    def __new__(cls, *a, **kw):
+        import os
+        from tests.gpu_backend import GpuBackend
+        old = os.environ.get("MARO_AMD_SPECIALIZE")
+        os.environ["MARO_AMD_SPECIALIZE"] = "1"
+        try:
+            b = GpuBackend(*a, **kw)
+        finally:
+            if old is None:
+                del os.environ["MARO_AMD_SPECIALIZE"]
+            else:
+                os.environ["MARO_AMD_SPECIALIZE"] = old
+        assert b.eng.specialized
+        return b
+
+
+@pytest.mark.parametrize("name", SUBSET)
+def test_specialized_kernels_reproduce_reference(name):
+    from tests.backend_adapter import SingleEnvAdapter
+    from tests.test_oracle_golden import replay_case
+
+    def make(topo, kwargs):
+        return SingleEnvAdapter(_Spec(topo, n_envs=1, durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
+                                      max_snapshots=kwargs.get("max_snapshots"), max_actions=2))
+    replay_case(make, name)
+
+
+@pytest.mark.parametrize("name", joint_golden_cases()[:2])
+def test_specialized_kernels_joint_modes(name):
+    from tests.golden_util import replay_joint_case
+    from tests.test_emu_joint import JointAdapter
+
+    def make(topo, kwargs, mode):
+        return JointAdapter(_Spec(topo, n_envs=3, durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
+                                  max_snapshots=kwargs.get("max_snapshots"), max_actions=topo.n_vessels, decision_mode=mode), env=2)
+    replay_joint_case(make, name)
+
+
+@pytest.mark.parametrize("order_table", [0, -1])
+def test_specialized_equals_generic_batch_with_fused_observation(order_table):
+    """700 envs of global_trade.22p, device policy keyed on the decision: decisions, metrics, fused observations and the final
+    workspace state of a specialised engine equal the generic engine's, bit for bit."""
+    import torch
+
+    from maro_amd.cim.engine import CimBatchEngine
+    n, topo = 700, "global_trade.22p_l0.8"
+    seeds = torch.arange(n, dtype=torch.int64) * 5 + 2
+    engs = [CimBatchEngine(topo, n, durations=90, seeds=seeds, max_snapshots=5, order_table=order_table, specialize=s) for s in (False, True)]
+    assert not engs[0].specialized and engs[1].specialized
+    obs = [e.set_observation(["empty", "full", "shortage", "transfer_cost"], ["empty", "remaining_space"]) for e in engs]
+    acts = [torch.zeros((n, 1, 4), dtype=torch.int32, device="cuda") for _ in engs]
+    nact = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in engs]
+    for e in engs:
+        e.step()
+    for _ in range(300):
+        for e, a, k in zip(engs, acts, nact):
+            e.random_policy(-1, a, k)
+            e.step(a, k)
+        torch.cuda.synchronize()
+        assert torch.equal(engs[0].decisions, engs[1].decisions) and torch.equal(engs[0].metrics, engs[1].metrics)
+        assert torch.equal(obs[0][0], obs[1][0]) and torch.equal(obs[0][1], obs[1][1])
+    assert bool(engs[0].done.all()) and torch.equal(engs[0].done, engs[1].done)
+    assert torch.equal(engs[0].live, engs[1].live) and torch.equal(engs[0].ring, engs[1].ring) and int(engs[1].status.max()) == 0
+
+
+def test_code_object_of_another_plan_is_rejected():
+    from maro_amd import _lib
+    from maro_amd.cim import specialize as spec
+    from maro_amd.cim.engine import CimBatchEngine
+    eng = CimBatchEngine("toy.4p_ssdd_l0.0", 8, durations=50)
+    other = spec.plan_defines(eng._cs, _lib.MrxCimConfig(8, 0, 0, 51, 1, 0, 1, 0, 0, 0))
+    img = spec.code_object(other)
+    buf = ctypes.create_string_buffer(img, len(img))
+    assert _lib.load().mrx_cim_load_step_kernels(eng._h, buf, len(img), other.encode()) < 0
+    assert b"different plan" in _lib.load().mrx_last_error()
+    assert not eng.specialized and np.asarray(eng.step()[2].cpu()).sum() == 0   # still steps with the generic kernels

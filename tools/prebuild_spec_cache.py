@@ -1,0 +1,51 @@
+"""Compile the plan-specialised CIM step kernels (maro_amd/cim/specialize.py) ahead of time into the in-tree cache — no GPU
+needed.  `bench`: the plans bench.py uses by default (called by __graft_entry__.build()); `goldens`: every plan the golden
+replays create (for a full GPU test run with MARO_AMD_SPECIALIZE=1)."""
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def plans(which):
+    from maro_amd import _lib
+    from maro_amd.cim.topology import load_topology
+
+    def cfg(durations, res=1, ring=0, max_actions=1, mode=0, order_table=0, start_tick=0):
+        return _lib.MrxCimConfig(1, 0, start_tick, durations, res, ring or 0, max_actions, 0, mode, order_table)
+
+    out = []
+    if which in ("bench", "all"):
+        t = load_topology("global_trade.22p_l0.8")
+        out += [(t, cfg(1120, ring=4)), (t, cfg(1120, ring=8))]            # bench.py default / --policy dqn
+    if which in ("goldens", "all"):
+        from tests.golden_util import case_topology, golden_cases, joint_golden_cases, load_case, load_joint_case
+        for name in golden_cases():
+            meta = load_case(name)[1]
+            topo, kw = case_topology(meta), meta["kwargs"]
+            out.append((topo, cfg(kw["durations"], kw.get("snapshot_resolution", 1), kw.get("max_snapshots"), 2)))
+        for name in joint_golden_cases():
+            meta = load_joint_case(name)[1]
+            topo, kw = case_topology(meta), meta["kwargs"]
+            out.append((topo, cfg(kw["durations"], kw.get("snapshot_resolution", 1), kw.get("max_snapshots"), topo.n_vessels, meta["decision_mode"])))
+    return out
+
+
+def main(which="bench"):
+    from maro_amd.cim import specialize as spec
+    todo = {}
+    for topo, c in plans(which):
+        cs = topo.c_struct()
+        for order_table in (0, 1) if which != "bench" else (0,):
+            c.order_table = order_table
+            d = spec.plan_defines(cs, c)
+            todo[d] = 1
+    with ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as ex:
+        sizes = list(ex.map(lambda d: len(spec.code_object(d)), todo))
+    print(f"spec cache: {len(sizes)} plan(s) ready in {spec.CACHE}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "bench")
