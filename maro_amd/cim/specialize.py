@@ -1,7 +1,7 @@
 """Plan-specialised CIM step kernels: compile ``maro_amd/csrc/cim_spec.hip`` for one (topology, config) plan with every
 integer dimension / layout offset of the plan as a compile-time constant (the text of ``mrx_cim_plan_defines``), cache the
 gfx950 code object in-tree (``maro_amd/csrc/spec_cache/`` — git-ignored like the built ``.so``, so it travels with a repo
-snapshot), and hand it to ``mrx_cim_load_step_kernels``.  Compiling needs ``hipcc`` (no GPU); ~15 s per plan, once.
+snapshot), and hand it to ``mrx_cim_load_step_kernels``.  Compiling needs ``hipcc`` (no GPU); a few seconds per plan, once.
 """
 from __future__ import annotations
 

@@ -486,8 +486,8 @@ MRX_DEV void gen_orders(const CimParams& K, Lds& L, long long otg, int& idx_ord,
 //  cim_data_generator.py:18-205; parsers.py:57-106; sim_random.py:35-63)
 MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd) {
   Lds L = make_lds(K, lds);
-  uint32_t* mt_route = (uint32_t*)(lds + K.l_mt2);
-  uint32_t* mt_oinit = (uint32_t*)(lds + K.l_mt3);
+  uint32_t* mt_route = (uint32_t*)(lds + KD(l_mt2));
+  uint32_t* mt_oinit = (uint32_t*)(lds + KD(l_mt3));
   const int lane = wave::lane();
   const int P = KD(P), V = KD(V), TT = KD(T);
   uint32_t* g_mt = K.mt + (size_t)env * MTS_COUNT * MT_WORDS;
@@ -646,19 +646,19 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
 MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {
   const int lane = wave::lane();
   Lds L = make_lds(K, lds);
-  L.mt_ord = (uint32_t*)(lds + K.g_mt0);
-  L.dsrc = (double*)(lds + K.g_dsrc);
-  L.dtgt = (double*)(lds + K.g_dtgt);
-  L.oq = lds + K.g_oq;
-  L.srcn = lds + K.g_srcn;
-  stage_tables(K, L, lds + K.g_ctab);
+  L.mt_ord = (uint32_t*)(lds + KD(g_mt0));
+  L.dsrc = (double*)(lds + KD(g_dsrc));
+  L.dtgt = (double*)(lds + KD(g_dtgt));
+  L.oq = lds + KD(g_oq);
+  L.srcn = lds + KD(g_srcn);
+  stage_tables(K, L, lds + KD(g_ctab));
   copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(K.mt + ((size_t)env * MTS_COUNT + MTS_ORDER) * MT_WORDS), MT_WORDS);
   TickPf pf = {};
   tick_prefetch_static(K, pf, true);
   // the source ratio tables into LDS: a global load inside the tick loop would wait (vmcnt) for the previous tick's
   // row stores every time
   {
-    double* sb = (double*)(lds + K.g_srctab);
+    double* sb = (double*)(lds + KD(g_srctab));
     if (lane < KD(P)) { sb[lane] = K.src_base[lane]; sb[KD(P) + lane] = K.src_noise[lane]; }
     L.tab.src_base = sb; L.tab.src_noise = sb + KD(P);
   }

@@ -33,23 +33,6 @@ struct Prof {
 #include "cim_layout.h"
 
 // ------------------------------------------------------------------------------------------ kernels
-extern "C" __global__ void __launch_bounds__(64)
-mrx_k_cim_reset(CimParams K, const long long* __restrict__ seed_cmd, const uint8_t* __restrict__ mask, long long default_cmd) {
-  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-  const int env = blockIdx.x;
-  if (mask && !mask[env]) return;
-  cim::reset_env(K, env, lds, seed_cmd ? seed_cmd[env] : default_cmd);
-}
-
-extern "C" __global__ void __launch_bounds__(64)
-mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const uint8_t* __restrict__ mask, long long default_cmd) {
-  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-  const int env = blockIdx.x;
-  if (mask && !mask[env]) return;
-  if ((seed_cmd ? seed_cmd[env] : default_cmd) == -1) return;  // reset(keep_seed=True): same seed, same table
-  cim::gen_order_table(K, env, lds);
-}
-
 // Two builds of the step kernel: mrx_k_cim_step generates the tick's orders itself (any order mode);
 // mrx_k_cim_step_tab reads them from the order table drawn at reset (CimParams::pregen) and carries neither the
 // generator's code nor its LDS (order RNG state, fp64 scratch).
@@ -118,6 +101,7 @@ struct mrx_cim_engine {
   CimObs obs;  // fused observation (all zero = off)
   hipModule_t spec_module = nullptr;      // plan-specialised step kernels (mrx_cim_load_step_kernels), else the generic ones
   hipFunction_t spec_fn[4] = {nullptr, nullptr, nullptr, nullptr};  // [pregen * 2 + obs]
+  hipFunction_t spec_reset = nullptr, spec_order_table = nullptr;
   ~mrx_cim_engine() { if (spec_module) hipModuleUnload(spec_module); }
 };
 
@@ -218,9 +202,20 @@ int mrx_cim_reset(mrx_handle h, const int64_t* d_seed_cmd, const uint8_t* d_env_
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
   const CimParams& K = h->plan.kp;
+  const bool table = K.pregen && K.orders_stride && d_seed_cmd && !K.data_mode;  // envs that keep their seed keep their order table
+  if (h->spec_module) {  // plan-specialised builds of the same two kernels
+    CimParams Kc = K;
+    const long long* cmd = (const long long*)d_seed_cmd;
+    long long dflt = -1;
+    void* params[] = {&Kc, &cmd, &d_env_mask, &dflt};
+    HIP_TRY(hipModuleLaunchKernel(h->spec_reset, (unsigned)K.n_envs, 1, 1, 64, 1, 1, (unsigned)((size_t)K.lds_words_reset * 4), (hipStream_t)stream, params, nullptr));
+    if (table)
+      HIP_TRY(hipModuleLaunchKernel(h->spec_order_table, (unsigned)K.n_envs, 1, 1, 64, 1, 1, (unsigned)((size_t)K.lds_words_gen * 4), (hipStream_t)stream, params, nullptr));
+    return MRX_OK;
+  }
   hipLaunchKernelGGL(mrx_k_cim_reset, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_reset * 4, (hipStream_t)stream, K,
                      (const long long*)d_seed_cmd, d_env_mask, (long long)-1);
-  if (K.pregen && K.orders_stride && d_seed_cmd && !K.data_mode)  // envs that keep their seed keep their order table
+  if (table)
     hipLaunchKernelGGL(mrx_k_cim_order_table, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_gen * 4, (hipStream_t)stream, K,
                        (const long long*)d_seed_cmd, d_env_mask, (long long)-1);
   HIP_TRY(hipGetLastError());
@@ -403,9 +398,17 @@ int mrx_cim_load_step_kernels(mrx_handle h, const void* image, int64_t bytes, co
     }
     if ((size_t)h->plan.kp.lds_words * 4 > 64 * 1024) hipFuncSetAttribute((const void*)fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, h->plan.kp.lds_words * 4);
   }
+  hipFunction_t f_reset = nullptr, f_table = nullptr;
+  if (hipModuleGetFunction(&f_reset, mod, "mrx_k_cim_reset") != hipSuccess || hipModuleGetFunction(&f_table, mod, "mrx_k_cim_order_table") != hipSuccess) {
+    hipModuleUnload(mod);
+    return set_err(MRX_ERR_INVALID_ARG, "code object lacks the reset kernels");
+  }
+  if ((size_t)h->plan.kp.lds_words_reset * 4 > 64 * 1024) hipFuncSetAttribute((const void*)f_reset, hipFuncAttributeMaxDynamicSharedMemorySize, h->plan.kp.lds_words_reset * 4);
   if (h->spec_module) hipModuleUnload(h->spec_module);
   h->spec_module = mod;
   for (int i = 0; i < 4; i++) h->spec_fn[i] = fn[i];
+  h->spec_reset = f_reset;
+  h->spec_order_table = f_table;
   return MRX_OK;
 }
 

@@ -129,7 +129,18 @@ struct CimParams {
   X(data_mode) \
   X(data_T) \
   X(pregen) \
-  X(NTP)
+  X(NTP) \
+  X(l_mt2) \
+  X(l_mt3) \
+  X(lds_words_reset) \
+  X(g_mt0) \
+  X(g_dsrc) \
+  X(g_dtgt) \
+  X(g_oq) \
+  X(g_srcn) \
+  X(g_srctab) \
+  X(g_ctab) \
+  X(lds_words_gen)
 
 // Observation fused into the step kernel (mrx_cim_set_observation): per stepped env with a new decision,
 //   ports  [n_envs][P][np] = snapshot_list["ports"][decision frame :: port attrs]

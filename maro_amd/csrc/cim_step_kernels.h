@@ -1,6 +1,23 @@
 // cim_step_kernels.h — the four step-kernel entry points, shared by the generic build (cim_engine.hip, plan dimensions read
 // from the kernel arguments) and the plan-specialised build (cim_spec.hip, MRX_SPECIALIZED: dimensions are constants).
-// No include guard on purpose: it only instantiates kernels.
+// No include guard on purpose: it only instantiates kernels (reset, order table, and the four step kernels).
+extern "C" __global__ void __launch_bounds__(64)
+mrx_k_cim_reset(CimParams K, const long long* __restrict__ seed_cmd, const uint8_t* __restrict__ mask, long long default_cmd) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const int env = blockIdx.x;
+  if (mask && !mask[env]) return;
+  cim::reset_env(K, env, lds, seed_cmd ? seed_cmd[env] : default_cmd);
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const uint8_t* __restrict__ mask, long long default_cmd) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const int env = blockIdx.x;
+  if (mask && !mask[env]) return;
+  if ((seed_cmd ? seed_cmd[env] : default_cmd) == -1) return;  // reset(keep_seed=True): same seed, same table
+  cim::gen_order_table(K, env, lds);
+}
+
 #ifndef MRX_STEP_WAVES
 #define MRX_STEP_WAVES 2  // generic build: ~197 VGPRs, 2 waves/SIMD
 #endif
