@@ -356,31 +356,34 @@ def main():
 
     graphs = [None] * G
 
+    for eng, st in zip(engines, streams):
+        eng.use_stream(st)   # every engine call goes to its group's stream without a per-call stream switch
+
     def one_step(i, g, timing=None):
-        eng, b = engines[g], bufs[g]
-        with torch.cuda.stream(streams[g]):
-            if i == 0:
-                eng.step()  # first step of the episode: action=None
-                return
-            if graphs[g] is not None and timing is None:
+        eng, b, st = engines[g], bufs[g], streams[g]
+        if i == 0:
+            eng.step()  # first step of the episode: action=None
+            return
+        if graphs[g] is not None and timing is None:
+            with torch.cuda.stream(st):
                 graphs[g].replay()  # policy -> step -> snapshot slices, captured once (hipGraph)
-                return
-            if qnet is not None:
-                # mrx_cim_dqn_act: state gather + MFMA MLP + argmax + translation
-                if timing is not None:
-                    timing[2].record()
-                qnet[g].act(b["actions"], b["n_actions"], counter=b["counter"] if timing is None else None)
-            else:
-                eng.random_policy(-1 if args.graphs else i, b["actions"], b["n_actions"], b["counter"] if timing is None else None)
+            return
+        if qnet is not None:
+            # mrx_cim_dqn_act: state gather + MFMA MLP + argmax + translation
             if timing is not None:
-                timing[0].record()
-            eng.step(b["actions"], b["n_actions"])
-            if timing is not None:
-                timing[1].record()
-            if b["q_ports"] is not None:
-                # ports[frame::7 attrs] and vessels[frame:vessel:3 attrs] of the pending decision
-                eng.query("ports", eng.decisions[:, 6:7], ports, QUERY_ATTRS, out=b["q_ports"])
-                eng.query("vessels", eng.decisions[:, 6:7], eng.decisions[:, 2:3], VESSEL_QUERY_ATTRS, out=b["q_vessel"])
+                timing[2].record(st)
+            qnet[g].act(b["actions"], b["n_actions"], counter=b["counter"] if timing is None else None)
+        else:
+            eng.random_policy(-1 if args.graphs else i, b["actions"], b["n_actions"], b["counter"] if timing is None else None)
+        if timing is not None:
+            timing[0].record(st)
+        eng.step(b["actions"], b["n_actions"])
+        if timing is not None:
+            timing[1].record(st)
+        if b["q_ports"] is not None:
+            # ports[frame::7 attrs] and vessels[frame:vessel:3 attrs] of the pending decision
+            eng.query("ports", eng.decisions[:, 6:7], ports, QUERY_ATTRS, out=b["q_ports"])
+            eng.query("vessels", eng.decisions[:, 6:7], eng.decisions[:, 2:3], VESSEL_QUERY_ATTRS, out=b["q_vessel"])
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -424,6 +427,7 @@ def main():
         for g in range(G):
             one_step(step_i, g)
         step_i += 1
+    t_issued = time.perf_counter() - t0   # host time to enqueue every launch of the window (the loop never waits for the GPU)
     sync_all()
     dt = time.perf_counter() - t0
     # decisions answered inside the timed window (K policy calls per group in the window)
@@ -482,7 +486,7 @@ def main():
                                    f"{'random legal agent' if args.policy == 'random' else 'per-port dueling DQN (f32 MFMA, greedy) + CIMEnvSampler state shaping (mrx_cim_dqn_act)'} on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step (' + args.obs + ')'}",
                        "envs_per_gpu": n, "groups_per_gpu": G, "specialized_kernels": bool(engines[0].specialized), "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,
                        "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
-                       "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms,
+                       "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms, "host_enqueue_ms_per_step": t_issued / args.steps * 1e3,
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
             "roofline": {"bound": "hbm", "kernel": ("mrx_k_cim_step_tab" if engines[0].layout.order_table_on else "mrx_k_cim_step") + ("_obs" if bufs[0].get("obs") is not None else ""), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -70,6 +70,7 @@ class CimBatchEngine:
             _lib.check(self._L.mrx_cim_create(ctypes.byref(self._cs), ctypes.byref(self._cfg),
                                               self.workspace.data_ptr(), nbytes, ctypes.byref(h)), "mrx_cim_create")
         self._h = h
+        self._bound_stream, self._bound_handle = None, None
         self.specialized = False
         if specialize:
             from . import specialize as spec
@@ -107,12 +108,21 @@ class CimBatchEngine:
         n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
         return self.workspace[off:off + n].view(dtype).view(*shape)
 
+    def use_stream(self, stream: Optional[torch.cuda.Stream]) -> None:
+        """Bind every later call of this engine to `stream` (None: back to torch's current stream at call time).  A rollout
+        loop that drives several engines on their own streams saves the per-call stream lookup / context switch."""
+        self._bound_stream = stream
+        self._bound_handle = None if stream is None else stream.cuda_stream
+
     def _stream(self) -> int:
-        return torch.cuda.current_stream(self.device).cuda_stream
+        h = self._bound_handle
+        return torch.cuda.current_stream(self.device).cuda_stream if h is None else h
 
     def _dev(self, x, dtype) -> Optional[torch.Tensor]:
         if x is None:
             return None
+        if isinstance(x, torch.Tensor) and x.dtype == dtype and x.device == self.device and x.is_contiguous():
+            return x   # the usual case in a rollout loop: no conversion, no extra launch
         if not isinstance(x, torch.Tensor):
             x = torch.as_tensor(np.asarray(x), dtype=dtype)
         return x.to(device=self.device, dtype=dtype).contiguous()
