@@ -73,7 +73,7 @@ class PipelinedCimBatch:
     fill that tail (+30 % env-steps/s at 16384 envs).  Envs never interact, so this is pure scheduling:
     env e of the batch behaves exactly as in a single engine created with the same seeds.
 
-        batch = PipelinedCimBatch("global_trade.22p_l0.8", 16384, groups=3, durations=1120, max_snapshots=4)
+        batch = PipelinedCimBatch("global_trade.22p_l0.8", 16384, groups=3, durations=1120, max_snapshots=4, specialize=True)
         batch.for_each(lambda g, eng: eng.step())                          # first step of the episode
         batch.for_each(lambda g, eng: (policy(g, eng), eng.step(a[g], n[g])))   # one rollout step, all groups
         batch.synchronize()
@@ -91,6 +91,8 @@ class PipelinedCimBatch:
                                        seeds=seeds[self.offsets[g]:self.offsets[g] + self.sizes[g]], **engine_kwargs)
                         for g in range(groups)]
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(groups)]
+        for eng, st in zip(self.engines, self.streams):
+            eng.use_stream(st)   # engine calls go to the group's stream even outside for_each()
         torch.cuda.synchronize(self.device)
 
     def __len__(self) -> int:
