@@ -272,8 +272,9 @@ int mrx_cim_random_policy(mrx_handle h, const int32_t* d_decisions, int64_t step
  * saved as cim_spec_dims.h) has them as compile-time constants: ~40 % fewer VGPRs, no SGPR spill traffic, +15-20 % env-steps/s.
  *   mrx_cim_plan_defines       host only, no device needed: writes the "#define MRXC_<field> <value>" text of the plan that
  *                              (topo, cfg) produce into buf (n_envs does not matter); returns the bytes needed incl. the NUL
- *   mrx_cim_load_step_kernels  loads a gfx950 code object (hipcc --genco) holding mrx_k_cim_step{,_obs,_tab,_tab_obs} and
- *                              uses it for every later mrx_cim_step*; `defines` must equal the handle's own text (checked)
+ *   mrx_cim_load_step_kernels  loads a gfx950 code object (hipcc --genco of cim_spec.hip: the step-kernel pair of the plan's
+ *                              order mode, mrx_k_cim_reset, mrx_k_cim_order_table) and uses it for every later mrx_cim_step* /
+ *                              mrx_cim_reset; `defines` must equal the handle's own text (checked)
  */
 int64_t mrx_cim_plan_defines(const mrx_cim_topology* topo, const mrx_cim_config* cfg, char* buf, int64_t len);
 int mrx_cim_load_step_kernels(mrx_handle h, const void* image, int64_t bytes, const char* defines);
