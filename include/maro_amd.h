@@ -269,7 +269,7 @@ int mrx_cim_random_policy(mrx_handle h, const int32_t* d_decisions, int64_t step
 /*
  * Plan-specialised step kernels.  The generic kernels read the plan's ~65 integer dimensions / layout offsets from the kernel
  * arguments; a code object built from maro_amd/csrc/cim_spec.hip with those values as macros (the text this function returns,
- * saved as cim_spec_dims.h) has them as compile-time constants: ~40 % fewer VGPRs, no SGPR spill traffic, +15-20 % env-steps/s.
+ * saved as cim_spec_dims.h) has them as compile-time constants: 40 % fewer VGPRs, a third of the SGPR spill traffic, +12 % env-steps/s.
  *   mrx_cim_plan_defines       host only, no device needed: writes the "#define MRXC_<field> <value>" text of the plan that
  *                              (topo, cfg) produce into buf (n_envs does not matter); returns the bytes needed incl. the NUL
  *   mrx_cim_load_step_kernels  loads a gfx950 code object (hipcc --genco of cim_spec.hip: the step-kernel pair of the plan's

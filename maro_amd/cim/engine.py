@@ -41,7 +41,7 @@ class CimBatchEngine:
                  device: Union[str, torch.device] = "cuda:0", seeds: Optional[Sequence[int]] = None, order_table: int = 0,
                  decision_mode: int = 0, specialize: Union[bool, str, None] = None):
         """specialize: True = step with kernels compiled for this exact plan (maro_amd/cim/specialize.py: ~15 s of hipcc
-        the first time a (topology, config) is seen, cached in-tree; +15-20 % env-steps/s); "cached" = use them only if the
+        the first time a (topology, config) is seen, cached in-tree; +12 % env-steps/s); "cached" = use them only if the
         code object is already in the cache; False = the generic kernels; None = $MARO_AMD_SPECIALIZE ("1" / "cached" / "0"),
         default generic."""
         if specialize is None:
