@@ -152,8 +152,14 @@ def bench_citi_bike(args):
     n, res = args.envs, 10
     topology = args.topology if args.topology != "global_trade.22p_l0.8" else "toy.3s_4t"
     durations = args.durations if args.durations != 1120 else 44000
-    eng = CitiBikeBatchEngine(topology, n, durations=durations, snapshot_resolution=res, max_snapshots=16, max_actions=1, device=dev,
-                              seeds=np.arange(n) + rank * n + 1)
+    kw = dict(durations=durations, snapshot_resolution=res, max_snapshots=16, max_actions=1, device=dev, seeds=np.arange(n) + rank * n + 1)
+    try:
+        eng = CitiBikeBatchEngine(topology, n, specialize=bool(args.specialize), **kw)   # kernels compiled for this plan (cached in-tree)
+    except (RuntimeError, OSError, subprocess.CalledProcessError) as e:
+        if not args.specialize:
+            raise
+        print(f"bench: specialised kernels unavailable ({e}); using the generic ones", file=sys.stderr)
+        eng = CitiBikeBatchEngine(topology, n, specialize=False, **kw)
     S = eng.data.n_stations
     actions = torch.zeros((n, 1, 3), dtype=torch.int32, device=dev)
     n_actions = torch.zeros((n,), dtype=torch.int32, device=dev)
@@ -245,7 +251,7 @@ def bench_citi_bike(args):
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": f"citi_bike {topology}, {n} envs/GPU x {world} GPU, durations {durations}, resolution {res}, "
                                    f"device policy, stations snapshot slice {'off' if args.no_query else 'every step'}",
-                       "envs_per_gpu": n, "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective)",
+                       "envs_per_gpu": n, "specialized_kernels": bool(eng.specialized), "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective)",
                        "trajectory_gather_ms_32_steps": gather_ms, "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
             "roofline": {"bound": "hbm", "kernel": "mrx_k_cb_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": step_kernel_ms,

@@ -49,7 +49,8 @@ EXPORTS = ("mrx_last_error", "mrx_version", "mrx_cim_workspace_bytes", "mrx_cim_
            "mrx_cim_dqn_pack_net", "mrx_cim_dqn_scratch_bytes", "mrx_cim_dqn_act", "mrx_cim_plan_defines", "mrx_cim_load_step_kernels",
            # include/maro_amd_citi_bike.h
            "mrx_cb_workspace_bytes", "mrx_cb_create", "mrx_cb_destroy", "mrx_cb_get_layout", "mrx_cb_reset", "mrx_cb_step",
-           "mrx_cb_query", "mrx_cb_random_policy", "mrx_cb_attr_id", "mrx_cb_attr_slots")
+           "mrx_cb_query", "mrx_cb_random_policy", "mrx_cb_attr_id", "mrx_cb_attr_slots", "mrx_cb_plan_defines",
+           "mrx_cb_load_step_kernels")
 
 _lib = None
 
@@ -127,6 +128,10 @@ def load() -> ctypes.CDLL:
     L.mrx_cb_query.argtypes = [vp, i32, vp, i32, i32, vp, i32, i32, vp, i32, vp, vp]
     L.mrx_cb_random_policy.restype = i32
     L.mrx_cb_random_policy.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
+    L.mrx_cb_plan_defines.restype = i64
+    L.mrx_cb_plan_defines.argtypes = [vp, vp, ctypes.c_char_p, i64]
+    L.mrx_cb_load_step_kernels.restype = i32
+    L.mrx_cb_load_step_kernels.argtypes = [vp, vp, i64, ctypes.c_char_p]
     L.mrx_cb_attr_id.restype = i32
     L.mrx_cb_attr_id.argtypes = [i32, ctypes.c_char_p]
     L.mrx_cb_attr_slots.restype = i32

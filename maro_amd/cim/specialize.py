@@ -1,7 +1,7 @@
-"""Plan-specialised CIM step kernels: compile ``maro_amd/csrc/cim_spec.hip`` for one (topology, config) plan with every
-integer dimension / layout offset of the plan as a compile-time constant (the text of ``mrx_cim_plan_defines``), cache the
-gfx950 code object in-tree (``maro_amd/csrc/spec_cache/`` — git-ignored like the built ``.so``, so it travels with a repo
-snapshot), and hand it to ``mrx_cim_load_step_kernels``.  Compiling needs ``hipcc`` (no GPU); a few seconds per plan, once.
+"""Plan-specialised kernels: compile ``maro_amd/csrc/cim_spec.hip`` (CIM) or ``cb_spec.hip`` (citi_bike) for one plan with every
+integer dimension / layout offset of the plan as a compile-time constant (the text of ``mrx_cim_plan_defines`` /
+``mrx_cb_plan_defines``), cache the gfx950 code object in-tree (``maro_amd/csrc/spec_cache/`` — git-ignored like the built
+``.so``, so it travels with a repo snapshot), and hand it to ``mrx_cim_load_step_kernels`` / ``mrx_cb_load_step_kernels``.  Compiling needs ``hipcc`` (no GPU); a few seconds per plan, once.
 """
 from __future__ import annotations
 
@@ -18,30 +18,34 @@ CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 CACHE = os.environ.get("MARO_AMD_SPEC_CACHE", os.path.join(CSRC, "spec_cache"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"] + os.environ.get("MARO_AMD_SPEC_FLAGS", "").split()
-SOURCES = ("cim_spec.hip", "cim_step_kernels.h", "cim_device.h", "cim_params.h", "wave.h")
+UNITS = {   # scenario -> (translation unit, generated dims header, the sources the cache key covers, ABI prefix)
+    "cim": ("cim_spec.hip", "cim_spec_dims.h", ("cim_spec.hip", "cim_step_kernels.h", "cim_device.h", "cim_params.h", "wave.h"), "mrx_cim"),
+    "citi_bike": ("cb_spec.hip", "cb_spec_dims.h", ("cb_spec.hip", "cb_step_kernels.h", "cb_device.h", "cb_params.h", "wave.h"), "mrx_cb"),
+}
 
 
-def plan_defines(topo_struct, cfg) -> str:
+def plan_defines(topo_struct, cfg, scenario: str = "cim") -> str:
     """The plan's ``#define MRXC_<field> <value>`` text (host only; no device needed)."""
-    L = _lib.load()
-    n = _lib.check(L.mrx_cim_plan_defines(ctypes.byref(topo_struct), ctypes.byref(cfg), None, 0), "mrx_cim_plan_defines")
+    fn = getattr(_lib.load(), UNITS[scenario][3] + "_plan_defines")
+    n = _lib.check(fn(ctypes.byref(topo_struct), ctypes.byref(cfg), None, 0), fn.__name__)
     buf = ctypes.create_string_buffer(n)
-    _lib.check(L.mrx_cim_plan_defines(ctypes.byref(topo_struct), ctypes.byref(cfg), buf, n), "mrx_cim_plan_defines")
+    _lib.check(fn(ctypes.byref(topo_struct), ctypes.byref(cfg), buf, n), fn.__name__)
     return buf.value.decode()
 
 
-def _key(defines: str) -> str:
+def _key(defines: str, scenario: str) -> str:
     h = hashlib.sha256(defines.encode())
-    for name in SOURCES:
+    for name in UNITS[scenario][2]:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()[:24]
 
 
-def code_object(defines: str, build: bool = True) -> bytes:
-    """The gfx950 code object of cim_spec.hip for `defines` — from the cache, else compiled now (build=False: KeyError)."""
-    path = os.path.join(CACHE, _key(defines) + ".hsaco")
+def code_object(defines: str, build: bool = True, scenario: str = "cim") -> bytes:
+    """The gfx950 code object of the scenario's spec unit for `defines` — from the cache, else compiled now (build=False: KeyError)."""
+    unit, dims_header = UNITS[scenario][:2]
+    path = os.path.join(CACHE, _key(defines, scenario) + ".hsaco")
     if not os.path.exists(path):
         if not build:
             raise KeyError(path)
@@ -50,10 +54,10 @@ def code_object(defines: str, build: bool = True) -> bytes:
             raise RuntimeError("specialised CIM kernels requested but hipcc was not found (set HIPCC, or use specialize=False)")
         os.makedirs(CACHE, exist_ok=True)
         with tempfile.TemporaryDirectory() as tmp:
-            with open(os.path.join(tmp, "cim_spec_dims.h"), "w") as f:
-                f.write("// generated: mrx_cim_plan_defines\n" + defines)
+            with open(os.path.join(tmp, dims_header), "w") as f:
+                f.write("// generated: " + UNITS[scenario][3] + "_plan_defines\n" + defines)
             out = os.path.join(tmp, "spec.hsaco")
-            subprocess.check_call([hipcc] + FLAGS + ["-I", tmp, "-I", CSRC, "-o", out, os.path.join(CSRC, "cim_spec.hip")])
+            subprocess.check_call([hipcc] + FLAGS + ["-I", tmp, "-I", CSRC, "-o", out, os.path.join(CSRC, unit)])
             tmp_dst = path + f".{os.getpid()}.tmp"
             shutil.copyfile(out, tmp_dst)
             os.replace(tmp_dst, path)   # atomic: several ranks may build the same plan concurrently
@@ -61,7 +65,8 @@ def code_object(defines: str, build: bool = True) -> bytes:
         return f.read()
 
 
-def load_into(engine, defines: str, build: bool = True) -> None:
-    img = code_object(defines, build)
+def load_into(engine, defines: str, build: bool = True, scenario: str = "cim") -> None:
+    img = code_object(defines, build, scenario)
     buf = ctypes.create_string_buffer(img, len(img))
-    _lib.check(_lib.load().mrx_cim_load_step_kernels(engine._h, buf, len(img), defines.encode()), "mrx_cim_load_step_kernels")
+    fn = getattr(_lib.load(), UNITS[scenario][3] + "_load_step_kernels")
+    _lib.check(fn(engine._h, buf, len(img), defines.encode()), fn.__name__)

@@ -10,6 +10,7 @@ maro_amd/csrc/cb_engine.hip.  Tensor conventions are those of the C ABI:
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence, Union
 
 import numpy as np
@@ -27,7 +28,12 @@ class CitiBikeBatchEngine:
     def __init__(self, topology: Union[str, CitiBikeData], n_envs: int, start_tick: int = 0, durations: int = 1440,
                  snapshot_resolution: int = 1, max_snapshots: Optional[int] = None, max_actions: int = 1,
                  device: Union[str, torch.device] = "cuda:0", seeds: Optional[Sequence[int]] = None,
-                 delivery_capacity: int = 0, transfer_times_cap: int = 0):
+                 delivery_capacity: int = 0, transfer_times_cap: int = 0, specialize: Union[bool, str, None] = None):
+        """specialize: as CimBatchEngine — True = reset / step kernels compiled for this exact plan (maro_amd/cim/specialize.py,
+        a few seconds of hipcc the first time, cached in-tree), "cached" = only if already cached, False = generic kernels,
+        None = $MARO_AMD_SPECIALIZE."""
+        if specialize is None:
+            specialize = {"1": True, "cached": "cached"}.get(os.environ.get("MARO_AMD_SPECIALIZE", "0"), False)
         self._L = _lib.load()  # raises if the HIP extension is not built
         if not torch.cuda.is_available():
             raise RuntimeError("maro_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
@@ -54,6 +60,14 @@ class CitiBikeBatchEngine:
             _lib.check(self._L.mrx_cb_create(ctypes.byref(self._ts), ctypes.byref(self._cfg), self.workspace.data_ptr(), nbytes,
                                              ctypes.byref(h)), "mrx_cb_create")
         self._h = h
+        self.specialized = False
+        if specialize:
+            from ..cim import specialize as spec
+            try:
+                spec.load_into(self, spec.plan_defines(self._ts, self._cfg, "citi_bike"), build=specialize != "cached", scenario="citi_bike")
+                self.specialized = True
+            except KeyError:
+                pass   # "cached" and not in the cache: generic kernels
         self.layout = MrxCbLayout()
         _lib.check(self._L.mrx_cb_get_layout(self._h, ctypes.byref(self.layout)), "mrx_cb_get_layout")
         lay = self.layout

@@ -23,14 +23,25 @@
 
 #include "cb_params.h"
 
+// CD(f) / CDA(f, i): an integer dimension of the plan (CbParams::f, CbParams::f[i]).  The generic kernels read it from the
+// kernel arguments; a build specialised for one plan (cb_spec.hip, compiled at engine creation) turns every one of them into
+// a compile-time constant MRXC_f / MRXC_f(i): station loops unroll, the SoA strides fold, SGPR spills drop from 100 to 4.
+#ifdef MRX_SPECIALIZED
+#define CD(f) (MRXC_##f)
+#define CDA(f, i) (MRXC_##f(i))
+#else
+#define CD(f) (K.f)
+#define CDA(f, i) (K.f[i])
+#endif
+
 namespace cb {
 
-#define GHDR(w) K.hdr[(size_t)(w) * K.stride + e] /* header word in HBM */
+#define GHDR(w) K.hdr[(size_t)(w) * CD(stride) + e] /* header word in HBM */
 #define HDR(w) hd[(w)]                           /* header word of the env being stepped: a register copy (step_env) */
-#define ST(a, s) K.live[((size_t)(a) * K.S + (size_t)(s)) * K.stride + e]
-#define ADJ(i, j) K.live[((size_t)LV_COUNT * K.S + (size_t)(i) * K.S + (size_t)(j)) * K.stride + e]
-#define POOL(i, w) K.pool[((size_t)(i) * CB_POOL_WORDS + (w)) * K.stride + e]
-#define SCR(i) K.scratch[(size_t)(i) * K.stride + e]
+#define ST(a, s) K.live[((size_t)(a) * CD(S) + (size_t)(s)) * CD(stride) + e]
+#define ADJ(i, j) K.live[((size_t)LV_COUNT * CD(S) + (size_t)(i) * CD(S) + (size_t)(j)) * CD(stride) + e]
+#define POOL(i, w) K.pool[((size_t)(i) * CB_POOL_WORDS + (w)) * CD(stride) + e]
+#define SCR(i) K.scratch[(size_t)(i) * CD(stride) + e]
 
 MRX_DEV void set_bikes(const CbParams& K, int e, int s, int v) {  // station.py:71-75
   ST(LV_BIKES, s) = v;
@@ -41,12 +52,12 @@ MRX_DEV void set_bikes(const CbParams& K, int e, int s, int v) {  // station.py:
 MRX_DEV void move_to_neighbor(const CbParams& K, int e, int src, int cur, int number) {
   const int cnt = K.nb_cnt[cur];
   for (int i = 0; i < cnt && number > 0; i++) {
-    const int nb = K.nb[(size_t)cur * K.nb_stride + i];
+    const int nb = K.nb[(size_t)cur * CD(nb_stride) + i];
     const int b = ST(LV_BIKES, nb);
     int accept = K.capacity[nb] - b;
     if (accept > number) accept = number;
     set_bikes(K, e, nb, b + accept);
-    const int target = K.extra_cost_mode == 0 ? src : K.extra_cost_mode == 1 ? cur : nb;
+    const int target = CD(extra_cost_mode) == 0 ? src : CD(extra_cost_mode) == 1 ? cur : nb;
     ST(LV_EXTRA_COST, target) += accept * (i + 1);
     number -= accept;
   }
@@ -72,7 +83,7 @@ MRX_DEV void land_bikes(const CbParams& K, int e, int32_t* hd, bool deliver, int
 // `p` is the scan position (monotonic counter); entries are appended in scheduling order.
 MRX_DEV void pool_exec_until(const CbParams& K, int e, int32_t* hd, int t, int sched_lt, int& p, int tail) {
   while (p != tail) {
-    const int idx = p % K.pool_cap;
+    const int idx = p % CD(pool_cap);
     if (POOL(idx, 0) == t && POOL(idx, 4) >= 0) {
       if (POOL(idx, 1) >= sched_lt) return;
       land_bikes(K, e, hd, true, POOL(idx, 2), POOL(idx, 3), POOL(idx, 4));
@@ -85,11 +96,11 @@ MRX_DEV void pool_exec_until(const CbParams& K, int e, int32_t* hd, int t, int s
 MRX_DEV void pool_compact(const CbParams& K, int e, int32_t* hd) {
   int head = HDR(CH_POOL_HEAD);
   const int tail = HDR(CH_POOL_TAIL);
-  while (head != tail && POOL(head % K.pool_cap, 4) < 0) head++;
+  while (head != tail && POOL(head % CD(pool_cap), 4) < 0) head++;
   HDR(CH_POOL_HEAD) = head;
   int m = CB_NO_LAND;
   for (int p = head; p != tail; p++) {
-    const int idx = p % K.pool_cap;
+    const int idx = p % CD(pool_cap);
     if (POOL(idx, 4) >= 0 && POOL(idx, 0) < m) m = POOL(idx, 0);
   }
   HDR(CH_POOL_MINLAND) = m;
@@ -97,11 +108,11 @@ MRX_DEV void pool_compact(const CbParams& K, int e, int32_t* hd) {
 
 MRX_DEV void pool_push(const CbParams& K, int e, int32_t* hd, int land, int sched, int frm, int to, int n) {
   const int head = HDR(CH_POOL_HEAD), tail = HDR(CH_POOL_TAIL);
-  if (tail - head >= K.pool_cap) {
+  if (tail - head >= CD(pool_cap)) {
     HDR(CH_STATUS) |= MRX_CB_ENV_DELIVERY_OVERFLOW;
     return;
   }
-  const int idx = tail % K.pool_cap;
+  const int idx = tail % CD(pool_cap);
   POOL(idx, 0) = land; POOL(idx, 1) = sched; POOL(idx, 2) = frm; POOL(idx, 3) = to; POOL(idx, 4) = n;
   HDR(CH_POOL_TAIL) = tail + 1;
   if (land < HDR(CH_POOL_MINLAND)) HDR(CH_POOL_MINLAND) = land;
@@ -109,7 +120,7 @@ MRX_DEV void pool_push(const CbParams& K, int e, int32_t* hd, int land, int sche
 
 // phases 1-3 of tick t
 MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t) {
-  const int d = t - K.start_tick;
+  const int d = t - CD(start_tick);
   // ---- 1: events queued by earlier ticks, by (scheduling tick, ReturnBike before DeliverBike, insertion order)
   const bool deliveries = HDR(CH_POOL_MINLAND) == t;
   int p = HDR(CH_POOL_HEAD);
@@ -118,7 +129,7 @@ MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t) {
   for (int r = K.ret_off[d]; r < r_mid; r++) {
     const int i = K.ret_trip[r];
     if (deliveries) pool_exec_until(K, e, hd, t, K.trip_tick[i], p, tail);
-    if (K.fulfilled[(size_t)((i & K.w_mask) >> 5) * K.stride + e] >> (i & 31) & 1u) land_bikes(K, e, hd, false, K.trip_src[i], K.trip_dst[i], 1);
+    if (K.fulfilled[(size_t)((i & CD(w_mask)) >> 5) * CD(stride) + e] >> (i & 31) & 1u) land_bikes(K, e, hd, false, K.trip_src[i], K.trip_dst[i], 1);
   }
   if (deliveries) {
     pool_exec_until(K, e, hd, t, CB_NO_LAND, p, tail);
@@ -133,7 +144,7 @@ MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t) {
     ST(LV_TRIP_REQUIREMENT, src) += 1;
     ADJ(src, dst) += 1;
     n_trips++;
-    uint32_t& word = K.fulfilled[(size_t)((i & K.w_mask) >> 5) * K.stride + e];
+    uint32_t& word = K.fulfilled[(size_t)((i & CD(w_mask)) >> 5) * CD(stride) + e];
     if (b < 1) {
       ST(LV_SHORTAGE, src) += 1;
       n_short++;
@@ -146,34 +157,34 @@ MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t) {
   }
   if (n_trips) { HDR(CH_TRIPS) += n_trips; HDR(CH_SHORT) += n_short; }
   // ---- 3: RebalanceBike :468-492 + decision_strategy.py:229-251 (decided BEFORE the zero-duration returns run)
-  if ((t + 1) % K.dres == 0) {
-    for (int w = 0; w < K.mask_words; w++) {
+  if ((t + 1) % CD(dres) == 0) {
+    for (int w = 0; w < CD(mask_words); w++) {
       uint32_t sup = 0, dem = 0;
-      for (int j = 0; j < 32 && w * 32 + j < K.S; j++) {
+      for (int j = 0; j < 32 && w * 32 + j < CD(S); j++) {
         const int s = w * 32 + j;
         const double ratio = (double)ST(LV_BIKES, s) / (double)K.capacity[s];
         if (ratio >= K.supply_wm) sup |= 1u << j;
         else if (ratio <= K.demand_wm) dem |= 1u << j;
       }
-      K.decmask[(size_t)w * K.stride + e] = sup;
-      K.decmask[(size_t)(K.mask_words + w) * K.stride + e] = dem;
+      K.decmask[(size_t)w * CD(stride) + e] = sup;
+      K.decmask[(size_t)(CD(mask_words) + w) * CD(stride) + e] = dem;
     }
   }
   for (int r = r_mid; r < r_end; r++) {
     const int i = K.ret_trip[r];
-    if (K.fulfilled[(size_t)((i & K.w_mask) >> 5) * K.stride + e] >> (i & 31) & 1u) land_bikes(K, e, hd, false, K.trip_src[i], K.trip_dst[i], 1);
+    if (K.fulfilled[(size_t)((i & CD(w_mask)) >> 5) * CD(stride) + e] >> (i & 31) & 1u) land_bikes(K, e, hd, false, K.trip_src[i], K.trip_dst[i], 1);
   }
   HDR(CH_LATE) = 0;
 }
 
 // np_backend.pyx:481-518 — frame `fi` goes to ring slot fi % ring_slots (frames are taken in increasing order)
 MRX_DEV void take_snapshot(const CbParams& K, int e, int t) {
-  const int fi = (t - K.start_tick) / K.res, slot = fi % K.ring_slots;
-  int32_t* dst = K.ring + (size_t)slot * (K.FW + 1) * K.stride + e;
+  const int fi = (t - CD(start_tick)) / CD(res), slot = fi % CD(ring_slots);
+  int32_t* dst = K.ring + (size_t)slot * (CD(FW) + 1) * CD(stride) + e;
   const int32_t* src = K.live + e;
-  for (int w = 0; w < K.FW; w++) dst[(size_t)w * K.stride] = src[(size_t)w * K.stride];
-  dst[(size_t)K.FW * K.stride] = t;
-  K.ring_fi[(size_t)slot * K.stride + e] = fi;
+  for (int w = 0; w < CD(FW); w++) dst[(size_t)w * CD(stride)] = src[(size_t)w * CD(stride)];
+  dst[(size_t)CD(FW) * CD(stride)] = t;
+  K.ring_fi[(size_t)slot * CD(stride) + e] = fi;
 }
 
 // phases 5-6 of tick t; returns true when the episode is over
@@ -183,16 +194,16 @@ MRX_DEV bool end_tick(const CbParams& K, int e, int32_t* hd, int t) {
     pool_exec_until(K, e, hd, t, CB_NO_LAND, p, HDR(CH_POOL_TAIL));
     pool_compact(K, e, hd);
   }
-  const bool frame_end = (t + 1) % K.res == 0;  // post_step :130-147
+  const bool frame_end = (t + 1) % CD(res) == 0;  // post_step :130-147
   if (frame_end) {
     take_snapshot(K, e, t);
-    for (int s = 0; s < K.S; s++) {
+    for (int s = 0; s < CD(S); s++) {
       ST(LV_SHORTAGE, s) = 0; ST(LV_TRIP_REQUIREMENT, s) = 0; ST(LV_EXTRA_COST, s) = 0; ST(LV_TRANSFER_COST, s) = 0;
       ST(LV_FULFILLMENT, s) = 0; ST(LV_FAILED_RETURN, s) = 0;
       ST(LV_MIN_BIKES, s) = ST(LV_BIKES, s);
     }
   }
-  if (t + 1 == K.max_tick) {
+  if (t + 1 == CD(max_tick)) {
     if (!frame_end) take_snapshot(K, e, t);  // core.py:371-375: the last, partial frame
     return true;
   }
@@ -200,8 +211,8 @@ MRX_DEV bool end_tick(const CbParams& K, int e, int32_t* hd, int t) {
 }
 
 MRX_DEV int next_decision(const CbParams& K, int e, int* type) {
-  for (int w = 0; w < K.mask_words; w++) {
-    const uint32_t sup = K.decmask[(size_t)w * K.stride + e], dem = K.decmask[(size_t)(K.mask_words + w) * K.stride + e];
+  for (int w = 0; w < CD(mask_words); w++) {
+    const uint32_t sup = K.decmask[(size_t)w * CD(stride) + e], dem = K.decmask[(size_t)(CD(mask_words) + w) * CD(stride) + e];
     const uint32_t any = sup | dem;
     if (any) {
       int j = 0;
@@ -216,7 +227,7 @@ MRX_DEV int next_decision(const CbParams& K, int e, int* type) {
 // Partial selection sort of the scope work arrays (key, val, trips): the best `n_out` of `n` come first.
 // mode 0: (val, key) descending   1: (trips, key) ascending   2: (trips, key) descending
 MRX_DEV void scope_select(const CbParams& K, int e, int n, int n_out, int mode) {
-  const int S = K.S;
+  const int S = CD(S);
   for (int j = 0; j < n_out; j++) {
     int best = j;
     int bk = SCR(j), bv = mode == 0 ? SCR(S + j) : SCR(2 * S + j);
@@ -239,19 +250,19 @@ MRX_DEV void scope_select(const CbParams& K, int e, int n, int n_out, int mode) 
 // decision (the reference evaluates it lazily when the agent reads DecisionEvent.action_scope; reading it is
 // what feeds the TripsWindowFilter cache, :131-138).  Writes ordered (station, max) pairs; returns their count.
 MRX_DEV int action_scope(const CbParams& K, int e, int s, int type, int t, int32_t* out) {
-  const int S = K.S;
+  const int S = CD(S);
   int n = K.nb_cnt[s];
   for (int i = 0; i < n; i++) {
-    const int nb = K.nb[(size_t)s * K.nb_stride + i];
+    const int nb = K.nb[(size_t)s * CD(nb_stride) + i];
     SCR(i) = nb;
     SCR(S + i) = type == MRX_CB_SUPPLY ? K.capacity[nb] - ST(LV_BIKES, nb) : (int)floor((double)ST(LV_BIKES, nb) * K.scope_high);
   }
-  const int fi_cur = (t - K.start_tick) / K.res;
-  for (int f = 0; f < K.n_filters; f++) {
-    const int n_out = K.f_num[f] < n ? K.f_num[f] : n;
-    if (K.f_type[f] == MRX_CB_FILTER_DISTANCE) {
+  const int fi_cur = (t - CD(start_tick)) / CD(res);
+  for (int f = 0; f < CD(n_filters); f++) {
+    const int n_out = CDA(f_num, f) < n ? CDA(f_num, f) : n;
+    if (CDA(f_type, f) == MRX_CB_FILTER_DISTANCE) {
       n = n_out;  // still in distance order (cb_plan rejects a distance filter after a reordering one)
-    } else if (K.f_type[f] == MRX_CB_FILTER_REQUIREMENTS) {
+    } else if (CDA(f_type, f) == MRX_CB_FILTER_REQUIREMENTS) {
       scope_select(K, e, n, n_out, 0);
       n = n_out;
     } else {
@@ -259,20 +270,20 @@ MRX_DEV int action_scope(const CbParams& K, int e, int s, int type, int t, int32
       // snapshot, aliased to the live frame) included; a frame's value is frozen the first time it is seen,
       // except that the newest frame of the list is always re-read.  `lst[-0:]` is the whole list in Python,
       // so windows == 0 means "every frame, none of them special".
-      const int avail = fi_cur + 1 < K.ring_slots ? fi_cur + 1 : K.ring_slots;
-      const int aw = K.f_win[f] < avail ? K.f_win[f] : avail;
+      const int avail = fi_cur + 1 < CD(ring_slots) ? fi_cur + 1 : CD(ring_slots);
+      const int aw = CDA(f_win, f) < avail ? CDA(f_win, f) : avail;
       const int first = aw > 0 ? fi_cur - aw + 1 : fi_cur - avail + 1;
       for (int i = 0; i < n; i++) SCR(2 * S + i) = 0;
       for (int fi = first; fi <= fi_cur; fi++) {
-        const int slot = fi % K.ring_slots;
-        int32_t& cfi = K.twc_fi[(size_t)slot * K.stride + e];
-        int32_t* cache = K.twc + (size_t)slot * S * K.stride + e;
+        const int slot = fi % CD(ring_slots);
+        int32_t& cfi = K.twc_fi[(size_t)slot * CD(stride) + e];
+        int32_t* cache = K.twc + (size_t)slot * S * CD(stride) + e;
         if (fi == fi_cur && (aw > 0 || cfi != fi)) {
-          for (int x = 0; x < S; x++) cache[(size_t)x * K.stride] = ST(LV_TRIP_REQUIREMENT, x);
+          for (int x = 0; x < S; x++) cache[(size_t)x * CD(stride)] = ST(LV_TRIP_REQUIREMENT, x);
           cfi = fi;
         }
-        const int32_t* src = cfi == fi ? cache : K.ring + ((size_t)slot * (K.FW + 1) + (size_t)LV_TRIP_REQUIREMENT * S) * K.stride + e;
-        for (int i = 0; i < n; i++) SCR(2 * S + i) += src[(size_t)SCR(i) * K.stride];
+        const int32_t* src = cfi == fi ? cache : K.ring + ((size_t)slot * (CD(FW) + 1) + (size_t)LV_TRIP_REQUIREMENT * S) * CD(stride) + e;
+        for (int i = 0; i < n; i++) SCR(2 * S + i) += src[(size_t)SCR(i) * CD(stride)];
       }
       scope_select(K, e, n, n_out, type == MRX_CB_DEMAND ? 2 : 1);
       n = n_out;
@@ -281,15 +292,15 @@ MRX_DEV int action_scope(const CbParams& K, int e, int s, int type, int t, int32
   for (int i = 0; i < n; i++) { out[2 * i] = SCR(i); out[2 * i + 1] = SCR(S + i); }
   out[2 * n] = s;
   out[2 * n + 1] = type == MRX_CB_SUPPLY ? (int)floor((double)ST(LV_BIKES, s) * K.scope_low_keep) : K.capacity[s] - ST(LV_BIKES, s);
-  for (int i = n + 1; i < K.scope_cap; i++) { out[2 * i] = -1; out[2 * i + 1] = -1; }
+  for (int i = n + 1; i < CD(scope_cap); i++) { out[2 * i] = -1; out[2 * i + 1] = -1; }
   return n + 1;
 }
 
 // _on_action_received :521-559 for the pending decision of station `s` at tick t
 MRX_DEV void apply_actions(const CbParams& K, int e, int32_t* hd, int t, int s, const int32_t* actions, int n_actions) {
   // pop the decision from the tick's list
-  K.decmask[(size_t)(s >> 5) * K.stride + e] &= ~(1u << (s & 31));
-  K.decmask[(size_t)(K.mask_words + (s >> 5)) * K.stride + e] &= ~(1u << (s & 31));
+  K.decmask[(size_t)(s >> 5) * CD(stride) + e] &= ~(1u << (s & 31));
+  K.decmask[(size_t)(CD(mask_words) + (s >> 5)) * CD(stride) + e] &= ~(1u << (s & 31));
   // Reference behaviour (event_linked_list.py:86-108): when the answered decision was the LAST element of the
   // tick's list, popping it leaves `_tail` on the removed node, so a DeliverBike appended to this same tick
   // (transfer time 0) is linked behind it and never runs.  It does run when later decisions, or an earlier
@@ -299,17 +310,17 @@ MRX_DEV void apply_actions(const CbParams& K, int e, int32_t* hd, int t, int s, 
   for (int a = 0; a < n_actions; a++) {
     const int frm = actions[3 * a], to = actions[3 * a + 1], number = actions[3 * a + 2];
     if (frm < 0 || to < 0) continue;
-    if (frm >= K.S || to >= K.S) { HDR(CH_STATUS) |= MRX_CB_ENV_INVALID_ACTION; continue; }
+    if (frm >= CD(S) || to >= CD(S)) { HDR(CH_STATUS) |= MRX_CB_ENV_INVALID_ACTION; continue; }
     const int b = ST(LV_BIKES, frm);
     const int ex = b < number ? b : number;
     if (ex <= 0) continue;
     set_bikes(K, e, frm, b - ex);
     const int pos = HDR(CH_TT_POS);
     int tt = 1;
-    if (pos < K.tt_cap) tt = K.tt[(size_t)pos * K.stride + e];
+    if (pos < CD(tt_cap)) tt = K.tt[(size_t)pos * CD(stride) + e];
     else HDR(CH_STATUS) |= MRX_CB_ENV_TRANSFER_TIMES_OUT;
     HDR(CH_TT_POS) = pos + 1;
-    if (tt < 0 || t + tt >= K.max_tick) continue;  // lands in the past / after the episode: never executed
+    if (tt < 0 || t + tt >= CD(max_tick)) continue;  // lands in the past / after the episode: never executed
     if (tt == 0) {
       if (tail_stale) continue;
       HDR(CH_LATE) += 1;
@@ -344,7 +355,7 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
         HDR(CH_CUR_STATION) = s;
         HDR(CH_CUR_TYPE) = type;
         HDR(CH_NDEC) += 1;
-        dec[0] = t; dec[1] = s; dec[2] = type; dec[3] = (t - K.start_tick) / K.res;
+        dec[0] = t; dec[1] = s; dec[2] = type; dec[3] = (t - CD(start_tick)) / CD(res);
         dec[4] = action_scope(K, e, s, type, t, scope);
         dec[5] = 1; dec[6] = 0; dec[7] = 0;
         break;
@@ -363,8 +374,8 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     for (int w = 0; w < CH_WORDS; w++) GHDR(w) = hd[w];
   }
   if (finished) {
-    dec[0] = t; dec[1] = -1; dec[2] = -1; dec[3] = (t - K.start_tick) / K.res; dec[4] = 0; dec[5] = 0; dec[6] = 0; dec[7] = 0;
-    for (int i = 0; i < K.scope_cap; i++) { scope[2 * i] = -1; scope[2 * i + 1] = -1; }
+    dec[0] = t; dec[1] = -1; dec[2] = -1; dec[3] = (t - CD(start_tick)) / CD(res); dec[4] = 0; dec[5] = 0; dec[6] = 0; dec[7] = 0;
+    for (int i = 0; i < CD(scope_cap); i++) { scope[2 * i] = -1; scope[2 * i + 1] = -1; }
   }
   met[0] = HDR(CH_TRIPS); met[1] = HDR(CH_SHORT); met[2] = HDR(CH_OPER);
   *done = finished ? 1 : 0;
@@ -373,19 +384,19 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
 // Env.reset: citi_bike/business_engine.py:164-190, station.py:63-69
 MRX_DEV void reset_env(const CbParams& K, int e) {
   for (int w = 0; w < CH_WORDS; w++) GHDR(w) = 0;
-  GHDR(CH_TICK) = K.start_tick;
+  GHDR(CH_TICK) = CD(start_tick);
   GHDR(CH_FLAGS) = CFL_FRESH;
   GHDR(CH_POOL_MINLAND) = CB_NO_LAND;
-  for (int w = 0; w < K.FW; w++) K.live[(size_t)w * K.stride + e] = 0;
-  for (int s = 0; s < K.S; s++) { ST(LV_BIKES, s) = K.init_bikes[s]; ST(LV_MIN_BIKES, s) = K.init_bikes[s]; }
-  for (int i = 0; i < K.ring_slots; i++) { K.ring_fi[(size_t)i * K.stride + e] = -1; K.twc_fi[(size_t)i * K.stride + e] = -1; }
-  for (int w = 0; w < 2 * K.mask_words; w++) K.decmask[(size_t)w * K.stride + e] = 0;
-  for (int w = 0; w < K.w_words; w++) K.fulfilled[(size_t)w * K.stride + e] = 0;
+  for (int w = 0; w < CD(FW); w++) K.live[(size_t)w * CD(stride) + e] = 0;
+  for (int s = 0; s < CD(S); s++) { ST(LV_BIKES, s) = K.init_bikes[s]; ST(LV_MIN_BIKES, s) = K.init_bikes[s]; }
+  for (int i = 0; i < CD(ring_slots); i++) { K.ring_fi[(size_t)i * CD(stride) + e] = -1; K.twc_fi[(size_t)i * CD(stride) + e] = -1; }
+  for (int w = 0; w < 2 * CD(mask_words); w++) K.decmask[(size_t)w * CD(stride) + e] = 0;
+  for (int w = 0; w < CD(w_words); w++) K.fulfilled[(size_t)w * CD(stride) + e] = 0;
 }
 
 MRX_DEV int attr_slots(const CbParams& K, int node_type, int attr) {
   if (node_type == 0) return attr >= 0 && attr < SA_COUNT ? 1 : 0;
-  return attr == CB_MA_TRIPS_ADJ ? K.S * K.S : 0;
+  return attr == CB_MA_TRIPS_ADJ ? CD(S) * CD(S) : 0;
 }
 
 // one element of snapshot_list[...]: row = (env, tick, node), col = flat (attr, slot)
@@ -396,20 +407,20 @@ MRX_DEV double query_elem(const CbParams& K, int node_type, const int32_t* ticks
   const int e = (int)(row / ((long long)nn * nt));
   const int fi = ticks[(size_t)e * ticks_per_env + ti];
   if (fi < 0) return 0.0;
-  const int slot = fi % K.ring_slots;
+  const int slot = fi % CD(ring_slots);
   // while an env is paused at a decision its current frame is the live frame (core.py:345), which also evicts
   // whatever the slot held
   const int flags = GHDR(CH_FLAGS);
   const bool paused = (flags & (CFL_FRESH | CFL_FINISHED)) == 0;
   const int t_cur = GHDR(CH_TICK);
-  const int cur_fi = (t_cur - K.start_tick) / K.res;
+  const int cur_fi = (t_cur - CD(start_tick)) / CD(res);
   const int32_t* frame;
   int t_frame;
   if (paused && fi == cur_fi) { frame = K.live + e; t_frame = t_cur; }
-  else if (paused && slot == cur_fi % K.ring_slots) return 0.0;
-  else if (K.ring_fi[(size_t)slot * K.stride + e] == fi) {
-    frame = K.ring + (size_t)slot * (K.FW + 1) * K.stride + e;
-    t_frame = frame[(size_t)K.FW * K.stride];
+  else if (paused && slot == cur_fi % CD(ring_slots)) return 0.0;
+  else if (K.ring_fi[(size_t)slot * CD(stride) + e] == fi) {
+    frame = K.ring + (size_t)slot * (CD(FW) + 1) * CD(stride) + e;
+    t_frame = frame[(size_t)CD(FW) * CD(stride)];
   } else return 0.0;  // padding for missing frames, np_backend.pyx:541-545
   int a = 0, sl = col;
   for (int i = 0; i < na; i++) {
@@ -418,8 +429,8 @@ MRX_DEV double query_elem(const CbParams& K, int node_type, const int32_t* ticks
     sl -= ns;
   }
   const int node = nodes[(size_t)e * nodes_per_env + ni];
-  if (node_type == 1) return node == 0 ? (double)frame[((size_t)LV_COUNT * K.S + sl) * K.stride] : 0.0;
-  if (node < 0 || node >= K.S) return 0.0;
+  if (node_type == 1) return node == 0 ? (double)frame[((size_t)LV_COUNT * CD(S) + sl) * CD(stride)] : 0.0;
+  if (node < 0 || node >= CD(S)) return 0.0;
   int lv = -1;
   switch (a) {
     case SA_BIKES: lv = LV_BIKES; break;
@@ -432,9 +443,9 @@ MRX_DEV double query_elem(const CbParams& K, int node_type, const int32_t* ticks
     case SA_MIN_BIKES: lv = LV_MIN_BIKES; break;
     case SA_CAPACITY: return (double)K.capacity[node];
     case SA_ID: return (double)K.station_id[node];
-    default: return (double)K.cal[(size_t)K.tick_day[t_frame - K.start_tick] * 4 + (a - SA_WEEKDAY)];
+    default: return (double)K.cal[(size_t)K.tick_day[t_frame - CD(start_tick)] * 4 + (a - SA_WEEKDAY)];
   }
-  return (double)frame[((size_t)lv * K.S + node) * K.stride];
+  return (double)frame[((size_t)lv * CD(S) + node) * CD(stride)];
 }
 
 MRX_DEV uint64_t mix64(uint64_t x) {  // splitmix64 finaliser

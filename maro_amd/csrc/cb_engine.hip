@@ -18,25 +18,7 @@
 int mrx_set_error_(int code, const std::string& m);  // cim_engine.hip (thread-local message behind mrx_last_error)
 
 // ------------------------------------------------------------------------------------------ kernels
-extern "C" __global__ void __launch_bounds__(64)
-mrx_k_cb_reset(CbParams K, const int32_t* __restrict__ tt, int n_times, const uint8_t* __restrict__ mask) {
-  const int e = blockIdx.x * 64 + threadIdx.x;
-  if (e >= K.n_envs || (mask && !mask[e])) return;
-  if (tt)
-    for (int i = 0; i < K.tt_cap; i++) K.tt[(size_t)i * K.stride + e] = i < n_times ? tt[(size_t)e * n_times + i] : 1;
-  cb::reset_env(K, e);
-}
-
-extern "C" __global__ void __launch_bounds__(64)
-mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions, const uint8_t* __restrict__ mask,
-              int32_t* __restrict__ decisions, int32_t* __restrict__ scope, long long* __restrict__ metrics, uint8_t* __restrict__ done) {
-  const int e = blockIdx.x * 64 + threadIdx.x;
-  if (e >= K.n_envs || (mask && !mask[e])) return;
-  int na = (actions && n_actions) ? n_actions[e] : 0;
-  if (na > K.max_actions) na = K.max_actions;
-  cb::step_env(K, e, actions ? actions + (size_t)e * K.max_actions * 3 : nullptr, na, decisions + (size_t)e * 8,
-               scope + (size_t)e * K.scope_cap * 2, (int64_t*)metrics + (size_t)e * 3, done + e);
-}
+#include "cb_step_kernels.h"
 
 struct CbAttrList { int n; int32_t id[16]; };
 
@@ -73,6 +55,9 @@ mrx_k_cb_random_policy(CbParams K, const int32_t* __restrict__ decisions, const 
 struct mrx_cb_engine {
   CbHostPlan plan;
   int device;
+  hipModule_t spec_module = nullptr;   // plan-specialised reset / step kernels (mrx_cb_load_step_kernels), else the generic ones
+  hipFunction_t spec_reset = nullptr, spec_step = nullptr;
+  ~mrx_cb_engine() { if (spec_module) hipModuleUnload(spec_module); }
 };
 
 static int set_err(int code, const std::string& m) { return mrx_set_error_(code, m); }
@@ -149,6 +134,13 @@ int mrx_cb_reset(mrx_cb_handle h, const int32_t* d_transfer_times, int32_t n_tim
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
   const CbParams& K = h->plan.kp;
+  if (h->spec_module) {
+    CbParams Kc = K;
+    int nt = (int)n_times;
+    void* params[] = {&Kc, &d_transfer_times, &nt, &d_env_mask};
+    HIP_TRY(hipModuleLaunchKernel(h->spec_reset, (unsigned)((K.n_envs + 63) / 64), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, params, nullptr));
+    return MRX_OK;
+  }
   hipLaunchKernelGGL(mrx_k_cb_reset, dim3((K.n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, K, d_transfer_times, (int)n_times, d_env_mask);
   HIP_TRY(hipGetLastError());
   return MRX_OK;
@@ -160,9 +152,62 @@ int mrx_cb_step(mrx_cb_handle h, const int32_t* d_actions, const int32_t* d_n_ac
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
   const CbParams& K = h->plan.kp;
+  if (h->spec_module) {
+    CbParams Kc = K;
+    long long* met = (long long*)d_metrics;
+    void* params[] = {&Kc, &d_actions, &d_n_actions, &d_env_mask, &d_decisions, &d_scope, &met, &d_done};
+    HIP_TRY(hipModuleLaunchKernel(h->spec_step, (unsigned)((K.n_envs + 63) / 64), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, params, nullptr));
+    return MRX_OK;
+  }
   hipLaunchKernelGGL(mrx_k_cb_step, dim3((K.n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, K, d_actions, d_n_actions, d_env_mask,
                      d_decisions, d_scope, (long long*)d_metrics, d_done);
   HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+// ---- plan-specialised kernels (cb_spec.hip)
+static std::string cb_plan_defines(const CbParams& K) {
+  std::string o;
+#define X(f) o += std::string("#define MRXC_") + #f + " " + std::to_string((long long)K.f) + "\n";
+  MRX_CB_DIM_FIELDS(X)
+#undef X
+#define X(f)                                                                                                    \
+  o += std::string("#define MRXC_") + #f + "(i) ((i) == 0 ? " + std::to_string(K.f[0]) + " : (i) == 1 ? " +     \
+       std::to_string(K.f[1]) + " : (i) == 2 ? " + std::to_string(K.f[2]) + " : " + std::to_string(K.f[3]) + ")\n";
+  MRX_CB_DIM_ARRAYS(X)
+#undef X
+  return o;
+}
+
+int64_t mrx_cb_plan_defines(const mrx_cb_topology* topo, const mrx_cb_config* cfg, char* buf, int64_t len) {
+  CbHostPlan plan;
+  std::string err;
+  const int rc = cb_plan(topo, cfg, &plan, &err);
+  if (rc != MRX_OK) return set_err(rc, err);
+  const std::string d = cb_plan_defines(plan.kp);
+  if (buf && len > 0) {
+    if ((int64_t)d.size() + 1 > len) return set_err(MRX_ERR_INVALID_ARG, "buffer too small");
+    memcpy(buf, d.c_str(), d.size() + 1);
+  }
+  return (int64_t)d.size() + 1;
+}
+
+int mrx_cb_load_step_kernels(mrx_cb_handle h, const void* image, int64_t bytes, const char* defines) {
+  if (!h || !image || bytes <= 0 || !defines) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
+  if (cb_plan_defines(h->plan.kp) != defines) return set_err(MRX_ERR_INVALID_ARG, "the code object was built for a different plan (defines differ)");
+  int rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  hipModule_t mod = nullptr;
+  HIP_TRY(hipModuleLoadData(&mod, image));
+  hipFunction_t f_reset = nullptr, f_step = nullptr;
+  if (hipModuleGetFunction(&f_reset, mod, "mrx_k_cb_reset") != hipSuccess || hipModuleGetFunction(&f_step, mod, "mrx_k_cb_step") != hipSuccess) {
+    hipModuleUnload(mod);
+    return set_err(MRX_ERR_INVALID_ARG, "code object lacks mrx_k_cb_reset / mrx_k_cb_step");
+  }
+  if (h->spec_module) hipModuleUnload(h->spec_module);
+  h->spec_module = mod;
+  h->spec_reset = f_reset;
+  h->spec_step = f_step;
   return MRX_OK;
 }
 

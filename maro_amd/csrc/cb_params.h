@@ -42,3 +42,26 @@ struct CbParams {
   const int32_t *capacity, *init_bikes, *station_id, *nb, *nb_cnt;
   const int32_t *tick_day, *cal;  // tick_day [durations] (relative to start_tick) -> cal [n_days][4] weekday, temperature, weather, holiday
 };
+
+// The integer fields of CbParams that are constant for one (topology, config, batch size) plan: what a specialised build
+// (cb_spec.hip) receives as MRXC_<field> macros (CD() in cb_device.h); the filter arrays become MRXC_f_type(i) etc.
+#define MRX_CB_DIM_FIELDS(X) \
+  X(stride) \
+  X(S) \
+  X(start_tick) \
+  X(max_tick) \
+  X(res) \
+  X(ring_slots) \
+  X(max_actions) \
+  X(dres) \
+  X(extra_cost_mode) \
+  X(n_filters) \
+  X(FW) \
+  X(w_mask) \
+  X(w_words) \
+  X(pool_cap) \
+  X(tt_cap) \
+  X(scope_cap) \
+  X(mask_words) \
+  X(nb_stride)
+#define MRX_CB_DIM_ARRAYS(X) X(f_type) X(f_num) X(f_win)

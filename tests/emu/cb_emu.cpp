@@ -81,3 +81,17 @@ void cb_emu_random_policy(void* h, const int32_t* dec, const int32_t* scope, int
                           actions + (size_t)env * K.max_actions * 3, n_actions + env);
 }
 }
+
+// The plan's integer dimensions as "NAME value" lines (tools: kernel specialisation experiments).
+extern "C" int cb_emu_dump_dims(void* h, char* buf, int len) {
+  const CbParams& K = ((CbEmu*)h)->plan.kp;
+  std::string o;
+#define D(f) o += std::string(#f) + " " + std::to_string((long long)K.f) + "\n";
+  D(stride) D(S) D(start_tick) D(max_tick) D(res) D(ring_slots) D(max_actions) D(dres) D(extra_cost_mode) D(n_filters) D(FW)
+  D(w_mask) D(w_words) D(pool_cap) D(tt_cap) D(scope_cap) D(mask_words) D(nb_stride)
+#undef D
+  for (int i = 0; i < 4; i++) o += "f_type[" + std::to_string(i) + "] " + std::to_string(K.f_type[i]) + "\nf_num[" + std::to_string(i) + "] " + std::to_string(K.f_num[i]) + "\nf_win[" + std::to_string(i) + "] " + std::to_string(K.f_win[i]) + "\n";
+  if ((int)o.size() + 1 > len) return -1;
+  memcpy(buf, o.c_str(), o.size() + 1);
+  return (int)o.size();
+}

@@ -91,3 +91,45 @@ def test_code_object_of_another_plan_is_rejected():
     assert _lib.load().mrx_cim_load_step_kernels(eng._h, buf, len(img), other.encode()) < 0
     assert b"different plan" in _lib.load().mrx_last_error()
     assert not eng.specialized and np.asarray(eng.step()[2].cpu()).sum() == 0   # still steps with the generic kernels
+
+
+# ---- citi_bike: mrx_cb_load_step_kernels
+def _cb_cases():
+    from tests.test_citi_bike_oracle import CASES
+    return [c for i, c in enumerate(CASES) if i % 3 == 0]
+
+
+@pytest.mark.parametrize("case", _cb_cases())
+def test_specialized_citi_bike_kernels_reproduce_reference(case, monkeypatch):
+    from tests.cb_backend_adapter import CbBackendEnv
+    from tests.cb_gpu_backend import CbGpuBackend
+    from tests.test_citi_bike_oracle import replay_citi_bike
+    monkeypatch.setenv("MARO_AMD_SPECIALIZE", "1")
+
+    def make(data, kw, tt, n_envs=70):
+        b = CbGpuBackend(data, n_envs=n_envs, max_actions=1, **kw)
+        assert b.eng.specialized
+        b.reset(transfer_times=[tt[: b.layout.transfer_times_cap]] * n_envs)   # the reset kernel is specialised too
+        return CbBackendEnv(b, env=n_envs - 1)
+    replay_citi_bike(make, case)
+
+
+def test_specialized_citi_bike_equals_generic_batch():
+    import torch
+
+    from maro_amd.citi_bike.engine import CitiBikeBatchEngine
+    n = 300
+    engs = [CitiBikeBatchEngine("toy.5s_6t", n, durations=1500, snapshot_resolution=10, seeds=np.arange(n) + 3, specialize=s) for s in (False, True)]
+    assert not engs[0].specialized and engs[1].specialized
+    acts = [torch.zeros((n, 1, 3), dtype=torch.int32, device="cuda") for _ in engs]
+    nact = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in engs]
+    outs = [e.step() for e in engs]
+    for i in range(400):
+        for e, a, k in zip(engs, acts, nact):
+            e.random_policy(i, a, k)
+        outs = [e.step(a, k) for e, a, k in zip(engs, acts, nact)]
+        torch.cuda.synchronize()
+        for x, y in zip(*outs):
+            assert torch.equal(x, y), i
+    for name in ("hdr", "live", "ring", "ring_fi"):   # the engines' state views (the raw workspace also holds scratch areas)
+        assert torch.equal(getattr(engs[0], name), getattr(engs[1], name)), name

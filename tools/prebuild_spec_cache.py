@@ -42,8 +42,18 @@ def main(which="bench"):
             c.order_table = order_table
             d = spec.plan_defines(cs, c)
             todo[d] = 1
+    if which in ("bench", "all"):   # bench.py --scenario citi_bike: toy.3s_4t, 4096 envs per GPU
+        import numpy as np
+
+        from maro_amd.citi_bike.abi import MrxCbConfig, topology_struct
+        from maro_amd.citi_bike.data import load_topology as load_cb
+        data = load_cb("toy.3s_4t")
+        ts, keep = topology_struct(data)
+        cap = data.n_stations * (int((data.time_mean + 6 * data.time_std) / max(data.resolution, 1)) + 2) + 4
+        todo[("citi_bike", spec.plan_defines(ts, MrxCbConfig(4096, 0, 0, 44000, 10, 16, 1, cap, 0), "citi_bike"))] = 1
+        del np, keep
     with ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as ex:
-        sizes = list(ex.map(lambda d: len(spec.code_object(d)), todo))
+        sizes = list(ex.map(lambda d: len(spec.code_object(d[1], scenario=d[0]) if isinstance(d, tuple) else spec.code_object(d)), todo))
     print(f"spec cache: {len(sizes)} plan(s) ready in {spec.CACHE}")
 
 
