@@ -271,12 +271,16 @@ int mrx_cim_random_policy(mrx_handle h, const int32_t* d_decisions, int64_t step
  * arguments; a code object built from maro_amd/csrc/cim_spec.hip with those values as macros (the text this function returns,
  * saved as cim_spec_dims.h) has them as compile-time constants: 40 % fewer VGPRs, a third of the SGPR spill traffic, +12 % env-steps/s.
  *   mrx_cim_plan_defines       host only, no device needed: writes the "#define MRXC_<field> <value>" text of the plan that
- *                              (topo, cfg) produce into buf (n_envs does not matter); returns the bytes needed incl. the NUL
+ *                              (topo, cfg) produce — n_envs does not matter — and of the fused observation's configuration
+ *                              (the attribute lists of mrx_cim_set_observation; 0 attributes = off) into buf; returns the
+ *                              bytes needed incl. the NUL.  mrx_cim_set_observation with another configuration drops a loaded
+ *                              code object (generic kernels again) until one built for the new text is loaded
  *   mrx_cim_load_step_kernels  loads a gfx950 code object (hipcc --genco of cim_spec.hip: the step-kernel pair of the plan's
  *                              order mode, mrx_k_cim_reset, mrx_k_cim_order_table) and uses it for every later mrx_cim_step* /
- *                              mrx_cim_reset; `defines` must equal the handle's own text (checked)
+ *                              mrx_cim_reset; `defines` must equal the handle's own text, observation included (checked)
  */
-int64_t mrx_cim_plan_defines(const mrx_cim_topology* topo, const mrx_cim_config* cfg, char* buf, int64_t len);
+int64_t mrx_cim_plan_defines(const mrx_cim_topology* topo, const mrx_cim_config* cfg, const int32_t* obs_port_attrs, int n_obs_port_attrs,
+                             const int32_t* obs_vessel_attrs, int n_obs_vessel_attrs, char* buf, int64_t len);
 int mrx_cim_load_step_kernels(mrx_handle h, const void* image, int64_t bytes, const char* defines);
 
 /*

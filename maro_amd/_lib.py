@@ -96,7 +96,7 @@ def load() -> ctypes.CDLL:
     L.mrx_cim_set_observation.restype = i32
     L.mrx_cim_set_observation.argtypes = [vp, vp, i32, vp, i32, vp, vp]
     L.mrx_cim_plan_defines.restype = i64
-    L.mrx_cim_plan_defines.argtypes = [vp, vp, ctypes.c_char_p, i64]
+    L.mrx_cim_plan_defines.argtypes = [vp, vp, vp, i32, vp, i32, ctypes.c_char_p, i64]
     L.mrx_cim_load_step_kernels.restype = i32
     L.mrx_cim_load_step_kernels.argtypes = [vp, vp, i64, ctypes.c_char_p]
     L.mrx_cim_dqn_net_floats.restype = i64

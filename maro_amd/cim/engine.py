@@ -72,13 +72,8 @@ class CimBatchEngine:
         self._h = h
         self._bound_stream, self._bound_handle = None, None
         self.specialized = False
-        if specialize:
-            from . import specialize as spec
-            try:
-                spec.load_into(self, spec.plan_defines(self._cs, self._cfg), build=specialize != "cached")
-                self.specialized = True
-            except KeyError:
-                pass   # "cached" and not in the cache: generic kernels
+        self._specialize, self._obs_ids = specialize, ((), ())
+        self._load_specialized()
         self.layout = _lib.MrxCimLayout()
         _lib.check(self._L.mrx_cim_get_layout(self._h, ctypes.byref(self.layout)), "mrx_cim_get_layout")
         lay = self.layout
@@ -107,6 +102,18 @@ class CimBatchEngine:
     def _view(self, off: int, dtype: torch.dtype, shape) -> torch.Tensor:
         n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
         return self.workspace[off:off + n].view(dtype).view(*shape)
+
+    def _load_specialized(self) -> None:
+        """(Re)load the step kernels compiled for this plan and the current fused-observation configuration."""
+        self.specialized = False
+        if not self._specialize:
+            return
+        from . import specialize as spec
+        try:
+            spec.load_into(self, spec.plan_defines(self._cs, self._cfg, obs=self._obs_ids), build=self._specialize != "cached")
+            self.specialized = True
+        except KeyError:
+            pass   # "cached" and not in the cache: generic kernels
 
     def use_stream(self, stream: Optional[torch.cuda.Stream]) -> None:
         """Bind every later call of this engine to `stream` (None: back to torch's current stream at call time).  A rollout
@@ -180,6 +187,9 @@ class CimBatchEngine:
         pa_c, va_c = (ctypes.c_int32 * max(len(pa), 1))(*pa), (ctypes.c_int32 * max(len(va), 1))(*va)
         _lib.check(self._L.mrx_cim_set_observation(self._h, pa_c, len(pa), va_c, len(va), self.obs_ports.data_ptr(),
                                                    self.obs_vessel.data_ptr()), "mrx_cim_set_observation")
+        if (tuple(pa), tuple(va)) != tuple(map(tuple, self._obs_ids)):
+            self._obs_ids = (tuple(pa), tuple(va))
+            self._load_specialized()   # the observation's configuration is compiled into the specialised kernels
         return self.obs_ports, self.obs_vessel
 
     def attr_ids(self, node: str, attrs: Sequence[str]):

@@ -24,12 +24,17 @@ UNITS = {   # scenario -> (translation unit, generated dims header, the sources 
 }
 
 
-def plan_defines(topo_struct, cfg, scenario: str = "cim") -> str:
-    """The plan's ``#define MRXC_<field> <value>`` text (host only; no device needed)."""
+def plan_defines(topo_struct, cfg, scenario: str = "cim", obs=((), ())) -> str:
+    """The plan's ``#define MRXC_<field> <value>`` text (host only; no device needed).  CIM: `obs` = (port attribute ids,
+    vessel attribute ids) of the fused observation (mrx_cim_set_observation), part of what is compiled in."""
     fn = getattr(_lib.load(), UNITS[scenario][3] + "_plan_defines")
-    n = _lib.check(fn(ctypes.byref(topo_struct), ctypes.byref(cfg), None, 0), fn.__name__)
+    extra = ()
+    if scenario == "cim":
+        pa, va = ((ctypes.c_int32 * len(x))(*x) for x in obs)
+        extra = (pa, len(obs[0]), va, len(obs[1]))
+    n = _lib.check(fn(ctypes.byref(topo_struct), ctypes.byref(cfg), *extra, None, 0), fn.__name__)
     buf = ctypes.create_string_buffer(n)
-    _lib.check(fn(ctypes.byref(topo_struct), ctypes.byref(cfg), buf, n), fn.__name__)
+    _lib.check(fn(ctypes.byref(topo_struct), ctypes.byref(cfg), *extra, buf, n), fn.__name__)
     return buf.value.decode()
 
 

@@ -23,10 +23,16 @@
 // arguments; a build specialised for one (topology, config) plan (cim_spec.hip, compiled at engine creation) turns every
 // one of them into a compile-time constant MRXC_f — which removes ~60 live SGPRs and their spill traffic, folds the
 // divisions / loop bounds / LDS offsets, and drops the VGPR count from ~197 to ~118.
+// OD(f) / ODA(va, i): the same for the fused observation's configuration (CimObs: attribute counts and ids) — with np a
+// constant the per-element `i / np` of the observation writer is a multiply, and the attribute ids need no scalar loads.
 #ifdef MRX_SPECIALIZED
 #define KD(f) (MRXC_##f)
+#define OD(f) (MRXC_obs_##f)
+#define ODA(f, i) (MRXC_obs_##f(i))
 #else
 #define KD(f) (K.f)
+#define OD(f) (O.f)
+#define ODA(f, i) (O.f[i])
 #endif
 
 namespace cim {
@@ -1043,7 +1049,7 @@ MRX_DEV void fast_rows_request(const CimParams& K, const CimObs& O, int env, Fas
   for (int k = 0; k < 4; k++) R.pl[k] = (KD(NC) <= 256 && lane + 64 * k < KD(NC)) ? g_live[KD(f_plans) + lane + 64 * k] : 0;
   if constexpr (OBS) {
 #pragma unroll
-    for (int a = 0; a < 8; a++) R.vo[a] = a < O.nv ? g_live[KD(f_vessels) + O.va[a] * KD(V) + v] : 0;
+    for (int a = 0; a < 8; a++) R.vo[a] = a < OD(nv) ? g_live[KD(f_vessels) + ODA(va, a) * KD(V) + v] : 0;
   }
 }
 
@@ -1123,15 +1129,15 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
   // this env, which paused at the same tick; since then only this action changed anything, so it is patched in place.
   if constexpr (OBS) {
     if (applied && lane == 0) {
-      if (O.i_empty >= 0) O.ports[((size_t)env * P + ap) * O.np + O.i_empty] = (double)o_pe;
-      if (O.i_tc >= 0) O.ports[((size_t)env * P + ap) * O.np + O.i_tc] = (double)bits_f(o_tc);
+      if (OD(i_empty) >= 0) O.ports[((size_t)env * P + ap) * OD(np) + OD(i_empty)] = (double)o_pe;
+      if (OD(i_tc) >= 0) O.ports[((size_t)env * P + ap) * OD(np) + OD(i_tc)] = (double)bits_f(o_tc);
     }
 #pragma unroll
     for (int a = 0; a < 8; a++) {
-      if (a < O.nv) {
+      if (a < OD(nv)) {
         int raw = wave::shfl(R.vo[a], v2);
-        if (applied && av == v2) { if (O.va[a] == VA_EMPTY) raw = o_ve; else if (O.va[a] == VA_REMAINING_SPACE) raw = o_rs; }
-        if (lane == 0) O.vessel[(size_t)env * O.nv + a] = (double)raw;
+        if (applied && av == v2) { if (ODA(va, a) == VA_EMPTY) raw = o_ve; else if (ODA(va, a) == VA_REMAINING_SPACE) raw = o_rs; }
+        if (lane == 0) O.vessel[(size_t)env * OD(nv) + a] = (double)raw;
       }
     }
   }
@@ -1344,16 +1350,16 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
     // fused observation: the decision's frame is the live frame (aliased pre-decision snapshot); consecutive lanes
     // write consecutive doubles of the [P][np] block
     if constexpr (OBS) {
-      const int tot = P * O.np;
+      const int tot = P * OD(np);
       double* op = O.ports + (size_t)env * tot;
       for (int i = lane; i < tot; i += 64) {
-        const int p = i / O.np, a = i - p * O.np;
-        const int attr = (int)((O.pa_packed >> (4 * a)) & 15u);
+        const int p = i / OD(np), a = i - p * OD(np);
+        const int attr = (int)((OD(pa_packed) >> (4 * a)) & 15u);
         op[i] = port_attr_value(attr, FP(attr, p));
       }
 #pragma unroll
       for (int a = 0; a < 8; a++)
-        if (a < O.nv && lane == 0) O.vessel[(size_t)env * O.nv + a] = (double)FV(O.va[a], dec_v);
+        if (a < OD(nv) && lane == 0) O.vessel[(size_t)env * OD(nv) + a] = (double)FV(ODA(va, a), dec_v);
     }
   } else if (lane == 0) {
     dec_out[0] = t; dec_out[1] = 0; dec_out[2] = 0; dec_out[3] = 0; dec_out[4] = 0; dec_out[5] = 0;

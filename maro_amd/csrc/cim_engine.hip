@@ -261,28 +261,23 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
   return MRX_OK;
 }
 
+static std::string plan_defines(const CimParams& K, const CimObs& O);
+static int make_obs(const int32_t* port_attrs, int n_port_attrs, const int32_t* vessel_attrs, int n_vessel_attrs, CimObs* out);
+
 int mrx_cim_set_observation(mrx_handle h, const int32_t* port_attrs, int n_port_attrs, const int32_t* vessel_attrs, int n_vessel_attrs,
                             double* d_obs_ports, double* d_obs_vessel) {
   if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
   if (h->plan.kp.decision_mode != 0) return set_err(MRX_ERR_UNSUPPORTED, "the fused observation is defined for Sequential decision mode");
-  if (n_port_attrs < 0 || n_port_attrs > 8 || n_vessel_attrs < 0 || n_vessel_attrs > 8) return set_err(MRX_ERR_INVALID_ARG, "at most 8 port and 8 vessel attributes");
-  if ((n_port_attrs && (!port_attrs || !d_obs_ports)) || (n_vessel_attrs && (!vessel_attrs || !d_obs_vessel))) return set_err(MRX_ERR_INVALID_ARG, "null attribute list / output");
+  if ((n_port_attrs > 0 && !d_obs_ports) || (n_vessel_attrs > 0 && !d_obs_vessel)) return set_err(MRX_ERR_INVALID_ARG, "null attribute list / output");
   CimObs o;
-  memset(&o, 0, sizeof(o));
-  for (int i = 0; i < n_port_attrs; i++) {
-    if (port_attrs[i] < 0 || port_attrs[i] >= PA_COUNT) return set_err(MRX_ERR_INVALID_ARG, "unknown port attribute id");
-    o.pa[i] = port_attrs[i];
-  }
-  for (int i = 0; i < n_vessel_attrs; i++) {
-    if (vessel_attrs[i] < 0 || vessel_attrs[i] >= VA_PAST_STOP_LIST) return set_err(MRX_ERR_INVALID_ARG, "vessel attribute must be a single-slot attribute");
-    o.va[i] = vessel_attrs[i];
-  }
-  o.np = n_port_attrs; o.nv = n_vessel_attrs; o.ports = d_obs_ports; o.vessel = d_obs_vessel;
-  o.i_empty = o.i_tc = -1;
-  for (int i = 0; i < n_port_attrs; i++) {
-    o.pa_packed |= (unsigned)o.pa[i] << (4 * i);
-    if (o.pa[i] == PA_EMPTY) o.i_empty = i;
-    if (o.pa[i] == PA_TRANSFER_COST) o.i_tc = i;
+  const int rc = make_obs(port_attrs, n_port_attrs, vessel_attrs, n_vessel_attrs, &o);
+  if (rc != MRX_OK) return rc;
+  o.ports = d_obs_ports; o.vessel = d_obs_vessel;
+  if (h->spec_module && plan_defines(h->plan.kp, o) != plan_defines(h->plan.kp, h->obs)) {
+    // the loaded specialised kernels have the previous observation configuration compiled in: back to the generic ones until
+    // mrx_cim_load_step_kernels is called with a code object for the new configuration
+    hipModuleUnload(h->spec_module);
+    h->spec_module = nullptr;
   }
   h->obs = o;
   return MRX_OK;
@@ -361,20 +356,56 @@ int mrx_cim_query(mrx_handle h, int node_type, const int32_t* d_ticks, int nt, i
 }
 
 // ---- plan-specialised step kernels (cim_spec.hip)
-static std::string plan_defines(const CimParams& K) {
+static std::string plan_defines(const CimParams& K, const CimObs& O) {
   std::string o;
 #define X(f) o += std::string("#define MRXC_") + #f + " " + std::to_string((long long)K.f) + "\n";
   MRX_CIM_DIM_FIELDS(X)
 #undef X
+  // the fused observation's configuration (all zero: off)
+  o += "#define MRXC_obs_np " + std::to_string(O.np) + "\n#define MRXC_obs_nv " + std::to_string(O.nv) + "\n#define MRXC_obs_pa_packed " +
+       std::to_string(O.pa_packed) + "u\n#define MRXC_obs_i_empty " + std::to_string(O.i_empty) + "\n#define MRXC_obs_i_tc " + std::to_string(O.i_tc) + "\n";
+  o += "#define MRXC_obs_va(i) (";
+  for (int i = 0; i < 7; i++) o += "(i) == " + std::to_string(i) + " ? " + std::to_string(O.va[i]) + " : ";
+  o += std::to_string(O.va[7]) + ")\n";
   return o;
 }
 
-int64_t mrx_cim_plan_defines(const mrx_cim_topology* topo, const mrx_cim_config* cfg, char* buf, int64_t len) {
+// CimObs for a list of attribute ids (device pointers left null); shared by mrx_cim_set_observation and mrx_cim_plan_defines
+static int make_obs(const int32_t* port_attrs, int n_port_attrs, const int32_t* vessel_attrs, int n_vessel_attrs, CimObs* out) {
+  if (n_port_attrs < 0 || n_port_attrs > 8 || n_vessel_attrs < 0 || n_vessel_attrs > 8) return set_err(MRX_ERR_INVALID_ARG, "at most 8 port and 8 vessel attributes");
+  if ((n_port_attrs && !port_attrs) || (n_vessel_attrs && !vessel_attrs)) return set_err(MRX_ERR_INVALID_ARG, "null attribute list");
+  CimObs o;
+  memset(&o, 0, sizeof(o));
+  for (int i = 0; i < n_port_attrs; i++) {
+    if (port_attrs[i] < 0 || port_attrs[i] >= PA_COUNT) return set_err(MRX_ERR_INVALID_ARG, "unknown port attribute id");
+    o.pa[i] = port_attrs[i];
+  }
+  for (int i = 0; i < n_vessel_attrs; i++) {
+    if (vessel_attrs[i] < 0 || vessel_attrs[i] >= VA_PAST_STOP_LIST) return set_err(MRX_ERR_INVALID_ARG, "vessel attribute must be a single-slot attribute");
+    o.va[i] = vessel_attrs[i];
+  }
+  o.np = n_port_attrs; o.nv = n_vessel_attrs;
+  o.i_empty = o.i_tc = -1;
+  for (int i = 0; i < n_port_attrs; i++) {
+    o.pa_packed |= (unsigned)o.pa[i] << (4 * i);
+    if (o.pa[i] == PA_EMPTY) o.i_empty = i;
+    if (o.pa[i] == PA_TRANSFER_COST) o.i_tc = i;
+  }
+  if (!o.np && !o.nv) o.i_empty = o.i_tc = 0;  // "off" is the all-zero struct
+  *out = o;
+  return MRX_OK;
+}
+
+int64_t mrx_cim_plan_defines(const mrx_cim_topology* topo, const mrx_cim_config* cfg, const int32_t* obs_port_attrs, int n_obs_port_attrs,
+                             const int32_t* obs_vessel_attrs, int n_obs_vessel_attrs, char* buf, int64_t len) {
   CimHostPlan plan;
   std::string err;
-  const int rc = cim_plan(topo, cfg, &plan, &err);
+  int rc = cim_plan(topo, cfg, &plan, &err);
   if (rc != MRX_OK) return set_err(rc, err);
-  const std::string d = plan_defines(plan.kp);
+  CimObs obs;
+  rc = make_obs(obs_port_attrs, n_obs_port_attrs, obs_vessel_attrs, n_obs_vessel_attrs, &obs);
+  if (rc != MRX_OK) return rc;
+  const std::string d = plan_defines(plan.kp, obs);
   if (buf && len > 0) {
     if ((int64_t)d.size() + 1 > len) return set_err(MRX_ERR_INVALID_ARG, "buffer too small");
     memcpy(buf, d.c_str(), d.size() + 1);
@@ -384,7 +415,8 @@ int64_t mrx_cim_plan_defines(const mrx_cim_topology* topo, const mrx_cim_config*
 
 int mrx_cim_load_step_kernels(mrx_handle h, const void* image, int64_t bytes, const char* defines) {
   if (!h || !image || bytes <= 0 || !defines) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
-  if (plan_defines(h->plan.kp) != defines) return set_err(MRX_ERR_INVALID_ARG, "the code object was built for a different plan (defines differ)");
+  if (plan_defines(h->plan.kp, h->obs) != defines)
+    return set_err(MRX_ERR_INVALID_ARG, "the code object was built for a different plan or observation (defines differ)");
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
   hipModule_t mod = nullptr;

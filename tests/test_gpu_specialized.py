@@ -80,6 +80,31 @@ def test_specialized_equals_generic_batch_with_fused_observation(order_table):
     assert torch.equal(engs[0].live, engs[1].live) and torch.equal(engs[0].ring, engs[1].ring) and int(engs[1].status.max()) == 0
 
 
+def test_changing_the_observation_reloads_the_specialized_kernels():
+    """The fused observation's configuration is compiled in: set_observation with other attributes must not leave kernels built
+    for the previous ones in place (the C side drops them; the Python engine loads the right ones)."""
+    import torch
+
+    from maro_amd.cim.engine import CimBatchEngine
+    n, topo = 64, "toy.5p_ssddd_l0.5"
+    eng = CimBatchEngine(topo, n, durations=60, specialize=True)
+    ref = CimBatchEngine(topo, n, durations=60, specialize=False)
+    acts, nact = torch.zeros((n, 1, 4), dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda")
+    for attrs in ((["empty", "shortage"], ["remaining_space"]), (["full", "booking", "transfer_cost", "empty"], ["empty", "full", "early_discharge"]), ([], [])):
+        for e in (eng, ref):
+            e.reset(torch.full((n,), 7, dtype=torch.int64))
+        obs = [e.set_observation(*attrs) for e in (eng, ref)]
+        assert eng.specialized and not ref.specialized
+        for e in (eng, ref):
+            e.step()
+        for _ in range(40):
+            for e in (eng, ref):
+                e.random_policy(-1, acts, nact)
+                e.step(acts, nact)
+            torch.cuda.synchronize()
+            assert torch.equal(eng.decisions, ref.decisions) and torch.equal(obs[0][0], obs[1][0]) and torch.equal(obs[0][1], obs[1][1])
+
+
 def test_code_object_of_another_plan_is_rejected():
     from maro_amd import _lib
     from maro_amd.cim import specialize as spec

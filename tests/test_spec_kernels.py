@@ -19,7 +19,7 @@ def _cfg(n_envs=4, durations=100, ring=0, order_table=0, mode=0, res=1):
 
 def test_plan_defines_cover_every_dimension_field():
     text = spec.plan_defines(load_topology("global_trade.22p_l0.8").c_struct(), _cfg(durations=1120, ring=4))
-    got = dict(re.findall(r"#define MRXC_(\w+) (-?\d+)", text))
+    got = {k: v for k, v in re.findall(r"#define MRXC_(\w+) (-?\d+)", text) if not k.startswith("obs_")}
     params = open(os.path.join(REPO, "maro_amd", "csrc", "cim_params.h")).read()
     fields = re.findall(r"X\((\w+)\)", params[params.index("#define MRX_CIM_DIM_FIELDS"):params.index("// Observation fused")])
     assert sorted(got) == sorted(fields) and len(fields) > 50
@@ -28,6 +28,18 @@ def test_plan_defines_cover_every_dimension_field():
     dev = open(os.path.join(REPO, "maro_amd", "csrc", "cim_device.h")).read()
     assert set(re.findall(r"KD\((\w+)\)", dev)) - {"f"} <= set(fields)
     assert not [f for f in fields if re.search(r"\bK\." + f + r"\b", dev)]
+
+
+def test_plan_defines_include_the_fused_observation():
+    cs, cfg = load_topology("toy.5p_ssddd_l0.5").c_struct(), _cfg(durations=80)
+    off = spec.plan_defines(cs, cfg)
+    assert "#define MRXC_obs_np 0\n" in off and "#define MRXC_obs_nv 0\n" in off
+    on = spec.plan_defines(cs, cfg, obs=([1, 2, 5], [1, 3]))     # ports: empty, full, shortage; vessels: empty, remaining_space
+    assert "#define MRXC_obs_np 3\n" in on and "#define MRXC_obs_nv 2\n" in on and "#define MRXC_obs_i_empty 0\n" in on
+    assert f"#define MRXC_obs_pa_packed {1 | (2 << 4) | (5 << 8)}u\n" in on and "(i) == 1 ? 3 :" in on
+    assert on != spec.plan_defines(cs, cfg, obs=([1, 2, 5], [3, 1])) and on.replace("obs_", "") != off.replace("obs_", "")
+    dev = open(os.path.join(REPO, "maro_amd", "csrc", "cim_device.h")).read()
+    assert not re.search(r"\bO\.(np|nv|pa_packed|i_empty|i_tc|va)\b", dev)   # every use goes through OD() / ODA()
 
 
 def test_plan_defines_depend_on_the_plan_not_on_the_batch_size():

@@ -35,13 +35,17 @@ def plans(which):
 
 def main(which="bench"):
     from maro_amd.cim import specialize as spec
+    from maro_amd.cim.engine import NODE_ATTRS
+    bench_obs = ([NODE_ATTRS["ports"].index(a) for a in ("empty", "full", "on_shipper", "on_consignee", "booking", "shortage", "fulfillment")],
+                 [NODE_ATTRS["vessels"].index(a) for a in ("empty", "full", "remaining_space")])   # bench.py QUERY_ATTRS / VESSEL_QUERY_ATTRS
     todo = {}
     for topo, c in plans(which):
         cs = topo.c_struct()
         for order_table in (0, 1) if which != "bench" else (0,):
             c.order_table = order_table
-            d = spec.plan_defines(cs, c)
-            todo[d] = 1
+            todo[spec.plan_defines(cs, c)] = 1
+            if which in ("bench", "all") and topo.n_ports == 22:
+                todo[spec.plan_defines(cs, c, obs=bench_obs)] = 1   # bench.py fuses this observation into the step
     if which in ("bench", "all"):   # bench.py --scenario citi_bike: toy.3s_4t, 4096 envs per GPU
         import numpy as np
 
