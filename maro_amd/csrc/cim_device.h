@@ -1350,10 +1350,10 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
     // fused observation: the decision's frame is the live frame (aliased pre-decision snapshot); consecutive lanes
     // write consecutive doubles of the [P][np] block
     if constexpr (OBS) {
-      const int tot = P * OD(np);
+      const int tot = P * OD(np), npd = OD(np) > 0 ? OD(np) : 1;  // (vessel-only observation: tot = 0, no division by a constant 0)
       double* op = O.ports + (size_t)env * tot;
       for (int i = lane; i < tot; i += 64) {
-        const int p = i / OD(np), a = i - p * OD(np);
+        const int p = i / npd, a = i - p * npd;
         const int attr = (int)((OD(pa_packed) >> (4 * a)) & 15u);
         op[i] = port_attr_value(attr, FP(attr, p));
       }

@@ -423,7 +423,8 @@ int mrx_cim_load_step_kernels(mrx_handle h, const void* image, int64_t bytes, co
   HIP_TRY(hipModuleLoadData(&mod, image));
   static const char* names[4] = {"mrx_k_cim_step", "mrx_k_cim_step_obs", "mrx_k_cim_step_tab", "mrx_k_cim_step_tab_obs"};
   hipFunction_t fn[4] = {nullptr, nullptr, nullptr, nullptr};
-  for (int i = h->plan.kp.pregen ? 2 : 0; i < (h->plan.kp.pregen ? 4 : 2); i++) {  // the pair for this plan's order mode
+  const int want = (h->plan.kp.pregen ? 2 : 0) + ((h->obs.np > 0 || h->obs.nv > 0) ? 1 : 0);  // the one kernel this configuration launches
+  for (int i = want; i <= want; i++) {
     if (hipModuleGetFunction(&fn[i], mod, names[i]) != hipSuccess) {
       hipModuleUnload(mod);
       return set_err(MRX_ERR_INVALID_ARG, std::string("code object lacks kernel ") + names[i]);

@@ -35,13 +35,24 @@ mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const
     cim::step_env<PG, OBS>(K, O, env, lds, a, na, n_answered ? n_answered[env] : -1, decisions + (size_t)env * drow,     \
                       metrics + (size_t)env * 3, done + env);                                                       \
   }
-// a specialised build only needs the pair that matches its plan's order mode (CimParams::pregen)
-#if !defined(MRX_SPECIALIZED) || !MRXC_pregen
+// a specialised build only needs the one kernel that matches its plan's order mode (CimParams::pregen) and whether a fused
+// observation is configured (mrx_cim_set_observation reloads the code object when that changes)
+#ifdef MRX_SPECIALIZED
+#define MRX_WANT(PG, OBS) ((PG) == (MRXC_pregen != 0) && (OBS) == ((MRXC_obs_np | MRXC_obs_nv) != 0))
+#else
+#define MRX_WANT(PG, OBS) 1
+#endif
+#if MRX_WANT(0, 0)
 MRX_STEP_KERNEL(mrx_k_cim_step, false, false, MRX_STEP_WAVES)
+#endif
+#if MRX_WANT(0, 1)
 MRX_STEP_KERNEL(mrx_k_cim_step_obs, false, true, MRX_STEP_WAVES)      // + fused observation (mrx_cim_set_observation)
 #endif
-#if !defined(MRX_SPECIALIZED) || MRXC_pregen
+#if MRX_WANT(1, 0)
 MRX_STEP_KERNEL(mrx_k_cim_step_tab, true, false, MRX_STEP_WAVES)
+#endif
+#if MRX_WANT(1, 1)
 MRX_STEP_KERNEL(mrx_k_cim_step_tab_obs, true, true, MRX_STEP_WAVES)
 #endif
+#undef MRX_WANT
 #undef MRX_STEP_KERNEL
