@@ -70,8 +70,13 @@ def code_object(defines: str, build: bool = True, scenario: str = "cim") -> byte
         return f.read()
 
 
+LOADS = 0   # code objects handed to engines in this process (diagnostics: e.g. that a sweep really ran specialised)
+
+
 def load_into(engine, defines: str, build: bool = True, scenario: str = "cim") -> None:
+    global LOADS
     img = code_object(defines, build, scenario)
     buf = ctypes.create_string_buffer(img, len(img))
     fn = getattr(_lib.load(), UNITS[scenario][3] + "_load_step_kernels")
     _lib.check(fn(engine._h, buf, len(img), defines.encode()), fn.__name__)
+    LOADS += 1

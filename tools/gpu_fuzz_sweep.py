@@ -20,6 +20,8 @@ for s in range(first, first + count):
             fn(s, backend=be)
         except Exception as e:  # noqa: BLE001
             bad.append((name, s, repr(e)[:200]))
-print(f"{count} seeds x 2 scenarios in {time.time() - t0:.0f} s; failures: {len(bad)}")
+from maro_amd.cim import specialize  # noqa: E402
+print(f"{count} seeds x 2 scenarios in {time.time() - t0:.0f} s; failures: {len(bad)}; engines that ran plan-specialised kernels "
+      f"(MARO_AMD_SPECIALIZE={os.environ.get('MARO_AMD_SPECIALIZE', '0')}): {specialize.LOADS}")
 for b in bad[:20]:
     print(b)
