@@ -458,6 +458,31 @@ def main():
     span_ms = max([ev[0][g][0].elapsed_time(ev[-1][g2][1]) for g in range(G) for g2 in range(G)]) if G > 1 else sum(durs)
     in_flight = max(1.0, sum(durs) / span_ms) if G > 1 else 1.0    # mean number of step kernels running concurrently
 
+    # the one exchange step of a sharded rollout (north_star: RCCL "only to gather trajectories to the learner"): 32 steps of
+    # (decision, action, metrics, done) per env from every rank to rank 0 (maro_amd/cim/rollout.py::gather_to_learner);
+    # outside the timed env-step window
+    gather_ms = None
+    if dist is not None:
+        from maro_amd.cim.rollout import gather_to_learner
+        T = 32
+        traj = {"decisions": torch.zeros((T, n, 8), dtype=torch.int32, device=dev), "actions": torch.zeros((T, n, 1, 4), dtype=torch.int32, device=dev),
+                "metrics": torch.zeros((T, n, 3), dtype=torch.int64, device=dev), "done": torch.zeros((T, n), dtype=torch.uint8, device=dev)}
+        for k in range(T):
+            for g in range(G):
+                one_step(step_i, g)
+                with torch.cuda.stream(streams[g]):
+                    sl = slice(offs[g], offs[g] + sizes[g])
+                    traj["decisions"][k, sl], traj["actions"][k, sl] = engines[g].decisions, bufs[g]["actions"]
+                    traj["metrics"][k, sl], traj["done"][k, sl] = engines[g].metrics, engines[g].done
+            step_i += 1
+        sync_all()
+        tg = time.perf_counter()
+        gathered = gather_to_learner(traj, dst=0)
+        torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        if rank == 0:
+            assert gathered["decisions"].shape[1] == n * world
+
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
     tot = torch.tensor([float(resolved), float(ticks_adv), float(n_done), float(status_bad)], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -492,7 +517,7 @@ def main():
                                    f"{'random legal agent' if args.policy == 'random' else 'per-port dueling DQN (f32 MFMA, greedy) + CIMEnvSampler state shaping (mrx_cim_dqn_act)'} on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step (' + args.obs + ')'}",
                        "envs_per_gpu": n, "groups_per_gpu": G, "specialized_kernels": bool(engines[0].specialized), "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,
                        "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
-                       "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms, "host_enqueue_ms_per_step": t_issued / args.steps * 1e3,
+                       "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms, "host_enqueue_ms_per_step": t_issued / args.steps * 1e3, "trajectory_gather_ms_32_steps": gather_ms,
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
             "roofline": {"bound": "hbm", "kernel": ("mrx_k_cim_step_tab" if engines[0].layout.order_table_on else "mrx_k_cim_step") + ("_obs" if bufs[0].get("obs") is not None else ""), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
