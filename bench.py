@@ -524,7 +524,7 @@ def main():
                          "traffic_GBps": None if traffic is None else traffic / (step_kernel_ms * 1e-3) / 1e9 * in_flight,
                          "traffic_source": "profiles/latest_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
                          "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": step_kernel_ms, "launches_in_flight": in_flight,
-                         "definition": "achieved = algorithmic_bytes_per_launch / kernel_ms x launches_in_flight (mean number of overlapping step kernels, one per group stream)",
+                         "definition": "achieved = algorithmic_bytes_per_launch / kernel_ms x launches_in_flight (mean number of overlapping step kernels, one per group stream); algorithmic bytes are SURVEY.md 8(d)'s fixed per-env-step formula (reference dtypes, every snapshot copy counted), so frac can exceed 1: the engine moves fewer real bytes (traffic, traffic_GBps)",
                          "algorithmic_bytes_per_env_step": b_step, "env_steps_per_launch": ng},
         }
         if world == 1 and not args.no_cpu:
