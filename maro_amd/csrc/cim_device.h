@@ -230,7 +230,15 @@ MRX_DEV void copy_words(int32_t* dst, const int32_t* src, int n_words) {
   const int n4 = n_words >> 2;
   const int4* s4 = (const int4*)src;
   int4* d4 = (int4*)dst;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // LDS -> HBM write-back of frame / private state / snapshot: non-temporal stores.  The rows are next read one env-step
+  // later (tens of µs, usually by another CU), so letting them allocate in L2 only evicts the topology tables and order rows
+  // the other waves are using: measured +6.5 % env-steps/s (the matching `nt` on the LDS-DMA loads changes nothing).
+  typedef int v4i_ __attribute__((ext_vector_type(4)));
+  for (int i = l; i < n4; i += 64) __builtin_nontemporal_store(((const v4i_*)s4)[i], (v4i_*)d4 + i);
+#else
   for (int i = l; i < n4; i += 64) d4[i] = s4[i];
+#endif
 }
 
 // HBM -> LDS through LDS-DMA (all chunks in flight at once); rows are multiples of 4 words.
