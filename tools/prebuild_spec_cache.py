@@ -58,7 +58,7 @@ def main(which="bench"):
         del np, keep
     with ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as ex:
         sizes = list(ex.map(lambda d: len(spec.code_object(d[1], scenario=d[0]) if isinstance(d, tuple) else spec.code_object(d)), todo))
-    print(f"spec cache: {len(sizes)} plan(s) ready in {spec.CACHE}")
+    print(f"spec cache: {len(sizes)} plan(s) ready in {spec.CACHE}", file=sys.stderr)   # stderr: bench.py's stdout is one JSON line
 
 
 if __name__ == "__main__":
