@@ -93,7 +93,8 @@ class GpuVectorEnv:
     def __init__(self, batch_num: int, scenario: str = "cim", topology: str = None, start_tick: int = 0,
                  durations: int = 100, snapshot_resolution: int = 1, max_snapshots: int = None, decision_mode=0,
                  options: Optional[dict] = None, seeds: Optional[Sequence[int]] = None, device="cuda:0",
-                 max_actions: int = 4, _engine=None):
+                 max_actions: int = 4, specialize=None, _engine=None):
+        """specialize: passed to the engine (CimBatchEngine / CitiBikeBatchEngine): True = kernels compiled for this plan."""
         if scenario != "cim":
             raise NotImplementedError("the GPU engine implements the 'cim' and 'citi_bike' scenarios; use "
                                       "maro.simulator.Env for others")
@@ -102,7 +103,7 @@ class GpuVectorEnv:
             raise ValueError("decision_mode must be Sequential (0), Joint (1) or JointWithSequentialAction (2)")
         self.engine = _engine if _engine is not None else CimBatchEngine(
             topology, batch_num, start_tick=start_tick, durations=durations, snapshot_resolution=snapshot_resolution,
-            max_snapshots=max_snapshots, max_actions=max_actions, device=device, seeds=seeds, decision_mode=mode)
+            max_snapshots=max_snapshots, max_actions=max_actions, device=device, seeds=seeds, decision_mode=mode, specialize=specialize)
         self._mode = int(getattr(self.engine, "decision_mode", mode))
         self._init_state(batch_num)
 

@@ -24,7 +24,7 @@ class CitiBikeVectorEnv(GpuVectorEnv):
     def __init__(self, batch_num: int, scenario: str = "citi_bike", topology: str = None, start_tick: int = 0,
                  durations: int = 1440, snapshot_resolution: int = 1, max_snapshots: int = None, decision_mode=0,
                  options: Optional[dict] = None, seeds: Optional[Sequence[int]] = None, device="cuda:0", max_actions: int = 4,
-                 _engine=None):
+                 specialize=None, _engine=None):
         assert scenario == "citi_bike"
         if int(getattr(decision_mode, "value", decision_mode)) != 0:
             raise NotImplementedError("only DecisionMode.Sequential is implemented on the GPU engine")
@@ -32,7 +32,7 @@ class CitiBikeVectorEnv(GpuVectorEnv):
             seeds = np.arange(batch_num)
         self.engine = _engine if _engine is not None else CitiBikeBatchEngine(
             topology, batch_num, start_tick=start_tick, durations=durations, snapshot_resolution=snapshot_resolution,
-            max_snapshots=max_snapshots, max_actions=max_actions, device=device, seeds=seeds)
+            max_snapshots=max_snapshots, max_actions=max_actions, device=device, seeds=seeds, specialize=specialize)
         self._init_state(batch_num)
 
     def reset(self, keep_seed: bool = False, envs: Optional[Sequence[int]] = None):
