@@ -282,6 +282,9 @@ int mrx_cim_random_policy(mrx_handle h, const int32_t* d_decisions, int64_t step
 int64_t mrx_cim_plan_defines(const mrx_cim_topology* topo, const mrx_cim_config* cfg, const int32_t* obs_port_attrs, int n_obs_port_attrs,
                              const int32_t* obs_vessel_attrs, int n_obs_vessel_attrs, char* buf, int64_t len);
 int mrx_cim_load_step_kernels(mrx_handle h, const void* image, int64_t bytes, const char* defines);
+/* Tools: copy out (and optionally zero) a __device__ global of the loaded code object — e.g. the phase-cycle counters
+ * g_mrx_prof of a code object built with -DMRX_PROFILE_PHASES (tools/phase_profile.py --specialized). */
+int mrx_cim_read_kernel_global(mrx_handle h, const char* name, void* out, int64_t bytes, int reset);
 
 /*
  * On-device action selection of the CIM RL example — for every env with a valid decision:

@@ -14,21 +14,7 @@
 #include <string>
 
 #include "wave.h"
-#ifdef MRX_PROFILE_PHASES
-// tools-only build (libmaro_amd_prof.so): wave cycles (s_memtime) attributed to the phases of mrx_k_cim_step
-__device__ unsigned long long g_mrx_prof[16];
-namespace cim {
-struct Prof {
-  long long last, acc[16];
-  __device__ __forceinline__ Prof() { for (int i = 0; i < 16; i++) acc[i] = 0; last = clock64(); }
-  __device__ __forceinline__ void mark(int i) { long long c = clock64(); acc[i] += c - last; last = c; }
-  __device__ __forceinline__ void mark(int i, long long add) { acc[i] += add; }
-  __device__ __forceinline__ void flush() {
-    if (wave::lane() == 0) for (int i = 0; i < 16; i++) if (acc[i]) atomicAdd(&g_mrx_prof[i], (unsigned long long)acc[i]);
-  }
-};
-}  // namespace cim
-#endif
+#include "cim_prof.h"
 #include "cim_device.h"
 #include "cim_layout.h"
 
@@ -130,6 +116,10 @@ int mrx_prof_read(unsigned long long* out16, int reset) {
   return 0;
 }
 #endif
+
+// Tools: read (and optionally zero) a `__device__` global of the loaded plan-specialised code object, e.g. g_mrx_prof of a
+// code object built with -DMRX_PROFILE_PHASES.
+int mrx_cim_read_kernel_global(mrx_handle h, const char* name, void* out, int64_t bytes, int reset);
 
 const char* mrx_last_error(void) { return g_err.c_str(); }
 const char* mrx_version(void) { return "maro_amd 0.1 (gfx950)"; }
@@ -442,6 +432,20 @@ int mrx_cim_load_step_kernels(mrx_handle h, const void* image, int64_t bytes, co
   for (int i = 0; i < 4; i++) h->spec_fn[i] = fn[i];
   h->spec_reset = f_reset;
   h->spec_order_table = f_table;
+  return MRX_OK;
+}
+
+int mrx_cim_read_kernel_global(mrx_handle h, const char* name, void* out, int64_t bytes, int reset) {
+  if (!h || !name || !out || bytes <= 0) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
+  if (!h->spec_module) return set_err(MRX_ERR_INVALID_ARG, "no plan-specialised code object is loaded");
+  int rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  hipDeviceptr_t p = nullptr;
+  size_t n = 0;
+  HIP_TRY(hipModuleGetGlobal(&p, &n, h->spec_module, name));
+  if ((size_t)bytes > n) return set_err(MRX_ERR_INVALID_ARG, "the global is smaller than the requested size");
+  HIP_TRY(hipMemcpy(out, (const void*)p, (size_t)bytes, hipMemcpyDeviceToHost));
+  if (reset) HIP_TRY(hipMemset((void*)p, 0, (size_t)bytes));
   return MRX_OK;
 }
 

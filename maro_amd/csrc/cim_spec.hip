@@ -9,6 +9,7 @@
 #include "wave.h"
 #define MRX_SPECIALIZED 1
 #include "cim_spec_dims.h"
+#include "cim_prof.h"
 #include "cim_device.h"
 
 #ifndef MRX_STEP_WAVES

@@ -18,14 +18,29 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--topology", default="global_trade.22p_l0.8")
+    ap.add_argument("--specialized", action="store_true", help="profile the plan-specialised kernel (a code object built with "
+                    "-DMRX_PROFILE_PHASES, counters read through mrx_cim_read_kernel_global) instead of libmaro_amd_prof.so")
     args = ap.parse_args()
     import maro_amd._lib as L
-    L.LIB_PATH = os.path.join(REPO, "maro_amd", "csrc", "libmaro_amd_prof.so")
+    if args.specialized:
+        os.environ["MARO_AMD_SPEC_FLAGS"] = (os.environ.get("MARO_AMD_SPEC_FLAGS", "") + " -DMRX_PROFILE_PHASES").strip()
+    else:
+        L.LIB_PATH = os.path.join(REPO, "maro_amd", "csrc", "libmaro_amd_prof.so")
     import torch
     from maro_amd.cim.engine import CimBatchEngine
     lib = L.load()
     n = args.envs
-    eng = CimBatchEngine(args.topology, n, durations=1120, max_snapshots=4, seeds=torch.arange(n) + 1)
+    eng = CimBatchEngine(args.topology, n, durations=1120, max_snapshots=4, seeds=torch.arange(n) + 1, specialize=args.specialized)
+    if args.specialized:
+        eng.set_observation(["empty", "full", "on_shipper", "on_consignee", "booking", "shortage", "fulfillment"], ["empty", "full", "remaining_space"])
+
+        real = lib
+
+        class _Read:   # same call shape as the profile build's mrx_prof_read
+            @staticmethod
+            def mrx_prof_read(buf, reset):
+                L.check(real.mrx_cim_read_kernel_global(eng._h, b"g_mrx_prof", buf, 128, int(reset)), "mrx_cim_read_kernel_global")
+        lib = _Read
     actions = torch.zeros((n, 1, 4), dtype=torch.int32, device="cuda")
     nact = torch.zeros((n,), dtype=torch.int32, device="cuda")
     eng.step()
