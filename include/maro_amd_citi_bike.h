@@ -129,7 +129,7 @@ int mrx_cb_random_policy(mrx_cb_handle h, const int32_t* d_decisions, const int3
  * Plan-specialised kernels (same scheme as mrx_cim_plan_defines / mrx_cim_load_step_kernels in maro_amd.h): the text returned by
  * mrx_cb_plan_defines (host only; here the batch size matters: the struct-of-arrays stride is one of the constants), saved as
  * cb_spec_dims.h, turns maro_amd/csrc/cb_spec.hip into a code object whose mrx_k_cb_reset / mrx_k_cb_step have every plan
- * dimension as a compile-time constant (+16 % env-steps/s on toy.3s_4t); mrx_cb_load_step_kernels makes the handle use it.
+ * dimension as a compile-time constant and keep frames of up to 128 words in registers (+50 % env-steps/s on toy.3s_4t); mrx_cb_load_step_kernels makes the handle use it.
  */
 int64_t mrx_cb_plan_defines(const mrx_cb_topology* topo, const mrx_cb_config* cfg, char* buf, int64_t len);
 int mrx_cb_load_step_kernels(mrx_cb_handle h, const void* image, int64_t bytes, const char* defines);

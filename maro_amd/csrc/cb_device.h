@@ -38,25 +38,62 @@ namespace cb {
 
 #define GHDR(w) K.hdr[(size_t)(w) * CD(stride) + e] /* header word in HBM */
 #define HDR(w) hd[(w)]                           /* header word of the env being stepped: a register copy (step_env) */
-#define ST(a, s) K.live[((size_t)(a) * CD(S) + (size_t)(s)) * CD(stride) + e]
-#define ADJ(i, j) K.live[((size_t)LV_COUNT * CD(S) + (size_t)(i) * CD(S) + (size_t)(j)) * CD(stride) + e]
+// the live frame in HBM (reset, query, and the generic step)
+#define GST(a, s) K.live[((size_t)(a) * CD(S) + (size_t)(s)) * CD(stride) + e]
+#define GADJ(i, j) K.live[((size_t)LV_COUNT * CD(S) + (size_t)(i) * CD(S) + (size_t)(j)) * CD(stride) + e]
+// Register-resident live frame: a specialised build whose whole frame is at most 128 words (up to 8 stations: the toy topologies)
+// loads it once per step into the tail of the header array hd[] and keeps it in VGPRs — the store -> load chains through L2
+// that dominate a lane's latency (bikes / shortage / trip counters are read-modify-written several times per tick) disappear.
+// A runtime station index becomes a select chain over the S candidates (LvRef), so every array index stays static.
+#if defined(MRX_SPECIALIZED) && (MRXC_FW <= 128)
+#define MRX_CB_REGFRAME 1
+template <int N>
+struct LvRef {
+  int32_t* p;
+  int i;
+  MRX_DEV operator int32_t() const {
+    int32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) r = i == j ? p[j] : r;
+    return r;
+  }
+  MRX_DEV LvRef& operator=(int32_t v) {
+#pragma unroll
+    for (int j = 0; j < N; j++) p[j] = i == j ? v : p[j];
+    return *this;
+  }
+  MRX_DEV LvRef& operator=(const LvRef& o) { return *this = (int32_t)o; }
+  MRX_DEV LvRef& operator+=(int32_t v) {
+#pragma unroll
+    for (int j = 0; j < N; j++) p[j] = i == j ? p[j] + v : p[j];
+    return *this;
+  }
+};
+#define ST(a, s) (LvRef<MRXC_S>{hd + CH_WORDS + (a) * MRXC_S, (int)(s)})
+#define ADJ(i, j) (LvRef<MRXC_S * MRXC_S>{hd + CH_WORDS + LV_COUNT * MRXC_S, (int)(i) * MRXC_S + (int)(j)})
+#define CB_HD_WORDS (CH_WORDS + MRXC_FW)
+#else
+#define ST(a, s) GST(a, s)
+#define ADJ(i, j) GADJ(i, j)
+#define CB_HD_WORDS CH_WORDS
+#endif
 #define POOL(i, w) K.pool[((size_t)(i) * CB_POOL_WORDS + (w)) * CD(stride) + e]
 #define SCR(i) K.scratch[(size_t)(i) * CD(stride) + e]
 
-MRX_DEV void set_bikes(const CbParams& K, int e, int s, int v) {  // station.py:71-75
+MRX_DEV void set_bikes(const CbParams& K, int e, int32_t* hd, int s, int v) {  // station.py:71-75
   ST(LV_BIKES, s) = v;
   if (v < ST(LV_MIN_BIKES, s)) ST(LV_MIN_BIKES, s) = v;
 }
 
 // decision_strategy.py:295-343 — bikes that do not fit go to the neighbours of `cur`, nearest first
-MRX_DEV void move_to_neighbor(const CbParams& K, int e, int src, int cur, int number) {
+MRX_DEV void move_to_neighbor(const CbParams& K, int e, int32_t* hd, int src, int cur, int number) {
   const int cnt = K.nb_cnt[cur];
   for (int i = 0; i < cnt && number > 0; i++) {
     const int nb = K.nb[(size_t)cur * CD(nb_stride) + i];
     const int b = ST(LV_BIKES, nb);
     int accept = K.capacity[nb] - b;
     if (accept > number) accept = number;
-    set_bikes(K, e, nb, b + accept);
+    set_bikes(K, e, hd, nb, b + accept);
     const int target = CD(extra_cost_mode) == 0 ? src : CD(extra_cost_mode) == 1 ? cur : nb;
     ST(LV_EXTRA_COST, target) += accept * (i + 1);
     number -= accept;
@@ -70,13 +107,13 @@ MRX_DEV void land_bikes(const CbParams& K, int e, int32_t* hd, bool deliver, int
   if (accept > n) accept = n;
   if (accept < n) {
     if (!deliver) ST(LV_FAILED_RETURN, to) += n - accept;
-    move_to_neighbor(K, e, frm, to, n - accept);
+    move_to_neighbor(K, e, hd, frm, to, n - accept);
   }
   if (deliver && accept > 0) {
     ST(LV_TRANSFER_COST, to) += accept;
     HDR(CH_OPER) += accept;
   }
-  set_bikes(K, e, to, b + accept);
+  set_bikes(K, e, hd, to, b + accept);
 }
 
 // Executes, in insertion order, the pool's deliveries landing at tick `t` whose scheduling tick is < sched_lt.
@@ -151,7 +188,7 @@ MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t) {
       word &= ~(1u << (i & 31));
     } else {
       ST(LV_FULFILLMENT, src) += 1;
-      set_bikes(K, e, src, b - 1);
+      set_bikes(K, e, hd, src, b - 1);
       word |= 1u << (i & 31);
     }
   }
@@ -178,11 +215,16 @@ MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t) {
 }
 
 // np_backend.pyx:481-518 — frame `fi` goes to ring slot fi % ring_slots (frames are taken in increasing order)
-MRX_DEV void take_snapshot(const CbParams& K, int e, int t) {
+MRX_DEV void take_snapshot(const CbParams& K, int e, int32_t* hd, int t) {
   const int fi = (t - CD(start_tick)) / CD(res), slot = fi % CD(ring_slots);
   int32_t* dst = K.ring + (size_t)slot * (CD(FW) + 1) * CD(stride) + e;
+#ifdef MRX_CB_REGFRAME
+#pragma unroll
+  for (int w = 0; w < MRXC_FW; w++) dst[(size_t)w * CD(stride)] = hd[CH_WORDS + w];
+#else
   const int32_t* src = K.live + e;
   for (int w = 0; w < CD(FW); w++) dst[(size_t)w * CD(stride)] = src[(size_t)w * CD(stride)];
+#endif
   dst[(size_t)CD(FW) * CD(stride)] = t;
   K.ring_fi[(size_t)slot * CD(stride) + e] = fi;
 }
@@ -196,7 +238,7 @@ MRX_DEV bool end_tick(const CbParams& K, int e, int32_t* hd, int t) {
   }
   const bool frame_end = (t + 1) % CD(res) == 0;  // post_step :130-147
   if (frame_end) {
-    take_snapshot(K, e, t);
+    take_snapshot(K, e, hd, t);
     for (int s = 0; s < CD(S); s++) {
       ST(LV_SHORTAGE, s) = 0; ST(LV_TRIP_REQUIREMENT, s) = 0; ST(LV_EXTRA_COST, s) = 0; ST(LV_TRANSFER_COST, s) = 0;
       ST(LV_FULFILLMENT, s) = 0; ST(LV_FAILED_RETURN, s) = 0;
@@ -204,7 +246,7 @@ MRX_DEV bool end_tick(const CbParams& K, int e, int32_t* hd, int t) {
     }
   }
   if (t + 1 == CD(max_tick)) {
-    if (!frame_end) take_snapshot(K, e, t);  // core.py:371-375: the last, partial frame
+    if (!frame_end) take_snapshot(K, e, hd, t);  // core.py:371-375: the last, partial frame
     return true;
   }
   return false;
@@ -249,7 +291,7 @@ MRX_DEV void scope_select(const CbParams& K, int e, int n, int n_out, int mode) 
 // BikeDecisionStrategy.action_scope (decision_strategy.py:253-293) for station s at tick t.  Evaluated at every
 // decision (the reference evaluates it lazily when the agent reads DecisionEvent.action_scope; reading it is
 // what feeds the TripsWindowFilter cache, :131-138).  Writes ordered (station, max) pairs; returns their count.
-MRX_DEV int action_scope(const CbParams& K, int e, int s, int type, int t, int32_t* out) {
+MRX_DEV int action_scope(const CbParams& K, int e, int32_t* hd, int s, int type, int t, int32_t* out) {
   const int S = CD(S);
   int n = K.nb_cnt[s];
   for (int i = 0; i < n; i++) {
@@ -314,7 +356,7 @@ MRX_DEV void apply_actions(const CbParams& K, int e, int32_t* hd, int t, int s, 
     const int b = ST(LV_BIKES, frm);
     const int ex = b < number ? b : number;
     if (ex <= 0) continue;
-    set_bikes(K, e, frm, b - ex);
+    set_bikes(K, e, hd, frm, b - ex);
     const int pos = HDR(CH_TT_POS);
     int tt = 1;
     if (pos < CD(tt_cap)) tt = K.tt[(size_t)pos * CD(stride) + e];
@@ -332,9 +374,13 @@ MRX_DEV void apply_actions(const CbParams& K, int e, int32_t* hd, int t, int s, 
 // Env.step for one env.  dec[8], scope[scope_cap][2], met[3]
 MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_actions, int32_t* dec, int32_t* scope, int64_t* met,
                       uint8_t* done) {
-  int32_t hd[CH_WORDS];  // the env's header lives in registers for the whole step
+  int32_t hd[CB_HD_WORDS];  // the env's header (and, MRX_CB_REGFRAME, its live frame) lives in registers for the whole step
 #pragma unroll
   for (int w = 0; w < CH_WORDS; w++) hd[w] = GHDR(w);
+#ifdef MRX_CB_REGFRAME
+#pragma unroll
+  for (int w = 0; w < MRXC_FW; w++) hd[CH_WORDS + w] = K.live[(size_t)w * CD(stride) + e];
+#endif
   int flags = HDR(CH_FLAGS);
   int t = HDR(CH_TICK);
   bool finished = (flags & CFL_FINISHED) != 0;
@@ -356,7 +402,7 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
         HDR(CH_CUR_TYPE) = type;
         HDR(CH_NDEC) += 1;
         dec[0] = t; dec[1] = s; dec[2] = type; dec[3] = (t - CD(start_tick)) / CD(res);
-        dec[4] = action_scope(K, e, s, type, t, scope);
+        dec[4] = action_scope(K, e, hd, s, type, t, scope);
         dec[5] = 1; dec[6] = 0; dec[7] = 0;
         break;
       }
@@ -372,6 +418,10 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     HDR(CH_FLAGS) = flags;
 #pragma unroll
     for (int w = 0; w < CH_WORDS; w++) GHDR(w) = hd[w];
+#ifdef MRX_CB_REGFRAME
+#pragma unroll
+    for (int w = 0; w < MRXC_FW; w++) K.live[(size_t)w * CD(stride) + e] = hd[CH_WORDS + w];
+#endif
   }
   if (finished) {
     dec[0] = t; dec[1] = -1; dec[2] = -1; dec[3] = (t - CD(start_tick)) / CD(res); dec[4] = 0; dec[5] = 0; dec[6] = 0; dec[7] = 0;
@@ -388,7 +438,7 @@ MRX_DEV void reset_env(const CbParams& K, int e) {
   GHDR(CH_FLAGS) = CFL_FRESH;
   GHDR(CH_POOL_MINLAND) = CB_NO_LAND;
   for (int w = 0; w < CD(FW); w++) K.live[(size_t)w * CD(stride) + e] = 0;
-  for (int s = 0; s < CD(S); s++) { ST(LV_BIKES, s) = K.init_bikes[s]; ST(LV_MIN_BIKES, s) = K.init_bikes[s]; }
+  for (int s = 0; s < CD(S); s++) { GST(LV_BIKES, s) = K.init_bikes[s]; GST(LV_MIN_BIKES, s) = K.init_bikes[s]; }
   for (int i = 0; i < CD(ring_slots); i++) { K.ring_fi[(size_t)i * CD(stride) + e] = -1; K.twc_fi[(size_t)i * CD(stride) + e] = -1; }
   for (int w = 0; w < 2 * CD(mask_words); w++) K.decmask[(size_t)w * CD(stride) + e] = 0;
   for (int w = 0; w < CD(w_words); w++) K.fulfilled[(size_t)w * CD(stride) + e] = 0;
