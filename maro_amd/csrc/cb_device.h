@@ -69,13 +69,45 @@ struct LvRef {
     return *this;
   }
 };
+template <int N>
+struct LuRef {  // the same for the unsigned bit words (fulfilled ring, decision masks)
+  int32_t* p;
+  int i;
+  MRX_DEV operator uint32_t() const {
+    uint32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) r = i == j ? (uint32_t)p[j] : r;
+    return r;
+  }
+  MRX_DEV LuRef& operator=(uint32_t v) {
+#pragma unroll
+    for (int j = 0; j < N; j++) p[j] = i == j ? (int32_t)v : p[j];
+    return *this;
+  }
+  MRX_DEV LuRef& operator&=(uint32_t v) { return *this = (uint32_t)*this & v; }
+  MRX_DEV LuRef& operator|=(uint32_t v) { return *this = (uint32_t)*this | v; }
+};
 #define ST(a, s) (LvRef<MRXC_S>{hd + CH_WORDS + (a) * MRXC_S, (int)(s)})
 #define ADJ(i, j) (LvRef<MRXC_S * MRXC_S>{hd + CH_WORDS + LV_COUNT * MRXC_S, (int)(i) * MRXC_S + (int)(j)})
+// ... and, when they are small too, the per-env bit words: the fulfilled ring and the pending-decision masks
+#if (MRXC_w_words <= 16) && (MRXC_mask_words <= 2)
+#define MRX_CB_REGBITS 1
+#define FUL(i) (LuRef<MRXC_w_words>{hd + CH_WORDS + MRXC_FW, (int)(i)})
+#define DMK(i) (LuRef<2 * MRXC_mask_words>{hd + CH_WORDS + MRXC_FW + MRXC_w_words, (int)(i)})
+#define CB_HD_WORDS (CH_WORDS + MRXC_FW + MRXC_w_words + 2 * MRXC_mask_words)
+#else
 #define CB_HD_WORDS (CH_WORDS + MRXC_FW)
+#endif
 #else
 #define ST(a, s) GST(a, s)
 #define ADJ(i, j) GADJ(i, j)
 #define CB_HD_WORDS CH_WORDS
+#endif
+#define GFUL(i) K.fulfilled[(size_t)(i) * CD(stride) + e]
+#define GDMK(i) K.decmask[(size_t)(i) * CD(stride) + e]
+#ifndef MRX_CB_REGBITS
+#define FUL(i) GFUL(i)
+#define DMK(i) GDMK(i)
 #endif
 #define POOL(i, w) K.pool[((size_t)(i) * CB_POOL_WORDS + (w)) * CD(stride) + e]
 #define SCR(i) K.scratch[(size_t)(i) * CD(stride) + e]
@@ -166,7 +198,7 @@ MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t) {
   for (int r = K.ret_off[d]; r < r_mid; r++) {
     const int i = K.ret_trip[r];
     if (deliveries) pool_exec_until(K, e, hd, t, K.trip_tick[i], p, tail);
-    if (K.fulfilled[(size_t)((i & CD(w_mask)) >> 5) * CD(stride) + e] >> (i & 31) & 1u) land_bikes(K, e, hd, false, K.trip_src[i], K.trip_dst[i], 1);
+    if ((uint32_t)FUL((i & CD(w_mask)) >> 5) >> (i & 31) & 1u) land_bikes(K, e, hd, false, K.trip_src[i], K.trip_dst[i], 1);
   }
   if (deliveries) {
     pool_exec_until(K, e, hd, t, CB_NO_LAND, p, tail);
@@ -181,15 +213,15 @@ MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t) {
     ST(LV_TRIP_REQUIREMENT, src) += 1;
     ADJ(src, dst) += 1;
     n_trips++;
-    uint32_t& word = K.fulfilled[(size_t)((i & CD(w_mask)) >> 5) * CD(stride) + e];
+    const int fw = (i & CD(w_mask)) >> 5;
     if (b < 1) {
       ST(LV_SHORTAGE, src) += 1;
       n_short++;
-      word &= ~(1u << (i & 31));
+      FUL(fw) &= ~(1u << (i & 31));
     } else {
       ST(LV_FULFILLMENT, src) += 1;
       set_bikes(K, e, hd, src, b - 1);
-      word |= 1u << (i & 31);
+      FUL(fw) |= 1u << (i & 31);
     }
   }
   if (n_trips) { HDR(CH_TRIPS) += n_trips; HDR(CH_SHORT) += n_short; }
@@ -203,13 +235,13 @@ MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t) {
         if (ratio >= K.supply_wm) sup |= 1u << j;
         else if (ratio <= K.demand_wm) dem |= 1u << j;
       }
-      K.decmask[(size_t)w * CD(stride) + e] = sup;
-      K.decmask[(size_t)(CD(mask_words) + w) * CD(stride) + e] = dem;
+      DMK(w) = sup;
+      DMK(CD(mask_words) + w) = dem;
     }
   }
   for (int r = r_mid; r < r_end; r++) {
     const int i = K.ret_trip[r];
-    if (K.fulfilled[(size_t)((i & CD(w_mask)) >> 5) * CD(stride) + e] >> (i & 31) & 1u) land_bikes(K, e, hd, false, K.trip_src[i], K.trip_dst[i], 1);
+    if ((uint32_t)FUL((i & CD(w_mask)) >> 5) >> (i & 31) & 1u) land_bikes(K, e, hd, false, K.trip_src[i], K.trip_dst[i], 1);
   }
   HDR(CH_LATE) = 0;
 }
@@ -252,9 +284,9 @@ MRX_DEV bool end_tick(const CbParams& K, int e, int32_t* hd, int t) {
   return false;
 }
 
-MRX_DEV int next_decision(const CbParams& K, int e, int* type) {
+MRX_DEV int next_decision(const CbParams& K, int e, int32_t* hd, int* type) {
   for (int w = 0; w < CD(mask_words); w++) {
-    const uint32_t sup = K.decmask[(size_t)w * CD(stride) + e], dem = K.decmask[(size_t)(CD(mask_words) + w) * CD(stride) + e];
+    const uint32_t sup = DMK(w), dem = DMK(CD(mask_words) + w);
     const uint32_t any = sup | dem;
     if (any) {
       int j = 0;
@@ -341,14 +373,14 @@ MRX_DEV int action_scope(const CbParams& K, int e, int32_t* hd, int s, int type,
 // _on_action_received :521-559 for the pending decision of station `s` at tick t
 MRX_DEV void apply_actions(const CbParams& K, int e, int32_t* hd, int t, int s, const int32_t* actions, int n_actions) {
   // pop the decision from the tick's list
-  K.decmask[(size_t)(s >> 5) * CD(stride) + e] &= ~(1u << (s & 31));
-  K.decmask[(size_t)(CD(mask_words) + (s >> 5)) * CD(stride) + e] &= ~(1u << (s & 31));
+  DMK(s >> 5) &= ~(1u << (s & 31));
+  DMK(CD(mask_words) + (s >> 5)) &= ~(1u << (s & 31));
   // Reference behaviour (event_linked_list.py:86-108): when the answered decision was the LAST element of the
   // tick's list, popping it leaves `_tail` on the removed node, so a DeliverBike appended to this same tick
   // (transfer time 0) is linked behind it and never runs.  It does run when later decisions, or an earlier
   // zero-time delivery, still follow it in the list.
   int ty;
-  const bool tail_stale = next_decision(K, e, &ty) < 0 && HDR(CH_LATE) == 0;
+  const bool tail_stale = next_decision(K, e, hd, &ty) < 0 && HDR(CH_LATE) == 0;
   for (int a = 0; a < n_actions; a++) {
     const int frm = actions[3 * a], to = actions[3 * a + 1], number = actions[3 * a + 2];
     if (frm < 0 || to < 0) continue;
@@ -380,6 +412,12 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
 #ifdef MRX_CB_REGFRAME
 #pragma unroll
   for (int w = 0; w < MRXC_FW; w++) hd[CH_WORDS + w] = K.live[(size_t)w * CD(stride) + e];
+#ifdef MRX_CB_REGBITS
+#pragma unroll
+  for (int w = 0; w < MRXC_w_words; w++) hd[CH_WORDS + MRXC_FW + w] = (int32_t)GFUL(w);
+#pragma unroll
+  for (int w = 0; w < 2 * MRXC_mask_words; w++) hd[CH_WORDS + MRXC_FW + MRXC_w_words + w] = (int32_t)GDMK(w);
+#endif
 #endif
   int flags = HDR(CH_FLAGS);
   int t = HDR(CH_TICK);
@@ -394,7 +432,7 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     }
     for (;;) {
       int type;
-      const int s = next_decision(K, e, &type);
+      const int s = next_decision(K, e, hd, &type);
       if (s >= 0) {
         // core.py:345 takes a snapshot of the current frame here; queries alias it to the live frame instead
         flags |= CFL_PENDING;
@@ -421,6 +459,12 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
 #ifdef MRX_CB_REGFRAME
 #pragma unroll
     for (int w = 0; w < MRXC_FW; w++) K.live[(size_t)w * CD(stride) + e] = hd[CH_WORDS + w];
+#ifdef MRX_CB_REGBITS
+#pragma unroll
+    for (int w = 0; w < MRXC_w_words; w++) GFUL(w) = (uint32_t)hd[CH_WORDS + MRXC_FW + w];
+#pragma unroll
+    for (int w = 0; w < 2 * MRXC_mask_words; w++) GDMK(w) = (uint32_t)hd[CH_WORDS + MRXC_FW + MRXC_w_words + w];
+#endif
 #endif
   }
   if (finished) {
@@ -440,8 +484,8 @@ MRX_DEV void reset_env(const CbParams& K, int e) {
   for (int w = 0; w < CD(FW); w++) K.live[(size_t)w * CD(stride) + e] = 0;
   for (int s = 0; s < CD(S); s++) { GST(LV_BIKES, s) = K.init_bikes[s]; GST(LV_MIN_BIKES, s) = K.init_bikes[s]; }
   for (int i = 0; i < CD(ring_slots); i++) { K.ring_fi[(size_t)i * CD(stride) + e] = -1; K.twc_fi[(size_t)i * CD(stride) + e] = -1; }
-  for (int w = 0; w < 2 * CD(mask_words); w++) K.decmask[(size_t)w * CD(stride) + e] = 0;
-  for (int w = 0; w < CD(w_words); w++) K.fulfilled[(size_t)w * CD(stride) + e] = 0;
+  for (int w = 0; w < 2 * CD(mask_words); w++) GDMK(w) = 0;
+  for (int w = 0; w < CD(w_words); w++) GFUL(w) = 0;
 }
 
 MRX_DEV int attr_slots(const CbParams& K, int node_type, int attr) {
