@@ -47,23 +47,28 @@ namespace cb {
 // A runtime station index becomes a select chain over the S candidates (LvRef), so every array index stays static.
 #if defined(MRX_SPECIALIZED) && (MRXC_FW <= 128)
 #define MRX_CB_REGFRAME 1
+#ifdef __HIPCC__
+#define MRX_DEVM __device__ __forceinline__
+#else
+#define MRX_DEVM inline /* host harness (tests/emu): MRX_DEV is `static inline`, not valid on members */
+#endif
 template <int N>
 struct LvRef {
   int32_t* p;
   int i;
-  MRX_DEV operator int32_t() const {
+  MRX_DEVM operator int32_t() const {
     int32_t r = 0;
 #pragma unroll
     for (int j = 0; j < N; j++) r = i == j ? p[j] : r;
     return r;
   }
-  MRX_DEV LvRef& operator=(int32_t v) {
+  MRX_DEVM LvRef& operator=(int32_t v) {
 #pragma unroll
     for (int j = 0; j < N; j++) p[j] = i == j ? v : p[j];
     return *this;
   }
-  MRX_DEV LvRef& operator=(const LvRef& o) { return *this = (int32_t)o; }
-  MRX_DEV LvRef& operator+=(int32_t v) {
+  MRX_DEVM LvRef& operator=(const LvRef& o) { return *this = (int32_t)o; }
+  MRX_DEVM LvRef& operator+=(int32_t v) {
 #pragma unroll
     for (int j = 0; j < N; j++) p[j] = i == j ? p[j] + v : p[j];
     return *this;
@@ -73,19 +78,19 @@ template <int N>
 struct LuRef {  // the same for the unsigned bit words (fulfilled ring, decision masks)
   int32_t* p;
   int i;
-  MRX_DEV operator uint32_t() const {
+  MRX_DEVM operator uint32_t() const {
     uint32_t r = 0;
 #pragma unroll
     for (int j = 0; j < N; j++) r = i == j ? (uint32_t)p[j] : r;
     return r;
   }
-  MRX_DEV LuRef& operator=(uint32_t v) {
+  MRX_DEVM LuRef& operator=(uint32_t v) {
 #pragma unroll
     for (int j = 0; j < N; j++) p[j] = i == j ? (int32_t)v : p[j];
     return *this;
   }
-  MRX_DEV LuRef& operator&=(uint32_t v) { return *this = (uint32_t)*this & v; }
-  MRX_DEV LuRef& operator|=(uint32_t v) { return *this = (uint32_t)*this | v; }
+  MRX_DEVM LuRef& operator&=(uint32_t v) { return *this = (uint32_t)*this & v; }
+  MRX_DEVM LuRef& operator|=(uint32_t v) { return *this = (uint32_t)*this | v; }
 };
 #define ST(a, s) (LvRef<MRXC_S>{hd + CH_WORDS + (a) * MRXC_S, (int)(s)})
 #define ADJ(i, j) (LvRef<MRXC_S * MRXC_S>{hd + CH_WORDS + LV_COUNT * MRXC_S, (int)(i) * MRXC_S + (int)(j)})

@@ -23,7 +23,51 @@ def build():
     return LIB
 
 
+def build_specialized(defines: str) -> str:
+    """The same harness with the device source compiled as a plan-specialised build (MRX_SPECIALIZED + the plan's MRXC_* text
+    of mrx_cb_plan_defines): CD() constants, and for small frames the register-resident frame (MRX_CB_REGFRAME / LvRef) — so
+    that path is checked against the oracle on the CPU too.  One .so per plan, cached in a temp dir."""
+    import hashlib
+    import tempfile
+    key = hashlib.sha256(defines.encode() + open(os.path.join(REPO, "maro_amd", "csrc", "cb_device.h"), "rb").read()
+                         + open(os.path.join(HERE, "cb_emu.cpp"), "rb").read()).hexdigest()[:20]
+    d = os.path.join(tempfile.gettempdir(), "maro_amd_cb_emu_spec")
+    os.makedirs(d, exist_ok=True)
+    so = os.path.join(d, key + ".so")
+    if not os.path.exists(so):
+        hdr = os.path.join(d, key + "_dims.h")
+        with open(hdr, "w") as f:
+            f.write(defines)
+        tmp = so + f".{os.getpid()}.tmp"
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function", "-DMRX_SPECIALIZED",
+                               "-include", hdr, "-shared", "-o", tmp, os.path.join(HERE, "cb_emu.cpp")])
+        os.replace(tmp, so)
+    return so
+
+
 _lib = None
+_spec_libs = {}
+
+
+def _declare(L):
+    vp, i32 = ctypes.c_void_p, ctypes.c_int
+    L.cb_emu_create.restype = vp
+    L.cb_emu_create.argtypes = [vp, vp, ctypes.c_char_p, i32]
+    L.cb_emu_destroy.argtypes = [vp]
+    L.cb_emu_get_layout.argtypes = [vp, vp]
+    L.cb_emu_workspace.restype = vp
+    L.cb_emu_workspace.argtypes = [vp]
+    L.cb_emu_reset.argtypes = [vp, vp, i32, vp]
+    L.cb_emu_step.argtypes = [vp] * 8
+    L.cb_emu_query.argtypes = [vp, i32, vp, i32, i32, vp, i32, i32, vp, i32, vp]
+    L.cb_emu_random_policy.argtypes = [vp, vp, vp, ctypes.c_int64, vp, vp]
+    return L
+
+
+def spec_lib(defines: str):
+    if defines not in _spec_libs:
+        _spec_libs[defines] = _declare(ctypes.CDLL(build_specialized(defines)))
+    return _spec_libs[defines]
 
 
 def lib():
@@ -53,22 +97,26 @@ class CbEmuBackend:
     """numpy-facing batch backend; tests/cb_backend_adapter.py gives the GPU engine the same surface."""
 
     def __init__(self, data, n_envs=1, start_tick=0, durations=100, snapshot_resolution=1, max_snapshots=None, max_actions=1,
-                 delivery_capacity=0, transfer_times_cap=0):
+                 delivery_capacity=0, transfer_times_cap=0, specialized=False):
         self.data = data
         if not delivery_capacity:   # same default as maro_amd.citi_bike.engine.CitiBikeBatchEngine
             delivery_capacity = data.n_stations * (int((data.time_mean + 6 * data.time_std) / max(data.resolution, 1)) + 2) + 4
         self._ts, self._keep = topology_struct(data)
         self.cfg = MrxCbConfig(n_envs, 0, start_tick, durations, snapshot_resolution, max_snapshots or 0, max_actions,
                                delivery_capacity, transfer_times_cap)
+        self._L = lib()
+        if specialized:   # the plan's constants come from the product library's host-only mrx_cb_plan_defines
+            from maro_amd.cim import specialize as spec
+            self._L = spec_lib(spec.plan_defines(self._ts, self.cfg, "citi_bike"))
         err = ctypes.create_string_buffer(256)
-        self._h = lib().cb_emu_create(ctypes.byref(self._ts), ctypes.byref(self.cfg), err, 256)
+        self._h = self._L.cb_emu_create(ctypes.byref(self._ts), ctypes.byref(self.cfg), err, 256)
         if not self._h:
             raise RuntimeError(err.value.decode())
         self.layout = MrxCbLayout()
-        lib().cb_emu_get_layout(self._h, ctypes.byref(self.layout))
+        self._L.cb_emu_get_layout(self._h, ctypes.byref(self.layout))
         self.n_envs, self.max_actions = n_envs, max_actions
         self.start_tick, self.max_tick, self.res = start_tick, start_tick + durations, snapshot_resolution
-        base = lib().cb_emu_workspace(self._h)
+        base = self._L.cb_emu_workspace(self._h)
         self._ws = (ctypes.c_uint8 * self.layout.workspace_bytes).from_address(base)
         self.ws = np.frombuffer(self._ws, dtype=np.uint8)
         self._dec = np.zeros((n_envs, 8), np.int32)
@@ -77,8 +125,8 @@ class CbEmuBackend:
         self._done = np.zeros(n_envs, np.uint8)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().cb_emu_destroy(self._h)
+        if getattr(self, "_h", None) and getattr(self, "_L", None) is not None:
+            self._L.cb_emu_destroy(self._h)
             self._h = None
 
     def view(self, off, words):
@@ -89,19 +137,19 @@ class CbEmuBackend:
     def reset(self, transfer_times=None, mask=None):
         tt = None if transfer_times is None else np.ascontiguousarray(transfer_times, np.int32).reshape(self.n_envs, -1)
         mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
-        lib().cb_emu_reset(self._h, _ptr(tt), 0 if tt is None else tt.shape[1], _ptr(mk))
+        self._L.cb_emu_reset(self._h, _ptr(tt), 0 if tt is None else tt.shape[1], _ptr(mk))
 
     def step(self, actions=None, n_actions=None, mask=None):
         a = None if actions is None else np.ascontiguousarray(actions, np.int32).reshape(self.n_envs, self.max_actions, 3)
         na = None if n_actions is None else np.ascontiguousarray(n_actions, np.int32)
         mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
-        lib().cb_emu_step(self._h, _ptr(a), _ptr(na), _ptr(mk), _ptr(self._dec), _ptr(self._scope), _ptr(self._met), _ptr(self._done))
+        self._L.cb_emu_step(self._h, _ptr(a), _ptr(na), _ptr(mk), _ptr(self._dec), _ptr(self._scope), _ptr(self._met), _ptr(self._done))
         return self._dec.copy(), self._scope.copy(), self._met.copy(), self._done.copy()
 
     def random_policy(self, dec, scope, step):
         a = np.zeros((self.n_envs, self.max_actions, 3), np.int32)
         na = np.zeros(self.n_envs, np.int32)
-        lib().cb_emu_random_policy(self._h, _ptr(np.ascontiguousarray(dec, np.int32)), _ptr(np.ascontiguousarray(scope, np.int32)),
+        self._L.cb_emu_random_policy(self._h, _ptr(np.ascontiguousarray(dec, np.int32)), _ptr(np.ascontiguousarray(scope, np.int32)),
                                    int(step), _ptr(a), _ptr(na))
         return a, na
 
@@ -112,7 +160,7 @@ class CbEmuBackend:
         nn, npe = n.shape[-1], (n.shape[-1] if n.ndim == 2 else 0)
         a = np.ascontiguousarray(attrs, np.int32)
         out = np.zeros((self.n_envs, nt, nn, row_slots), np.float64)
-        lib().cb_emu_query(self._h, node_type, _ptr(t), nt, per_env, _ptr(n), nn, npe, _ptr(a), len(a), _ptr(out))
+        self._L.cb_emu_query(self._h, node_type, _ptr(t), nt, per_env, _ptr(n), nn, npe, _ptr(a), len(a), _ptr(out))
         return out
 
     def hdr(self):
