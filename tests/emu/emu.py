@@ -37,13 +37,47 @@ def build():
     return LIB
 
 
+def build_specialized(defines: str) -> str:
+    """The emulator with the device source compiled as a plan-specialised build (MRX_SPECIALIZED + the MRXC_* text of
+    mrx_cim_plan_defines): what cim_spec.hip compiles for the GPU, checked against the oracle on the CPU.  One .so per plan."""
+    import hashlib
+    import tempfile
+    h = hashlib.sha256(defines.encode())
+    for f in (os.path.join(HERE, "cim_emu.cpp"), os.path.join(HERE, "wave_emu.h"), os.path.join(REPO, "maro_amd", "csrc", "cim_device.h")):
+        h.update(open(f, "rb").read())
+    d = os.path.join(tempfile.gettempdir(), "maro_amd_cim_emu_spec")
+    os.makedirs(d, exist_ok=True)
+    so = os.path.join(d, h.hexdigest()[:20] + ".so")
+    if not os.path.exists(so):
+        hdr = so[:-3] + "_dims.h"
+        with open(hdr, "w") as f:
+            f.write(defines)
+        tmp = so + f".{os.getpid()}.tmp"
+        subprocess.check_call(["g++", "-O1", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wno-unused-function", "-DMRX_SPECIALIZED",
+                               "-include", hdr, "-shared", "-o", tmp, os.path.join(HERE, "cim_emu.cpp")])
+        os.replace(tmp, so)
+    return so
+
+
 _lib = None
+_spec_libs = {}
+
+
+def spec_lib(defines: str):
+    if defines not in _spec_libs:
+        _spec_libs[defines] = _declare(ctypes.CDLL(build_specialized(defines)))
+    return _spec_libs[defines]
 
 
 def lib():
     global _lib
     if _lib is None:
-        L = ctypes.CDLL(build())
+        _lib = _declare(ctypes.CDLL(build()))
+    return _lib
+
+
+def _declare(L):
+    if True:
         L.emu_create.restype = ctypes.c_void_p
         L.emu_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         L.emu_destroy.argtypes = [ctypes.c_void_p]
@@ -56,8 +90,7 @@ def lib():
                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.emu_set_observation.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                           ctypes.c_void_p]
-        _lib = L
-    return _lib
+    return L
 
 
 def _ptr(a):
@@ -68,26 +101,30 @@ class EmuBackend:
     """Batch backend with the same numpy-facing surface as the tests' GPU backend wrapper."""
 
     def __init__(self, topo, n_envs=1, start_tick=0, durations=100, snapshot_resolution=1, max_snapshots=None,
-                 max_actions=2, reverse=False, order_table=0, decision_mode=0):
+                 max_actions=2, reverse=False, order_table=0, decision_mode=0, specialized=False):
         self.topo = topo
         self._cs = topo.c_struct()
         self.cfg = MrxCimConfig(n_envs, 0, start_tick, durations, snapshot_resolution, max_snapshots or 0,
                                 max_actions, 0, decision_mode, order_table)
+        self._L = lib()
+        if specialized:   # no fused observation here: set_observation would need the matching build (as on the GPU)
+            from maro_amd.cim import specialize as spec
+            self._L = spec_lib(spec.plan_defines(self._cs, self.cfg))
         err = ctypes.create_string_buffer(256)
-        self._h = lib().emu_create(ctypes.byref(self._cs), ctypes.byref(self.cfg), err, 256)
+        self._h = self._L.emu_create(ctypes.byref(self._cs), ctypes.byref(self.cfg), err, 256)
         if not self._h:
             raise RuntimeError(err.value.decode())
         self.layout = MrxCimLayout()
-        lib().emu_get_layout(self._h, ctypes.byref(self.layout))
+        self._L.emu_get_layout(self._h, ctypes.byref(self.layout))
         self.n_envs, self.max_actions, self.reverse = n_envs, max_actions, reverse
         self.max_tick = start_tick + durations
-        base = lib().emu_workspace(self._h)
+        base = self._L.emu_workspace(self._h)
         self._ws = (ctypes.c_uint8 * self.layout.workspace_bytes).from_address(base)
         self.ws = np.frombuffer(self._ws, dtype=np.uint8)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().emu_destroy(self._h)
+        if getattr(self, "_h", None) and getattr(self, "_L", None) is not None:
+            self._L.emu_destroy(self._h)
             self._h = None
 
     def view(self, off, dtype, shape):
@@ -97,7 +134,7 @@ class EmuBackend:
     def reset(self, seed_cmd=None, mask=None):
         sc = None if seed_cmd is None else np.ascontiguousarray(seed_cmd, np.int64)
         mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
-        lib().emu_reset(self._h, _ptr(sc), _ptr(mk), int(self.reverse))
+        self._L.emu_reset(self._h, _ptr(sc), _ptr(mk), int(self.reverse))
 
     def step(self, actions=None, n_actions=None, mask=None, n_answered=None):
         a = None if actions is None else np.ascontiguousarray(actions, np.int32).reshape(self.n_envs, self.max_actions, 4)
@@ -108,7 +145,7 @@ class EmuBackend:
             self._dec = np.zeros((self.n_envs, 8) if self.cfg.decision_mode == 0 else (self.n_envs, self.layout.n_vessels, 8), np.int32)
             self._met = np.zeros((self.n_envs, 3), np.int64)
             self._done = np.zeros(self.n_envs, np.uint8)
-        lib().emu_step(self._h, _ptr(a), _ptr(na), _ptr(mk), _ptr(self._dec), _ptr(self._met), _ptr(self._done),
+        self._L.emu_step(self._h, _ptr(a), _ptr(na), _ptr(mk), _ptr(self._dec), _ptr(self._met), _ptr(self._done),
                        int(self.reverse), _ptr(nans))
         return self._dec.copy(), self._met.copy(), self._done.copy()
 
@@ -117,7 +154,7 @@ class EmuBackend:
         pa, va = np.ascontiguousarray(port_attr_ids, np.int32), np.ascontiguousarray(vessel_attr_ids, np.int32)
         self.obs_ports = np.zeros((self.n_envs, self.layout.n_ports, len(pa)), np.float64)
         self.obs_vessel = np.zeros((self.n_envs, len(va)), np.float64)
-        lib().emu_set_observation(self._h, _ptr(pa), len(pa), _ptr(va), len(va), _ptr(self.obs_ports), _ptr(self.obs_vessel))
+        self._L.emu_set_observation(self._h, _ptr(pa), len(pa), _ptr(va), len(va), _ptr(self.obs_ports), _ptr(self.obs_vessel))
         return self.obs_ports, self.obs_vessel
 
     def query(self, node_type, ticks, nodes, attrs, row_slots):
@@ -129,5 +166,5 @@ class EmuBackend:
         npe = nn if n.ndim == 2 else 0
         a = np.ascontiguousarray(attrs, np.int32)
         out = np.zeros((self.n_envs, nt, nn, row_slots), np.float64)
-        lib().emu_query(self._h, node_type, _ptr(t), nt, per_env, _ptr(n), nn, npe, _ptr(a), len(a), _ptr(out))
+        self._L.emu_query(self._h, node_type, _ptr(t), nt, per_env, _ptr(n), nn, npe, _ptr(a), len(a), _ptr(out))
         return out
