@@ -280,6 +280,8 @@ def main():
                     help="how the per-step ports / deciding-vessel snapshot slices are produced: fused into the step kernel, or by mrx_cim_query")
     ap.add_argument("--graphs", type=int, default=0, help="1: capture one step per group in a hipGraph and replay it (cim)")
     ap.add_argument("--groups", type=int, default=3, help="independent env groups per GPU, each on its own HIP stream (cim)")
+    ap.add_argument("--step-mode", type=int, default=0, help="launch form of mrx_cim_step (mrx_cim_set_step_mode): 0 best available, "
+                    "1 unsorted, 2 sorted, 3 persistent pipelined")
     ap.add_argument("--topology", default="global_trade.22p_l0.8")
     ap.add_argument("--durations", type=int, default=1120)
     ap.add_argument("--specialize", type=int, default=1, help="1: step with kernels compiled for this exact plan (maro_amd/cim/specialize.py; "
@@ -323,12 +325,12 @@ def main():
         kw = dict(durations=sim_durations, max_snapshots=max(args.ring, 8) if args.policy == "dqn" else args.ring, max_actions=1,
                   device=dev, seeds=seeds)  # dqn: the look-back window must fit the ring
         try:
-            eng = CimBatchEngine(args.topology, ng, specialize=bool(args.specialize), **kw)
+            eng = CimBatchEngine(args.topology, ng, specialize=bool(args.specialize), step_mode=args.step_mode, **kw)
         except (RuntimeError, OSError, subprocess.CalledProcessError) as e:   # no hipcc and not in the cache: generic kernels
             if not args.specialize:
                 raise
             print(f"bench: specialised kernels unavailable ({e}); using the generic ones", file=sys.stderr)
-            eng = CimBatchEngine(args.topology, ng, specialize=False, **kw)
+            eng = CimBatchEngine(args.topology, ng, specialize=False, step_mode=args.step_mode, **kw)
         engines.append(eng)
         streams.append(torch.cuda.Stream(device=dev) if G > 1 else torch.cuda.current_stream(dev))
         bufs.append(dict(actions=torch.zeros((ng, 1, 4), dtype=torch.int32, device=dev),
@@ -515,7 +517,7 @@ def main():
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {sim_durations}, "
                                    f"{'random legal agent' if args.policy == 'random' else 'per-port dueling DQN (f32 MFMA, greedy) + CIMEnvSampler state shaping (mrx_cim_dqn_act)'} on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step (' + args.obs + ')'}",
-                       "envs_per_gpu": n, "groups_per_gpu": G, "specialized_kernels": bool(engines[0].specialized), "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,
+                       "envs_per_gpu": n, "groups_per_gpu": G, "step_mode": engines[0].step_mode, "specialized_kernels": bool(engines[0].specialized), "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,
                        "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
                        "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms, "host_enqueue_ms_per_step": t_issued / args.steps * 1e3, "trajectory_gather_ms_32_steps": gather_ms,
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},

@@ -209,6 +209,22 @@ int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_acti
                  uint8_t* d_done, void* stream);
 
 /*
+ * How mrx_cim_step / mrx_cim_step_joint launch their work (no reference counterpart: the reference steps one env per
+ * process, vector_env/env_process.py:26-67; this is pure scheduling — results are identical in every mode):
+ *   1  one workgroup (one wave) per env in env order; the env's private header is read first to pick its path;
+ *   2  the same kernels over the ORDER LIST of the step: every env records, at the end of its step, whether its next step
+ *      runs a tick (full path: LDS-staged state, ~25 us) or only answers another decision of the same tick (fast path out
+ *      of HBM); a small kernel (mrx_k_cim_schedule) puts the full-path envs first, so the long waves start first, the
+ *      short ones fill the tail of the launch, and a full-path wave skips the header round trip;
+ *   3  (plan-specialised code objects with the order table, mrx_cim_load_step_kernels) the persistent pipelined kernel:
+ *      as many waves as the device holds at once walk that list; the next env's state is prefetched into registers while
+ *      the current env is computed out of LDS, write-backs drain under the next env, fast-path envs go 64 per wave.
+ *   0  automatic (default): 3 where available, else 2.
+ * Returns the mode the next step will actually use (>= 1), or a negative mrx_status.
+ */
+int mrx_cim_set_step_mode(mrx_handle h, int mode);
+
+/*
  * Fuses an agent's per-decision snapshot slices into mrx_cim_step (Sequential mode): after this call every step also writes,
  * for each stepped env that pauses at a new decision,
  *   d_obs_ports  float64 [n_envs][n_ports][n_port_attrs] = snapshot_list["ports"][decision frame :: port_attrs]
@@ -218,8 +234,8 @@ int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_acti
  * Attribute ids as mrx_cim_attr_id; single-slot attributes only, at most 8 each; HOST arrays (copied).  Rows of envs
  * that did not get a new decision (episode over, masked out) are left untouched.  n = 0 switches a part off.
  * The two buffers are engine state between steps: a step that stays inside the current tick (another vessel's decision)
- * only patches the cells its action changed — so call this before the reset / first step of an episode, and do not
- * write to the buffers.
+ * only patches the cells its action changed, so do not write to the buffers.  The call may come at any time (it drains the
+ * device): the next step of every env takes the full path and writes its whole block.
  */
 int mrx_cim_set_observation(mrx_handle h, const int32_t* port_attrs, int n_port_attrs, const int32_t* vessel_attrs,
                             int n_vessel_attrs, double* d_obs_ports, double* d_obs_vessel);

@@ -39,8 +39,11 @@ class CimBatchEngine:
     def __init__(self, topology: Union[str, CimTopology], n_envs: int, start_tick: int = 0, durations: int = 100,
                  snapshot_resolution: int = 1, max_snapshots: Optional[int] = None, max_actions: int = 1,
                  device: Union[str, torch.device] = "cuda:0", seeds: Optional[Sequence[int]] = None, order_table: int = 0,
-                 decision_mode: int = 0, specialize: Union[bool, str, None] = None):
-        """specialize: True = step with kernels compiled for this exact plan (maro_amd/cim/specialize.py: ~15 s of hipcc
+                 decision_mode: int = 0, specialize: Union[bool, str, None] = None, step_mode: int = 0):
+        """step_mode: how step() launches its work (mrx_cim_set_step_mode): 0 = the best form available (the persistent
+        pipelined kernel with specialised kernels and the order table, else the sorted launch), 1 = unsorted, 2 = sorted,
+        3 = persistent pipelined.  Pure scheduling: results are identical.
+        specialize: True = step with kernels compiled for this exact plan (maro_amd/cim/specialize.py: ~15 s of hipcc
         the first time a (topology, config) is seen, cached in-tree; +12 % env-steps/s); "cached" = use them only if the
         code object is already in the cache; False = the generic kernels; None = $MARO_AMD_SPECIALIZE ("1" / "cached" / "0"),
         default generic."""
@@ -73,6 +76,7 @@ class CimBatchEngine:
         self._bound_stream, self._bound_handle = None, None
         self.specialized = False
         self._specialize, self._obs_ids = specialize, ((), ())
+        self._step_mode = int(step_mode)
         self._load_specialized()
         self.layout = _lib.MrxCimLayout()
         _lib.check(self._L.mrx_cim_get_layout(self._h, ctypes.byref(self.layout)), "mrx_cim_get_layout")
@@ -106,14 +110,20 @@ class CimBatchEngine:
     def _load_specialized(self) -> None:
         """(Re)load the step kernels compiled for this plan and the current fused-observation configuration."""
         self.specialized = False
-        if not self._specialize:
-            return
-        from . import specialize as spec
-        try:
-            spec.load_into(self, spec.plan_defines(self._cs, self._cfg, obs=self._obs_ids), build=self._specialize != "cached")
-            self.specialized = True
-        except KeyError:
-            pass   # "cached" and not in the cache: generic kernels
+        if self._specialize:
+            from . import specialize as spec
+            try:
+                spec.load_into(self, spec.plan_defines(self._cs, self._cfg, obs=self._obs_ids), build=self._specialize != "cached")
+                self.specialized = True
+            except KeyError:
+                pass   # "cached" and not in the cache: generic kernels
+        self.set_step_mode(self._step_mode)
+
+    def set_step_mode(self, mode: int) -> int:
+        """Select the launch form of step() (see __init__); returns — and keeps in `step_mode` — the form in effect."""
+        self._step_mode = int(mode)
+        self.step_mode = _lib.check(self._L.mrx_cim_set_step_mode(self._h, self._step_mode), "mrx_cim_set_step_mode")
+        return self.step_mode
 
     def use_stream(self, stream: Optional[torch.cuda.Stream]) -> None:
         """Bind every later call of this engine to `stream` (None: back to torch's current stream at call time).  A rollout

@@ -161,7 +161,9 @@ MRX_DEV void mt_twist(uint32_t* mt) {
 
 // The lane holding `rank` (0 <= rank < n) receives the rank-th next random() of the stream;
 // lanes with rank < 0 receive 0.  n is wave-uniform (<= 64).  Advances the stream by n draws.
-MRX_DEV double mt_draw_batch(uint32_t* mt, int& idx, int rank, int n) {
+// `twisted` is set when the state array was regenerated (only then does it have to be written back; a draw without a
+// twist only moves the cursor, which lives in the private header).
+MRX_DEV double mt_draw_batch(uint32_t* mt, int& idx, int rank, int n, bool& twisted) {
   uint32_t a = 0, b = 0;
   const bool has = rank >= 0;
   const int w0 = idx + 2 * rank, w1 = w0 + 1;
@@ -170,6 +172,7 @@ MRX_DEV double mt_draw_batch(uint32_t* mt, int& idx, int rank, int n) {
   if (idx + 2 * n > MT_WORDS) {  // wave-uniform
     wave::sync();
     mt_twist(mt);
+    twisted = true;
     if (has && w0 >= MT_WORDS) a = mt_temper(mt[w0 - MT_WORDS]);
     if (has && w1 >= MT_WORDS) b = mt_temper(mt[w1 - MT_WORDS]);
     idx = idx + 2 * n - MT_WORDS;
@@ -180,7 +183,7 @@ MRX_DEV double mt_draw_batch(uint32_t* mt, int& idx, int rank, int n) {
 }
 
 // one random() delivered to every lane (wave-uniform control flow)
-MRX_DEV double mt_draw_uniform(uint32_t* mt, int& idx) { return mt_draw_batch(mt, idx, 0, 1); }
+MRX_DEV double mt_draw_uniform(uint32_t* mt, int& idx) { bool tw = false; return mt_draw_batch(mt, idx, 0, 1, tw); }
 
 // one raw 32-bit output delivered to every lane
 MRX_DEV uint32_t mt_next_u32(uint32_t* mt, int& idx) {
@@ -384,14 +387,14 @@ MRX_DEV void tick_prefetch(const CimParams& K, int env, Lds& L, int t, TickPf& p
 // Order generation of one tick (cim_data_container.py:309-398): `otg` orders -> L.oq[pair].  Used by the step kernel
 // (online generation) and by the reset kernel (order table).  pf.tb / tn / src hold the target tables of pairs
 // lane + 64 b (tick_prefetch_static).
-MRX_DEV void gen_orders(const CimParams& K, Lds& L, long long otg, int& idx_ord, const TickPf& pf) {
+MRX_DEV void gen_orders(const CimParams& K, Lds& L, long long otg, int& idx_ord, const TickPf& pf, bool& ord_twisted) {
   const int lane = wave::lane();
   const int P = KD(P), NT = KD(NT);
   const Tabs& T = L.tab;
   for (int k = lane; k < NT; k += 64) L.oq[k] = 0;
   double ns = 0.0;
   if (KD(use_order_rng)) {
-    const double r = mt_draw_batch(L.mt_ord, idx_ord, lane < P ? lane : -1, P);
+    const double r = mt_draw_batch(L.mt_ord, idx_ord, lane < P ? lane : -1, P, ord_twisted);
     if (lane < P) ns = apply_noise(T.src_base[lane], T.src_noise[lane], r);
   } else if (lane < P) {
     ns = T.src_base[lane] + 0.0;
@@ -435,7 +438,7 @@ MRX_DEV void gen_orders(const CimParams& K, Lds& L, long long otg, int& idx_ord,
     const int k = (k0) + lane;                                                               \
     const int n = (NTb - (k0)) < 64 ? (NTb - (k0)) : 64;                                      \
     if (KD(use_order_rng)) {                                                                   \
-      const double r = mt_draw_batch(L.mt_ord, idx_ord, k < NTb ? lane : -1, n);             \
+      const double r = mt_draw_batch(L.mt_ord, idx_ord, k < NTb ? lane : -1, n, ord_twisted);  \
       if (k < NTb) L.dtgt[k] = apply_noise(TB, TN, r);                                       \
     } else if (k < NTb) {                                                                    \
       L.dtgt[k] = (TB) + 0.0;                                                                \
@@ -560,7 +563,8 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
     if (KD(has_order_init)) {
       const uint64_t m = wave::ballot(nz);
       const int rank = nz ? __builtin_popcountll(m & ((1ull << lane) - 1ull)) : -1;
-      const double r = mt_draw_batch(mt_oinit, idx_oi, rank, __builtin_popcountll(m));
+      bool tw = false;
+      const double r = mt_draw_batch(mt_oinit, idx_oi, rank, __builtin_popcountll(m), tw);
       if (nz) orders = apply_noise(orders, K.sample_noise, r);
     }
     if (t < TT) {
@@ -643,6 +647,7 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
     K.seed[env] = base;
     K.status[env] = status;
     K.tick[env] = KD(start_tick);
+    K.hint[env] = 1;  // the first step of an episode takes the full path
   }
   wave::sync();
   copy_words(g_live, L.frame, KD(FW));
@@ -686,7 +691,8 @@ MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {
     wave::touch(mine);  // wait for it HERE: inside the tick loop the same wait would also drain the previous tick's row stores
     const int n_here = D - t0 < 64 ? D - t0 : 64;
     for (int j = 0; j < n_here; j++) {  // wave-uniform
-      gen_orders(K, L, (long long)wave::shfl(mine, j), idx_ord, pf);
+      bool tw = false;
+      gen_orders(K, L, (long long)wave::shfl(mine, j), idx_ord, pf, tw);
       wave::sync();
       int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t0 + j) * KD(NTP);
       for (int k = lane; k < KD(NTP); k += 64) row[k] = k < KD(NT) ? L.oq[k] : 0;
@@ -697,7 +703,8 @@ MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {
 
 // One tick, phases A..B4.  Returns the mask of vessels that arrived (their decisions follow).
 template <bool PG>
-MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf, int& idx_ord, int& idx_buf, int& status, Prof& prof) {
+MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf, int& idx_ord, int& idx_buf, int& status, Prof& prof,
+                          bool& ord_twisted, bool& buf_twisted) {
   const int lane = wave::lane();
   const int P = KD(P), V = KD(V), NT = KD(NT), H = KD(H);
   const Tabs& T = L.tab;
@@ -723,7 +730,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
       const long long delta = (long long)KD(total_containers) - wave::reduce_add(mine);
       if (otg <= delta) gen = false; else otg -= delta;
     }
-    if (gen) gen_orders(K, L, otg, idx_ord, pf);
+    if (gen) gen_orders(K, L, otg, idx_ord, pf, ord_twisted);
     else for (int k = lane; k < NT; k += 64) L.oq[k] = 0;
   }
   wave::sync();
@@ -828,7 +835,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
       const int i = i0 + lane;
       const bool has = i < n_ent;
       const int nb = (n_ent - i0) < 64 ? (n_ent - i0) : 64;
-      const double r = KD(use_buffer_rng) ? mt_draw_batch(L.mt_buf, idx_buf, has ? lane : -1, nb) : 0.0;
+      const double r = KD(use_buffer_rng) ? mt_draw_batch(L.mt_buf, idx_buf, has ? lane : -1, nb, buf_twisted) : 0.0;
       if (has) {
         const int v = ent[3 * i + 1], q = ent[3 * i + 2];
         const int rpi = T.v_route_base[v] + V_POS(v);
@@ -872,7 +879,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
       if (KD(use_buffer_rng)) {
         const uint64_t m = wave::ballot(has);
         const int rank = has ? __builtin_popcountll(m & ((1ull << lane) - 1ull)) : -1;
-        const double r = mt_draw_batch(L.mt_buf, idx_buf, rank, __builtin_popcountll(m));
+        const double r = mt_draw_batch(L.mt_buf, idx_buf, rank, __builtin_popcountll(m), buf_twisted);
         if (has) { const int src = MRX_PAIR_SRC(k0, k); b = (int)ceil(apply_noise(T.fr_base[src], T.fr_noise[src], r)); }
       } else if (has) {
         b = T.fr_delay[MRX_PAIR_SRC(k0, k)];
@@ -1071,7 +1078,13 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
   const int P = KD(P), V = KD(V);
   const int hdr = R.hdr;
   const int flags = wave::shfl(hdr, PH_FLAGS);
-  if (flags & (FL_FRESH | FL_FINISHED)) return false;
+  if (flags & FL_FINISHED) {  // reference: (None, None, True) once the generator is exhausted (core.py:128-133)
+    if (lane < 8) dec_out[lane] = lane == 7 ? -1 : 0;
+    if (lane < 3) met_out[lane] = 0;
+    if (lane == 0) *done_out = 1;
+    return true;
+  }
+  if (flags & FL_FRESH) return false;
   const uint64_t pend = ((uint64_t)(uint32_t)wave::shfl(hdr, PH_PEND_HI) << 32) | (uint32_t)wave::shfl(hdr, PH_PEND_LO);
   const int cur = wave::shfl(hdr, PH_CUR_VESSEL);
   const uint64_t pend_after = pend & ~(1ull << (cur & 63));
@@ -1162,13 +1175,122 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
     g_priv[PH_CUR_VESSEL] = v2;
     g_priv[PH_OPNUM_LO] = (int32_t)(uint32_t)((unsigned long long)opnum & 0xffffffffull);
     g_priv[PH_OPNUM_HI] = (int32_t)(opnum >> 32);
+    K.hint[env] = (pend_after & ~(1ull << v2)) ? 0 : 1;  // answering v2 leaves another decision of this tick pending: fast again
     if (status) wave::global_or(&K.status[env], status);  // fire-and-forget: a read-modify-write would wait for every store in flight
   }
   return true;
 }
 
 // ==========================================================================================
-// STEP: Env.step(action) in Sequential mode
+// FAST PATH, one env per LANE (persistent step kernel): the same transition as fast_step above, written as plain
+// per-thread code — 64 envs of the sorted order list per wave, three dependent gathers (header + action; the acting
+// port / vessel and the next vessel; that vessel's port and the plan cell).  No wave collectives: lanes may diverge.
+// Returns false if the env needs the full path (more than one action, or its hint was stale).
+template <bool OBS>
+MRX_DEV bool fast_step_lane(const CimParams& K, const CimObs& O, int env, const int32_t* act, int n_act, int32_t* dec_out,
+                            long long* met_out, uint8_t* done_out) {
+  const int P = KD(P), V = KD(V);
+  int32_t* g_live = K.live + (size_t)env * KD(FW);
+  int32_t* g_priv = K.priv + (size_t)env * KD(PW);
+  // ---- round trip 1: the 64-byte private header and the first action
+  const wave::v4i h0 = wave::ld16(g_priv), h1 = wave::ld16(g_priv + 4), h3 = wave::ld16(g_priv + 12);
+  wave::v4i a4 = {0, 0, 0, 0};
+  if (act) a4 = wave::ld16(act);
+  const int flags = h0.y;  // PH_FLAGS
+  if (flags & FL_FINISHED) {  // reference: (None, None, True) once the generator is exhausted (core.py:128-133)
+    for (int j = 0; j < 8; j++) dec_out[j] = j == 7 ? -1 : 0;
+    for (int j = 0; j < 3; j++) met_out[j] = 0;
+    *done_out = 1;
+    return true;
+  }
+  if (flags & FL_FRESH) return false;
+  const uint64_t pend = ((uint64_t)(uint32_t)h0.w << 32) | (uint32_t)h0.z;  // PH_PEND_HI, PH_PEND_LO
+  const int cur = h1.x;                                                       // PH_CUR_VESSEL
+  const uint64_t pend_after = pend & ~(1ull << (cur & 63));
+  if (!pend_after || n_act > 1) return false;
+  const int t = h0.x;  // PH_TICK
+  long long opnum = ((long long)h1.z << 32) | (uint32_t)h1.y;               // PH_OPNUM_HI, PH_OPNUM_LO
+  const long long acc_b = ((long long)h3.y << 32) | (uint32_t)h3.x, acc_s = ((long long)h3.w << 32) | (uint32_t)h3.z;
+  int status = 0;
+  const int v2 = __builtin_ctzll(pend_after);  // the vessel whose decision comes next
+#define GP(a, p) g_live[KD(f_ports) + (a) * P + (p)]
+#define GV(a, v) g_live[KD(f_vessels) + (a) * V + (v)]
+  bool do_act = n_act == 1;
+  const int av = a4.x, ap = a4.y, q = a4.z, ty = a4.w;
+  if (do_act && (av < 0 || av >= V || ap < 0 || ap >= P || q < 0 || (ty != 0 && ty != 1))) { status |= 1; do_act = false; }
+  const int sv = do_act ? av : 0, sp = do_act ? ap : 0;
+  // ---- round trip 2
+  const int c = do_act ? K.cidx_dense[sv * P + sp] : -1;
+  const int pe = GP(PA_EMPTY, sp), tc = GP(PA_TRANSFER_COST, sp);
+  const int ve = GV(VA_EMPTY, sv), rs = GV(VA_REMAINING_SPACE, sv);
+  const int period = g_priv[KD(pv_period) + sv];
+  const int lp2 = GV(VA_LOC_PORT_IDX, v2), ed2 = GV(VA_EARLY_DISCHARGE, v2);
+  int ve2 = GV(VA_EMPTY, v2), rs2 = GV(VA_REMAINING_SPACE, v2);
+  int vo[8];
+  if constexpr (OBS) {
+#pragma unroll
+    for (int a = 0; a < 8; a++) vo[a] = a < OD(nv) ? GV(ODA(va, a), v2) : 0;
+  }
+  // ---- round trip 3
+  int pe2 = GP(PA_EMPTY, lp2 >= 0 ? lp2 : 0);
+  const int pl = c >= 0 ? g_live[KD(f_plans) + c] : 0;
+  // ---- the action (business_engine.py:708-748)
+  bool applied = false;
+  int o_pe = 0, o_tc = 0, o_ve = 0, o_rs = 0;
+  if (do_act) {
+    int npe = pe, nve = ve;
+    bool ok = true;
+    if (ty == 1) { if (q > ve) ok = false; else { npe = pe + q; nve = ve - q; } }
+    else { if (q > (pe < rs ? pe : rs)) ok = false; else { npe = pe - q; nve = ve + q; } }
+    if (!ok) status |= 1;
+    else {
+      const int nrs = rs - (nve - ve);
+      applied = true; o_pe = npe; o_tc = f_bits((float)((double)bits_f(tc) + (double)q)); o_ve = nve; o_rs = nrs;
+      GP(PA_EMPTY, ap) = npe;
+      GP(PA_TRANSFER_COST, ap) = o_tc;
+      GV(VA_EMPTY, av) = nve;
+      GV(VA_REMAINING_SPACE, av) = nrs;
+      if (c >= 0) g_live[KD(f_plans) + c] = pl + period;
+      else status |= 32;  // MRX_ENV_OFFROUTE_ACTION
+      opnum += q;
+      if (ap == lp2) pe2 = npe;
+      if (av == v2) { ve2 = nve; rs2 = nrs; }
+    }
+  }
+#undef GP
+#undef GV
+  if constexpr (OBS) {  // see fast_step: the ports block of this tick is patched, the deciding vessel's row rewritten
+    if (applied) {
+      if (OD(i_empty) >= 0) O.ports[((size_t)env * P + ap) * OD(np) + OD(i_empty)] = (double)o_pe;
+      if (OD(i_tc) >= 0) O.ports[((size_t)env * P + ap) * OD(np) + OD(i_tc)] = (double)bits_f(o_tc);
+    }
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+      if (a < OD(nv)) {
+        int raw = vo[a];
+        if (applied && av == v2) { if (ODA(va, a) == VA_EMPTY) raw = o_ve; else if (ODA(va, a) == VA_REMAINING_SPACE) raw = o_rs; }
+        O.vessel[(size_t)env * OD(nv) + a] = (double)raw;
+      }
+    }
+  }
+  dec_out[0] = t; dec_out[1] = lp2; dec_out[2] = v2;
+  dec_out[3] = pe2 < rs2 ? pe2 : rs2;
+  dec_out[4] = ve2; dec_out[5] = ed2;
+  dec_out[6] = (t - KD(start_tick)) / KD(resolution); dec_out[7] = 1;
+  met_out[0] = acc_b; met_out[1] = acc_s; met_out[2] = opnum;
+  *done_out = 0;
+  g_priv[PH_PEND_LO] = (int32_t)(uint32_t)(pend_after & 0xffffffffull);
+  g_priv[PH_PEND_HI] = (int32_t)(uint32_t)(pend_after >> 32);
+  g_priv[PH_CUR_VESSEL] = v2;
+  g_priv[PH_OPNUM_LO] = (int32_t)(uint32_t)((unsigned long long)opnum & 0xffffffffull);
+  g_priv[PH_OPNUM_HI] = (int32_t)(opnum >> 32);
+  K.hint[env] = (pend_after & ~(1ull << v2)) ? 0 : 1;
+  if (status) wave::global_or(&K.status[env], status);
+  return true;
+}
+
+// ==========================================================================================
+// STEP: Env.step(action)
 //   decision[8] = (tick, port, vessel, scope.load, scope.discharge, early_discharge, frame_index, valid)
 // Decision events consumed by a step (core.py:349-366): Sequential answers the current vessel's event; Joint finishes
 // every pending event of the tick (answered or not); JointWithSequentialAction the first n_answered in event order.
@@ -1179,48 +1301,73 @@ MRX_DEV uint64_t consume_decisions(const CimParams& K, uint64_t pend, int cur, i
   return pend;
 }
 
-template <bool PG, bool OBS>
-MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds, const int32_t* actions, int n_act, int n_answered,
-                      int32_t* dec_out, long long* met_out, uint8_t* done_out) {
-  Lds L = make_lds(K, lds);
-  Prof prof;
-  const int lane = wave::lane();
-  const int P = KD(P), V = KD(V);
-  int32_t* g_priv = K.priv + (size_t)env * KD(PW);
-  int32_t* g_live = K.live + (size_t)env * KD(FW);
-  uint32_t* g_mt = K.mt + (size_t)env * MTS_COUNT * MT_WORDS;
+// one env's arguments / outputs of a step
+struct StepIO {
+  const int32_t* actions;  // this env's action rows [max_actions][4]; nullptr: none
+  int n_act, n_answered;
+  int32_t* dec_out;
+  long long* met_out;
+  uint8_t* done_out;
+};
+// the batch-level arguments of one step launch (kernel arguments)
+struct StepBatch {
+  const int32_t *actions, *n_actions, *n_answered;
+  int32_t* decisions;
+  long long* metrics;
+  uint8_t* done;
+};
+MRX_DEV StepIO step_io(const CimParams& K, const StepBatch& B, int env, bool counts = true) {
+  StepIO io;
+  io.actions = B.actions ? B.actions + (size_t)env * KD(max_actions) * 4 : nullptr;
+  io.n_act = (counts && B.actions && B.n_actions) ? B.n_actions[env] : 0;
+  io.n_answered = (counts && B.n_answered) ? B.n_answered[env] : -1;
+  io.dec_out = B.decisions + (size_t)env * (KD(decision_mode) ? (size_t)KD(V) * 8 : 8);  // Joint modes: one row per vessel
+  io.met_out = B.metrics + (size_t)env * 3;
+  io.done_out = B.done + env;
+  return io;
+}
+struct StepEnd { bool store, ord_dirty, buf_dirty; };
 
-  // The 64-byte private header and the first action decide which path this step takes.
-  if (n_act > KD(max_actions)) n_act = KD(max_actions);
-  if (KD(decision_mode) == 0) {  // Sequential
-    FastRows rows;
-    fast_rows_request<OBS>(K, O, env, rows);
-    int f0v = 0, f0p = 0, f0q = 0, f0t = 0;
-    if (actions) { f0v = actions[0]; f0p = actions[1]; f0q = actions[2]; f0t = actions[3]; }
-    if (fast_step<OBS>(K, O, env, rows, n_act, f0v, f0p, f0q, f0t, dec_out, met_out, done_out)) {
-#ifdef MRX_PROFILE_FAST_PATH  // tools build: fast-path cycles and count (its atomics perturb the full-path numbers)
-      prof.mark(13); prof.mark(14, 1);
-      prof.flush();
-#endif
-      return;
-    }
-    prof.mark(12);  // header round trip of the full path
-  }
-
-  // Everything this step needs from HBM is requested before the first wait: hot frame, private state and
-  // topology tables by LDS-DMA, the action words into registers.
-  copy_in_async(L.frame, g_live, KD(FW));
-  copy_in_async(L.priv, g_priv, KD(PW));
-  stage_tables(K, L, lds + KD(l_ctab));
-  const Tabs& T = L.tab;
+// HBM -> LDS of one env's state by LDS-DMA (complete with wave::lds_dma_wait()), and the write-back.  The RNG state
+// arrays only go back when a twist regenerated them (a plain draw moves the cursor, which is a private-header word).
+template <bool PG>
+MRX_DEV void state_load_async(const CimParams& K, Lds& L, int env) {
+  const uint32_t* g_mt = K.mt + (size_t)env * MTS_COUNT * MT_WORDS;
+  copy_in_async(L.frame, K.live + (size_t)env * KD(FW), KD(FW));
+  copy_in_async(L.priv, K.priv + (size_t)env * KD(PW), KD(PW));
   // The RNG states are requested unconditionally: whether a tick will run is only known once the private
   // state has arrived, and a second LDS-DMA round trip would serialise behind every later LDS access.
   if (!PG && KD(use_order_rng)) copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(g_mt + MTS_ORDER * MT_WORDS), MT_WORDS);
   if (KD(use_buffer_rng)) copy_in_async((int32_t*)L.mt_buf, (const int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), MT_WORDS);
+}
+template <bool PG>
+MRX_DEV void state_store(const CimParams& K, Lds& L, int env, const StepEnd& e) {
+  uint32_t* g_mt = K.mt + (size_t)env * MTS_COUNT * MT_WORDS;
+  copy_words(K.live + (size_t)env * KD(FW), L.frame, KD(FW));
+  copy_words(K.priv + (size_t)env * KD(PW), L.priv, KD(PW));
+  if (!PG && KD(use_order_rng) && e.ord_dirty) copy_words((int32_t*)(g_mt + MTS_ORDER * MT_WORDS), (const int32_t*)L.mt_ord, MT_WORDS);
+  if (KD(use_buffer_rng) && e.buf_dirty) copy_words((int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), (const int32_t*)L.mt_buf, MT_WORDS);
+}
+
+// The FULL PATH of a step on state that is already staged in LDS (frame, private state, RNG states, tables): action(s),
+// then ticks until the next decision event or the end of the episode, outputs, and the updated private header — all in
+// LDS; the caller moves the state back to HBM (StepEnd::store).  `after_land()` is called exactly once, right after the
+// first tick's prefetched inputs have landed: the point where a pipelined caller requests the NEXT env's state, so that
+// no later wait of this step stands behind that request for long.
+template <bool PG, bool OBS, class Hook>
+MRX_DEV StepEnd full_body(const CimParams& K, const CimObs& O, int env, Lds& L, const StepIO& io, int a0v, int a0p, int a0q, int a0t,
+                          Hook&& after_land, Prof& prof) {
+  const int lane = wave::lane();
+  const int P = KD(P), V = KD(V);
+  const Tabs& T = L.tab;
+  const int32_t* actions = io.actions;
+  int n_act = io.n_act;
+  const int n_answered = io.n_answered;
+  int32_t* dec_out = io.dec_out;
+  long long* met_out = io.met_out;
+  uint8_t* done_out = io.done_out;
   if (n_act > KD(max_actions)) n_act = KD(max_actions);
-  int a0v = 0, a0p = 0, a0q = 0, a0t = 0;
-  if (actions) { a0v = actions[0]; a0p = actions[1]; a0q = actions[2]; a0t = actions[3]; }
-  wave::lds_dma_wait();
+  StepEnd end = {false, false, false};
   // plan cell of the first action's (vessel, port): a shared L2-resident table, requested now and used after the tick
   // prefetch below has been issued
   int a0c = K.cidx_dense[(a0v >= 0 && a0v < V && a0p >= 0 && a0p < P) ? a0v * P + a0p : 0];
@@ -1229,7 +1376,8 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
     if (lane < 8) dec_out[lane] = lane == 7 ? -1 : 0;
     if (lane < 3) met_out[lane] = 0;
     if (lane == 0) *done_out = 1;
-    return;
+    after_land();
+    return end;
   }
   prof.mark(PF_LOAD);
 
@@ -1243,8 +1391,8 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
   int dec_v = -1;
 
   // A tick will run in this step iff no other vessel of the current tick is still waiting for its decision.
-  // Its inputs (RNG states by LDS-DMA, order count, arrival records, noise tables) are requested NOW, so that
-  // second memory round trip overlaps with the action handling and post_step below.
+  // Its inputs (order row / order count, arrival records, noise tables) are requested NOW, so that
+  // second memory round trip overlaps with the action handling below.
   TickPf pf = {};
   {
     const uint64_t pend_after = fresh ? 0ull : consume_decisions(K, pend, L.priv[PH_CUR_VESSEL], n_answered);
@@ -1288,13 +1436,13 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
   prof.mark(PF_ACTION);
 
   // ---- advance to the next decision event or the end of the episode (core.py:329-381)
-  bool mt_waited = false;
+  tick_prefetch_land(pf);  // before the snapshot stores below, so that nothing later waits behind them
+  after_land();
   for (;;) {
     if (pend) {
       dec_v = __builtin_ctzll(pend);
       break;
     }
-    tick_prefetch_land(pf);  // before the snapshot stores below, so that nothing later waits behind them
     if (!fresh) {
       // C. post_step (business_engine.py:201-224)
       if ((t + 1) % KD(resolution) == 0) {
@@ -1314,9 +1462,11 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
     }
     prof.mark(PF_POST_STEP);
     fresh = false;
-    mt_waited = true;  // RNG states are modified from here on
-    pend = run_tick<PG>(K, env, L, t, pf, idx_ord, idx_buf, status, prof);
-    if (!pend && t + 1 < KD(T)) tick_prefetch<PG>(K, env, L, t + 1, pf);  // another tick follows: request its inputs now
+    pend = run_tick<PG>(K, env, L, t, pf, idx_ord, idx_buf, status, prof, end.ord_dirty, end.buf_dirty);
+    if (!pend && t + 1 < KD(T)) {  // another tick follows: its inputs, landed before that tick's snapshot stores are issued
+      tick_prefetch<PG>(K, env, L, t + 1, pf);
+      tick_prefetch_land(pf);
+    }
   }
 
   // ---- outputs
@@ -1388,19 +1538,218 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
     L.priv[PH_ACCB_LO] = (int32_t)(uint32_t)((unsigned long long)acc_b & 0xffffffffull); L.priv[PH_ACCB_HI] = (int32_t)(acc_b >> 32);
     L.priv[PH_ACCS_LO] = (int32_t)(uint32_t)((unsigned long long)acc_s & 0xffffffffull); L.priv[PH_ACCS_HI] = (int32_t)(acc_s >> 32);
     K.tick[env] = t;
+    // the coming step of this env: fast path iff (Sequential mode and) answering dec_v leaves another decision of the
+    // tick pending, or the episode is over (the fast path reports "finished"); else a tick will run -> full path
+    K.hint[env] = (KD(decision_mode) == 0 && (finished || (pend & ~(1ull << (dec_v & 63))))) ? 0 : 1;
     if (status) wave::global_or(&K.status[env], status);  // fire-and-forget: a read-modify-write would wait for every store in flight
   }
   wave::sync();
   prof.mark(PF_OUTPUT);
-  copy_words(g_live, L.frame, KD(FW));
-  copy_words(g_priv, L.priv, KD(PW));
-  if (mt_waited) {
-    if (!PG && KD(use_order_rng)) copy_words((int32_t*)(g_mt + MTS_ORDER * MT_WORDS), (const int32_t*)L.mt_ord, MT_WORDS);
-    if (KD(use_buffer_rng)) copy_words((int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), (const int32_t*)L.mt_buf, MT_WORDS);
+  end.store = true;
+  return end;
+}
+
+// which path a step of `env` takes
+enum { PATH_PROBE = 0,  // unsorted launch: read the hint with the fast rows, then decide
+       PATH_FAST = 1,   // sorted launch, fast-hinted: fast path, full path as the fallback
+       PATH_FULL = 2 }; // sorted launch, full-hinted: no header round trip, straight to the state transfer
+
+// One env per workgroup (one wave): fast path out of HBM, or LDS-DMA in -> full_body -> write-back.
+template <bool PG, bool OBS>
+MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds, const StepIO& io, int path) {
+  Lds L = make_lds(K, lds);
+  Prof prof;
+  // The 64-byte private header and the first action decide which path this step takes.
+  if (KD(decision_mode) == 0 && path != PATH_FULL) {  // Sequential
+    FastRows rows;
+    fast_rows_request<OBS>(K, O, env, rows);
+    int hint = 0;
+    if (path == PATH_PROBE) hint = K.hint[env];
+    int f0v = 0, f0p = 0, f0q = 0, f0t = 0;
+    if (io.actions) { f0v = io.actions[0]; f0p = io.actions[1]; f0q = io.actions[2]; f0t = io.actions[3]; }
+    if (!U(hint) && fast_step<OBS>(K, O, env, rows, io.n_act > KD(max_actions) ? KD(max_actions) : io.n_act, f0v, f0p, f0q, f0t, io.dec_out,
+                                   io.met_out, io.done_out)) {
+#ifdef MRX_PROFILE_FAST_PATH  // tools build: fast-path cycles and count (its atomics perturb the full-path numbers)
+      prof.mark(13); prof.mark(14, 1);
+      prof.flush();
+#endif
+      return;
+    }
+    prof.mark(12);  // header round trip of the full path
+  }
+  // Everything this step needs from HBM is requested before the first wait: hot frame, private state and
+  // topology tables by LDS-DMA, the action words into registers.
+  state_load_async<PG>(K, L, env);
+  stage_tables(K, L, lds + KD(l_ctab));
+  int a0v = 0, a0p = 0, a0q = 0, a0t = 0;
+  if (io.actions) { a0v = io.actions[0]; a0p = io.actions[1]; a0q = io.actions[2]; a0t = io.actions[3]; }
+  wave::lds_dma_wait();
+  const StepEnd e = full_body<PG, OBS>(K, O, env, L, io, a0v, a0p, a0q, a0t, [] {}, prof);
+  if (e.store) state_store<PG>(K, L, env, e);
+  prof.mark(PF_STORE);
+  prof.flush();
+}
+
+// ==========================================================================================
+// PERSISTENT, PIPELINED STEP (plan-specialised builds with the order table): `W` resident waves walk the sorted order
+// list of the step (mrx_k_cim_schedule: full-path envs first).  Wave w takes full-path entries w, w + W, ...; while
+// env k is computed out of LDS, the state of env k+1 (frame | private state | buffer RNG state: one contiguous LDS
+// block, ST4 16-byte pieces) is already on its way from HBM into REGISTERS (56 VGPRs for 22p), requested right after
+// env k's tick inputs landed; at the end of env k its final state is read LDS -> registers, the prefetched state is
+// written registers -> LDS, and the write-back of env k is issued as fire-and-forget stores that drain under env k+1.
+// So in steady state a wave never waits for HBM, and there is no header round trip at all (the order list says which
+// path an env takes).  Fast-hinted envs are handled 64 per wave (one per lane, fast_step_lane) by the last waves.
+#if defined(MRX_SPECIALIZED)
+#if MRXC_pregen && MRXC_l_frame == 0 && MRXC_l_priv == MRXC_FW && MRXC_l_mt1 == MRXC_FW + MRXC_PW
+#define MRX_HAVE_PIPE 1
+enum { SF4 = MRXC_FW / 4, SP4 = MRXC_PW / 4, SM4 = MRXC_use_buffer_rng ? MT_WORDS / 4 : 0, ST4 = SF4 + SP4 + SM4, STN = (ST4 + 63) / 64 };
+struct EnvRegs {
+  wave::v4i r[STN];
+  int a0v, a0p, a0q, a0t, n_act, n_answered;
+};
+#ifdef __HIP_DEVICE_COMPILE__
+#define MRX_ASSUME(x) __builtin_assume(x)
+#else
+#define MRX_ASSUME(x) ((void)0)
+#endif
+// HBM address of 16-byte piece g of env's state block
+MRX_DEV int32_t* state_piece(const CimParams& K, int env, int g) {
+  int32_t* f = K.live + (size_t)env * MRXC_FW + 4 * g;
+  int32_t* p = K.priv + (size_t)env * MRXC_PW + 4 * (g - SF4);
+  int32_t* m = (int32_t*)(K.mt + ((size_t)env * MTS_COUNT + MTS_BUFFER) * MT_WORDS) + 4 * (g - SF4 - SP4);
+  return g < SF4 ? f : g < SF4 + SP4 ? p : m;
+}
+// `on` = false: there is no next env.  The loads are still issued — from one shared 16-byte dummy (the scheduling
+// block), i.e. an L2 hit and no HBM traffic — so that R is assigned UNCONDITIONALLY: a conditional prefetch would keep
+// the previous contents of all 56 registers alive across the whole step (the not-taken path's value of a phi).
+MRX_DEV void regs_load(const CimParams& K, const StepBatch& B, int env, bool on, EnvRegs& R) {
+  const int lane = wave::lane();
+  MRX_ASSUME(lane >= 0 && lane < 64);
+#pragma unroll
+  for (int c = 0; c < STN; c++) {
+    int g = c * 64 + lane;
+    g = g < ST4 ? g : ST4 - 1;
+    const int32_t* src = state_piece(K, env, g);
+    R.r[c] = wave::ld16(on ? src : K.sched);
+  }
+  const int32_t* a = (on && B.actions) ? B.actions + (size_t)env * MRXC_max_actions * 4 : K.sched + 4;  // (dummy: zeros)
+  const int32_t* na = (on && B.actions && B.n_actions) ? B.n_actions + env : K.sched + 4;
+  const int32_t* nw = (on && B.n_answered) ? B.n_answered + env : K.sched + 8;                          // (dummy: -1)
+  R.a0v = wave::ld_uniform_v(a); R.a0p = wave::ld_uniform_v(a + 1); R.a0q = wave::ld_uniform_v(a + 2); R.a0t = wave::ld_uniform_v(a + 3);
+  R.n_act = wave::ld_uniform_v(na);
+  R.n_answered = wave::ld_uniform_v(nw);
+}
+MRX_DEV void regs_to_lds(const EnvRegs& R, int32_t* lds) {
+  const int lane = wave::lane();
+  MRX_ASSUME(lane >= 0 && lane < 64);
+#pragma unroll
+  for (int c = 0; c < STN; c++) {
+    const int g = c * 64 + lane;
+    if (g < ST4) wave::lds_st16(lds + 4 * g, R.r[c]);
+  }
+}
+MRX_DEV void lds_to_regs(const int32_t* lds, EnvRegs& S) {
+  const int lane = wave::lane();
+  MRX_ASSUME(lane >= 0 && lane < 64);
+#pragma unroll
+  for (int c = 0; c < STN; c++) {
+    int g = c * 64 + lane;
+    g = g < ST4 ? g : ST4 - 1;
+    S.r[c] = wave::lds_ld16(lds + 4 * g);
+  }
+}
+MRX_DEV void regs_store(const CimParams& K, int env, const EnvRegs& S, bool buf_dirty) {
+  const int lane = wave::lane();
+  MRX_ASSUME(lane >= 0 && lane < 64);
+#pragma unroll
+  for (int c = 0; c < STN; c++) {
+    const int g = c * 64 + lane;
+    if (g < ST4 && (g < SF4 + SP4 || buf_dirty)) wave::st16_nt(state_piece(K, env, g), S.r[c]);
+  }
+}
+
+template <bool OBS>
+MRX_DEV void step_persistent(const CimParams& K, const CimObs& O, int32_t* lds, int w, int W, const StepBatch& B) {
+  Lds L = make_lds(K, lds);
+  Prof prof;
+  const int lane = wave::lane();
+  const int n = K.n_envs;
+  int i = w;
+  int e0 = i < n ? wave::ld_uniform_v(K.order + i) : -1;
+  int e1 = i + W < n ? wave::ld_uniform_v(K.order + i + W) : -1;
+  int n_tick = wave::ld_uniform_v(K.sched + 0), n_active = wave::ld_uniform_v(K.sched + 1);
+  stage_tables(K, L, lds + MRXC_l_ctab);
+  e0 = U(e0); e1 = U(e1); n_tick = U(n_tick); n_active = U(n_active);
+  EnvRegs R;
+  bool have_cur = e0 >= 0 && (e0 & MRX_ORDER_TICK);
+  int env_cur = e0 & (MRX_ORDER_TICK - 1);
+  regs_load(K, B, env_cur, have_cur, R);
+
+  // ---- fast-hinted envs: chunks of 64 entries behind the full-path ones, dealt to the LAST waves (which have the
+  // fewest full-path entries), one env per lane
+#ifndef MRX_X1
+  {
+    const int n_fast = n_active - n_tick;
+    for (int q = W - 1 - w; q * 64 < n_fast; q += W) {  // wave-uniform
+      const int j = n_tick + q * 64 + lane;
+      const bool have = j < n_active;
+      bool handled = true;
+      int env = 0;
+      if (have) {
+        env = K.order[j] & (MRX_ORDER_TICK - 1);
+        const StepIO io = step_io(K, B, env);
+        handled = fast_step_lane<OBS>(K, O, env, io.actions, io.n_act > MRXC_max_actions ? MRXC_max_actions : io.n_act, io.dec_out, io.met_out,
+                                      io.done_out);
+      }
+      uint64_t todo = wave::ballot(have && !handled);
+      while (todo) {  // stale hint / several actions: the general path, one env at a time (LDS is still free here)
+        const int b = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int env_b = wave::shfl(env, b);
+#ifndef MRX_X2
+        step_env<true, OBS>(K, O, env_b, lds, step_io(K, B, env_b), PATH_FULL);
+#endif
+        wave::sync();
+      }
+    }
+  }
+#endif
+
+  wave::lds_dma_wait();  // tables staged, first state landed
+  if (have_cur) regs_to_lds(R, lds);
+  wave::sync();
+  while (have_cur) {  // wave-uniform
+    const int e2 = U(i + 2 * W < n ? wave::ld_uniform_v(K.order + i + 2 * W) : -1);
+    const bool have_next = e1 >= 0 && (e1 & MRX_ORDER_TICK);
+    const int env_next = e1 & (MRX_ORDER_TICK - 1);
+    StepIO io = step_io(K, B, env_cur, false);  // (the counts and the first action were prefetched with the state)
+    io.n_act = U(R.n_act);
+    io.n_answered = U(R.n_answered);
+    const int a0v = U(R.a0v), a0p = U(R.a0p), a0q = U(R.a0q), a0t = U(R.a0t);
+    const StepEnd end = full_body<true, OBS>(K, O, env_cur, L, io, a0v, a0p, a0q, a0t,
+                                             [&] { regs_load(K, B, env_next, have_next, R); }, prof);
+    // env_cur's final state leaves LDS, the prefetched state of env_next enters, then env_cur's write-back is issued
+    EnvRegs S;
+#ifndef MRX_X3
+    if (end.store) lds_to_regs(lds, S);
+#endif
+    wave::sync();
+#ifndef MRX_X4
+    if (have_next) regs_to_lds(R, lds);
+#endif
+#ifndef MRX_X3
+    if (end.store) regs_store(K, env_cur, S, end.buf_dirty);
+#endif
+    wave::sync();
+    i += W; e0 = e1; e1 = e2;
+    have_cur = have_next;
+    env_cur = env_next;
   }
   prof.mark(PF_STORE);
   prof.flush();
 }
+#endif
+#endif
 
 // ==========================================================================================
 // QUERY: snapshot_list[node][ticks:nodes:attrs] -> float64 (np_backend.pyx:520-549)

@@ -26,6 +26,75 @@
 
 #include "cim_dqn.h"
 
+// Order list of the coming step (CimParams::order / sched): the envs whose step needs the full path (hint = 1: a tick
+// will run, or the episode starts) first — those are the long waves, so they start first and the short fast-path steps
+// fill the tail of the launch — then the fast-hinted ones, each class in env order; masked-out envs are left out and the
+// rest of the list is -1.  One workgroup: thread t owns envs [t * per, (t + 1) * per), a block-wide exclusive scan of
+// the two class counts gives its output offsets.  16384 envs: one 16-byte load per thread.
+// bit b of the result = byte b of the 16-byte piece is non-zero
+__device__ __forceinline__ unsigned mrx_nz16(uint4 v) {
+  auto nib = [](unsigned w) { return ((((w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u) * 0x01020408u) >> 24; };
+  return nib(v.x) | (nib(v.y) << 4) | (nib(v.z) << 8) | (nib(v.w) << 12);
+}
+
+extern "C" __global__ void __launch_bounds__(1024)
+mrx_k_cim_schedule(const uint8_t* __restrict__ hint, const uint8_t* __restrict__ mask, int mask_vec, int n, int per, int32_t* __restrict__ order,
+                   int32_t* __restrict__ sched) {
+  __shared__ int s_t[16], s_f[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lo = tid * per, hi = lo + per < n ? lo + per : n;  // per is a multiple of 16; the hint array is padded to whole pieces
+  // the two classes of a 16-env piece as bit masks
+  auto piece = [&](int p0, unsigned& t, unsigned& f) {
+    const unsigned valid = p0 + 16 <= n ? 0xffffu : ((1u << (n - p0)) - 1u);
+    const unsigned tk = mrx_nz16(*(const uint4*)(hint + p0));
+    unsigned on = 0xffffu;
+    if (mask) {
+      if (mask_vec && p0 + 16 <= n) on = mrx_nz16(*(const uint4*)(mask + p0));
+      else { on = 0; for (int b = 0; b < 16 && p0 + b < n; b++) on |= mask[p0 + b] ? (1u << b) : 0u; }
+    }
+    t = tk & on & valid;
+    f = ~tk & on & valid;
+  };
+  // pass 1: class counts of this thread's envs (kept as bit masks when the thread owns at most 64 envs)
+  int ct = 0, cf = 0;
+  unsigned long long bt = 0, bf = 0;
+  const bool small = per <= 64;
+  for (int p0 = lo; p0 < hi; p0 += 16) {
+    unsigned t, f;
+    piece(p0, t, f);
+    ct += __builtin_popcount(t); cf += __builtin_popcount(f);
+    if (small) { bt |= (unsigned long long)t << (p0 - lo); bf |= (unsigned long long)f << (p0 - lo); }
+  }
+  // block-wide exclusive scans
+  int it = ct, jf = cf;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_up(it, d, 64), v = __shfl_up(jf, d, 64);
+    if (lane >= d) { it += u; jf += v; }
+  }
+  if (lane == 63) { s_t[wid] = it; s_f[wid] = jf; }
+  __syncthreads();
+  int base_t = 0, base_f = 0, tot_t = 0, tot_f = 0;
+  for (int w = 0; w < 16; w++) {
+    if (w < wid) { base_t += s_t[w]; base_f += s_f[w]; }
+    tot_t += s_t[w]; tot_f += s_f[w];
+  }
+  int ot = base_t + it - ct, of = tot_t + base_f + jf - cf;
+  // pass 2: write the entries
+  if (small) {
+    for (unsigned long long m = bt; m; m &= m - 1) order[ot++] = (lo + __builtin_ctzll(m)) | MRX_ORDER_TICK;
+    for (unsigned long long m = bf; m; m &= m - 1) order[of++] = lo + __builtin_ctzll(m);
+  } else {
+    for (int p0 = lo; p0 < hi; p0 += 16) {
+      unsigned t, f;
+      piece(p0, t, f);
+      for (; t; t &= t - 1) order[ot++] = (p0 + __builtin_ctz(t)) | MRX_ORDER_TICK;
+      for (; f; f &= f - 1) order[of++] = p0 + __builtin_ctz(f);
+    }
+  }
+  for (int i = tot_t + tot_f + tid; i < n; i += 1024) order[i] = -1;
+  if (tid < 16) sched[tid] = tid == 0 ? tot_t : tid == 1 ? tot_t + tot_f : tid >= 8 ? -1 : 0;  // [4..7] = 0, [8..11] = -1: dummies of cim::regs_load
+}
+
 struct AttrList { int n; int32_t id[16]; };
 
 extern "C" __global__ void __launch_bounds__(256)
@@ -88,7 +157,25 @@ struct mrx_cim_engine {
   hipModule_t spec_module = nullptr;      // plan-specialised step kernels (mrx_cim_load_step_kernels), else the generic ones
   hipFunction_t spec_fn[4] = {nullptr, nullptr, nullptr, nullptr};  // [pregen * 2 + obs]
   hipFunction_t spec_reset = nullptr, spec_order_table = nullptr;
-  ~mrx_cim_engine() { if (spec_module) hipModuleUnload(spec_module); }
+  hipFunction_t spec_pipe = nullptr;      // mrx_k_cim_step_pipe (persistent pipelined step), when the code object has it
+  int pipe_waves = 0;                     // its grid: the number of waves that are resident at once
+  int step_mode = 0;                      // mrx_cim_set_step_mode (0 = automatic)
+  // Kernels of a module may still be queued or running on the caller's stream(s): drain the device before unloading it.
+  void unload_spec() {
+    if (!spec_module) return;
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess) {
+      if (cur != device) hipSetDevice(device);
+      hipDeviceSynchronize();
+      hipModuleUnload(spec_module);
+      if (cur != device && cur >= 0) hipSetDevice(cur);
+    }
+    spec_module = nullptr;
+    spec_pipe = spec_reset = spec_order_table = nullptr;
+    for (auto& f : spec_fn) f = nullptr;
+    pipe_waves = 0;
+  }
+  ~mrx_cim_engine() { unload_spec(); }
 };
 
 static thread_local std::string g_err;
@@ -227,6 +314,16 @@ int mrx_cim_step_joint(mrx_handle h, const int32_t* d_actions, const int32_t* d_
   return launch_step(h, d_actions, d_n_actions, d_n_answered, d_env_mask, d_decisions, d_metrics, d_done, stream);
 }
 
+// The launch form a step uses: 1 unsorted (workgroup b = env b), 2 sorted by mrx_k_cim_schedule, 3 persistent pipelined
+// kernel (plan-specialised code objects with the order table).  0 / unset: the best one available.
+static int effective_step_mode(mrx_handle h) {
+  static const int env_mode = getenv("MRX_CIM_STEP_MODE") ? atoi(getenv("MRX_CIM_STEP_MODE")) : 0;  // experiments
+  int m = h->step_mode ? h->step_mode : env_mode;
+  if (m < 1 || m > 3) m = 3;
+  if (m == 3 && !(h->spec_module && h->spec_pipe && h->pipe_waves > 0)) m = 2;
+  return m;
+}
+
 static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const int32_t* d_n_answered,
                        const uint8_t* d_env_mask, int32_t* d_decisions, int64_t* d_metrics, uint8_t* d_done, void* stream) {
   if (!h || !d_decisions || !d_metrics || !d_done) return set_err(MRX_ERR_INVALID_ARG, "null handle/output pointer");
@@ -235,20 +332,40 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
   const CimParams& K = h->plan.kp;
   static const size_t lds_pad = getenv("MRX_DEBUG_LDS_PAD_BYTES") ? (size_t)atoi(getenv("MRX_DEBUG_LDS_PAD_BYTES")) : 0;  // occupancy experiments
   const bool obs = h->obs.np > 0 || h->obs.nv > 0;
+  const int mode = effective_step_mode(h);
+  cim::StepBatch B = {d_actions, d_n_actions, d_n_answered, d_decisions, (long long*)d_metrics, d_done};
+  if (mode >= 2) {
+    const int per = ((K.n_envs + 1023) / 1024 + 15) / 16 * 16;  // envs per thread, whole 16-byte pieces
+    hipLaunchKernelGGL(mrx_k_cim_schedule, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const uint8_t*)K.hint, d_env_mask,
+                       ((uintptr_t)d_env_mask & 15) ? 0 : 1, K.n_envs, per, K.order, K.sched);
+  }
+  const int sorted = mode >= 2 ? 1 : 0;
   if (h->spec_module) {
     CimParams Kc = K;
     CimObs Oc = h->obs;
-    long long* met = (long long*)d_metrics;
-    void* params[] = {&Kc, &Oc, &d_actions, &d_n_actions, &d_n_answered, &d_env_mask, &d_decisions, &met, &d_done};
+    if (mode == 3) {
+      void* params[] = {&Kc, &Oc, &B};
+      HIP_TRY(hipModuleLaunchKernel(h->spec_pipe, (unsigned)(h->pipe_waves < K.n_envs ? h->pipe_waves : K.n_envs), 1, 1, 64, 1, 1,
+                                    (unsigned)((size_t)K.lds_words * 4 + lds_pad), (hipStream_t)stream, params, nullptr));
+      return MRX_OK;
+    }
+    int srt = sorted;
+    void* params[] = {&Kc, &Oc, &B, &d_env_mask, &srt};
     HIP_TRY(hipModuleLaunchKernel(h->spec_fn[(K.pregen ? 2 : 0) + (obs ? 1 : 0)], (unsigned)K.n_envs, 1, 1, 64, 1, 1,
                                   (unsigned)((size_t)K.lds_words * 4 + lds_pad), (hipStream_t)stream, params, nullptr));
     return MRX_OK;
   }
   auto kern = K.pregen ? (obs ? mrx_k_cim_step_tab_obs : mrx_k_cim_step_tab) : (obs ? mrx_k_cim_step_obs : mrx_k_cim_step);
-  hipLaunchKernelGGL(kern, dim3(K.n_envs), dim3(64), (size_t)K.lds_words * 4 + lds_pad, (hipStream_t)stream, K, h->obs, d_actions,
-                     d_n_actions, d_n_answered, d_env_mask, d_decisions, (long long*)d_metrics, d_done);
+  hipLaunchKernelGGL(kern, dim3(K.n_envs), dim3(64), (size_t)K.lds_words * 4 + lds_pad, (hipStream_t)stream, K, h->obs, B, d_env_mask, sorted);
   HIP_TRY(hipGetLastError());
   return MRX_OK;
+}
+
+int mrx_cim_set_step_mode(mrx_handle h, int mode) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  if (mode < 0 || mode > 3) return set_err(MRX_ERR_INVALID_ARG, "step mode must be 0 (automatic), 1, 2 or 3");
+  h->step_mode = mode;
+  return effective_step_mode(h);
 }
 
 static std::string plan_defines(const CimParams& K, const CimObs& O);
@@ -266,10 +383,16 @@ int mrx_cim_set_observation(mrx_handle h, const int32_t* port_attrs, int n_port_
   if (h->spec_module && plan_defines(h->plan.kp, o) != plan_defines(h->plan.kp, h->obs)) {
     // the loaded specialised kernels have the previous observation configuration compiled in: back to the generic ones until
     // mrx_cim_load_step_kernels is called with a code object for the new configuration
-    hipModuleUnload(h->spec_module);
-    h->spec_module = nullptr;
+    h->unload_spec();
   }
   h->obs = o;
+  // The fast path only patches the observation block (the cells its action changed): it relies on the env's previous
+  // step having written the whole block.  A (re)configured observation is cold, so the next step of EVERY env is sent
+  // down the full path, which writes the block in full, whatever the env's state.
+  int rc2 = use_device(h->device);
+  if (rc2 != MRX_OK) return rc2;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(h->plan.kp.hint, 1, (size_t)h->plan.kp.n_envs));
   return MRX_OK;
 }
 
@@ -427,11 +550,26 @@ int mrx_cim_load_step_kernels(mrx_handle h, const void* image, int64_t bytes, co
     return set_err(MRX_ERR_INVALID_ARG, "code object lacks the reset kernels");
   }
   if ((size_t)h->plan.kp.lds_words_reset * 4 > 64 * 1024) hipFuncSetAttribute((const void*)f_reset, hipFuncAttributeMaxDynamicSharedMemorySize, h->plan.kp.lds_words_reset * 4);
-  if (h->spec_module) hipModuleUnload(h->spec_module);
+  h->unload_spec();  // (drains the device first: kernels of the old module may still be running)
   h->spec_module = mod;
   for (int i = 0; i < 4; i++) h->spec_fn[i] = fn[i];
   h->spec_reset = f_reset;
   h->spec_order_table = f_table;
+  // the persistent pipelined step, if this plan's code object has it (order table on): its grid is the number of waves the
+  // device holds at once for this kernel's registers + LDS
+  hipFunction_t f_pipe = nullptr;
+  if (hipModuleGetFunction(&f_pipe, mod, "mrx_k_cim_step_pipe") == hipSuccess && f_pipe) {
+    if ((size_t)h->plan.kp.lds_words * 4 > 64 * 1024) hipFuncSetAttribute((const void*)f_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, h->plan.kp.lds_words * 4);
+    int per_cu = 0, cus = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_pipe, 64, (size_t)h->plan.kp.lds_words * 4) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && per_cu > 0 && cus > 0) {
+      if (getenv("MRX_CIM_PIPE_WAVES_PER_CU")) per_cu = atoi(getenv("MRX_CIM_PIPE_WAVES_PER_CU"));  // experiments
+      h->spec_pipe = f_pipe;
+      h->pipe_waves = per_cu * cus;
+    }
+  } else {
+    (void)hipGetLastError();
+  }
   return MRX_OK;
 }
 

@@ -20,7 +20,7 @@ struct CimHostPlan {
   int64_t const_off = 0;
   int64_t workspace_bytes = 0;
   // byte offsets of per-env arrays inside the workspace
-  int64_t o_live, o_ring, o_ring_fi, o_priv, o_rec, o_status, o_tick, o_nstops, o_order_prop, o_mt, o_stops, o_seed, o_vperiod, o_orders;
+  int64_t o_live, o_ring, o_ring_fi, o_priv, o_rec, o_status, o_tick, o_nstops, o_order_prop, o_mt, o_stops, o_seed, o_vperiod, o_orders, o_hint, o_order, o_sched;
   // relative offsets of const tables inside const_blob, in the order of CimParams' const pointers
   std::vector<std::pair<size_t, int64_t>> binds;  // (byte offset of a pointer field inside kp, offset in const_blob)
   int64_t ctab_rel = 0;
@@ -69,6 +69,27 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   if (t->n_ports <= 0 || t->n_ports > 64) return fail("engine limit: 1..64 ports (one lane per port)");
   if (t->n_vessels <= 0 || t->n_vessels > 64) return fail("engine limit: 1..64 vessels (one lane per vessel)");
   if (t->container_volume <= 0) return fail("container_volume must be positive");
+  if (c->n_envs >= (1 << 30)) return fail("engine limit: n_envs < 2^30");
+  // the topology arrives through the C ABI: every index / offset array is range-checked before it is used as an index
+  {
+    auto bad = [&](const char* m) { if (err) *err = m; return (int)MRX_ERR_INVALID_ARG; };
+    if (t->period < 1 || !t->order_dist) return bad("topology: period must be >= 1 (order_dist[period])");
+    if (t->n_routes <= 0 || t->n_targets < 0 || t->n_route_points <= 0) return bad("topology: n_routes / n_route_points must be positive, n_targets >= 0");
+    if (!t->route_offset || !t->route_port || !t->target_offset || !t->vessel_route || !t->vessel_start_offset) return bad("topology: null index array");
+    if (t->n_targets > 0 && !t->target_port) return bad("topology: null target_port");
+    if (t->route_offset[0] != 0 || t->route_offset[t->n_routes] != t->n_route_points) return bad("topology: route_offset must run from 0 to n_route_points");
+    for (int r = 0; r < t->n_routes; r++) if (t->route_offset[r + 1] < t->route_offset[r]) return bad("topology: route_offset must be non-decreasing");
+    for (int i = 0; i < t->n_route_points; i++) if (t->route_port[i] < 0 || t->route_port[i] >= t->n_ports) return bad("topology: route_port out of range");
+    if (t->target_offset[0] != 0 || t->target_offset[t->n_ports] != t->n_targets) return bad("topology: target_offset must run from 0 to n_targets");
+    for (int p = 0; p < t->n_ports; p++) if (t->target_offset[p + 1] < t->target_offset[p]) return bad("topology: target_offset must be non-decreasing");
+    for (int i = 0; i < t->n_targets; i++) if (t->target_port[i] < 0 || t->target_port[i] >= t->n_ports) return bad("topology: target_port out of range");
+    for (int v = 0; v < t->n_vessels; v++) {
+      const int r = t->vessel_route[v];
+      if (r < 0 || r >= t->n_routes) return bad("topology: vessel_route out of range");
+      const int L = t->route_offset[r + 1] - t->route_offset[r];
+      if (t->vessel_start_offset[v] < 0 || t->vessel_start_offset[v] >= (L > 0 ? L : 1)) return bad("topology: vessel_start_offset out of range");
+    }
+  }
   CimParams& k = pl->kp;
   memset(&k, 0, sizeof(k));
   const int P = t->n_ports, V = t->n_vessels, R = t->n_routes, NT = t->n_targets, NRP = t->n_route_points;
@@ -346,6 +367,9 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   pl->o_stops = A.take(N * (int64_t)V * k.SMAX * 4);
   pl->o_seed = A.take(N * 8);
   pl->o_vperiod = A.take(N * V * 4);
+  pl->o_hint = A.take(N + 64);  // (mrx_k_cim_schedule reads whole 16-byte pieces)
+  pl->o_order = A.take(N * 4);
+  pl->o_sched = A.take(64);
   pl->shared_orders_rel = shared_orders_rel;
   k.orders_stride = shared_orders_rel >= 0 ? 0 : (long long)c->durations * k.NTP;
   pl->o_orders = (k.pregen && shared_orders_rel < 0) ? A.take(N * (int64_t)c->durations * k.NTP * 4) : 0;
@@ -378,5 +402,6 @@ inline void cim_plan_bind(CimHostPlan* pl, void* base_) {
   k.order_prop = (int32_t*)(base + pl->o_order_prop); k.mt = (uint32_t*)(base + pl->o_mt);
   k.stops = (uint32_t*)(base + pl->o_stops); k.seed = (int64_t*)(base + pl->o_seed);
   k.vperiod = (int32_t*)(base + pl->o_vperiod);
+  k.hint = base + pl->o_hint; k.order = (int32_t*)(base + pl->o_order); k.sched = (int32_t*)(base + pl->o_sched);
   k.orders = !k.pregen ? nullptr : pl->shared_orders_rel >= 0 ? (int32_t*)(cb + pl->shared_orders_rel) : (int32_t*)(base + pl->o_orders);
 }

@@ -63,7 +63,13 @@ struct CimParams {
   int32_t *live, *ring, *ring_fi, *priv, *rec, *status, *tick, *nstops, *order_prop, *vperiod, *orders;
   uint32_t *mt, *stops;
   int64_t* seed;
+  // ---- step scheduling (engine-owned, rewritten every step)
+  uint8_t* hint;   // [n_envs] 1: the env's next step needs the full path (a tick will run / fresh); 0: it stays inside the
+                   // current tick (another vessel's decision is pending) or the episode is over -> fast path
+  int32_t* order;  // [n_envs] env ids of the coming step, full-path envs first (MRX_ORDER_TICK set), -1 padded
+  int32_t* sched;  // [4] n_tick, n_active (mrx_k_cim_schedule)
 };
+#define MRX_ORDER_TICK 0x40000000  // order[] entry flag: full-path env
 
 // The integer fields of CimParams that are constant for one (topology, config) plan: the set a specialised build
 // (cim_spec.hip) receives as MRXC_<field> macros (KD() in cim_device.h).

@@ -21,19 +21,23 @@ mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const
 #ifndef MRX_STEP_WAVES
 #define MRX_STEP_WAVES 2  // generic build: ~197 VGPRs, 2 waves/SIMD
 #endif
-#define MRX_STEP_KERNEL(NAME, PG, OBS, WAVES)                                                                                  \
-  extern "C" __global__ void __launch_bounds__(64, WAVES)                                                           \
-  NAME(CimParams K, CimObs O, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions,           \
-       const int32_t* __restrict__ n_answered, const uint8_t* __restrict__ mask, int32_t* __restrict__ decisions,   \
-       long long* __restrict__ metrics, uint8_t* __restrict__ done) {                                               \
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];                                                   \
-    const int env = blockIdx.x;                                                                                     \
-    if (mask && !mask[env]) return;                                                                                 \
-    const int32_t* a = actions ? actions + (size_t)env * KD(max_actions) * 4 : nullptr;                               \
-    const int na = (actions && n_actions) ? n_actions[env] : 0;                                                     \
-    const size_t drow = KD(decision_mode) ? (size_t)KD(V) * 8 : 8; /* Joint modes: one row per vessel */                \
-    cim::step_env<PG, OBS>(K, O, env, lds, a, na, n_answered ? n_answered[env] : -1, decisions + (size_t)env * drow,     \
-                      metrics + (size_t)env * 3, done + env);                                                       \
+// One env per workgroup.  sorted = 0: workgroup b steps env b (the fast rows and the env's hint are read first);
+// sorted = 1: workgroup b steps entry b of the order list of this step (mrx_k_cim_schedule: full-path envs first, so the
+// long waves start first and the short ones fill the tail; a full-path entry skips the header round trip).
+#define MRX_STEP_KERNEL(NAME, PG, OBS, WAVES)                                                                            \
+  extern "C" __global__ void __launch_bounds__(64, WAVES)                                                               \
+  NAME(CimParams K, CimObs O, cim::StepBatch B, const uint8_t* __restrict__ mask, int sorted) {                          \
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];                                                       \
+    int env = blockIdx.x, path = cim::PATH_PROBE;                                                                       \
+    if (sorted) {                                                                                                       \
+      const int e = K.order[blockIdx.x];                                                                                \
+      if (e < 0) return;                                                                                                \
+      env = e & (MRX_ORDER_TICK - 1);                                                                                   \
+      path = (e & MRX_ORDER_TICK) ? cim::PATH_FULL : cim::PATH_FAST;                                                    \
+    } else if (mask && !mask[env]) {                                                                                    \
+      return;                                                                                                           \
+    }                                                                                                                   \
+    cim::step_env<PG, OBS>(K, O, env, lds, cim::step_io(K, B, env), path);                                              \
   }
 // a specialised build only needs the one kernel that matches its plan's order mode (CimParams::pregen) and whether a fused
 // observation is configured (mrx_cim_set_observation reloads the code object when that changes)
@@ -56,3 +60,15 @@ MRX_STEP_KERNEL(mrx_k_cim_step_tab_obs, true, true, MRX_STEP_WAVES)
 #endif
 #undef MRX_WANT
 #undef MRX_STEP_KERNEL
+
+// The persistent, pipelined step (cim::step_persistent): gridDim.x resident waves walk the sorted order list.
+#ifdef MRX_HAVE_PIPE
+#ifndef MRX_PIPE_WAVES
+#define MRX_PIPE_WAVES 2  // the prefetched state of the next env lives in ~56 more VGPRs: 2 waves/SIMD = 8 waves/CU
+#endif
+extern "C" __global__ void __launch_bounds__(64, MRX_PIPE_WAVES)
+mrx_k_cim_step_pipe(CimParams K, CimObs O, cim::StepBatch B) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  cim::step_persistent<(MRXC_obs_np | MRXC_obs_nv) != 0>(K, O, lds, (int)blockIdx.x, (int)gridDim.x, B);
+}
+#endif

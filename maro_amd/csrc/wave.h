@@ -83,4 +83,21 @@ MRX_DEV void touch(double& x) { asm volatile("" : "+v"(x)); }
 // make a wave-uniform value provably uniform (scalar register)
 MRX_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// 16-byte register transfers of the persistent step kernel (state of the NEXT env prefetched into VGPRs while the
+// current one is computed out of LDS): plain vector loads (vmcnt), non-temporal stores, ds_read/write_b128.
+typedef int v4i __attribute__((ext_vector_type(4)));
+MRX_DEV v4i ld16(const int32_t* p) { return *(const v4i*)p; }
+MRX_DEV void st16_nt(int32_t* p, v4i v) { __builtin_nontemporal_store(v, (v4i*)p); }
+MRX_DEV v4i lds_ld16(const int32_t* p) { return *(const v4i*)p; }
+MRX_DEV void lds_st16(int32_t* p, v4i v) { *(v4i*)p = v; }
+// a wave-uniform word through the VECTOR memory path (a plain global_load: vmcnt only).  A scalar load — and a
+// flat_load — count in lgkmcnt, so the next wave::sync() would wait for them: they could not stay in flight across LDS
+// phases.  The empty asm makes the (global-address-space) pointer opaque, so the compiler cannot scalarise the load.
+MRX_DEV int ld_uniform_v(const int32_t* p) {
+  typedef const __attribute__((address_space(1))) int32_t* gptr_t;
+  gptr_t g = (gptr_t)p;
+  asm volatile("" : "+v"(g));
+  return *g;
+}
+
 }  // namespace wave

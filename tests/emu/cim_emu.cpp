@@ -66,21 +66,55 @@ void emu_reset(void* h, const int64_t* seed_cmd, const uint8_t* mask, int revers
   }
 }
 
+// the host twin of mrx_k_cim_schedule (cim_engine.hip): full-path envs first, then the fast-hinted ones, -1 padded
+static void emu_schedule(Emu* e, const uint8_t* mask) {
+  const CimParams& K = e->plan.kp;
+  int nt = 0, na = 0;
+  for (int env = 0; env < K.n_envs; env++) if ((!mask || mask[env]) && K.hint[env]) K.order[nt++] = env | MRX_ORDER_TICK;
+  na = nt;
+  for (int env = 0; env < K.n_envs; env++) if ((!mask || mask[env]) && !K.hint[env]) K.order[na++] = env;
+  for (int i = na; i < K.n_envs; i++) K.order[i] = -1;
+  for (int i = 0; i < 16; i++) K.sched[i] = i == 0 ? nt : i == 1 ? na : i >= 8 ? -1 : 0;
+}
+
+// mode 1: unsorted (workgroup b = env b, hint probed); 2: sorted one-env-per-workgroup launch; 3: persistent pipelined
+// kernel with `pipe_waves` resident waves (plan-specialised builds with the order table only)
 void emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const uint8_t* mask, int32_t* dec,
-              int64_t* met, uint8_t* done, int reverse, const int32_t* n_answered) {
+              int64_t* met, uint8_t* done, int reverse, const int32_t* n_answered, int mode, int pipe_waves) {
   Emu* e = (Emu*)h;
   const CimParams& K = e->plan.kp;
   e->wave.reverse = reverse != 0;
-  for (int env = 0; env < K.n_envs; env++) {
-    if (mask && !mask[env]) continue;
+  cim::StepBatch B = {actions, n_actions, n_answered, dec, (long long*)met, done};
+  const bool obs = e->obs.np > 0 || e->obs.nv > 0;
+  if (mode >= 2) emu_schedule(e, mask);
+  if (mode == 3) {
+#ifdef MRX_HAVE_PIPE
     memset(e->lds, 0xAB, (size_t)K.lds_words * 4);
-    const int32_t* a = actions ? actions + (size_t)env * K.max_actions * 4 : nullptr;
-    int na = (actions && n_actions) ? n_actions[env] : 0;
+    for (int w = 0; w < pipe_waves; w++) {
+      wave::run_wave(e->wave, [&]() {
+        if (obs) cim::step_persistent<true>(K, e->obs, e->lds, w, pipe_waves, B);
+        else cim::step_persistent<false>(K, e->obs, e->lds, w, pipe_waves, B);
+      });
+    }
+    return;
+#else
+    fprintf(stderr, "emu_step: mode 3 needs a plan-specialised build with the order table\n");
+    abort();
+#endif
+  }
+  for (int b = 0; b < K.n_envs; b++) {
+    int env = b, path = cim::PATH_PROBE;
+    if (mode == 2) {
+      const int en = K.order[b];
+      if (en < 0) continue;
+      env = en & (MRX_ORDER_TICK - 1);
+      path = (en & MRX_ORDER_TICK) ? cim::PATH_FULL : cim::PATH_FAST;
+    } else if (mask && !mask[env]) {
+      continue;
+    }
+    memset(e->lds, 0xAB, (size_t)K.lds_words * 4);
     wave::run_wave(e->wave, [&]() {
-      const size_t drow = K.decision_mode ? (size_t)K.V * 8 : 8;
-      const int nans = n_answered ? n_answered[env] : -1;
-      const bool obs = e->obs.np > 0 || e->obs.nv > 0;
-#define EMU_STEP(PG, OBS) cim::step_env<PG, OBS>(K, e->obs, env, e->lds, a, na, nans, dec + (size_t)env * drow, (long long*)(met + (size_t)env * 3), done + env)
+#define EMU_STEP(PG, OBS) cim::step_env<PG, OBS>(K, e->obs, env, e->lds, cim::step_io(K, B, env), path)
       if (K.pregen) { if (obs) EMU_STEP(true, true); else EMU_STEP(true, false); }
       else { if (obs) EMU_STEP(false, true); else EMU_STEP(false, false); }
 #undef EMU_STEP
@@ -94,6 +128,7 @@ void emu_set_observation(void* h, const int32_t* pa, int np, const int32_t* va, 
   for (int i = 0; i < np; i++) e->obs.pa[i] = pa[i];
   for (int i = 0; i < nv; i++) e->obs.va[i] = va[i];
   e->obs.np = np; e->obs.nv = nv; e->obs.ports = ports; e->obs.vessel = vessel;
+  memset(e->plan.kp.hint, 1, (size_t)e->plan.kp.n_envs);  // as mrx_cim_set_observation: the next step of every env writes the whole block
   e->obs.i_empty = e->obs.i_tc = -1;
   for (int i = 0; i < np; i++) {
     e->obs.pa_packed |= (unsigned)pa[i] << (4 * i);

@@ -85,7 +85,7 @@ def _declare(L):
         L.emu_workspace.restype = ctypes.c_void_p
         L.emu_workspace.argtypes = [ctypes.c_void_p]
         L.emu_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-        L.emu_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_void_p]
+        L.emu_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.emu_query.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.emu_set_observation.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
@@ -101,15 +101,21 @@ class EmuBackend:
     """Batch backend with the same numpy-facing surface as the tests' GPU backend wrapper."""
 
     def __init__(self, topo, n_envs=1, start_tick=0, durations=100, snapshot_resolution=1, max_snapshots=None,
-                 max_actions=2, reverse=False, order_table=0, decision_mode=0, specialized=False):
+                 max_actions=2, reverse=False, order_table=0, decision_mode=0, specialized=False, step_mode=1, pipe_waves=3,
+                 spec_obs=((), ())):
+        """step_mode: 1 unsorted launch, 2 sorted launch (mrx_k_cim_schedule's order), 3 persistent pipelined kernel with
+        `pipe_waves` waves (specialized=True and the order table only) — the three launch forms of mrx_cim_step."""
+        self.step_mode, self.pipe_waves = step_mode, pipe_waves
         self.topo = topo
         self._cs = topo.c_struct()
         self.cfg = MrxCimConfig(n_envs, 0, start_tick, durations, snapshot_resolution, max_snapshots or 0,
                                 max_actions, 0, decision_mode, order_table)
         self._L = lib()
-        if specialized:   # no fused observation here: set_observation would need the matching build (as on the GPU)
-            from maro_amd.cim import specialize as spec
-            self._L = spec_lib(spec.plan_defines(self._cs, self.cfg))
+        self._spec_obs = None
+        if specialized:   # the fused observation's configuration is compiled in (spec_obs = (port attr ids, vessel attr ids)):
+            from maro_amd.cim import specialize as spec   # set_observation must then be called with exactly that configuration
+            self._spec_obs = (tuple(spec_obs[0]), tuple(spec_obs[1]))
+            self._L = spec_lib(spec.plan_defines(self._cs, self.cfg, obs=self._spec_obs))
         err = ctypes.create_string_buffer(256)
         self._h = self._L.emu_create(ctypes.byref(self._cs), ctypes.byref(self.cfg), err, 256)
         if not self._h:
@@ -146,12 +152,13 @@ class EmuBackend:
             self._met = np.zeros((self.n_envs, 3), np.int64)
             self._done = np.zeros(self.n_envs, np.uint8)
         self._L.emu_step(self._h, _ptr(a), _ptr(na), _ptr(mk), _ptr(self._dec), _ptr(self._met), _ptr(self._done),
-                       int(self.reverse), _ptr(nans))
+                       int(self.reverse), _ptr(nans), int(self.step_mode), int(self.pipe_waves))
         return self._dec.copy(), self._met.copy(), self._done.copy()
 
     def set_observation(self, port_attr_ids, vessel_attr_ids):
         """Fused observation (mrx_cim_set_observation): returns (obs_ports [n, P, np], obs_vessel [n, nv]) written by step()."""
         pa, va = np.ascontiguousarray(port_attr_ids, np.int32), np.ascontiguousarray(vessel_attr_ids, np.int32)
+        assert self._spec_obs is None or self._spec_obs == (tuple(pa.tolist()), tuple(va.tolist())), "specialised build: other observation compiled in"
         self.obs_ports = np.zeros((self.n_envs, self.layout.n_ports, len(pa)), np.float64)
         self.obs_vessel = np.zeros((self.n_envs, len(va)), np.float64)
         self._L.emu_set_observation(self._h, _ptr(pa), len(pa), _ptr(va), len(va), _ptr(self.obs_ports), _ptr(self.obs_vessel))

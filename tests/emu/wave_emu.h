@@ -144,6 +144,13 @@ inline int scan_incl_add(int v) {
 // then every lane writes the same value) behaves as it does in lockstep on the GPU
 inline int uniform(int v) { rendezvous(6, v); return (int)cur_wave()->snap[first_live_lane()]; }
 
+struct v4i { int x, y, z, w; };
+inline v4i ld16(const int32_t* p) { v4i v; memcpy(&v, p, 16); return v; }
+inline void st16_nt(int32_t* p, v4i v) { memcpy(p, &v, 16); }
+inline v4i lds_ld16(const int32_t* p) { return ld16(p); }
+inline void lds_st16(int32_t* p, v4i v) { memcpy(p, &v, 16); }
+inline int ld_uniform_v(const int32_t* p) { return *p; }
+
 inline void lds_dma_16(int32_t* lds_chunk, const int32_t* gsrc_lane) { memcpy(lds_chunk + 4 * lane(), gsrc_lane, 16); }
 inline void lds_dma_wait() { sync(); }
 

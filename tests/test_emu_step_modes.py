@@ -1,0 +1,124 @@
+"""The three launch forms of mrx_cim_step on the CPU wave emulator (tests/emu): 1 = unsorted one-env-per-workgroup launch
+(the hint is probed), 2 = sorted launch (the order list of mrx_k_cim_schedule: full-path envs first, no header round trip),
+3 = the persistent pipelined kernel of the plan-specialised builds (register-prefetched next env, lane-parallel fast
+path).  All three must produce the same outputs and the same engine state, step by step, and replay the goldens."""
+import numpy as np
+import pytest
+
+from maro_amd.cim.engine import PORT_ATTRS, VESSEL_ATTRS
+from maro_amd.cim.topology import load_topology
+from oracle.cim_oracle import hash_policy_action
+from tests.backend_adapter import SingleEnvAdapter
+from tests.emu.emu import EmuBackend
+from tests.test_oracle_golden import replay_case
+
+P_ATTRS = ["empty", "full", "on_shipper", "on_consignee", "booking", "shortage", "fulfillment"]
+V_ATTRS = ["empty", "full", "remaining_space"]
+OBS = ([PORT_ATTRS.index(a) for a in P_ATTRS], [VESSEL_ATTRS.index(a) for a in V_ATTRS])
+
+
+def state_of(b):
+    lay, n = b.layout, b.n_envs
+    return {
+        "live": b.view(lay.off_live, np.int32, (n, lay.frame_words)).copy(),
+        "ring": b.view(lay.off_ring, np.int32, (n, lay.ring_slots, lay.frame_words)).copy(),
+        "ring_fi": b.view(lay.off_ring_fi, np.int32, (n, lay.ring_slots)).copy(),
+        "status": b.view(lay.off_status, np.int32, (n,)).copy(),
+        "tick": b.view(lay.off_tick, np.int32, (n,)).copy(),
+    }
+
+
+def side_by_side(topology, modes, n=6, durations=45, obs=False, max_actions=1, steps=10**9, joint=0):
+    topo = load_topology(topology)
+    seeds = np.arange(n, dtype=np.int64) * 7 + 3
+    bs = []
+    for m in modes:
+        kw = dict(n_envs=n, durations=durations, max_actions=max_actions, max_snapshots=4, decision_mode=joint)
+        if m == 3:
+            kw.update(specialized=True, step_mode=3, pipe_waves=4, spec_obs=OBS if obs else ((), ()))
+        else:
+            kw.update(step_mode=m)
+        b = EmuBackend(topo, **kw)
+        if obs:
+            b.set_observation(*OBS)
+        b.reset(seeds)
+        bs.append(b)
+    outs = [b.step() for b in bs]
+    k = 0
+    rng = np.random.RandomState(5)
+    while not outs[0][2].all() and k < steps:
+        for o in outs[1:]:
+            for x, y in zip(outs[0], o):
+                assert np.array_equal(x, y), (topology, modes, k)
+        if obs:
+            live = np.flatnonzero(outs[0][0][:, 7] == 1)
+            for b in bs[1:]:
+                assert np.array_equal(np.array(bs[0].obs_ports)[live], np.array(b.obs_ports)[live]), k
+                assert np.array_equal(np.array(bs[0].obs_vessel)[live], np.array(b.obs_vessel)[live]), k
+        dec, met, done = outs[0]
+        acts = np.zeros((n, max_actions, 4), np.int32)
+        na = np.zeros(n, np.int32)
+        if joint == 0:
+            for e in range(n):
+                if dec[e, 7] == 1:
+                    acts[e, 0] = hash_policy_action(int(seeds[e]), k, dec[e])
+                    na[e] = 1
+                    if max_actions > 1 and rng.rand() < 0.3:   # a second action: the fast path must hand over to the full path
+                        acts[e, 1] = (dec[e, 2], dec[e, 1], 0, 1)
+                        na[e] = 2
+        mask = (1 - done).astype(np.uint8)
+        if k % 7 == 3:
+            mask[k % n] = 0   # one live env sits this step out
+        outs = [b.step(acts, na, mask=mask) for b in bs]
+        k += 1
+        if k == 25:   # part of the batch starts a new episode mid-run
+            cmd = np.full(n, -2, np.int64)
+            rm = np.zeros(n, np.uint8)
+            rm[::2] = 1
+            for b in bs:
+                b.reset(cmd, rm)
+            outs = [b.step(None, None, mask=rm) for b in bs]
+    s0 = state_of(bs[0])
+    for b in bs[1:]:
+        s = state_of(b)
+        for key in s0:
+            assert np.array_equal(s0[key], s[key]), (topology, modes, key)
+    return k
+
+
+@pytest.mark.parametrize("topology", ["global_trade.22p_l0.8", "toy.5p_ssddd_l0.5"])
+def test_sorted_launch_equals_unsorted(topology):
+    assert side_by_side(topology, (1, 2)) > 30
+
+
+def test_sorted_launch_with_observation_and_two_actions():
+    side_by_side("global_trade.22p_l0.8", (1, 2), obs=True, max_actions=2, durations=30)
+
+
+@pytest.mark.parametrize("topology", ["global_trade.22p_l0.8", "toy.5p_ssddd_l0.5", "toy.4p_ssdd_l0.0"])
+def test_persistent_pipelined_kernel_equals_unsorted(topology):
+    assert side_by_side(topology, (1, 3)) > 30
+
+
+def test_persistent_pipelined_kernel_with_observation_and_two_actions():
+    side_by_side("global_trade.22p_l0.8", (1, 3), n=9, obs=True, max_actions=2, durations=30)
+
+
+def test_persistent_pipelined_kernel_joint_mode():
+    side_by_side("toy.5p_ssddd_l0.5", (1, 3), joint=1, durations=40)
+
+
+def _make(mode):
+    def make(topo, kwargs):
+        kw = dict(n_envs=1, durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
+                  max_snapshots=kwargs.get("max_snapshots"), max_actions=2, step_mode=mode)
+        if mode == 3:
+            kw.update(specialized=True, pipe_waves=2)
+        return SingleEnvAdapter(EmuBackend(topo, **kw))
+    return make
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("name", ["gt22p_l08_rand0", "toy4p_l03_res7_ring5", "gt22p_l08_res3", "toy6p_l08_rand0", "syn_immediate_returns", "case_config_folder_kat", "real_csv_rand0", "gt22p_l08_reset_chain"])
+def test_goldens_replay_in_every_launch_form(name, mode):
+    replay_case(_make(mode), name)
