@@ -219,7 +219,7 @@ int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_acti
  *   3  (plan-specialised code objects with the order table, mrx_cim_load_step_kernels) the persistent pipelined kernel:
  *      as many waves as the device holds at once walk that list; the next env's state is prefetched into registers while
  *      the current env is computed out of LDS, write-backs drain under the next env, fast-path envs go 64 per wave.
- *   0  automatic (default): 3 where available, else 2.
+ *   0  automatic (default): 2 (measured fastest on MI355X at the benchmark's batch sizes; 3 is opt-in).
  * Returns the mode the next step will actually use (>= 1), or a negative mrx_status.
  */
 int mrx_cim_set_step_mode(mrx_handle h, int mode);

@@ -40,9 +40,9 @@ class CimBatchEngine:
                  snapshot_resolution: int = 1, max_snapshots: Optional[int] = None, max_actions: int = 1,
                  device: Union[str, torch.device] = "cuda:0", seeds: Optional[Sequence[int]] = None, order_table: int = 0,
                  decision_mode: int = 0, specialize: Union[bool, str, None] = None, step_mode: int = 0):
-        """step_mode: how step() launches its work (mrx_cim_set_step_mode): 0 = the best form available (the persistent
-        pipelined kernel with specialised kernels and the order table, else the sorted launch), 1 = unsorted, 2 = sorted,
-        3 = persistent pipelined.  Pure scheduling: results are identical.
+        """step_mode: how step() launches its work (mrx_cim_set_step_mode): 0 = default (the sorted launch), 1 = unsorted,
+        2 = sorted, 3 = persistent pipelined kernel (needs specialised kernels and the order table).  Pure scheduling:
+        results are identical.
         specialize: True = step with kernels compiled for this exact plan (maro_amd/cim/specialize.py: ~15 s of hipcc
         the first time a (topology, config) is seen, cached in-tree; +12 % env-steps/s); "cached" = use them only if the
         code object is already in the cache; False = the generic kernels; None = $MARO_AMD_SPECIALIZE ("1" / "cached" / "0"),

@@ -1349,95 +1349,122 @@ MRX_DEV void state_store(const CimParams& K, Lds& L, int env, const StepEnd& e) 
   if (KD(use_buffer_rng) && e.buf_dirty) copy_words((int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), (const int32_t*)L.mt_buf, MT_WORDS);
 }
 
-// The FULL PATH of a step on state that is already staged in LDS (frame, private state, RNG states, tables): action(s),
-// then ticks until the next decision event or the end of the episode, outputs, and the updated private header — all in
-// LDS; the caller moves the state back to HBM (StepEnd::store).  `after_land()` is called exactly once, right after the
-// first tick's prefetched inputs have landed: the point where a pipelined caller requests the NEXT env's state, so that
-// no later wait of this step stands behind that request for long.
-template <bool PG, bool OBS, class Hook>
-MRX_DEV StepEnd full_body(const CimParams& K, const CimObs& O, int env, Lds& L, const StepIO& io, int a0v, int a0p, int a0q, int a0t,
-                          Hook&& after_land, Prof& prof) {
-  const int lane = wave::lane();
-  const int P = KD(P), V = KD(V);
+// ------------------------------------------------------------------------------------------
+// The FULL PATH of a step on state that is already staged in LDS (frame, private state, RNG states, tables), as STAGES,
+// so that a pipelined caller can place its own memory traffic between them (gfx950 has ONE in-order vmcnt for loads and
+// stores: a wait for a load also waits for every store issued before it, so loads must be issued BEFORE store batches
+// and outputs are held in registers until a point where nothing will be waited for soon):
+//   body_open  header out of LDS; the first tick's inputs are requested (global loads)
+//   body_act   the action(s) of the pending decision (LDS only)
+//   [caller]   tick_prefetch_land(c.pf)
+//   body_run   ticks until the next decision event or the end of the episode; outputs -> registers (StepOut);
+//              updated private header -> LDS.  The caller moves the state back to HBM (StepEnd::store).
+//   body_emit  the outputs -> HBM
+struct StepCtx {
+  int t;
+  bool fresh;
+  uint64_t pend;
+  int idx_ord, idx_buf;
+  long long opnum;
+  int status;
+  int a0v, a0p, a0q, a0t, n_act, n_answered;
+  TickPf pf;
+};
+struct StepOut {
+  int kind;            // 0 nothing, 1 a regular step, 2 the episode was already over: (None, None, True)
+  int dec[8];          // Sequential mode: the decision row (lane 0)
+  long long met[3];
+  int done, hint, tick, status;
+  bool obs_on;         // fused observation written by this step
+  double obs[8];       // elements lane + 64 j of the [P][np] block
+  double vobs[8];      // the deciding vessel's row (lane 0)
+};
+
+// plan cell of (vessel v, port p) out of the staged route tables: v_cbase[v] + route_cidx of p's position on the route;
+// -1 if p is not on the vessel's route (== CimParams::cidx_dense[v * P + p], without the trip to global memory)
+MRX_DEV int plan_cell(const Lds& L, int v, int p) {
   const Tabs& T = L.tab;
-  const int32_t* actions = io.actions;
-  int n_act = io.n_act;
-  const int n_answered = io.n_answered;
-  int32_t* dec_out = io.dec_out;
-  long long* met_out = io.met_out;
-  uint8_t* done_out = io.done_out;
-  if (n_act > KD(max_actions)) n_act = KD(max_actions);
-  StepEnd end = {false, false, false};
-  // plan cell of the first action's (vessel, port): a shared L2-resident table, requested now and used after the tick
-  // prefetch below has been issued
-  int a0c = K.cidx_dense[(a0v >= 0 && a0v < V && a0p >= 0 && a0p < P) ? a0v * P + a0p : 0];
+  const int lane = wave::lane();
+  const int Lr = T.v_route_len[v], rb = T.v_route_base[v];
+  const bool hit = lane < Lr && (int)T.route_port[rb + (lane < Lr ? lane : 0)] == p;
+  const uint64_t m = wave::ballot(hit);
+  if (!m) return -1;
+  return (int)T.v_cbase[v] + (int)T.route_cidx[rb + __builtin_ctzll(m)];
+}
+
+template <bool PG>
+MRX_DEV bool body_open(const CimParams& K, int env, Lds& L, StepCtx& c, StepOut& out) {
   const int flags0 = U(L.priv[PH_FLAGS]);
+  out.kind = 0;
+  out.obs_on = false;
+  c.pf = TickPf{};
   if (flags0 & FL_FINISHED) {  // reference: (None, None, True) once the generator is exhausted
-    if (lane < 8) dec_out[lane] = lane == 7 ? -1 : 0;
-    if (lane < 3) met_out[lane] = 0;
-    if (lane == 0) *done_out = 1;
-    after_land();
-    return end;
+    out.kind = 2;
+    return false;
   }
-  prof.mark(PF_LOAD);
-
-  int t = L.priv[PH_TICK];
-  bool fresh = (flags0 & FL_FRESH) != 0;
-  uint64_t pend = ((uint64_t)(uint32_t)L.priv[PH_PEND_HI] << 32) | (uint32_t)L.priv[PH_PEND_LO];
-  int idx_ord = L.priv[PH_IDX_ORDER], idx_buf = L.priv[PH_IDX_BUFFER];
-  long long opnum = ((long long)L.priv[PH_OPNUM_HI] << 32) | (uint32_t)L.priv[PH_OPNUM_LO];
-  int status = 0;
-  bool finished = false;
-  int dec_v = -1;
-
+  if (c.n_act > KD(max_actions)) c.n_act = KD(max_actions);
+  c.t = L.priv[PH_TICK];
+  c.fresh = (flags0 & FL_FRESH) != 0;
+  c.pend = ((uint64_t)(uint32_t)L.priv[PH_PEND_HI] << 32) | (uint32_t)L.priv[PH_PEND_LO];
+  c.idx_ord = L.priv[PH_IDX_ORDER];
+  c.idx_buf = L.priv[PH_IDX_BUFFER];
+  c.opnum = ((long long)L.priv[PH_OPNUM_HI] << 32) | (uint32_t)L.priv[PH_OPNUM_LO];
+  c.status = 0;
   // A tick will run in this step iff no other vessel of the current tick is still waiting for its decision.
   // Its inputs (order row / order count, arrival records, noise tables) are requested NOW, so that
-  // second memory round trip overlaps with the action handling below.
-  TickPf pf = {};
-  {
-    const uint64_t pend_after = fresh ? 0ull : consume_decisions(K, pend, L.priv[PH_CUR_VESSEL], n_answered);
-    const int tn = fresh ? t : t + 1;
-    if (!pend_after && tn < KD(T)) {
-      if constexpr (!PG) tick_prefetch_static(K, pf, true);
-      tick_prefetch<PG>(K, env, L, tn, pf);
+  // second memory round trip overlaps with the action handling.
+  const uint64_t pend_after = c.fresh ? 0ull : consume_decisions(K, c.pend, L.priv[PH_CUR_VESSEL], c.n_answered);
+  const int tn = c.fresh ? c.t : c.t + 1;
+  if (!pend_after && tn < KD(T)) {
+    if constexpr (!PG) tick_prefetch_static(K, c.pf, true);
+    tick_prefetch<PG>(K, env, L, tn, c.pf);
+  }
+  return true;
+}
+
+// actions for the pending decision (core.py:301-315 -> business_engine.py:708-748)
+MRX_DEV void body_act(const CimParams& K, Lds& L, const int32_t* actions, StepCtx& c) {
+  const int P = KD(P), V = KD(V);
+  if (c.fresh) return;
+  for (int i = 0; i < c.n_act; i++) {  // wave-uniform
+    const int32_t* a = actions + 4 * i;
+    const int v = U(i == 0 ? c.a0v : a[0]), p = U(i == 0 ? c.a0p : a[1]), q = U(i == 0 ? c.a0q : a[2]), ty = U(i == 0 ? c.a0t : a[3]);
+    if (v < 0 || v >= V || p < 0 || p >= P || q < 0 || (ty != 0 && ty != 1)) { c.status |= 1; continue; }
+    const int pe = U(FP(PA_EMPTY, p)), ve = U(FV(VA_EMPTY, v));
+    int npe, nve;
+    if (ty == 1) {  // DISCHARGE
+      if (q > ve) { c.status |= 1; continue; }
+      npe = pe + q; nve = ve - q;
+    } else {
+      const int rs = U(FV(VA_REMAINING_SPACE, v));
+      if (q > (pe < rs ? pe : rs)) { c.status |= 1; continue; }
+      npe = pe - q; nve = ve + q;
+    }
+    FP(PA_EMPTY, p) = npe;
+    FV(VA_EMPTY, v) = nve;
+    { const int rs0 = U(FV(VA_REMAINING_SPACE, v)); FV(VA_REMAINING_SPACE, v) = rs0 - (nve - ve); }  // total_space - full - empty
+    c.opnum += q;
+    FP(PA_TRANSFER_COST, p) = f_bits((float)((double)bits_f(U(FP(PA_TRANSFER_COST, p))) + (double)q));
+    {  // vessel_plans[v, p] += period (:748): the compact plan cell of (v, p), -1 if p is not on the vessel's route
+      const int cc = plan_cell(L, v, p);
+      if (cc >= 0) { const int pl = U(L.frame[KD(f_plans) + cc]); L.frame[KD(f_plans) + cc] = pl + U(V_PERIOD(v)); }
+      else c.status |= 32;  // MRX_ENV_OFFROUTE_ACTION
     }
   }
+  c.pend = consume_decisions(K, c.pend, L.priv[PH_CUR_VESSEL], c.n_answered);
+  wave::sync();
+}
 
-  // ---- actions for the pending decision (core.py:301-315 -> business_engine.py:708-748)
-  if (!fresh) {
-    for (int i = 0; i < n_act; i++) {  // wave-uniform
-      const int32_t* a = actions + 4 * i;
-      const int v = U(i == 0 ? a0v : a[0]), p = U(i == 0 ? a0p : a[1]), q = U(i == 0 ? a0q : a[2]), ty = U(i == 0 ? a0t : a[3]);
-      if (v < 0 || v >= V || p < 0 || p >= P || q < 0 || (ty != 0 && ty != 1)) { status |= 1; continue; }
-      const int pe = U(FP(PA_EMPTY, p)), ve = U(FV(VA_EMPTY, v));
-      int npe, nve;
-      if (ty == 1) {  // DISCHARGE
-        if (q > ve) { status |= 1; continue; }
-        npe = pe + q; nve = ve - q;
-      } else {
-        const int rs = U(FV(VA_REMAINING_SPACE, v));
-        if (q > (pe < rs ? pe : rs)) { status |= 1; continue; }
-        npe = pe - q; nve = ve + q;
-      }
-      FP(PA_EMPTY, p) = npe;
-      FV(VA_EMPTY, v) = nve;
-      { const int rs0 = U(FV(VA_REMAINING_SPACE, v)); FV(VA_REMAINING_SPACE, v) = rs0 - (nve - ve); }  // total_space - full - empty
-      opnum += q;
-      FP(PA_TRANSFER_COST, p) = f_bits((float)((double)bits_f(U(FP(PA_TRANSFER_COST, p))) + (double)q));
-      {  // vessel_plans[v, p] += period (:748): the compact plan cell of (v, p), -1 if p is not on the vessel's route
-        const int c = U(i == 0 ? a0c : K.cidx_dense[v * P + p]);
-        if (c >= 0) { const int pl = U(L.frame[KD(f_plans) + c]); L.frame[KD(f_plans) + c] = pl + U(V_PERIOD(v)); }
-        else status |= 32;  // MRX_ENV_OFFROUTE_ACTION
-      }
-    }
-    pend = consume_decisions(K, pend, L.priv[PH_CUR_VESSEL], n_answered);
-    wave::sync();
-  }
-  prof.mark(PF_ACTION);
-
+template <bool PG, bool OBS>
+MRX_DEV StepEnd body_run(const CimParams& K, const CimObs& O, int env, Lds& L, const StepIO& io, StepCtx& c, StepOut& out, Prof& prof) {
+  const int lane = wave::lane();
+  const int P = KD(P), V = KD(V);
+  StepEnd end = {true, false, false};
+  int t = c.t;
+  bool fresh = c.fresh, finished = false;
+  uint64_t pend = c.pend;
+  int dec_v = -1;
   // ---- advance to the next decision event or the end of the episode (core.py:329-381)
-  tick_prefetch_land(pf);  // before the snapshot stores below, so that nothing later waits behind them
-  after_land();
   for (;;) {
     if (pend) {
       dec_v = __builtin_ctzll(pend);
@@ -1462,21 +1489,23 @@ MRX_DEV StepEnd full_body(const CimParams& K, const CimObs& O, int env, Lds& L, 
     }
     prof.mark(PF_POST_STEP);
     fresh = false;
-    pend = run_tick<PG>(K, env, L, t, pf, idx_ord, idx_buf, status, prof, end.ord_dirty, end.buf_dirty);
+    pend = run_tick<PG>(K, env, L, t, c.pf, c.idx_ord, c.idx_buf, c.status, prof, end.ord_dirty, end.buf_dirty);
     if (!pend && t + 1 < KD(T)) {  // another tick follows: its inputs, landed before that tick's snapshot stores are issued
-      tick_prefetch<PG>(K, env, L, t + 1, pf);
-      tick_prefetch_land(pf);
+      tick_prefetch<PG>(K, env, L, t + 1, c.pf);
+      tick_prefetch_land(c.pf);
     }
   }
 
-  // ---- outputs
+  // ---- outputs (into registers; body_emit stores them)
   long long acc_b = 0, acc_s = 0;
   if (lane < P) { acc_b = FP(PA_ACC_BOOKING, lane); acc_s = FP(PA_ACC_SHORTAGE, lane); }
   acc_b = wave::reduce_add(acc_b);
   acc_s = wave::reduce_add(acc_s);
   const int fi = (t - KD(start_tick)) / KD(resolution);
+  out.kind = 1;
   if (KD(decision_mode) != 0) {
-    // Joint modes: one row per pending decision event, in event (= vessel) order; dec_out is [V][8]
+    // Joint modes: one row per pending decision event, in event (= vessel) order; dec_out is [V][8] (stored right here)
+    int32_t* dec_out = io.dec_out;
     const uint64_t pm = finished ? 0ull : pend;
     const bool mine = lane < V && ((pm >> lane) & 1ull);
     if (mine) {
@@ -1496,56 +1525,118 @@ MRX_DEV StepEnd full_body(const CimParams& K, const CimObs& O, int env, Lds& L, 
   } else if (!finished) {
     // The pre-decision snapshot (core.py:345) is ALIASED, not copied: while an env is paused, frame index
     // fi(t) of its snapshot list is its live frame (mrx_cim_query resolves it); see DESIGN.md.
-    if (lane == 0) {
+    {
       const int v = dec_v, p = FV(VA_LOC_PORT_IDX, v);
       const int pe = FP(PA_EMPTY, p), rs = FV(VA_REMAINING_SPACE, v);
-      dec_out[0] = t; dec_out[1] = p; dec_out[2] = v;
-      dec_out[3] = pe < rs ? pe : rs;  // action_scope :247-260
-      dec_out[4] = FV(VA_EMPTY, v);
-      dec_out[5] = FV(VA_EARLY_DISCHARGE, v);
-      dec_out[6] = fi; dec_out[7] = 1;
+      out.dec[0] = t; out.dec[1] = p; out.dec[2] = v;
+      out.dec[3] = pe < rs ? pe : rs;  // action_scope :247-260
+      out.dec[4] = FV(VA_EMPTY, v);
+      out.dec[5] = FV(VA_EARLY_DISCHARGE, v);
+      out.dec[6] = fi; out.dec[7] = 1;
     }
     // fused observation: the decision's frame is the live frame (aliased pre-decision snapshot); consecutive lanes
-    // write consecutive doubles of the [P][np] block
+    // hold consecutive doubles of the [P][np] block
     if constexpr (OBS) {
+      out.obs_on = true;
       const int tot = P * OD(np), npd = OD(np) > 0 ? OD(np) : 1;  // (vessel-only observation: tot = 0, no division by a constant 0)
-      double* op = O.ports + (size_t)env * tot;
-      for (int i = lane; i < tot; i += 64) {
-        const int p = i / npd, a = i - p * npd;
-        const int attr = (int)((OD(pa_packed) >> (4 * a)) & 15u);
-        op[i] = port_attr_value(attr, FP(attr, p));
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int i = lane + 64 * j;
+        out.obs[j] = 0.0;
+        if (i < tot) {
+          const int p = i / npd, a = i - p * npd;
+          const int attr = (int)((OD(pa_packed) >> (4 * a)) & 15u);
+          out.obs[j] = port_attr_value(attr, FP(attr, p));
+        }
       }
 #pragma unroll
-      for (int a = 0; a < 8; a++)
-        if (a < OD(nv) && lane == 0) O.vessel[(size_t)env * OD(nv) + a] = (double)FV(ODA(va, a), dec_v);
+      for (int a = 0; a < 8; a++) out.vobs[a] = a < OD(nv) ? (double)FV(ODA(va, a), dec_v) : 0.0;
     }
-  } else if (lane == 0) {
-    dec_out[0] = t; dec_out[1] = 0; dec_out[2] = 0; dec_out[3] = 0; dec_out[4] = 0; dec_out[5] = 0;
-    dec_out[6] = fi; dec_out[7] = 0;
+  } else {
+    out.dec[0] = t; out.dec[1] = 0; out.dec[2] = 0; out.dec[3] = 0; out.dec[4] = 0; out.dec[5] = 0;
+    out.dec[6] = fi; out.dec[7] = 0;
   }
+  out.met[0] = acc_b; out.met[1] = acc_s; out.met[2] = c.opnum;  // get_metrics :270-282
+  out.done = finished ? 1 : 0;
+  out.tick = t;
+  out.status = c.status;
+  // the coming step of this env: fast path iff (Sequential mode and) answering dec_v leaves another decision of the
+  // tick pending, or the episode is over (the fast path reports "finished"); else a tick will run -> full path
+  out.hint = (KD(decision_mode) == 0 && (finished || (pend & ~(1ull << (dec_v & 63))))) ? 0 : 1;
   if (lane == 0) {
-    met_out[0] = acc_b; met_out[1] = acc_s; met_out[2] = opnum;  // get_metrics :270-282
-    *done_out = finished ? 1 : 0;
     L.priv[PH_TICK] = t;
     L.priv[PH_FLAGS] = finished ? FL_FINISHED : 0;
     L.priv[PH_PEND_LO] = (int32_t)(uint32_t)(pend & 0xffffffffull);
     L.priv[PH_PEND_HI] = (int32_t)(uint32_t)(pend >> 32);
     L.priv[PH_CUR_VESSEL] = dec_v;
-    L.priv[PH_OPNUM_LO] = (int32_t)(uint32_t)((unsigned long long)opnum & 0xffffffffull);
-    L.priv[PH_OPNUM_HI] = (int32_t)(opnum >> 32);
-    L.priv[PH_IDX_ORDER] = idx_ord;
-    L.priv[PH_IDX_BUFFER] = idx_buf;
+    L.priv[PH_OPNUM_LO] = (int32_t)(uint32_t)((unsigned long long)c.opnum & 0xffffffffull);
+    L.priv[PH_OPNUM_HI] = (int32_t)(c.opnum >> 32);
+    L.priv[PH_IDX_ORDER] = c.idx_ord;
+    L.priv[PH_IDX_BUFFER] = c.idx_buf;
     L.priv[PH_ACCB_LO] = (int32_t)(uint32_t)((unsigned long long)acc_b & 0xffffffffull); L.priv[PH_ACCB_HI] = (int32_t)(acc_b >> 32);
     L.priv[PH_ACCS_LO] = (int32_t)(uint32_t)((unsigned long long)acc_s & 0xffffffffull); L.priv[PH_ACCS_HI] = (int32_t)(acc_s >> 32);
-    K.tick[env] = t;
-    // the coming step of this env: fast path iff (Sequential mode and) answering dec_v leaves another decision of the
-    // tick pending, or the episode is over (the fast path reports "finished"); else a tick will run -> full path
-    K.hint[env] = (KD(decision_mode) == 0 && (finished || (pend & ~(1ull << (dec_v & 63))))) ? 0 : 1;
-    if (status) wave::global_or(&K.status[env], status);  // fire-and-forget: a read-modify-write would wait for every store in flight
   }
   wave::sync();
   prof.mark(PF_OUTPUT);
-  end.store = true;
+  return end;
+}
+
+template <bool OBS>
+MRX_DEV void body_emit(const CimParams& K, const CimObs& O, int env, const StepIO& io, const StepOut& out) {
+  const int lane = wave::lane();
+  if (out.kind == 0) return;
+  if (out.kind == 2) {  // the episode was over before this step: (None, None, True)
+    if (lane < 8) io.dec_out[lane] = lane == 7 ? -1 : 0;
+    if (lane < 3) io.met_out[lane] = 0;
+    if (lane == 0) *io.done_out = 1;
+    return;
+  }
+  if (KD(decision_mode) == 0) {
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) io.dec_out[j] = out.dec[j];
+    }
+    if constexpr (OBS) {
+      if (out.obs_on) {
+        const int tot = KD(P) * OD(np);
+        double* op = O.ports + (size_t)env * tot;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const int i = lane + 64 * j;
+          if (i < tot) op[i] = out.obs[j];
+        }
+#pragma unroll
+        for (int a = 0; a < 8; a++)
+          if (a < OD(nv) && lane == 0) O.vessel[(size_t)env * OD(nv) + a] = out.vobs[a];
+      }
+    }
+  }
+  if (lane == 0) {
+    io.met_out[0] = out.met[0]; io.met_out[1] = out.met[1]; io.met_out[2] = out.met[2];
+    *io.done_out = (uint8_t)out.done;
+    K.tick[env] = out.tick;
+    K.hint[env] = (uint8_t)out.hint;
+    if (out.status) wave::global_or(&K.status[env], out.status);  // fire-and-forget: a read-modify-write would wait for every store in flight
+  }
+}
+
+// the stages back to back (one env per workgroup kernels)
+template <bool PG, bool OBS>
+MRX_DEV StepEnd full_body(const CimParams& K, const CimObs& O, int env, Lds& L, const StepIO& io, int a0v, int a0p, int a0q, int a0t, Prof& prof) {
+  StepCtx c;
+  StepOut out;
+  c.a0v = a0v; c.a0p = a0p; c.a0q = a0q; c.a0t = a0t;
+  c.n_act = io.n_act; c.n_answered = io.n_answered;
+  StepEnd end = {false, false, false};
+  if (body_open<PG>(K, env, L, c, out)) {
+    prof.mark(PF_LOAD);
+    body_act(K, L, io.actions, c);
+    prof.mark(PF_ACTION);
+    tick_prefetch_land(c.pf);  // before the snapshot stores of post_step, so that nothing later waits behind them
+    prof.mark(PF_MT_LOAD);
+    end = body_run<PG, OBS>(K, O, env, L, io, c, out, prof);
+  }
+  body_emit<OBS>(K, O, env, io, out);
   return end;
 }
 
@@ -1584,7 +1675,7 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
   int a0v = 0, a0p = 0, a0q = 0, a0t = 0;
   if (io.actions) { a0v = io.actions[0]; a0p = io.actions[1]; a0q = io.actions[2]; a0t = io.actions[3]; }
   wave::lds_dma_wait();
-  const StepEnd e = full_body<PG, OBS>(K, O, env, L, io, a0v, a0p, a0q, a0t, [] {}, prof);
+  const StepEnd e = full_body<PG, OBS>(K, O, env, L, io, a0v, a0p, a0q, a0t, prof);
   if (e.store) state_store<PG>(K, L, env, e);
   prof.mark(PF_STORE);
   prof.flush();
@@ -1599,6 +1690,9 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
 // written registers -> LDS, and the write-back of env k is issued as fire-and-forget stores that drain under env k+1.
 // So in steady state a wave never waits for HBM, and there is no header round trip at all (the order list says which
 // path an env takes).  Fast-hinted envs are handled 64 per wave (one per lane, fast_step_lane) by the last waves.
+#ifndef MRX_EXP_STORE
+#define MRX_EXP_STORE 0
+#endif
 #if defined(MRX_SPECIALIZED)
 #if MRXC_pregen && MRXC_l_frame == 0 && MRXC_l_priv == MRXC_FW && MRXC_l_mt1 == MRXC_FW + MRXC_PW
 #define MRX_HAVE_PIPE 1
@@ -1658,13 +1752,38 @@ MRX_DEV void lds_to_regs(const int32_t* lds, EnvRegs& S) {
     S.r[c] = wave::lds_ld16(lds + 4 * g);
   }
 }
-MRX_DEV void regs_store(const CimParams& K, int env, const EnvRegs& S, bool buf_dirty) {
+// Exactly STN store instructions with a full exec mask, always (the caller counts on that number: s_waitcnt vmcnt).
+// Lanes behind the end of the block rewrite its last piece (same data).  Pieces that must not be written — the RNG state
+// when no twist regenerated it, everything when `on` is false — go to this wave's own 64-byte scratch line instead (all
+// lanes to one address: one line per instruction, and no line shared between waves).
+MRX_DEV void regs_store(const CimParams& K, int env, const EnvRegs& S, bool on, bool buf_dirty, int w) {
   const int lane = wave::lane();
   MRX_ASSUME(lane >= 0 && lane < 64);
+  int32_t* dummy = K.sched + 16 + 16 * (w & (MRX_PIPE_MAX_WAVES - 1));
+  // the two wave-uniform predicates as per-lane values the compiler cannot see through: address selects by arithmetic
+  // instead of branches around the stores — one straight line of STN stores on every path
+  int on_v = on ? 1 : 0, dirty_v = buf_dirty ? 1 : 0;
+  wave::opaque(on_v);
+  wave::opaque(dirty_v);
 #pragma unroll
   for (int c = 0; c < STN; c++) {
-    const int g = c * 64 + lane;
-    if (g < ST4 && (g < SF4 + SP4 || buf_dirty)) wave::st16_nt(state_piece(K, env, g), S.r[c]);
+    int g = c * 64 + lane;
+    g = g < ST4 ? g : ST4 - 1;
+    int wr = (on_v != 0 && (g < SF4 + SP4 || dirty_v != 0)) ? 1 : 0;
+    wave::opaque(wr);
+    const uintptr_t pa = (uintptr_t)state_piece(K, env, g), da = (uintptr_t)dummy;
+#if MRX_EXP_STORE == 1
+    *(__attribute__((address_space(1))) wave::v4i*)(da + ((pa - da) & (uintptr_t)(-(long long)wr))) = S.r[c];
+#elif MRX_EXP_STORE == 3
+    wave::st16_nt_addr(c < 13 ? da + ((pa - da) & (uintptr_t)(-(long long)wr)) : da, S.r[c]);   // (the last piece carries the header)
+    if (c == 12) { for (int z = 0; z < 13; z++) wave::st16_nt_addr(da, S.r[z]); }
+#elif MRX_EXP_STORE == 4
+    wave::st16_nt_addr(c == 12 ? da + ((pa - da) & (uintptr_t)(-(long long)wr)) : da, S.r[c]);
+#elif MRX_EXP_STORE == 2
+    if (c == 0) wave::st16_nt_addr(da + ((pa - da) & (uintptr_t)(-(long long)wr)), S.r[c]);
+#else
+    wave::st16_nt_addr(da + ((pa - da) & (uintptr_t)(-(long long)wr)), S.r[c]);
+#endif
   }
 }
 
@@ -1687,7 +1806,6 @@ MRX_DEV void step_persistent(const CimParams& K, const CimObs& O, int32_t* lds, 
 
   // ---- fast-hinted envs: chunks of 64 entries behind the full-path ones, dealt to the LAST waves (which have the
   // fewest full-path entries), one env per lane
-#ifndef MRX_X1
   {
     const int n_fast = n_active - n_tick;
     for (int q = W - 1 - w; q * 64 < n_fast; q += W) {  // wave-uniform
@@ -1706,45 +1824,75 @@ MRX_DEV void step_persistent(const CimParams& K, const CimObs& O, int32_t* lds, 
         const int b = __builtin_ctzll(todo);
         todo &= todo - 1;
         const int env_b = wave::shfl(env, b);
-#ifndef MRX_X2
         step_env<true, OBS>(K, O, env_b, lds, step_io(K, B, env_b), PATH_FULL);
-#endif
         wave::sync();
       }
     }
   }
-#endif
 
+  // ---- the pipelined loop over this wave's full-path entries.  Order of the memory traffic of one iteration (env k):
+  //   [k-1's end]  tick inputs of env k requested (loads L1), THEN the write-back of env k-1 (exactly STN stores)
+  //   body_act(k); wait for L1 only: s_waitcnt vmcnt(STN) — the stores stay in flight
+  //   outputs of env k-1 stored (they were held in registers), state of env k+1 requested (loads L2)
+  //   body_run(k): the tick phases — long enough for the stores and L2 to finish before the next wait:
+  //   state of env k: LDS -> registers; state of env k+1: registers -> LDS (L2 landed long ago)
   wave::lds_dma_wait();  // tables staged, first state landed
-  if (have_cur) regs_to_lds(R, lds);
-  wave::sync();
+  StepCtx c;
+  StepOut out_prev, out;
+  out_prev.kind = 0;
+  StepIO io_prev = step_io(K, B, 0, false);
+  int env_prev = 0;
+  bool open_ok = false;
+  if (have_cur) {
+    regs_to_lds(R, lds);
+    wave::sync();
+    c.a0v = U(R.a0v); c.a0p = U(R.a0p); c.a0q = U(R.a0q); c.a0t = U(R.a0t); c.n_act = U(R.n_act); c.n_answered = U(R.n_answered);
+    open_ok = body_open<true>(K, env_cur, L, c, out);
+    // STN stores to the scratch area: on EVERY path into the loop the tick inputs requested by body_open are followed by
+    // exactly STN stores (here: dummies; later: the previous env's write-back), so one s_waitcnt vmcnt(STN) fits all
+    regs_store(K, 0, R, false, false, w);
+  }
   while (have_cur) {  // wave-uniform
-    const int e2 = U(i + 2 * W < n ? wave::ld_uniform_v(K.order + i + 2 * W) : -1);
     const bool have_next = e1 >= 0 && (e1 & MRX_ORDER_TICK);
     const int env_next = e1 & (MRX_ORDER_TICK - 1);
-    StepIO io = step_io(K, B, env_cur, false);  // (the counts and the first action were prefetched with the state)
-    io.n_act = U(R.n_act);
-    io.n_answered = U(R.n_answered);
-    const int a0v = U(R.a0v), a0p = U(R.a0p), a0q = U(R.a0q), a0t = U(R.a0t);
-    const StepEnd end = full_body<true, OBS>(K, O, env_cur, L, io, a0v, a0p, a0q, a0t,
-                                             [&] { regs_load(K, B, env_next, have_next, R); }, prof);
-    // env_cur's final state leaves LDS, the prefetched state of env_next enters, then env_cur's write-back is issued
+    const StepIO io = step_io(K, B, env_cur, false);  // (the counts and the first action were prefetched with the state)
+    StepEnd end = {false, false, false};
+    prof.mark(PF_LOAD);
+    if (open_ok) body_act(K, L, io.actions, c);
+    prof.mark(PF_ACTION);
+    // L1 was issued before the STN write-back stores of the previous env: with the in-order vmcnt, "at most STN
+    // operations outstanding" means L1 has landed while the stores may still be in flight
+    wave::wait_vm<STN>();
+    tick_prefetch_land(c.pf);
+    body_emit<OBS>(K, O, env_prev, io_prev, out_prev);  // the previous env's outputs, held back until here
+    regs_load(K, B, env_next, have_next, R);             // L2: the next env's state (dummy loads when there is none)
+    int e2 = wave::ld_uniform_v(i + 2 * W < n ? K.order + i + 2 * W : K.sched + 8);  // (the entry after that; dummy: -1)
+    prof.mark(PF_MT_LOAD);
+    if (open_ok) end = body_run<true, OBS>(K, O, env_cur, L, io, c, out, prof);
+    e2 = U(e2);  // (consumed here, with L2: a wait for it behind the stores below would wait for them as well)
+    prof.mark(12);  // (tools: wait for L2)
+    // env_cur's final state leaves LDS, the prefetched state of env_next enters
     EnvRegs S;
-#ifndef MRX_X3
-    if (end.store) lds_to_regs(lds, S);
-#endif
+    lds_to_regs(lds, S);
     wave::sync();
-#ifndef MRX_X4
-    if (have_next) regs_to_lds(R, lds);
-#endif
-#ifndef MRX_X3
-    if (end.store) regs_store(K, env_cur, S, end.buf_dirty);
-#endif
-    wave::sync();
+    out_prev = out; io_prev = io; env_prev = env_cur;
+    open_ok = false;
+    if (have_next) {
+      regs_to_lds(R, lds);
+      wave::sync();
+      prof.mark(13);  // (tools: state swap through LDS)
+      c.a0v = U(R.a0v); c.a0p = U(R.a0p); c.a0q = U(R.a0q); c.a0t = U(R.a0t); c.n_act = U(R.n_act); c.n_answered = U(R.n_answered);
+      open_ok = body_open<true>(K, env_next, L, c, out);  // L1 of the next env: BEFORE the stores below
+      prof.mark(14);  // (tools: body_open of the next env)
+    }
+    // exactly STN store instructions, whatever the lane / dirty predicates (they redirect to a dummy address)
+    regs_store(K, env_cur, S, end.store, end.buf_dirty, w);
+    prof.mark(PF_STORE);
     i += W; e0 = e1; e1 = e2;
     have_cur = have_next;
     env_cur = env_next;
   }
+  body_emit<OBS>(K, O, env_prev, io_prev, out_prev);
   prof.mark(PF_STORE);
   prof.flush();
 }

@@ -369,7 +369,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   pl->o_vperiod = A.take(N * V * 4);
   pl->o_hint = A.take(N + 64);  // (mrx_k_cim_schedule reads whole 16-byte pieces)
   pl->o_order = A.take(N * 4);
-  pl->o_sched = A.take(64);
+  pl->o_sched = A.take(64 + 64 * MRX_PIPE_MAX_WAVES);  // counters + dummies of cim::regs_load, then the scratch pieces of cim::regs_store
   pl->shared_orders_rel = shared_orders_rel;
   k.orders_stride = shared_orders_rel >= 0 ? 0 : (long long)c->durations * k.NTP;
   pl->o_orders = (k.pregen && shared_orders_rel < 0) ? A.take(N * (int64_t)c->durations * k.NTP * 4) : 0;

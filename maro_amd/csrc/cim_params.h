@@ -70,6 +70,7 @@ struct CimParams {
   int32_t* sched;  // [4] n_tick, n_active (mrx_k_cim_schedule)
 };
 #define MRX_ORDER_TICK 0x40000000  // order[] entry flag: full-path env
+#define MRX_PIPE_MAX_WAVES 4096    // persistent step kernel: at most this many waves (each owns a 64-byte scratch line behind sched[16])
 
 // The integer fields of CimParams that are constant for one (topology, config) plan: the set a specialised build
 // (cim_spec.hip) receives as MRXC_<field> macros (KD() in cim_device.h).

@@ -88,8 +88,21 @@ MRX_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 typedef int v4i __attribute__((ext_vector_type(4)));
 MRX_DEV v4i ld16(const int32_t* p) { return *(const v4i*)p; }
 MRX_DEV void st16_nt(int32_t* p, v4i v) { __builtin_nontemporal_store(v, (v4i*)p); }
+// ... to a computed address: the cast keeps it a GLOBAL store (an address that went through integer arithmetic would
+// otherwise become a flat_store, which also counts in lgkmcnt — the next wave::sync() would wait for it)
+MRX_DEV void st16_nt_addr(uintptr_t a, v4i v) { __builtin_nontemporal_store(v, (__attribute__((address_space(1))) v4i*)a); }
 MRX_DEV v4i lds_ld16(const int32_t* p) { return *(const v4i*)p; }
 MRX_DEV void lds_st16(int32_t* p, v4i v) { *(v4i*)p = v; }
+// hide a value's provenance (e.g. its wave-uniformity) from the compiler
+MRX_DEV void opaque(int& x) { asm volatile("" : "+v"(x)); }
+
+// wait until at most N vector-memory operations (loads AND stores: gfx950 has one in-order counter) are outstanding
+template <int N>
+MRX_DEV void wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));  // vmcnt(N); expcnt / lgkmcnt: no wait
+}
+
 // a wave-uniform word through the VECTOR memory path (a plain global_load: vmcnt only).  A scalar load — and a
 // flat_load — count in lgkmcnt, so the next wave::sync() would wait for them: they could not stay in flight across LDS
 // phases.  The empty asm makes the (global-address-space) pointer opaque, so the compiler cannot scalarise the load.

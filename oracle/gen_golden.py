@@ -78,7 +78,15 @@ CASES["real_csv_rand0"] = ("=real_folder_csv:@tests/data/cim/case_data/real_fold
                             ("run", "rand0", None)])
 CASES["real_bin_none"] = ("=real_folder_bin:@tests/data/cim/case_data/real_folder_bin", dict(durations=100), [("run", "none", None)])
 CASES["toy5p_l05_sampler"] = ("toy.5p_ssddd_l0.5", dict(durations=160), [("run", "rand0", None)])  # + CIMEnvSampler state/reward
-LIGHT = {"toy4p_l00_full", "gt22p_l00_full"}  # only decisions/metrics kept (size)
+# the exact configuration bench.py times (global_trade.22p_l0.8, 1120 ticks), with the rand0 agent: every decision + metrics, and the
+# last frame of the episode ("parity on the exact timed configuration")
+CASES["gt22p_l08_full_rand0"] = ("global_trade.22p_l0.8", dict(durations=1120), [("run", "rand0", None)])
+# start_tick > 0 together with snapshot_resolution > 1 (frame_index = (tick - start_tick) // resolution, utils/common.py:81-93)
+CASES["gt22p_l08_start13_res2"] = ("global_trade.22p_l0.8", dict(start_tick=13, durations=90, snapshot_resolution=2), [("run", "rand0", None)])
+CASES["toy5p_l05_start40_res3_ring4"] = ("toy.5p_ssddd_l0.5", dict(start_tick=40, durations=100, snapshot_resolution=3, max_snapshots=4),
+                                         [("run", "rand0", 50), ("reset", False), ("run", "rand0", None)])
+LIGHT = {"toy4p_l00_full", "gt22p_l00_full", "gt22p_l08_full_rand0"}  # only decisions/metrics kept (size)
+LIGHT_FINAL = {"gt22p_l08_full_rand0"}  # ... plus the last frame of the snapshot list
 
 
 def worker(maro_root, case_name, out_path):
@@ -107,7 +115,7 @@ def worker(maro_root, case_name, out_path):
         with open(os.path.join(folder, "config.yml"), "w") as fp:
             yaml.safe_dump(VARIANTS[topology[1:]], fp, sort_keys=False)
         topology = folder
-    env = Env(scenario="cim", topology=topology, start_tick=0, **kwargs)
+    env = Env(scenario="cim", topology=topology, **{"start_tick": 0, **kwargs})
     be = env.business_engine
     light = case_name in LIGHT
     out = {}
@@ -207,6 +215,13 @@ def worker(maro_root, case_name, out_path):
             out[f"{tag}/final_tick"] = np.array([env.tick], np.int32)
             if not light:
                 record_snapshots(tag)
+            elif case_name in LIGHT_FINAL:
+                sl = env.snapshot_list
+                fi = sl.get_frame_index_list()[-1]
+                out[f"{tag}/final_frame_index"] = np.array([fi], np.int32)
+                out[f"{tag}/final_ports"] = sl["ports"][fi::PORT_ATTRS]
+                out[f"{tag}/final_vessels"] = sl["vessels"][fi::VESSEL_ATTRS]
+                out[f"{tag}/final_matrices"] = sl["matrices"][fi::MATRIX_ATTRS]
             if case_name.endswith("_sampler"):  # env_sampler.py:65-80 with config.py:24-29
                 out[f"{tag}/sampler_state"] = np.array(sampler_states, np.float64)
                 ps = env.snapshot_list["ports"]

@@ -147,9 +147,12 @@ inline int uniform(int v) { rendezvous(6, v); return (int)cur_wave()->snap[first
 struct v4i { int x, y, z, w; };
 inline v4i ld16(const int32_t* p) { v4i v; memcpy(&v, p, 16); return v; }
 inline void st16_nt(int32_t* p, v4i v) { memcpy(p, &v, 16); }
+inline void st16_nt_addr(uintptr_t a, v4i v) { memcpy((void*)a, &v, 16); }
 inline v4i lds_ld16(const int32_t* p) { return ld16(p); }
 inline void lds_st16(int32_t* p, v4i v) { memcpy(p, &v, 16); }
 inline int ld_uniform_v(const int32_t* p) { return *p; }
+template <int N> inline void wait_vm() {}
+inline void opaque(int&) {}
 
 inline void lds_dma_16(int32_t* lds_chunk, const int32_t* gsrc_lane) { memcpy(lds_chunk + 4 * lane(), gsrc_lane, 16); }
 inline void lds_dma_wait() { sync(); }

@@ -15,7 +15,7 @@ FAST = [c for c in golden_cases() if not c.endswith("_full")]
 def _make(reverse, order_table=0):
     def make(topo, kwargs):
         kw = dict(kwargs)
-        b = EmuBackend(topo, n_envs=1, durations=kw["durations"], snapshot_resolution=kw.get("snapshot_resolution", 1),
+        b = EmuBackend(topo, n_envs=1, start_tick=kw.get("start_tick", 0), durations=kw["durations"], snapshot_resolution=kw.get("snapshot_resolution", 1),
                        max_snapshots=kw.get("max_snapshots"), max_actions=2, reverse=reverse, order_table=order_table)
         assert b.layout.order_table_on == (1 if order_table >= 0 and topo.order_mode == 0 else 0)
         return SingleEnvAdapter(b)

@@ -28,7 +28,7 @@ class JointAdapter(SingleEnvAdapter):
 
 def make_emu(order_table=0, reverse=False):
     def make(topo, kwargs, mode):
-        b = EmuBackend(topo, n_envs=2, durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
+        b = EmuBackend(topo, n_envs=2, start_tick=kwargs.get("start_tick", 0), durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
                        max_snapshots=kwargs.get("max_snapshots"), max_actions=topo.n_vessels, decision_mode=mode,
                        order_table=order_table, reverse=reverse)
         return JointAdapter(b, env=1)

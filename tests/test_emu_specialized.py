@@ -15,7 +15,7 @@ SUBSET = [c for c in golden_cases() if not c.endswith("_full")][::5]
 
 def _make(order_table=0):
     def make(topo, kwargs):
-        b = EmuBackend(topo, n_envs=1, durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
+        b = EmuBackend(topo, n_envs=1, start_tick=kwargs.get("start_tick", 0), durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
                        max_snapshots=kwargs.get("max_snapshots"), max_actions=2, order_table=order_table, specialized=True)
         return SingleEnvAdapter(b)
     return make

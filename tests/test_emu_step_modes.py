@@ -110,7 +110,7 @@ def test_persistent_pipelined_kernel_joint_mode():
 
 def _make(mode):
     def make(topo, kwargs):
-        kw = dict(n_envs=1, durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
+        kw = dict(n_envs=1, start_tick=kwargs.get("start_tick", 0), durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
                   max_snapshots=kwargs.get("max_snapshots"), max_actions=2, step_mode=mode)
         if mode == 3:
             kw.update(specialized=True, pipe_waves=2)

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 def _make(topo, kwargs):
     from tests.backend_adapter import SingleEnvAdapter
     from tests.gpu_backend import GpuBackend
-    b = GpuBackend(topo, n_envs=1, durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
+    b = GpuBackend(topo, n_envs=1, start_tick=kwargs.get("start_tick", 0), durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
                    max_snapshots=kwargs.get("max_snapshots"), max_actions=2)
     return SingleEnvAdapter(b)
 
@@ -31,7 +31,7 @@ def test_hip_engine_joint_decision_modes(name):
     from tests.test_emu_joint import JointAdapter
 
     def make(topo, kwargs, mode):
-        b = GpuBackend(topo, n_envs=3, durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
+        b = GpuBackend(topo, n_envs=3, start_tick=kwargs.get("start_tick", 0), durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
                        max_snapshots=kwargs.get("max_snapshots"), max_actions=topo.n_vessels, decision_mode=mode)
         return JointAdapter(b, env=2)
     replay_joint_case(make, name)

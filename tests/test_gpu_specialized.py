@@ -37,7 +37,7 @@ def test_specialized_kernels_reproduce_reference(name):
     from tests.test_oracle_golden import replay_case
 
     def make(topo, kwargs):
-        return SingleEnvAdapter(_Spec(topo, n_envs=1, durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
+        return SingleEnvAdapter(_Spec(topo, n_envs=1, start_tick=kwargs.get("start_tick", 0), durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
                                       max_snapshots=kwargs.get("max_snapshots"), max_actions=2))
     replay_case(make, name)
 
@@ -48,7 +48,7 @@ def test_specialized_kernels_joint_modes(name):
     from tests.test_emu_joint import JointAdapter
 
     def make(topo, kwargs, mode):
-        return JointAdapter(_Spec(topo, n_envs=3, durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
+        return JointAdapter(_Spec(topo, n_envs=3, start_tick=kwargs.get("start_tick", 0), durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
                                   max_snapshots=kwargs.get("max_snapshots"), max_actions=topo.n_vessels, decision_mode=mode), env=2)
     replay_joint_case(make, name)
 

@@ -67,10 +67,10 @@ def test_goldens_replay_in_every_launch_form(name, mode):
 
     def make(topo, kwargs):
         b = GpuBackend.__new__(GpuBackend)
-        b.eng = CimBatchEngine(topo, 5, durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
+        b.eng = CimBatchEngine(topo, 5, start_tick=kwargs.get("start_tick", 0), durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
                                max_snapshots=kwargs.get("max_snapshots"), max_actions=2, specialize=(mode == 3), step_mode=mode)
         assert b.eng.step_mode == mode
-        b.topo, b.layout, b.n_envs, b.max_actions, b.max_tick = b.eng.topo, b.eng.layout, 5, 2, kwargs["durations"]
+        b.topo, b.layout, b.n_envs, b.max_actions, b.max_tick = b.eng.topo, b.eng.layout, 5, 2, kwargs.get("start_tick", 0) + kwargs["durations"]
         return SingleEnvAdapter(b, env=3)
     replay_case(make, name)
 

@@ -74,6 +74,11 @@ def replay_case(make_env, name):
             if done:
                 assert np.array_equal(met, z[f"{tag}/final_metrics"])
                 assert i == len(gd)
+            if f"{tag}/final_frame_index" in z:
+                fi = [int(z[f"{tag}/final_frame_index"][0])]
+                assert np.array_equal(env.query("ports", fi, [], PORT_ATTRS), z[f"{tag}/final_ports"])
+                assert np.array_equal(env.query("vessels", fi, [], VESSEL_ATTRS), z[f"{tag}/final_vessels"])
+                assert np.array_equal(env.query("matrices", fi, [], MATRIX_ATTRS), z[f"{tag}/final_matrices"])
             if not light:
                 assert env.frame_indices() == z[f"{tag}/frame_indices"].tolist()
                 assert np.array_equal(env.query("ports", [], [], PORT_ATTRS), z[f"{tag}/snap_ports"])

@@ -20,12 +20,15 @@ def plans(which):
     if which in ("bench", "all"):
         t = load_topology("global_trade.22p_l0.8")
         out += [(t, cfg(1120, ring=4)), (t, cfg(1120, ring=8))]            # bench.py default / --policy dqn
+    if which in ("tests", "all"):   # tests/test_gpu_step_modes.py, tests/test_gpu_bench_parity.py
+        out += [(load_topology("global_trade.22p_l0.8"), cfg(100, ring=5)), (load_topology("toy.5p_ssddd_l0.5"), cfg(100, ring=5)),
+                (load_topology("toy.6p_sssbdd_l0.8"), cfg(80, max_actions=6, mode=1))]
     if which in ("goldens", "all"):
         from tests.golden_util import case_topology, golden_cases, joint_golden_cases, load_case, load_joint_case
         for name in golden_cases():
             meta = load_case(name)[1]
             topo, kw = case_topology(meta), meta["kwargs"]
-            out.append((topo, cfg(kw["durations"], kw.get("snapshot_resolution", 1), kw.get("max_snapshots"), 2)))
+            out.append((topo, cfg(kw["durations"], kw.get("snapshot_resolution", 1), kw.get("max_snapshots"), 2, start_tick=kw.get("start_tick", 0))))
         for name in joint_golden_cases():
             meta = load_joint_case(name)[1]
             topo, kw = case_topology(meta), meta["kwargs"]
@@ -38,6 +41,8 @@ def main(which="bench"):
     from maro_amd.cim.engine import NODE_ATTRS
     bench_obs = ([NODE_ATTRS["ports"].index(a) for a in ("empty", "full", "on_shipper", "on_consignee", "booking", "shortage", "fulfillment")],
                  [NODE_ATTRS["vessels"].index(a) for a in ("empty", "full", "remaining_space")])   # bench.py QUERY_ATTRS / VESSEL_QUERY_ATTRS
+    test_obs = ([NODE_ATTRS["ports"].index(a) for a in ("empty", "full", "shortage", "transfer_cost")],
+                [NODE_ATTRS["vessels"].index(a) for a in ("empty", "remaining_space")])
     todo = {}
     for topo, c in plans(which):
         cs = topo.c_struct()
@@ -46,6 +51,8 @@ def main(which="bench"):
             todo[spec.plan_defines(cs, c)] = 1
             if which in ("bench", "all") and topo.n_ports == 22:
                 todo[spec.plan_defines(cs, c, obs=bench_obs)] = 1   # bench.py fuses this observation into the step
+            if which in ("tests", "all") and c.decision_mode == 0 and c.max_snapshots == 5:
+                todo[spec.plan_defines(cs, c, obs=test_obs)] = 1
     if which in ("bench", "all"):   # bench.py --scenario citi_bike: toy.3s_4t, 4096 envs per GPU
         import numpy as np
 
