@@ -29,12 +29,17 @@ VESSEL_QUERY_ATTRS = ["empty", "full", "remaining_space"]
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def init_dist(world, local_rank):
-    """One process per GPU over RCCL (backend "nccl").  MRX_BENCH_BACKEND=gloo + MRX_BENCH_DEVICE=<i> are test hooks only: they
-    let a 1-GPU box run the N>1 code path with every rank on the same device (RCCL refuses two ranks per GPU)."""
+def init_dist(world, local_rank, build=None):
+    """One process per GPU over RCCL (backend "nccl").  Rank 0 runs `build()` (compiles whatever is stale: the extension, the
+    plan-specialised code objects) and every other rank waits for it at a barrier BEFORE it loads anything.
+    MRX_BENCH_BACKEND=gloo + MRX_BENCH_DEVICE=<i> are test hooks only: they let a 1-GPU box run the N>1 code path with
+    every rank on the same device (RCCL refuses two ranks per GPU)."""
     import torch
     dev = torch.device(f"cuda:{os.environ.get('MRX_BENCH_DEVICE', local_rank)}")
+    rank = int(os.environ.get("RANK", "0"))
     if world <= 1:
+        if build is not None:
+            build()
         return None, dev
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -44,7 +49,9 @@ def init_dist(world, local_rank):
         dist.init_process_group("nccl", device_id=dev)
     else:
         dist.init_process_group(backend)
-    dist.barrier()
+    if build is not None and rank == 0:
+        build()
+    dist.barrier()   # ranks != 0 get here first and wait: nothing is imported from the package before the build is complete
     return dist, dev
 
 
@@ -141,9 +148,7 @@ def bench_citi_bike(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank == 0:
-        ge.build()
-    dist, dev = init_dist(world, local_rank)
+    dist, dev = init_dist(world, local_rank, build=ge.build)
     torch.cuda.set_device(dev)
     import numpy as np
 
@@ -266,6 +271,84 @@ def bench_citi_bike(args):
         dist.destroy_process_group()
 
 
+def build_cim_groups(topology, n, G, dev, rank=0, durations=1120, ring=4, specialize=True, step_mode=0, obs="fused", policy="random"):
+    """The per-GPU configuration bench.py times: the batch split into G independent groups (engine + HIP stream each), fused
+    observation, snapshot ring.  Shared with tests/test_gpu_bench_parity.py so that the parity test runs EXACTLY this setup."""
+    import torch
+
+    from maro_amd.cim.engine import CimBatchEngine
+    sizes = [n // G + (1 if g < n % G else 0) for g in range(G)]   # group sizes differ by at most one env
+    offs = [sum(sizes[:g]) for g in range(G)]
+    engines, streams, bufs = [], [], []
+    for g in range(G):
+        ng = sizes[g]
+        seeds = torch.arange(ng, dtype=torch.int64) + rank * n + offs[g] + 1
+        kw = dict(durations=durations, max_snapshots=max(ring, 8) if policy == "dqn" else ring, max_actions=1, device=dev, seeds=seeds,
+                  step_mode=step_mode)  # dqn: the look-back window must fit the ring
+        try:
+            eng = CimBatchEngine(topology, ng, specialize=bool(specialize), **kw)
+        except (RuntimeError, OSError, subprocess.CalledProcessError) as e:   # no hipcc and not in the cache: generic kernels
+            if not specialize:
+                raise
+            print(f"bench: specialised kernels unavailable ({e}); using the generic ones", file=sys.stderr)
+            eng = CimBatchEngine(topology, ng, specialize=False, **kw)
+        engines.append(eng)
+        streams.append(torch.cuda.Stream(device=dev) if G > 1 else torch.cuda.current_stream(dev))
+        P = eng.topo.n_ports
+        bufs.append(dict(actions=torch.zeros((ng, 1, 4), dtype=torch.int32, device=dev),
+                         n_actions=torch.zeros((ng,), dtype=torch.int32, device=dev),
+                         counter=torch.zeros((1,), dtype=torch.int64, device=dev),
+                         q_ports=torch.empty((ng, 1, P, len(QUERY_ATTRS)), dtype=torch.float64, device=dev) if obs == "query" else None,
+                         q_vessel=torch.empty((ng, 1, 1, len(VESSEL_QUERY_ATTRS)), dtype=torch.float64, device=dev) if obs == "query" else None))
+        if obs == "fused" and policy != "dqn":
+            # the same two slices, written by the step kernel itself (mrx_cim_set_observation) instead of two more launches
+            bufs[-1]["obs"] = eng.set_observation(QUERY_ATTRS, VESSEL_QUERY_ATTRS)
+    for eng, st in zip(engines, streams):
+        eng.use_stream(st)   # every engine call goes to its group's stream without a per-call stream switch
+    return engines, streams, bufs, sizes, offs
+
+
+def cpu_baseline_reference(topology, durations, budget_s):
+    """The REAL reference (microsoft/maro built by oracle/build_ref.sh, present in the build container only) timed on this
+    box: single-process Env.step with the same kind of random legal agent.  None when no built
+    reference is importable (e.g. on the GPU box)."""
+    root = os.environ.get("MARO_REFERENCE_BUILD", "/tmp/oracle/maro_src")
+    if not os.path.isdir(os.path.join(root, "maro")) or not any(f.startswith("frame.") and f.endswith(".so") for f in os.listdir(os.path.join(root, "maro", "backends"))):
+        return None
+    code = r"""
+import os, sys, time, random
+os.environ.setdefault("HOME", "/tmp/oracle/home"); os.environ.setdefault("SKIP_DEPLOYMENT", "TRUE")
+sys.path.insert(0, sys.argv[1])
+from maro.simulator import Env
+from maro.simulator.scenarios.cim.common import Action, ActionType
+env = Env("cim", sys.argv[2], durations=int(sys.argv[3]))
+budget = float(sys.argv[4]); rng = random.Random(0)
+steps = episodes = 0; t_step = 0.0; t_reset = 0.0
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < budget:
+    tr = time.perf_counter(); env.reset(); t_reset += time.perf_counter() - tr
+    ts = time.perf_counter()
+    m, de, done = env.step(None)
+    while not done:
+        sc = de.action_scope
+        if rng.random() < 0.5 and sc.load > 0: a = Action(de.vessel_idx, de.port_idx, rng.randint(0, sc.load), ActionType.LOAD)
+        else: a = Action(de.vessel_idx, de.port_idx, rng.randint(0, sc.discharge), ActionType.DISCHARGE)
+        m, de, done = env.step(a); steps += 1
+    t_step += time.perf_counter() - ts; episodes += 1
+print(steps, episodes, t_step, t_reset)
+"""
+    try:
+        out = subprocess.run([sys.executable, "-c", code, root, topology, str(durations), str(budget_s)], capture_output=True, text=True, timeout=budget_s * 4 + 120)
+        steps, episodes, t_step, t_reset = out.stdout.split()[-4:]
+        steps, episodes, t_step, t_reset = int(steps), int(episodes), float(t_step), float(t_reset)
+    except Exception as e:   # the reference is a convenience leg, never a reason to fail the bench
+        return {"error": str(e)[:200]}
+    return {"value": steps / t_step, "unit": "env-steps/s", "cores": 1, "kind": "reference",
+            "value_end_to_end": steps / (t_step + t_reset), "reset_s_per_episode": t_reset / max(episodes, 1),
+            "sample": f"{episodes} full episode(s) of {topology} ({durations} ticks) on the reference's own Env (maro.simulator.Env, single process, "
+                      f"Python {sys.version_info.major}.{sys.version_info.minor}): {steps} decisions in {t_step:.1f} s of stepping + {t_reset:.1f} s of env.reset()"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scenario", default="cim", choices=["cim", "citi_bike"])
@@ -280,14 +363,18 @@ def main():
                     help="how the per-step ports / deciding-vessel snapshot slices are produced: fused into the step kernel, or by mrx_cim_query")
     ap.add_argument("--graphs", type=int, default=0, help="1: capture one step per group in a hipGraph and replay it (cim)")
     ap.add_argument("--groups", type=int, default=3, help="independent env groups per GPU, each on its own HIP stream (cim)")
-    ap.add_argument("--step-mode", type=int, default=0, help="launch form of mrx_cim_step (mrx_cim_set_step_mode): 0 best available, "
+    ap.add_argument("--step-mode", type=int, default=0, help="launch form of mrx_cim_step (mrx_cim_set_step_mode): 0 default (sorted), "
                     "1 unsorted, 2 sorted, 3 persistent pipelined")
     ap.add_argument("--topology", default="global_trade.22p_l0.8")
     ap.add_argument("--durations", type=int, default=1120)
+    ap.add_argument("--preroll-ticks", type=int, default=300, help="untimed steps before the warmup until the batch's mean tick reaches this "
+                    "(the timed window then measures mid-episode steady state, whatever --steps / --warmup are)")
     ap.add_argument("--specialize", type=int, default=1, help="1: step with kernels compiled for this exact plan (maro_amd/cim/specialize.py; "
                     "built by __graft_entry__.build() for the default workload, else ~3 s of hipcc at engine creation); 0: generic kernels")
     ap.add_argument("--ring", type=int, default=4, help="snapshot ring slots per env (max_snapshots)")
     ap.add_argument("--no-query", action="store_true", help="skip the per-step snapshot slice")
+    ap.add_argument("--no-episode", action="store_true", help="skip the end-to-end leg (reset + one full episode of the whole batch)")
+    ap.add_argument("--parity-envs", type=int, default=64, help="envs replayed on the CPU oracle after the run (0: off)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -302,45 +389,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank == 0:
-        ge.build()
-    dist, dev = init_dist(world, local_rank)
+    dist, dev = init_dist(world, local_rank, build=ge.build)
     torch.cuda.set_device(dev)
 
-    from maro_amd.cim.engine import CimBatchEngine
-
-    # The per-GPU batch is split into G independent groups, each with its own engine and HIP stream: a step kernel
-    # ends with a tail of long (ticking) waves while most of the chip is already idle, and the next group's kernel
-    # fills exactly that tail.  Envs never interact, so this is pure scheduling.
-    # the episode must outlast the run (finished envs would idle): ~0.45 ticks per env-step on 22p, so only very long runs
-    # (more than ~2300 steps in total) stretch the nominal 1120 ticks
-    sim_durations = max(args.durations, int(0.55 * (args.warmup + args.steps + min(args.steps, 100) + 10)) + 64)
+    # The per-GPU batch is split into G independent groups, each with its own engine and HIP stream: the kernels of the
+    # other groups fill a group's launch gaps and tail.  Envs never interact, so this is pure scheduling.
     n, G = args.envs, max(1, args.groups)
-    sizes = [n // G + (1 if g < n % G else 0) for g in range(G)]   # group sizes differ by at most one env
-    offs = [sum(sizes[:g]) for g in range(G)]
-    engines, streams, bufs = [], [], []
-    for g in range(G):
-        ng = sizes[g]
-        seeds = torch.arange(ng, dtype=torch.int64) + rank * n + offs[g] + 1
-        kw = dict(durations=sim_durations, max_snapshots=max(args.ring, 8) if args.policy == "dqn" else args.ring, max_actions=1,
-                  device=dev, seeds=seeds)  # dqn: the look-back window must fit the ring
-        try:
-            eng = CimBatchEngine(args.topology, ng, specialize=bool(args.specialize), step_mode=args.step_mode, **kw)
-        except (RuntimeError, OSError, subprocess.CalledProcessError) as e:   # no hipcc and not in the cache: generic kernels
-            if not args.specialize:
-                raise
-            print(f"bench: specialised kernels unavailable ({e}); using the generic ones", file=sys.stderr)
-            eng = CimBatchEngine(args.topology, ng, specialize=False, step_mode=args.step_mode, **kw)
-        engines.append(eng)
-        streams.append(torch.cuda.Stream(device=dev) if G > 1 else torch.cuda.current_stream(dev))
-        bufs.append(dict(actions=torch.zeros((ng, 1, 4), dtype=torch.int32, device=dev),
-                         n_actions=torch.zeros((ng,), dtype=torch.int32, device=dev),
-                         counter=torch.zeros((1,), dtype=torch.int64, device=dev),
-                         q_ports=None if (args.no_query or args.obs == "fused") else torch.empty((ng, 1, engines[0].topo.n_ports, len(QUERY_ATTRS)), dtype=torch.float64, device=dev),
-                         q_vessel=None if (args.no_query or args.obs == "fused") else torch.empty((ng, 1, 1, len(VESSEL_QUERY_ATTRS)), dtype=torch.float64, device=dev)))
-        if args.obs == "fused" and not args.no_query and args.policy != "dqn":
-            # the same two slices, written by the step kernel itself (mrx_cim_set_observation) instead of two more launches
-            bufs[-1]["obs"] = eng.set_observation(QUERY_ATTRS, VESSEL_QUERY_ATTRS)
+    # the episode must outlast the run (finished envs would idle): ~0.45 ticks per env-step on 22p
+    need_ticks = args.preroll_ticks + int(0.55 * (args.warmup + args.steps + min(args.steps, 100) + 64)) + 64
+    sim_durations = max(args.durations, need_ticks)
+    obs_mode = "none" if args.no_query else args.obs
+    engines, streams, bufs, sizes, offs = build_cim_groups(args.topology, n, G, dev, rank, sim_durations, args.ring, args.specialize, args.step_mode,
+                                                           obs_mode, args.policy)
     topo = engines[0].topo
     ports = torch.arange(topo.n_ports, dtype=torch.int32, device=dev)
     qnet = None
@@ -353,21 +413,24 @@ def main():
         chains = random_chains(topo.n_ports, CimBatchSampler(engines[0]).state_dim, len(ACTION_SPACE), seed=0)
         qnet = [FusedPerPortDQN(e, chains) for e in engines]
     torch.cuda.synchronize(dev)
-    # Env.reset for the whole batch (route unrolling, order proportion and — with the order table — every order of the
-    # episode are generated on the device here, outside the timed step loop): reported next to the step rate
-    t_r = time.perf_counter()
-    for g, eng in enumerate(engines):
-        with torch.cuda.stream(streams[g]):
-            eng.reset(torch.arange(sizes[g], dtype=torch.int64) + rank * n + offs[g] + 1)
-    torch.cuda.synchronize(dev)
-    reset_ms = (time.perf_counter() - t_r) * 1e3
 
+    def group_seeds(g):
+        return torch.arange(sizes[g], dtype=torch.int64) + rank * n + offs[g] + 1
+
+    def reset_all():
+        """Env.reset for the whole batch: route unrolling, order proportion and — with the order table — every order of the
+        episode are generated on the device.  Returns the wall time in ms."""
+        torch.cuda.synchronize(dev)
+        t_r = time.perf_counter()
+        for g, eng in enumerate(engines):
+            eng.reset(group_seeds(g))
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t_r) * 1e3
+
+    reset_ms = reset_all()
     graphs = [None] * G
 
-    for eng, st in zip(engines, streams):
-        eng.use_stream(st)   # every engine call goes to its group's stream without a per-call stream switch
-
-    def one_step(i, g, timing=None):
+    def one_step(i, g, timing=None, count=True):
         eng, b, st = engines[g], bufs[g], streams[g]
         if i == 0:
             eng.step()  # first step of the episode: action=None
@@ -376,13 +439,14 @@ def main():
             with torch.cuda.stream(st):
                 graphs[g].replay()  # policy -> step -> snapshot slices, captured once (hipGraph)
             return
+        ctr = b["counter"] if (timing is None and count) else None
         if qnet is not None:
             # mrx_cim_dqn_act: state gather + MFMA MLP + argmax + translation
             if timing is not None:
                 timing[2].record(st)
-            qnet[g].act(b["actions"], b["n_actions"], counter=b["counter"] if timing is None else None)
+            qnet[g].act(b["actions"], b["n_actions"], counter=ctr)
         else:
-            eng.random_policy(-1 if args.graphs else i, b["actions"], b["n_actions"], b["counter"] if timing is None else None)
+            eng.random_policy(-1 if args.graphs else i, b["actions"], b["n_actions"], ctr)
         if timing is not None:
             timing[0].record(st)
         eng.step(b["actions"], b["n_actions"])
@@ -402,14 +466,24 @@ def main():
     def total_ticks():
         return sum(e.ticks.to(torch.int64).sum().item() for e in engines)
 
+    # ---- untimed: into mid-episode (vessels loaded, discharge records and return rings populated), then the warmup
     step_i = 0
+    while True:
+        for _ in range(64):
+            for g in range(G):
+                one_step(step_i, g)
+            step_i += 1
+        torch.cuda.synchronize(dev)
+        if total_ticks() / n >= args.preroll_ticks or step_i > 8 * args.preroll_ticks + 64:
+            break
+    preroll_steps = step_i
     for _ in range(args.warmup):
         for g in range(G):
             one_step(step_i, g)
         step_i += 1
     sync_all()
     if args.graphs:
-        # the launch-bound inner loop (4 small launches per group and step) is captured once per group and replayed
+        # the launch-bound inner loop (policy + step (+ slices) per group and step) is captured once per group and replayed
         for g in range(G):
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr, stream=streams[g]):
@@ -429,6 +503,8 @@ def main():
     for b in bufs:
         b["counter"].zero_()
     tick0 = total_ticks()
+    tick_mean0 = tick0 / n
+    # ---- the timed window: exactly --steps steps between barrier + synchronize on both sides
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -444,8 +520,8 @@ def main():
     n_done = sum(int(e.done.sum().item()) for e in engines)
     status_bad = sum(int((e.status != 0).sum().item()) for e in engines)
 
-    # ---- dominant kernel (mrx_k_cim_step) timed live with HIP events, each pair on the stream of its launch, in
-    # the same interleaved schedule as the timed loop
+    # ---- dominant kernel (the step kernel) timed live with HIP events, each pair on the stream of its launch, in the same
+    # interleaved schedule as the timed loop (informational: roofline.achieved comes from the timed window above)
     reps = min(args.steps, 100)
     ev = [[tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(G)] for _ in range(reps)]
     sync_all()
@@ -456,81 +532,152 @@ def main():
     torch.cuda.synchronize(dev)
     durs = [a.elapsed_time(b) for row in ev for a, b, _ in row]
     policy_ms = sum(c.elapsed_time(a) for row in ev for a, _, c in row) / len(durs) if qnet is not None else None
-    step_kernel_ms = sum(durs) / len(durs)                      # mean duration of one launch (ng envs)
+    step_kernel_ms = sum(durs) / len(durs)                      # mean duration of one launch (ng envs; sorted launch: + the schedule kernel)
     span_ms = max([ev[0][g][0].elapsed_time(ev[-1][g2][1]) for g in range(G) for g2 in range(G)]) if G > 1 else sum(durs)
     in_flight = max(1.0, sum(durs) / span_ms) if G > 1 else 1.0    # mean number of step kernels running concurrently
 
-    # the one exchange step of a sharded rollout (north_star: RCCL "only to gather trajectories to the learner"): 32 steps of
-    # (decision, action, metrics, done) per env from every rank to rank 0 (maro_amd/cim/rollout.py::gather_to_learner);
-    # outside the timed env-step window
-    gather_ms = None
+    # ---- the one exchange step of a sharded rollout (north_star: RCCL "only to gather trajectories to the learner"): 32 steps of
+    # (decision, action, metrics, done, fused observation) per env from every rank to rank 0 in ONE collective
+    # (maro_amd/cim/rollout.py::gather_to_learner); outside the timed env-step window
+    gather_ms = gather_bytes = None
     if dist is not None:
         from maro_amd.cim.rollout import gather_to_learner
         T = 32
         traj = {"decisions": torch.zeros((T, n, 8), dtype=torch.int32, device=dev), "actions": torch.zeros((T, n, 1, 4), dtype=torch.int32, device=dev),
                 "metrics": torch.zeros((T, n, 3), dtype=torch.int64, device=dev), "done": torch.zeros((T, n), dtype=torch.uint8, device=dev)}
+        if bufs[0].get("obs") is not None:
+            traj["obs_ports"] = torch.zeros((T, n, topo.n_ports * len(QUERY_ATTRS)), dtype=torch.float32, device=dev)
         for k in range(T):
             for g in range(G):
-                one_step(step_i, g)
+                one_step(step_i, g, count=False)
                 with torch.cuda.stream(streams[g]):
                     sl = slice(offs[g], offs[g] + sizes[g])
                     traj["decisions"][k, sl], traj["actions"][k, sl] = engines[g].decisions, bufs[g]["actions"]
                     traj["metrics"][k, sl], traj["done"][k, sl] = engines[g].metrics, engines[g].done
+                    if "obs_ports" in traj:
+                        traj["obs_ports"][k, sl] = bufs[g]["obs"][0].reshape(sizes[g], -1)
             step_i += 1
         sync_all()
         tg = time.perf_counter()
         gathered = gather_to_learner(traj, dst=0)
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - tg) * 1e3
+        gather_bytes = sum(t.numel() * t.element_size() for t in traj.values())
         if rank == 0:
             assert gathered["decisions"].shape[1] == n * world
+        del gathered, traj
+
+    # ---- end to end (untimed window of its own): reset of the whole batch + one complete episode of every env, the same
+    # agent; envs that finish early keep being stepped (they report done) until the slowest one is through
+    episode = None
+    if not args.no_episode and qnet is None and not args.graphs:
+        if sim_durations != args.durations:   # (only very long runs stretch the episode: measure the nominal one on fresh engines)
+            del engines[:]
+            torch.cuda.empty_cache()
+            ep_engines, streams, bufs, sizes, offs = build_cim_groups(args.topology, n, G, dev, rank, args.durations, args.ring, args.specialize,
+                                                                      args.step_mode, obs_mode, args.policy)
+            engines.extend(ep_engines)
+        for b in bufs:
+            b["counter"].zero_()
+        sync_all()
+        t_e = time.perf_counter()
+        ep_reset_ms = reset_all()
+        k = 0
+        while True:
+            for _ in range(128):
+                for g in range(G):
+                    one_step(k, g)
+                k += 1
+            torch.cuda.synchronize(dev)
+            if all(bool(e.done.all().item()) for e in engines) or k > 8 * args.durations:
+                break
+        sync_all()
+        t_ep = time.perf_counter() - t_e
+        ep_steps = sum(int(b["counter"].item()) for b in bufs)
+        episode = {"env_steps": ep_steps, "seconds": t_ep, "reset_ms": ep_reset_ms, "batch_steps": k}
+
+    # ---- parity (untimed): a sample of envs of THIS configuration replayed on the CPU oracle — every decision, metric,
+    # fused observation and the final snapshot ring (tests/bench_parity.py; the oracle is the checker, never the thing measured)
+    parity = None
+    if args.parity_envs > 0 and qnet is None and not args.graphs and world == 1:
+        from tests.bench_parity import replay_against_oracle
+        parity = replay_against_oracle(engines, bufs, streams, sizes, offs, rank * n, args.topology, engines[0].durations, args.parity_envs,
+                                       obs=bufs[0].get("obs") is not None)
 
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(resolved), float(ticks_adv), float(n_done), float(status_bad)], dtype=torch.float64, device=dev)
+    ep_t = torch.tensor([episode["seconds"] if episode else 0.0], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(resolved), float(ticks_adv), float(n_done), float(status_bad), float(episode["env_steps"] if episode else 0)],
+                       dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ep_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt = float(t_max.item())
-    resolved, ticks_adv, n_done, status_bad = (float(x) for x in tot.tolist())
+    resolved, ticks_adv, n_done, status_bad, ep_steps_all = (float(x) for x in tot.tolist())
 
     if rank == 0:
         value = resolved / dt
+        ms_per_step = dt / args.steps * 1e3
         tbar = ticks_adv / max(resolved, 1.0)  # mean ticks advanced per env-step
         F = frame_bytes(topo)
-        b_step = (3.0 + tbar) * F + 4.0 * topo.n_targets * tbar + 40.0
-        ng = n / G                                  # mean env-steps per launch
-        bytes_per_launch = b_step * ng
-        # one launch moves bytes_per_launch in step_kernel_ms, and `in_flight` launches (one per group/stream) overlap
-        achieved = bytes_per_launch / (step_kernel_ms * 1e-3) / 1e9 * in_flight
-        traffic = None  # HBM bytes per launch from the committed PMC passes of this same workload (profiles/)
+        b_step = (3.0 + tbar) * F + 4.0 * topo.n_targets * tbar + 40.0  # fixed per-env-step formula
+        ng = n / G                                  # env-steps per launch
+        kernel = ("mrx_k_cim_step_pipe" if engines[0].step_mode == 3 else
+                  ("mrx_k_cim_step_tab" if engines[0].layout.order_table_on else "mrx_k_cim_step") + ("_obs" if bufs[0].get("obs") is not None else ""))
+        # HBM bytes one launch really moves: the committed PMC passes of this same workload (tools/refresh_pmc.py -> profiles/latest_pmc.json)
+        traffic = pmc_src = None
         try:
             with open(os.path.join(REPO, "profiles", "latest_pmc.json")) as fp:
                 pmc = json.load(fp)
-            if pmc["topology"] == args.topology and abs(pmc["envs_per_launch"] - ng) <= 1:
+            if pmc["topology"] == args.topology and abs(pmc["envs_per_launch"] - ng) <= 1 and pmc.get("kernel") == kernel:
                 traffic = (2.0 * pmc["fetch_size_kib"] + pmc["write_size_kib"]) * 1024.0
+                pmc_src = pmc.get("source")
         except Exception:
             pass
+        alg_per_launch = b_step * (resolved / world / args.steps / G)   # algorithmic bytes of one launch (its env-steps x B_step)
+        alg_gbps = alg_per_launch * G / (ms_per_step * 1e-3) / 1e9
+        if traffic is not None:
+            # achieved = bytes the kernel really moves per launch x launches per step / the TIMED window's ms_per_step (per GPU)
+            achieved = traffic * G / (ms_per_step * 1e-3) / 1e9
+            basis = "measured HBM bytes (PMC: 2 x FETCH_SIZE + WRITE_SIZE per launch) x launches per step / ms_per_step of the timed window"
+        else:
+            achieved = alg_gbps
+            basis = "ALGORITHMIC bytes (no matching PMC record in profiles/latest_pmc.json for this configuration): see algorithmic_*"
         out = {
             "metric": "env-steps/sec (decision events/sec), CIM global_trade.22p",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {sim_durations}, "
                                    f"{'random legal agent' if args.policy == 'random' else 'per-port dueling DQN (f32 MFMA, greedy) + CIMEnvSampler state shaping (mrx_cim_dqn_act)'} on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step (' + args.obs + ')'}",
                        "envs_per_gpu": n, "groups_per_gpu": G, "step_mode": engines[0].step_mode, "specialized_kernels": bool(engines[0].specialized), "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,
                        "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
-                       "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms, "host_enqueue_ms_per_step": t_issued / args.steps * 1e3, "trajectory_gather_ms_32_steps": gather_ms,
+                       "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms, "host_enqueue_ms_per_step": t_issued / args.steps * 1e3,
+                       "trajectory_gather_ms_32_steps": gather_ms, "trajectory_gather_bytes_per_rank": gather_bytes,
+                       "untimed_preroll_steps": preroll_steps, "mean_tick_at_window_start": tick_mean0,
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
-            "roofline": {"bound": "hbm", "kernel": ("mrx_k_cim_step_tab" if engines[0].layout.order_table_on else "mrx_k_cim_step") + ("_obs" if bufs[0].get("obs") is not None else ""), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_GBps": None if traffic is None else traffic / (step_kernel_ms * 1e-3) / 1e9 * in_flight,
-                         "traffic_source": "profiles/latest_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)",
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": step_kernel_ms, "launches_in_flight": in_flight,
-                         "definition": "achieved = algorithmic_bytes_per_launch / kernel_ms x launches_in_flight (mean number of overlapping step kernels, one per group stream); algorithmic bytes are SURVEY.md 8(d)'s fixed per-env-step formula (reference dtypes, every snapshot copy counted), so frac can exceed 1: the engine moves fewer real bytes (traffic, traffic_GBps)",
-                         "algorithmic_bytes_per_env_step": b_step, "env_steps_per_launch": ng},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": pmc_src, "basis": basis,
+                         "algorithmic_GBps": alg_gbps, "algorithmic_frac": alg_gbps / HBM_PEAK_GBPS,
+                         "algorithmic_bytes_per_launch": alg_per_launch, "algorithmic_bytes_per_env_step": b_step,
+                         "algorithmic_note": "SURVEY.md 8(d)'s fixed formula (reference dtypes, every snapshot copy counted); it exceeds the measured traffic "
+                                             "because the engine eliminated copies (aliased pre-decision snapshot, compact matrices, HBM-direct fast path), "
+                                             "so algorithmic_frac may exceed 1 and is NOT a bandwidth fraction",
+                         "kernel_ms": step_kernel_ms, "launches_in_flight": in_flight, "env_steps_per_launch": ng, "launches_per_step": G},
         }
+        if episode is not None:
+            ep_s = float(ep_t.item())
+            out["value_end_to_end"] = ep_steps_all / ep_s
+            out["end_to_end"] = {"definition": "env-steps of one COMPLETE episode of every env / (reset of the whole batch + stepping until the slowest env is done)",
+                                 "env_steps": ep_steps_all, "seconds": ep_s, "reset_ms": episode["reset_ms"], "batch_steps": episode["batch_steps"],
+                                 "durations": engines[0].durations}
+        if parity is not None:
+            out["parity"] = parity
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.topology, args.durations, args.cpu_seconds)
+            ref = cpu_baseline_reference(args.topology, args.durations, args.cpu_seconds)
+            if ref is not None:
+                out["cpu_baseline_reference"] = ref
         if qnet is not None:
             # the policy's own roofline: exact-f32 MFMA (MI355X_MICROARCH.md: 157.3 TFLOP/s), algorithmic flops = 2 x sum(in x out)
             # of the example's real layer sizes x the deciding envs of one launch; mrx_cim_dqn_act = bin + forward kernels

@@ -127,7 +127,13 @@ class CimBatchEngine:
 
     def use_stream(self, stream: Optional[torch.cuda.Stream]) -> None:
         """Bind every later call of this engine to `stream` (None: back to torch's current stream at call time).  A rollout
-        loop that drives several engines on their own streams saves the per-call stream lookup / context switch."""
+        loop that drives several engines on their own streams saves the per-call stream lookup / context switch.
+
+        Stream discipline while a stream is bound: kernels launch on it; inputs that need a conversion / host-to-device copy
+        are converted ON it (so the copy is ordered before the kernel, and the allocator ties the temporary to that stream);
+        device tensors passed as they are must have been produced on it (or be complete).  Outputs (`decisions`, `metrics`,
+        `done`, observation buffers, query results) must be read on the bound stream (`with torch.cuda.stream(s): ...`) or
+        after `s.synchronize()` — a side stream does not synchronise with torch's default stream."""
         self._bound_stream = stream
         self._bound_handle = None if stream is None else stream.cuda_stream
 
@@ -142,7 +148,15 @@ class CimBatchEngine:
             return x   # the usual case in a rollout loop: no conversion, no extra launch
         if not isinstance(x, torch.Tensor):
             x = torch.as_tensor(np.asarray(x), dtype=dtype)
-        return x.to(device=self.device, dtype=dtype).contiguous()
+        if self._bound_stream is None:
+            return x.to(device=self.device, dtype=dtype).contiguous()
+        # a bound (side) stream does not wait for torch's current stream: the copy / cast must be enqueued on the bound stream
+        # itself, or the kernel could read the tensor before a pageable host-to-device copy has landed.  A device tensor
+        # produced on the current stream is waited for first.
+        if x.is_cuda:
+            self._bound_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._bound_stream):
+            return x.to(device=self.device, dtype=dtype).contiguous()
 
     @staticmethod
     def _p(t: Optional[torch.Tensor]):
@@ -237,7 +251,11 @@ class CimBatchEngine:
         nt, nn = int(t.shape[-1]), int(n.shape[-1])
         slots = self.row_slots(node, ids)
         if out is None:
-            out = torch.empty((self.n_envs, nt, nn, slots), dtype=torch.float64, device=self.device)
+            if self._bound_stream is None:
+                out = torch.empty((self.n_envs, nt, nn, slots), dtype=torch.float64, device=self.device)
+            else:   # allocated on the stream that writes it (caching allocator: the block belongs to that stream)
+                with torch.cuda.stream(self._bound_stream):
+                    out = torch.empty((self.n_envs, nt, nn, slots), dtype=torch.float64, device=self.device)
         ida = (ctypes.c_int32 * len(ids))(*ids)
         _lib.check(self._L.mrx_cim_query(self._h, NODE_TYPE[node], t.data_ptr(), nt, per_env, n.data_ptr(), nn, nodes_per_env, ida,
                                          len(ids), out.data_ptr(), self._stream()), "mrx_cim_query")

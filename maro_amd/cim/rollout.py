@@ -25,16 +25,19 @@ def rollout(engine, n_steps: int, policy: Callable[[int, torch.Tensor, torch.Ten
             first_step: bool = True) -> Dict[str, torch.Tensor]:
     """Run `n_steps` batched env-steps.  `policy(step, decisions, done) -> (actions [n,A,4], n_actions [n])` works on
     device tensors.  Returns the trajectory: decisions [T,n,8], actions [T,n,A,4], metrics [T,n,3], done [T,n]."""
-    dec, met, done = engine.step() if first_step else (engine.decisions, engine.metrics, engine.done)
-    D, A, M, Dn = [], [], [], []
-    for t in range(n_steps):
-        actions, n_actions = policy(t, dec, done)
-        D.append(dec.clone())
-        A.append(actions.clone())
-        dec, met, done = engine.step(actions, n_actions, mask=(done == 0).to(torch.uint8))
-        M.append(met.clone())
-        Dn.append(done.clone())
-    return {"decisions": torch.stack(D), "actions": torch.stack(A), "metrics": torch.stack(M), "done": torch.stack(Dn)}
+    import contextlib
+    st = getattr(engine, "_bound_stream", None)   # an engine bound to a side stream: the tensor ops below go to that stream too
+    with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+        dec, met, done = engine.step() if first_step else (engine.decisions, engine.metrics, engine.done)
+        D, A, M, Dn = [], [], [], []
+        for t in range(n_steps):
+            actions, n_actions = policy(t, dec, done)
+            D.append(dec.clone())
+            A.append(actions.clone())
+            dec, met, done = engine.step(actions, n_actions, mask=(done == 0).to(torch.uint8))
+            M.append(met.clone())
+            Dn.append(done.clone())
+        return {"decisions": torch.stack(D), "actions": torch.stack(A), "metrics": torch.stack(M), "done": torch.stack(Dn)}
 
 
 def gather_to_learner(traj: Dict[str, torch.Tensor], dst: int = 0, group=None) -> Optional[Dict[str, torch.Tensor]]:
@@ -92,7 +95,8 @@ class PipelinedCimBatch:
                         for g in range(groups)]
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(groups)]
         for eng, st in zip(self.engines, self.streams):
-            eng.use_stream(st)   # engine calls go to the group's stream even outside for_each()
+            eng.use_stream(st)   # engine calls go to the group's stream even outside for_each() (see CimBatchEngine.use_stream
+                                 # for the stream discipline: read outputs inside for_each() or after synchronize())
         torch.cuda.synchronize(self.device)
 
     def __len__(self) -> int:

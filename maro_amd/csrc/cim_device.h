@@ -256,6 +256,17 @@ MRX_DEV void copy_in_async(int32_t* lds_dst, const int32_t* gsrc, int n_words) {
 MRX_DEV int stop_arrival(uint32_t s) { return (int)(s >> 8); }
 MRX_DEV int stop_parking(uint32_t s) { return (int)(s & 0xffu); }
 
+// start_tick > 0 (core.py:46: "usually used for pre-processed data streaming"): the reference's event buffer only ever
+// executes ticks >= start_tick, so the VESSEL_DEPARTURE events that business_engine.py:371-379 scheduled at earlier leave
+// ticks are never run, while every later one still fires ON SCHEDULE, whatever the vessel's state (:634-656 just does
+// next_loc_idx += 1).  A vessel whose first departure fell before start_tick therefore never arrives anywhere again
+// (stops[next_loc_idx].arrival_tick is always in the past, :151-160): it keeps "departing" at the leave ticks of its
+// later stops.  Reproduced literally: those vessels are flagged in the private header, V_NEXT holds the schedule index
+// of their next departure event.
+MRX_DEV uint64_t zombie_mask(const Lds& L) {
+  return ((uint64_t)(uint32_t)L.priv[PH_ZOMBIE_HI] << 32) | (uint32_t)L.priv[PH_ZOMBIE_LO];
+}
+
 // ------------------------------------------------------------------------------------------
 // predicted stops (vessel_future_stops_prediction.py:49-85): noise-free legs from `arrival`
 // at route position `pos`
@@ -378,7 +389,8 @@ MRX_DEV void tick_prefetch(const CimParams& K, int env, Lds& L, int t, TickPf& p
   } else {
     pf.otg = K.order_prop[(size_t)env * KD(T) + t];
   }
-  const bool arr = lane < KD(V) && !FV(VA_IS_PARKING, lane) && FV(VA_NEXT_LOC_IDX, lane) > 0 && V_EVT(lane) == t;
+  bool arr = lane < KD(V) && !FV(VA_IS_PARKING, lane) && FV(VA_NEXT_LOC_IDX, lane) > 0 && V_EVT(lane) == t;
+  if (KD(start_tick) > 0) arr = arr && !((zombie_mask(L) >> lane) & 1ull);  // (their V_EVT is a departure; they never arrive)
   pf.arr_mask = wave::ballot(arr);
   tick_prefetch_arrivals(K, env, L, pf.arr_mask, pf);
 }
@@ -638,12 +650,27 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
     V_PERIOD(v) = K.vperiod[(size_t)env * V + v];
     V_NEXT(v) = K.nstops[(size_t)env * V + v] > 1 ? stop_arrival(g_stops[(size_t)v * KD(SMAX) + 1]) : 0x7fffffff;
   }
+  bool zombie = false;
+  if (KD(start_tick) > 0 && lane < V) {  // (see zombie_mask) the first departure event that is still executed
+    const int v = lane, ns = K.nstops[(size_t)env * V + v];
+    int ks = 0;
+    while (ks < ns && stop_arrival(g_stops[(size_t)v * KD(SMAX) + ks]) + stop_parking(g_stops[(size_t)v * KD(SMAX) + ks]) < KD(start_tick)) ks++;
+    if (ks > 0) {
+      zombie = true;
+      const uint32_t st = g_stops[(size_t)v * KD(SMAX) + (ks < ns ? ks : 0)];
+      V_EVT(v) = ks < ns ? stop_arrival(st) + stop_parking(st) : 0x7fffffff;
+      V_NEXT(v) = ks;
+    }
+  }
+  const uint64_t zm = wave::ballot(zombie);
   if (lane == 0) {
     L.priv[PH_TICK] = KD(start_tick);
     L.priv[PH_FLAGS] = FL_FRESH;
     L.priv[PH_IDX_ORDER] = MT_WORDS;
     L.priv[PH_IDX_BUFFER] = MT_WORDS;
     L.priv[PH_IDX_ROUTE] = idx_route;
+    L.priv[PH_ZOMBIE_LO] = (int32_t)(uint32_t)(zm & 0xffffffffull);
+    L.priv[PH_ZOMBIE_HI] = (int32_t)(uint32_t)(zm >> 32);
     K.seed[env] = base;
     K.status[env] = status;
     K.tick[env] = KD(start_tick);
@@ -737,16 +764,32 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
   prof.mark(PF_ORDER_GEN);
 
   // ---------------- B1. departures (business_engine.py:634-656; past stops = shift + append)
+  const uint64_t zmask = KD(start_tick) > 0 ? zombie_mask(L) : 0ull;
   if (lane < V) {
     const int v = lane;
-    if (FV(VA_IS_PARKING, v) && V_EVT(v) == t) {
+    const bool z = (zmask >> v) & 1ull;
+    if ((z || FV(VA_IS_PARKING, v)) && V_EVT(v) == t) {
+      int app_port = FV(VA_LOC_PORT_IDX, v), app_tick = V_ARR(v);
+      const uint32_t* srow = K.stops + ((size_t)env * V + v) * KD(SMAX);
+      if (z) {  // vessel_past_stops[v, last, next] (vessel_past_stops_wrapper.py:23-38): the appended entry is stop next - 1 of the table
+        const int k_old = FV(VA_NEXT_LOC_IDX, v);
+        app_port = T.route_port[T.v_route_base[v] + V_POS(v)];
+        app_tick = stop_arrival(srow[k_old < KD(SMAX) ? k_old : KD(SMAX) - 1]);
+      }
       for (int s = 0; s + 1 < KD(past_n); s++) { FV_PAST(s, v) = FV_PAST(s + 1, v); FV_PASTT(s, v) = FV_PASTT(s + 1, v); }
-      if (KD(past_n) > 0) { FV_PAST(KD(past_n) - 1, v) = FV(VA_LOC_PORT_IDX, v); FV_PASTT(KD(past_n) - 1, v) = V_ARR(v); }
+      if (KD(past_n) > 0) { FV_PAST(KD(past_n) - 1, v) = app_port; FV_PASTT(KD(past_n) - 1, v) = app_tick; }
       FV(VA_NEXT_LOC_IDX, v) += 1;
       { const int Lr = T.v_route_len[v]; const int x = V_POS(v) + 1, y = V_KRL(v) + 1; V_POS(v) = x == Lr ? 0 : x; V_KRL(v) = y == Lr + 1 ? 0 : y; }
       FV(VA_IS_PARKING, v) = 0;
       FV(VA_LOC_PORT_IDX, v) = -1;
-      V_EVT(v) = V_NEXT(v);  // arrival tick of the next stop, cached at the previous arrival
+      if (z) {  // the next scheduled departure event
+        const int ks = V_NEXT(v) + 1, ns = K.nstops[(size_t)env * V + v];
+        V_NEXT(v) = ks;
+        const uint32_t st = srow[ks < KD(SMAX) ? ks : KD(SMAX) - 1];
+        V_EVT(v) = ks < ns ? stop_arrival(st) + stop_parking(st) : 0x7fffffff;
+      } else {
+        V_EVT(v) = V_NEXT(v);  // arrival tick of the next stop, cached at the previous arrival
+      }
     }
   }
 

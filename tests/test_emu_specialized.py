@@ -10,7 +10,7 @@ from tests.emu.emu import EmuBackend
 from tests.golden_util import golden_cases
 from tests.test_oracle_golden import replay_case
 
-SUBSET = [c for c in golden_cases() if not c.endswith("_full")][::5]
+SUBSET = [c for c in golden_cases() if "_full" not in c][::5]
 
 
 def _make(order_table=0):

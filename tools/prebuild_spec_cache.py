@@ -22,7 +22,8 @@ def plans(which):
         out += [(t, cfg(1120, ring=4)), (t, cfg(1120, ring=8))]            # bench.py default / --policy dqn
     if which in ("tests", "all"):   # tests/test_gpu_step_modes.py, tests/test_gpu_bench_parity.py
         out += [(load_topology("global_trade.22p_l0.8"), cfg(100, ring=5)), (load_topology("toy.5p_ssddd_l0.5"), cfg(100, ring=5)),
-                (load_topology("toy.6p_sssbdd_l0.8"), cfg(80, max_actions=6, mode=1))]
+                (load_topology("toy.6p_sssbdd_l0.8"), cfg(80, max_actions=6, mode=1)),
+                (load_topology("global_trade.22p_l0.8"), cfg(1120, ring=4, max_actions=2))]
     if which in ("goldens", "all"):
         from tests.golden_util import case_topology, golden_cases, joint_golden_cases, load_case, load_joint_case
         for name in golden_cases():
