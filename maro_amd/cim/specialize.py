@@ -20,7 +20,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"] + os.environ.get("MARO_AMD_SPEC_FLAGS", "").split()
 UNITS = {   # scenario -> (translation unit, generated dims header, the sources the cache key covers, ABI prefix)
     "cim": ("cim_spec.hip", "cim_spec_dims.h", ("cim_spec.hip", "cim_step_kernels.h", "cim_device.h", "cim_params.h", "cim_prof.h", "wave.h"), "mrx_cim"),
-    "citi_bike": ("cb_spec.hip", "cb_spec_dims.h", ("cb_spec.hip", "cb_step_kernels.h", "cb_device.h", "cb_params.h", "wave.h"), "mrx_cb"),
+    "citi_bike": ("cb_spec.hip", "cb_spec_dims.h", ("cb_spec.hip", "cb_step_kernels.h", "cb_device.h", "cb_params.h", "wave.h",
+                                                    "../../include/maro_amd_citi_bike.h"), "mrx_cb"),
 }
 
 
@@ -38,12 +39,37 @@ def plan_defines(topo_struct, cfg, scenario: str = "cim", obs=((), ())) -> str:
     return buf.value.decode()
 
 
+_TOOLCHAIN = None
+
+
+def _toolchain() -> bytes:
+    """The compiler's identity, part of the cache key: a ROCm upgrade must not load code objects of the old compiler.  Where
+    hipcc is absent (a box that only consumes the cache) the version recorded by the last build is used."""
+    global _TOOLCHAIN
+    if _TOOLCHAIN is None:
+        stamp = os.path.join(CACHE, "TOOLCHAIN")
+        hipcc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
+        try:
+            _TOOLCHAIN = subprocess.run([hipcc, "--version"], capture_output=True, check=True).stdout if hipcc else None
+        except (OSError, subprocess.CalledProcessError):
+            _TOOLCHAIN = None
+        if _TOOLCHAIN is None:
+            _TOOLCHAIN = open(stamp, "rb").read() if os.path.exists(stamp) else b"unknown"
+        else:
+            os.makedirs(CACHE, exist_ok=True)
+            if not os.path.exists(stamp) or open(stamp, "rb").read() != _TOOLCHAIN:
+                with open(stamp, "wb") as f:
+                    f.write(_TOOLCHAIN)
+    return _TOOLCHAIN
+
+
 def _key(defines: str, scenario: str) -> str:
     h = hashlib.sha256(defines.encode())
     for name in UNITS[scenario][2]:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(_toolchain())
     return h.hexdigest()[:24]
 
 

@@ -12,6 +12,7 @@ from __future__ import annotations
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
+import torch
 
 from .engine import NODE_ATTRS, SEED_KEEP, SEED_REDRAW, CimBatchEngine
 from .payloads import encode_action, make_decision_event
@@ -88,6 +89,18 @@ class GpuVectorEnv:
         if cls is GpuVectorEnv and scenario == "citi_bike":
             from ..citi_bike.vector_env import CitiBikeVectorEnv
             return super().__new__(CitiBikeVectorEnv)
+        if cls is GpuVectorEnv and (scenario not in ("cim", "citi_bike") or kwargs.get("business_engine_cls") is not None):
+            # SURVEY.md 8(b) "custom BE plugin": scenarios / business engines the GPU engines do not implement run on the
+            # reference's own process-per-env VectorEnv when MARO is importable (core.py:51, 270-271); there is no GPU path
+            # and nothing is emulated here.
+            try:
+                from maro.vector_env import VectorEnv
+            except ImportError as e:
+                raise NotImplementedError(
+                    f"the GPU engines implement the 'cim' and 'citi_bike' scenarios; scenario={scenario!r} / a custom "
+                    f"business_engine_cls needs the reference (maro.vector_env.VectorEnv), which is not importable: {e}") from None
+            drop = ("seeds", "device", "max_actions", "specialize", "_engine")
+            return VectorEnv(batch_num, scenario=scenario, *args, **{k: v for k, v in kwargs.items() if k not in drop})
         return super().__new__(cls)
 
     def __init__(self, batch_num: int, scenario: str = "cim", topology: str = None, start_tick: int = 0,
@@ -166,6 +179,9 @@ class GpuVectorEnv:
             self._pending_seed.pop(e, None)
             self._started[e] = self._paused[e] = self._finished[e] = False
             self._joint_events.pop(e, None)
+            self._last_met[e] = 0          # Env.reset: fresh metrics (business_engine.py:226-242)
+            self._n_pending[e] = 0
+            self._last_dec[e] = None
         self.engine.reset(cmd, mask)
 
     def set_seed(self, seed: int, envs: Optional[Sequence[int]] = None):
@@ -217,12 +233,10 @@ class GpuVectorEnv:
         if mask.any():
             dec, met, done, extra = self._engine_step(acts, nact, mask, nans if joint else None)
             status = eng.status.cpu().numpy()
+            offenders = [e for e in envs if mask[e] and (status[e] & 1)]
             for e in envs:
                 if not mask[e]:
                     continue
-                if status[e] & 1:
-                    eng.status[e] = 0
-                    raise InvalidActionError(f"env {e}: invalid action (cim/business_engine.py:731,736)")
                 self._started[e] = True
                 self._last_dec[e], self._last_met[e] = dec[e], met[e]
                 metrics = {k: int(met[e, i]) for i, k in enumerate(self.METRIC_KEYS)}
@@ -232,6 +246,13 @@ class GpuVectorEnv:
                 else:
                     self._paused[e] = True
                     out[e] = (metrics, self._make_joint_events(e, dec[e]) if joint else self._make_event(e, dec[e], extra), False)
+            if offenders:
+                # The whole masked batch has stepped (the engine skips an action the reference would reject with an
+                # AssertionError, cim/business_engine.py:731,736, and carries on); the bookkeeping above is complete for
+                # every env, only the INVALID_ACTION bit of the offenders is cleared, and all of them are named.
+                idx = torch.as_tensor(offenders, dtype=torch.int64, device=eng.status.device)
+                eng.status[idx] = eng.status[idx] & ~1
+                raise InvalidActionError(f"env(s) {offenders}: invalid action (cim/business_engine.py:731,736); the action was skipped")
         return [out[e] for e in envs]
 
     def _make_joint_events(self, e: int, rows) -> list:

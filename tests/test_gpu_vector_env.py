@@ -19,6 +19,11 @@ def test_env_view_on_gpu():
     check_env_view(gpu_factory)
 
 
+def test_invalid_action_in_a_batch_on_gpu():
+    from tests.test_vector_env_api import check_invalid_action_in_a_batch
+    check_invalid_action_in_a_batch(gpu_factory)
+
+
 def test_joint_decision_modes_object_api_on_gpu():
     from tests.test_vector_env_api import check_joint_object_api
     check_joint_object_api(gpu_factory, "jointseq_toy5p_l05_some")

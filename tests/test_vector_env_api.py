@@ -157,3 +157,54 @@ def check_joint_object_api(engine_factory, case):
 @pytest.mark.parametrize("case", ["jointseq_toy5p_l05_some", "joint_toy6p_l08_all"])
 def test_joint_decision_modes_object_api(case):
     check_joint_object_api(emu_factory, case)
+
+
+def check_invalid_action_in_a_batch(engine_factory):
+    """An invalid action (the reference asserts, cim/business_engine.py:731,736) in ONE env of a batch: the error names it,
+    the other envs' results of that step are kept, only the INVALID_ACTION status bit is cleared, and stepping goes on."""
+    env = make_env(3, engine_factory, durations=60)
+    oracles = [CimOracle(TOPO, durations=60) for _ in range(3)]
+    ost = [o.step(None) for o in oracles]
+    metrics, events, all_done = env.step(None)
+    bad = Action(events[1].vessel_idx, events[1].port_idx, events[1].action_scope.discharge + 5, ActionType.DISCHARGE)
+    with pytest.raises(InvalidActionError, match=r"\[1\]"):
+        env.step([None, bad, None])
+    ost = [o.step(None) for o in oracles]   # the engine skipped the bad action: same as no action
+    assert int(env.engine.status[1]) & 1 == 0
+    metrics, events, all_done = env.step(None)
+    ost = [o.step(None) for o in oracles]
+    for e, (om, od, odone) in enumerate(ost):
+        assert (events[e].tick, events[e].vessel_idx) == (int(od[0]), int(od[2])) and metrics[e]["order_requirements"] == om[0]
+    # reset: fresh metrics (Env.reset), not the previous episode's
+    view = env.env_view(2)
+    assert view.metrics["order_requirements"] > 0
+    view.reset(keep_seed=True)
+    assert view.metrics == {"order_requirements": 0, "container_shortage": 0, "operation_number": 0}
+
+
+def test_invalid_action_in_a_batch_on_emulator():
+    check_invalid_action_in_a_batch(emu_factory)
+
+
+def test_unknown_scenario_dispatches_to_the_reference_vector_env(monkeypatch):
+    """a scenario / business engine the GPU engines do not implement runs on maro.vector_env.VectorEnv when
+    MARO is importable; otherwise the constructor says so."""
+    import sys
+    import types
+    monkeypatch.setitem(sys.modules, "maro", None)   # not importable
+    with pytest.raises(NotImplementedError, match="not importable"):
+        GpuVectorEnv(2, "vm_scheduling", topology="azure.2019.10k", durations=10)
+    seen = {}
+
+    class FakeVectorEnv:
+        def __init__(self, batch_num, **kw):
+            seen.update(batch_num=batch_num, **kw)
+    pkg, mod = types.ModuleType("maro"), types.ModuleType("maro.vector_env")
+    mod.VectorEnv = FakeVectorEnv
+    pkg.vector_env = mod
+    monkeypatch.setitem(sys.modules, "maro", pkg)
+    monkeypatch.setitem(sys.modules, "maro.vector_env", mod)
+    env = GpuVectorEnv(2, "vm_scheduling", topology="azure.2019.10k", durations=10, device="cuda:0")
+    assert isinstance(env, FakeVectorEnv) and seen == dict(batch_num=2, scenario="vm_scheduling", topology="azure.2019.10k", durations=10)
+    env = GpuVectorEnv(1, "cim", topology="toy.4p_ssdd_l0.0", durations=10, business_engine_cls=object)
+    assert isinstance(env, FakeVectorEnv) and seen["business_engine_cls"] is object
