@@ -241,6 +241,20 @@ int mrx_cim_set_observation(mrx_handle h, const int32_t* port_attrs, int n_port_
                             int n_vessel_attrs, double* d_obs_ports, double* d_obs_vessel);
 
 /*
+ * Per-attribute retention next to the snapshot ring: from this call on every snapshot the engine takes
+ * (business_engine.py:215, core.py:376-378) also stores the listed port attributes of its frame into
+ *   d_hist int32 [n_envs][frames][n_port_attrs][n_ports]     (frame f of env e at ((e * frames + f) * n_port_attrs + a) * n_ports)
+ * so that a consumer which needs a few attributes over the WHOLE episode — the CIM RL example's delayed reward reads
+ * ports[tick+1 .. tick+99]["fulfillment" | "shortage"] after its rollout loop (examples/cim/rl/env_sampler.py:65-80,
+ * rl/rollout/env_sampler.py:516-526) — can run with a ring of a few frames (max_snapshots) instead of the full history
+ * (15.4 KB per frame on global_trade.22p vs 176 B here).  Integer attributes only, at most 4; HOST array of ids
+ * (mrx_cim_attr_id).  `frames` = rows per env (normally ceil(durations / snapshot_resolution)); frames beyond it are not
+ * stored.  The caller owns and zeroes the buffer (rows of frames that were not reached stay as they are); n = 0 switches
+ * it off.  Drains the device.
+ */
+int mrx_cim_set_port_history(mrx_handle h, const int32_t* port_attrs, int n_port_attrs, int32_t* d_hist, int64_t frames);
+
+/*
  * Env.step in DecisionMode.Joint / JointWithSequentialAction (core.py:354-366; engines created with
  * mrx_cim_config.decision_mode 1 / 2): every pending decision event of the tick is reported at once.
  *   d_decisions  int32 [n_envs][n_vessels][8]: one row per pending event in event (= vessel index) order, same columns as

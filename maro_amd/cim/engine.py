@@ -216,6 +216,18 @@ class CimBatchEngine:
             self._load_specialized()   # the observation's configuration is compiled into the specialised kernels
         return self.obs_ports, self.obs_vessel
 
+    def set_port_history(self, port_attrs: Sequence[str] = ()) -> Optional[torch.Tensor]:
+        """Per-attribute retention (mrx_cim_set_port_history): returns int32 [n_envs, frames, len(port_attrs), n_ports], into
+        which every snapshot of an env also writes these port attributes of its frame — the whole episode of a few
+        attributes (e.g. fulfillment / shortage for the CIM example's delayed reward) next to a short snapshot ring.
+        Rows are NOT cleared by reset(): zero them (`hist[envs] = 0`) when envs start a new episode.  () switches it off."""
+        ids = self.attr_ids("ports", port_attrs)
+        frames = -(-self.durations // self.snapshot_resolution)
+        self.port_history = torch.zeros((self.n_envs, frames, len(ids), self.layout.n_ports), dtype=torch.int32, device=self.device) if ids else None
+        arr = (ctypes.c_int32 * max(len(ids), 1))(*ids)
+        _lib.check(self._L.mrx_cim_set_port_history(self._h, arr, len(ids), self._p(self.port_history), frames), "mrx_cim_set_port_history")
+        return self.port_history
+
     def attr_ids(self, node: str, attrs: Sequence[str]):
         ids = []
         for a in attrs:

@@ -40,32 +40,60 @@ def rollout(engine, n_steps: int, policy: Callable[[int, torch.Tensor, torch.Ten
         return {"decisions": torch.stack(D), "actions": torch.stack(A), "metrics": torch.stack(M), "done": torch.stack(Dn)}
 
 
-def gather_to_learner(traj: Dict[str, torch.Tensor], dst: int = 0, group=None) -> Optional[Dict[str, torch.Tensor]]:
-    """Concatenate every rank's trajectory along the env axis (dim 1) on rank `dst`.  Shards may differ in size by
-    one env, so sizes are exchanged first and the payload is padded to the largest shard."""
+_SHARD_SIZES: Dict[tuple, list] = {}   # (group, world, local n) -> env count of every rank (exchanged once per sharding)
+
+
+def gather_to_learner(traj: Dict[str, torch.Tensor], dst: int = 0, group=None, sizes: Optional[list] = None) -> Optional[Dict[str, torch.Tensor]]:
+    """Concatenate every rank's trajectory along the env axis (dim 1 of tensors shaped [T, n_local, ...]) on rank `dst`.
+
+    ONE grouped exchange (`batch_isend_irecv`: a single RCCL group of point-to-point transfers over xGMI on GPUs, plain
+    send/recv under gloo): every rank sends each tensor exactly as it is — no padding copy, no packing copy — and `dst`
+    receives each rank's piece at its true size, then joins the pieces per key (the only copy, on the learner).  Shards may
+    differ in size; the per-rank env counts are `sizes` if given (e.g. from `shard_range`), else they are exchanged once
+    per (group, sharding) and cached, so steady-state calls issue no other collective.  Returns the dict on `dst`, None elsewhere.
+    Replaces the reference's pickle-over-Pipe result collection (vector_env.py:186-217) and the zmq fan-in of
+    BatchEnvSampler (rl/rollout/batch_env_sampler.py:150-190)."""
     import torch.distributed as dist
 
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return traj
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    any_t = next(iter(traj.values()))
-    n_local = torch.tensor([any_t.shape[1]], dtype=torch.int64, device=any_t.device)
-    sizes = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(sizes, n_local, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    n_max = max(sizes)
-    out = {} if rank == dst else None
-    for key in sorted(traj):
-        t = traj[key]
-        pad_shape = list(t.shape)
-        pad_shape[1] = n_max
-        buf = torch.zeros(pad_shape, dtype=t.dtype, device=t.device)
-        buf[:, :t.shape[1]] = t
-        recv = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-        dist.gather(buf, recv, dst=dst, group=group)
-        if rank == dst:
-            out[key] = torch.cat([r[:, :sizes[i]] for i, r in enumerate(recv)], dim=1)
-    return out
+    keys = sorted(traj)
+    any_t = traj[keys[0]]
+    n_local = int(any_t.shape[1])
+    if sizes is None:
+        ck = (id(group), world, n_local)
+        if ck not in _SHARD_SIZES:
+            mine = torch.tensor([n_local], dtype=torch.int64, device=any_t.device)
+            allsz = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allsz, mine, group=group)
+            _SHARD_SIZES[ck] = [int(x.item()) for x in allsz]
+        sizes = _SHARD_SIZES[ck]
+    assert len(sizes) == world and sizes[rank] == n_local, "sizes must list every rank's env count"
+    src = {k: traj[k].contiguous() for k in keys}   # (already contiguous in a rollout loop: no copy)
+    dev = any_t.device
+    if dev.type == "cuda" and dist.get_backend(group) == "gloo":
+        # test hook only (bench.py under MRX_BENCH_BACKEND=gloo on a 1-GPU box): gloo's send / recv take host tensors
+        src = {k: v.cpu() for k, v in src.items()}
+    if rank != dst:
+        ops = [dist.P2POp(dist.isend, src[k], dst, group) for k in keys]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        return None
+    pieces = {k: [None] * world for k in keys}
+    ops = []
+    for r in range(world):
+        for k in keys:
+            if r == rank:
+                pieces[k][r] = src[k]
+            else:
+                shape = list(src[k].shape)
+                shape[1] = sizes[r]
+                pieces[k][r] = torch.empty(shape, dtype=src[k].dtype, device=src[k].device)
+                ops.append(dist.P2POp(dist.irecv, pieces[k][r], r, group))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    return {k: torch.cat(pieces[k], dim=1).to(dev) for k in keys}
 
 
 class PipelinedCimBatch:

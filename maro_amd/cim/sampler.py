@@ -6,7 +6,7 @@ queries and a handful of tensor ops, no per-env Python loop and no host round tr
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence
+from typing import Callable, Dict, Optional, Sequence
 
 import torch
 
@@ -21,6 +21,7 @@ class CimBatchSampler:
         self.eng = engine
         self.look_back, self.time_window = look_back, time_window
         self.ff, self.sf = fulfillment_factor, shortage_factor
+        self.reward_eval_delay = time_window   # examples/cim/rl/rl_component_bundle: reward_eval_delay = reward_shaping_conf["time_window"]
         self.port_attributes, self.vessel_attributes = list(port_attributes), list(vessel_attributes)
         dev = engine.decisions.device
         self._back = torch.arange(look_back - 1, dtype=torch.int32, device=dev)          # range(look_back - 1)
@@ -51,3 +52,182 @@ class CimBatchSampler:
         q = self.eng.query("ports", ticks, nodes, ["fulfillment", "shortage"]).view(n, self.time_window, 2)
         r = self.ff * (q[:, :, 0] @ self._decay) - self.sf * (q[:, :, 1] @ self._decay)
         return r.to(torch.float32)
+
+    # ------------------------------------------------------------------ AbsEnvSampler.sample, batched
+    def _cache_alloc(self, cap: int) -> None:
+        n, D, dev = self.eng.n_envs, self.state_dim, self.eng.decisions.device
+        old = getattr(self, "_c", None)
+        c = dict(tick=torch.zeros((n, cap), dtype=torch.int32, device=dev), agent=torch.zeros((n, cap), dtype=torch.int64, device=dev),
+                 state=torch.zeros((n, cap, D), dtype=self.state_dtype, device=dev), action=torch.zeros((n, cap), dtype=torch.int64, device=dev),
+                 env_action=torch.zeros((n, cap, 4), dtype=torch.int32, device=dev),
+                 next_state=torch.zeros((n, cap, D), dtype=self.state_dtype, device=dev),
+                 next_agent_state=torch.zeros((n, cap, D), dtype=self.state_dtype, device=dev),
+                 terminal=torch.zeros((n, cap), dtype=torch.bool, device=dev))
+        if old is not None:
+            k = old["tick"].shape[1]
+            for key in c:
+                c[key][:, :k] = old[key]
+        self._c, self._cap = c, cap
+
+    def _sample_init(self, state_dtype) -> None:
+        eng = self.eng
+        n, dev = eng.n_envs, eng.decisions.device
+        assert eng.start_tick == 0 and eng.snapshot_resolution == 1, "the CIM example's shaping indexes snapshots by tick"
+        self.state_dtype = state_dtype
+        self._cache_alloc(256)
+        self._count = torch.zeros(n, dtype=torch.int64, device=dev)
+        self._last = torch.full((n, eng.layout.n_ports), -1, dtype=torch.int64, device=dev)   # _agent_last_index
+        self._eoe = torch.ones(n, dtype=torch.bool, device=dev)                               # _end_of_episode
+        self._episodes = 0
+        self._cur_state = torch.zeros((n, self.state_dim), dtype=state_dtype, device=dev)
+        # per-attribute retention: the whole episode of (fulfillment, shortage) per port, written by the step kernel at every
+        # snapshot — the delayed reward reads up to time_window ticks ahead of decisions that may be an episode old
+        self._hist = eng.set_port_history(["fulfillment", "shortage"])
+        self._ports = torch.arange(eng.layout.n_ports, dtype=torch.int32, device=dev)
+
+    def _finalize_and_emit(self, envs: torch.Tensor, out: Dict[str, list]) -> None:
+        """`_append_cache_element(None)` + the emission loop of AbsEnvSampler.sample (rl/rollout/env_sampler.py:404-410,
+        514-530) for the envs in the bool mask `envs`."""
+        eng, c = self.eng, self._c
+        n, cap = c["tick"].shape
+        dev = c["tick"].device
+        rows = torch.nonzero(envs).view(-1)
+        if rows.numel() == 0:
+            return
+        # last element of every agent: terminal = end_of_episode, next agent state = its own state
+        li = self._last[rows]                                   # [m, P]
+        has = li >= 0
+        r_idx = rows[:, None].expand_as(li)[has]
+        j_idx = li[has]
+        c["terminal"][r_idx, j_idx] = self._eoe[r_idx]
+        c["next_agent_state"][r_idx, j_idx] = c["state"][r_idx, j_idx]
+        # elements old enough for their reward window: tick <= env.tick - reward_eval_delay (ticks are non-decreasing: a prefix)
+        tick_now = eng.ticks.to(torch.int64)
+        bound = tick_now[rows] - self.reward_eval_delay
+        pos = torch.arange(cap, device=dev)[None, :]
+        emit = (pos < self._count[rows, None]) & (c["tick"][rows].to(torch.int64) <= bound[:, None])      # [m, cap]
+        n_emit = emit.sum(dim=1)
+        if int(n_emit.sum()) > 0:
+            # the frame of the tick an env is paused at is its live frame (pre-decision snapshot, core.py:345): its retention
+            # row is only written when the tick completes, so it is filled in from a snapshot query here
+            paused = rows[~self._eoe[rows]]
+            if paused.numel() > 0:
+                live = eng.query("ports", tick_now.to(torch.int32).view(n, 1), self._ports, ["fulfillment", "shortage"]).view(n, -1, 2)
+                self._hist[paused, tick_now[paused]] = live[paused].permute(0, 2, 1).to(torch.int32)
+            er, ej = torch.nonzero(emit, as_tuple=True)
+            e_env = rows[er]
+            tick = c["tick"][e_env, ej].to(torch.int64)
+            agent = c["agent"][e_env, ej]
+            frames = self._hist.shape[1]
+            t_idx = tick[:, None] + self._ahead.to(torch.int64)[None, :]                 # tick + 1 .. tick + window
+            ok = t_idx < frames                                                          # beyond the episode: zeros (snapshot padding)
+            vals = self._hist[e_env[:, None], t_idx.clamp(max=frames - 1), :, agent[:, None]].to(torch.float64) * ok[:, :, None]   # [K, window, 2]
+            reward = (self.ff * (vals[:, :, 0] @ self._decay) - self.sf * (vals[:, :, 1] @ self._decay)).to(torch.float32)
+            out["env_id"].append(e_env.to(torch.int32)); out["tick"].append(tick.to(torch.int32)); out["agent"].append(agent.to(torch.int32))
+            out["reward"].append(reward)
+            for key in ("state", "action", "env_action", "next_state", "next_agent_state", "terminal"):
+                out[key].append(c[key][e_env, ej])
+            # pop the emitted prefix
+            shift = (pos + n_emit[:, None]).clamp(max=cap - 1)
+            for key in c:
+                src = c[key][rows]
+                idx = shift if src.dim() == 2 else shift[:, :, None].expand(-1, -1, src.shape[2])
+                c[key][rows] = torch.gather(src, 1, idx)
+            self._count[rows] -= n_emit
+            li = self._last[rows]
+            self._last[rows] = torch.where(li >= n_emit[:, None], li - n_emit[:, None], torch.full_like(li, -1))
+
+    def sample(self, policy: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], num_steps: Optional[int] = None,
+               seeds: Optional[Callable[[int], torch.Tensor]] = None, state_dtype: torch.dtype = torch.float32) -> Dict[str, torch.Tensor]:
+        """``AbsEnvSampler.sample(num_steps)`` (rl/rollout/env_sampler.py:438-537) with the CIM example's shaping
+        (examples/cim/rl/env_sampler.py:15-80) for every env of the engine at once, on device tensors.
+
+        `policy(states [n, state_dim], decisions [n, 8]) -> model actions int64 [n]` (indices into the example's action
+        space; rows of envs without a pending decision are ignored).  Every env performs `num_steps` interactions (None:
+        until the end of ITS episode); an env whose episode ends inside the call is reset (`seeds(episode_index) -> int64
+        [n]` explicit seeds, or the reference's seed re-draw) and goes on, exactly like the reference loop.  Transitions
+        are emitted once they are `reward_eval_delay` (= time_window) ticks old — the delayed reward is evaluated after
+        the loop on the per-attribute retention rows (mrx_cim_set_port_history), so the snapshot ring can stay a few
+        frames deep (look_back) — and younger ones stay in the per-env cache for the next call, with the per-agent next
+        state / terminal bookkeeping of ``_append_cache_element``.
+
+        Returns flat tensors over the K emitted experiences, ordered by emission: state [K, D], action int64 [K]
+        (model action), env_action int32 [K, 4], reward float32 [K], next_state [K, D], next_agent_state [K, D],
+        terminal bool [K], env_id int32 [K], tick int32 [K], agent int32 [K] (the deciding port).  Plus "env_metric"
+        int64 [n, 3] (`_post_step`)."""
+        from .engine import SEED_REDRAW
+        from .policy import translate_actions
+        eng = self.eng
+        n, dev = eng.n_envs, eng.decisions.device
+        if not hasattr(self, "_c") or self.state_dtype != state_dtype:
+            self._sample_init(state_dtype)
+        c = self._c
+        out = {k: [] for k in ("state", "action", "env_action", "reward", "next_state", "next_agent_state", "terminal", "env_id", "tick", "agent")}
+        acts = torch.zeros((n, eng.max_actions, 4), dtype=torch.int32, device=dev)
+        nact = torch.zeros(n, dtype=torch.int32, device=dev)
+        steps_to_go = num_steps
+
+        def reset_envs(mask: torch.Tensor) -> None:   # AbsEnvSampler._reset for the envs in `mask`
+            cmd = seeds(self._episodes).to(torch.int64) if seeds is not None else torch.full((n,), SEED_REDRAW, dtype=torch.int64)
+            self._episodes += 1
+            eng.reset(cmd, mask.to(torch.uint8))
+            rows = torch.nonzero(mask).view(-1)
+            self._hist[rows] = 0
+            self._count[rows] = 0
+            self._last[rows] = -1
+            eng.step(mask=mask.to(torch.uint8))          # _step(None): the first decision event
+            self._eoe = torch.where(mask, eng.done.to(torch.bool), self._eoe)
+            st = self.state().to(self.state_dtype)
+            self._cur_state = torch.where(mask[:, None], st, self._cur_state)
+
+        if bool(self._eoe.any()):
+            reset_envs(self._eoe.clone())
+        while True:
+            if num_steps is None:
+                if bool(self._eoe.all()):
+                    break
+            else:
+                if steps_to_go == 0:
+                    break
+                if bool(self._eoe.any()):                # the outer loop of the reference: finish that episode's batch, reset, go on
+                    ended = self._eoe.clone()
+                    self._finalize_and_emit(ended, out)
+                    reset_envs(ended)
+            active = ~self._eoe
+            dec = eng.decisions.clone()
+            state = self._cur_state
+            model_action = policy(state, dec).to(torch.int64)
+            translate_actions(model_action, dec, state[:, -1].to(torch.float64), dec[:, 5], out=acts)   # vessel remaining_space = last state entry
+            nact[:] = active.to(torch.int32)
+            if int(self._count.max()) >= self._cap:
+                self._cache_alloc(2 * self._cap)
+                c = self._c
+            rows = torch.nonzero(active).view(-1)
+            j = self._count[rows]
+            agent = dec[rows, 1].to(torch.int64)
+            c["tick"][rows, j] = dec[rows, 0]
+            c["agent"][rows, j] = agent
+            c["state"][rows, j] = state[rows]
+            c["action"][rows, j] = model_action[rows]
+            c["env_action"][rows, j] = acts[rows, 0]
+            c["terminal"][rows, j] = False
+            prev = self._last[rows, agent]               # this agent's previous element gets its next agent state
+            hp = prev >= 0
+            c["next_agent_state"][rows[hp], prev[hp]] = state[rows[hp]]
+            c["terminal"][rows[hp], prev[hp]] = False
+            self._last[rows, agent] = j
+            self._count[rows] += 1
+            eng.step(acts, nact, mask=active.to(torch.uint8))
+            self._eoe = torch.where(active, eng.done.to(torch.bool), self._eoe)
+            st = self.state().to(self.state_dtype)
+            self._cur_state = torch.where((active & ~self._eoe)[:, None], st, self._cur_state)
+            c["next_state"][rows, j] = self._cur_state[rows]
+            if steps_to_go is not None:
+                steps_to_go -= 1
+        self._finalize_and_emit(torch.ones(n, dtype=torch.bool, device=dev), out)
+        res = {k: (torch.cat(v) if v else torch.zeros((0,) + tuple(c[k].shape[2:]) if k in c else (0,), dtype=(c[k].dtype if k in c else torch.int32), device=dev))
+               for k, v in out.items()}
+        if not out["reward"]:
+            res["reward"] = torch.zeros(0, dtype=torch.float32, device=dev)
+        res["env_metric"] = eng.metrics.clone()
+        return res

@@ -1068,10 +1068,15 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
 }
 
 // snapshot of the LDS frame into the env's ring (np_backend.pyx:481-518: slot = fi mod S)
-MRX_DEV void take_snapshot(const CimParams& K, int env, Lds& L, int fi) {
+MRX_DEV void take_snapshot(const CimParams& K, const CimObs& O, int env, Lds& L, int fi) {
   const int s = fi % KD(S);
   copy_words(K.ring + ((size_t)env * KD(S) + s) * KD(FW), L.frame, KD(FW));
   if (wave::lane() == 0) K.ring_fi[(size_t)env * KD(S) + s] = fi;
+  if (O.hist_n > 0 && fi < O.hist_frames) {  // per-attribute retention (mrx_cim_set_port_history): this frame's rows
+    int32_t* row = O.hist + ((size_t)env * O.hist_frames + fi) * O.hist_n * KD(P);
+    for (int a = 0; a < O.hist_n; a++)
+      if (wave::lane() < KD(P)) row[a * KD(P) + wave::lane()] = FP(O.hist_attr[a], wave::lane());
+  }
 }
 
 // ==========================================================================================
@@ -1518,13 +1523,13 @@ MRX_DEV StepEnd body_run(const CimParams& K, const CimObs& O, int env, Lds& L, c
       if ((t + 1) % KD(resolution) == 0) {
         if (lane < P) FP(PA_ACC_FULFILLMENT, lane) = FP(PA_ACC_BOOKING, lane) - FP(PA_ACC_SHORTAGE, lane);
         wave::sync();
-        take_snapshot(K, env, L, (t - KD(start_tick)) / KD(resolution));
+        take_snapshot(K, O, env, L, (t - KD(start_tick)) / KD(resolution));
         wave::sync();
         if (lane < P) { FP(PA_SHORTAGE, lane) = 0; FP(PA_BOOKING, lane) = 0; FP(PA_FULFILLMENT, lane) = 0; FP(PA_TRANSFER_COST, lane) = 0; }
         wave::sync();
       }
       if (t + 1 == KD(T)) {
-        if ((t + 1) % KD(resolution) != 0) take_snapshot(K, env, L, (t - KD(start_tick)) / KD(resolution));  // core.py:376-378
+        if ((t + 1) % KD(resolution) != 0) take_snapshot(K, O, env, L, (t - KD(start_tick)) / KD(resolution));  // core.py:376-378
         finished = true;
         break;
       }

@@ -331,7 +331,7 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
   if (rc != MRX_OK) return rc;
   const CimParams& K = h->plan.kp;
   static const size_t lds_pad = getenv("MRX_DEBUG_LDS_PAD_BYTES") ? (size_t)atoi(getenv("MRX_DEBUG_LDS_PAD_BYTES")) : 0;  // occupancy experiments
-  const bool obs = h->obs.np > 0 || h->obs.nv > 0;
+  const bool obs = h->obs.np > 0 || h->obs.nv > 0;  // (the _obs kernels are only needed for the fused observation; the retention rows are written by every build)
   const int mode = effective_step_mode(h);
   cim::StepBatch B = {d_actions, d_n_actions, d_n_answered, d_decisions, (long long*)d_metrics, d_done};
   if (mode >= 2) {
@@ -380,6 +380,8 @@ int mrx_cim_set_observation(mrx_handle h, const int32_t* port_attrs, int n_port_
   const int rc = make_obs(port_attrs, n_port_attrs, vessel_attrs, n_vessel_attrs, &o);
   if (rc != MRX_OK) return rc;
   o.ports = d_obs_ports; o.vessel = d_obs_vessel;
+  o.hist_n = h->obs.hist_n; o.hist_frames = h->obs.hist_frames; o.hist = h->obs.hist;  // (mrx_cim_set_port_history is independent of this call)
+  for (int i = 0; i < 4; i++) o.hist_attr[i] = h->obs.hist_attr[i];
   if (h->spec_module && plan_defines(h->plan.kp, o) != plan_defines(h->plan.kp, h->obs)) {
     // the loaded specialised kernels have the previous observation configuration compiled in: back to the generic ones until
     // mrx_cim_load_step_kernels is called with a code object for the new configuration
@@ -393,6 +395,23 @@ int mrx_cim_set_observation(mrx_handle h, const int32_t* port_attrs, int n_port_
   if (rc2 != MRX_OK) return rc2;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(h->plan.kp.hint, 1, (size_t)h->plan.kp.n_envs));
+  return MRX_OK;
+}
+
+int mrx_cim_set_port_history(mrx_handle h, const int32_t* port_attrs, int n_port_attrs, int32_t* d_hist, int64_t frames) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  if (n_port_attrs < 0 || n_port_attrs > 4) return set_err(MRX_ERR_INVALID_ARG, "at most 4 retained port attributes");
+  if (n_port_attrs > 0 && (!port_attrs || !d_hist || frames <= 0 || frames > 0x7fffffff)) return set_err(MRX_ERR_INVALID_ARG, "null attribute list / buffer, or frames out of range");
+  int rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());  // (steps may be in flight with the previous configuration)
+  h->obs.hist_n = 0; h->obs.hist = nullptr; h->obs.hist_frames = 0;
+  for (int i = 0; i < n_port_attrs; i++) {
+    if (port_attrs[i] < 0 || port_attrs[i] >= PA_COUNT || port_attrs[i] == PA_TRANSFER_COST)
+      return set_err(MRX_ERR_INVALID_ARG, "retained attributes must be integer port attributes");
+    h->obs.hist_attr[i] = port_attrs[i];
+  }
+  if (n_port_attrs > 0) { h->obs.hist_n = n_port_attrs; h->obs.hist = d_hist; h->obs.hist_frames = (int)frames; }
   return MRX_OK;
 }
 

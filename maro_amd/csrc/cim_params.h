@@ -158,4 +158,10 @@ struct CimObs {
   unsigned pa_packed;  // pa[] as 4-bit codes (lane-varying attribute index without indexing a kernel argument)
   int i_empty, i_tc;   // position of `empty` / `transfer_cost` in pa[] (-1: not requested)
   double *ports, *vessel;
+  // Per-attribute retention (mrx_cim_set_port_history; runtime configuration, not part of a specialised plan): every
+  // snapshot also stores the listed (integer) port attributes of its frame into hist [n_envs][hist_frames][hist_n][P]
+  // — the whole episode of e.g. fulfillment / shortage (176 B per frame on 22p) next to a short ring for everything else.
+  int hist_n, hist_frames;
+  int hist_attr[4];
+  int32_t* hist;
 };

@@ -124,7 +124,10 @@ void emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const u
 
 void emu_set_observation(void* h, const int32_t* pa, int np, const int32_t* va, int nv, double* ports, double* vessel) {
   Emu* e = (Emu*)h;
+  const CimObs keep = e->obs;
   memset(&e->obs, 0, sizeof(e->obs));
+  e->obs.hist_n = keep.hist_n; e->obs.hist_frames = keep.hist_frames; e->obs.hist = keep.hist;
+  for (int i = 0; i < 4; i++) e->obs.hist_attr[i] = keep.hist_attr[i];
   for (int i = 0; i < np; i++) e->obs.pa[i] = pa[i];
   for (int i = 0; i < nv; i++) e->obs.va[i] = va[i];
   e->obs.np = np; e->obs.nv = nv; e->obs.ports = ports; e->obs.vessel = vessel;
@@ -135,6 +138,12 @@ void emu_set_observation(void* h, const int32_t* pa, int np, const int32_t* va, 
     if (pa[i] == PA_EMPTY) e->obs.i_empty = i;
     if (pa[i] == PA_TRANSFER_COST) e->obs.i_tc = i;
   }
+}
+
+void emu_set_port_history(void* h, const int32_t* attrs, int n, int32_t* hist, int frames) {
+  Emu* e = (Emu*)h;
+  e->obs.hist_n = n; e->obs.hist = n ? hist : nullptr; e->obs.hist_frames = n ? frames : 0;
+  for (int i = 0; i < n; i++) e->obs.hist_attr[i] = attrs[i];
 }
 
 void emu_query(void* h, int node_type, const int32_t* ticks, int nt, int per_env, const int32_t* nodes, int nn, int nodes_per_env,

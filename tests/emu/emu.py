@@ -88,6 +88,7 @@ def _declare(L):
         L.emu_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.emu_query.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.emu_set_port_history.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.emu_set_observation.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                           ctypes.c_void_p]
     return L
@@ -163,6 +164,14 @@ class EmuBackend:
         self.obs_vessel = np.zeros((self.n_envs, len(va)), np.float64)
         self._L.emu_set_observation(self._h, _ptr(pa), len(pa), _ptr(va), len(va), _ptr(self.obs_ports), _ptr(self.obs_vessel))
         return self.obs_ports, self.obs_vessel
+
+    def set_port_history(self, port_attr_ids):
+        """mrx_cim_set_port_history: int32 [n, frames, len(ids), P] written at every snapshot."""
+        ids = np.ascontiguousarray(port_attr_ids, np.int32)
+        frames = -(-self.cfg.durations // self.cfg.snapshot_resolution)
+        self.port_history = np.zeros((self.n_envs, frames, len(ids), self.layout.n_ports), np.int32)
+        self._L.emu_set_port_history(self._h, _ptr(ids), len(ids), _ptr(self.port_history), frames)
+        return self.port_history
 
     def query(self, node_type, ticks, nodes, attrs, row_slots):
         t = np.ascontiguousarray(ticks, np.int32)

@@ -39,6 +39,10 @@ class EmuEngine:
         self.decisions, self.metrics, self.done = torch.from_numpy(d), torch.from_numpy(m), torch.from_numpy(dn)
         return self.decisions, self.metrics, self.done
 
+    def set_port_history(self, port_attrs=()):
+        self.port_history = torch.from_numpy(self.b.set_port_history([NODE_ATTRS["ports"].index(a) for a in port_attrs]))
+        return self.port_history
+
     def query(self, node, ticks, nodes, attrs, out=None):
         ids = [NODE_ATTRS[node].index(a) for a in attrs]
         t = self.topo

@@ -44,7 +44,10 @@ def _worker(rank, world, port, result_path):
     seeds = np.arange(lo, hi, dtype=np.int64) + 100
     eng = EmuEngine(TOPO, hi - lo, durations=DUR, max_actions=1, seeds=seeds)
     traj = rollout(eng, STEPS, _hash_policy(seeds))
-    full = gather_to_learner(traj, dst=0)
+    traj["env_id"] = torch.arange(lo, hi, dtype=torch.int32).expand(STEPS, hi - lo).contiguous()   # env_id i32[n]
+    traj["obs"] = (traj["decisions"][:, :, :5].to(torch.float32) * 0.5).contiguous()                  # stands in for obs f32[n, 171]
+    sizes = [shard_range(TOTAL, r, world)[1] - shard_range(TOTAL, r, world)[0] for r in range(world)]
+    full = gather_to_learner(traj, dst=0, sizes=sizes if world == 4 else None)   # both ways of learning the shard sizes
     if rank == 0:
         torch.save({k: v for k, v in full.items()}, result_path)
     dist.barrier()
@@ -61,11 +64,15 @@ def test_shard_range_covers_everything():
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
 
 
-def test_two_rank_gloo_rollout_matches_oracle(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_rollout_matches_oracle(tmp_path, world):
+    """world 2: shards of 3 + 2 envs; world 4: 2 + 1 + 1 + 1 (uneven, one grouped send/recv exchange, no padding)."""
     from oracle.cim_oracle import CimOracle, hash_policy_action
     path = str(tmp_path / "traj.pt")
-    mp.spawn(_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), path), nprocs=world, join=True)
     traj = torch.load(path)
+    assert traj["env_id"][0].tolist() == list(range(TOTAL)) and traj["obs"].dtype == torch.float32
+    assert torch.equal(traj["obs"], traj["decisions"][:, :, :5].to(torch.float32) * 0.5)
     dec, act, done = traj["decisions"].numpy(), traj["actions"].numpy(), traj["done"].numpy()
     assert dec.shape == (STEPS, TOTAL, 8) and act.shape == (STEPS, TOTAL, 1, 4)
     for e in range(TOTAL):

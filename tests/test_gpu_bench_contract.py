@@ -38,3 +38,32 @@ def test_bench_line_contract(extra):
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == j["unit"] and "sample" in c
     if "dqn" in extra:
         assert j["roofline_policy"]["bound"] == "mfma" and j["roofline_policy"]["unit"] == "TFLOP/s"
+    if extra[:2] == ("--envs", "192") and "dqn" not in extra:   # the CIM headline line: end-to-end leg + oracle parity replay
+        assert j["value_end_to_end"] > 0 and j["end_to_end"]["env_steps"] > 0 and j["end_to_end"]["reset_ms"] > 0
+        assert j["parity"]["ok"] is True and j["parity"]["envs_checked"] >= 60 and j["parity"]["env_steps_checked"] > 1000
+        assert j["config"]["mean_tick_at_window_start"] >= 300 and "algorithmic_frac" in r and "basis" in r
+
+
+@pytest.mark.parametrize("scenario,world", [("cim", 2), ("citi_bike", 4)])
+def test_bench_multi_rank_path_under_gloo(scenario, world):
+    """`bench.py --gpus N` as the driver launches it (torch.distributed.run, one process per rank), with the test hooks
+    MRX_BENCH_BACKEND=gloo + MRX_BENCH_DEVICE=0 so that a 1-GPU box can run it (RCCL refuses several ranks on one device):
+    barriers, max-over-ranks timing, summed counts, the grouped send/recv trajectory gather and rank != 0 waiting for build()."""
+    env = dict(os.environ, MRX_BENCH_BACKEND="gloo", MRX_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(world), "--steps", "8", "--warmup", "3",
+           "--scenario", scenario, "--envs", "256" if scenario == "cim" else "128", "--no-cpu"]
+    if scenario == "cim":
+        cmd += ["--preroll-ticks", "20", "--durations", "200"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == world and j["value"] > 0 and j["scaling"] == "weak"
+    assert j["config"]["trajectory_gather_ms_32_steps"] > 0

@@ -58,3 +58,63 @@ def test_sampler_on_emulator():
 def test_sampler_on_gpu():
     from maro_amd.cim.engine import CimBatchEngine
     run_sampler_case(lambda topo, n, **kw: CimBatchEngine(topo, n, **kw), n_envs=5)
+
+
+# ---- the batched sampling loop against the REAL maro.rl sampler (oracle/gen_golden_sampler.py)
+def run_sample_case(engine_factory, case, n_envs=2):
+    """CimBatchSampler.sample(num_steps) called like the golden's CIMEnvSampler.sample: same seeds, the recorded model actions
+    replayed as the policy; every emitted experience (tick, agent, state, action, reward, terminal, next_state,
+    next_agent_state) of every env must equal the reference's, call by call."""
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"sampler_{case}.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    eng = engine_factory(meta["topology"], n_envs, durations=meta["durations"], max_actions=1, max_snapshots=16)
+    smp = CimBatchSampler(eng)
+    assert smp.state_dim == meta["state_dim"]
+    inter = z["interactions"]
+    k = [0]
+    dev = eng.decisions.device
+
+    def policy(states, dec):
+        a = int(inter[k[0], 1])
+        d = dec.cpu().numpy()
+        live = d[:, 7] == 1
+        assert (d[live, 1] == inter[k[0], 0]).all() and (d[live, 0] == inter[k[0], 6]).all(), k[0]   # same agent, same tick as the reference
+        k[0] += 1
+        return torch.full((n_envs,), a, dtype=torch.int64, device=dev)
+
+    def seeds(ep):
+        return torch.full((n_envs,), meta["seed"] + ep, dtype=torch.int64)
+
+    for c, num_steps in enumerate(meta["calls"]):
+        res = smp.sample(policy, num_steps=num_steps, seeds=seeds, state_dtype=torch.float64)
+        assert k[0] == int(z[f"call{c}/interactions"][1]), (c, k[0])
+        n_exp = len(z[f"call{c}/tick"])
+        env_id = res["env_id"].cpu().numpy()
+        for e in range(n_envs):
+            sel = np.flatnonzero(env_id == e)
+            assert len(sel) == n_exp, (c, e, len(sel), n_exp)
+            if n_exp == 0:
+                continue
+            g = {key: res[key].cpu().numpy()[sel] for key in ("tick", "agent", "state", "action", "reward", "terminal", "next_state", "next_agent_state")}
+            assert np.array_equal(g["tick"], z[f"call{c}/tick"]) and np.array_equal(g["agent"], z[f"call{c}/agent"])
+            assert np.array_equal(g["action"], z[f"call{c}/action"]) and np.array_equal(g["terminal"], z[f"call{c}/terminal"])
+            assert np.array_equal(g["state"], z[f"call{c}/state"]) and np.array_equal(g["next_state"], z[f"call{c}/next_state"])
+            assert np.array_equal(g["next_agent_state"], z[f"call{c}/next_agent_state"])
+            np.testing.assert_allclose(g["reward"], z[f"call{c}/reward"], rtol=1e-6, atol=1e-6)   # float32 of a 99-term float64 dot product
+        env_act = res["env_action"].cpu().numpy()
+        assert bool(eng.done.cpu().numpy().all()) == bool(z[f"call{c}/end_of_episode"][0])
+    assert k[0] == len(inter)
+
+
+@pytest.mark.parametrize("case", ["toy5p_l05", "gt22p_l08", "toy5p_l05_rollover"])
+def test_batched_sample_matches_the_reference_sampler_on_emulator(case):
+    run_sample_case(emu_factory, case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["toy5p_l05", "gt22p_l08", "toy5p_l05_rollover"])
+def test_batched_sample_matches_the_reference_sampler_on_gpu(case):
+    from maro_amd.cim.engine import CimBatchEngine
+    run_sample_case(lambda topo, n, **kw: CimBatchEngine(topo, n, **kw), case, n_envs=7)
