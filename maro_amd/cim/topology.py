@@ -283,6 +283,149 @@ def parse_config(conf: dict, name: str = "custom") -> CimTopology:
     )
 
 
+# ------------------------------------------------------------------------------------------ data read from files
+def _csv_rows(path: str) -> List[dict]:
+    import csv
+    with open(path, "rt") as fp:
+        return list(csv.DictReader(fp))
+
+
+def load_data_folder(folder: str, name: str = None) -> CimTopology:
+    """Compile a MARO CIM *dump folder* (``data_from_dumps``: ports / vessels / routes / order_proportion csv,
+    global_order_proportion.txt, misc.yml, stops.bin|csv) or *real data folder* (``data_from_files``: ports / vessels /
+    routes csv, misc.yml, stops.csv|bin, orders.csv|bin) into a packaged topology (data_mode 1 / 2), natively — the csv
+    layouts of ``maro/data_lib/cim/cim_data_loader.py:52-357`` and the binary format of ``maro/data_lib`` (read by
+    ``maro_amd.data_lib.read_binary``); no MARO checkout needed.  A folder is a dump iff it has order_proportion.csv
+    (``cim_data_container_helpers.py:79-123`` picks the loader the same way).
+
+    Representable data: a vessel's stops follow its route from its start port, a tick lists its orders by (source,
+    destination) port index with no pair twice, parking of 1..255 ticks (checked here / at engine creation)."""
+    import yaml
+
+    from ..data_lib import read_binary
+
+    def path(f):
+        return os.path.join(folder, f)
+
+    with open(path("misc.yml"), "rt") as fp:
+        misc = yaml.safe_load(fp)
+    real = not os.path.exists(path("order_proportion.csv"))
+    # ---- routes (:112-133): rows in file order; a new route index appends a route
+    rmap, routes = {}, []
+    for r in _csv_rows(path("routes.csv")):
+        ri = int(r["index"])
+        rmap[r["name"]] = ri
+        if ri >= len(routes):
+            routes.append([])
+        routes[ri].append((r["port_name"], int(r["distance_to_next_port"])))
+    # ---- ports (:213-296)
+    prow = _csv_rows(path("ports.csv"))
+    pmap = {r["name"]: int(r["index"]) for r in prow}
+    P = len(prow)
+    # ---- vessels (:52-90)
+    vrow = _csv_rows(path("vessels.csv"))
+    V = len(vrow)
+    r_off, r_port, r_dist = [0], [], []
+    for pts in routes:
+        for pn, d in pts:
+            r_port.append(pmap[pn])
+            r_dist.append(float(d))
+        r_off.append(len(r_port))
+    v_route = [rmap[r["route_name"]] for r in vrow]
+    v_start = [[pn for pn, _ in routes[v_route[i]]].index(r["start_port_name"]) for i, r in enumerate(vrow)]
+    # ---- stops (:136-192): per vessel in file order
+    stops = [[] for _ in range(V)]
+    if os.path.exists(path("stops.bin")):
+        _, rec = read_binary(path("stops.bin"))
+        for vi, a, l, pi in zip(rec["vessel_index"].tolist(), rec["timestamp"].tolist(), rec["leave_tick"].tolist(), rec["port_index"].tolist()):
+            stops[vi].append((a, l, pi))
+    else:
+        for r in _csv_rows(path("stops.csv")):
+            stops[int(r["vessel_index"])].append((int(r["arrival_tick"]), int(r["departure_tick"]), int(r["port_index"])))
+    n_stops = [len(x) for x in stops]
+    smax = max(n_stops)
+    arr, lea = np.zeros((V, smax), np.int32), np.zeros((V, smax), np.int32)
+    for v, ss in enumerate(stops):
+        L = r_off[v_route[v] + 1] - r_off[v_route[v]]
+        for k, (a, l, pi) in enumerate(ss):
+            want = r_port[r_off[v_route[v]] + (v_start[v] + k) % L]
+            if pi != want:
+                raise ValueError(f"vessel {v} stop {k} is at port {pi}, its route says {want}: not representable")
+            arr[v, k], lea[v, k] = a, l
+    T = int(misc["max_tick"])
+    f64 = lambda xs: np.array([float(x) for x in xs], dtype=np.float64)  # noqa: E731
+    i32 = lambda xs: np.array([int(x) for x in xs], dtype=np.int32)  # noqa: E731
+    kw = {}
+    if real:
+        # ---- orders (:299-357): tick -> list in file order
+        if os.path.exists(path("orders.bin")):
+            _, rec = read_binary(path("orders.bin"))
+            olist = list(zip(rec["timestamp"].tolist(), rec["src_port_index"].tolist(), rec["dest_port_index"].tolist(), rec["quantity"].tolist()))
+        else:
+            olist = [(int(r["tick"]), int(r["source_port_index"]), int(r["dest_port_index"]), int(r["quantity"])) for r in _csv_rows(path("orders.csv"))]
+        by_tick: Dict[int, list] = {}
+        for t, sp, dp, q in olist:
+            by_tick.setdefault(t, []).append((sp, dp, q))
+        # the pair universe and its order come from the order file: within a tick the reference handles orders in file
+        # order, which matters per source port (sequential use of `empty`) and for the buffer-tick draw order
+        pairs = sorted({(sp, dp) for lst in by_tick.values() for sp, dp, _ in lst})   # CSR order: by source port, then destination
+        pidx = {pr: i for i, pr in enumerate(pairs)}
+        for t, lst in by_tick.items():
+            ks = [pidx[(sp, dp)] for sp, dp, _ in lst]
+            if len(set(ks)) != len(ks):
+                raise ValueError(f"tick {t}: two orders for the same (src, dst) pair are not representable")
+            if ks != sorted(ks):
+                raise ValueError(f"tick {t}: orders are not listed by (source, destination) port index: not representable")
+        t_off = [0]
+        for p in range(P):
+            t_off.append(t_off[-1] + sum(1 for sp, _ in pairs if sp == p))
+        orders = np.zeros((T, len(pairs)), np.int32)
+        for t, lst in by_tick.items():
+            if t < T:
+                for sp, dp, q in lst:
+                    orders[t, pidx[(sp, dp)]] = q
+        # vessel_period_without_noise of real data is computed (:93-109): sum over the route of parking + ceil(distance / speed)
+        import math
+        period = []
+        for i, r in enumerate(vrow):
+            period.append(sum(int(r["parking_duration"]) + math.ceil(d / float(r["sailing_speed"])) for _, d in routes[v_route[i]]))
+        kw.update(target_offset=i32(t_off), target_port=i32(d for _, d in pairs), target_base=f64([0] * len(pairs)),
+                  target_noise=f64([0] * len(pairs)), source_base=f64([0] * P), source_noise=f64([0] * P),
+                  fixed_orders=orders, fixed_order_prop=np.zeros(0, np.int32), total_containers=int(sum(int(r["empty"]) for r in prow)),
+                  order_mode=0, data_mode=2, fixed_vessel_period=i32(period))
+    else:
+        tprop: Dict[int, list] = {}
+        for r in _csv_rows(path("order_proportion.csv")):   # (:195-210)
+            tprop.setdefault(int(r["source_port_index"]), []).append((int(r["dest_port_index"]), float(r["proportion"]), float(r["proportion_noise"])))
+        t_off, t_port, t_base, t_noise = [0], [], [], []
+        for r in prow:
+            for dp, b, nz in tprop.get(int(r["index"]), []):
+                t_port.append(dp); t_base.append(b); t_noise.append(nz)
+            t_off.append(len(t_port))
+        gprop = np.loadtxt(path("global_order_proportion.txt"))
+        kw.update(target_offset=i32(t_off), target_port=i32(t_port), target_base=f64(t_base), target_noise=f64(t_noise),
+                  source_base=f64(r["order_proportion"] for r in prow), source_noise=f64(r["order_proportion_noise"] for r in prow),
+                  fixed_order_prop=np.asarray(gprop, np.int32)[:T], fixed_orders=np.zeros(0, np.int32),
+                  total_containers=int(misc["total_container"]), order_mode={"fixed": 0, "unfixed": 1}[str(misc["order_mode"])], data_mode=1,
+                  fixed_vessel_period=i32(r["period"] for r in vrow))
+    rnames = [n for n, _ in sorted(rmap.items(), key=lambda kv: kv[1])]
+    return CimTopology(
+        name=name or os.path.basename(os.path.normpath(folder)), n_ports=P, n_vessels=V, n_routes=len(routes), n_targets=len(kw["target_port"]),
+        n_route_points=len(r_port), past_stop_number=int(misc["past_stop_number"]), future_stop_number=int(misc["future_stop_number"]),
+        container_volume=int(misc["container_volume"]), seed=int(misc["seed"]), period=1, sample_noise=0.0, order_dist=f64([0]),
+        port_capacity=i32(r["capacity"] for r in prow), port_init_empty=i32(r["empty"] for r in prow),
+        empty_return_base=f64(int(r["empty_return_buffer"]) for r in prow), empty_return_noise=f64(int(r["empty_return_buffer_noise"]) for r in prow),
+        full_return_base=f64(int(r["full_return_buffer"]) for r in prow), full_return_noise=f64(int(r["full_return_buffer_noise"]) for r in prow),
+        route_offset=i32(r_off), route_port=i32(r_port), route_dist=f64(r_dist),
+        vessel_capacity=i32(r["capacity"] for r in vrow), vessel_init_empty=i32(r["empty"] for r in vrow),
+        vessel_route=i32(v_route), vessel_start_offset=i32(v_start),
+        vessel_speed=f64(r["sailing_speed"] for r in vrow), vessel_speed_noise=f64(r["sailing_speed_noise"] for r in vrow),
+        vessel_duration=f64(int(r["parking_duration"]) for r in vrow), vessel_duration_noise=f64(r["parking_noise"] for r in vrow),
+        port_names=[r["name"] for r in prow], vessel_names=[r["name"] for r in vrow], route_names=rnames,
+        load_cost_factor=float(misc["load_cost_factor"]), dsch_cost_factor=float(misc["dsch_cost_factor"]),
+        data_max_tick=T, fixed_max_stops=smax, fixed_n_stops=i32(n_stops), fixed_stops_arrival=arr, fixed_stops_leave=lea, **kw)
+
+
 def available_topologies() -> List[str]:
     if not os.path.isdir(_PKG_TOPOLOGY_DIR):
         return []

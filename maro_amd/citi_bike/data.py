@@ -2,9 +2,9 @@
 (``maro/simulator/scenarios/citi_bike/business_engine.py:205-260``: config.yml, trips.bin via BinaryReader,
 KNYC_daily.bin via WeatherTable, station_meta.csv, distance_adj.csv) flattened into arrays.
 
-The flat form is produced once by ``tools/import_maro_citi_bike.py`` (which needs a MARO checkout: the on-disk
-binary format is read with the reference's own reader) and shipped as ``topologies/<name>.npz``; the trip table
-is shared by every env of a batch and lives in HBM as SoA columns.
+The flat form is produced by ``load_build_folder`` below — a native reader of the topology's ``config.yml`` and of the
+built data folder (``maro_amd.data_lib`` reads MARO's binary format; no MARO checkout needed) — and shipped as
+``topologies/<name>.npz``; the trip table is shared by every env of a batch and lives in HBM as SoA columns.
 """
 from __future__ import annotations
 
@@ -87,6 +87,68 @@ class CitiBikeData:
         z = np.load(path)
         meta = json.loads(bytes(z["meta"]).decode())
         return CitiBikeData(**meta, **{k: z[k] for k in z.files if k != "meta"})
+
+
+def load_build_folder(config, build_dir: str, name: str = None, is_holiday=None) -> CitiBikeData:
+    """Compile a citi_bike topology natively: `config` = the topology's config.yml (path or dict: ``decision`` block,
+    ``time_zone``), `build_dir` = the folder ``maro data build`` / the toy generator wrote (trips.bin, KNYC_daily.bin,
+    station_meta.csv, distance_adj.csv).  Mirrors what ``CitibikeBusinessEngine`` reads at construction
+    (``business_engine.py:205-260``): trips through ``ItemTickPicker`` with one tick per minute
+    (``data_lib/binary_reader.py:80-112`` -> ``maro_amd.data_lib.pick_ticks``), stations (``stations_info.py:19-37``), the
+    distance matrix (``adj_loader.py``, first row skipped), the weather table keyed by local date (``weather_table.py:29-41``),
+    and per tick the local date's weekday / holiday flag (``business_engine.py:367-392``).  `is_holiday(date) -> bool`:
+    the reference asks ``holidays.US()``; the default knows no holidays (the package is not available offline; the
+    packaged toy topologies and their goldens were generated the same way)."""
+    import csv
+    from datetime import datetime, timedelta, timezone
+
+    import yaml
+    from dateutil.tz import gettz
+
+    from ..data_lib import pick_ticks, read_binary
+    if not isinstance(config, dict):
+        with open(config, "rt") as fp:
+            config = yaml.safe_load(fp)
+    tz = gettz(config["time_zone"])
+    hdr, rec = read_binary(os.path.join(build_dir, "trips.bin"))
+    t0 = int(hdr["starttime"])
+    n_ticks = int((int(hdr["endtime"]) - t0) // 60) + 2
+    tick = pick_ticks(rec["timestamp"], t0, n_ticks, "m")
+    keep = tick >= 0
+    trips = np.stack([tick[keep], rec["src_station"][keep], rec["dest_station"][keep], rec["durations"][keep]], axis=1).astype(np.int32)
+    with open(os.path.join(build_dir, "station_meta.csv"), "rt") as fp:
+        st = sorted(((int(r["station_index"]), int(r["init"]), int(r["capacity"]), int(float(r["station_id"]))) for r in csv.DictReader(fp)))
+    with open(os.path.join(build_dir, "distance_adj.csv"), "rt") as fp:
+        rows = list(csv.reader(fp))[1:]
+    dist = np.array([[float(c) for c in row] for row in rows], np.float64).reshape(len(st), len(st))
+    _, wrec = read_binary(os.path.join(build_dir, "KNYC_daily.bin"))
+    weather = {}
+    for ts, w, temp in zip(wrec["timestamp"].tolist(), wrec["weather"].tolist(), wrec["temp"].tolist()):
+        weather[datetime.fromtimestamp(ts, timezone.utc).astimezone(tz).date()] = (w, temp)   # later rows win, like the dict in the reference
+    start = datetime.fromtimestamp(t0, timezone.utc).astimezone(tz)
+    days, tick_day, feats = {}, [], []
+    for t in range(n_ticks):
+        d = (start + timedelta(minutes=t)).date()          # relativedelta(minutes=t) on an aware datetime: wall-clock arithmetic
+        if d not in days:
+            days[d] = len(days)
+            w = weather.get(d)
+            feats.append((d.weekday(), int(bool(is_holiday(d))) if is_holiday else 0, 0 if w is None else w[0], 0 if w is None else w[1]))
+        tick_day.append(days[d])
+    dec = config["decision"]
+    ftype = {"distance": FILTER_DISTANCE, "requirements": FILTER_REQUIREMENTS, "trip_window": FILTER_TRIP_WINDOW}
+    return CitiBikeData(
+        name=name or os.path.basename(os.path.normpath(build_dir)), trip_tick=trips[:, 0].copy(), trip_src=trips[:, 1].copy(),
+        trip_dst=trips[:, 2].copy(), trip_duration=trips[:, 3].copy(),
+        capacity=np.array([x[2] for x in st], np.int32), init_bikes=np.array([x[1] for x in st], np.int32),
+        station_id=np.array([x[3] for x in st], np.int32), distance=dist, tick_day=np.array(tick_day, np.int32),
+        day_weekday=np.array([f[0] for f in feats]).astype(np.int16), day_holiday=np.array([f[1] for f in feats]).astype(np.int16),
+        day_weather=np.array([f[2] for f in feats]).astype(np.int16),
+        day_temperature=np.array([f[3] for f in feats], np.float64).astype(np.int16),   # float -> i2 attribute: numpy truncation
+        resolution=int(dec["resolution"]), time_mean=float(dec["effective_time_mean"]), time_std=float(dec["effective_time_std"]),
+        supply_water_mark_ratio=float(dec["supply_water_mark_ratio"]), demand_water_mark_ratio=float(dec["demand_water_mark_ratio"]),
+        scope_low_ratio=float(dec["action_scope"]["low"]), scope_high_ratio=float(dec["action_scope"]["high"]),
+        extra_cost_mode={"source": EXTRA_COST_SOURCE, "target": EXTRA_COST_TARGET}[dec["extra_cost_mode"]],  # common.py:155-160
+        filters=[dict(type=ftype[f["type"]], num=int(f["num"]), windows=int(f.get("windows", 0))) for f in dec["action_scope"]["filters"]])
 
 
 def available_topologies() -> List[str]:
