@@ -219,6 +219,8 @@ int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_acti
  *   3  (plan-specialised code objects with the order table, mrx_cim_load_step_kernels) the persistent pipelined kernel:
  *      as many waves as the device holds at once walk that list; the next env's state is prefetched into registers while
  *      the current env is computed out of LDS, write-backs drain under the next env, fast-path envs go 64 per wave.
+ *   4  the step split in two kernels: the fast-path envs one per LANE in a small kernel without LDS, then the full-path list
+ *      walked by as many workgroups as the device holds at once;
  *   0  automatic (default): 2 (measured fastest on MI355X at the benchmark's batch sizes; 3 is opt-in).
  * Returns the mode the next step will actually use (>= 1), or a negative mrx_status.
  */

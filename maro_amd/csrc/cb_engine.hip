@@ -57,7 +57,19 @@ struct mrx_cb_engine {
   int device;
   hipModule_t spec_module = nullptr;   // plan-specialised reset / step kernels (mrx_cb_load_step_kernels), else the generic ones
   hipFunction_t spec_reset = nullptr, spec_step = nullptr;
-  ~mrx_cb_engine() { if (spec_module) hipModuleUnload(spec_module); }
+  // kernels of the module may still be queued or running on the caller's stream: drain the device before unloading
+  void unload_spec() {
+    if (!spec_module) return;
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess) {
+      if (cur != device) hipSetDevice(device);
+      hipDeviceSynchronize();
+      hipModuleUnload(spec_module);
+      if (cur != device && cur >= 0) hipSetDevice(cur);
+    }
+    spec_module = nullptr;
+  }
+  ~mrx_cb_engine() { unload_spec(); }
 };
 
 static int set_err(int code, const std::string& m) { return mrx_set_error_(code, m); }
@@ -204,7 +216,7 @@ int mrx_cb_load_step_kernels(mrx_cb_handle h, const void* image, int64_t bytes, 
     hipModuleUnload(mod);
     return set_err(MRX_ERR_INVALID_ARG, "code object lacks mrx_k_cb_reset / mrx_k_cb_step");
   }
-  if (h->spec_module) hipModuleUnload(h->spec_module);
+  h->unload_spec();
   h->spec_module = mod;
   h->spec_reset = f_reset;
   h->spec_step = f_step;

@@ -238,6 +238,8 @@ MRX_DEV void copy_words(int32_t* dst, const int32_t* src, int n_words) {
   // later (tens of µs, usually by another CU), so letting them allocate in L2 only evicts the topology tables and order rows
   // the other waves are using: measured +6.5 % env-steps/s (the matching `nt` on the LDS-DMA loads changes nothing).
   typedef int v4i_ __attribute__((ext_vector_type(4)));
+  // (deliberately NOT unrolled: a burst of all the row's stores at once measured 10 % slower than read -> store -> read ...)
+#pragma unroll 1
   for (int i = l; i < n4; i += 64) __builtin_nontemporal_store(((const v4i_*)s4)[i], (v4i_*)d4 + i);
 #else
   for (int i = l; i < n4; i += 64) d4[i] = s4[i];
@@ -719,7 +721,7 @@ MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {
     const int n_here = D - t0 < 64 ? D - t0 : 64;
     for (int j = 0; j < n_here; j++) {  // wave-uniform
       bool tw = false;
-      gen_orders(K, L, (long long)wave::shfl(mine, j), idx_ord, pf, tw);
+      gen_orders(K, L, (long long)wave::bcast(mine, j), idx_ord, pf, tw);
       wave::sync();
       int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t0 + j) * KD(NTP);
       for (int k = lane; k < KD(NTP); k += 64) row[k] = k < KD(NT) ? L.oq[k] : 0;
@@ -928,7 +930,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
         b = T.fr_delay[MRX_PAIR_SRC(k0, k)];
       }
       const int incl = wave::scan_incl_add(q) + carry;
-      carry = wave::shfl(incl, 63);
+      carry = wave::bcast(incl, 63);
       if (k < NT) { pre[k] = incl; if (has) L.oq[k] = q | ((b < 0 ? 0 : (b > 126 ? 127 : b + 1)) << 24); }
       any_imm = any_imm || (wave::ballot(has && b == 0) != 0);
     }
@@ -1000,23 +1002,31 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
       const int full0 = full, empty0 = empty;
       const int Lr = wave::readlane(r_len, v), rb = wave::readlane(r_rb, v), RL = Lr + 1;
       const int p = T.route_port[rb + pos];
-      const int ns = wave::shfl(pf.ns, a_idx);  // prefetched by lane a_idx (tick_prefetch_arrivals)
-      const uint32_t st_k = (uint32_t)wave::shfl((int)pf.stk, a_idx);
-      const uint32_t st_k1 = (uint32_t)wave::shfl((int)pf.stk1, a_idx);
+      const int ns = wave::bcast(pf.ns, a_idx);  // prefetched by lane a_idx (tick_prefetch_arrivals)
+      const uint32_t st_k = (uint32_t)wave::bcast((int)pf.stk, a_idx);
+      const uint32_t st_k1 = (uint32_t)wave::bcast((int)pf.stk1, a_idx);
       prof.mark(10);
       // lane i: the i-th stop after this one — route position, port, compact matrix column, predicted tick
       const int nlan = Lr > KD(future_n) ? Lr : KD(future_n);
       const bool act = lane < nlan;
       int xi = pos + lane, xn = pos + 1 + lane;  // leg out of stop i-1, position of stop i
-      xi %= Lr; xn %= Lr;
+      if (Lr >= KD(future_n)) {  // (wave-uniform) the usual case: lanes < nlan = Lr stay below 2 Lr — a conditional subtraction, no integer division
+        xi = act ? (xi >= Lr ? xi - Lr : xi) : 0;
+        xn = act ? (xn >= Lr ? xn - Lr : xn) : 0;
+      } else {
+        xi %= Lr; xn %= Lr;
+      }
       const int leg = act ? T.leg_time[T.leg_off[v] + xi] : 0;
       const int tick_i = t + wave::scan_incl_add(leg);  // vessel_future_stops_prediction.py:49-85
       const int port_i = T.route_port[rb + xn], c_i = T.route_cidx[rb + xn];
-      bool dup_later = false, dup_earlier = false;  // the route may visit a port twice
-      for (int j = 0; j < Lr; j++) {
-        const int cj = wave::shfl(c_i, j);
-        dup_later = dup_later || (j > lane && cj == c_i);
-        dup_earlier = dup_earlier || (j < lane && cj == c_i);
+      bool dup_later = false, dup_earlier = false;  // the route may visit a port twice ...
+      const int n_distinct = (v + 1 < V ? (int)T.v_cbase[v + 1] : KD(NC)) - (int)T.v_cbase[v];
+      if (n_distinct != Lr) {  // ... (wave-uniform) but most routes do not: as many plan cells as stops
+        for (int j = 0; j < Lr; j++) {
+          const int cj = wave::bcast(c_i, j);
+          dup_later = dup_later || (j > lane && cj == c_i);
+          dup_earlier = dup_earlier || (j < lane && cj == c_i);
+        }
       }
       if (lane < KD(future_n)) { FV_FUT(lane, v) = port_i; FV_FUTT(lane, v) = tick_i; }
       if (lane < Lr && !dup_later) PLANC(v, c_i) = tick_i;  // vessel_sailing_plan_wrapper.py:24-28 (later stops overwrite)
@@ -1031,7 +1041,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
       const int incl = wave::scan_incl_add(pend);
       int l = 0;
       if (acceptable > 0 && pend > 0) { const int room = acceptable - (incl - pend); l = room <= 0 ? 0 : (pend < room ? pend : room); }
-      const int loaded_total = wave::shfl(incl < acceptable ? incl : (acceptable > 0 ? acceptable : 0), 63);
+      const int loaded_total = wave::bcast(incl < acceptable ? incl : (acceptable > 0 ? acceptable : 0), 63);
       if (l > 0) {
         FOPK(kk) = pend - l;
         FOVC(v, c_i) += l;
@@ -1125,7 +1135,7 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
   const int lane = wave::lane();
   const int P = KD(P), V = KD(V);
   const int hdr = R.hdr;
-  const int flags = wave::shfl(hdr, PH_FLAGS);
+  const int flags = wave::bcast(hdr, PH_FLAGS);
   if (flags & FL_FINISHED) {  // reference: (None, None, True) once the generator is exhausted (core.py:128-133)
     if (lane < 8) dec_out[lane] = lane == 7 ? -1 : 0;
     if (lane < 3) met_out[lane] = 0;
@@ -1133,16 +1143,16 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
     return true;
   }
   if (flags & FL_FRESH) return false;
-  const uint64_t pend = ((uint64_t)(uint32_t)wave::shfl(hdr, PH_PEND_HI) << 32) | (uint32_t)wave::shfl(hdr, PH_PEND_LO);
-  const int cur = wave::shfl(hdr, PH_CUR_VESSEL);
+  const uint64_t pend = ((uint64_t)(uint32_t)wave::bcast(hdr, PH_PEND_HI) << 32) | (uint32_t)wave::bcast(hdr, PH_PEND_LO);
+  const int cur = wave::bcast(hdr, PH_CUR_VESSEL);
   const uint64_t pend_after = pend & ~(1ull << (cur & 63));
   if (!pend_after || n_act > 1) return false;
   int32_t* g_live = K.live + (size_t)env * KD(FW);
   int32_t* g_priv = K.priv + (size_t)env * KD(PW);
-  const int t = wave::shfl(hdr, PH_TICK);
-  long long opnum = ((long long)wave::shfl(hdr, PH_OPNUM_HI) << 32) | (uint32_t)wave::shfl(hdr, PH_OPNUM_LO);
-  const long long acc_b = ((long long)wave::shfl(hdr, PH_ACCB_HI) << 32) | (uint32_t)wave::shfl(hdr, PH_ACCB_LO);
-  const long long acc_s = ((long long)wave::shfl(hdr, PH_ACCS_HI) << 32) | (uint32_t)wave::shfl(hdr, PH_ACCS_LO);
+  const int t = wave::bcast(hdr, PH_TICK);
+  long long opnum = ((long long)wave::bcast(hdr, PH_OPNUM_HI) << 32) | (uint32_t)wave::bcast(hdr, PH_OPNUM_LO);
+  const long long acc_b = ((long long)wave::bcast(hdr, PH_ACCB_HI) << 32) | (uint32_t)wave::bcast(hdr, PH_ACCB_LO);
+  const long long acc_s = ((long long)wave::bcast(hdr, PH_ACCS_HI) << 32) | (uint32_t)wave::bcast(hdr, PH_ACCS_LO);
   int status = 0;
   const int v2 = __builtin_ctzll(pend_after);  // the vessel whose decision comes next
 #define GP(a, p) g_live[KD(f_ports) + (a) * P + (p)]
@@ -1152,18 +1162,18 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
   if (act && (av < 0 || av >= V || ap < 0 || ap >= P || q < 0 || (ty != 0 && ty != 1))) { status |= 1; act = false; }
   const int sv = act ? av : 0, sp = act ? ap : 0;  // safe lanes when there is no (valid) action
   const int c = act ? K.cidx_dense[sv * P + sp] : -1;
-  const int pe = wave::shfl(R.pe, sp), tc = wave::shfl(R.tc, sp);
-  const int ve = wave::shfl(R.ve, sv), rs = wave::shfl(R.rs, sv);
-  const int period = wave::shfl(R.per, sv);
-  const int lp2 = wave::shfl(R.lp, v2);
-  int ve2 = wave::shfl(R.ve, v2), rs2 = wave::shfl(R.rs, v2);
-  const int ed2 = wave::shfl(R.ed, v2);
-  int pe2 = wave::shfl(R.pe, lp2);
+  const int pe = wave::bcast(R.pe, sp), tc = wave::bcast(R.tc, sp);
+  const int ve = wave::bcast(R.ve, sv), rs = wave::bcast(R.rs, sv);
+  const int period = wave::bcast(R.per, sv);
+  const int lp2 = wave::bcast(R.lp, v2);
+  int ve2 = wave::bcast(R.ve, v2), rs2 = wave::bcast(R.rs, v2);
+  const int ed2 = wave::bcast(R.ed, v2);
+  int pe2 = wave::bcast(R.pe, lp2);
   int pl;
   {
     const int cc = c >= 0 ? c : 0;
-    const int p0 = wave::shfl(R.pl[0], cc & 63), p1 = wave::shfl(R.pl[1], cc & 63), p2 = wave::shfl(R.pl[2], cc & 63),
-              p3 = wave::shfl(R.pl[3], cc & 63);
+    const int p0 = wave::bcast(R.pl[0], cc & 63), p1 = wave::bcast(R.pl[1], cc & 63), p2 = wave::bcast(R.pl[2], cc & 63),
+              p3 = wave::bcast(R.pl[3], cc & 63);
     pl = cc < 64 ? p0 : cc < 128 ? p1 : cc < 192 ? p2 : p3;
     if (KD(NC) > 256) pl = g_live[KD(f_plans) + cc];  // large plan blocks: a second, dependent trip
   }
@@ -1204,7 +1214,7 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
 #pragma unroll
     for (int a = 0; a < 8; a++) {
       if (a < OD(nv)) {
-        int raw = wave::shfl(R.vo[a], v2);
+        int raw = wave::bcast(R.vo[a], v2);
         if (applied && av == v2) { if (ODA(va, a) == VA_EMPTY) raw = o_ve; else if (ODA(va, a) == VA_REMAINING_SPACE) raw = o_rs; }
         if (lane == 0) O.vessel[(size_t)env * OD(nv) + a] = (double)raw;
       }
@@ -1478,21 +1488,22 @@ MRX_DEV void body_act(const CimParams& K, Lds& L, const int32_t* actions, StepCt
     const int32_t* a = actions + 4 * i;
     const int v = U(i == 0 ? c.a0v : a[0]), p = U(i == 0 ? c.a0p : a[1]), q = U(i == 0 ? c.a0q : a[2]), ty = U(i == 0 ? c.a0t : a[3]);
     if (v < 0 || v >= V || p < 0 || p >= P || q < 0 || (ty != 0 && ty != 1)) { c.status |= 1; continue; }
-    const int pe = U(FP(PA_EMPTY, p)), ve = U(FV(VA_EMPTY, v));
+    // every word this action reads, requested back to back (one LDS round trip instead of one per word)
+    const int pe_v = FP(PA_EMPTY, p), ve_v = FV(VA_EMPTY, v), rs_v = FV(VA_REMAINING_SPACE, v), tc_v = FP(PA_TRANSFER_COST, p);
+    const int pe = U(pe_v), ve = U(ve_v), rs = U(rs_v), tc = U(tc_v);
     int npe, nve;
     if (ty == 1) {  // DISCHARGE
       if (q > ve) { c.status |= 1; continue; }
       npe = pe + q; nve = ve - q;
     } else {
-      const int rs = U(FV(VA_REMAINING_SPACE, v));
       if (q > (pe < rs ? pe : rs)) { c.status |= 1; continue; }
       npe = pe - q; nve = ve + q;
     }
     FP(PA_EMPTY, p) = npe;
     FV(VA_EMPTY, v) = nve;
-    { const int rs0 = U(FV(VA_REMAINING_SPACE, v)); FV(VA_REMAINING_SPACE, v) = rs0 - (nve - ve); }  // total_space - full - empty
+    FV(VA_REMAINING_SPACE, v) = rs - (nve - ve);  // total_space - full - empty
     c.opnum += q;
-    FP(PA_TRANSFER_COST, p) = f_bits((float)((double)bits_f(U(FP(PA_TRANSFER_COST, p))) + (double)q));
+    FP(PA_TRANSFER_COST, p) = f_bits((float)((double)bits_f(tc) + (double)q));
     {  // vessel_plans[v, p] += period (:748): the compact plan cell of (v, p), -1 if p is not on the vessel's route
       const int cc = plan_cell(L, v, p);
       if (cc >= 0) { const int pl = U(L.frame[KD(f_plans) + cc]); L.frame[KD(f_plans) + cc] = pl + U(V_PERIOD(v)); }
@@ -1730,6 +1741,32 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
 }
 
 // ==========================================================================================
+// SPLIT STEP (launch form 4): the fast-hinted envs and the full-path envs of a step go to two kernels.
+//  * fast_lanes_env: one env per LANE, no LDS at all (fast_step_lane) — a few dozen workgroups for the whole batch instead
+//    of one LDS-carrying workgroup per fast env queueing behind the full-path ones for an LDS slot.  An env the fast path
+//    cannot handle (several actions, stale hint) is appended to the full-path list of the step.
+//  * step_loop: as many workgroups as the device holds at once walk the full-path list (order[0 .. sched[0])), one env
+//    per iteration through step_env.
+template <bool OBS>
+MRX_DEV void fast_lanes_env(const CimParams& K, const CimObs& O, const StepBatch& B, const uint8_t* mask, int env) {
+  if (env >= K.n_envs || (mask && !mask[env]) || K.hint[env]) return;
+  const StepIO io = step_io(K, B, env);
+  const int n_act = io.n_act > KD(max_actions) ? KD(max_actions) : io.n_act;
+  if (KD(decision_mode) == 0 && fast_step_lane<OBS>(K, O, env, io.actions, n_act, io.dec_out, io.met_out, io.done_out)) return;
+  K.order[wave::global_add(&K.sched[0], 1)] = env | MRX_ORDER_TICK;   // the general path after all (launched next, in stream order)
+}
+
+template <bool PG, bool OBS>
+MRX_DEV void step_loop(const CimParams& K, const CimObs& O, int32_t* lds, int w, int W, const StepBatch& B) {
+  const int n_tick = U(wave::ld_uniform_v(K.sched + 0));
+  for (int i = w; i < n_tick; i += W) {  // wave-uniform
+    const int env = U(wave::ld_uniform_v(K.order + i)) & (MRX_ORDER_TICK - 1);
+    step_env<PG, OBS>(K, O, env, lds, step_io(K, B, env), PATH_FULL);
+    wave::sync();
+  }
+}
+
+// ==========================================================================================
 // PERSISTENT, PIPELINED STEP (plan-specialised builds with the order table): `W` resident waves walk the sorted order
 // list of the step (mrx_k_cim_schedule: full-path envs first).  Wave w takes full-path entries w, w + W, ...; while
 // env k is computed out of LDS, the state of env k+1 (frame | private state | buffer RNG state: one contiguous LDS
@@ -1871,7 +1908,7 @@ MRX_DEV void step_persistent(const CimParams& K, const CimObs& O, int32_t* lds, 
       while (todo) {  // stale hint / several actions: the general path, one env at a time (LDS is still free here)
         const int b = __builtin_ctzll(todo);
         todo &= todo - 1;
-        const int env_b = wave::shfl(env, b);
+        const int env_b = wave::bcast(env, b);
         step_env<true, OBS>(K, O, env_b, lds, step_io(K, B, env_b), PATH_FULL);
         wave::sync();
       }

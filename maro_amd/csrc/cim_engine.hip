@@ -10,8 +10,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "wave.h"
 #include "cim_prof.h"
@@ -150,6 +152,44 @@ mrx_k_cim_random_policy(CimParams K, const int32_t* __restrict__ decisions, long
 }
 
 // ------------------------------------------------------------------------------------------ C ABI
+// Plan-specialised code objects are shared between the engines of a process (one hipModule per (device, image)): the
+// groups of a batch — same plan, one engine each — then execute the SAME code addresses, so the instruction cache (64 KB per
+// CU pair) holds one copy of the ~40 KB step kernel instead of one per group.
+struct SharedModule { hipModule_t mod; int device; size_t hash; size_t bytes; int refs; };
+static std::vector<SharedModule> g_modules;
+static std::mutex g_modules_mu;
+static size_t image_hash(const void* image, size_t bytes) {
+  size_t h = 1469598103934665603ull;
+  const unsigned char* p = (const unsigned char*)image;
+  for (size_t i = 0; i < bytes; i++) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+static hipError_t shared_module_acquire(const void* image, size_t bytes, int device, hipModule_t* out) {
+  const size_t hs = image_hash(image, bytes);
+  std::lock_guard<std::mutex> lk(g_modules_mu);
+  for (auto& m : g_modules)
+    if (m.device == device && m.hash == hs && m.bytes == bytes) { m.refs++; *out = m.mod; return hipSuccess; }
+  hipModule_t mod = nullptr;
+  const hipError_t e = hipModuleLoadData(&mod, image);
+  if (e != hipSuccess) return e;
+  g_modules.push_back({mod, device, hs, bytes, 1});
+  *out = mod;
+  return hipSuccess;
+}
+// drops one reference; the last one drains the device (kernels of the module may still be running) and unloads
+static void shared_module_release(hipModule_t mod) {
+  std::lock_guard<std::mutex> lk(g_modules_mu);
+  for (size_t i = 0; i < g_modules.size(); i++) {
+    if (g_modules[i].mod != mod) continue;
+    if (--g_modules[i].refs == 0) {
+      hipDeviceSynchronize();
+      hipModuleUnload(mod);
+      g_modules.erase(g_modules.begin() + i);
+    }
+    return;
+  }
+}
+
 struct mrx_cim_engine {
   CimHostPlan plan;
   int device;
@@ -159,6 +199,8 @@ struct mrx_cim_engine {
   hipFunction_t spec_reset = nullptr, spec_order_table = nullptr;
   hipFunction_t spec_pipe = nullptr;      // mrx_k_cim_step_pipe (persistent pipelined step), when the code object has it
   int pipe_waves = 0;                     // its grid: the number of waves that are resident at once
+  hipFunction_t spec_fast = nullptr, spec_loop = nullptr;   // launch form 4 (mrx_k_cim_fast_lanes*, mrx_k_cim_step_loop*)
+  int loop_waves = 0;                     // grid of the looped full-path kernel (generic or specialised build in use)
   int step_mode = 0;                      // mrx_cim_set_step_mode (0 = automatic)
   // Kernels of a module may still be queued or running on the caller's stream(s): drain the device before unloading it.
   void unload_spec() {
@@ -166,12 +208,13 @@ struct mrx_cim_engine {
     int cur = -1;
     if (hipGetDevice(&cur) == hipSuccess) {
       if (cur != device) hipSetDevice(device);
-      hipDeviceSynchronize();
-      hipModuleUnload(spec_module);
+      hipDeviceSynchronize();   // (this engine's launches; other engines sharing the module keep it loaded)
+      shared_module_release(spec_module);
       if (cur != device && cur >= 0) hipSetDevice(cur);
     }
     spec_module = nullptr;
-    spec_pipe = spec_reset = spec_order_table = nullptr;
+    spec_pipe = spec_reset = spec_order_table = spec_fast = spec_loop = nullptr;
+    loop_waves = 0;
     for (auto& f : spec_fn) f = nullptr;
     pipe_waves = 0;
   }
@@ -319,9 +362,19 @@ int mrx_cim_step_joint(mrx_handle h, const int32_t* d_actions, const int32_t* d_
 static int effective_step_mode(mrx_handle h) {
   static const int env_mode = getenv("MRX_CIM_STEP_MODE") ? atoi(getenv("MRX_CIM_STEP_MODE")) : 0;  // experiments
   int m = h->step_mode ? h->step_mode : env_mode;
-  if (m < 1 || m > 3) m = 2;  // measured (profiles/r02_*): the sorted launch is the fastest form at 16384 envs per GPU
+  if (m < 1 || m > 4) m = 2;  // measured (profiles/r02_*): the sorted launch is the fastest form at 16384 envs per GPU
   if (m == 3 && !(h->spec_module && h->spec_pipe && h->pipe_waves > 0)) m = 2;
+  if (m == 4 && h->spec_module && !(h->spec_fast && h->spec_loop)) m = 2;
   return m;
+}
+
+// grid of the looped full-path kernel: the workgroups the device holds at once with this kernel's registers + LDS
+static int resident_waves(const void* kern, size_t lds_bytes, int device) {
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds_bytes) != hipSuccess || per_cu <= 0) per_cu = 8;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+  if (getenv("MRX_CIM_LOOP_WAVES_PER_CU")) per_cu = atoi(getenv("MRX_CIM_LOOP_WAVES_PER_CU"));  // experiments
+  return per_cu * cus;
 }
 
 static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const int32_t* d_n_answered,
@@ -340,6 +393,33 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
                        ((uintptr_t)d_env_mask & 15) ? 0 : 1, K.n_envs, per, K.order, K.sched);
   }
   const int sorted = mode >= 2 ? 1 : 0;
+  const size_t lds_bytes = (size_t)K.lds_words * 4 + lds_pad;
+  if (mode == 4) {
+    // the fast-hinted envs, one per lane, no LDS; then the full-path list on as many workgroups as are resident at once
+    const unsigned fast_blocks = (unsigned)((K.n_envs + 63) / 64);
+    if (h->spec_module) {
+      CimParams Kc = K;
+      CimObs Oc = h->obs;
+      void* pf[] = {&Kc, &Oc, &B, &d_env_mask};
+      HIP_TRY(hipModuleLaunchKernel(h->spec_fast, fast_blocks, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, pf, nullptr));
+      void* pl[] = {&Kc, &Oc, &B};
+      const int W = h->loop_waves < K.n_envs ? h->loop_waves : K.n_envs;
+      HIP_TRY(hipModuleLaunchKernel(h->spec_loop, (unsigned)W, 1, 1, 64, 1, 1, (unsigned)lds_bytes, (hipStream_t)stream, pl, nullptr));
+      return MRX_OK;
+    }
+#define MRX_LAUNCH_SPLIT(SUFFIX)                                                                                                    \
+    {                                                                                                                              \
+      if (!h->loop_waves) h->loop_waves = resident_waves((const void*)mrx_k_cim_step_loop##SUFFIX, lds_bytes, h->device);                       \
+      const int W = h->loop_waves < K.n_envs ? h->loop_waves : K.n_envs;                                                           \
+      hipLaunchKernelGGL(mrx_k_cim_fast_lanes##SUFFIX, dim3(fast_blocks), dim3(64), 0, (hipStream_t)stream, K, h->obs, B, d_env_mask); \
+      hipLaunchKernelGGL(mrx_k_cim_step_loop##SUFFIX, dim3(W), dim3(64), lds_bytes, (hipStream_t)stream, K, h->obs, B);            \
+    }
+    if (K.pregen) { if (obs) MRX_LAUNCH_SPLIT(_tab_obs) else MRX_LAUNCH_SPLIT(_tab) }
+    else { if (obs) MRX_LAUNCH_SPLIT(_obs) else MRX_LAUNCH_SPLIT() }
+#undef MRX_LAUNCH_SPLIT
+    HIP_TRY(hipGetLastError());
+    return MRX_OK;
+  }
   if (h->spec_module) {
     CimParams Kc = K;
     CimObs Oc = h->obs;
@@ -363,7 +443,7 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
 
 int mrx_cim_set_step_mode(mrx_handle h, int mode) {
   if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
-  if (mode < 0 || mode > 3) return set_err(MRX_ERR_INVALID_ARG, "step mode must be 0 (automatic), 1, 2 or 3");
+  if (mode < 0 || mode > 4) return set_err(MRX_ERR_INVALID_ARG, "step mode must be 0 (automatic), 1, 2, 3 or 4");
   h->step_mode = mode;
   return effective_step_mode(h);
 }
@@ -552,20 +632,20 @@ int mrx_cim_load_step_kernels(mrx_handle h, const void* image, int64_t bytes, co
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
   hipModule_t mod = nullptr;
-  HIP_TRY(hipModuleLoadData(&mod, image));
+  HIP_TRY(shared_module_acquire(image, (size_t)bytes, h->device, &mod));
   static const char* names[4] = {"mrx_k_cim_step", "mrx_k_cim_step_obs", "mrx_k_cim_step_tab", "mrx_k_cim_step_tab_obs"};
   hipFunction_t fn[4] = {nullptr, nullptr, nullptr, nullptr};
   const int want = (h->plan.kp.pregen ? 2 : 0) + ((h->obs.np > 0 || h->obs.nv > 0) ? 1 : 0);  // the one kernel this configuration launches
   for (int i = want; i <= want; i++) {
     if (hipModuleGetFunction(&fn[i], mod, names[i]) != hipSuccess) {
-      hipModuleUnload(mod);
+      shared_module_release(mod);
       return set_err(MRX_ERR_INVALID_ARG, std::string("code object lacks kernel ") + names[i]);
     }
     if ((size_t)h->plan.kp.lds_words * 4 > 64 * 1024) hipFuncSetAttribute((const void*)fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, h->plan.kp.lds_words * 4);
   }
   hipFunction_t f_reset = nullptr, f_table = nullptr;
   if (hipModuleGetFunction(&f_reset, mod, "mrx_k_cim_reset") != hipSuccess || hipModuleGetFunction(&f_table, mod, "mrx_k_cim_order_table") != hipSuccess) {
-    hipModuleUnload(mod);
+    shared_module_release(mod);
     return set_err(MRX_ERR_INVALID_ARG, "code object lacks the reset kernels");
   }
   if ((size_t)h->plan.kp.lds_words_reset * 4 > 64 * 1024) hipFuncSetAttribute((const void*)f_reset, hipFuncAttributeMaxDynamicSharedMemorySize, h->plan.kp.lds_words_reset * 4);
@@ -574,6 +654,21 @@ int mrx_cim_load_step_kernels(mrx_handle h, const void* image, int64_t bytes, co
   for (int i = 0; i < 4; i++) h->spec_fn[i] = fn[i];
   h->spec_reset = f_reset;
   h->spec_order_table = f_table;
+  {  // launch form 4: the two kernels of this configuration
+    static const char* sfx[4] = {"", "_obs", "_tab", "_tab_obs"};
+    const std::string nf = std::string("mrx_k_cim_fast_lanes") + sfx[want], nl = std::string("mrx_k_cim_step_loop") + sfx[want];
+    hipFunction_t ff = nullptr, fl = nullptr;
+    if (hipModuleGetFunction(&ff, mod, nf.c_str()) == hipSuccess && hipModuleGetFunction(&fl, mod, nl.c_str()) == hipSuccess && ff && fl) {
+      if ((size_t)h->plan.kp.lds_words * 4 > 64 * 1024) hipFuncSetAttribute((const void*)fl, hipFuncAttributeMaxDynamicSharedMemorySize, h->plan.kp.lds_words * 4);
+      int per_cu = 0, cus = 0;
+      if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fl, 64, (size_t)h->plan.kp.lds_words * 4) != hipSuccess || per_cu <= 0) per_cu = 8;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus <= 0) cus = 256;
+      if (getenv("MRX_CIM_LOOP_WAVES_PER_CU")) per_cu = atoi(getenv("MRX_CIM_LOOP_WAVES_PER_CU"));
+      h->spec_fast = ff; h->spec_loop = fl; h->loop_waves = per_cu * cus;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   // the persistent pipelined step, if this plan's code object has it (order table on): its grid is the number of waves the
   // device holds at once for this kernel's registers + LDS
   hipFunction_t f_pipe = nullptr;

@@ -46,20 +46,36 @@ mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const
 #else
 #define MRX_WANT(PG, OBS) 1
 #endif
+// launch form 4: the lane-parallel fast-path kernel (no LDS) and the looped full-path kernel
+#define MRX_SPLIT_KERNELS(SUFFIX, PG, OBS, WAVES)                                                                       \
+  extern "C" __global__ void __launch_bounds__(64)                                                                      \
+  mrx_k_cim_fast_lanes##SUFFIX(CimParams K, CimObs O, cim::StepBatch B, const uint8_t* __restrict__ mask) {               \
+    cim::fast_lanes_env<OBS>(K, O, B, mask, (int)(blockIdx.x * 64 + threadIdx.x));                                      \
+  }                                                                                                                     \
+  extern "C" __global__ void __launch_bounds__(64, WAVES)                                                               \
+  mrx_k_cim_step_loop##SUFFIX(CimParams K, CimObs O, cim::StepBatch B) {                                                 \
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];                                                       \
+    cim::step_loop<PG, OBS>(K, O, lds, (int)blockIdx.x, (int)gridDim.x, B);                                             \
+  }
 #if MRX_WANT(0, 0)
 MRX_STEP_KERNEL(mrx_k_cim_step, false, false, MRX_STEP_WAVES)
+MRX_SPLIT_KERNELS(, false, false, MRX_STEP_WAVES)
 #endif
 #if MRX_WANT(0, 1)
 MRX_STEP_KERNEL(mrx_k_cim_step_obs, false, true, MRX_STEP_WAVES)      // + fused observation (mrx_cim_set_observation)
+MRX_SPLIT_KERNELS(_obs, false, true, MRX_STEP_WAVES)
 #endif
 #if MRX_WANT(1, 0)
 MRX_STEP_KERNEL(mrx_k_cim_step_tab, true, false, MRX_STEP_WAVES)
+MRX_SPLIT_KERNELS(_tab, true, false, MRX_STEP_WAVES)
 #endif
 #if MRX_WANT(1, 1)
 MRX_STEP_KERNEL(mrx_k_cim_step_tab_obs, true, true, MRX_STEP_WAVES)
+MRX_SPLIT_KERNELS(_tab_obs, true, true, MRX_STEP_WAVES)
 #endif
 #undef MRX_WANT
 #undef MRX_STEP_KERNEL
+#undef MRX_SPLIT_KERNELS
 
 // The persistent, pipelined step (cim::step_persistent): gridDim.x resident waves walk the sorted order list.
 #ifdef MRX_HAVE_PIPE

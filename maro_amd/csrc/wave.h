@@ -30,19 +30,22 @@ MRX_DEV uint64_t ballot(bool pred) { return __ballot(pred); }
 MRX_DEV int shfl(int v, int src) { return __shfl(v, src, 64); }
 // value of lane `src`, src wave-uniform: v_readlane_b32 (a register read; no trip through the LDS crossbar)
 MRX_DEV int readlane(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+// value of lane `src` for a WAVE-UNIFORM src (any lane for a lane-varying src is undefined behaviour): the cheap form of shfl
+MRX_DEV int bcast(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src) & 63); }
 MRX_DEV long long shfl(long long v, int src) {
   int lo = __shfl((int)(v & 0xffffffffll), src, 64), hi = __shfl((int)(v >> 32), src, 64);
   return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-// butterfly all-reduce (sum) over the 64 lanes; every lane gets the total
+// all-reduce (sum) over the 64 lanes; every lane gets the total.  Three 22-bit limbs, each summed by the DPP scan (64 x 2^22
+// fits an int) and read from lane 63: no ds_bpermute.  |v| < 2^62.
+MRX_DEV int scan_incl_add(int v);
 MRX_DEV long long reduce_add(long long v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    int lo = __shfl_xor((int)(v & 0xffffffffll), m, 64), hi = __shfl_xor((int)(v >> 32), m, 64);
-    v += ((long long)hi << 32) | (unsigned int)lo;
-  }
-  return v;
+  const unsigned long long u = (unsigned long long)v;
+  const int l0 = (int)(u & 0x3fffffu), l1 = (int)((u >> 22) & 0x3fffffu), l2 = (int)((long long)v >> 44);  // (top limb keeps the sign)
+  const long long s0 = __builtin_amdgcn_readlane(scan_incl_add(l0), 63), s1 = __builtin_amdgcn_readlane(scan_incl_add(l1), 63),
+                  s2 = __builtin_amdgcn_readlane(scan_incl_add(l2), 63);
+  return s0 + (s1 << 22) + (s2 << 44);
 }
 
 // Direct HBM -> LDS copy (LDS-DMA, `global_load_lds_dwordx4`): every active lane moves 16 bytes from its
@@ -59,17 +62,22 @@ MRX_DEV void lds_dma_wait() {
 // fire-and-forget LDS add (ds_add_u32): concurrent lanes may target the same word
 MRX_DEV void lds_add(int32_t* p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// global counter: returns the previous value (device scope)
+MRX_DEV int global_add(int32_t* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // fire-and-forget OR into global memory (no return value, hence no s_waitcnt)
 MRX_DEV void global_or(int32_t* p, int v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// inclusive prefix sum over the lanes (lane i gets v_0 + ... + v_i)
+// inclusive prefix sum over the lanes (lane i gets v_0 + ... + v_i): six DPP adds — shifts inside the rows of 16 lanes, then
+// the gfx9 row broadcasts (row_bcast:15 into rows 1 / 3, row_bcast:31 into rows 2 / 3).  No trip through the LDS crossbar
+// (a __shfl_up scan is six dependent ds_bpermute round trips, ~10x the latency).  All 64 lanes must be active.
 MRX_DEV int scan_incl_add(int v) {
-  const int l = lane();
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int u = __shfl_up(v, d, 64);
-    if (l >= d) v += u;
-  }
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
   return v;
 }
 

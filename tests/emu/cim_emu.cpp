@@ -87,6 +87,21 @@ void emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const u
   cim::StepBatch B = {actions, n_actions, n_answered, dec, (long long*)met, done};
   const bool obs = e->obs.np > 0 || e->obs.nv > 0;
   if (mode >= 2) emu_schedule(e, mask);
+  if (mode == 4) {  // split step: lane-parallel fast kernel (64 envs per wave, no LDS), then the looped full-path kernel
+    for (int b0 = 0; b0 < K.n_envs; b0 += 64)
+      wave::run_wave(e->wave, [&]() {
+        if (obs) cim::fast_lanes_env<true>(K, e->obs, B, mask, b0 + wave::lane());
+        else cim::fast_lanes_env<false>(K, e->obs, B, mask, b0 + wave::lane());
+      });
+    for (int w = 0; w < pipe_waves; w++) {
+      memset(e->lds, 0xAB, (size_t)K.lds_words * 4);
+      wave::run_wave(e->wave, [&]() {
+        if (K.pregen) { if (obs) cim::step_loop<true, true>(K, e->obs, e->lds, w, pipe_waves, B); else cim::step_loop<true, false>(K, e->obs, e->lds, w, pipe_waves, B); }
+        else { if (obs) cim::step_loop<false, true>(K, e->obs, e->lds, w, pipe_waves, B); else cim::step_loop<false, false>(K, e->obs, e->lds, w, pipe_waves, B); }
+      });
+    }
+    return;
+  }
   if (mode == 3) {
 #ifdef MRX_HAVE_PIPE
     memset(e->lds, 0xAB, (size_t)K.lds_words * 4);

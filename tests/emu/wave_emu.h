@@ -117,7 +117,9 @@ inline uint64_t ballot(bool pred) {
 inline int shfl(int v, int src) { rendezvous(3, v); return (int)cur_wave()->snap[src & 63]; }
 inline long long shfl(long long v, int src) { rendezvous(4, v); return cur_wave()->snap[src & 63]; }
 inline int readlane(int v, int src) { return shfl(v, src); }
+inline int bcast(int v, int src) { return shfl(v, src); }
 inline void global_or(int32_t* p, int v) { *p |= v; }
+inline int global_add(int32_t* p, int v) { const int o = *p; *p += v; return o; }
 
 inline long long reduce_add(long long v) {
   rendezvous(5, v);

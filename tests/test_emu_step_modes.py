@@ -36,6 +36,8 @@ def side_by_side(topology, modes, n=6, durations=45, obs=False, max_actions=1, s
         kw = dict(n_envs=n, durations=durations, max_actions=max_actions, max_snapshots=4, decision_mode=joint)
         if m == 3:
             kw.update(specialized=True, step_mode=3, pipe_waves=4, spec_obs=OBS if obs else ((), ()))
+        elif m == 4:
+            kw.update(step_mode=4, pipe_waves=3)
         else:
             kw.update(step_mode=m)
         b = EmuBackend(topo, **kw)
@@ -104,6 +106,19 @@ def test_persistent_pipelined_kernel_with_observation_and_two_actions():
     side_by_side("global_trade.22p_l0.8", (1, 3), n=9, obs=True, max_actions=2, durations=30)
 
 
+@pytest.mark.parametrize("topology", ["global_trade.22p_l0.8", "toy.5p_ssddd_l0.5"])
+def test_split_step_equals_unsorted(topology):
+    assert side_by_side(topology, (1, 4)) > 30
+
+
+def test_split_step_with_observation_and_two_actions():
+    side_by_side("global_trade.22p_l0.8", (1, 4), n=70, obs=True, max_actions=2, durations=24)
+
+
+def test_split_step_joint_mode():
+    side_by_side("toy.5p_ssddd_l0.5", (1, 4), joint=1, durations=40)
+
+
 def test_persistent_pipelined_kernel_joint_mode():
     side_by_side("toy.5p_ssddd_l0.5", (1, 3), joint=1, durations=40)
 
@@ -118,7 +133,7 @@ def _make(mode):
     return make
 
 
-@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("mode", [2, 3, 4])
 @pytest.mark.parametrize("name", ["gt22p_l08_rand0", "toy4p_l03_res7_ring5", "gt22p_l08_res3", "toy6p_l08_rand0", "syn_immediate_returns", "case_config_folder_kat", "real_csv_rand0", "gt22p_l08_reset_chain"])
 def test_goldens_replay_in_every_launch_form(name, mode):
     replay_case(_make(mode), name)

@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("step_mode", [0, 3])
+@pytest.mark.parametrize("step_mode", [0, 3, 4])
 def test_bench_configuration_matches_the_oracle_over_a_full_episode(step_mode):
     import torch
 
@@ -15,7 +15,7 @@ def test_bench_configuration_matches_the_oracle_over_a_full_episode(step_mode):
     dev = torch.device("cuda:0")
     engines, streams, bufs, sizes, offs = bench.build_cim_groups("global_trade.22p_l0.8", 16384, 3, dev, 0, 1120, 4, True, step_mode, "fused", "random")
     assert all(e.specialized for e in engines) and engines[0].layout.order_table_on and sizes == [5462, 5461, 5461]
-    assert engines[0].step_mode == (3 if step_mode == 3 else 2)
+    assert engines[0].step_mode == (step_mode or 2)
     res = replay_against_oracle(engines, bufs, streams, sizes, offs, 0, "global_trade.22p_l0.8", 1120, 66, obs=True)
     assert res["ok"], res
     assert res["envs_checked"] >= 64 and res["env_steps_checked"] > 64 * 2300 and res["observation_checks"] > 64 * 250
