@@ -238,8 +238,11 @@ MRX_DEV void copy_words(int32_t* dst, const int32_t* src, int n_words) {
   // later (tens of µs, usually by another CU), so letting them allocate in L2 only evicts the topology tables and order rows
   // the other waves are using: measured +6.5 % env-steps/s (the matching `nt` on the LDS-DMA loads changes nothing).
   typedef int v4i_ __attribute__((ext_vector_type(4)));
-  // (deliberately NOT unrolled: a burst of all the row's stores at once measured 10 % slower than read -> store -> read ...)
-#pragma unroll 1
+  // (deliberately NOT fully unrolled: a burst of all the row's stores at once measured 10 % slower than read -> store -> read ...)
+#ifndef MRX_COPY_UNROLL
+#define MRX_COPY_UNROLL 1
+#endif
+#pragma unroll MRX_COPY_UNROLL
   for (int i = l; i < n4; i += 64) __builtin_nontemporal_store(((const v4i_*)s4)[i], (v4i_*)d4 + i);
 #else
   for (int i = l; i < n4; i += 64) d4[i] = s4[i];
@@ -416,8 +419,17 @@ MRX_DEV void gen_orders(const CimParams& K, Lds& L, long long otg, int& idx_ord,
   if (lane < P) L.dsrc[lane] = ns;
   wave::sync();
   // list_sum_normalize (utils.py:44-56): left-to-right fp64 sum, then one division per port (lane-parallel)
+  // (lane p holds term p: the terms are broadcast out of registers — no LDS round trip per term — and added in list order)
   double tot = 0.0;
-  for (int p = 0; p < P; p++) tot += L.dsrc[p];
+  {
+    union { double d; int w[2]; } u;
+    u.d = ns;
+    for (int p = 0; p < P; p++) {
+      union { double d; int w[2]; } b;
+      b.w[0] = wave::bcast(u.w[0], p); b.w[1] = wave::bcast(u.w[1], p);
+      tot += b.d;
+    }
+  }
   long long c = 0;
   if (lane < P) {
     const double ratio = (tot == 0.0) ? ns : ns / tot;
@@ -468,7 +480,14 @@ MRX_DEV void gen_orders(const CimParams& K, Lds& L, long long otg, int& idx_ord,
   if (lane < brk) {
     const int off = T.tgt_off[lane], cnt = T.tgt_off[lane + 1] - off;
     double ts = 0.0;
-    for (int j = 0; j < cnt; j++) ts += L.dtgt[off + j];
+    for (int j = 0; j < cnt; j += 4) {  // four terms requested per LDS round trip, added strictly left to right
+      const double d0 = L.dtgt[off + j], d1 = L.dtgt[off + (j + 1 < cnt ? j + 1 : j)], d2 = L.dtgt[off + (j + 2 < cnt ? j + 2 : j)],
+                   d3 = L.dtgt[off + (j + 3 < cnt ? j + 3 : j)];
+      ts += d0;
+      if (j + 1 < cnt) ts += d1;
+      if (j + 2 < cnt) ts += d2;
+      if (j + 3 < cnt) ts += d3;
+    }
     L.dsrc[lane] = ts;
   }
   wave::sync();
@@ -501,11 +520,19 @@ MRX_DEV void gen_orders(const CimParams& K, Lds& L, long long otg, int& idx_ord,
     if (n_p > 0) {
       const int off = T.tgt_off[lane], cnt = T.tgt_off[lane + 1] - off;
       long long rem = n_p;
-      for (int j = 0; j < cnt; j++) {
-        long long cur = L.oq[off + j];
-        if (cur > rem) cur = rem;
-        rem -= cur;
-        L.oq[off + j] = cur > 0 ? (int32_t)cur : 0;
+      for (int j = 0; j < cnt; j += 4) {  // four quantities per LDS round trip, handed out strictly in order
+        int32_t q[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) q[u] = L.oq[off + (j + u < cnt ? j + u : j)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (j + u < cnt) {
+            long long cur = q[u];
+            if (cur > rem) cur = rem;
+            rem -= cur;
+            L.oq[off + j + u] = cur > 0 ? (int32_t)cur : 0;
+          }
+        }
       }
     }
   }
