@@ -39,9 +39,8 @@ __device__ __forceinline__ unsigned mrx_nz16(uint4 v) {
   return nib(v.x) | (nib(v.y) << 4) | (nib(v.z) << 8) | (nib(v.w) << 12);
 }
 
-extern "C" __global__ void __launch_bounds__(1024)
-mrx_k_cim_schedule(const uint8_t* __restrict__ hint, const uint8_t* __restrict__ mask, int mask_vec, int n, int per, int32_t* __restrict__ order,
-                   int32_t* __restrict__ sched) {
+__device__ __forceinline__ void mrx_schedule_block(const uint8_t* __restrict__ hint, const uint8_t* __restrict__ mask, int mask_vec, int n, int per,
+                                                   int32_t* __restrict__ order, int32_t* __restrict__ sched) {
   __shared__ int s_t[16], s_f[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lo = tid * per, hi = lo + per < n ? lo + per : n;  // per is a multiple of 16; the hint array is padded to whole pieces
@@ -76,7 +75,8 @@ mrx_k_cim_schedule(const uint8_t* __restrict__ hint, const uint8_t* __restrict__
   if (lane == 63) { s_t[wid] = it; s_f[wid] = jf; }
   __syncthreads();
   int base_t = 0, base_f = 0, tot_t = 0, tot_f = 0;
-  for (int w = 0; w < 16; w++) {
+  const int n_waves = (int)(blockDim.x >> 6);   // (any multiple of 64 threads up to 1024)
+  for (int w = 0; w < n_waves; w++) {
     if (w < wid) { base_t += s_t[w]; base_f += s_f[w]; }
     tot_t += s_t[w]; tot_f += s_f[w];
   }
@@ -93,8 +93,14 @@ mrx_k_cim_schedule(const uint8_t* __restrict__ hint, const uint8_t* __restrict__
       for (; f; f &= f - 1) order[of++] = p0 + __builtin_ctz(f);
     }
   }
-  for (int i = tot_t + tot_f + tid; i < n; i += 1024) order[i] = -1;
+  for (int i = tot_t + tot_f + tid; i < n; i += (int)blockDim.x) order[i] = -1;
   if (tid < 16) sched[tid] = tid == 0 ? tot_t : tid == 1 ? tot_t + tot_f : tid >= 8 ? -1 : 0;  // [4..7] = 0, [8..11] = -1: dummies of cim::regs_load
+}
+
+extern "C" __global__ void __launch_bounds__(1024)
+mrx_k_cim_schedule(const uint8_t* __restrict__ hint, const uint8_t* __restrict__ mask, int mask_vec, int n, int per, int32_t* __restrict__ order,
+                   int32_t* __restrict__ sched) {
+  mrx_schedule_block(hint, mask, mask_vec, n, per, order, sched);
 }
 
 struct AttrList { int n; int32_t id[16]; };
@@ -124,10 +130,16 @@ __device__ __forceinline__ unsigned long long mrx_mix64(unsigned long long seed,
   return x;
 }
 
+// sched_per > 0: workgroup 0 builds the order list of the coming step instead (mrx_schedule_block, all envs unmasked) — the
+// list only depends on the previous step's hints, so it rides along with the policy instead of costing a launch of its own
 extern "C" __global__ void __launch_bounds__(256)
 mrx_k_cim_random_policy(CimParams K, const int32_t* __restrict__ decisions, long long step, int32_t* __restrict__ actions,
-                        int32_t* __restrict__ n_actions, unsigned long long* __restrict__ counter) {
-  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+                        int32_t* __restrict__ n_actions, unsigned long long* __restrict__ counter, int sched_per) {
+  if (sched_per > 0 && blockIdx.x == 0) {
+    mrx_schedule_block((const uint8_t*)K.hint, nullptr, 0, K.n_envs, sched_per, K.order, K.sched);
+    return;
+  }
+  const int env = (int)((blockIdx.x - (sched_per > 0 ? 1 : 0)) * blockDim.x + threadIdx.x);
   bool valid = false;
   if (env < K.n_envs) {
     const int32_t* d = decisions + (size_t)env * 8;
@@ -202,6 +214,7 @@ struct mrx_cim_engine {
   hipFunction_t spec_fast = nullptr, spec_loop = nullptr;   // launch form 4 (mrx_k_cim_fast_lanes*, mrx_k_cim_step_loop*)
   int loop_waves = 0;                     // grid of the looped full-path kernel (generic or specialised build in use)
   int step_mode = 0;                      // mrx_cim_set_step_mode (0 = automatic)
+  bool order_ready = false;               // the order list of the coming step was built by the policy launch (no mask)
   // Kernels of a module may still be queued or running on the caller's stream(s): drain the device before unloading it.
   void unload_spec() {
     if (!spec_module) return;
@@ -319,6 +332,7 @@ int mrx_cim_get_layout(mrx_handle h, mrx_cim_layout* out) {
 
 int mrx_cim_reset(mrx_handle h, const int64_t* d_seed_cmd, const uint8_t* d_env_mask, void* stream) {
   if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  h->order_ready = false;  // (reset rewrites hints)
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
   const CimParams& K = h->plan.kp;
@@ -387,7 +401,9 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
   const bool obs = h->obs.np > 0 || h->obs.nv > 0;  // (the _obs kernels are only needed for the fused observation; the retention rows are written by every build)
   const int mode = effective_step_mode(h);
   cim::StepBatch B = {d_actions, d_n_actions, d_n_answered, d_decisions, (long long*)d_metrics, d_done};
-  if (mode >= 2) {
+  const bool have_order = h->order_ready && !d_env_mask;   // built by mrx_cim_random_policy for exactly this step
+  h->order_ready = false;
+  if (mode >= 2 && !have_order) {
     const int per = ((K.n_envs + 1023) / 1024 + 15) / 16 * 16;  // envs per thread, whole 16-byte pieces
     hipLaunchKernelGGL(mrx_k_cim_schedule, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const uint8_t*)K.hint, d_env_mask,
                        ((uintptr_t)d_env_mask & 15) ? 0 : 1, K.n_envs, per, K.order, K.sched);
@@ -475,6 +491,7 @@ int mrx_cim_set_observation(mrx_handle h, const int32_t* port_attrs, int n_port_
   if (rc2 != MRX_OK) return rc2;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(h->plan.kp.hint, 1, (size_t)h->plan.kp.n_envs));
+  h->order_ready = false;
   return MRX_OK;
 }
 
@@ -501,9 +518,15 @@ int mrx_cim_random_policy(mrx_handle h, const int32_t* d_decisions, int64_t step
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
   const CimParams& K = h->plan.kp;
-  hipLaunchKernelGGL(mrx_k_cim_random_policy, dim3((K.n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, K, d_decisions,
-                     (long long)step, d_actions, d_n_actions, (unsigned long long*)d_counter);
+  // with a sorted launch form the order list of the coming step is built by workgroup 0 of this launch (the step that
+  // follows on the same stream then needs no schedule kernel of its own, unless it is given an env mask)
+  static const bool fuse = !(getenv("MRX_CIM_FUSE_SCHEDULE") && atoi(getenv("MRX_CIM_FUSE_SCHEDULE")) == 0);
+  // (256-thread workgroups: a 1024-thread one needs 16 free wave slots on ONE CU at once and waits for them behind the step kernels)
+  const int sched_per = (fuse && effective_step_mode(h) >= 2) ? ((K.n_envs + 255) / 256 + 15) / 16 * 16 : 0;
+  hipLaunchKernelGGL(mrx_k_cim_random_policy, dim3((K.n_envs + 255) / 256 + (sched_per > 0 ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, K,
+                     d_decisions, (long long)step, d_actions, d_n_actions, (unsigned long long*)d_counter, sched_per);
   HIP_TRY(hipGetLastError());
+  h->order_ready = sched_per > 0;
   return MRX_OK;
 }
 
