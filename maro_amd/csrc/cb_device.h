@@ -192,28 +192,40 @@ MRX_DEV void pool_push(const CbParams& K, int e, int32_t* hd, int land, int sche
   if (land < HDR(CH_POOL_MINLAND)) HDR(CH_POOL_MINLAND) = land;
 }
 
-// phases 1-3 of tick t
-MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t) {
-  const int d = t - CD(start_tick);
+// everything tick d needs from the shared offset tables: two consecutive records of CbParams::tick_rec (one 32-byte read)
+struct TickRec { int r0, r_mid, q0, r_end, q_end; };
+MRX_DEV TickRec load_tick_rec(const CbParams& K, int t) {
+  int d = t - CD(start_tick);
+  const int D = CD(max_tick) - CD(start_tick);
+  d = d < D ? d : D - 1;  // (a prefetch for the tick after the last one reads the last record again)
+  const int32_t* p = K.tick_rec + (size_t)d * 4;
+  TickRec R;
+  R.r0 = p[0]; R.r_mid = p[1]; R.q0 = p[2]; R.r_end = p[4]; R.q_end = p[6];
+  return R;
+}
+
+// phases 1-3 of tick t; `R` = load_tick_rec(K, t), requested one tick ahead by the caller
+MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t, const TickRec& R) {
   // ---- 1: events queued by earlier ticks, by (scheduling tick, ReturnBike before DeliverBike, insertion order)
   const bool deliveries = HDR(CH_POOL_MINLAND) == t;
   int p = HDR(CH_POOL_HEAD);
   const int tail = HDR(CH_POOL_TAIL);
-  const int r_mid = K.ret_mid[d], r_end = K.ret_off[d + 1];
-  for (int r = K.ret_off[d]; r < r_mid; r++) {
-    const int i = K.ret_trip[r];
-    if (deliveries) pool_exec_until(K, e, hd, t, K.trip_tick[i], p, tail);
-    if ((uint32_t)FUL((i & CD(w_mask)) >> 5) >> (i & 31) & 1u) land_bikes(K, e, hd, false, K.trip_src[i], K.trip_dst[i], 1);
+  const int r_mid = R.r_mid, r_end = R.r_end;
+  for (int r = R.r0; r < r_mid; r++) {
+    const int32_t* rr = K.ret_rec + (size_t)r * 4;  // (trip index, its scheduling tick, src, dst)
+    const int i = rr[0];
+    if (deliveries) pool_exec_until(K, e, hd, t, rr[1], p, tail);
+    if ((uint32_t)FUL((i & CD(w_mask)) >> 5) >> (i & 31) & 1u) land_bikes(K, e, hd, false, rr[2], rr[3], 1);
   }
   if (deliveries) {
     pool_exec_until(K, e, hd, t, CB_NO_LAND, p, tail);
     pool_compact(K, e, hd);
   }
   // ---- 2: RequireBike :398-437
-  const int q_end = K.trip_off[d + 1];
+  const int q_end = R.q_end;
   int n_trips = 0, n_short = 0;
-  for (int i = K.trip_off[d]; i < q_end; i++) {
-    const int src = K.trip_src[i], dst = K.trip_dst[i];
+  for (int i = R.q0; i < q_end; i++) {
+    const int src = K.trip_rec[(size_t)i * 2], dst = K.trip_rec[(size_t)i * 2 + 1];
     const int b = ST(LV_BIKES, src);
     ST(LV_TRIP_REQUIREMENT, src) += 1;
     ADJ(src, dst) += 1;
@@ -245,8 +257,9 @@ MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t) {
     }
   }
   for (int r = r_mid; r < r_end; r++) {
-    const int i = K.ret_trip[r];
-    if ((uint32_t)FUL((i & CD(w_mask)) >> 5) >> (i & 31) & 1u) land_bikes(K, e, hd, false, K.trip_src[i], K.trip_dst[i], 1);
+    const int32_t* rr = K.ret_rec + (size_t)r * 4;
+    const int i = rr[0];
+    if ((uint32_t)FUL((i & CD(w_mask)) >> 5) >> (i & 31) & 1u) land_bikes(K, e, hd, false, rr[2], rr[3], 1);
   }
   HDR(CH_LATE) = 0;
 }
@@ -433,9 +446,10 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
       flags &= ~CFL_PENDING;
     } else if (flags & CFL_FRESH) {
       flags &= ~CFL_FRESH;
-      begin_tick(K, e, hd, t);
+      begin_tick(K, e, hd, t, load_tick_rec(K, t));
     }
     for (;;) {
+      const TickRec R1 = load_tick_rec(K, t + 1);  // the next tick's offsets, requested before this tick's decisions / end are handled
       int type;
       const int s = next_decision(K, e, hd, &type);
       if (s >= 0) {
@@ -455,7 +469,7 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
         break;
       }
       t++;
-      begin_tick(K, e, hd, t);
+      begin_tick(K, e, hd, t, R1);
     }
     HDR(CH_TICK) = t;
     HDR(CH_FLAGS) = flags;

@@ -149,6 +149,16 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
   };
   put(&CbParams::trip_off, trip_off); put(&CbParams::trip_tick, ttick); put(&CbParams::trip_src, tsrc); put(&CbParams::trip_dst, tdst);
   put(&CbParams::ret_off, ret_off); put(&CbParams::ret_mid, ret_mid); put(&CbParams::ret_trip, ret_trip);
+  {
+    std::vector<int32_t> tick_rec((size_t)(D + 2) * 4, 0), ret_rec(ret_trip.size() * 4 + 4, 0), trip_rec((size_t)n * 2 + 2, 0);
+    for (int d = 0; d <= D; d++) { tick_rec[(size_t)d * 4] = ret_off[d]; tick_rec[(size_t)d * 4 + 1] = d < D ? ret_mid[d] : ret_off[D]; tick_rec[(size_t)d * 4 + 2] = trip_off[d]; }
+    for (size_t r = 0; r < ret_trip.size(); r++) {
+      const int i = ret_trip[r];
+      ret_rec[r * 4] = i; ret_rec[r * 4 + 1] = ttick[i]; ret_rec[r * 4 + 2] = tsrc[i]; ret_rec[r * 4 + 3] = tdst[i];
+    }
+    for (int i = 0; i < n; i++) { trip_rec[(size_t)i * 2] = tsrc[i]; trip_rec[(size_t)i * 2 + 1] = tdst[i]; }
+    put(&CbParams::tick_rec, tick_rec); put(&CbParams::ret_rec, ret_rec); put(&CbParams::trip_rec, trip_rec);
+  }
   put(&CbParams::capacity, std::vector<int32_t>(t->capacity, t->capacity + S));
   put(&CbParams::init_bikes, std::vector<int32_t>(t->init_bikes, t->init_bikes + S));
   put(&CbParams::station_id, std::vector<int32_t>(t->station_id, t->station_id + S));

@@ -39,6 +39,11 @@ struct CbParams {
   // ---- shared tables (trips restricted to [start_tick, max_tick), re-indexed from 0)
   const int32_t *trip_off, *trip_tick, *trip_src, *trip_dst;  // trip_off [durations + 1]
   const int32_t *ret_off, *ret_mid, *ret_trip;                // returns landing at each tick, insertion order
+  // the same tables as RECORDS, so that one tick costs two dependent loads instead of four (a lane's step is one long
+  // chain of L2 round trips; every env of a batch reads the same shared tables):
+  const int32_t* tick_rec;  // [durations + 1][4] = (ret_off, ret_mid, trip_off, 0): 8 consecutive words = everything tick d needs
+  const int32_t* ret_rec;   // [n_returns][4]     = (trip index, its scheduling tick, src station, dst station)
+  const int32_t* trip_rec;  // [n_trips][2]       = (src station, dst station)
   const int32_t *capacity, *init_bikes, *station_id, *nb, *nb_cnt;
   const int32_t *tick_day, *cal;  // tick_day [durations] (relative to start_tick) -> cal [n_days][4] weekday, temperature, weather, holiday
 };
