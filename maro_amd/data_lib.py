@@ -34,6 +34,8 @@ class _Loader(yaml.SafeLoader):
 
 
 _Loader.add_multi_constructor("!Maro", lambda loader, suffix, node: loader.construct_mapping(node, deep=True))
+for _tag in ("!MaroAttribute", "!MaroEvent"):   # explicit too: they win over constructors a MARO import registers on yaml.SafeLoader
+    _Loader.add_constructor(_tag, lambda loader, node: loader.construct_mapping(node, deep=True))
 
 
 def read_binary(path: str) -> Tuple[dict, np.ndarray]:

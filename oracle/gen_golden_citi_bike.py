@@ -38,7 +38,28 @@ CASES = {
     "cb_filters_d1000_r3_half": ("toy.5s_filters", dict(durations=1000, snapshot_resolution=3, max_snapshots=7), "half"),
     "cb_win0_d1400_r10_all": ("toy.5s_win0", dict(durations=1400, snapshot_resolution=10), "all"),
     "cb_tight_d800_r20_none": ("toy.3s_tight", dict(durations=800, snapshot_resolution=20, max_snapshots=6), "none"),
+    # city.180s: the seeded synthetic city-shaped topology (maro_amd/citi_bike/synthetic.py: 180 stations, 24 neighbours each,
+    # the default distance 20 -> requirements 10 -> trip_window 6 chain), written as a MARO build folder by maro_amd's own
+    # binary writer and run through the reference's Env: ~60 deciding stations per decision tick
+    "cb_city180_d1440_r10_ring16_half": ("city.180s", dict(durations=1440, snapshot_resolution=10, max_snapshots=16), "half"),
+    "cb_city180_d2000_r20_ring9_all": ("city.180s", dict(durations=2000, snapshot_resolution=20, max_snapshots=9), "all"),
 }
+
+
+def ensure_synthetic(maro_root, topology):
+    """city.*: (re)generate the build folder + config.yml and register the topology with the reference checkout."""
+    sys.path.insert(0, REPO)
+    import yaml
+    from maro_amd.citi_bike.synthetic import PACKAGED, build_packaged
+    if topology not in PACKAGED:
+        return
+    home = os.environ.get("MARO_ORACLE_HOME", "/tmp/oracle/home")
+    bd = os.path.join(home, ".maro", "data", "citi_bike", ".build", topology)
+    cfg, _ = build_packaged(topology, bd)
+    tdir = os.path.join(maro_root, "maro", "simulator", "scenarios", "citi_bike", "topologies", topology)
+    os.makedirs(tdir, exist_ok=True)
+    with open(os.path.join(tdir, "config.yml"), "wt") as fp:
+        yaml.safe_dump(cfg, fp)
 
 
 def worker(maro_root, stubs, case, out_path):
@@ -50,6 +71,7 @@ def worker(maro_root, stubs, case, out_path):
     from maro.simulator.scenarios.citi_bike.common import Action, DecisionType
 
     topology, kwargs, policy = CASES[case]
+    ensure_synthetic(maro_root, topology)
     np.random.seed(0)
     env = Env("citi_bike", topology, start_tick=0, **kwargs)
     decs, scopes, mets, acts = [], [], [], []

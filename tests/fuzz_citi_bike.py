@@ -35,6 +35,18 @@ def random_data(rng):
         scope_high_ratio=float(rng.choice([1, 0.85, 0.5])), extra_cost_mode=int(rng.randint(0, 2)), filters=filters)
 
 
+def run_city_case(case_seed, S, backend=None, n_envs=3, **kw):
+    from tests.cb_batch_check import run_batch_vs_oracle
+    from tests.emu.cb_emu import CbEmuBackend
+    B = backend or CbEmuBackend
+    from maro_amd.citi_bike.synthetic import city_data
+    data = city_data(np.random.RandomState(case_seed), S=S)
+    kw = dict(dict(durations=400, snapshot_resolution=10), **kw)
+    b = B(data, n_envs=n_envs, max_actions=1, **kw)
+    return run_batch_vs_oracle(b, data, kw, seeds=np.arange(n_envs) + case_seed, episodes=1,
+                               check_envs=sorted({0, n_envs // 2, n_envs - 1}))
+
+
 def run_case(case_seed, backend=None):
     from tests.cb_batch_check import run_batch_vs_oracle
     from tests.emu.cb_emu import CbEmuBackend

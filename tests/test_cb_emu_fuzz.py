@@ -8,3 +8,36 @@ from tests.fuzz_citi_bike import run_case
 @pytest.mark.parametrize("case_seed", [1, 5, 22, 36, 58])
 def test_random_citi_bike_data(case_seed):
     assert run_case(case_seed) >= 0
+
+
+@pytest.mark.parametrize("S,seed,kw", [(180, 1, {}), (333, 2, dict(snapshot_resolution=7, max_snapshots=11)), (97, 3, dict(durations=470))])
+def test_city_sized_data(S, seed, kw):
+    """City-shaped synthetic topologies (97 / 180 / 333 stations, 24 nearest neighbours, hub traffic with a rush hour, the
+    reference's default three-filter chain): the generic station loops, 2..6 decision-mask words, filters that cut."""
+    from tests.fuzz_citi_bike import run_city_case
+    assert run_city_case(seed, S, **kw) > 100
+
+
+def test_city_sized_data_specialized():
+    import functools
+
+    from tests.emu.cb_emu import CbEmuBackend
+    from tests.fuzz_citi_bike import run_city_case
+    assert run_city_case(4, 150, backend=functools.partial(CbEmuBackend, specialized=True)) > 100
+
+
+def test_packaged_city_topology_regenerates(tmp_path):
+    """The packaged synthetic topology is the seeded generator's output (unlike the reference's unseeded toy generator),
+    taken through MARO's on-disk form: write_build_folder (trips.bin / KNYC_daily.bin / csv) -> load_build_folder."""
+    import numpy as np
+
+    from maro_amd.citi_bike.data import load_topology
+    from maro_amd.citi_bike.synthetic import PACKAGED, build_packaged
+    for name in PACKAGED:
+        cfg, fresh = build_packaged(name, str(tmp_path / name))
+        have = load_topology(name)
+        for k in ("trip_tick", "trip_src", "trip_dst", "trip_duration", "capacity", "init_bikes", "station_id", "distance", "tick_day",
+                  "day_weekday", "day_holiday", "day_weather", "day_temperature"):
+            assert np.array_equal(getattr(fresh, k), getattr(have, k)), (name, k)
+        assert fresh.filters == have.filters and fresh.n_stations == 180 and cfg["time_zone"] == "America/New_York"
+        assert have.day_weekday.tolist() == [0, 1] and (fresh.time_mean, fresh.resolution) == (have.time_mean, have.resolution)

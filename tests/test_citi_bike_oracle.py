@@ -21,7 +21,7 @@ def load(case):
 def replay_citi_bike(make_env, case):
     z, meta = load(case)
     data = load_topology(meta["topology"])
-    env = make_env(data, meta["kwargs"], draw_transfer_times(data, meta["np_seed"], 4096))
+    env = make_env(data, meta["kwargs"], draw_transfer_times(data, meta["np_seed"], max(4096, len(z["actions"]) + 8)))
     gd, gs, gm, ga = z["decisions"], z["scopes"], z["metrics"], z["actions"]
     m, de, done = env.step(None)
     i = 0
