@@ -157,6 +157,8 @@ def bench_citi_bike(args):
     n, res = args.envs, 10
     topology = args.topology if args.topology != "global_trade.22p_l0.8" else "toy.3s_4t"
     durations = args.durations if args.durations != 1120 else 44000
+    from maro_amd.citi_bike.data import load_topology as load_cb
+    durations = min(durations, len(load_cb(topology).tick_day))   # (city.180s holds two days of trips, the toys a month)
     kw = dict(durations=durations, snapshot_resolution=res, max_snapshots=16, max_actions=1, device=dev, seeds=np.arange(n) + rank * n + 1)
     try:
         eng = CitiBikeBatchEngine(topology, n, specialize=bool(args.specialize), **kw)   # kernels compiled for this plan (cached in-tree)
@@ -250,7 +252,7 @@ def bench_citi_bike(args):
         b_step = (3.0 + tbar / res) * F + 20.0 * (n_trips / durations) * tbar + 40.0   # SURVEY.md §8(d) general form
         achieved = b_step * n / (step_kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": "env-steps/sec (decision events/sec), citi_bike toy.3s_4t",
+            "metric": f"env-steps/sec (decision events/sec), citi_bike {topology}",
             "value": resolved / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",

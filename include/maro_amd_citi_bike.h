@@ -71,7 +71,7 @@ typedef struct mrx_cb_config {
 typedef struct mrx_cb_layout {
   int32_t n_envs, env_stride, n_stations, frame_words, ring_slots, scope_cap, delivery_capacity, transfer_times_cap;
   int64_t off_hdr;     /* int32 [16][stride]: tick, flags, ..., status (MRX_CB_HDR_*) */
-  int64_t off_live;    /* int32 [frame_words][stride]: 8 attrs x S (attr-major) then trips_adj S*S */
+  int64_t off_live;    /* int32 [frame_words][stride]: the 8 per-env station attrs x S (attr-major); trips_adj is a shared table */
   int64_t off_ring;    /* int32 [ring_slots][frame_words + 1][stride] (last word: tick of the snapshot) */
   int64_t off_ring_fi; /* int32 [ring_slots][stride] frame index held by each slot, -1 = empty */
   int64_t off_transfer_times; /* int32 [transfer_times_cap][stride] */

@@ -40,12 +40,11 @@ namespace cb {
 #define HDR(w) hd[(w)]                           /* header word of the env being stepped: a register copy (step_env) */
 // the live frame in HBM (reset, query, and the generic step)
 #define GST(a, s) K.live[((size_t)(a) * CD(S) + (size_t)(s)) * CD(stride) + e]
-#define GADJ(i, j) K.live[((size_t)LV_COUNT * CD(S) + (size_t)(i) * CD(S) + (size_t)(j)) * CD(stride) + e]
-// Register-resident live frame: a specialised build whose whole frame is at most 128 words (up to 8 stations: the toy topologies)
+// Register-resident live frame: a specialised build for at most 8 stations (the toy topologies: a frame of at most 64 words)
 // loads it once per step into the tail of the header array hd[] and keeps it in VGPRs — the store -> load chains through L2
 // that dominate a lane's latency (bikes / shortage / trip counters are read-modify-written several times per tick) disappear.
 // A runtime station index becomes a select chain over the S candidates (LvRef), so every array index stays static.
-#if defined(MRX_SPECIALIZED) && (MRXC_FW <= 128)
+#if defined(MRX_SPECIALIZED) && (MRXC_S <= 8)
 #define MRX_CB_REGFRAME 1
 #ifdef __HIPCC__
 #define MRX_DEVM __device__ __forceinline__
@@ -93,7 +92,6 @@ struct LuRef {  // the same for the unsigned bit words (fulfilled ring, decision
   MRX_DEVM LuRef& operator|=(uint32_t v) { return *this = (uint32_t)*this | v; }
 };
 #define ST(a, s) (LvRef<MRXC_S>{hd + CH_WORDS + (a) * MRXC_S, (int)(s)})
-#define ADJ(i, j) (LvRef<MRXC_S * MRXC_S>{hd + CH_WORDS + LV_COUNT * MRXC_S, (int)(i) * MRXC_S + (int)(j)})
 // ... and, when they are small too, the per-env bit words: the fulfilled ring and the pending-decision masks
 #if (MRXC_w_words <= 16) && (MRXC_mask_words <= 2)
 #define MRX_CB_REGBITS 1
@@ -105,7 +103,6 @@ struct LuRef {  // the same for the unsigned bit words (fulfilled ring, decision
 #endif
 #else
 #define ST(a, s) GST(a, s)
-#define ADJ(i, j) GADJ(i, j)
 #define CB_HD_WORDS CH_WORDS
 #endif
 #define GFUL(i) K.fulfilled[(size_t)(i) * CD(stride) + e]
@@ -228,7 +225,6 @@ MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t, const Tick
     const int src = K.trip_rec[(size_t)i * 2], dst = K.trip_rec[(size_t)i * 2 + 1];
     const int b = ST(LV_BIKES, src);
     ST(LV_TRIP_REQUIREMENT, src) += 1;
-    ADJ(src, dst) += 1;
     n_trips++;
     const int fw = (i & CD(w_mask)) >> 5;
     if (b < 1) {
@@ -542,7 +538,18 @@ MRX_DEV double query_elem(const CbParams& K, int node_type, const int32_t* ticks
     sl -= ns;
   }
   const int node = nodes[(size_t)e * nodes_per_env + ni];
-  if (node_type == 1) return node == 0 ? (double)frame[((size_t)LV_COUNT * CD(S) + sl) * CD(stride)] : 0.0;
+  if (node_type == 1) {
+    // trips_adj of the frame taken at tick t_frame: the (src, dst) pair's trips up to and including that tick
+    if (node != 0) return 0.0;
+    const int bound = K.trip_off[t_frame - CD(start_tick) + 1];
+    const int lo0 = K.adj_off[sl];
+    int lo = lo0, hi = K.adj_off[sl + 1];
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (K.adj_idx[mid] < bound) lo = mid + 1; else hi = mid;
+    }
+    return (double)(lo - lo0);
+  }
   if (node < 0 || node >= CD(S)) return 0.0;
   int lv = -1;
   switch (a) {
@@ -590,7 +597,6 @@ MRX_DEV int random_policy_env(const CbParams& K, int e, const int32_t* dec, cons
 #undef HDR
 #undef GHDR
 #undef ST
-#undef ADJ
 #undef POOL
 #undef SCR
 

@@ -72,7 +72,7 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
   k.supply_wm = t->supply_water_mark_ratio; k.demand_wm = t->demand_water_mark_ratio;
   k.scope_low_keep = 1 - t->scope_low_ratio;  // decision_strategy.py:287: floor(bikes * (1 - scope_low_ratio))
   k.scope_high = t->scope_high_ratio;
-  k.FW = LV_COUNT * S + S * S;
+  k.FW = LV_COUNT * S;  // (trips_adj is not per-env state: see adj_off below)
   k.mask_words = (S + 31) / 32;
   k.pool_cap = c->delivery_capacity > 0 ? c->delivery_capacity : 4 * S + 4;
   k.tt_cap = c->transfer_times_cap > 0 ? c->transfer_times_cap : S * (c->durations / t->resolution + 1);
@@ -158,6 +158,17 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
     }
     for (int i = 0; i < n; i++) { trip_rec[(size_t)i * 2] = tsrc[i]; trip_rec[(size_t)i * 2 + 1] = tdst[i]; }
     put(&CbParams::tick_rec, tick_rec); put(&CbParams::ret_rec, ret_rec); put(&CbParams::trip_rec, trip_rec);
+  }
+  {
+    // trips_adj[src][dst] counts EVERY RequireBike of the episode so far, fulfilled or not (business_engine.py:412), and is
+    // never reset inside an episode: it is a function of (shared trip table, tick) only.  Kept as trip indices grouped by
+    // (src, dst) pair: the matrix of a frame taken at tick t = per pair, how many of its indices are < trip_off[t + 1].
+    std::vector<int32_t> adj_off((size_t)S * S + 1, 0), adj_idx(n);
+    for (int i = 0; i < n; i++) adj_off[(size_t)tsrc[i] * S + tdst[i] + 1]++;
+    for (size_t c2 = 0; c2 < (size_t)S * S; c2++) adj_off[c2 + 1] += adj_off[c2];
+    std::vector<int32_t> fill(adj_off.begin(), adj_off.end() - 1);
+    for (int i = 0; i < n; i++) adj_idx[fill[(size_t)tsrc[i] * S + tdst[i]]++] = i;
+    put(&CbParams::adj_off, adj_off); put(&CbParams::adj_idx, adj_idx);
   }
   put(&CbParams::capacity, std::vector<int32_t>(t->capacity, t->capacity + S));
   put(&CbParams::init_bikes, std::vector<int32_t>(t->init_bikes, t->init_bikes + S));

@@ -26,7 +26,7 @@ struct CbParams {
   double supply_wm, demand_wm, scope_low_keep, scope_high;
   // ---- per-env struct-of-arrays state: X[word][stride]
   int32_t* hdr;       // [CH_WORDS]
-  int32_t* live;      // [FW]  LV_* x S (attr-major), then trips_adj S x S
+  int32_t* live;      // [FW]  LV_* x S (attr-major)
   int32_t* ring;      // [ring_slots][FW + 1]  (+1: tick the snapshot was taken at)
   int32_t* ring_fi;   // [ring_slots]
   int32_t* twc;       // [ring_slots][S]   TripsWindowFilter cache of trip_requirement
@@ -44,6 +44,7 @@ struct CbParams {
   const int32_t* tick_rec;  // [durations + 1][4] = (ret_off, ret_mid, trip_off, 0): 8 consecutive words = everything tick d needs
   const int32_t* ret_rec;   // [n_returns][4]     = (trip index, its scheduling tick, src station, dst station)
   const int32_t* trip_rec;  // [n_trips][2]       = (src station, dst station)
+  const int32_t *adj_off, *adj_idx;  // trips_adj, shared: trip indices grouped by (src, dst); adj_off [S * S + 1]
   const int32_t *capacity, *init_bikes, *station_id, *nb, *nb_cnt;
   const int32_t *tick_day, *cal;  // tick_day [durations] (relative to start_tick) -> cal [n_days][4] weekday, temperature, weather, holiday
 };

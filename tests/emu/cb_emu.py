@@ -29,7 +29,8 @@ def build_specialized(defines: str) -> str:
     that path is checked against the oracle on the CPU too.  One .so per plan, cached in a temp dir."""
     import hashlib
     import tempfile
-    key = hashlib.sha256(defines.encode() + open(os.path.join(REPO, "maro_amd", "csrc", "cb_device.h"), "rb").read()
+    key = hashlib.sha256(defines.encode() + b"".join(open(os.path.join(REPO, "maro_amd", "csrc", f), "rb").read() for f in
+                                                     ("cb_device.h", "cb_layout.h", "cb_params.h"))
                          + open(os.path.join(HERE, "cb_emu.cpp"), "rb").read()).hexdigest()[:20]
     d = os.path.join(tempfile.gettempdir(), "maro_amd_cb_emu_spec")
     os.makedirs(d, exist_ok=True)

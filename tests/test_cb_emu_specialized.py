@@ -40,4 +40,4 @@ def test_register_frame_is_what_small_plans_compile():
         ts, keep = topology_struct(load_topology(name))
         d = spec.plan_defines(ts, MrxCbConfig(64, 0, 0, 500, 10, 0, 1, 20, 0), "citi_bike")
         fw[name] = int(re.search(r"#define MRXC_FW (\d+)", d).group(1))
-    assert fw == {"toy.3s_4t": 33, "toy.5s_6t": 65} and max(fw.values()) <= 128   # both below the MRX_CB_REGFRAME threshold
+    assert fw == {"toy.3s_4t": 24, "toy.5s_6t": 40} and max(fw.values()) <= 128   # both below the MRX_CB_REGFRAME threshold
