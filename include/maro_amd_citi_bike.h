@@ -76,6 +76,7 @@ typedef struct mrx_cb_layout {
   int64_t off_ring_fi; /* int32 [ring_slots][stride] frame index held by each slot, -1 = empty */
   int64_t off_transfer_times; /* int32 [transfer_times_cap][stride] */
   int64_t workspace_bytes;
+  int64_t off_prof;    /* int32 [16][stride]: per-env phase cycle counters, written only by -DMRX_CB_PROFILE builds (tools) */
 } mrx_cb_layout;
 enum { MRX_CB_HDR_TICK = 0, MRX_CB_HDR_FLAGS = 1, MRX_CB_HDR_STATUS = 13, MRX_CB_HDR_WORDS = 16 };
 
@@ -109,6 +110,15 @@ int mrx_cb_reset(mrx_cb_handle h, const int32_t* d_transfer_times, int32_t n_tim
  */
 int mrx_cb_step(mrx_cb_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const uint8_t* d_env_mask,
                 int32_t* d_decisions, int32_t* d_scope, int64_t* d_metrics, uint8_t* d_done, void* stream);
+
+/*
+ * How many envs share one 64-lane wave of the step kernel (no reference counterpart: the reference steps one env per process).
+ * One lane owns one env; a wave executes the union of its lanes' control flow and env-steps differ a lot in length (0 to
+ * 20+ ticks), so few envs per wave means less divergence but more waves.  lanes = 1, 2, 4, ..., 64; 0 = automatic (the
+ * default: the largest power of two that still gives the chip about four waves per SIMD, i.e. 1 at 4096 envs, 64 from 262144
+ * envs on; env var MRX_CB_LANES overrides it at creation).  Results do not depend on it.
+ */
+int mrx_cb_set_lanes_per_wave(mrx_cb_handle h, int lanes);
 
 /*
  * Replaces snapshot_list["stations" | "matrices"][ticks:nodes:attrs] (frame.pyx:754-801, np_backend.pyx:520-549).

@@ -40,7 +40,7 @@ class MrxCbLayout(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_int32) for n in ("n_envs", "env_stride", "n_stations", "frame_words", "ring_slots", "scope_cap",
                                                "delivery_capacity", "transfer_times_cap")]
                 + [(n, ctypes.c_int64) for n in ("off_hdr", "off_live", "off_ring", "off_ring_fi", "off_transfer_times",
-                                                 "workspace_bytes")])
+                                                 "workspace_bytes", "off_prof")])
 
 
 def topology_struct(d: CitiBikeData):

@@ -123,6 +123,11 @@ class CitiBikeBatchEngine:
                    "mrx_cb_reset")
         self._keep = (tt, mk)
 
+    def set_lanes_per_wave(self, lanes: int = 0) -> None:
+        """Envs per 64-lane wave of the step kernel (1, 2, ..., 64; 0 = the automatic choice): few envs per wave = less
+        control-flow divergence, more waves.  Results do not depend on it (include/maro_amd_citi_bike.h)."""
+        _lib.check(self._L.mrx_cb_set_lanes_per_wave(self._h, int(lanes)), "mrx_cb_set_lanes_per_wave")
+
     def step(self, actions=None, n_actions=None, mask=None):
         a = self._dev(actions, torch.int32)
         na = self._dev(n_actions, torch.int32)

@@ -17,6 +17,13 @@
 //     "trip got a bike" bits, merged by scheduling tick with this env's DeliverBike pool)
 //   2 RequireBike for the tick's trips   3 RebalanceBike -> decision set; zero-duration returns
 //   4 decisions, one env-step each       5 DeliverBike events with transfer time 0   6 post_step / snapshot.
+// Everything in 1-3 and 6 that does not depend on the env is laid out ONCE on the host as a single stream of event records
+// (CbParams::ev_rec, cb_layout.h); an env's step replays the stream from its cursor until a decision comes up.  The step is
+// written for SIMT execution: lanes of a wave stand at different places of the stream, so the replay is ONE flat loop that
+// handles one record per iteration whatever its kind (a wave then runs max-over-lanes(records per step) iterations; nested
+// per-tick / per-phase loops ran the SUM over ticks of the per-tick maxima, ~10x more), and the expensive, rare pieces (the
+// station sweep of a rebalance check, the end of a tick with its snapshot, the action scope of the decision) sit outside
+// that loop at points where the wave has reconverged, so each runs once per wave, not once per divergent subset of lanes.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -34,23 +41,93 @@
 #define CDA(f, i) (K.f[i])
 #endif
 
+#ifdef __HIPCC__
+#define MRX_DEVM_EARLY __device__ __forceinline__
+#else
+#define MRX_DEVM_EARLY inline
+#endif
 namespace cb {
+
+// tools only (-DMRX_CB_PROFILE, e.g. MARO_AMD_SPEC_FLAGS): shader-clock cycles of a lane's step attributed to phases, summed
+// per env in CbParams::prof (tools/cb_phase_profile.py)
+#if defined(MRX_CB_PROFILE) && defined(__HIPCC__)
+struct Prof {
+  long long last;
+  int acc[16];
+  __device__ __forceinline__ Prof() { for (int i = 0; i < 16; i++) acc[i] = 0; last = clock64(); }
+  __device__ __forceinline__ void mark(int i) { const long long c = clock64(); acc[i] += (int)(c - last); last = c; }
+  __device__ __forceinline__ void flush(const CbParams& K, int e) {
+    for (int i = 0; i < 16; i++) if (acc[i]) K.prof[(size_t)i * K.stride + e] += acc[i];
+  }
+};
+#else
+struct Prof {
+  MRX_DEVM_EARLY void mark(int) {}
+  MRX_DEVM_EARLY void flush(const CbParams&, int) {}
+};
+#endif
 
 #define GHDR(w) K.hdr[(size_t)(w) * CD(stride) + e] /* header word in HBM */
 #define HDR(w) hd[(w)]                           /* header word of the env being stepped: a register copy (step_env) */
 // the live frame in HBM (reset, query, and the generic step)
 #define GST(a, s) K.live[((size_t)(a) * CD(S) + (size_t)(s)) * CD(stride) + e]
+#ifdef __HIPCC__
+#define MRX_DEVM __device__ __forceinline__
+#else
+#define MRX_DEVM inline /* host harness (tests/emu): MRX_DEV is `static inline`, not valid on members */
+#endif
+
+// Look-ahead window over the shared event stream (4 words per record).  The stream is read strictly in order from a cursor
+// kept in the env header, so it is read in blocks of D records: `cur` is being consumed while `nxt` (requested when `cur`
+// was opened, D records of work ago) is in flight; an L2 round trip is paid at most once per D records.  Static register
+// indices only: the record at `pos` comes out of a select chain over cur[0..D).  (A shifting window does not work: the shift
+// reads the newest register, so the compiler's s_waitcnt makes every pop wait for the load just issued.)  The stream is
+// padded by CB_WIN_PAD records so a block may run past the last record.
+#define CB_WIN_PAD 16
+template <int D>
+struct RecWin {
+  int32_t cur[D][4], nxt[D][4];
+  int pos, base;  // stream index of the next record / of cur[0]; nxt = records base + D ...
+  MRX_DEVM void fetch(int32_t (*blk)[4], int k, const int32_t* tab, int idx) {
+    struct alignas(16) I4 { int32_t a, b, c, d; };
+    const I4 r = *(const I4*)(tab + (size_t)idx * 4);
+    blk[k][0] = r.a; blk[k][1] = r.b; blk[k][2] = r.c; blk[k][3] = r.d;
+  }
+  MRX_DEVM void open(const int32_t* tab, int p) {
+    pos = base = p;
+#pragma unroll
+    for (int k = 0; k < D; k++) fetch(cur, k, tab, p + k);
+#pragma unroll
+    for (int k = 0; k < D; k++) fetch(nxt, k, tab, p + D + k);
+  }
+  MRX_DEVM int32_t get(int w) const {  // word w of the record at pos
+    const int k = pos - base;
+    int32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < D; j++) r = k == j ? cur[j][w] : r;
+    return r;
+  }
+  MRX_DEVM void advance(const int32_t* tab) {
+    pos++;
+    if (pos - base == D) {
+#pragma unroll
+      for (int k = 0; k < D; k++) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) cur[k][w] = nxt[k][w];
+      }
+      base += D;
+#pragma unroll
+      for (int k = 0; k < D; k++) fetch(nxt, k, tab, base + D + k);
+    }
+  }
+};
+
 // Register-resident live frame: a specialised build for at most 8 stations (the toy topologies: a frame of at most 64 words)
 // loads it once per step into the tail of the header array hd[] and keeps it in VGPRs — the store -> load chains through L2
 // that dominate a lane's latency (bikes / shortage / trip counters are read-modify-written several times per tick) disappear.
 // A runtime station index becomes a select chain over the S candidates (LvRef), so every array index stays static.
 #if defined(MRX_SPECIALIZED) && (MRXC_S <= 8)
 #define MRX_CB_REGFRAME 1
-#ifdef __HIPCC__
-#define MRX_DEVM __device__ __forceinline__
-#else
-#define MRX_DEVM inline /* host harness (tests/emu): MRX_DEV is `static inline`, not valid on members */
-#endif
 template <int N>
 struct LvRef {
   int32_t* p;
@@ -92,17 +169,20 @@ struct LuRef {  // the same for the unsigned bit words (fulfilled ring, decision
   MRX_DEVM LuRef& operator|=(uint32_t v) { return *this = (uint32_t)*this | v; }
 };
 #define ST(a, s) (LvRef<MRXC_S>{hd + CH_WORDS + (a) * MRXC_S, (int)(s)})
+#define CAP(s) ((int32_t)LvRef<MRXC_S>{hd + CH_WORDS + MRXC_FW, (int)(s)}) /* the (shared, read-only) capacities too */
+#define CB_REG_FRAME_WORDS (MRXC_FW + MRXC_S)
 // ... and, when they are small too, the per-env bit words: the fulfilled ring and the pending-decision masks
 #if (MRXC_w_words <= 16) && (MRXC_mask_words <= 2)
 #define MRX_CB_REGBITS 1
-#define FUL(i) (LuRef<MRXC_w_words>{hd + CH_WORDS + MRXC_FW, (int)(i)})
-#define DMK(i) (LuRef<2 * MRXC_mask_words>{hd + CH_WORDS + MRXC_FW + MRXC_w_words, (int)(i)})
-#define CB_HD_WORDS (CH_WORDS + MRXC_FW + MRXC_w_words + 2 * MRXC_mask_words)
+#define FUL(i) (LuRef<MRXC_w_words>{hd + CH_WORDS + CB_REG_FRAME_WORDS, (int)(i)})
+#define DMK(i) (LuRef<2 * MRXC_mask_words>{hd + CH_WORDS + CB_REG_FRAME_WORDS + MRXC_w_words, (int)(i)})
+#define CB_HD_WORDS (CH_WORDS + CB_REG_FRAME_WORDS + MRXC_w_words + 2 * MRXC_mask_words)
 #else
-#define CB_HD_WORDS (CH_WORDS + MRXC_FW)
+#define CB_HD_WORDS (CH_WORDS + CB_REG_FRAME_WORDS)
 #endif
 #else
 #define ST(a, s) GST(a, s)
+#define CAP(s) K.capacity[s]
 #define CB_HD_WORDS CH_WORDS
 #endif
 #define GFUL(i) K.fulfilled[(size_t)(i) * CD(stride) + e]
@@ -125,7 +205,7 @@ MRX_DEV void move_to_neighbor(const CbParams& K, int e, int32_t* hd, int src, in
   for (int i = 0; i < cnt && number > 0; i++) {
     const int nb = K.nb[(size_t)cur * CD(nb_stride) + i];
     const int b = ST(LV_BIKES, nb);
-    int accept = K.capacity[nb] - b;
+    int accept = CAP(nb) - b;
     if (accept > number) accept = number;
     set_bikes(K, e, hd, nb, b + accept);
     const int target = CD(extra_cost_mode) == 0 ? src : CD(extra_cost_mode) == 1 ? cur : nb;
@@ -137,7 +217,7 @@ MRX_DEV void move_to_neighbor(const CbParams& K, int e, int32_t* hd, int src, in
 // _on_bike_returned :439-466 (deliver = false) and _on_bike_deliver :494-519 (deliver = true)
 MRX_DEV void land_bikes(const CbParams& K, int e, int32_t* hd, bool deliver, int frm, int to, int n) {
   const int b = ST(LV_BIKES, to);
-  int accept = K.capacity[to] - b;
+  int accept = CAP(to) - b;
   if (accept > n) accept = n;
   if (accept < n) {
     if (!deliver) ST(LV_FAILED_RETURN, to) += n - accept;
@@ -189,75 +269,74 @@ MRX_DEV void pool_push(const CbParams& K, int e, int32_t* hd, int land, int sche
   if (land < HDR(CH_POOL_MINLAND)) HDR(CH_POOL_MINLAND) = land;
 }
 
-// everything tick d needs from the shared offset tables: two consecutive records of CbParams::tick_rec (one 32-byte read)
-struct TickRec { int r0, r_mid, q0, r_end, q_end; };
-MRX_DEV TickRec load_tick_rec(const CbParams& K, int t) {
-  int d = t - CD(start_tick);
-  const int D = CD(max_tick) - CD(start_tick);
-  d = d < D ? d : D - 1;  // (a prefetch for the tick after the last one reads the last record again)
-  const int32_t* p = K.tick_rec + (size_t)d * 4;
-  TickRec R;
-  R.r0 = p[0]; R.r_mid = p[1]; R.q0 = p[2]; R.r_end = p[4]; R.q_end = p[6];
-  return R;
-}
-
-// phases 1-3 of tick t; `R` = load_tick_rec(K, t), requested one tick ahead by the caller
-MRX_DEV void begin_tick(const CbParams& K, int e, int32_t* hd, int t, const TickRec& R) {
-  // ---- 1: events queued by earlier ticks, by (scheduling tick, ReturnBike before DeliverBike, insertion order)
-  const bool deliveries = HDR(CH_POOL_MINLAND) == t;
-  int p = HDR(CH_POOL_HEAD);
-  const int tail = HDR(CH_POOL_TAIL);
-  const int r_mid = R.r_mid, r_end = R.r_end;
-  for (int r = R.r0; r < r_mid; r++) {
-    const int32_t* rr = K.ret_rec + (size_t)r * 4;  // (trip index, its scheduling tick, src, dst)
-    const int i = rr[0];
-    if (deliveries) pool_exec_until(K, e, hd, t, rr[1], p, tail);
-    if ((uint32_t)FUL((i & CD(w_mask)) >> 5) >> (i & 31) & 1u) land_bikes(K, e, hd, false, rr[2], rr[3], 1);
-  }
-  if (deliveries) {
-    pool_exec_until(K, e, hd, t, CB_NO_LAND, p, tail);
+// DeliverBike events (this env's pool) due before the records of tick t: landing ticks that have no record of their own,
+// oldest first — nothing else happens in between, so running them late changes nothing
+MRX_DEV void pool_flush_before(const CbParams& K, int e, int32_t* hd, int t) {
+  while (HDR(CH_POOL_MINLAND) < t) {
+    int p = HDR(CH_POOL_HEAD);
+    pool_exec_until(K, e, hd, HDR(CH_POOL_MINLAND), CB_NO_LAND, p, HDR(CH_POOL_TAIL));
     pool_compact(K, e, hd);
   }
-  // ---- 2: RequireBike :398-437
-  const int q_end = R.q_end;
-  int n_trips = 0, n_short = 0;
-  for (int i = R.q0; i < q_end; i++) {
-    const int src = K.trip_rec[(size_t)i * 2], dst = K.trip_rec[(size_t)i * 2 + 1];
-    const int b = ST(LV_BIKES, src);
-    ST(LV_TRIP_REQUIREMENT, src) += 1;
-    n_trips++;
-    const int fw = (i & CD(w_mask)) >> 5;
-    if (b < 1) {
-      ST(LV_SHORTAGE, src) += 1;
-      n_short++;
-      FUL(fw) &= ~(1u << (i & 31));
+}
+// ... and, when tick t's scheduled returns are over, the rest of the deliveries landing at t itself
+MRX_DEV void pool_flush_at(const CbParams& K, int e, int32_t* hd, int t) {
+  pool_flush_before(K, e, hd, t);
+  if (HDR(CH_POOL_MINLAND) == t) {
+    int p = HDR(CH_POOL_HEAD);
+    pool_exec_until(K, e, hd, t, CB_NO_LAND, p, HDR(CH_POOL_TAIL));
+    pool_compact(K, e, hd);
+  }
+}
+
+// One LIGHT record of the event stream (return / trip), at tick t
+MRX_DEV void light_event(const CbParams& K, int e, int32_t* hd, int t, int kind, int a, int b, int c) {
+  if (kind == CB_EV_TRIP) {  // RequireBike :398-437 (a = trip index, b = src)
+    if (HDR(CH_POOL_MINLAND) <= t) pool_flush_at(K, e, hd, t);
+    const int bikes = ST(LV_BIKES, b);
+    ST(LV_TRIP_REQUIREMENT, b) += 1;
+    HDR(CH_TRIPS) += 1;
+    const int fw = (a & CD(w_mask)) >> 5;
+    if (bikes < 1) {
+      ST(LV_SHORTAGE, b) += 1;
+      HDR(CH_SHORT) += 1;
+      FUL(fw) &= ~(1u << (a & 31));
     } else {
-      ST(LV_FULFILLMENT, src) += 1;
-      set_bikes(K, e, hd, src, b - 1);
-      FUL(fw) |= 1u << (i & 31);
+      ST(LV_FULFILLMENT, b) += 1;
+      set_bikes(K, e, hd, b, bikes - 1);
+      FUL(fw) |= 1u << (a & 31);
     }
-  }
-  if (n_trips) { HDR(CH_TRIPS) += n_trips; HDR(CH_SHORT) += n_short; }
-  // ---- 3: RebalanceBike :468-492 + decision_strategy.py:229-251 (decided BEFORE the zero-duration returns run)
-  if ((t + 1) % CD(dres) == 0) {
-    for (int w = 0; w < CD(mask_words); w++) {
-      uint32_t sup = 0, dem = 0;
-      for (int j = 0; j < 32 && w * 32 + j < CD(S); j++) {
-        const int s = w * 32 + j;
-        const double ratio = (double)ST(LV_BIKES, s) / (double)K.capacity[s];
-        if (ratio >= K.supply_wm) sup |= 1u << j;
-        else if (ratio <= K.demand_wm) dem |= 1u << j;
+  } else {  // ReturnBike :439-466 (a = trip index, b = the tick it was scheduled at, c = src | dst << 16)
+    if (HDR(CH_POOL_MINLAND) <= t) {
+      if (kind == CB_EV_RET) {
+        // events queued by earlier ticks run by (scheduling tick, ReturnBike before DeliverBike, insertion order)
+        pool_flush_before(K, e, hd, t);
+        if (HDR(CH_POOL_MINLAND) == t) {
+          int p = HDR(CH_POOL_HEAD);
+          pool_exec_until(K, e, hd, t, b, p, HDR(CH_POOL_TAIL));
+        }
+      } else {
+        pool_flush_at(K, e, hd, t);
       }
-      DMK(w) = sup;
-      DMK(CD(mask_words) + w) = dem;
     }
+    if ((uint32_t)FUL((a & CD(w_mask)) >> 5) >> (a & 31) & 1u) land_bikes(K, e, hd, false, c & 0xffff, (int)((uint32_t)c >> 16), 1);
   }
-  for (int r = r_mid; r < r_end; r++) {
-    const int32_t* rr = K.ret_rec + (size_t)r * 4;
-    const int i = rr[0];
-    if ((uint32_t)FUL((i & CD(w_mask)) >> 5) >> (i & 31) & 1u) land_bikes(K, e, hd, false, rr[2], rr[3], 1);
+}
+
+// RebalanceBike :468-492 + decision_strategy.py:229-251: which stations ask for a decision (decided BEFORE the tick's
+// zero-duration returns run)
+MRX_DEV void rebalance_check(const CbParams& K, int e, int32_t* hd, int t) {
+  if (HDR(CH_POOL_MINLAND) <= t) pool_flush_at(K, e, hd, t);
+  for (int w = 0; w < CD(mask_words); w++) {
+    uint32_t sup = 0, dem = 0;
+    for (int j = 0; j < 32 && w * 32 + j < CD(S); j++) {
+      const int s = w * 32 + j;
+      const double ratio = (double)ST(LV_BIKES, s) / (double)CAP(s);
+      if (ratio >= K.supply_wm) sup |= 1u << j;
+      else if (ratio <= K.demand_wm) dem |= 1u << j;
+    }
+    DMK(w) = sup;
+    DMK(CD(mask_words) + w) = dem;
   }
-  HDR(CH_LATE) = 0;
 }
 
 // np_backend.pyx:481-518 — frame `fi` goes to ring slot fi % ring_slots (frames are taken in increasing order)
@@ -275,14 +354,15 @@ MRX_DEV void take_snapshot(const CbParams& K, int e, int32_t* hd, int t) {
   K.ring_fi[(size_t)slot * CD(stride) + e] = fi;
 }
 
-// phases 5-6 of tick t; returns true when the episode is over
-MRX_DEV bool end_tick(const CbParams& K, int e, int32_t* hd, int t) {
+// the end of tick t (flags of its TICK_END record: 1 = a frame ends here, 2 = last tick); returns true when the episode is over
+MRX_DEV bool end_tick(const CbParams& K, int e, int32_t* hd, int t, int ev_flags) {
   if (HDR(CH_LATE) > 0) {  // DeliverBike appended to this very tick (transfer time 0)
     int p = HDR(CH_POOL_HEAD);
     pool_exec_until(K, e, hd, t, CB_NO_LAND, p, HDR(CH_POOL_TAIL));
     pool_compact(K, e, hd);
+    HDR(CH_LATE) = 0;
   }
-  const bool frame_end = (t + 1) % CD(res) == 0;  // post_step :130-147
+  const bool frame_end = (ev_flags & 1) != 0;  // post_step :130-147
   if (frame_end) {
     take_snapshot(K, e, hd, t);
     for (int s = 0; s < CD(S); s++) {
@@ -291,7 +371,7 @@ MRX_DEV bool end_tick(const CbParams& K, int e, int32_t* hd, int t) {
       ST(LV_MIN_BIKES, s) = ST(LV_BIKES, s);
     }
   }
-  if (t + 1 == CD(max_tick)) {
+  if (ev_flags & 2) {
     if (!frame_end) take_snapshot(K, e, hd, t);  // core.py:371-375: the last, partial frame
     return true;
   }
@@ -343,7 +423,7 @@ MRX_DEV int action_scope(const CbParams& K, int e, int32_t* hd, int s, int type,
   for (int i = 0; i < n; i++) {
     const int nb = K.nb[(size_t)s * CD(nb_stride) + i];
     SCR(i) = nb;
-    SCR(S + i) = type == MRX_CB_SUPPLY ? K.capacity[nb] - ST(LV_BIKES, nb) : (int)floor((double)ST(LV_BIKES, nb) * K.scope_high);
+    SCR(S + i) = type == MRX_CB_SUPPLY ? CAP(nb) - ST(LV_BIKES, nb) : (int)floor((double)ST(LV_BIKES, nb) * K.scope_high);
   }
   const int fi_cur = (t - CD(start_tick)) / CD(res);
   for (int f = 0; f < CD(n_filters); f++) {
@@ -379,7 +459,7 @@ MRX_DEV int action_scope(const CbParams& K, int e, int32_t* hd, int s, int type,
   }
   for (int i = 0; i < n; i++) { out[2 * i] = SCR(i); out[2 * i + 1] = SCR(S + i); }
   out[2 * n] = s;
-  out[2 * n + 1] = type == MRX_CB_SUPPLY ? (int)floor((double)ST(LV_BIKES, s) * K.scope_low_keep) : K.capacity[s] - ST(LV_BIKES, s);
+  out[2 * n + 1] = type == MRX_CB_SUPPLY ? (int)floor((double)ST(LV_BIKES, s) * K.scope_low_keep) : CAP(s) - ST(LV_BIKES, s);
   for (int i = n + 1; i < CD(scope_cap); i++) { out[2 * i] = -1; out[2 * i + 1] = -1; }
   return n + 1;
 }
@@ -426,47 +506,76 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
 #ifdef MRX_CB_REGFRAME
 #pragma unroll
   for (int w = 0; w < MRXC_FW; w++) hd[CH_WORDS + w] = K.live[(size_t)w * CD(stride) + e];
+#pragma unroll
+  for (int w = 0; w < MRXC_S; w++) hd[CH_WORDS + MRXC_FW + w] = K.capacity[w];
 #ifdef MRX_CB_REGBITS
 #pragma unroll
-  for (int w = 0; w < MRXC_w_words; w++) hd[CH_WORDS + MRXC_FW + w] = (int32_t)GFUL(w);
+  for (int w = 0; w < MRXC_w_words; w++) hd[CH_WORDS + CB_REG_FRAME_WORDS + w] = (int32_t)GFUL(w);
 #pragma unroll
-  for (int w = 0; w < 2 * MRXC_mask_words; w++) hd[CH_WORDS + MRXC_FW + MRXC_w_words + w] = (int32_t)GDMK(w);
+  for (int w = 0; w < 2 * MRXC_mask_words; w++) hd[CH_WORDS + CB_REG_FRAME_WORDS + MRXC_w_words + w] = (int32_t)GDMK(w);
 #endif
 #endif
   int flags = HDR(CH_FLAGS);
   int t = HDR(CH_TICK);
   bool finished = (flags & CFL_FINISHED) != 0;
   if (!finished) {
-    if (flags & CFL_PENDING) {
+    Prof P;
+    RecWin<8> W;
+    W.open(K.ev_rec, HDR(CH_EV_POS));
+    P.mark(0);
+    // a paused env stands AT the TICK_END record of its decision tick, with that tick's deliveries already done
+    bool resumed = (flags & CFL_PENDING) != 0;
+    if (resumed) {
       apply_actions(K, e, hd, t, HDR(CH_CUR_STATION), actions, n_actions);
       flags &= ~CFL_PENDING;
-    } else if (flags & CFL_FRESH) {
-      flags &= ~CFL_FRESH;
-      begin_tick(K, e, hd, t, load_tick_rec(K, t));
+      P.mark(1);
     }
+    flags &= ~CFL_FRESH;
+    int dec_s = -1, dec_type = 0;
     for (;;) {
-      const TickRec R1 = load_tick_rec(K, t + 1);  // the next tick's offsets, requested before this tick's decisions / end are handled
-      int type;
-      const int s = next_decision(K, e, hd, &type);
-      if (s >= 0) {
-        // core.py:345 takes a snapshot of the current frame here; queries alias it to the live frame instead
-        flags |= CFL_PENDING;
-        HDR(CH_CUR_STATION) = s;
-        HDR(CH_CUR_TYPE) = type;
-        HDR(CH_NDEC) += 1;
-        dec[0] = t; dec[1] = s; dec[2] = type; dec[3] = (t - CD(start_tick)) / CD(res);
-        dec[4] = action_scope(K, e, hd, s, type, t, scope);
-        dec[5] = 1; dec[6] = 0; dec[7] = 0;
-        break;
+      // ---- light records, one per iteration whatever their kind
+      int w0 = W.get(0);
+      while ((w0 & 7) != CB_EV_REBAL && (w0 & 7) != CB_EV_TICK_END) {
+        light_event(K, e, hd, CD(start_tick) + (w0 >> 3), w0 & 7, W.get(1), W.get(2), W.get(3));
+        W.advance(K.ev_rec);
+        w0 = W.get(0);
       }
-      if (end_tick(K, e, hd, t)) {
+      P.mark(2);
+      // ---- (the wave reconverges here) the rare, heavy records
+      t = CD(start_tick) + (w0 >> 3);
+      if ((w0 & 7) == CB_EV_REBAL) {
+        rebalance_check(K, e, hd, t);
+        W.advance(K.ev_rec);
+        P.mark(3);
+        continue;
+      }
+      if (!resumed && HDR(CH_POOL_MINLAND) <= t) pool_flush_at(K, e, hd, t);
+      resumed = false;
+      dec_s = next_decision(K, e, hd, &dec_type);
+      if (dec_s >= 0) break;
+      const bool over = end_tick(K, e, hd, t, W.get(1));
+      P.mark(4);
+      if (over) {
         flags |= CFL_FINISHED;
         finished = true;
         break;
       }
-      t++;
-      begin_tick(K, e, hd, t, R1);
+      W.advance(K.ev_rec);
     }
+    P.mark(5);
+    if (dec_s >= 0) {  // (reconverged again: every lane of the wave that found a decision computes its scope together)
+      // core.py:345 takes a snapshot of the current frame here; queries alias it to the live frame instead
+      flags |= CFL_PENDING;
+      HDR(CH_CUR_STATION) = dec_s;
+      HDR(CH_CUR_TYPE) = dec_type;
+      HDR(CH_NDEC) += 1;
+      dec[0] = t; dec[1] = dec_s; dec[2] = dec_type; dec[3] = (t - CD(start_tick)) / CD(res);
+      dec[4] = action_scope(K, e, hd, dec_s, dec_type, t, scope);
+      dec[5] = 1; dec[6] = 0; dec[7] = 0;
+      P.mark(6);
+    }
+    HDR(CH_EV_POS) = W.pos;
+    P.flush(K, e);
     HDR(CH_TICK) = t;
     HDR(CH_FLAGS) = flags;
 #pragma unroll
@@ -476,9 +585,9 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     for (int w = 0; w < MRXC_FW; w++) K.live[(size_t)w * CD(stride) + e] = hd[CH_WORDS + w];
 #ifdef MRX_CB_REGBITS
 #pragma unroll
-    for (int w = 0; w < MRXC_w_words; w++) GFUL(w) = (uint32_t)hd[CH_WORDS + MRXC_FW + w];
+    for (int w = 0; w < MRXC_w_words; w++) GFUL(w) = (uint32_t)hd[CH_WORDS + CB_REG_FRAME_WORDS + w];
 #pragma unroll
-    for (int w = 0; w < 2 * MRXC_mask_words; w++) GDMK(w) = (uint32_t)hd[CH_WORDS + MRXC_FW + MRXC_w_words + w];
+    for (int w = 0; w < 2 * MRXC_mask_words; w++) GDMK(w) = (uint32_t)hd[CH_WORDS + CB_REG_FRAME_WORDS + MRXC_w_words + w];
 #endif
 #endif
   }

@@ -6,6 +6,7 @@
 // (every env replays the same trip table).  No LDS, no cross-lane traffic, no atomics.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -55,6 +56,7 @@ mrx_k_cb_random_policy(CbParams K, const int32_t* __restrict__ decisions, const 
 struct mrx_cb_engine {
   CbHostPlan plan;
   int device;
+  int lanes = 64;  // envs per wave of the step kernel
   hipModule_t spec_module = nullptr;   // plan-specialised reset / step kernels (mrx_cb_load_step_kernels), else the generic ones
   hipFunction_t spec_reset = nullptr, spec_step = nullptr;
   // kernels of the module may still be queued or running on the caller's stream: drain the device before unloading
@@ -125,7 +127,23 @@ int mrx_cb_create(const mrx_cb_topology* topo, const mrx_cb_config* cfg, void* d
   }
   if (he == hipSuccess) he = hipGetLastError();
   if (he != hipSuccess) { delete e; return set_err(MRX_ERR_HIP, std::string("initial reset kernel: ") + hipGetErrorString(he)); }
+  // envs per wave of the step kernel: enough waves to give every SIMD of the chip a few (256 CUs x 4 SIMDs), see
+  // mrx_cb_set_lanes_per_wave
+  e->lanes = 64;
+  while (e->lanes > 1 && (int64_t)K.n_envs * 64 / e->lanes < 4096) e->lanes /= 2;
+  if (const char* v = getenv("MRX_CB_LANES")) mrx_cb_set_lanes_per_wave(e, atoi(v));
   *out = e;
+  return MRX_OK;
+}
+
+int mrx_cb_set_lanes_per_wave(mrx_cb_handle h, int lanes) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  if (lanes == 0) {
+    lanes = 64;
+    while (lanes > 1 && (int64_t)h->plan.kp.n_envs * 64 / lanes < 4096) lanes /= 2;
+  }
+  if (lanes < 1 || lanes > 64 || (lanes & (lanes - 1))) return set_err(MRX_ERR_INVALID_ARG, "lanes per wave must be 1, 2, 4, ..., 64 (0 = automatic)");
+  h->lanes = lanes;
   return MRX_OK;
 }
 
@@ -167,12 +185,13 @@ int mrx_cb_step(mrx_cb_handle h, const int32_t* d_actions, const int32_t* d_n_ac
   if (h->spec_module) {
     CbParams Kc = K;
     long long* met = (long long*)d_metrics;
-    void* params[] = {&Kc, &d_actions, &d_n_actions, &d_env_mask, &d_decisions, &d_scope, &met, &d_done};
-    HIP_TRY(hipModuleLaunchKernel(h->spec_step, (unsigned)((K.n_envs + 63) / 64), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, params, nullptr));
+    int lanes = h->lanes;
+    void* params[] = {&Kc, &d_actions, &d_n_actions, &d_env_mask, &d_decisions, &d_scope, &met, &d_done, &lanes};
+    HIP_TRY(hipModuleLaunchKernel(h->spec_step, (unsigned)((K.n_envs + h->lanes - 1) / h->lanes), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, params, nullptr));
     return MRX_OK;
   }
-  hipLaunchKernelGGL(mrx_k_cb_step, dim3((K.n_envs + 63) / 64), dim3(64), 0, (hipStream_t)stream, K, d_actions, d_n_actions, d_env_mask,
-                     d_decisions, d_scope, (long long*)d_metrics, d_done);
+  hipLaunchKernelGGL(mrx_k_cb_step, dim3((K.n_envs + h->lanes - 1) / h->lanes), dim3(64), 0, (hipStream_t)stream, K, d_actions, d_n_actions, d_env_mask,
+                     d_decisions, d_scope, (long long*)d_metrics, d_done, h->lanes);
   HIP_TRY(hipGetLastError());
   return MRX_OK;
 }

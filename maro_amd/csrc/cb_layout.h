@@ -147,17 +147,28 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
   auto put = [&](const int32_t* CbParams::*field, const std::vector<int32_t>& v) {
     crel.push_back({(size_t)((const char*)&(k.*field) - (const char*)&k), blob_put(blob, v)});
   };
-  put(&CbParams::trip_off, trip_off); put(&CbParams::trip_tick, ttick); put(&CbParams::trip_src, tsrc); put(&CbParams::trip_dst, tdst);
-  put(&CbParams::ret_off, ret_off); put(&CbParams::ret_mid, ret_mid); put(&CbParams::ret_trip, ret_trip);
+  put(&CbParams::trip_off, trip_off);
   {
-    std::vector<int32_t> tick_rec((size_t)(D + 2) * 4, 0), ret_rec(ret_trip.size() * 4 + 4, 0), trip_rec((size_t)n * 2 + 2, 0);
-    for (int d = 0; d <= D; d++) { tick_rec[(size_t)d * 4] = ret_off[d]; tick_rec[(size_t)d * 4 + 1] = d < D ? ret_mid[d] : ret_off[D]; tick_rec[(size_t)d * 4 + 2] = trip_off[d]; }
-    for (size_t r = 0; r < ret_trip.size(); r++) {
-      const int i = ret_trip[r];
-      ret_rec[r * 4] = i; ret_rec[r * 4 + 1] = ttick[i]; ret_rec[r * 4 + 2] = tsrc[i]; ret_rec[r * 4 + 3] = tdst[i];
+    // The ONE event stream every env replays (cb_device.h::step_env): per tick, in the reference's execution order, the
+    // returns scheduled by earlier ticks, the trips, the rebalance check of a decision tick, the zero-duration returns, and
+    // an end-of-tick record where something happens at the end (frame end, decision tick, last tick).  Ticks with
+    // nothing to do have no record at all.  4 words per record: (tick - start_tick) << 3 | kind, then
+    //   RET / RETZ: trip index, its scheduling tick, src | dst << 16      TRIP: trip index, src      TICK_END: flags
+    // (+16 records = CB_WIN_PAD in cb_device.h: the look-ahead blocks read past the last record)
+    std::vector<int32_t> ev;
+    auto rec = [&](int d, int kind, int a, int b, int c2) { ev.push_back(d << 3 | kind); ev.push_back(a); ev.push_back(b); ev.push_back(c2); };
+    for (int d = 0; d < D; d++) {
+      const int tk = c->start_tick + d;
+      for (int r = ret_off[d]; r < ret_mid[d]; r++) { const int i = ret_trip[r]; rec(d, CB_EV_RET, i, ttick[i], tsrc[i] | tdst[i] << 16); }
+      for (int i = trip_off[d]; i < trip_off[d + 1]; i++) rec(d, CB_EV_TRIP, i, tsrc[i], 0);
+      const bool decision_tick = (tk + 1) % t->resolution == 0, frame_end = (tk + 1) % c->snapshot_resolution == 0, last = d + 1 == D;
+      if (decision_tick) rec(d, CB_EV_REBAL, 0, 0, 0);
+      for (int r = ret_mid[d]; r < ret_off[d + 1]; r++) { const int i = ret_trip[r]; rec(d, CB_EV_RETZ, i, ttick[i], tsrc[i] | tdst[i] << 16); }
+      if (decision_tick || frame_end || last) rec(d, CB_EV_TICK_END, (frame_end ? 1 : 0) | (last ? 2 : 0), 0, 0);
     }
-    for (int i = 0; i < n; i++) { trip_rec[(size_t)i * 2] = tsrc[i]; trip_rec[(size_t)i * 2 + 1] = tdst[i]; }
-    put(&CbParams::tick_rec, tick_rec); put(&CbParams::ret_rec, ret_rec); put(&CbParams::trip_rec, trip_rec);
+    if (ev.size() / 4 > (size_t)0x7fffff00) return bad("event stream too long", MRX_ERR_UNSUPPORTED);
+    ev.resize(ev.size() + 16 * 4, (int32_t)((D << 3) | CB_EV_TICK_END));
+    put(&CbParams::ev_rec, ev);
   }
   {
     // trips_adj[src][dst] counts EVERY RequireBike of the episode so far, fulfilled or not (business_engine.py:412), and is
@@ -199,6 +210,7 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
   env_arr(&CbParams::scratch, 3 * (int64_t)S);
   env_arr(&CbParams::fulfilled, k.w_words);
   env_arr(&CbParams::decmask, 2 * (int64_t)k.mask_words);
+  L.off_prof = env_arr(&CbParams::prof, 16);
   pl->workspace_bytes = align_up(top, 256);
   L.n_envs = k.n_envs; L.env_stride = k.stride; L.n_stations = S; L.frame_words = k.FW; L.ring_slots = k.ring_slots;
   L.scope_cap = k.scope_cap; L.delivery_capacity = k.pool_cap; L.transfer_times_cap = k.tt_cap;

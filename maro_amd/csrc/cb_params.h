@@ -13,10 +13,11 @@ enum { LV_BIKES, LV_SHORTAGE, LV_TRIP_REQUIREMENT, LV_FULFILLMENT, LV_EXTRA_COST
 
 // Per-env header words (hdr[w][env]).
 enum { CH_TICK, CH_FLAGS, CH_CUR_STATION, CH_CUR_TYPE, CH_TT_POS, CH_TRIPS, CH_SHORT, CH_OPER, CH_POOL_HEAD, CH_POOL_TAIL,
-       CH_POOL_MINLAND, CH_LATE, CH_NDEC, CH_STATUS, CH_RES0, CH_RES1, CH_WORDS };
+       CH_POOL_MINLAND, CH_LATE, CH_NDEC, CH_STATUS, CH_EV_POS, CH_RES1, CH_WORDS };  // CH_EV_POS: cursor into ev_rec
 enum { CFL_FRESH = 1, CFL_FINISHED = 2, CFL_PENDING = 4 };
 enum { CB_POOL_WORDS = 5 };  // land tick, scheduling tick, from, to, number (<0: executed)
 #define CB_NO_LAND 0x7fffffff
+enum { CB_EV_RET, CB_EV_TRIP, CB_EV_REBAL, CB_EV_RETZ, CB_EV_TICK_END };  // kinds of CbParams::ev_rec records
 
 struct CbParams {
   // ---- dimensions / options
@@ -35,15 +36,11 @@ struct CbParams {
   int32_t* tt;        // [tt_cap] transfer times
   int32_t* scratch;   // [3 * S] action-scope work arrays
   uint32_t* fulfilled;  // [w_words]  bit ring over trip index: RequireBike got a bike
+  int32_t* prof;        // [16] phase cycle counters (MRX_CB_PROFILE builds only)
   uint32_t* decmask;    // [2 * mask_words] stations with a pending Supply / Demand decision this tick
   // ---- shared tables (trips restricted to [start_tick, max_tick), re-indexed from 0)
-  const int32_t *trip_off, *trip_tick, *trip_src, *trip_dst;  // trip_off [durations + 1]
-  const int32_t *ret_off, *ret_mid, *ret_trip;                // returns landing at each tick, insertion order
-  // the same tables as RECORDS, so that one tick costs two dependent loads instead of four (a lane's step is one long
-  // chain of L2 round trips; every env of a batch reads the same shared tables):
-  const int32_t* tick_rec;  // [durations + 1][4] = (ret_off, ret_mid, trip_off, 0): 8 consecutive words = everything tick d needs
-  const int32_t* ret_rec;   // [n_returns][4]     = (trip index, its scheduling tick, src station, dst station)
-  const int32_t* trip_rec;  // [n_trips][2]       = (src station, dst station)
+  const int32_t* trip_off;  // [durations + 1] CSR offsets of the trips by tick (trips_adj bound of a frame)
+  const int32_t* ev_rec;    // [n_events + 16][4] the event stream every env replays, see cb_layout.h
   const int32_t *adj_off, *adj_idx;  // trips_adj, shared: trip indices grouped by (src, dst); adj_off [S * S + 1]
   const int32_t *capacity, *init_bikes, *station_id, *nb, *nb_cnt;
   const int32_t *tick_day, *cal;  // tick_day [durations] (relative to start_tick) -> cal [n_days][4] weekday, temperature, weather, holiday

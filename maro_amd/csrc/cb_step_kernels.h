@@ -11,8 +11,11 @@ mrx_k_cb_reset(CbParams K, const int32_t* __restrict__ tt, int n_times, const ui
 
 extern "C" __global__ void __launch_bounds__(64)
 mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions, const uint8_t* __restrict__ mask,
-              int32_t* __restrict__ decisions, int32_t* __restrict__ scope, long long* __restrict__ metrics, uint8_t* __restrict__ done) {
-  const int e = blockIdx.x * 64 + threadIdx.x;
+              int32_t* __restrict__ decisions, int32_t* __restrict__ scope, long long* __restrict__ metrics, uint8_t* __restrict__ done, int lanes) {
+  // `lanes` envs per wave (mrx_cb_set_lanes_per_wave): the other lanes of the wave retire at once.  A wave runs the UNION of
+  // its lanes' control flow, and steps differ a lot in length, so a small batch is faster spread thin over many waves
+  if ((int)threadIdx.x >= lanes) return;
+  const int e = blockIdx.x * lanes + threadIdx.x;
   if (e >= K.n_envs || (mask && !mask[e])) return;
   int na = (actions && n_actions) ? n_actions[e] : 0;
   if (na > CD(max_actions)) na = CD(max_actions);
