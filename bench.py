@@ -168,6 +168,8 @@ def bench_citi_bike(args):
         print(f"bench: specialised kernels unavailable ({e}); using the generic ones", file=sys.stderr)
         eng = CitiBikeBatchEngine(topology, n, specialize=False, **kw)
     S = eng.data.n_stations
+    if args.step_budget:
+        eng.set_step_budget(args.step_budget)
     actions = torch.zeros((n, 1, 3), dtype=torch.int32, device=dev)
     n_actions = torch.zeros((n,), dtype=torch.int32, device=dev)
     counter = torch.zeros((1,), dtype=torch.int64, device=dev)
@@ -217,6 +219,26 @@ def bench_citi_bike(args):
         step_i += 1
     torch.cuda.synchronize(dev)
     step_kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    # the same loop with bounded steps (mrx_cb_set_step_budget): a call no longer waits for the batch's longest env-step; envs
+    # without a decision yet are skipped by the policy and continue in the next call.  Reported beside `value`, not as it.
+    bounded = None
+    if args.bounded_budget and not args.step_budget:
+        eng.set_step_budget(args.bounded_budget)
+        for _ in range(args.warmup):
+            one_step(step_i)
+            step_i += 1
+        sync_all()
+        counter.zero_()
+        sync_all()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(step_i)
+            step_i += 1
+        sync_all()
+        dtb = time.perf_counter() - tb
+        bounded = [float(counter.item()), dtb]
+        eng.set_step_budget(0)
+        sync_all()
     # the one exchange step of a sharded rollout: 32 steps of (decision, action, metrics, done) per env gathered to the
     # learner rank over RCCL (maro_amd/cim/rollout.py::gather_to_learner); outside the timed env-step window
     gather_ms = None
@@ -238,13 +260,13 @@ def bench_citi_bike(args):
         gather_ms = (time.perf_counter() - tg) * 1e3
         if rank == 0:
             assert out["decisions"].shape[1] == n * world
-    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(resolved), float(ticks_adv), float(n_done), float(status_bad)], dtype=torch.float64, device=dev)
+    t_max = torch.tensor([dt, bounded[1] if bounded else 0.0], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(resolved), float(ticks_adv), float(n_done), float(status_bad), bounded[0] if bounded else 0.0], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt = float(t_max.item())
-    resolved, ticks_adv, n_done, status_bad = (float(x) for x in tot.tolist())
+    dt, dtb = (float(x) for x in t_max.tolist())
+    resolved, ticks_adv, n_done, status_bad, resolved_b = (float(x) for x in tot.tolist())
     if rank == 0:
         tbar = ticks_adv / max(resolved, 1.0)
         F = S * 48 + 4 * S * S                       # reference-dtype frame bytes (180 B for 3 stations)
@@ -265,6 +287,11 @@ def bench_citi_bike(args):
                          "algorithmic_bytes_per_env_step": b_step, "env_steps_per_launch": n,
                          "note": "latency-bound by construction (SURVEY.md §8d: ~1 KB per env-step); the roofline fraction is judged on the CIM 22p workload"},
         }
+        out["config"]["step_budget"] = args.step_budget
+        if bounded:
+            out["bounded_steps"] = {"budget_records": args.bounded_budget, "value": resolved_b / dtb, "unit": "env-steps/s", "ms_per_call": dtb / args.steps * 1e3,
+                                    "decisions_per_call_per_env": resolved_b / (args.steps * n * world),
+                                    "what": "same loop with mrx_cb_set_step_budget: a call stops after ~budget events per env; envs without a decision yet continue in the next call (trajectories unchanged)"}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline_citi_bike(topology, min(durations, 1440), res, args.cpu_seconds)
         print(json.dumps(out))
@@ -368,6 +395,8 @@ def main():
     ap.add_argument("--step-mode", type=int, default=0, help="launch form of mrx_cim_step (mrx_cim_set_step_mode): 0 default (sorted), "
                     "1 unsorted, 2 sorted, 3 persistent pipelined")
     ap.add_argument("--topology", default="global_trade.22p_l0.8")
+    ap.add_argument("--step-budget", type=int, default=0, help="citi_bike: bounded steps for the main window (mrx_cb_set_step_budget; 0 = every call yields a decision)")
+    ap.add_argument("--bounded-budget", type=int, default=24, help="citi_bike: budget of the extra bounded-steps leg (0: skip it)")
     ap.add_argument("--durations", type=int, default=1120)
     ap.add_argument("--preroll-ticks", type=int, default=300, help="untimed steps before the warmup until the batch's mean tick reaches this "
                     "(the timed window then measures mid-episode steady state, whatever --steps / --warmup are)")

@@ -115,10 +115,21 @@ int mrx_cb_step(mrx_cb_handle h, const int32_t* d_actions, const int32_t* d_n_ac
  * How many envs share one 64-lane wave of the step kernel (no reference counterpart: the reference steps one env per process).
  * One lane owns one env; a wave executes the union of its lanes' control flow and env-steps differ a lot in length (0 to
  * 20+ ticks), so few envs per wave means less divergence but more waves.  lanes = 1, 2, 4, ..., 64; 0 = automatic (the
- * default: the largest power of two that still gives the chip about four waves per SIMD, i.e. 1 at 4096 envs, 64 from 262144
- * envs on; env var MRX_CB_LANES overrides it at creation).  Results do not depend on it.
+ * default: 64, lowered to 32 / 16 while the batch gives fewer than one wave per CU, and — plan-specialised kernels — until the
+ * lanes' LDS columns fit in 64 KB; env var MRX_CB_LANES overrides it at creation).  Results do not depend on it.
  */
 int mrx_cb_set_lanes_per_wave(mrx_cb_handle h, int lanes);
+
+/*
+ * Bounded steps (no reference counterpart).  mrx_cb_step returns when EVERY env of the batch has its next decision, so a call
+ * lasts as long as the batch's longest env-step — and env-steps differ by two orders of magnitude (another station deciding at
+ * the same tick: nothing to simulate; the last decision of a tick: twenty ticks of trips, two snapshots, a rebalance sweep).
+ * With max_records > 0 an env replays at most about that many events per call; if it has not reached a decision by then its
+ * row says so (decisions[e] = {tick, -1, -1, frame_index, 0, valid = 0, ..}, done = 0), the actions passed for it are ignored
+ * and the next call continues where it stopped.  Every env still sees exactly the reference's sequence of decisions, actions
+ * and snapshots; only the grouping into calls changes.  0 = off (the default: every call yields a decision or `done`).
+ */
+int mrx_cb_set_step_budget(mrx_cb_handle h, int max_records);
 
 /*
  * Replaces snapshot_list["stations" | "matrices"][ticks:nodes:attrs] (frame.pyx:754-801, np_backend.pyx:520-549).

@@ -128,6 +128,11 @@ class CitiBikeBatchEngine:
         control-flow divergence, more waves.  Results do not depend on it (include/maro_amd_citi_bike.h)."""
         _lib.check(self._L.mrx_cb_set_lanes_per_wave(self._h, int(lanes)), "mrx_cb_set_lanes_per_wave")
 
+    def set_step_budget(self, max_records: int = 0) -> None:
+        """Bounded steps: an env replays at most ~`max_records` events per `step()` call; envs that have not reached their
+        next decision report `decisions[e, 5] == 0` (and `done[e] == 0`) and continue in the next call.  0 = off."""
+        _lib.check(self._L.mrx_cb_set_step_budget(self._h, int(max_records)), "mrx_cb_set_step_budget")
+
     def step(self, actions=None, n_actions=None, mask=None):
         a = self._dev(actions, torch.int32)
         na = self._dev(n_actions, torch.int32)

@@ -77,122 +77,97 @@ struct Prof {
 #define MRX_DEVM inline /* host harness (tests/emu): MRX_DEV is `static inline`, not valid on members */
 #endif
 
-// Look-ahead window over the shared event stream (4 words per record).  The stream is read strictly in order from a cursor
-// kept in the env header, so it is read in blocks of D records: `cur` is being consumed while `nxt` (requested when `cur`
-// was opened, D records of work ago) is in flight; an L2 round trip is paid at most once per D records.  Static register
-// indices only: the record at `pos` comes out of a select chain over cur[0..D).  (A shifting window does not work: the shift
-// reads the newest register, so the compiler's s_waitcnt makes every pop wait for the load just issued.)  The stream is
-// padded by CB_WIN_PAD records so a block may run past the last record.
-#define CB_WIN_PAD 16
-template <int D>
-struct RecWin {
-  int32_t cur[D][4], nxt[D][4];
-  int pos, base;  // stream index of the next record / of cur[0]; nxt = records base + D ...
-  MRX_DEVM void fetch(int32_t (*blk)[4], int k, const int32_t* tab, int idx) {
-    struct alignas(16) I4 { int32_t a, b, c, d; };
-    const I4 r = *(const I4*)(tab + (size_t)idx * 4);
-    blk[k][0] = r.a; blk[k][1] = r.b; blk[k][2] = r.c; blk[k][3] = r.d;
-  }
-  MRX_DEVM void open(const int32_t* tab, int p) {
-    pos = base = p;
-#pragma unroll
-    for (int k = 0; k < D; k++) fetch(cur, k, tab, p + k);
-#pragma unroll
-    for (int k = 0; k < D; k++) fetch(nxt, k, tab, p + D + k);
-  }
-  MRX_DEVM int32_t get(int w) const {  // word w of the record at pos
-    const int k = pos - base;
-    int32_t r = 0;
-#pragma unroll
-    for (int j = 0; j < D; j++) r = k == j ? cur[j][w] : r;
-    return r;
-  }
-  MRX_DEVM void advance(const int32_t* tab) {
-    pos++;
-    if (pos - base == D) {
-#pragma unroll
-      for (int k = 0; k < D; k++) {
-#pragma unroll
-        for (int w = 0; w < 4; w++) cur[k][w] = nxt[k][w];
-      }
-      base += D;
-#pragma unroll
-      for (int k = 0; k < D; k++) fetch(nxt, k, tab, base + D + k);
-    }
-  }
-};
-
-// Register-resident live frame: a specialised build for at most 8 stations (the toy topologies: a frame of at most 64 words)
-// loads it once per step into the tail of the header array hd[] and keeps it in VGPRs — the store -> load chains through L2
-// that dominate a lane's latency (bikes / shortage / trip counters are read-modify-written several times per tick) disappear.
-// A runtime station index becomes a select chain over the S candidates (LvRef), so every array index stays static.
-#if defined(MRX_SPECIALIZED) && (MRXC_S <= 8)
-#define MRX_CB_REGFRAME 1
-template <int N>
-struct LvRef {
-  int32_t* p;
-  int i;
-  MRX_DEVM operator int32_t() const {
-    int32_t r = 0;
-#pragma unroll
-    for (int j = 0; j < N; j++) r = i == j ? p[j] : r;
-    return r;
-  }
-  MRX_DEVM LvRef& operator=(int32_t v) {
-#pragma unroll
-    for (int j = 0; j < N; j++) p[j] = i == j ? v : p[j];
-    return *this;
-  }
-  MRX_DEVM LvRef& operator=(const LvRef& o) { return *this = (int32_t)o; }
-  MRX_DEVM LvRef& operator+=(int32_t v) {
-#pragma unroll
-    for (int j = 0; j < N; j++) p[j] = i == j ? p[j] + v : p[j];
-    return *this;
-  }
-};
-template <int N>
-struct LuRef {  // the same for the unsigned bit words (fulfilled ring, decision masks)
-  int32_t* p;
-  int i;
-  MRX_DEVM operator uint32_t() const {
-    uint32_t r = 0;
-#pragma unroll
-    for (int j = 0; j < N; j++) r = i == j ? (uint32_t)p[j] : r;
-    return r;
-  }
-  MRX_DEVM LuRef& operator=(uint32_t v) {
-#pragma unroll
-    for (int j = 0; j < N; j++) p[j] = i == j ? (int32_t)v : p[j];
-    return *this;
-  }
-  MRX_DEVM LuRef& operator&=(uint32_t v) { return *this = (uint32_t)*this & v; }
-  MRX_DEVM LuRef& operator|=(uint32_t v) { return *this = (uint32_t)*this | v; }
-};
-#define ST(a, s) (LvRef<MRXC_S>{hd + CH_WORDS + (a) * MRXC_S, (int)(s)})
-#define CAP(s) ((int32_t)LvRef<MRXC_S>{hd + CH_WORDS + MRXC_FW, (int)(s)}) /* the (shared, read-only) capacities too */
-#define CB_REG_FRAME_WORDS (MRXC_FW + MRXC_S)
-// ... and, when they are small too, the per-env bit words: the fulfilled ring and the pending-decision masks
-#if (MRXC_w_words <= 16) && (MRXC_mask_words <= 2)
-#define MRX_CB_REGBITS 1
-#define FUL(i) (LuRef<MRXC_w_words>{hd + CH_WORDS + CB_REG_FRAME_WORDS, (int)(i)})
-#define DMK(i) (LuRef<2 * MRXC_mask_words>{hd + CH_WORDS + CB_REG_FRAME_WORDS + MRXC_w_words, (int)(i)})
-#define CB_HD_WORDS (CH_WORDS + CB_REG_FRAME_WORDS + MRXC_w_words + 2 * MRXC_mask_words)
+// Where an env's working state lives during a step.
+//   generic build:      in HBM (struct-of-arrays, any size), every access an L2 round trip
+//   specialised build:  in LDS, one column per lane — the live frame, the stations' capacities, the fulfilled-trip bit ring,
+//                       the pending-decision masks, the action-scope work arrays and a block of event records: loaded once at
+//                       the start of the step, stored back at its end.  A lane indexes its state with RUNTIME station numbers;
+//                       LDS takes a per-lane address in one instruction (the first specialised engine kept the frame in
+//                       registers behind select chains: S dependent v_cndmask per access, and a wave alone on its SIMD —
+//                       the usual batch gives the chip one wave per CU — pays every dependent instruction in full).
+//                       Layout: the lanes' event blocks first (lane-major), then word w of lane l at
+//                       lds[((32 + w) << K.lsh) + l], K.lsh = log2(envs per wave); the engine
+//                       lowers envs-per-wave until lds_words x 4 B x envs-per-wave fits (mrx_cb_set_lanes_per_wave).
+#if defined(MRX_SPECIALIZED) && (MRXC_lds_words * 4 <= MRX_CB_LDS_BYTES)
+#define MRX_CB_LDSFRAME 1
+#ifdef __HIPCC__
+extern __shared__ int32_t mrx_cb_lds[];
+#define LEV() (mrx_cb_lds + threadIdx.x * (CB_EV_BLOCK * 4)) /* the lane's event block: lane-major, so a record is one 16-byte read */
+#define LF(w) mrx_cb_lds[((CB_EV_BLOCK * 4 + (w)) << K.lsh) + threadIdx.x]
 #else
-#define CB_HD_WORDS (CH_WORDS + CB_REG_FRAME_WORDS)
+static int32_t mrx_cb_lds_host[MRXC_lds_words]; /* host harness: one env at a time */
+#define LEV() mrx_cb_lds_host
+#define LF(w) mrx_cb_lds_host[CB_EV_BLOCK * 4 + (w)]
 #endif
+#define LDS_CAP (MRXC_FW)
+#define LDS_FUL (LDS_CAP + MRXC_S)
+#define LDS_DMK (LDS_FUL + MRXC_w_words)
+#define LDS_SCR (LDS_DMK + 2 * MRXC_mask_words)
+static_assert(LDS_SCR + 3 * MRXC_S + CB_EV_BLOCK * 4 == MRXC_lds_words, "cb_layout.h and cb_device.h disagree on the LDS column");
+#define LIVE(w) LF(w)
+#define ST(a, s) LF((a) * MRXC_S + (s))
+#define CAP(s) LF(LDS_CAP + (s))
+#define FUL(i) (*(uint32_t*)&LF(LDS_FUL + (i)))
+#define DMK(i) (*(uint32_t*)&LF(LDS_DMK + (i)))
+#define SCR(i) LF(LDS_SCR + (i))
 #else
+#define LIVE(w) K.live[(size_t)(w) * CD(stride) + e]
 #define ST(a, s) GST(a, s)
 #define CAP(s) K.capacity[s]
-#define CB_HD_WORDS CH_WORDS
-#endif
-#define GFUL(i) K.fulfilled[(size_t)(i) * CD(stride) + e]
-#define GDMK(i) K.decmask[(size_t)(i) * CD(stride) + e]
-#ifndef MRX_CB_REGBITS
 #define FUL(i) GFUL(i)
 #define DMK(i) GDMK(i)
-#endif
-#define POOL(i, w) K.pool[((size_t)(i) * CB_POOL_WORDS + (w)) * CD(stride) + e]
 #define SCR(i) K.scratch[(size_t)(i) * CD(stride) + e]
+#endif
+
+// The env's place in the shared event stream (4 words per record).  LDS build: records are consumed out of a block of
+// CB_EV_BLOCK records in the lane's LDS column; the NEXT block is requested into registers when a block is opened and only
+// touched CB_EV_BLOCK records later, so an L2 round trip is paid once per step, not per record.  The stream is padded by
+// 2 x CB_EV_BLOCK records so a request may run past the last record.
+struct EvWin {
+  int pos;  // stream index of the next record
+#ifdef MRX_CB_LDSFRAME
+  int base;  // stream index of the first record of the LDS block
+  int32_t nxt[CB_EV_BLOCK][4];
+  MRX_DEVM void request(const CbParams& K, int idx) {
+    struct alignas(16) I4 { int32_t a, b, c, d; };
+#pragma unroll
+    for (int k = 0; k < CB_EV_BLOCK; k++) {
+      const I4 r = *(const I4*)(K.ev_rec + (size_t)(idx + k) * 4);
+      nxt[k][0] = r.a; nxt[k][1] = r.b; nxt[k][2] = r.c; nxt[k][3] = r.d;
+    }
+  }
+  struct alignas(16) Rec { int32_t w0, a, b, c; };
+  MRX_DEVM void land(const CbParams& K) {
+    Rec* blk = (Rec*)LEV();
+#pragma unroll
+    for (int k = 0; k < CB_EV_BLOCK; k++) blk[k] = Rec{nxt[k][0], nxt[k][1], nxt[k][2], nxt[k][3]};
+  }
+  MRX_DEVM void open(const CbParams& K, int p) {
+    pos = base = p;
+    request(K, p);
+    land(K);
+    request(K, p + CB_EV_BLOCK);
+  }
+  MRX_DEVM Rec rec(const CbParams& K) const { return ((const Rec*)LEV())[pos - base]; }
+  MRX_DEVM void advance(const CbParams& K) {
+    pos++;
+    if (pos - base == CB_EV_BLOCK) {
+      land(K);
+      base += CB_EV_BLOCK;
+      request(K, base + CB_EV_BLOCK);
+    }
+  }
+#else
+  struct alignas(16) Rec { int32_t w0, a, b, c; };
+  MRX_DEVM void open(const CbParams&, int p) { pos = p; }
+  MRX_DEVM Rec rec(const CbParams& K) const { return *(const Rec*)(K.ev_rec + (size_t)pos * 4); }
+  MRX_DEVM void advance(const CbParams&) { pos++; }
+#endif
+};
+
+#define GFUL(i) K.fulfilled[(size_t)(i) * CD(stride) + e]
+#define GDMK(i) K.decmask[(size_t)(i) * CD(stride) + e]
+#define POOL(i, w) K.pool[((size_t)(i) * CB_POOL_WORDS + (w)) * CD(stride) + e]
 
 MRX_DEV void set_bikes(const CbParams& K, int e, int32_t* hd, int s, int v) {  // station.py:71-75
   ST(LV_BIKES, s) = v;
@@ -288,37 +263,45 @@ MRX_DEV void pool_flush_at(const CbParams& K, int e, int32_t* hd, int t) {
   }
 }
 
-// One LIGHT record of the event stream (return / trip), at tick t
+// One LIGHT record of the event stream at tick t: RequireBike :398-437 (a = trip index, b = src station) or ReturnBike
+// :439-466 (a = trip index, b = the tick it was scheduled at, c = src | dst << 16).  Both touch one station's dock: everything
+// either may need is READ up front (independent LDS reads, one latency), the common outcomes are computed without branches
+// and only the writes differ — a lane alone on its SIMD pays every dependent LDS round trip in full.
 MRX_DEV void light_event(const CbParams& K, int e, int32_t* hd, int t, int kind, int a, int b, int c) {
-  if (kind == CB_EV_TRIP) {  // RequireBike :398-437 (a = trip index, b = src)
-    if (HDR(CH_POOL_MINLAND) <= t) pool_flush_at(K, e, hd, t);
-    const int bikes = ST(LV_BIKES, b);
-    ST(LV_TRIP_REQUIREMENT, b) += 1;
-    HDR(CH_TRIPS) += 1;
-    const int fw = (a & CD(w_mask)) >> 5;
-    if (bikes < 1) {
-      ST(LV_SHORTAGE, b) += 1;
-      HDR(CH_SHORT) += 1;
-      FUL(fw) &= ~(1u << (a & 31));
-    } else {
-      ST(LV_FULFILLMENT, b) += 1;
-      set_bikes(K, e, hd, b, bikes - 1);
-      FUL(fw) |= 1u << (a & 31);
-    }
-  } else {  // ReturnBike :439-466 (a = trip index, b = the tick it was scheduled at, c = src | dst << 16)
-    if (HDR(CH_POOL_MINLAND) <= t) {
-      if (kind == CB_EV_RET) {
-        // events queued by earlier ticks run by (scheduling tick, ReturnBike before DeliverBike, insertion order)
-        pool_flush_before(K, e, hd, t);
-        if (HDR(CH_POOL_MINLAND) == t) {
-          int p = HDR(CH_POOL_HEAD);
-          pool_exec_until(K, e, hd, t, b, p, HDR(CH_POOL_TAIL));
-        }
-      } else {
-        pool_flush_at(K, e, hd, t);
+  const bool trip = kind == CB_EV_TRIP;
+  if (HDR(CH_POOL_MINLAND) <= t) {  // (rare) this env's DeliverBike events that run first
+    if (kind == CB_EV_RET) {
+      // events queued by earlier ticks run by (scheduling tick, ReturnBike before DeliverBike, insertion order)
+      pool_flush_before(K, e, hd, t);
+      if (HDR(CH_POOL_MINLAND) == t) {
+        int p = HDR(CH_POOL_HEAD);
+        pool_exec_until(K, e, hd, t, b, p, HDR(CH_POOL_TAIL));
       }
+    } else {
+      pool_flush_at(K, e, hd, t);
     }
-    if ((uint32_t)FUL((a & CD(w_mask)) >> 5) >> (a & 31) & 1u) land_bikes(K, e, hd, false, c & 0xffff, (int)((uint32_t)c >> 16), 1);
+  }
+  const int st = trip ? b : (int)((uint32_t)c >> 16);  // the station whose dock changes
+  const int fw = (a & CD(w_mask)) >> 5;
+  const uint32_t bit = 1u << (a & 31);
+  const uint32_t ful = FUL(fw);
+  const int bikes = ST(LV_BIKES, st);
+  const int cap = CAP(st);
+  const int minb = ST(LV_MIN_BIKES, st);
+  if (trip) {
+    const int ok = bikes >= 1 ? 1 : 0;
+    ST(LV_TRIP_REQUIREMENT, st) += 1;
+    ST(LV_SHORTAGE, st) += 1 - ok;
+    ST(LV_FULFILLMENT, st) += ok;
+    HDR(CH_TRIPS) += 1;
+    HDR(CH_SHORT) += 1 - ok;
+    const int nb = bikes - ok;  // station.py:71-75 (min_bikes <= bikes always, so the min is a no-op when nothing left)
+    ST(LV_BIKES, st) = nb;
+    ST(LV_MIN_BIKES, st) = nb < minb ? nb : minb;
+    FUL(fw) = ok ? ful | bit : ful & ~bit;
+  } else if (ful & bit) {  // the trip did get a bike: it comes back now
+    if (bikes < cap) ST(LV_BIKES, st) = bikes + 1;
+    else land_bikes(K, e, hd, false, c & 0xffff, st, 1);  // full dock: failed return, on to the neighbours
   }
 }
 
@@ -343,13 +326,7 @@ MRX_DEV void rebalance_check(const CbParams& K, int e, int32_t* hd, int t) {
 MRX_DEV void take_snapshot(const CbParams& K, int e, int32_t* hd, int t) {
   const int fi = (t - CD(start_tick)) / CD(res), slot = fi % CD(ring_slots);
   int32_t* dst = K.ring + (size_t)slot * (CD(FW) + 1) * CD(stride) + e;
-#ifdef MRX_CB_REGFRAME
-#pragma unroll
-  for (int w = 0; w < MRXC_FW; w++) dst[(size_t)w * CD(stride)] = hd[CH_WORDS + w];
-#else
-  const int32_t* src = K.live + e;
-  for (int w = 0; w < CD(FW); w++) dst[(size_t)w * CD(stride)] = src[(size_t)w * CD(stride)];
-#endif
+  for (int w = 0; w < CD(FW); w++) dst[(size_t)w * CD(stride)] = LIVE(w);
   dst[(size_t)CD(FW) * CD(stride)] = t;
   K.ring_fi[(size_t)slot * CD(stride) + e] = fi;
 }
@@ -392,8 +369,10 @@ MRX_DEV int next_decision(const CbParams& K, int e, int32_t* hd, int* type) {
   return -1;
 }
 
-// Partial selection sort of the scope work arrays (key, val, trips): the best `n_out` of `n` come first.
-// mode 0: (val, key) descending   1: (trips, key) ascending   2: (trips, key) descending
+// The best `n_out` of the `n` rows of the scope work arrays (key, val, trips) come first, best first.
+// mode 0: (val, key) descending   1: (trips, key) ascending   2: (trips, key) descending.  Keys are distinct, so the order is total.
+// (Measured and rejected: ranking all rows in registers, n^2 branch-free compares — 576 for 24 neighbours — is slower than this
+// selection sort over LDS; a wave alone on its SIMD pays ~13 cycles per instruction whatever it is.)
 MRX_DEV void scope_select(const CbParams& K, int e, int n, int n_out, int mode) {
   const int S = CD(S);
   for (int j = 0; j < n_out; j++) {
@@ -417,7 +396,7 @@ MRX_DEV void scope_select(const CbParams& K, int e, int n, int n_out, int mode) 
 // BikeDecisionStrategy.action_scope (decision_strategy.py:253-293) for station s at tick t.  Evaluated at every
 // decision (the reference evaluates it lazily when the agent reads DecisionEvent.action_scope; reading it is
 // what feeds the TripsWindowFilter cache, :131-138).  Writes ordered (station, max) pairs; returns their count.
-MRX_DEV int action_scope(const CbParams& K, int e, int32_t* hd, int s, int type, int t, int32_t* out) {
+MRX_DEV int action_scope(const CbParams& K, int e, int32_t* hd, int s, int type, int t, int32_t* out, Prof& P) {
   const int S = CD(S);
   int n = K.nb_cnt[s];
   for (int i = 0; i < n; i++) {
@@ -425,6 +404,7 @@ MRX_DEV int action_scope(const CbParams& K, int e, int32_t* hd, int s, int type,
     SCR(i) = nb;
     SCR(S + i) = type == MRX_CB_SUPPLY ? CAP(nb) - ST(LV_BIKES, nb) : (int)floor((double)ST(LV_BIKES, nb) * K.scope_high);
   }
+  P.mark(9);
   const int fi_cur = (t - CD(start_tick)) / CD(res);
   for (int f = 0; f < CD(n_filters); f++) {
     const int n_out = CDA(f_num, f) < n ? CDA(f_num, f) : n;
@@ -433,6 +413,7 @@ MRX_DEV int action_scope(const CbParams& K, int e, int32_t* hd, int s, int type,
     } else if (CDA(f_type, f) == MRX_CB_FILTER_REQUIREMENTS) {
       scope_select(K, e, n, n_out, 0);
       n = n_out;
+      P.mark(10);
     } else {
       // TripsWindowFilter :88-163: sum trip_requirement over the latest frames, the current (pre-decision
       // snapshot, aliased to the live frame) included; a frame's value is frozen the first time it is seen,
@@ -441,20 +422,57 @@ MRX_DEV int action_scope(const CbParams& K, int e, int32_t* hd, int s, int type,
       const int avail = fi_cur + 1 < CD(ring_slots) ? fi_cur + 1 : CD(ring_slots);
       const int aw = CDA(f_win, f) < avail ? CDA(f_win, f) : avail;
       const int first = aw > 0 ? fi_cur - aw + 1 : fi_cur - avail + 1;
-      for (int i = 0; i < n; i++) SCR(2 * S + i) = 0;
-      for (int fi = first; fi <= fi_cur; fi++) {
-        const int slot = fi % CD(ring_slots);
-        int32_t& cfi = K.twc_fi[(size_t)slot * CD(stride) + e];
-        int32_t* cache = K.twc + (size_t)slot * S * CD(stride) + e;
-        if (fi == fi_cur && (aw > 0 || cfi != fi)) {
-          for (int x = 0; x < S; x++) cache[(size_t)x * CD(stride)] = ST(LV_TRIP_REQUIREMENT, x);
-          cfi = fi;
+      // trip_requirement counts EVERY RequireBike since the last frame reset, fulfilled or not: like trips_adj it is a
+      // function of (shared trip table, tick).  So the filter's per-frame cache is one word — the tick the frame was last
+      // read at — and a value is two reads of the shared running counts req_cum[tick][station]; a frame never seen as the
+      // current one is read at the tick its snapshot was taken.
+      if (aw > 0 && aw <= CB_TWC_REG) {
+        // the usual case (a window of a few frames): first where each frame's two rows of req_cum are (per-env words, all
+        // requested at once), then per candidate ONE batch of independent reads — as a plain frame-by-candidate loop every
+        // read was a dependent L2 round trip, a hundred of them per decision
+        int hi_o[CB_TWC_REG], lo_o[CB_TWC_REG];
+#pragma unroll
+        for (int k = 0; k < CB_TWC_REG; k++) {
+          hi_o[k] = lo_o[k] = 0;  // (frames beyond the window read row 0 twice: + 0)
+          if (k < aw) {
+            const int fi = fi_cur - k, slot = fi % CD(ring_slots);
+            int32_t& cfi = K.twc_fi[(size_t)slot * CD(stride) + e];
+            int32_t& ctick = K.twc_tick[(size_t)slot * CD(stride) + e];
+            if (k == 0) { ctick = t; cfi = fi; }
+            const int tb = cfi == fi ? ctick : K.ring[((size_t)slot * (CD(FW) + 1) + CD(FW)) * CD(stride) + e];
+            int w0 = tb / CD(res) * CD(res);
+            if (w0 < CD(start_tick)) w0 = CD(start_tick);
+            hi_o[k] = (tb + 1 - CD(start_tick)) * S;
+            lo_o[k] = (w0 - CD(start_tick)) * S;
+          }
         }
-        const int32_t* src = cfi == fi ? cache : K.ring + ((size_t)slot * (CD(FW) + 1) + (size_t)LV_TRIP_REQUIREMENT * S) * CD(stride) + e;
-        for (int i = 0; i < n; i++) SCR(2 * S + i) += src[(size_t)SCR(i) * CD(stride)];
+        P.mark(11);
+        for (int i = 0; i < n; i++) {
+          const int x = SCR(i);
+          int sum = 0;
+#pragma unroll
+          for (int k = 0; k < CB_TWC_REG; k++) sum += K.req_cum[hi_o[k] + x] - K.req_cum[lo_o[k] + x];
+          SCR(2 * S + i) = sum;
+        }
+      } else {
+        for (int i = 0; i < n; i++) SCR(2 * S + i) = 0;
+        for (int fi = first; fi <= fi_cur; fi++) {
+          const int slot = fi % CD(ring_slots);
+          int32_t& cfi = K.twc_fi[(size_t)slot * CD(stride) + e];
+          int32_t& ctick = K.twc_tick[(size_t)slot * CD(stride) + e];
+          if (fi == fi_cur && (aw > 0 || cfi != fi)) { ctick = t; cfi = fi; }
+          const int tb = cfi == fi ? ctick : K.ring[((size_t)slot * (CD(FW) + 1) + CD(FW)) * CD(stride) + e];
+          int w0 = tb / CD(res) * CD(res);  // the frame reset before tick tb happened at the end of tick w0 - 1 (post_step :130-147)
+          if (w0 < CD(start_tick)) w0 = CD(start_tick);
+          const int32_t* hi = K.req_cum + (size_t)(tb + 1 - CD(start_tick)) * S;
+          const int32_t* lo = K.req_cum + (size_t)(w0 - CD(start_tick)) * S;
+          for (int i = 0; i < n; i++) { const int x = SCR(i); SCR(2 * S + i) += hi[x] - lo[x]; }
+        }
       }
+      P.mark(12);
       scope_select(K, e, n, n_out, type == MRX_CB_DEMAND ? 2 : 1);
       n = n_out;
+      P.mark(13);
     }
   }
   for (int i = 0; i < n; i++) { out[2 * i] = SCR(i); out[2 * i + 1] = SCR(S + i); }
@@ -500,28 +518,22 @@ MRX_DEV void apply_actions(const CbParams& K, int e, int32_t* hd, int t, int s, 
 // Env.step for one env.  dec[8], scope[scope_cap][2], met[3]
 MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_actions, int32_t* dec, int32_t* scope, int64_t* met,
                       uint8_t* done) {
-  int32_t hd[CB_HD_WORDS];  // the env's header (and, MRX_CB_REGFRAME, its live frame) lives in registers for the whole step
+  int32_t hd[CH_WORDS];  // the env's header lives in registers for the whole step
 #pragma unroll
   for (int w = 0; w < CH_WORDS; w++) hd[w] = GHDR(w);
-#ifdef MRX_CB_REGFRAME
-#pragma unroll
-  for (int w = 0; w < MRXC_FW; w++) hd[CH_WORDS + w] = K.live[(size_t)w * CD(stride) + e];
-#pragma unroll
-  for (int w = 0; w < MRXC_S; w++) hd[CH_WORDS + MRXC_FW + w] = K.capacity[w];
-#ifdef MRX_CB_REGBITS
-#pragma unroll
-  for (int w = 0; w < MRXC_w_words; w++) hd[CH_WORDS + CB_REG_FRAME_WORDS + w] = (int32_t)GFUL(w);
-#pragma unroll
-  for (int w = 0; w < 2 * MRXC_mask_words; w++) hd[CH_WORDS + CB_REG_FRAME_WORDS + MRXC_w_words + w] = (int32_t)GDMK(w);
-#endif
-#endif
   int flags = HDR(CH_FLAGS);
   int t = HDR(CH_TICK);
   bool finished = (flags & CFL_FINISHED) != 0;
   if (!finished) {
     Prof P;
-    RecWin<8> W;
-    W.open(K.ev_rec, HDR(CH_EV_POS));
+    EvWin W;
+    W.open(K, HDR(CH_EV_POS));
+#if defined(MRX_CB_LDSFRAME) && !defined(__HIPCC__) /* (the HIP kernel moves the state with all 64 lanes: cb_step_kernels.h) */
+    for (int w = 0; w < MRXC_FW; w++) LF(w) = K.live[(size_t)w * CD(stride) + e];
+    for (int w = 0; w < MRXC_S; w++) LF(LDS_CAP + w) = K.capacity[w];
+    for (int w = 0; w < MRXC_w_words; w++) LF(LDS_FUL + w) = (int32_t)GFUL(w);
+    for (int w = 0; w < 2 * MRXC_mask_words; w++) LF(LDS_DMK + w) = (int32_t)GDMK(w);
+#endif
     P.mark(0);
     // a paused env stands AT the TICK_END record of its decision tick, with that tick's deliveries already done
     bool resumed = (flags & CFL_PENDING) != 0;
@@ -532,20 +544,27 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     }
     flags &= ~CFL_FRESH;
     int dec_s = -1, dec_type = 0;
+    // mrx_cb_set_step_budget: at most this many records per call; an env that has not reached its next decision by then
+    // reports "no decision yet" and goes on from the same place in the next call (any record boundary is a consistent state)
+    int left = K.step_budget > 0 ? K.step_budget : 0x7fffffff;
     for (;;) {
       // ---- light records, one per iteration whatever their kind
-      int w0 = W.get(0);
-      while ((w0 & 7) != CB_EV_REBAL && (w0 & 7) != CB_EV_TICK_END) {
-        light_event(K, e, hd, CD(start_tick) + (w0 >> 3), w0 & 7, W.get(1), W.get(2), W.get(3));
-        W.advance(K.ev_rec);
-        w0 = W.get(0);
+      EvWin::Rec r = W.rec(K);
+      while ((r.w0 & 7) != CB_EV_REBAL && (r.w0 & 7) != CB_EV_TICK_END && left > 0) {
+        light_event(K, e, hd, CD(start_tick) + (r.w0 >> 3), r.w0 & 7, r.a, r.b, r.c);
+        W.advance(K);
+        r = W.rec(K);
+        left--;
       }
+      const int w0 = r.w0;
       P.mark(2);
       // ---- (the wave reconverges here) the rare, heavy records
       t = CD(start_tick) + (w0 >> 3);
+      if ((w0 & 7) != CB_EV_REBAL && (w0 & 7) != CB_EV_TICK_END) break;  // budget spent between two light records
+      left -= 4;
       if ((w0 & 7) == CB_EV_REBAL) {
         rebalance_check(K, e, hd, t);
-        W.advance(K.ev_rec);
+        W.advance(K);
         P.mark(3);
         continue;
       }
@@ -553,14 +572,14 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
       resumed = false;
       dec_s = next_decision(K, e, hd, &dec_type);
       if (dec_s >= 0) break;
-      const bool over = end_tick(K, e, hd, t, W.get(1));
+      const bool over = end_tick(K, e, hd, t, r.a);
       P.mark(4);
       if (over) {
         flags |= CFL_FINISHED;
         finished = true;
         break;
       }
-      W.advance(K.ev_rec);
+      W.advance(K);
     }
     P.mark(5);
     if (dec_s >= 0) {  // (reconverged again: every lane of the wave that found a decision computes its scope together)
@@ -570,7 +589,7 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
       HDR(CH_CUR_TYPE) = dec_type;
       HDR(CH_NDEC) += 1;
       dec[0] = t; dec[1] = dec_s; dec[2] = dec_type; dec[3] = (t - CD(start_tick)) / CD(res);
-      dec[4] = action_scope(K, e, hd, dec_s, dec_type, t, scope);
+      dec[4] = action_scope(K, e, hd, dec_s, dec_type, t, scope, P);
       dec[5] = 1; dec[6] = 0; dec[7] = 0;
       P.mark(6);
     }
@@ -580,18 +599,13 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     HDR(CH_FLAGS) = flags;
 #pragma unroll
     for (int w = 0; w < CH_WORDS; w++) GHDR(w) = hd[w];
-#ifdef MRX_CB_REGFRAME
-#pragma unroll
-    for (int w = 0; w < MRXC_FW; w++) K.live[(size_t)w * CD(stride) + e] = hd[CH_WORDS + w];
-#ifdef MRX_CB_REGBITS
-#pragma unroll
-    for (int w = 0; w < MRXC_w_words; w++) GFUL(w) = (uint32_t)hd[CH_WORDS + CB_REG_FRAME_WORDS + w];
-#pragma unroll
-    for (int w = 0; w < 2 * MRXC_mask_words; w++) GDMK(w) = (uint32_t)hd[CH_WORDS + CB_REG_FRAME_WORDS + MRXC_w_words + w];
-#endif
+#if defined(MRX_CB_LDSFRAME) && !defined(__HIPCC__)
+    for (int w = 0; w < MRXC_FW; w++) K.live[(size_t)w * CD(stride) + e] = LF(w);
+    for (int w = 0; w < MRXC_w_words; w++) GFUL(w) = (uint32_t)LF(LDS_FUL + w);
+    for (int w = 0; w < 2 * MRXC_mask_words; w++) GDMK(w) = (uint32_t)LF(LDS_DMK + w);
 #endif
   }
-  if (finished) {
+  if (finished || !(flags & CFL_PENDING)) {  // episode over, or (step budget) no decision reached yet
     dec[0] = t; dec[1] = -1; dec[2] = -1; dec[3] = (t - CD(start_tick)) / CD(res); dec[4] = 0; dec[5] = 0; dec[6] = 0; dec[7] = 0;
     for (int i = 0; i < CD(scope_cap); i++) { scope[2 * i] = -1; scope[2 * i + 1] = -1; }
   }
@@ -607,7 +621,7 @@ MRX_DEV void reset_env(const CbParams& K, int e) {
   GHDR(CH_POOL_MINLAND) = CB_NO_LAND;
   for (int w = 0; w < CD(FW); w++) K.live[(size_t)w * CD(stride) + e] = 0;
   for (int s = 0; s < CD(S); s++) { GST(LV_BIKES, s) = K.init_bikes[s]; GST(LV_MIN_BIKES, s) = K.init_bikes[s]; }
-  for (int i = 0; i < CD(ring_slots); i++) { K.ring_fi[(size_t)i * CD(stride) + e] = -1; K.twc_fi[(size_t)i * CD(stride) + e] = -1; }
+  for (int i = 0; i < CD(ring_slots); i++) { K.ring_fi[(size_t)i * CD(stride) + e] = -1; K.twc_fi[(size_t)i * CD(stride) + e] = -1; K.twc_tick[(size_t)i * CD(stride) + e] = 0; }
   for (int w = 0; w < 2 * CD(mask_words); w++) GDMK(w) = 0;
   for (int w = 0; w < CD(w_words); w++) GFUL(w) = 0;
 }
@@ -629,7 +643,7 @@ MRX_DEV double query_elem(const CbParams& K, int node_type, const int32_t* ticks
   // while an env is paused at a decision its current frame is the live frame (core.py:345), which also evicts
   // whatever the slot held
   const int flags = GHDR(CH_FLAGS);
-  const bool paused = (flags & (CFL_FRESH | CFL_FINISHED)) == 0;
+  const bool paused = (flags & CFL_PENDING) != 0;
   const int t_cur = GHDR(CH_TICK);
   const int cur_fi = (t_cur - CD(start_tick)) / CD(res);
   const int32_t* frame;

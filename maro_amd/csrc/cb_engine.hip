@@ -57,6 +57,7 @@ struct mrx_cb_engine {
   CbHostPlan plan;
   int device;
   int lanes = 64;  // envs per wave of the step kernel
+  int step_budget = 0;  // mrx_cb_set_step_budget
   hipModule_t spec_module = nullptr;   // plan-specialised reset / step kernels (mrx_cb_load_step_kernels), else the generic ones
   hipFunction_t spec_reset = nullptr, spec_step = nullptr;
   // kernels of the module may still be queued or running on the caller's stream: drain the device before unloading
@@ -98,6 +99,15 @@ int64_t mrx_cb_workspace_bytes(const mrx_cb_topology* topo, const mrx_cb_config*
   return pl.workspace_bytes;
 }
 
+// envs per wave of the step kernel when the caller does not say: a wave runs the union of its lanes' control flow, so a
+// small batch is spread over at least one wave per CU (256); below 16 envs per wave the extra waves stop paying
+// (profiles/r02_citi_bike.md: 4096 envs 60 -> 66 M env-steps/s at 16 lanes, 32768 envs best at 64)
+static int auto_lanes(int n_envs) {
+  int lanes = 64;
+  while (lanes > 16 && n_envs / lanes < 256) lanes /= 2;
+  return lanes;
+}
+
 int mrx_cb_create(const mrx_cb_topology* topo, const mrx_cb_config* cfg, void* d_workspace, int64_t workspace_bytes, mrx_cb_handle* out) {
   if (!out) return set_err(MRX_ERR_INVALID_ARG, "out handle is null");
   *out = nullptr;
@@ -127,10 +137,7 @@ int mrx_cb_create(const mrx_cb_topology* topo, const mrx_cb_config* cfg, void* d
   }
   if (he == hipSuccess) he = hipGetLastError();
   if (he != hipSuccess) { delete e; return set_err(MRX_ERR_HIP, std::string("initial reset kernel: ") + hipGetErrorString(he)); }
-  // envs per wave of the step kernel: enough waves to give every SIMD of the chip a few (256 CUs x 4 SIMDs), see
-  // mrx_cb_set_lanes_per_wave
-  e->lanes = 64;
-  while (e->lanes > 1 && (int64_t)K.n_envs * 64 / e->lanes < 4096) e->lanes /= 2;
+  e->lanes = auto_lanes(K.n_envs);
   if (const char* v = getenv("MRX_CB_LANES")) mrx_cb_set_lanes_per_wave(e, atoi(v));
   *out = e;
   return MRX_OK;
@@ -138,12 +145,15 @@ int mrx_cb_create(const mrx_cb_topology* topo, const mrx_cb_config* cfg, void* d
 
 int mrx_cb_set_lanes_per_wave(mrx_cb_handle h, int lanes) {
   if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
-  if (lanes == 0) {
-    lanes = 64;
-    while (lanes > 1 && (int64_t)h->plan.kp.n_envs * 64 / lanes < 4096) lanes /= 2;
-  }
+  if (lanes == 0) lanes = auto_lanes(h->plan.kp.n_envs);
   if (lanes < 1 || lanes > 64 || (lanes & (lanes - 1))) return set_err(MRX_ERR_INVALID_ARG, "lanes per wave must be 1, 2, 4, ..., 64 (0 = automatic)");
   h->lanes = lanes;
+  return MRX_OK;
+}
+
+int mrx_cb_set_step_budget(mrx_cb_handle h, int max_records) {
+  if (!h || max_records < 0) return set_err(MRX_ERR_INVALID_ARG, "null handle or negative budget");
+  h->step_budget = max_records;
   return MRX_OK;
 }
 
@@ -182,15 +192,24 @@ int mrx_cb_step(mrx_cb_handle h, const int32_t* d_actions, const int32_t* d_n_ac
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
   const CbParams& K = h->plan.kp;
+  CbParams Kc = K;
+  Kc.step_budget = h->step_budget;
   if (h->spec_module) {
-    CbParams Kc = K;
     long long* met = (long long*)d_metrics;
+    // the specialised kernel keeps each env's working state in an LDS column of lds_words words (when one column fits at
+    // all): as many envs per wave as asked for and as fit
     int lanes = h->lanes;
+    const bool lds_frame = (int64_t)K.lds_words * 4 <= MRX_CB_LDS_BYTES;
+    while (lds_frame && lanes > 1 && (int64_t)K.lds_words * 4 * lanes > MRX_CB_LDS_BYTES) lanes /= 2;
+    int lsh = 0;
+    while ((1 << lsh) < lanes) lsh++;
+    Kc.lsh = lsh;
+    const unsigned lds_bytes = lds_frame ? (unsigned)(K.lds_words * 4 * lanes) : 0u;
     void* params[] = {&Kc, &d_actions, &d_n_actions, &d_env_mask, &d_decisions, &d_scope, &met, &d_done, &lanes};
-    HIP_TRY(hipModuleLaunchKernel(h->spec_step, (unsigned)((K.n_envs + h->lanes - 1) / h->lanes), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, params, nullptr));
+    HIP_TRY(hipModuleLaunchKernel(h->spec_step, (unsigned)((K.n_envs + lanes - 1) / lanes), 1, 1, 64, 1, 1, lds_bytes, (hipStream_t)stream, params, nullptr));
     return MRX_OK;
   }
-  hipLaunchKernelGGL(mrx_k_cb_step, dim3((K.n_envs + h->lanes - 1) / h->lanes), dim3(64), 0, (hipStream_t)stream, K, d_actions, d_n_actions, d_env_mask,
+  hipLaunchKernelGGL(mrx_k_cb_step, dim3((K.n_envs + h->lanes - 1) / h->lanes), dim3(64), 0, (hipStream_t)stream, Kc, d_actions, d_n_actions, d_env_mask,
                      d_decisions, d_scope, (long long*)d_metrics, d_done, h->lanes);
   HIP_TRY(hipGetLastError());
   return MRX_OK;

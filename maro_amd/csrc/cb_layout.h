@@ -132,6 +132,7 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
     while (w < span) w *= 2;
     k.w_mask = w - 1; k.w_words = w / 32;
   }
+  k.lds_words = k.FW + S + k.w_words + 2 * k.mask_words + 3 * S + CB_EV_BLOCK * 4;  // cb_device.h: LDS_CAP .. LDS_EV
   std::vector<int32_t> tick_day(D), cal((size_t)std::max(t->n_days, 1) * 4, 0);
   for (int d = 0; d < D; d++) {
     tick_day[d] = t->tick_day[c->start_tick + d];
@@ -154,7 +155,7 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
     // an end-of-tick record where something happens at the end (frame end, decision tick, last tick).  Ticks with
     // nothing to do have no record at all.  4 words per record: (tick - start_tick) << 3 | kind, then
     //   RET / RETZ: trip index, its scheduling tick, src | dst << 16      TRIP: trip index, src      TICK_END: flags
-    // (+16 records = CB_WIN_PAD in cb_device.h: the look-ahead blocks read past the last record)
+    // (+2 blocks of padding: the look-ahead of cb_device.h::EvWin reads past the last record)
     std::vector<int32_t> ev;
     auto rec = [&](int d, int kind, int a, int b, int c2) { ev.push_back(d << 3 | kind); ev.push_back(a); ev.push_back(b); ev.push_back(c2); };
     for (int d = 0; d < D; d++) {
@@ -167,7 +168,7 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
       if (decision_tick || frame_end || last) rec(d, CB_EV_TICK_END, (frame_end ? 1 : 0) | (last ? 2 : 0), 0, 0);
     }
     if (ev.size() / 4 > (size_t)0x7fffff00) return bad("event stream too long", MRX_ERR_UNSUPPORTED);
-    ev.resize(ev.size() + 16 * 4, (int32_t)((D << 3) | CB_EV_TICK_END));
+    ev.resize(ev.size() + 2 * CB_EV_BLOCK * 4, (int32_t)((D << 3) | CB_EV_TICK_END));
     put(&CbParams::ev_rec, ev);
   }
   {
@@ -180,6 +181,17 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
     std::vector<int32_t> fill(adj_off.begin(), adj_off.end() - 1);
     for (int i = 0; i < n; i++) adj_idx[fill[(size_t)tsrc[i] * S + tdst[i]]++] = i;
     put(&CbParams::adj_off, adj_off); put(&CbParams::adj_idx, adj_idx);
+  }
+  {
+    bool has_window = false;
+    for (int f = 0; f < t->n_filters; f++) has_window |= t->filter_type[f] == MRX_CB_FILTER_TRIP_WINDOW;
+    std::vector<int32_t> req_cum(has_window ? (size_t)(D + 1) * S : 1, 0);
+    if (has_window)
+      for (int d = 0; d < D; d++) {
+        memcpy(&req_cum[(size_t)(d + 1) * S], &req_cum[(size_t)d * S], sizeof(int32_t) * S);
+        for (int i = trip_off[d]; i < trip_off[d + 1]; i++) req_cum[(size_t)(d + 1) * S + tsrc[i]]++;
+      }
+    put(&CbParams::req_cum, req_cum);
   }
   put(&CbParams::capacity, std::vector<int32_t>(t->capacity, t->capacity + S));
   put(&CbParams::init_bikes, std::vector<int32_t>(t->init_bikes, t->init_bikes + S));
@@ -203,8 +215,8 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
   L.off_live = env_arr(&CbParams::live, k.FW);
   L.off_ring = env_arr(&CbParams::ring, (int64_t)k.ring_slots * (k.FW + 1));
   L.off_ring_fi = env_arr(&CbParams::ring_fi, k.ring_slots);
-  env_arr(&CbParams::twc, (int64_t)k.ring_slots * S);
   env_arr(&CbParams::twc_fi, k.ring_slots);
+  env_arr(&CbParams::twc_tick, k.ring_slots);
   env_arr(&CbParams::pool, (int64_t)k.pool_cap * CB_POOL_WORDS);
   L.off_transfer_times = env_arr(&CbParams::tt, k.tt_cap);
   env_arr(&CbParams::scratch, 3 * (int64_t)S);

@@ -17,6 +17,9 @@ enum { CH_TICK, CH_FLAGS, CH_CUR_STATION, CH_CUR_TYPE, CH_TT_POS, CH_TRIPS, CH_S
 enum { CFL_FRESH = 1, CFL_FINISHED = 2, CFL_PENDING = 4 };
 enum { CB_POOL_WORDS = 5 };  // land tick, scheduling tick, from, to, number (<0: executed)
 #define CB_NO_LAND 0x7fffffff
+#define CB_TWC_REG 12            /* trip-window frames whose table rows are kept in registers (cb_device.h::action_scope) */
+#define CB_EV_BLOCK 8            /* event records per look-ahead block (cb_device.h::EvWin) */
+#define MRX_CB_LDS_BYTES 65536   /* LDS one workgroup (= one wave) of the step kernel may take */
 enum { CB_EV_RET, CB_EV_TRIP, CB_EV_REBAL, CB_EV_RETZ, CB_EV_TICK_END };  // kinds of CbParams::ev_rec records
 
 struct CbParams {
@@ -24,14 +27,17 @@ struct CbParams {
   int32_t n_envs, stride, S, start_tick, max_tick, res, ring_slots, max_actions;
   int32_t dres, extra_cost_mode, n_filters, f_type[4], f_num[4], f_win[4];
   int32_t FW, w_mask, w_words, pool_cap, tt_cap, scope_cap, mask_words, nb_stride;
+  int32_t lds_words;  // a lane's LDS column in the specialised step kernel: frame, capacities, bit words, scope scratch, event block
+  int32_t lsh;        // per launch: log2(envs per wave)
+  int32_t step_budget;  // per launch: records an env may replay in one step call before it reports "no decision yet" (0: no limit)
   double supply_wm, demand_wm, scope_low_keep, scope_high;
   // ---- per-env struct-of-arrays state: X[word][stride]
   int32_t* hdr;       // [CH_WORDS]
   int32_t* live;      // [FW]  LV_* x S (attr-major)
   int32_t* ring;      // [ring_slots][FW + 1]  (+1: tick the snapshot was taken at)
   int32_t* ring_fi;   // [ring_slots]
-  int32_t* twc;       // [ring_slots][S]   TripsWindowFilter cache of trip_requirement
-  int32_t* twc_fi;    // [ring_slots]
+  int32_t* twc_fi;    // [ring_slots] TripsWindowFilter cache: the frame a slot was read for ...
+  int32_t* twc_tick;  // [ring_slots] ... and the tick it was last read at (the values come from req_cum)
   int32_t* pool;      // [pool_cap][CB_POOL_WORDS]  in-flight DeliverBike events, insertion order
   int32_t* tt;        // [tt_cap] transfer times
   int32_t* scratch;   // [3 * S] action-scope work arrays
@@ -41,6 +47,7 @@ struct CbParams {
   // ---- shared tables (trips restricted to [start_tick, max_tick), re-indexed from 0)
   const int32_t* trip_off;  // [durations + 1] CSR offsets of the trips by tick (trips_adj bound of a frame)
   const int32_t* ev_rec;    // [n_events + 16][4] the event stream every env replays, see cb_layout.h
+  const int32_t* req_cum;   // [durations + 1][S] trips with src = s before relative tick d (running trip_requirement)
   const int32_t *adj_off, *adj_idx;  // trips_adj, shared: trip indices grouped by (src, dst); adj_off [S * S + 1]
   const int32_t *capacity, *init_bikes, *station_id, *nb, *nb_cnt;
   const int32_t *tick_day, *cal;  // tick_day [durations] (relative to start_tick) -> cal [n_days][4] weekday, temperature, weather, holiday
@@ -66,5 +73,6 @@ struct CbParams {
   X(tt_cap) \
   X(scope_cap) \
   X(mask_words) \
-  X(nb_stride)
+  X(nb_stride) \
+  X(lds_words)
 #define MRX_CB_DIM_ARRAYS(X) X(f_type) X(f_num) X(f_win)

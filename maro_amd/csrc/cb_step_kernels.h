@@ -12,14 +12,42 @@ mrx_k_cb_reset(CbParams K, const int32_t* __restrict__ tt, int n_times, const ui
 extern "C" __global__ void __launch_bounds__(64)
 mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions, const uint8_t* __restrict__ mask,
               int32_t* __restrict__ decisions, int32_t* __restrict__ scope, long long* __restrict__ metrics, uint8_t* __restrict__ done, int lanes) {
-  // `lanes` envs per wave (mrx_cb_set_lanes_per_wave): the other lanes of the wave retire at once.  A wave runs the UNION of
-  // its lanes' control flow, and steps differ a lot in length, so a small batch is faster spread thin over many waves
-  if ((int)threadIdx.x >= lanes) return;
-  const int e = blockIdx.x * lanes + threadIdx.x;
-  if (e >= K.n_envs || (mask && !mask[e])) return;
-  int na = (actions && n_actions) ? n_actions[e] : 0;
-  if (na > CD(max_actions)) na = CD(max_actions);
-  cb::step_env(K, e, actions ? actions + (size_t)e * CD(max_actions) * 3 : nullptr, na, decisions + (size_t)e * 8,
-               scope + (size_t)e * CD(scope_cap) * 2, (int64_t*)metrics + (size_t)e * 3, done + e);
+  // `lanes` envs per wave (mrx_cb_set_lanes_per_wave): lane l < lanes owns env blockIdx.x * lanes + l.  A wave runs the UNION
+  // of its lanes' control flow, and steps differ a lot in length, so a small batch is faster spread thin over many waves.
+  const int lane = (int)threadIdx.x;
+  const int e0 = blockIdx.x * lanes;
+  const int e = e0 + lane;
+  const bool active = lane < lanes && e < K.n_envs && !(mask && !mask[e]);
+#ifdef MRX_CB_LDSFRAME
+  // All 64 lanes move the wave's envs' state between HBM and the LDS columns (row w of the `lanes` envs = `lanes` consecutive
+  // words): with a few envs per wave the owning lanes alone would issue one narrow load per word of the frame.
+  const int cl = lane & (lanes - 1), r0 = lane >> K.lsh, rstep = 64 >> K.lsh;
+  const bool cok = e0 + cl < K.n_envs;
+  const size_t cbase = (size_t)e0 + cl;
+#define MRX_CB_LFX(w) cb::mrx_cb_lds[((CB_EV_BLOCK * 4 + (w)) << K.lsh) + cl]
+  if (cok) {
+#pragma unroll 4
+    for (int w = r0; w < MRXC_FW; w += rstep) MRX_CB_LFX(w) = K.live[(size_t)w * CD(stride) + cbase];
+    for (int w = r0; w < MRXC_S; w += rstep) MRX_CB_LFX(LDS_CAP + w) = K.capacity[w];
+    for (int w = r0; w < MRXC_w_words; w += rstep) MRX_CB_LFX(LDS_FUL + w) = (int32_t)K.fulfilled[(size_t)w * CD(stride) + cbase];
+    for (int w = r0; w < 2 * MRXC_mask_words; w += rstep) MRX_CB_LFX(LDS_DMK + w) = (int32_t)K.decmask[(size_t)w * CD(stride) + cbase];
+  }
+  __syncthreads();
+#endif
+  if (active) {
+    int na = (actions && n_actions) ? n_actions[e] : 0;
+    if (na > CD(max_actions)) na = CD(max_actions);
+    cb::step_env(K, e, actions ? actions + (size_t)e * CD(max_actions) * 3 : nullptr, na, decisions + (size_t)e * 8,
+                 scope + (size_t)e * CD(scope_cap) * 2, (int64_t*)metrics + (size_t)e * 3, done + e);
+  }
+#ifdef MRX_CB_LDSFRAME
+  __syncthreads();
+  if (cok) {
+#pragma unroll 4
+    for (int w = r0; w < MRXC_FW; w += rstep) K.live[(size_t)w * CD(stride) + cbase] = MRX_CB_LFX(w);
+    for (int w = r0; w < MRXC_w_words; w += rstep) K.fulfilled[(size_t)w * CD(stride) + cbase] = (uint32_t)MRX_CB_LFX(LDS_FUL + w);
+    for (int w = r0; w < 2 * MRXC_mask_words; w += rstep) K.decmask[(size_t)w * CD(stride) + cbase] = (uint32_t)MRX_CB_LFX(LDS_DMK + w);
+  }
+#undef MRX_CB_LFX
+#endif
 }
-

@@ -67,3 +67,59 @@ def run_batch_vs_oracle(backend, data, kwargs, seeds, episodes=1, check_envs=Non
             assert np.array_equal(got, o.query("matrices", fis, [], ["trips_adj"])), e
         assert (backend.hdr()[13, :n] == 0).all(), backend.hdr()[13, :n]
     return step
+
+
+def run_bounded_vs_oracle(backend, data, kwargs, seeds, budget, check_envs=None, max_calls=200000):
+    """Bounded steps (mrx_cb_set_step_budget): a step call may leave an env without a decision (valid = 0); every env must
+    still go through exactly the oracle's sequence of decisions / metrics, and end with the same snapshots.  The policy acts
+    per env on that env's own decision counter, so the grouping into calls cannot leak into the trajectories."""
+    n = backend.n_envs
+    tts = draw_transfer_times(data, seeds, backend.layout.transfer_times_cap)
+    check_envs = list(range(n)) if check_envs is None else check_envs
+    backend.reset(transfer_times=tts)
+    backend.set_step_budget(budget)
+    oracles = {e: CitiBikeOracle(data, transfer_times=tts[e], **kwargs) for e in check_envs}
+    o_out = {e: o.step(None) for e, o in oracles.items()}
+    n_dec = np.zeros(n, np.int64)
+    a = np.zeros((n, backend.max_actions, 3), np.int32)
+    na = np.zeros(n, np.int32)
+    unready = calls = 0
+    dec, scope, met, done = backend.step()
+    while True:
+        calls += 1
+        assert calls < max_calls
+        a[:], na[:] = 0, 0
+        for e in range(n):
+            if done[e]:
+                continue
+            if not dec[e, 5]:
+                unready += 1
+                assert dec[e, 1] == -1 and dec[e, 4] == 0
+                continue
+            n_dec[e] += 1
+            de = dict(tick=int(dec[e, 0]), station_idx=int(dec[e, 1]), type=int(dec[e, 2]), frame_index=int(dec[e, 3]),
+                      action_scope=[tuple(x) for x in scope[e, : dec[e, 4]].tolist()])
+            act = policy_action(int(n_dec[e]), e, de)
+            if act:
+                a[e, 0], na[e] = act, 1
+            if e in oracles:
+                m, ode, od = o_out[e]
+                assert not od, (e, calls)
+                assert met[e].tolist() == [m["trip_requirements"], m["bike_shortage"], m["operation_number"]], (e, calls)
+                assert (de["tick"], de["station_idx"], de["type"], de["frame_index"]) == (ode["tick"], ode["station_idx"], ode["type"], ode["frame_index"]), (e, calls, de, ode)
+                assert de["action_scope"] == [tuple(x) for x in ode["action_scope"]], (e, calls)
+                o_out[e] = oracles[e].step([act] if act else None)
+        if done.all():
+            break
+        dec, scope, met, done = backend.step(a, na)
+    for e in check_envs:
+        o = oracles[e]
+        m, _, od = o_out[e]
+        assert od and met[e].tolist() == [m["trip_requirements"], m["bike_shortage"], m["operation_number"]], e
+        fis = o.frame_indices()
+        S = data.n_stations
+        got = backend.query(NODE_TYPE["stations"], fis, list(range(S)), list(range(len(STATION_ATTRS))), len(STATION_ATTRS))[e].reshape(-1)
+        assert np.array_equal(got, o.query("stations", fis, [], STATION_ATTRS)), e
+    assert (backend.hdr()[13, :n] == 0).all()
+    backend.set_step_budget(0)
+    return calls, unready

@@ -21,6 +21,9 @@ class CbGpuBackend:
         tt = None if transfer_times is None else np.ascontiguousarray(transfer_times, np.int32).reshape(self.n_envs, -1)
         self.eng.reset(transfer_times=tt, mask=mask)
 
+    def set_step_budget(self, max_records):
+        self.eng.set_step_budget(max_records)
+
     def step(self, actions=None, n_actions=None, mask=None):
         out = self.eng.step(actions, n_actions, mask)
         torch.cuda.synchronize()

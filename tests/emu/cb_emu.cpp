@@ -49,6 +49,8 @@ void cb_emu_reset(void* h, const int32_t* tt, int n_times, const uint8_t* mask) 
   }
 }
 
+void cb_emu_set_step_budget(void* h, int max_records) { ((CbEmu*)h)->plan.kp.step_budget = max_records; }
+
 void cb_emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const uint8_t* mask, int32_t* dec, int32_t* scope,
                  int64_t* met, uint8_t* done) {
   CbEmu* e = (CbEmu*)h;

@@ -140,6 +140,9 @@ class CbEmuBackend:
         mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         self._L.cb_emu_reset(self._h, _ptr(tt), 0 if tt is None else tt.shape[1], _ptr(mk))
 
+    def set_step_budget(self, max_records):
+        self._L.cb_emu_set_step_budget(ctypes.c_void_p(self._h), int(max_records))
+
     def step(self, actions=None, n_actions=None, mask=None):
         a = None if actions is None else np.ascontiguousarray(actions, np.int32).reshape(self.n_envs, self.max_actions, 3)
         na = None if n_actions is None else np.ascontiguousarray(n_actions, np.int32)

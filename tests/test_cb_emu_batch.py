@@ -29,3 +29,18 @@ def test_masked_envs_do_not_move():
     b.step(mask=mask)
     t1 = b.hdr()[0]
     assert (t1[[1, 3]] == t0[[1, 3]]).all()
+
+
+@pytest.mark.parametrize("budget,specialized", [(1, False), (7, True), (40, False)])
+def test_bounded_steps_do_not_change_trajectories(budget, specialized):
+    """mrx_cb_set_step_budget: envs that run out of budget report "no decision yet" and continue in the next call."""
+    import functools
+
+    from tests.cb_batch_check import run_bounded_vs_oracle
+    from tests.emu.cb_emu import CbEmuBackend
+    data = load_topology("toy.5s_6t")
+    kw = dict(durations=700, snapshot_resolution=5)
+    B = functools.partial(CbEmuBackend, specialized=True) if specialized else CbEmuBackend
+    b = B(data, n_envs=6, max_actions=1, **kw)
+    calls, unready = run_bounded_vs_oracle(b, data, kw, seeds=np.arange(6) + 3, budget=budget)
+    assert unready > 0 and calls > 50

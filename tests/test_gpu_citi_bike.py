@@ -51,6 +51,19 @@ def test_packaged_city_topology_day():
     run_batch_vs_oracle(b, data, kw, seeds=np.arange(200) + 5, episodes=1, check_envs=[0, 77, 199])
 
 
+@pytest.mark.parametrize("budget,lanes", [(5, 64), (24, 16), (3, 1)])
+def test_bounded_steps_and_lanes_per_wave_do_not_change_trajectories(budget, lanes):
+    """mrx_cb_set_step_budget / mrx_cb_set_lanes_per_wave only regroup the work: every env still follows the oracle."""
+    from tests.cb_batch_check import run_bounded_vs_oracle
+    from tests.cb_gpu_backend import CbGpuBackend
+    data = load_topology("toy.5s_6t")
+    kw = dict(durations=700, snapshot_resolution=5)
+    b = CbGpuBackend(data, n_envs=150, max_actions=1, **kw)
+    b.eng.set_lanes_per_wave(lanes)
+    calls, unready = run_bounded_vs_oracle(b, data, kw, seeds=np.arange(150) + 3, budget=budget, check_envs=[0, 1, 63, 64, 149])
+    assert unready > 0
+
+
 def test_full_size_batch_properties():
     """BASELINE config 4 size on one GPU (4096 envs, a month-long... one day here): conservation laws that hold for any
     trajectory: trips = fulfilled + shortage; bikes are conserved up to in-flight / lost ones; identical seeds and

@@ -158,3 +158,19 @@ def test_specialized_citi_bike_equals_generic_batch():
             assert torch.equal(x, y), i
     for name in ("hdr", "live", "ring", "ring_fi"):   # the engines' state views (the raw workspace also holds scratch areas)
         assert torch.equal(getattr(engs[0], name), getattr(engs[1], name)), name
+
+
+@pytest.mark.parametrize("budget,lanes", [(6, 0), (30, 4)])
+def test_specialized_citi_bike_bounded_steps(budget, lanes, monkeypatch):
+    """The LDS-frame step kernel under mrx_cb_set_step_budget / mrx_cb_set_lanes_per_wave: trajectories stay the oracle's."""
+    from maro_amd.citi_bike.data import load_topology
+    from tests.cb_batch_check import run_bounded_vs_oracle
+    from tests.cb_gpu_backend import CbGpuBackend
+    monkeypatch.setenv("MARO_AMD_SPECIALIZE", "1")
+    data = load_topology("toy.5s_6t")
+    kw = dict(durations=700, snapshot_resolution=5)
+    b = CbGpuBackend(data, n_envs=150, max_actions=1, **kw)
+    assert b.eng.specialized
+    b.eng.set_lanes_per_wave(lanes)
+    calls, unready = run_bounded_vs_oracle(b, data, kw, seeds=np.arange(150) + 3, budget=budget, check_envs=[0, 63, 64, 149])
+    assert unready > 0

@@ -10,7 +10,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 PHASES = ["header + frame load, stream window open", "apply action", "light records (returns, trips) incl. waiting for the wave's longest run",
           "rebalance check (station sweep)", "end of tick (late deliveries, snapshot, frame reset)", "waiting for the wave at the loop exit",
-          "decision output + action_scope", "-", "tail"]
+          "decision output + end of action_scope (scope rows out)", "-", "-", "scope: neighbour list", "scope: requirements select", "scope: trip-window frame rows",
+          "scope: trip-window sums", "scope: trip-window select"]
 
 
 def main():
