@@ -64,6 +64,8 @@ typedef struct mrx_cb_config {
                                  S * (ceil(longest transfer time / decision resolution) + 2): overflow is flagged
                                  (MRX_CB_ENV_DELIVERY_OVERFLOW) and the delivery dropped */
   int32_t transfer_times_cap; /* transfer times per env; <=0 -> S*(durations/resolution+1) */
+  int32_t decision_mode;      /* DecisionMode, maro/simulator/abs_core.py:14-22: 0 Sequential (mrx_cb_step), 1 Joint,
+                                 2 JointWithSequentialAction (mrx_cb_step_joint) */
 } mrx_cb_config;
 
 /* Layout of the per-env arrays inside the workspace.  Every per-env array is struct-of-arrays
@@ -110,6 +112,21 @@ int mrx_cb_reset(mrx_cb_handle h, const int32_t* d_transfer_times, int32_t n_tim
  */
 int mrx_cb_step(mrx_cb_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const uint8_t* d_env_mask,
                 int32_t* d_decisions, int32_t* d_scope, int64_t* d_metrics, uint8_t* d_done, void* stream);
+
+/*
+ * Replaces Env.step(actions) in the Joint decision modes (core.py:354-366; mrx_cb_config.decision_mode 1 / 2): every pending
+ * decision event of the tick — one per station the rebalance check flagged, in station order — is reported at once.
+ *   d_decisions  int32 [n_envs][S][8]: row i = the i-th pending event (layout as mrx_cb_step, plus [6] = number of events
+ *                reported, [7] = i); rows beyond the events have valid = 0
+ *   d_scope      int32 [n_envs][S][scope_cap][2]: row i = that event's action_scope, evaluated on the state at report time
+ *                (the reference caches a payload's scope at its first read; an object layer on top re-serves it)
+ *   d_actions    int32 [n_envs][S][A][3], d_n_actions int32 [n_envs][S]: the action list of the i-th reported event
+ *   d_n_answered int32 [n_envs]: how many of the reported events the agent answered (the reference zips actions with events:
+ *                the first len(actions)); the others are finished without effect (Joint) or stay pending and are reported
+ *                again by this call (JointWithSequentialAction).  NULL = 0 answered.
+ */
+int mrx_cb_step_joint(mrx_cb_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const int32_t* d_n_answered,
+                      const uint8_t* d_env_mask, int32_t* d_decisions, int32_t* d_scope, int64_t* d_metrics, uint8_t* d_done, void* stream);
 
 /*
  * How many envs share one 64-lane wave of the step kernel (no reference counterpart: the reference steps one env per process).

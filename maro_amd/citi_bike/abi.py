@@ -33,7 +33,7 @@ class MrxCbTopology(ctypes.Structure):
 
 class MrxCbConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("n_envs", "device", "start_tick", "durations", "snapshot_resolution",
-                                              "max_snapshots", "max_actions", "delivery_capacity", "transfer_times_cap")]
+                                              "max_snapshots", "max_actions", "delivery_capacity", "transfer_times_cap", "decision_mode")]
 
 
 class MrxCbLayout(ctypes.Structure):

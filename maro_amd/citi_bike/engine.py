@@ -23,12 +23,14 @@ from .data import CitiBikeData, load_topology
 
 
 class CitiBikeBatchEngine:
-    """N independent citi_bike environments (Sequential decision mode) resident on one MI355X."""
+    """N independent citi_bike environments resident on one MI355X (`decision_mode` 0 Sequential: `step`; 1 Joint /
+    2 JointWithSequentialAction: `step_joint`, decisions [n, S, 8], scope [n, S, scope_cap, 2])."""
 
     def __init__(self, topology: Union[str, CitiBikeData], n_envs: int, start_tick: int = 0, durations: int = 1440,
                  snapshot_resolution: int = 1, max_snapshots: Optional[int] = None, max_actions: int = 1,
                  device: Union[str, torch.device] = "cuda:0", seeds: Optional[Sequence[int]] = None,
-                 delivery_capacity: int = 0, transfer_times_cap: int = 0, specialize: Union[bool, str, None] = None):
+                 delivery_capacity: int = 0, transfer_times_cap: int = 0, specialize: Union[bool, str, None] = None,
+                 decision_mode: int = 0):
         """specialize: as CimBatchEngine — True = reset / step kernels compiled for this exact plan (maro_amd/cim/specialize.py,
         a few seconds of hipcc the first time, cached in-tree), "cached" = only if already cached, False = generic kernels,
         None = $MARO_AMD_SPECIALIZE."""
@@ -50,7 +52,9 @@ class CitiBikeBatchEngine:
             delivery_capacity = d.n_stations * (int((d.time_mean + 6 * d.time_std) / max(d.resolution, 1)) + 2) + 4
         self._ts, self._keep_topo = topology_struct(self.data)
         self._cfg = MrxCbConfig(self.n_envs, dev_index, self.start_tick, self.durations, self.snapshot_resolution,
-                                int(max_snapshots or 0), self.max_actions, int(delivery_capacity), int(transfer_times_cap))
+                                int(max_snapshots or 0), self.max_actions, int(delivery_capacity), int(transfer_times_cap),
+                                int(decision_mode))
+        self.decision_mode = int(decision_mode)
         nbytes = self._L.mrx_cb_workspace_bytes(ctypes.byref(self._ts), ctypes.byref(self._cfg))
         _lib.check(nbytes, "mrx_cb_workspace_bytes")
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -78,8 +82,9 @@ class CitiBikeBatchEngine:
         self.ring = self._view(lay.off_ring, (lay.ring_slots, lay.frame_words + 1, st))[:, :, :self.n_envs]
         self.ring_fi = self._view(lay.off_ring_fi, (lay.ring_slots, st))[:, :self.n_envs]
         self.ticks, self.status = self.hdr[HDR_TICK], self.hdr[HDR_STATUS]
-        self.decisions = torch.zeros((self.n_envs, 8), dtype=torch.int32, device=self.device)
-        self.scope = torch.full((self.n_envs, lay.scope_cap, 2), -1, dtype=torch.int32, device=self.device)
+        rows = (self.data.n_stations,) if self.decision_mode else ()
+        self.decisions = torch.zeros((self.n_envs,) + rows + (8,), dtype=torch.int32, device=self.device)
+        self.scope = torch.full((self.n_envs,) + rows + (lay.scope_cap, 2), -1, dtype=torch.int32, device=self.device)
         self.metrics = torch.zeros((self.n_envs, 3), dtype=torch.int64, device=self.device)
         self.done = torch.zeros((self.n_envs,), dtype=torch.uint8, device=self.device)
         if seeds is not None:
@@ -144,6 +149,22 @@ class CitiBikeBatchEngine:
         _lib.check(self._L.mrx_cb_step(self._h, self._p(a), self._p(na), self._p(mk), self.decisions.data_ptr(), self.scope.data_ptr(),
                                        self.metrics.data_ptr(), self.done.data_ptr(), self._stream()), "mrx_cb_step")
         self._keep = (a, na, mk)
+        return self.decisions, self.scope, self.metrics, self.done
+
+    def step_joint(self, actions=None, n_actions=None, n_answered=None, mask=None):
+        """Joint decision modes: `actions` int32 [n, S, A, 3] (row i = the action list of the i-th reported event),
+        `n_actions` int32 [n, S], `n_answered` int32 [n] (include/maro_amd_citi_bike.h::mrx_cb_step_joint)."""
+        a = self._dev(actions, torch.int32)
+        na = self._dev(n_actions, torch.int32)
+        nans = self._dev(n_answered, torch.int32)
+        mk = self._dev(mask, torch.uint8)
+        S = self.data.n_stations
+        if a is not None:
+            assert a.numel() == self.n_envs * S * self.max_actions * 3, "actions must be [n_envs, S, max_actions, 3]"
+            assert na is not None and na.numel() == self.n_envs * S and nans is not None and nans.numel() == self.n_envs
+        _lib.check(self._L.mrx_cb_step_joint(self._h, self._p(a), self._p(na), self._p(nans), self._p(mk), self.decisions.data_ptr(),
+                                             self.scope.data_ptr(), self.metrics.data_ptr(), self.done.data_ptr(), self._stream()), "mrx_cb_step_joint")
+        self._keep_step = (a, na, nans, mk)
         return self.decisions, self.scope, self.metrics, self.done
 
     def random_policy(self, step: int, actions: torch.Tensor, n_actions: torch.Tensor, counter: Optional[torch.Tensor] = None) -> None:

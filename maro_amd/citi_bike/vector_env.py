@@ -6,7 +6,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-from ..cim.vector_env import GpuVectorEnv
+from ..cim.vector_env import GpuVectorEnv, _as_list
 from .abi import NODE_ATTRS
 from .engine import CitiBikeBatchEngine
 from .payloads import encode_action, make_decision_event
@@ -26,13 +26,15 @@ class CitiBikeVectorEnv(GpuVectorEnv):
                  options: Optional[dict] = None, seeds: Optional[Sequence[int]] = None, device="cuda:0", max_actions: int = 4,
                  specialize=None, _engine=None):
         assert scenario == "citi_bike"
-        if int(getattr(decision_mode, "value", decision_mode)) != 0:
-            raise NotImplementedError("only DecisionMode.Sequential is implemented on the GPU engine")
+        mode = int(getattr(decision_mode, "value", decision_mode))
+        if mode not in (0, 1, 2):
+            raise ValueError("decision_mode must be Sequential (0), Joint (1) or JointWithSequentialAction (2)")
         if seeds is None:
             seeds = np.arange(batch_num)
         self.engine = _engine if _engine is not None else CitiBikeBatchEngine(
             topology, batch_num, start_tick=start_tick, durations=durations, snapshot_resolution=snapshot_resolution,
-            max_snapshots=max_snapshots, max_actions=max_actions, device=device, seeds=seeds, specialize=specialize)
+            max_snapshots=max_snapshots, max_actions=max_actions, device=device, seeds=seeds, specialize=specialize, decision_mode=mode)
+        self._mode = int(getattr(self.engine, "decision_mode", mode))
         self._init_state(batch_num)
 
     def reset(self, keep_seed: bool = False, envs: Optional[Sequence[int]] = None):
@@ -42,10 +44,69 @@ class CitiBikeVectorEnv(GpuVectorEnv):
         for e in envs:
             mask[e] = 1
             self._started[e] = self._paused[e] = self._finished[e] = False
+            self._joint_events.pop(e, None)
+            self._last_met[e] = 0
+            self._n_pending[e] = 0
+            self._last_dec[e] = None
         self.engine.reset(mask=mask)
 
     def set_seed(self, seed: int, envs: Optional[Sequence[int]] = None):
         pass
+
+    # ---- Joint / JointWithSequentialAction (core.py:354-366): mrx_cb_step_joint takes one action list per reported event
+    def _step_envs(self, envs: Sequence[int], per_env: Dict[int, object]):
+        if self._mode == 0:
+            return super()._step_envs(envs, per_env)
+        eng = self.engine
+        A, S = eng.max_actions, eng.data.n_stations
+        acts = np.full((self._n, S, A, 3), -1, np.int32)
+        nact = np.zeros((self._n, S), np.int32)
+        nans = np.zeros(self._n, np.int32)
+        mask = np.zeros(self._n, np.uint8)
+        out = {}
+        for e in envs:
+            if self._finished[e]:
+                out[e] = (None, None, True)          # core.py:128-133
+                continue
+            mask[e] = 1
+            per_event = per_env.get(e)
+            per_event = [] if per_event is None else list(per_event) if isinstance(per_event, (list, tuple)) else [per_event]
+            per_event = per_event[:int(self._n_pending[e])]   # zip(actions, pending_events)
+            nans[e] = len(per_event)
+            for i, entry in enumerate(per_event):
+                alist = _as_list(entry)
+                if len(alist) > A:
+                    raise ValueError(f"{len(alist)} actions for one decision event; engine was built with max_actions={A}")
+                for j, a in enumerate(alist):
+                    acts[e, i, j] = self._encode_action(a)
+                nact[e, i] = len(alist)
+        if mask.any():
+            dec, scope, met, done = (x.cpu().numpy() for x in eng.step_joint(acts, nact, nans, mask))
+            for e in envs:
+                if not mask[e]:
+                    continue
+                self._started[e] = True
+                self._last_dec[e], self._last_met[e] = dec[e, 0], met[e]
+                metrics = {k: int(met[e, i]) for i, k in enumerate(self.METRIC_KEYS)}
+                if done[e]:
+                    self._paused[e], self._finished[e] = False, True
+                    self._joint_events.pop(e, None)
+                    out[e] = (metrics, None, True)
+                    continue
+                self._paused[e] = True
+                # an event that stayed pending (JointWithSequentialAction) is re-yielded as the SAME object, its action scope
+                # cached at the first read (citi_bike/common.py:96-104), like the reference does
+                cache = self._joint_events.get(e, {})
+                events, keep = [], {}
+                for k in range(int(dec[e, 0, 6])):
+                    key = (int(dec[e, k, 0]), int(dec[e, k, 1]))
+                    ev = cache.get(key) or make_decision_event(dec[e, k], scope[e, k])
+                    keep[key] = ev
+                    events.append(ev)
+                self._joint_events[e] = keep
+                self._n_pending[e] = len(events)
+                out[e] = (metrics, events, False)
+        return [out[e] for e in envs]
 
     # ---- scenario hooks
     def _encode_action(self, a) -> tuple:

@@ -515,9 +515,11 @@ MRX_DEV void apply_actions(const CbParams& K, int e, int32_t* hd, int t, int s, 
   }
 }
 
-// Env.step for one env.  dec[8], scope[scope_cap][2], met[3]
-MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_actions, int32_t* dec, int32_t* scope, int64_t* met,
-                      uint8_t* done) {
+// Env.step for one env.  Sequential mode: dec[8], scope[scope_cap][2], actions[A][3], n_actions = their count (n_act_ev unused).
+// Joint modes: dec[S][8], scope[S][scope_cap][2], actions[S][A][3], n_act_ev[S] = the action count of each reported event,
+// n_actions = how many of the reported events were answered.  met[3].
+MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_actions, const int32_t* n_act_ev, int32_t* dec, int32_t* scope,
+                      int64_t* met, uint8_t* done) {
   int32_t hd[CH_WORDS];  // the env's header lives in registers for the whole step
 #pragma unroll
   for (int w = 0; w < CH_WORDS; w++) hd[w] = GHDR(w);
@@ -538,7 +540,23 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     // a paused env stands AT the TICK_END record of its decision tick, with that tick's deliveries already done
     bool resumed = (flags & CFL_PENDING) != 0;
     if (resumed) {
-      apply_actions(K, e, hd, t, HDR(CH_CUR_STATION), actions, n_actions);
+      if (CD(decision_mode) == 0) {
+        apply_actions(K, e, hd, t, HDR(CH_CUR_STATION), actions, n_actions);
+      } else {
+        // core.py:354-366: the agent's i-th action list goes to the i-th reported event; each answered decision event runs, is
+        // popped, and its action event runs right behind it, in event (= station) order.  apply_actions' "was it the last
+        // element of the tick's list" test sees the unanswered events still in the list, as in the reference.
+        for (int i = 0; i < n_actions; i++) {
+          int ty;
+          const int s = next_decision(K, e, hd, &ty);
+          if (s < 0) break;
+          int na = n_act_ev ? n_act_ev[i] : 0;
+          if (na > CD(max_actions)) na = CD(max_actions);
+          apply_actions(K, e, hd, t, s, actions + (size_t)i * CD(max_actions) * 3, na < 0 ? 0 : na);
+        }
+        if (CD(decision_mode) == 1)  // Joint: the unanswered events are finished without effect
+          for (int w = 0; w < 2 * CD(mask_words); w++) DMK(w) = 0;
+      }
       flags &= ~CFL_PENDING;
       P.mark(1);
     }
@@ -588,9 +606,29 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
       HDR(CH_CUR_STATION) = dec_s;
       HDR(CH_CUR_TYPE) = dec_type;
       HDR(CH_NDEC) += 1;
-      dec[0] = t; dec[1] = dec_s; dec[2] = dec_type; dec[3] = (t - CD(start_tick)) / CD(res);
-      dec[4] = action_scope(K, e, hd, dec_s, dec_type, t, scope, P);
-      dec[5] = 1; dec[6] = 0; dec[7] = 0;
+      if (CD(decision_mode) == 0) {
+        dec[0] = t; dec[1] = dec_s; dec[2] = dec_type; dec[3] = (t - CD(start_tick)) / CD(res);
+        dec[4] = action_scope(K, e, hd, dec_s, dec_type, t, scope, P);
+        dec[5] = 1; dec[6] = 0; dec[7] = 0;
+      } else {
+        // every pending event of the tick, in station order (the order _on_rebalance_bikes inserted them)
+        int k = 0;
+        for (int w = 0; w < CD(mask_words); w++) {
+          const uint32_t sup = DMK(w), any = sup | DMK(CD(mask_words) + w);
+          for (int j = 0; j < 32; j++) {
+            if (!(any >> j & 1u)) continue;
+            const int s = w * 32 + j, ty = (sup >> j & 1u) ? MRX_CB_SUPPLY : MRX_CB_DEMAND;
+            int32_t* d = dec + (size_t)k * 8;
+            d[0] = t; d[1] = s; d[2] = ty; d[3] = (t - CD(start_tick)) / CD(res);
+            d[4] = action_scope(K, e, hd, s, ty, t, scope + (size_t)k * CD(scope_cap) * 2, P);
+            d[5] = 1; d[7] = k;
+            k++;
+          }
+        }
+        for (int i = 0; i < k; i++) dec[(size_t)i * 8 + 6] = k;
+        if (k < CD(S)) dec[(size_t)k * 8 + 5] = 0;
+        HDR(CH_NDEC) += k - 1;
+      }
       P.mark(6);
     }
     HDR(CH_EV_POS) = W.pos;

@@ -186,9 +186,9 @@ int mrx_cb_reset(mrx_cb_handle h, const int32_t* d_transfer_times, int32_t n_tim
   return MRX_OK;
 }
 
-int mrx_cb_step(mrx_cb_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const uint8_t* d_env_mask, int32_t* d_decisions,
-                int32_t* d_scope, int64_t* d_metrics, uint8_t* d_done, void* stream) {
-  if (!h || !d_decisions || !d_scope || !d_metrics || !d_done) return set_err(MRX_ERR_INVALID_ARG, "null handle/output pointer");
+static int cb_launch_step(mrx_cb_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const int32_t* d_n_answered, const uint8_t* d_env_mask,
+                          int32_t* d_decisions, int32_t* d_scope, int64_t* d_metrics, uint8_t* d_done, void* stream) {
+  if (!d_decisions || !d_scope || !d_metrics || !d_done) return set_err(MRX_ERR_INVALID_ARG, "null output pointer");
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
   const CbParams& K = h->plan.kp;
@@ -205,14 +205,28 @@ int mrx_cb_step(mrx_cb_handle h, const int32_t* d_actions, const int32_t* d_n_ac
     while ((1 << lsh) < lanes) lsh++;
     Kc.lsh = lsh;
     const unsigned lds_bytes = lds_frame ? (unsigned)(K.lds_words * 4 * lanes) : 0u;
-    void* params[] = {&Kc, &d_actions, &d_n_actions, &d_env_mask, &d_decisions, &d_scope, &met, &d_done, &lanes};
+    void* params[] = {&Kc, &d_actions, &d_n_actions, &d_env_mask, &d_decisions, &d_scope, &met, &d_done, &lanes, &d_n_answered};
     HIP_TRY(hipModuleLaunchKernel(h->spec_step, (unsigned)((K.n_envs + lanes - 1) / lanes), 1, 1, 64, 1, 1, lds_bytes, (hipStream_t)stream, params, nullptr));
     return MRX_OK;
   }
   hipLaunchKernelGGL(mrx_k_cb_step, dim3((K.n_envs + h->lanes - 1) / h->lanes), dim3(64), 0, (hipStream_t)stream, Kc, d_actions, d_n_actions, d_env_mask,
-                     d_decisions, d_scope, (long long*)d_metrics, d_done, h->lanes);
+                     d_decisions, d_scope, (long long*)d_metrics, d_done, h->lanes, d_n_answered);
   HIP_TRY(hipGetLastError());
   return MRX_OK;
+}
+
+int mrx_cb_step(mrx_cb_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const uint8_t* d_env_mask, int32_t* d_decisions,
+                int32_t* d_scope, int64_t* d_metrics, uint8_t* d_done, void* stream) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  if (h->plan.kp.decision_mode != 0) return set_err(MRX_ERR_INVALID_ARG, "engine was created in a Joint decision mode: use mrx_cb_step_joint");
+  return cb_launch_step(h, d_actions, d_n_actions, nullptr, d_env_mask, d_decisions, d_scope, d_metrics, d_done, stream);
+}
+
+int mrx_cb_step_joint(mrx_cb_handle h, const int32_t* d_actions, const int32_t* d_n_actions, const int32_t* d_n_answered, const uint8_t* d_env_mask,
+                      int32_t* d_decisions, int32_t* d_scope, int64_t* d_metrics, uint8_t* d_done, void* stream) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  if (h->plan.kp.decision_mode == 0) return set_err(MRX_ERR_INVALID_ARG, "engine was created in Sequential decision mode: use mrx_cb_step");
+  return cb_launch_step(h, d_actions, d_n_actions, d_n_answered, d_env_mask, d_decisions, d_scope, d_metrics, d_done, stream);
 }
 
 // ---- plan-specialised kernels (cb_spec.hip)
@@ -267,6 +281,7 @@ int mrx_cb_random_policy(mrx_cb_handle h, const int32_t* d_decisions, const int3
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
   const CbParams& K = h->plan.kp;
+  if (K.decision_mode != 0) return set_err(MRX_ERR_INVALID_ARG, "mrx_cb_random_policy answers Sequential-mode decisions");
   hipLaunchKernelGGL(mrx_k_cb_random_policy, dim3((K.n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, K, d_decisions, d_scope,
                      (long long)step, d_actions, d_n_actions, (unsigned long long*)d_counter);
   HIP_TRY(hipGetLastError());

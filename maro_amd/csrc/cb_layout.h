@@ -59,8 +59,10 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
     }
     if (t->filter_num[f] < 0 || t->filter_windows[f] < 0) return bad("negative filter option", MRX_ERR_INVALID_ARG);
   }
+  if (c->decision_mode < 0 || c->decision_mode > 2) return bad("decision_mode must be 0 (Sequential), 1 (Joint) or 2 (JointWithSequentialAction)", MRX_ERR_INVALID_ARG);
   CbParams& k = pl->kp;
   memset(&k, 0, sizeof(k));
+  k.decision_mode = c->decision_mode;
   k.n_envs = c->n_envs;
   k.stride = (int)align_up(c->n_envs, 64);
   k.S = S; k.start_tick = c->start_tick; k.max_tick = max_tick; k.res = c->snapshot_resolution;

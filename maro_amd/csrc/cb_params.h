@@ -26,6 +26,7 @@ struct CbParams {
   // ---- dimensions / options
   int32_t n_envs, stride, S, start_tick, max_tick, res, ring_slots, max_actions;
   int32_t dres, extra_cost_mode, n_filters, f_type[4], f_num[4], f_win[4];
+  int32_t decision_mode;  // 0 Sequential, 1 Joint, 2 JointWithSequentialAction (core.py:349-366)
   int32_t FW, w_mask, w_words, pool_cap, tt_cap, scope_cap, mask_words, nb_stride;
   int32_t lds_words;  // a lane's LDS column in the specialised step kernel: frame, capacities, bit words, scope scratch, event block
   int32_t lsh;        // per launch: log2(envs per wave)
@@ -74,5 +75,6 @@ struct CbParams {
   X(scope_cap) \
   X(mask_words) \
   X(nb_stride) \
-  X(lds_words)
+  X(lds_words) \
+  X(decision_mode)
 #define MRX_CB_DIM_ARRAYS(X) X(f_type) X(f_num) X(f_win)

@@ -11,7 +11,8 @@ mrx_k_cb_reset(CbParams K, const int32_t* __restrict__ tt, int n_times, const ui
 
 extern "C" __global__ void __launch_bounds__(64)
 mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions, const uint8_t* __restrict__ mask,
-              int32_t* __restrict__ decisions, int32_t* __restrict__ scope, long long* __restrict__ metrics, uint8_t* __restrict__ done, int lanes) {
+              int32_t* __restrict__ decisions, int32_t* __restrict__ scope, long long* __restrict__ metrics, uint8_t* __restrict__ done, int lanes,
+              const int32_t* __restrict__ n_answered) {
   // `lanes` envs per wave (mrx_cb_set_lanes_per_wave): lane l < lanes owns env blockIdx.x * lanes + l.  A wave runs the UNION
   // of its lanes' control flow, and steps differ a lot in length, so a small batch is faster spread thin over many waves.
   const int lane = (int)threadIdx.x;
@@ -35,10 +36,18 @@ mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __
   __syncthreads();
 #endif
   if (active) {
-    int na = (actions && n_actions) ? n_actions[e] : 0;
-    if (na > CD(max_actions)) na = CD(max_actions);
-    cb::step_env(K, e, actions ? actions + (size_t)e * CD(max_actions) * 3 : nullptr, na, decisions + (size_t)e * 8,
-                 scope + (size_t)e * CD(scope_cap) * 2, (int64_t*)metrics + (size_t)e * 3, done + e);
+    if (CD(decision_mode) == 0) {
+      int na = (actions && n_actions) ? n_actions[e] : 0;
+      if (na > CD(max_actions)) na = CD(max_actions);
+      cb::step_env(K, e, actions ? actions + (size_t)e * CD(max_actions) * 3 : nullptr, na, nullptr, decisions + (size_t)e * 8,
+                   scope + (size_t)e * CD(scope_cap) * 2, (int64_t*)metrics + (size_t)e * 3, done + e);
+    } else {  // Joint modes: S rows per env
+      const size_t S = (size_t)CD(S);
+      int nans = (actions && n_answered) ? n_answered[e] : 0;
+      if (nans < 0) nans = 0;
+      cb::step_env(K, e, actions ? actions + (size_t)e * S * CD(max_actions) * 3 : nullptr, nans, n_actions ? n_actions + (size_t)e * S : nullptr,
+                   decisions + (size_t)e * S * 8, scope + (size_t)e * S * CD(scope_cap) * 2, (int64_t*)metrics + (size_t)e * 3, done + e);
+    }
   }
 #ifdef MRX_CB_LDSFRAME
   __syncthreads();

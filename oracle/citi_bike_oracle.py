@@ -240,6 +240,72 @@ class CitiBikeOracle:
         self._finished = True
         return self.metrics(), None, True
 
+    # ------------------------------------------------------------------ Env.step, Joint modes (core.py:354-366)
+    def step_joint(self, actions_per_event: Optional[Sequence] = None, mode: int = 1):
+        """Joint (mode 1) / JointWithSequentialAction (mode 2): every pending decision event of the tick is reported at
+        once.  `actions_per_event[i]` = the action list ([(from, to, number), ...] or None) for the i-th reported event;
+        events beyond len(actions_per_event) are finished (mode 1) or stay pending and are reported again (mode 2).
+        Returns (metrics, [decision dicts] | None, done).  The scopes are evaluated on the state at report time (the
+        reference caches a payload's scope at its first read; the object API on top re-serves it)."""
+        if self._finished:
+            return None, None, True
+        if self._pending is not None:
+            lst = self.events.get(self.tick, [])
+            pend = self._pending
+            acts = list(actions_per_event or [])[: len(pend)]
+            for i, a in enumerate(acts):
+                # the decision event runs (no handler), is popped, and its TAKE_ACTION event runs right behind it
+                self._cursor += 1
+                tail_stale = self._cursor == len(self.events.get(self.tick, []))   # event_linked_list.py:86-108, see step()
+                for frm, to, number in (a or []):
+                    if frm < 0 or to < 0:
+                        continue
+                    b = int(self.bikes[frm])
+                    ex = min(b, int(number))
+                    if ex > 0:
+                        self._set_bikes(frm, b - ex)
+                        tt = int(self._transfer_times[self._tt_pos])
+                        self._tt_pos += 1
+                        if not (tt == 0 and tail_stale):
+                            self._insert(self.tick + tt, (EV_DELIVER, frm, to, ex))
+            if mode == 1:
+                self._cursor += len(pend) - len(acts)   # unanswered events: state FINISHED, popped without effect
+            self._pending = None
+            del lst
+        elif self._fresh:
+            self._fresh = False
+            self._cursor = 0
+            self._be_step(self.tick)
+        while True:
+            ev = self._execute(self.tick)
+            if ev is not None:
+                fi = self.frame_index(self.tick)
+                self._take_snapshot(fi)  # core.py:345
+                lst = self.events[self.tick]
+                pend = []
+                k = self._cursor
+                while k < len(lst) and lst[k][0] == EV_DECISION:   # event_linked_list.py:113-120: consecutive decision events
+                    pend.append(lst[k])
+                    k += 1
+                self._pending = pend
+                return self.metrics(), [dict(tick=self.tick, station_idx=s, type=dtype, frame_index=fi, action_scope=self._action_scope(s, dtype))
+                                        for _, s, dtype in pend], False
+            if (self.tick + 1) % self.res == 0:
+                self._take_snapshot(self.frame_index(self.tick))
+                for a in ("shortage", "trip_requirement", "extra_cost", "transfer_cost", "fulfillment", "failed_return"):
+                    getattr(self, a)[:] = 0
+                self.min_bikes[:] = self.bikes
+            if self.tick + 1 == self.max_tick:
+                break
+            self.events.pop(self.tick, None)
+            self.tick += 1
+            self._cursor = 0
+            self._be_step(self.tick)
+        if (self.tick + 1) % self.res != 0:
+            self._take_snapshot(self.frame_index(self.tick))
+        self._finished = True
+        return self.metrics(), None, True
+
     def metrics(self):
         return dict(trip_requirements=self.total_trips, bike_shortage=self.total_shortages, operation_number=self.total_operate)
 

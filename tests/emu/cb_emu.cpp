@@ -58,8 +58,23 @@ void cb_emu_step(void* h, const int32_t* actions, const int32_t* n_actions, cons
   for (int env = 0; env < K.n_envs; env++) {
     if (mask && !mask[env]) continue;
     const int na = n_actions ? n_actions[env] : 0;
-    cb::step_env(K, env, actions ? actions + (size_t)env * K.max_actions * 3 : nullptr, na < K.max_actions ? na : K.max_actions,
+    cb::step_env(K, env, actions ? actions + (size_t)env * K.max_actions * 3 : nullptr, na < K.max_actions ? na : K.max_actions, nullptr,
                  dec + (size_t)env * 8, scope + (size_t)env * K.scope_cap * 2, met + (size_t)env * 3, done + env);
+  }
+}
+
+// Joint modes (mrx_cb_step_joint): S rows per env
+void cb_emu_step_joint(void* h, const int32_t* actions, const int32_t* n_actions, const int32_t* n_answered, const uint8_t* mask, int32_t* dec,
+                       int32_t* scope, int64_t* met, uint8_t* done) {
+  CbEmu* e = (CbEmu*)h;
+  const CbParams& K = e->plan.kp;
+  const size_t S = (size_t)K.S;
+  for (int env = 0; env < K.n_envs; env++) {
+    if (mask && !mask[env]) continue;
+    int nans = (actions && n_answered) ? n_answered[env] : 0;
+    if (nans < 0) nans = 0;
+    cb::step_env(K, env, actions ? actions + (size_t)env * S * K.max_actions * 3 : nullptr, nans, n_actions ? n_actions + (size_t)env * S : nullptr,
+                 dec + (size_t)env * S * 8, scope + (size_t)env * S * K.scope_cap * 2, met + (size_t)env * 3, done + env);
   }
 }
 

@@ -10,9 +10,10 @@ from tests.emu.cb_emu import CbEmuBackend
 
 class CbEmuEngine:
     def __init__(self, topology, n_envs, start_tick=0, durations=1440, snapshot_resolution=1, max_snapshots=None, max_actions=1,
-                 seeds=None):
+                 seeds=None, decision_mode=0):
         self.data = topology if not isinstance(topology, str) else load_topology(topology)
-        self.b = CbEmuBackend(self.data, n_envs, start_tick, durations, snapshot_resolution, max_snapshots, max_actions)
+        self.b = CbEmuBackend(self.data, n_envs, start_tick, durations, snapshot_resolution, max_snapshots, max_actions, decision_mode=decision_mode)
+        self.decision_mode = decision_mode
         self.n_envs, self.max_actions = n_envs, max_actions
         self.start_tick, self.durations, self.snapshot_resolution = start_tick, durations, snapshot_resolution
         self.max_tick = start_tick + durations
@@ -30,6 +31,12 @@ class CbEmuEngine:
     def step(self, actions=None, n_actions=None, mask=None):
         out = self.b.step(None if actions is None else np.asarray(actions), None if n_actions is None else np.asarray(n_actions),
                           None if mask is None else np.asarray(mask))
+        self.decisions, self.scope, self.metrics, self.done = (torch.from_numpy(x) for x in out)
+        return self.decisions, self.scope, self.metrics, self.done
+
+    def step_joint(self, actions=None, n_actions=None, n_answered=None, mask=None):
+        out = self.b.step_joint(None if actions is None else np.asarray(actions), None if n_actions is None else np.asarray(n_actions),
+                                None if n_answered is None else np.asarray(n_answered), None if mask is None else np.asarray(mask))
         self.decisions, self.scope, self.metrics, self.done = (torch.from_numpy(x) for x in out)
         return self.decisions, self.scope, self.metrics, self.done
 

@@ -95,3 +95,59 @@ def check_vector_env(engine_factory):
 
 def test_vector_env_on_host_compiled_device_code():
     assert check_vector_env(emu_factory) > 10
+
+
+def check_vector_env_joint(engine_factory, mode):
+    """Joint (1) / JointWithSequentialAction (2) through the object API (core.py:354-366): lists of DecisionEvents, one
+    entry (Action / list / None) per event zipped in event order; an event left pending is re-yielded as the SAME object."""
+    topo, kw = "toy.5s_6t", dict(durations=500, snapshot_resolution=10)
+    seeds = [3, 4]
+    eng = engine_factory(topo, 2, max_actions=2, seeds=seeds, decision_mode=mode, **kw)
+    env = GpuVectorEnv(2, "citi_bike", topo, _engine=eng, decision_mode=mode, **kw)
+    data = load_topology(topo)
+    tts = draw_transfer_times(data, seeds, eng.layout.transfer_times_cap)
+    oracles = [CitiBikeOracle(data, transfer_times=tts[e], **kw) for e in range(2)]
+    ost = [o.step_joint(None, mode) for o in oracles]
+    metrics, events, all_done = env.step(None)
+    step = reyielded = 0
+    prev = [None, None]
+    while not all_done:
+        actions = []
+        for e in range(2):
+            om, ods, odone = ost[e]
+            if events[e] is None:
+                assert odone
+                actions.append(None)
+                continue
+            assert isinstance(events[e], list) and len(events[e]) == len(ods) and metrics[e] == om
+            acts, oacts = [], []
+            for ev, od in zip(events[e], ods):
+                assert (ev.tick, ev.station_idx, ev.frame_index) == (od["tick"], od["station_idx"], od["frame_index"])
+                if prev[e] is not None and any(ev is p for p in prev[e]):
+                    reyielded += 1          # same object, scope cached at its first read (may differ from the oracle's fresh one)
+                else:
+                    assert list(ev.action_scope.items()) == [tuple(x) for x in od["action_scope"]]
+                scope = dict(od["action_scope"])   # act on the oracle's (fresh) scope so both sides get the same actions
+                others = [k for k in scope if k != od["station_idx"]]
+                n = min(scope[od["station_idx"]], scope[others[0]]) // 2
+                frm, to = (od["station_idx"], others[0]) if od["type"] == 0 else (others[0], od["station_idx"])
+                acts.append(Action(frm, to, n) if (step + e) % 3 else [Action(frm, to, n)])
+                oacts.append([(frm, to, n)])
+            k = len(acts) if (step + e) % 2 == 0 else max(len(acts) - 1, 1 if mode == 2 else 0)
+            prev[e] = events[e]
+            actions.append(acts[:k])
+            ost[e] = oracles[e].step_joint(oacts[:k], mode)
+        metrics, events, all_done = env.step(actions)
+        step += 1
+    for e in range(2):
+        assert ost[e][2] and env.env_view(e).metrics == ost[e][0]
+    got = env.snapshot_list["stations"][::["bikes", "shortage", "fulfillment", "min_bikes"]]
+    for e in range(2):
+        assert np.array_equal(got[e], oracles[e].query("stations", [], [], ["bikes", "shortage", "fulfillment", "min_bikes"]))
+    assert (mode == 2) == (reyielded > 0)
+    return step
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_vector_env_joint_modes_on_host_compiled_device_code(mode):
+    assert check_vector_env_joint(emu_factory, mode) > 10

@@ -22,6 +22,24 @@ def test_hip_engine_reproduces_reference(case):
     replay_citi_bike(make, case)
 
 
+def _joint_cases():
+    from tests.test_citi_bike_joint_oracle import JOINT_CASES
+    return JOINT_CASES
+
+
+@pytest.mark.parametrize("case", _joint_cases())
+def test_hip_engine_reproduces_reference_joint_modes(case):
+    """mrx_cb_step_joint (Joint / JointWithSequentialAction) against the reference's vectors."""
+    from tests.cb_gpu_backend import CbGpuBackend
+    from tests.test_citi_bike_joint_oracle import replay_citi_bike_joint
+
+    def make_joint(data, kw, tt, mode, n_envs=70):
+        b = CbGpuBackend(data, n_envs=n_envs, max_actions=1, decision_mode=mode, **kw)
+        b.reset(transfer_times=[tt[: b.layout.transfer_times_cap]] * n_envs)
+        return CbBackendEnv(b, env=n_envs - 1)
+    replay_citi_bike_joint(make_joint, case)
+
+
 @pytest.mark.parametrize("topology,kwargs,n", [
     ("toy.3s_4t", dict(durations=1440, snapshot_resolution=10), 200),
     ("toy.3s_tight", dict(durations=1100, snapshot_resolution=7, max_snapshots=9), 130),

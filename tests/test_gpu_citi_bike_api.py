@@ -1,7 +1,7 @@
 """citi_bike object API on the HIP engine (same checks as tests/test_cb_vector_env_api.py)."""
 import pytest
 
-from tests.test_cb_vector_env_api import check_vector_env
+from tests.test_cb_vector_env_api import check_vector_env, check_vector_env_joint
 
 pytestmark = pytest.mark.gpu
 
@@ -13,6 +13,11 @@ def gpu_factory(topology, n, **kw):
 
 def test_vector_env_on_gpu():
     assert check_vector_env(gpu_factory) > 10
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_vector_env_joint_modes_on_gpu(mode):
+    assert check_vector_env_joint(gpu_factory, mode) > 10
 
 
 def test_constructs_its_own_engine():
