@@ -174,3 +174,19 @@ def test_specialized_citi_bike_bounded_steps(budget, lanes, monkeypatch):
     b.eng.set_lanes_per_wave(lanes)
     calls, unready = run_bounded_vs_oracle(b, data, kw, seeds=np.arange(150) + 3, budget=budget, check_envs=[0, 63, 64, 149])
     assert unready > 0
+
+
+@pytest.mark.parametrize("case", ["cbjoint_tight_m2_alt", "cbjoint_city180_m1_alt"])
+def test_specialized_citi_bike_joint_modes(case, monkeypatch):
+    """mrx_cb_step_joint on the LDS-frame step kernel."""
+    from tests.cb_backend_adapter import CbBackendEnv
+    from tests.cb_gpu_backend import CbGpuBackend
+    from tests.test_citi_bike_joint_oracle import replay_citi_bike_joint
+    monkeypatch.setenv("MARO_AMD_SPECIALIZE", "1")
+
+    def make_joint(data, kw, tt, mode, n_envs=70):
+        b = CbGpuBackend(data, n_envs=n_envs, max_actions=1, decision_mode=mode, **kw)
+        assert b.eng.specialized
+        b.reset(transfer_times=[tt[: b.layout.transfer_times_cap]] * n_envs)
+        return CbBackendEnv(b, env=n_envs - 1)
+    replay_citi_bike_joint(make_joint, case)
