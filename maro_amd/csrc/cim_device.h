@@ -1802,9 +1802,6 @@ MRX_DEV void step_loop(const CimParams& K, const CimObs& O, int32_t* lds, int w,
 // written registers -> LDS, and the write-back of env k is issued as fire-and-forget stores that drain under env k+1.
 // So in steady state a wave never waits for HBM, and there is no header round trip at all (the order list says which
 // path an env takes).  Fast-hinted envs are handled 64 per wave (one per lane, fast_step_lane) by the last waves.
-#ifndef MRX_EXP_STORE
-#define MRX_EXP_STORE 0
-#endif
 #if defined(MRX_SPECIALIZED)
 #if MRXC_pregen && MRXC_l_frame == 0 && MRXC_l_priv == MRXC_FW && MRXC_l_mt1 == MRXC_FW + MRXC_PW
 #define MRX_HAVE_PIPE 1
@@ -1884,18 +1881,7 @@ MRX_DEV void regs_store(const CimParams& K, int env, const EnvRegs& S, bool on, 
     int wr = (on_v != 0 && (g < SF4 + SP4 || dirty_v != 0)) ? 1 : 0;
     wave::opaque(wr);
     const uintptr_t pa = (uintptr_t)state_piece(K, env, g), da = (uintptr_t)dummy;
-#if MRX_EXP_STORE == 1
-    *(__attribute__((address_space(1))) wave::v4i*)(da + ((pa - da) & (uintptr_t)(-(long long)wr))) = S.r[c];
-#elif MRX_EXP_STORE == 3
-    wave::st16_nt_addr(c < 13 ? da + ((pa - da) & (uintptr_t)(-(long long)wr)) : da, S.r[c]);   // (the last piece carries the header)
-    if (c == 12) { for (int z = 0; z < 13; z++) wave::st16_nt_addr(da, S.r[z]); }
-#elif MRX_EXP_STORE == 4
-    wave::st16_nt_addr(c == 12 ? da + ((pa - da) & (uintptr_t)(-(long long)wr)) : da, S.r[c]);
-#elif MRX_EXP_STORE == 2
-    if (c == 0) wave::st16_nt_addr(da + ((pa - da) & (uintptr_t)(-(long long)wr)), S.r[c]);
-#else
     wave::st16_nt_addr(da + ((pa - da) & (uintptr_t)(-(long long)wr)), S.r[c]);
-#endif
   }
 }
 
