@@ -68,7 +68,6 @@ struct Prof {
 #endif
 
 #define GHDR(w) K.hdr[(size_t)(w) * CD(stride) + e] /* header word in HBM */
-#define HDR(w) hd[(w)]                           /* header word of the env being stepped: a register copy (step_env) */
 // the live frame in HBM (reset, query, and the generic step)
 #define GST(a, s) K.live[((size_t)(a) * CD(S) + (size_t)(s)) * CD(stride) + e]
 #ifdef __HIPCC__
@@ -103,7 +102,11 @@ static int32_t mrx_cb_lds_host[MRXC_lds_words]; /* host harness: one env at a ti
 #define LDS_FUL (LDS_CAP + MRXC_S)
 #define LDS_DMK (LDS_FUL + MRXC_w_words)
 #define LDS_SCR (LDS_DMK + 2 * MRXC_mask_words)
-static_assert(LDS_SCR + 3 * MRXC_S + CB_EV_BLOCK * 4 == MRXC_lds_words, "cb_layout.h and cb_device.h disagree on the LDS column");
+#define LDS_HDR (LDS_SCR + 3 * MRXC_S)
+static_assert(LDS_HDR + CH_WORDS + CB_EV_BLOCK * 4 == MRXC_lds_words, "cb_layout.h and cb_device.h disagree on the LDS column");
+// the env header too: as a register array that rare branches (the delivery pool) modify, every join of the replay loop copied
+// all 16 words back and forth
+#define HDR(w) LF(LDS_HDR + (w))
 #define LIVE(w) LF(w)
 #define ST(a, s) LF((a) * MRXC_S + (s))
 #define CAP(s) LF(LDS_CAP + (s))
@@ -111,6 +114,7 @@ static_assert(LDS_SCR + 3 * MRXC_S + CB_EV_BLOCK * 4 == MRXC_lds_words, "cb_layo
 #define DMK(i) (*(uint32_t*)&LF(LDS_DMK + (i)))
 #define SCR(i) LF(LDS_SCR + (i))
 #else
+#define HDR(w) hd[(w)] /* header word of the env being stepped: a register copy (step_env) */
 #define LIVE(w) K.live[(size_t)(w) * CD(stride) + e]
 #define ST(a, s) GST(a, s)
 #define CAP(s) K.capacity[s]
@@ -120,41 +124,35 @@ static_assert(LDS_SCR + 3 * MRXC_S + CB_EV_BLOCK * 4 == MRXC_lds_words, "cb_layo
 #endif
 
 // The env's place in the shared event stream (4 words per record).  LDS build: records are consumed out of a block of
-// CB_EV_BLOCK records in the lane's LDS column; the NEXT block is requested into registers when a block is opened and only
-// touched CB_EV_BLOCK records later, so an L2 round trip is paid once per step, not per record.  The stream is padded by
-// 2 x CB_EV_BLOCK records so a request may run past the last record.
+// CB_EV_BLOCK records in the lane's LDS block (one 16-byte LDS read per record), refilled with CB_EV_BLOCK independent loads:
+// an L2 round trip per block, not per record.  The stream is padded by 2 x CB_EV_BLOCK records so a refill may run past the
+// last record.
 struct EvWin {
   int pos;  // stream index of the next record
 #ifdef MRX_CB_LDSFRAME
   int base;  // stream index of the first record of the LDS block
-  int32_t nxt[CB_EV_BLOCK][4];
-  MRX_DEVM void request(const CbParams& K, int idx) {
-    struct alignas(16) I4 { int32_t a, b, c, d; };
-#pragma unroll
-    for (int k = 0; k < CB_EV_BLOCK; k++) {
-      const I4 r = *(const I4*)(K.ev_rec + (size_t)(idx + k) * 4);
-      nxt[k][0] = r.a; nxt[k][1] = r.b; nxt[k][2] = r.c; nxt[k][3] = r.d;
-    }
-  }
   struct alignas(16) Rec { int32_t w0, a, b, c; };
-  MRX_DEVM void land(const CbParams& K) {
+  // CB_EV_BLOCK records from stream index idx into the lane's LDS block: the loads are independent (one L2 round trip per
+  // block).  (Holding the NEXT block in registers while the current one is consumed was measured first: the registers are
+  // loop-carried, so the compiler copies all 32 of them — and waits for the loads — at the head of every iteration.)
+  MRX_DEVM void refill(const CbParams& K, int idx) {
+    Rec r[CB_EV_BLOCK];
+#pragma unroll
+    for (int k = 0; k < CB_EV_BLOCK; k++) r[k] = *(const Rec*)(K.ev_rec + (size_t)(idx + k) * 4);
     Rec* blk = (Rec*)LEV();
 #pragma unroll
-    for (int k = 0; k < CB_EV_BLOCK; k++) blk[k] = Rec{nxt[k][0], nxt[k][1], nxt[k][2], nxt[k][3]};
+    for (int k = 0; k < CB_EV_BLOCK; k++) blk[k] = r[k];
   }
   MRX_DEVM void open(const CbParams& K, int p) {
     pos = base = p;
-    request(K, p);
-    land(K);
-    request(K, p + CB_EV_BLOCK);
+    refill(K, p);
   }
   MRX_DEVM Rec rec(const CbParams& K) const { return ((const Rec*)LEV())[pos - base]; }
   MRX_DEVM void advance(const CbParams& K) {
     pos++;
     if (pos - base == CB_EV_BLOCK) {
-      land(K);
       base += CB_EV_BLOCK;
-      request(K, base + CB_EV_BLOCK);
+      refill(K, base);
     }
   }
 #else
@@ -520,9 +518,16 @@ MRX_DEV void apply_actions(const CbParams& K, int e, int32_t* hd, int t, int s, 
 // n_actions = how many of the reported events were answered.  met[3].
 MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_actions, const int32_t* n_act_ev, int32_t* dec, int32_t* scope,
                       int64_t* met, uint8_t* done) {
+#ifdef MRX_CB_LDSFRAME
+  int32_t* hd = nullptr;  // (the header lives in the LDS column, HDR())
+#ifndef __HIPCC__
+  for (int w = 0; w < CH_WORDS; w++) HDR(w) = GHDR(w);
+#endif
+#else
   int32_t hd[CH_WORDS];  // the env's header lives in registers for the whole step
 #pragma unroll
   for (int w = 0; w < CH_WORDS; w++) hd[w] = GHDR(w);
+#endif
   int flags = HDR(CH_FLAGS);
   int t = HDR(CH_TICK);
   bool finished = (flags & CFL_FINISHED) != 0;
@@ -635,8 +640,9 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     P.flush(K, e);
     HDR(CH_TICK) = t;
     HDR(CH_FLAGS) = flags;
-#pragma unroll
-    for (int w = 0; w < CH_WORDS; w++) GHDR(w) = hd[w];
+#if !(defined(MRX_CB_LDSFRAME) && defined(__HIPCC__))
+    for (int w = 0; w < CH_WORDS; w++) GHDR(w) = HDR(w);
+#endif
 #if defined(MRX_CB_LDSFRAME) && !defined(__HIPCC__)
     for (int w = 0; w < MRXC_FW; w++) K.live[(size_t)w * CD(stride) + e] = LF(w);
     for (int w = 0; w < MRXC_w_words; w++) GFUL(w) = (uint32_t)LF(LDS_FUL + w);

@@ -30,6 +30,7 @@ mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __
 #pragma unroll 4
     for (int w = r0; w < MRXC_FW; w += rstep) MRX_CB_LFX(w) = K.live[(size_t)w * CD(stride) + cbase];
     for (int w = r0; w < MRXC_S; w += rstep) MRX_CB_LFX(LDS_CAP + w) = K.capacity[w];
+    for (int w = r0; w < CH_WORDS; w += rstep) MRX_CB_LFX(LDS_HDR + w) = K.hdr[(size_t)w * CD(stride) + cbase];
     for (int w = r0; w < MRXC_w_words; w += rstep) MRX_CB_LFX(LDS_FUL + w) = (int32_t)K.fulfilled[(size_t)w * CD(stride) + cbase];
     for (int w = r0; w < 2 * MRXC_mask_words; w += rstep) MRX_CB_LFX(LDS_DMK + w) = (int32_t)K.decmask[(size_t)w * CD(stride) + cbase];
   }
@@ -54,6 +55,7 @@ mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __
   if (cok) {
 #pragma unroll 4
     for (int w = r0; w < MRXC_FW; w += rstep) K.live[(size_t)w * CD(stride) + cbase] = MRX_CB_LFX(w);
+    for (int w = r0; w < CH_WORDS; w += rstep) K.hdr[(size_t)w * CD(stride) + cbase] = MRX_CB_LFX(LDS_HDR + w);
     for (int w = r0; w < MRXC_w_words; w += rstep) K.fulfilled[(size_t)w * CD(stride) + cbase] = (uint32_t)MRX_CB_LFX(LDS_FUL + w);
     for (int w = r0; w < 2 * MRXC_mask_words; w += rstep) K.decmask[(size_t)w * CD(stride) + cbase] = (uint32_t)MRX_CB_LFX(LDS_DMK + w);
   }
