@@ -109,7 +109,7 @@ def test_code_object_of_another_plan_is_rejected():
     from maro_amd import _lib
     from maro_amd.cim import specialize as spec
     from maro_amd.cim.engine import CimBatchEngine
-    eng = CimBatchEngine("toy.4p_ssdd_l0.0", 8, durations=50)
+    eng = CimBatchEngine("toy.4p_ssdd_l0.0", 8, durations=50, specialize=False)   # (also when the suite runs with MARO_AMD_SPECIALIZE=1)
     other = spec.plan_defines(eng._cs, _lib.MrxCimConfig(8, 0, 0, 51, 1, 0, 1, 0, 0, 0))
     img = spec.code_object(other)
     buf = ctypes.create_string_buffer(img, len(img))

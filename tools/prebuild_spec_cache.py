@@ -64,6 +64,24 @@ def main(which="bench"):
         cap = data.n_stations * (int((data.time_mean + 6 * data.time_std) / max(data.resolution, 1)) + 2) + 4
         todo[("citi_bike", spec.plan_defines(ts, MrxCbConfig(4096, 0, 0, 44000, 10, 16, 1, cap, 0), "citi_bike"))] = 1
         del np, keep
+    if which in ("goldens", "all"):   # citi_bike golden replays on the GPU (tests/test_gpu_citi_bike.py, test_gpu_specialized.py: 70 envs)
+        import json
+
+        import numpy as np
+
+        from maro_amd.citi_bike.abi import MrxCbConfig, topology_struct
+        from maro_amd.citi_bike.data import load_topology as load_cb
+        gdir = os.path.join(REPO, "tests", "golden")
+        for f in sorted(os.listdir(gdir)):
+            if not (f.startswith("cb_") or f.startswith("cbjoint_")):
+                continue
+            meta = json.loads(bytes(np.load(os.path.join(gdir, f))["meta"]).decode())
+            data = load_cb(meta["topology"])
+            kw = meta["kwargs"]
+            ts, keep = topology_struct(data)
+            cap = data.n_stations * (int((data.time_mean + 6 * data.time_std) / max(data.resolution, 1)) + 2) + 4
+            cfg = MrxCbConfig(70, 0, 0, kw["durations"], kw.get("snapshot_resolution", 1), kw.get("max_snapshots") or 0, 1, cap, 0, meta.get("decision_mode", 0))
+            todo[("citi_bike", spec.plan_defines(ts, cfg, "citi_bike"))] = 1
     with ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as ex:
         sizes = list(ex.map(lambda d: len(spec.code_object(d[1], scenario=d[0]) if isinstance(d, tuple) else spec.code_object(d)), todo))
     print(f"spec cache: {len(sizes)} plan(s) ready in {spec.CACHE}", file=sys.stderr)   # stderr: bench.py's stdout is one JSON line
