@@ -625,19 +625,27 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
     const int Lr = K.v_route_len[v], rb = K.v_route_base[v];
     const double speed = K.v_speed[v], sn = K.v_speed_noise[v], dur = K.v_dur[v], dn = K.v_dur_noise[v];
     int loc = K.v_start[v], tick = 0, extra = 0, k = 0, period = 0;
+    // the vessel's leg distances and leg times: lane l holds leg l (route length <= 62), one load per vessel; inside the
+    // loop they come out of registers by lane index — a global load per stop was a dependent L2 round trip in a loop of
+    // ~5000 sequential stops per env
+    union { double d; int w[2]; } my_dist;
+    my_dist.d = lane < Lr ? K.route_dist[rb + lane] : 0.0;
+    const int my_leg = lane < Lr ? K.leg_time[K.leg_off[v] + lane] : 0;
     while (extra <= KD(future_n)) {
       const double r1 = mt_draw_uniform(mt_route, idx_route);
       const int parking = (int)ceil(apply_noise(dur, dn, r1));
       const double r2 = mt_draw_uniform(mt_route, idx_route);
       const double noised_speed = apply_noise(speed, sn, r2);
-      const int sailing = (int)ceil(K.route_dist[rb + loc] / noised_speed);
+      union { double d; int w[2]; } dist;
+      dist.w[0] = wave::bcast(my_dist.w[0], loc); dist.w[1] = wave::bcast(my_dist.w[1], loc);
+      const int sailing = (int)ceil(dist.d / noised_speed);
       if (parking <= 0 || parking > 255) status |= 8;  // reference: assert parking_duration > 0
       if (k < KD(SMAX)) {
         if (lane == 0) g_stops[(size_t)v * KD(SMAX) + k] = ((uint32_t)tick << 8) | (uint32_t)(parking & 0xff);
       } else {
         status |= 2;  // MRX_ENV_STOP_OVERFLOW
       }
-      if (k < Lr) period += K.leg_time[K.leg_off[v] + loc];  // cim_data_generator.py:93-101
+      if (k < Lr) period += wave::bcast(my_leg, loc);  // cim_data_generator.py:93-101
       tick += parking + sailing;
       loc = (loc + 1 == Lr) ? 0 : loc + 1;
       extra += (tick > TT) ? 1 : 0;
@@ -653,6 +661,7 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   copy_words((int32_t*)(g_mt + MTS_ORDER * MT_WORDS), (const int32_t*)L.mt_ord, MT_WORDS);
   copy_words((int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), (const int32_t*)L.mt_buf, MT_WORDS);
   copy_words((int32_t*)(g_mt + MTS_ROUTE * MT_WORDS), (const int32_t*)mt_route, MT_WORDS);
+  wave::sync();  // (the route / order-init / order streams may alias the frame region initialised next: cim_layout.h)
 
   // ---- frame (business_engine.py:321-356, 381-398) and private state
   for (int i = lane; i < KD(FW); i += 64) L.frame[i] = (i >= KD(f_plans) && i < KD(f_plans) + KD(NC)) ? -1 : 0;

@@ -333,9 +333,16 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   k.ctab_words = (int)((ctab_end - ctab_begin) / 4);
   k.l_ctab = (k.lds_words + 1) / 2 * 2;
   k.lds_words = (k.l_ctab + k.ctab_words + 3) / 4 * 4;
-  k.l_mt2 = k.lds_words; k.l_mt3 = k.l_mt2 + MT_WORDS; k.lds_words_reset = k.l_mt3 + MT_WORDS;
+  // reset_env's extra RNG streams (route, order-init, and with the order table the order stream it only seeds): they are dead
+  // once the streams are persisted, BEFORE frame and private state are initialised in LDS, so when they fit they alias that
+  // region — the reset kernel is a latency chain (route unrolling: ~5000 sequential stops per env) and its throughput is its
+  // occupancy: 25.6 KB -> 18.1 KB of LDS = 6 -> 9 waves per CU for global_trade.22p
+  const bool alias_reset_streams = k.FW + k.PW >= (k.pregen ? 3 : 2) * MT_WORDS;
+  if (alias_reset_streams) { k.l_mt2 = k.l_frame; k.l_mt3 = k.l_mt2 + MT_WORDS; k.lds_words_reset = k.lds_words; }
+  else { k.l_mt2 = k.lds_words; k.l_mt3 = k.l_mt2 + MT_WORDS; k.lds_words_reset = k.l_mt3 + MT_WORDS; }
   if (k.pregen) {
-    k.l_mt0 = k.lds_words_reset; k.lds_words_reset += MT_WORDS;  // reset_env seeds the order stream here
+    if (alias_reset_streams) k.l_mt0 = k.l_mt3 + MT_WORDS;
+    else { k.l_mt0 = k.lds_words_reset; k.lds_words_reset += MT_WORDS; }  // reset_env seeds the order stream here
     // the order-table kernel: order RNG state, generator scratch, staged tables
     int g = 0;
     k.g_mt0 = g; g += MT_WORDS;
