@@ -621,6 +621,25 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
 
   // ---- route unrolling (cim_data_generator.py:18-115): one sequential stream across vessels, two
   // draws per stop; executed wave-uniformly (every lane computes the same values, lane 0 stores)
+  // the stream's draws are tempered 64 at a time (lane l holds draw l of the batch) and handed out by lane index: one
+  // batch call instead of two LDS reads + two temperings per draw, in a loop whose cost is its instruction latency.  A batch
+  // never reaches past the current state block (no twist on draws that may stay unused); the unused tail is given back below.
+  double rt_batch = 0.0;
+  int rt_j = 0, rt_n = 0;
+  auto route_draw = [&]() -> double {
+    if (rt_j == rt_n) {
+      const int left = (MT_WORDS - idx_route) / 2;
+      rt_n = (idx_route >= MT_WORDS || left > 64) ? 64 : left;
+      bool tw = false;
+      rt_batch = mt_draw_batch(mt_route, idx_route, lane < rt_n ? lane : -1, rt_n, tw);
+      rt_j = 0;
+    }
+    union { double d; int w[2]; } u, r;
+    u.d = rt_batch;
+    r.w[0] = wave::bcast(u.w[0], rt_j); r.w[1] = wave::bcast(u.w[1], rt_j);
+    rt_j++;
+    return r.d;
+  };
   for (int v = 0; v < V; v++) {
     const int Lr = K.v_route_len[v], rb = K.v_route_base[v];
     const double speed = K.v_speed[v], sn = K.v_speed_noise[v], dur = K.v_dur[v], dn = K.v_dur_noise[v];
@@ -632,9 +651,9 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
     my_dist.d = lane < Lr ? K.route_dist[rb + lane] : 0.0;
     const int my_leg = lane < Lr ? K.leg_time[K.leg_off[v] + lane] : 0;
     while (extra <= KD(future_n)) {
-      const double r1 = mt_draw_uniform(mt_route, idx_route);
+      const double r1 = route_draw();
       const int parking = (int)ceil(apply_noise(dur, dn, r1));
-      const double r2 = mt_draw_uniform(mt_route, idx_route);
+      const double r2 = route_draw();
       const double noised_speed = apply_noise(speed, sn, r2);
       union { double d; int w[2]; } dist;
       dist.w[0] = wave::bcast(my_dist.w[0], loc); dist.w[1] = wave::bcast(my_dist.w[1], loc);
@@ -654,6 +673,7 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
     }
     if (lane == 0) { K.nstops[(size_t)env * V + v] = k < KD(SMAX) ? k : KD(SMAX); K.vperiod[(size_t)env * V + v] = period; }
   }
+  idx_route -= 2 * (rt_n - rt_j);  // draws of the last batch nobody asked for
   }  // generated data
   wave::sync();
 
