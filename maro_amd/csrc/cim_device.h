@@ -514,25 +514,62 @@ MRX_DEV void gen_orders(const CimParams& K, Lds& L, long long otg, int& idx_ord,
   for (int k0 = 192; k0 < NTb; k0 += 64) MRX_PAIR_BATCH(k0, K.pair_src[k0 + lane < NT ? k0 + lane : 0])
 #undef MRX_PAIR_BATCH
   wave::sync();
-  // sequential hand-out per source port (:381-393): cur = min(cur, remaining); only positive orders exist
-  if (lane < brk) {
+  // sequential hand-out per source port (:381-393): cur = min(cur, remaining), remaining -= cur; only positive orders exist.
+  // With no negative raw quantity (a negative noised ratio; rare) `remaining` only shrinks, so the hand-out is closed form:
+  // cur_j = min(raw_j, max(0, n_p - sum of the port's earlier raw quantities)) — an inclusive prefix over all pairs (the same
+  // device as phase B3's), lane-parallel, instead of 22 lanes walking up to 21 targets each.
+  uint64_t negq = 0;
+  for (int k0 = 0; k0 < NTb; k0 += 64) negq |= wave::ballot(k0 + lane < NTb && L.oq[k0 + lane] < 0);
+  if (!negq) {
+    uint32_t* pre = (uint32_t*)L.dtgt;  // the noised ratios are dead by now; unsigned: the running total may wrap, a port's share cannot
+    uint32_t carry = 0;
+#define MRX_HAND_SCAN(k0, SRC)                                                 \
+    {                                                                          \
+      const int k = (k0) + lane;                                               \
+      int v = 0;                                                               \
+      if (k < NTb) {                                                           \
+        const int n_p = L.srcn[(SRC)];                                         \
+        const int q = L.oq[k];                                                 \
+        v = q < n_p ? q : (n_p > 0 ? n_p : 0); /* n_p < 2^24: 64 of them fit */ \
+      }                                                                        \
+      const uint32_t incl = (uint32_t)wave::scan_incl_add(v) + carry;          \
+      carry = (uint32_t)wave::bcast((int)incl, 63);                            \
+      if (k < NTb) pre[k] = incl;                                              \
+    }
+    if (NTb > 0) MRX_HAND_SCAN(0, pf.src[0])
+    if (NTb > 64) MRX_HAND_SCAN(64, pf.src[1])
+    if (NTb > 128) MRX_HAND_SCAN(128, pf.src[2])
+    for (int k0 = 192; k0 < NTb; k0 += 64) MRX_HAND_SCAN(k0, K.pair_src[k0 + lane < NT ? k0 + lane : 0])
+#undef MRX_HAND_SCAN
+    wave::sync();
+#define MRX_HAND_OUT(k0, SRC)                                                                   \
+    {                                                                                           \
+      const int k = (k0) + lane;                                                                \
+      if (k < NTb) {                                                                            \
+        const int sp = (SRC);                                                                   \
+        const int n_p = L.srcn[sp], q = L.oq[k], off = T.tgt_off[sp];                           \
+        const int v = q < n_p ? q : (n_p > 0 ? n_p : 0);                                        \
+        const int before = (int)(pre[k] - (uint32_t)v - (off > 0 ? pre[off - 1] : 0u));         \
+        const int rem = n_p - before;                                                           \
+        const int cur = rem <= 0 ? 0 : (q < rem ? q : rem);                                     \
+        L.oq[k] = cur > 0 ? cur : 0;                                                            \
+      }                                                                                         \
+    }
+    if (NTb > 0) MRX_HAND_OUT(0, pf.src[0])
+    if (NTb > 64) MRX_HAND_OUT(64, pf.src[1])
+    if (NTb > 128) MRX_HAND_OUT(128, pf.src[2])
+    for (int k0 = 192; k0 < NTb; k0 += 64) MRX_HAND_OUT(k0, K.pair_src[k0 + lane < NT ? k0 + lane : 0])
+#undef MRX_HAND_OUT
+  } else if (lane < brk) {
     const long long n_p = L.srcn[lane];
     if (n_p > 0) {
       const int off = T.tgt_off[lane], cnt = T.tgt_off[lane + 1] - off;
       long long rem = n_p;
-      for (int j = 0; j < cnt; j += 4) {  // four quantities per LDS round trip, handed out strictly in order
-        int32_t q[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) q[u] = L.oq[off + (j + u < cnt ? j + u : j)];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          if (j + u < cnt) {
-            long long cur = q[u];
-            if (cur > rem) cur = rem;
-            rem -= cur;
-            L.oq[off + j + u] = cur > 0 ? (int32_t)cur : 0;
-          }
-        }
+      for (int j = 0; j < cnt; j++) {
+        long long cur = L.oq[off + j];
+        if (cur > rem) cur = rem;
+        rem -= cur;
+        L.oq[off + j] = cur > 0 ? (int32_t)cur : 0;
       }
     }
   }
