@@ -132,7 +132,7 @@ int mrx_cb_step_joint(mrx_cb_handle h, const int32_t* d_actions, const int32_t* 
  * How many envs share one 64-lane wave of the step kernel (no reference counterpart: the reference steps one env per process).
  * One lane owns one env; a wave executes the union of its lanes' control flow and env-steps differ a lot in length (0 to
  * 20+ ticks), so few envs per wave means less divergence but more waves.  lanes = 1, 2, 4, ..., 64; 0 = automatic (the
- * default: 64, lowered to 32 / 16 while the batch gives fewer than one wave per CU, and — plan-specialised kernels — until the
+ * default: 64, lowered to 32 / 16 / 8 while the batch gives fewer than about four waves per CU, and — plan-specialised kernels — until the
  * lanes' LDS columns fit in 64 KB; env var MRX_CB_LANES overrides it at creation).  Results do not depend on it.
  */
 int mrx_cb_set_lanes_per_wave(mrx_cb_handle h, int lanes);

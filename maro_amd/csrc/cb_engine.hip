@@ -100,11 +100,12 @@ int64_t mrx_cb_workspace_bytes(const mrx_cb_topology* topo, const mrx_cb_config*
 }
 
 // envs per wave of the step kernel when the caller does not say: a wave runs the union of its lanes' control flow, so a
-// small batch is spread over at least one wave per CU (256); below 16 envs per wave the extra waves stop paying
-// (profiles/r02_citi_bike.md: 4096 envs 60 -> 66 M env-steps/s at 16 lanes, 32768 envs best at 64)
+// small batch is spread over about a thousand waves (four per CU); below 8 envs per wave the extra waves stop paying
+// (profiles/r02_citi_bike.md: 4096 envs 62.5 / 64.1 / 66.7 / 64.4 / 54.2 M env-steps/s at 32 / 16 / 8 / 4 / 1 envs per wave;
+// 32768 envs 363 M at 64, 381 M at 32)
 static int auto_lanes(int n_envs) {
   int lanes = 64;
-  while (lanes > 16 && n_envs / lanes < 256) lanes /= 2;
+  while (lanes > 8 && n_envs / lanes < 1024) lanes /= 2;
   return lanes;
 }
 
