@@ -123,3 +123,64 @@ def run_bounded_vs_oracle(backend, data, kwargs, seeds, budget, check_envs=None,
     assert (backend.hdr()[13, :n] == 0).all()
     backend.set_step_budget(0)
     return calls, unready
+
+
+def run_joint_vs_oracle(backend, data, kwargs, seeds, mode, budget=0, check_envs=None, max_calls=100000):
+    """Joint (1) / JointWithSequentialAction (2) batches, every env with its own transfer-time stream and its own counter-based
+    choice of how many of the reported events it answers; optional bounded steps on top.  Every env must follow the oracle's
+    step_joint: the same events, scopes (evaluated at report time on both sides), metrics, and final snapshots."""
+    n, S = backend.n_envs, data.n_stations
+    tts = draw_transfer_times(data, seeds, backend.layout.transfer_times_cap)
+    check_envs = list(range(n)) if check_envs is None else check_envs
+    backend.reset(transfer_times=tts)
+    backend.set_step_budget(budget)
+    oracles = {e: CitiBikeOracle(data, transfer_times=tts[e], **kwargs) for e in check_envs}
+    o_out = {e: o.step_joint(None, mode) for e, o in oracles.items()}
+    n_rep = np.zeros(n, np.int64)
+    a = np.full((n, S, backend.max_actions, 3), -1, np.int32)
+    na = np.zeros((n, S), np.int32)
+    nans = np.zeros(n, np.int32)
+    calls = events = 0
+    dec, scope, met, done = backend.step_joint()
+    while True:
+        calls += 1
+        assert calls < max_calls
+        a[:], na[:], nans[:] = -1, 0, 0
+        for e in range(n):
+            if done[e] or not dec[e, 0, 5]:
+                continue                      # finished, or (bounded steps) no decision yet
+            n_ev = int(dec[e, 0, 6])
+            n_rep[e] += 1
+            r = mix64(mix64(int(n_rep[e])) ^ e)
+            k = n_ev if r % 3 == 0 else int(r >> 8) % (n_ev + 1)
+            if mode == 2 and k == 0:
+                k = 1                           # (the reference would report the same events forever)
+            des = [dict(tick=int(dec[e, i, 0]), station_idx=int(dec[e, i, 1]), type=int(dec[e, i, 2]), frame_index=int(dec[e, i, 3]),
+                        action_scope=[tuple(x) for x in scope[e, i, : dec[e, i, 4]].tolist()]) for i in range(n_ev)]
+            acts = [policy_action(int(n_rep[e]) * 64 + i, e, de) for i, de in enumerate(des)]
+            for i in range(k):
+                if acts[i]:
+                    a[e, i, 0], na[e, i] = acts[i], 1
+            nans[e] = k
+            events += n_ev
+            if e in oracles:
+                m, odes, od = o_out[e]
+                assert not od and len(odes) == n_ev, (e, calls, n_ev, None if odes is None else len(odes))
+                assert met[e].tolist() == [m["trip_requirements"], m["bike_shortage"], m["operation_number"]], (e, calls)
+                for de, ode in zip(des, odes):
+                    assert (de["tick"], de["station_idx"], de["type"], de["frame_index"]) == (ode["tick"], ode["station_idx"], ode["type"], ode["frame_index"]), (e, calls, de, ode)
+                    assert de["action_scope"] == [tuple(x) for x in ode["action_scope"]], (e, calls, de, ode)
+                o_out[e] = oracles[e].step_joint([[x] if x else None for x in acts[:k]], mode)
+        if done.all():
+            break
+        dec, scope, met, done = backend.step_joint(a, na, nans)
+    for e in check_envs:
+        o = oracles[e]
+        m, _, od = o_out[e]
+        assert od and met[e].tolist() == [m["trip_requirements"], m["bike_shortage"], m["operation_number"]], e
+        fis = o.frame_indices()
+        got = backend.query(NODE_TYPE["stations"], fis, list(range(S)), list(range(len(STATION_ATTRS))), len(STATION_ATTRS))[e].reshape(-1)
+        assert np.array_equal(got, o.query("stations", fis, [], STATION_ATTRS)), e
+    assert (backend.hdr()[13, :n] == 0).all()
+    backend.set_step_budget(0)
+    return calls, events

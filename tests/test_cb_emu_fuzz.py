@@ -41,3 +41,24 @@ def test_packaged_city_topology_regenerates(tmp_path):
             assert np.array_equal(getattr(fresh, k), getattr(have, k)), (name, k)
         assert fresh.filters == have.filters and fresh.n_stations == 180 and cfg["time_zone"] == "America/New_York"
         assert have.day_weekday.tolist() == [0, 1] and (fresh.time_mean, fresh.resolution) == (have.time_mean, have.resolution)
+
+
+@pytest.mark.parametrize("case_seed,mode,budget,specialized", [(3, 1, 0, False), (7, 2, 0, True), (11, 1, 9, True), (19, 2, 4, False), (23, 2, 0, False),
+                                                                (31, 1, 0, True)])
+def test_joint_modes_on_random_data(case_seed, mode, budget, specialized):
+    """Joint / JointWithSequentialAction (and bounded steps on top) on random citi_bike data sets: per-env random numbers of
+    answered events, host-compiled device code (generic / LDS-frame builds) vs the oracle's step_joint."""
+    import functools
+
+    import numpy as np
+
+    from tests.cb_batch_check import run_joint_vs_oracle
+    from tests.emu.cb_emu import CbEmuBackend
+    from tests.fuzz_citi_bike import random_data
+    rng = np.random.RandomState(case_seed)
+    data = random_data(rng)
+    kw = dict(durations=int(rng.choice([150, 400])), snapshot_resolution=int(rng.choice([1, 4, 10])))
+    B = functools.partial(CbEmuBackend, specialized=True) if specialized else CbEmuBackend
+    b = B(data, n_envs=4, max_actions=1, decision_mode=mode, **kw)
+    calls, events = run_joint_vs_oracle(b, data, kw, seeds=np.arange(4) + case_seed, mode=mode, budget=budget)
+    assert events > 10

@@ -82,6 +82,20 @@ def test_bounded_steps_and_lanes_per_wave_do_not_change_trajectories(budget, lan
     assert unready > 0
 
 
+@pytest.mark.parametrize("case_seed,mode,budget", [(7, 2, 0), (11, 1, 9), (23, 2, 5)])
+def test_joint_modes_on_random_data(case_seed, mode, budget):
+    """Joint modes (+ bounded steps) on random data sets, 100 envs with per-env random numbers of answered events, vs the oracle."""
+    from tests.cb_batch_check import run_joint_vs_oracle
+    from tests.cb_gpu_backend import CbGpuBackend
+    from tests.fuzz_citi_bike import random_data
+    rng = np.random.RandomState(case_seed)
+    data = random_data(rng)
+    kw = dict(durations=int(rng.choice([150, 400])), snapshot_resolution=int(rng.choice([1, 4, 10])))
+    b = CbGpuBackend(data, n_envs=100, max_actions=1, decision_mode=mode, **kw)
+    calls, events = run_joint_vs_oracle(b, data, kw, seeds=np.arange(100) + case_seed, mode=mode, budget=budget, check_envs=[0, 1, 63, 64, 99])
+    assert events > 100
+
+
 def test_full_size_batch_properties():
     """BASELINE config 4 size on one GPU (4096 envs, a month-long... one day here): conservation laws that hold for any
     trajectory: trips = fulfilled + shortage; bikes are conserved up to in-flight / lost ones; identical seeds and
