@@ -372,10 +372,35 @@ print(steps, episodes, t_step, t_reset)
         steps, episodes, t_step, t_reset = int(steps), int(episodes), float(t_step), float(t_reset)
     except Exception as e:   # the reference is a convenience leg, never a reason to fail the bench
         return {"error": str(e)[:200]}
-    return {"value": steps / t_step, "unit": "env-steps/s", "cores": 1, "kind": "reference",
-            "value_end_to_end": steps / (t_step + t_reset), "reset_s_per_episode": t_reset / max(episodes, 1),
-            "sample": f"{episodes} full episode(s) of {topology} ({durations} ticks) on the reference's own Env (maro.simulator.Env, single process, "
-                      f"Python {sys.version_info.major}.{sys.version_info.minor}): {steps} decisions in {t_step:.1f} s of stepping + {t_reset:.1f} s of env.reset()"}
+    res = {"value": steps / t_step, "unit": "env-steps/s", "cores": 1, "kind": "reference",
+           "value_end_to_end": steps / (t_step + t_reset), "reset_s_per_episode": t_reset / max(episodes, 1),
+           "sample": f"{episodes} full episode(s) of {topology} ({durations} ticks) on the reference's own Env (maro.simulator.Env, single process, "
+                     f"Python {sys.version_info.major}.{sys.version_info.minor}): {steps} decisions in {t_step:.1f} s of stepping + {t_reset:.1f} s of env.reset()"}
+    # the reference's own batch form, one process per env on every usable core, broadcast action=None
+    cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
+    vcode = r"""
+import os, sys, time
+os.environ.setdefault("HOME", "/tmp/oracle/home"); os.environ.setdefault("SKIP_DEPLOYMENT", "TRUE")
+sys.path.insert(0, sys.argv[1])
+from maro.vector_env import VectorEnv
+n = int(sys.argv[4])
+with VectorEnv(batch_num=n, scenario="cim", topology=sys.argv[2], durations=int(sys.argv[3])) as env:
+    t0 = time.perf_counter(); steps = 0
+    metrics, des, done = env.step(None)
+    while not done and time.perf_counter() - t0 < float(sys.argv[5]):
+        steps += sum(1 for d in des if d is not None)
+        metrics, des, done = env.step(None)
+    print(steps, time.perf_counter() - t0)
+"""
+    try:
+        out = subprocess.run([sys.executable, "-c", vcode, root, topology, str(durations), str(cores), str(budget_s)], capture_output=True, text=True,
+                             timeout=budget_s * 4 + 180)
+        vs, vt = out.stdout.split()[-2:]
+        res["vector_env"] = {"value": int(vs) / float(vt), "unit": "env-steps/s", "processes": cores,
+                             "sample": f"maro.vector_env.VectorEnv(batch_num={cores}), action=None broadcast, {int(vs)} decisions in {float(vt):.1f} s"}
+    except Exception as e:
+        res["vector_env"] = {"error": str(e)[:200]}
+    return res
 
 
 def main():
