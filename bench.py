@@ -273,6 +273,18 @@ def bench_citi_bike(args):
         n_trips = float((eng.data.trip_tick < durations).sum())
         b_step = (3.0 + tbar / res) * F + 20.0 * (n_trips / durations) * tbar + 40.0   # SURVEY.md §8(d) general form
         achieved = b_step * n / (step_kernel_ms * 1e-3) / 1e9
+        algorithmic = achieved
+        traffic, basis = None, "algorithmic bytes (SURVEY.md 8d general form): no PMC profile of this topology / batch size in profiles/latest_pmc_citi_bike.json"
+        try:
+            with open(os.path.join(REPO, "profiles", "latest_pmc_citi_bike.json")) as fp:
+                pmc = json.load(fp)
+            for ent in pmc["entries"]:
+                if ent["topology"] == topology and ent["envs_per_launch"] == n and not args.step_budget:
+                    traffic = (2 * ent["fetch_size_kib"] + ent["write_size_kib"]) * 1024
+                    achieved = traffic / (step_kernel_ms * 1e-3) / 1e9
+                    basis = "measured HBM bytes (PMC: 2 x FETCH_SIZE + WRITE_SIZE per launch, " + pmc["source"] + ") / mean launch duration"
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": f"env-steps/sec (decision events/sec), citi_bike {topology}",
             "value": resolved / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -283,7 +295,7 @@ def bench_citi_bike(args):
                        "envs_per_gpu": n, "specialized_kernels": bool(eng.specialized), "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective)",
                        "trajectory_gather_ms_32_steps": gather_ms, "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
             "roofline": {"bound": "hbm", "kernel": "mrx_k_cb_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": step_kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "basis": basis, "algorithmic_GBps": algorithmic, "kernel_ms": step_kernel_ms,
                          "algorithmic_bytes_per_env_step": b_step, "env_steps_per_launch": n,
                          "note": "latency-bound by construction (SURVEY.md §8d: ~1 KB per env-step); the roofline fraction is judged on the CIM 22p workload"},
         }
