@@ -103,7 +103,16 @@ static int32_t mrx_cb_lds_host[MRXC_lds_words]; /* host harness: one env at a ti
 #define LDS_DMK (LDS_FUL + MRXC_w_words)
 #define LDS_SCR (LDS_DMK + 2 * MRXC_mask_words)
 #define LDS_HDR (LDS_SCR + 3 * MRXC_S)
-static_assert(LDS_HDR + CH_WORDS + CB_EV_BLOCK * 4 == MRXC_lds_words, "cb_layout.h and cb_device.h disagree on the LDS column");
+#define LDS_TWC (LDS_HDR + CH_WORDS)
+#if MRXC_ring_slots <= CB_TWC_LDS
+#define MRX_CB_TWC_LDS 1 /* the trip-window filter's (frame, tick) tag of every ring slot: read at every decision */
+#define LDS_TWC_WORDS (2 * MRXC_ring_slots)
+#define TWCF(slot) LF(LDS_TWC + (slot))
+#define TWCT(slot) LF(LDS_TWC + MRXC_ring_slots + (slot))
+#else
+#define LDS_TWC_WORDS 0
+#endif
+static_assert(LDS_TWC + LDS_TWC_WORDS + CB_EV_BLOCK * 4 == MRXC_lds_words, "cb_layout.h and cb_device.h disagree on the LDS column");
 // the env header too: as a register array that rare branches (the delivery pool) modify, every join of the replay loop copied
 // all 16 words back and forth
 #define HDR(w) LF(LDS_HDR + (w))
@@ -121,6 +130,10 @@ static_assert(LDS_HDR + CH_WORDS + CB_EV_BLOCK * 4 == MRXC_lds_words, "cb_layout
 #define FUL(i) GFUL(i)
 #define DMK(i) GDMK(i)
 #define SCR(i) K.scratch[(size_t)(i) * CD(stride) + e]
+#endif
+#ifndef MRX_CB_TWC_LDS
+#define TWCF(slot) K.twc_fi[(size_t)(slot) * CD(stride) + e]
+#define TWCT(slot) K.twc_tick[(size_t)(slot) * CD(stride) + e]
 #endif
 
 // The env's place in the shared event stream (4 words per record).  LDS build: records are consumed out of a block of
@@ -320,6 +333,13 @@ MRX_DEV void rebalance_check(const CbParams& K, int e, int32_t* hd, int t) {
   }
 }
 
+// The tick at which the (complete) frame fi was snapshot: the one tick of its range with (tick + 1) % res == 0 (post_step
+// :130-147) — what the ring slot's tick word holds, without the read.
+MRX_DEV int snapshot_tick(const CbParams& K, int fi) {
+  const int lo = CD(start_tick) + fi * CD(res);
+  return lo + (CD(res) - 1 - lo % CD(res));
+}
+
 // np_backend.pyx:481-518 — frame `fi` goes to ring slot fi % ring_slots (frames are taken in increasing order)
 MRX_DEV void take_snapshot(const CbParams& K, int e, int32_t* hd, int t) {
   const int fi = (t - CD(start_tick)) / CD(res), slot = fi % CD(ring_slots);
@@ -434,10 +454,8 @@ MRX_DEV int action_scope(const CbParams& K, int e, int32_t* hd, int s, int type,
           hi_o[k] = lo_o[k] = 0;  // (frames beyond the window read row 0 twice: + 0)
           if (k < aw) {
             const int fi = fi_cur - k, slot = fi % CD(ring_slots);
-            int32_t& cfi = K.twc_fi[(size_t)slot * CD(stride) + e];
-            int32_t& ctick = K.twc_tick[(size_t)slot * CD(stride) + e];
-            if (k == 0) { ctick = t; cfi = fi; }
-            const int tb = cfi == fi ? ctick : K.ring[((size_t)slot * (CD(FW) + 1) + CD(FW)) * CD(stride) + e];
+            if (k == 0) { TWCT(slot) = t; TWCF(slot) = fi; }
+            const int tb = TWCF(slot) == fi ? TWCT(slot) : snapshot_tick(K, fi);
             int w0 = tb / CD(res) * CD(res);
             if (w0 < CD(start_tick)) w0 = CD(start_tick);
             hi_o[k] = (tb + 1 - CD(start_tick)) * S;
@@ -456,10 +474,8 @@ MRX_DEV int action_scope(const CbParams& K, int e, int32_t* hd, int s, int type,
         for (int i = 0; i < n; i++) SCR(2 * S + i) = 0;
         for (int fi = first; fi <= fi_cur; fi++) {
           const int slot = fi % CD(ring_slots);
-          int32_t& cfi = K.twc_fi[(size_t)slot * CD(stride) + e];
-          int32_t& ctick = K.twc_tick[(size_t)slot * CD(stride) + e];
-          if (fi == fi_cur && (aw > 0 || cfi != fi)) { ctick = t; cfi = fi; }
-          const int tb = cfi == fi ? ctick : K.ring[((size_t)slot * (CD(FW) + 1) + CD(FW)) * CD(stride) + e];
+          if (fi == fi_cur && (aw > 0 || TWCF(slot) != fi)) { TWCT(slot) = t; TWCF(slot) = fi; }
+          const int tb = TWCF(slot) == fi ? TWCT(slot) : snapshot_tick(K, fi);
           int w0 = tb / CD(res) * CD(res);  // the frame reset before tick tb happened at the end of tick w0 - 1 (post_step :130-147)
           if (w0 < CD(start_tick)) w0 = CD(start_tick);
           const int32_t* hi = K.req_cum + (size_t)(tb + 1 - CD(start_tick)) * S;
@@ -540,6 +556,9 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     for (int w = 0; w < MRXC_S; w++) LF(LDS_CAP + w) = K.capacity[w];
     for (int w = 0; w < MRXC_w_words; w++) LF(LDS_FUL + w) = (int32_t)GFUL(w);
     for (int w = 0; w < 2 * MRXC_mask_words; w++) LF(LDS_DMK + w) = (int32_t)GDMK(w);
+#ifdef MRX_CB_TWC_LDS
+    for (int w = 0; w < MRXC_ring_slots; w++) { TWCF(w) = K.twc_fi[(size_t)w * CD(stride) + e]; TWCT(w) = K.twc_tick[(size_t)w * CD(stride) + e]; }
+#endif
 #endif
     P.mark(0);
     // a paused env stands AT the TICK_END record of its decision tick, with that tick's deliveries already done
@@ -606,7 +625,10 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     }
     P.mark(5);
     if (dec_s >= 0) {  // (reconverged again: every lane of the wave that found a decision computes its scope together)
-      // core.py:345 takes a snapshot of the current frame here; queries alias it to the live frame instead
+      // core.py:345 takes a snapshot of the current frame here; queries alias it to the live frame instead — the frame's own
+      // post_step snapshot comes later and overwrites it anyway.  Except when start_tick is not a multiple of the snapshot
+      // resolution: then a frame's post_step snapshot falls on an EARLIER tick of the frame and this one is what stays.
+      if (t > snapshot_tick(K, (t - CD(start_tick)) / CD(res))) take_snapshot(K, e, hd, t);
       flags |= CFL_PENDING;
       HDR(CH_CUR_STATION) = dec_s;
       HDR(CH_CUR_TYPE) = dec_type;
@@ -647,6 +669,9 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     for (int w = 0; w < MRXC_FW; w++) K.live[(size_t)w * CD(stride) + e] = LF(w);
     for (int w = 0; w < MRXC_w_words; w++) GFUL(w) = (uint32_t)LF(LDS_FUL + w);
     for (int w = 0; w < 2 * MRXC_mask_words; w++) GDMK(w) = (uint32_t)LF(LDS_DMK + w);
+#ifdef MRX_CB_TWC_LDS
+    for (int w = 0; w < MRXC_ring_slots; w++) { K.twc_fi[(size_t)w * CD(stride) + e] = TWCF(w); K.twc_tick[(size_t)w * CD(stride) + e] = TWCT(w); }
+#endif
 #endif
   }
   if (finished || !(flags & CFL_PENDING)) {  // episode over, or (step budget) no decision reached yet

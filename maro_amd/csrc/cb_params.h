@@ -17,6 +17,7 @@ enum { CH_TICK, CH_FLAGS, CH_CUR_STATION, CH_CUR_TYPE, CH_TT_POS, CH_TRIPS, CH_S
 enum { CFL_FRESH = 1, CFL_FINISHED = 2, CFL_PENDING = 4 };
 enum { CB_POOL_WORDS = 5 };  // land tick, scheduling tick, from, to, number (<0: executed)
 #define CB_NO_LAND 0x7fffffff
+#define CB_TWC_LDS 32            /* the trip-window filter's per-slot words ride in the LDS column when the ring has at most this many slots */
 #define CB_TWC_REG 12            /* trip-window frames whose table rows are kept in registers (cb_device.h::action_scope) */
 #define CB_EV_BLOCK 8            /* event records per look-ahead block (cb_device.h::EvWin) */
 #define MRX_CB_LDS_BYTES 65536   /* LDS one workgroup (= one wave) of the step kernel may take */

@@ -31,6 +31,12 @@ mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __
     for (int w = r0; w < MRXC_FW; w += rstep) MRX_CB_LFX(w) = K.live[(size_t)w * CD(stride) + cbase];
     for (int w = r0; w < MRXC_S; w += rstep) MRX_CB_LFX(LDS_CAP + w) = K.capacity[w];
     for (int w = r0; w < CH_WORDS; w += rstep) MRX_CB_LFX(LDS_HDR + w) = K.hdr[(size_t)w * CD(stride) + cbase];
+#ifdef MRX_CB_TWC_LDS
+    for (int w = r0; w < MRXC_ring_slots; w += rstep) {
+      MRX_CB_LFX(LDS_TWC + w) = K.twc_fi[(size_t)w * CD(stride) + cbase];
+      MRX_CB_LFX(LDS_TWC + MRXC_ring_slots + w) = K.twc_tick[(size_t)w * CD(stride) + cbase];
+    }
+#endif
     for (int w = r0; w < MRXC_w_words; w += rstep) MRX_CB_LFX(LDS_FUL + w) = (int32_t)K.fulfilled[(size_t)w * CD(stride) + cbase];
     for (int w = r0; w < 2 * MRXC_mask_words; w += rstep) MRX_CB_LFX(LDS_DMK + w) = (int32_t)K.decmask[(size_t)w * CD(stride) + cbase];
   }
@@ -56,6 +62,12 @@ mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __
 #pragma unroll 4
     for (int w = r0; w < MRXC_FW; w += rstep) K.live[(size_t)w * CD(stride) + cbase] = MRX_CB_LFX(w);
     for (int w = r0; w < CH_WORDS; w += rstep) K.hdr[(size_t)w * CD(stride) + cbase] = MRX_CB_LFX(LDS_HDR + w);
+#ifdef MRX_CB_TWC_LDS
+    for (int w = r0; w < MRXC_ring_slots; w += rstep) {
+      K.twc_fi[(size_t)w * CD(stride) + cbase] = MRX_CB_LFX(LDS_TWC + w);
+      K.twc_tick[(size_t)w * CD(stride) + cbase] = MRX_CB_LFX(LDS_TWC + MRXC_ring_slots + w);
+    }
+#endif
     for (int w = r0; w < MRXC_w_words; w += rstep) K.fulfilled[(size_t)w * CD(stride) + cbase] = (uint32_t)MRX_CB_LFX(LDS_FUL + w);
     for (int w = r0; w < 2 * MRXC_mask_words; w += rstep) K.decmask[(size_t)w * CD(stride) + cbase] = (uint32_t)MRX_CB_LFX(LDS_DMK + w);
   }

@@ -41,6 +41,10 @@ CASES = {
     # city.180s: the seeded synthetic city-shaped topology (maro_amd/citi_bike/synthetic.py: 180 stations, 24 neighbours each,
     # the default distance 20 -> requirements 10 -> trip_window 6 chain), written as a MARO build folder by maro_amd's own
     # binary writer and run through the reference's Env: ~60 deciding stations per decision tick
+    # start_tick not a multiple of the snapshot resolution: a frame's post_step snapshot falls on its FIRST ticks and the
+    # pre-decision snapshots (core.py:345) of later ticks of the frame are what stays in the snapshot list
+    "cb_filters_start27_d500_r7_ring5_half": ("toy.5s_filters", dict(start_tick=27, durations=500, snapshot_resolution=7, max_snapshots=5), "half"),
+    "cb_tight_start13_d600_r10_all": ("toy.3s_tight", dict(start_tick=13, durations=600, snapshot_resolution=10), "all"),
     "cb_city180_d1440_r10_ring16_half": ("city.180s", dict(durations=1440, snapshot_resolution=10, max_snapshots=16), "half"),
     "cb_city180_d2000_r20_ring9_all": ("city.180s", dict(durations=2000, snapshot_resolution=20, max_snapshots=9), "all"),
 }
@@ -73,7 +77,7 @@ def worker(maro_root, stubs, case, out_path):
     topology, kwargs, policy = CASES[case]
     ensure_synthetic(maro_root, topology)
     np.random.seed(0)
-    env = Env("citi_bike", topology, start_tick=0, **kwargs)
+    env = Env("citi_bike", topology, **{"start_tick": 0, **kwargs})
     decs, scopes, mets, acts = [], [], [], []
     m, de, done = env.step(None)
     while not done:

@@ -11,6 +11,8 @@ from tests.emu.cb_emu import CbEmuBackend
     ("toy.3s_4t", dict(durations=1440, snapshot_resolution=10), 12),
     ("toy.3s_tight", dict(durations=1100, snapshot_resolution=7, max_snapshots=9), 12),
     ("toy.3s_tight", dict(start_tick=300, durations=500, snapshot_resolution=1), 6),
+    ("toy.5s_filters", dict(start_tick=13, durations=600, snapshot_resolution=10), 6),   # frames not aligned with the resolution
+    ("toy.5s_filters", dict(start_tick=27, durations=500, snapshot_resolution=7, max_snapshots=5), 6),
 ])
 def test_batch_matches_oracle(topology, kwargs, n):
     data = load_topology(topology)
@@ -44,3 +46,12 @@ def test_bounded_steps_do_not_change_trajectories(budget, specialized):
     b = B(data, n_envs=6, max_actions=1, **kw)
     calls, unready = run_bounded_vs_oracle(b, data, kw, seeds=np.arange(6) + 3, budget=budget)
     assert unready > 0 and calls > 50
+
+
+@pytest.mark.parametrize("kwargs", [dict(start_tick=13, durations=600, snapshot_resolution=10), dict(start_tick=27, durations=500, snapshot_resolution=7, max_snapshots=5)])
+def test_batch_matches_oracle_specialized_unaligned_frames(kwargs):
+    """The LDS-frame build with the trip-window tags in the LDS column and the computed snapshot tick, start_tick % resolution != 0."""
+    import functools
+    data = load_topology("toy.5s_filters")
+    b = functools.partial(CbEmuBackend, specialized=True)(data, n_envs=5, max_actions=1, **kwargs)
+    run_batch_vs_oracle(b, data, kwargs, seeds=np.arange(5) + 11, episodes=2)
