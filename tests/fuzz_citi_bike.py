@@ -56,6 +56,8 @@ def run_case(case_seed, backend=None):
     kw = dict(durations=int(rng.choice([150, 400])), snapshot_resolution=int(rng.choice([1, 4, 10])))
     if rng.rand() < 0.4:
         kw["max_snapshots"] = int(rng.randint(2, 12))
+    if rng.rand() < 0.35 and kw["durations"] == 150:   # start ticks that are not multiples of the snapshot / decision resolutions
+        kw["start_tick"] = int(rng.choice([7, 33, 101, 240]))
     b = CbEmuBackend(data, n_envs=3, max_actions=1, **kw)
     try:
         return run_batch_vs_oracle(b, data, kw, seeds=np.arange(3) + case_seed, episodes=1)
