@@ -66,8 +66,10 @@ def run_case(case_seed, durations=70, backend=None):
     rng = np.random.RandomState(case_seed)
     conf = random_conf(rng)
     try:
-        return run_pair(copy.deepcopy(conf), durations=durations, resolution=int(rng.choice([1, 1, 3])), seed=int(rng.randint(0, 10**6)),
-                        min_steps=0, backend=backend or EmuBackend)
+        res, seed = int(rng.choice([1, 1, 3])), int(rng.randint(0, 10**6))
+        start = int(rng.choice([0, 0, 0, 5, 13, 37]))   # start_tick > 0: departures before it never ran ("zombie" vessels)
+        return run_pair(copy.deepcopy(conf), durations=durations, resolution=res, seed=seed, min_steps=0, backend=backend or EmuBackend,
+                        start_tick=start)
     except Exception:
         import json
         print("FAILING CASE seed", case_seed, json.dumps(conf)[:2000])

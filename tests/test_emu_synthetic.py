@@ -82,12 +82,12 @@ def variants():
 VARIANTS = variants()
 
 
-def run_pair(conf, durations, resolution=1, ring=None, seed=5, policy=True, min_steps=11, backend=EmuBackend):
+def run_pair(conf, durations, resolution=1, ring=None, seed=5, policy=True, min_steps=11, backend=EmuBackend, start_tick=0):
     topo = parse_config(copy.deepcopy(conf), name="synthetic")
-    o = CimOracle(topo, durations=durations, snapshot_resolution=resolution, max_snapshots=ring)
+    o = CimOracle(topo, start_tick=start_tick, durations=durations, snapshot_resolution=resolution, max_snapshots=ring)
     o.set_seed(seed)
     o.reset(keep_seed=True)
-    e = SingleEnvAdapter(backend(topo, 1, durations=durations, snapshot_resolution=resolution, max_snapshots=ring, max_actions=3), seed=seed)
+    e = SingleEnvAdapter(backend(topo, 1, start_tick=start_tick, durations=durations, snapshot_resolution=resolution, max_snapshots=ring, max_actions=3), seed=seed)
     om, od, odone = o.step(None)
     em, ed, edone = e.step(None)
     n = 0
