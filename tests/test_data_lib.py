@@ -163,3 +163,18 @@ def test_compiled_real_data_folder_steps_identically_on_engine_and_oracle(tmp_pa
         om, od, odone = o.step([a])
         k += 1
     assert done.all() and np.array_equal(met[0], om) and k > 5
+
+
+def test_reader_semantics_match_the_reference_readers():
+    """pick_ticks / items_in_range against what the REAL BinaryReader yielded (oracle/gen_golden_data_lib.py: sorted, duplicated
+    and out-of-order timestamps, units s / m / h, windows that start before / at the first record)."""
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data_lib_reader_kat.json")))
+    assert len(gold["cases"]) >= 10
+    for c in gold["cases"]:
+        ts = np.array(c["timestamps"], np.int64)
+        assert pick_ticks(ts, c["starttime"], c["n_ticks"], c["unit"]).tolist() == c["ticks"], c
+        rec = np.zeros(len(ts), dtype=[("timestamp", "<i8"), ("idx", "<i4")])
+        rec["timestamp"], rec["idx"] = ts, np.arange(len(ts))
+        lo, hi = c["range"]
+        assert items_in_range(rec, c["starttime"], lo, hi, time_unit=c["unit"])["idx"].tolist() == c["range_idx"], c
