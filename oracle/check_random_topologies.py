@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Pins the C oracle against the REAL reference on RANDOM topologies — ORACLE tooling (needs oracle/build_ref.sh; log committed
+next to this file).  The goldens pin the oracle on 26 hand-picked cases; the device code is fuzzed against the oracle on
+hundreds of random topologies (tests/fuzz_topologies.py).  This script closes the triangle: the same random configs
+(tests.fuzz_topologies.random_conf: ports, routes that visit a port twice, noisy / zero buffer ticks, both order modes,
+random start ticks and snapshot resolutions) are written as config.yml, run through the reference's own Env in a fresh
+process each (its RNG registry is process-global), and compared with the oracle decision by decision, metric by metric, and
+on the full ports / vessels snapshot tensors at the end.
+
+    python oracle/check_random_topologies.py [first_seed=0] [count=40]
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+MARO = os.environ.get("MARO_REFERENCE_BUILD", "/tmp/oracle/maro_src")
+
+
+def worker(case_seed):
+    os.environ.setdefault("HOME", "/tmp/oracle/home")
+    os.environ.setdefault("SKIP_DEPLOYMENT", "TRUE")
+    sys.path.insert(0, MARO)
+    sys.path.insert(0, REPO)   # (the reference checkout has a `tests` package of its own: ours must come first)
+    import copy
+
+    import numpy as np
+    import yaml
+    from maro.simulator import Env
+    from maro.simulator.scenarios.cim.common import Action, ActionType
+
+    from maro_amd.cim.topology import parse_config
+    from oracle.cim_oracle import CimOracle, hash_policy_action
+    from tests.fuzz_topologies import random_conf
+    from tests.golden_util import PORT_ATTRS, VESSEL_ATTRS
+    def plain(x):   # numpy scalars -> Python (yaml.safe_dump)
+        if isinstance(x, dict):
+            return {plain(k): plain(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [plain(v) for v in x]
+        return x.item() if isinstance(x, np.generic) else x
+
+    rng = np.random.RandomState(case_seed)
+    conf = plain(random_conf(rng))
+    conf["stop_number"] = [max(2, int(x)) for x in conf["stop_number"]]   # the reference breaks on 1-slot stop lists (vessel.py:110)
+    res, seed = int(rng.choice([1, 1, 3])), int(rng.randint(0, 10**6))
+    start = int(rng.choice([0, 0, 0, 5, 13, 37]))
+    durations = 120
+    folder = tempfile.mkdtemp(prefix="rnd_topo_")
+    with open(os.path.join(folder, "config.yml"), "w") as fp:
+        yaml.safe_dump(copy.deepcopy(conf), fp, sort_keys=False)
+    class RefRaised(Exception):
+        pass
+
+    def ref(fn, *a, **k):   # a config the reference itself cannot run (its own asserts / slot-1 bug) is outside the comparison
+        try:
+            return fn(*a, **k)
+        except Exception as e:  # noqa: BLE001
+            raise RefRaised(f"{type(e).__name__}: {str(e)[:80]}")
+
+    try:
+        env = ref(Env, scenario="cim", topology=folder, start_tick=start, durations=durations, snapshot_resolution=res)
+        env.set_seed(seed)
+        ref(env.reset, keep_seed=True)
+    except RefRaised as e:
+        print(json.dumps(dict(seed=case_seed, skipped="the reference raises on this config: " + str(e))))
+        return
+    o = CimOracle(parse_config(copy.deepcopy(conf), name="rnd"), start_tick=start, durations=durations, snapshot_resolution=res)
+    o.set_seed(seed)
+    o.reset(keep_seed=True)
+    try:
+        m, de, done = ref(env.step, None)
+    except RefRaised as e:
+        print(json.dumps(dict(seed=case_seed, skipped="the reference raises on this config: " + str(e))))
+        return
+    om, od, odone = o.step(None)
+    n = 0
+    while True:
+        assert done == odone, (n, done, odone)
+        assert [m["order_requirements"], m["container_shortage"], m["operation_number"]] == [int(x) for x in om], (n, m, om)
+        if done:
+            break
+        row = [de.tick, de.port_idx, de.vessel_idx, de.action_scope.load, de.action_scope.discharge, de.early_discharge, env.frame_index, 1]
+        assert row == [int(x) for x in od], (n, row, od)
+        a = hash_policy_action(seed, n, od)
+        try:
+            m, de, done = ref(env.step, Action(int(a[0]), int(a[1]), int(a[2]), ActionType.LOAD if a[3] == 0 else ActionType.DISCHARGE))
+        except RefRaised as e:
+            print(json.dumps(dict(seed=case_seed, steps=n, skipped="the reference raises mid-episode (compared equal until then): " + str(e))))
+            return
+        om, od, odone = o.step([a])
+        n += 1
+    sl = env.snapshot_list
+    assert sl.get_frame_index_list() == o.frame_indices()
+    assert np.array_equal(sl["ports"][::PORT_ATTRS], o.query("ports", [], [], PORT_ATTRS))
+    assert np.array_equal(sl["vessels"][::VESSEL_ATTRS], o.query("vessels", [], [], VESSEL_ATTRS))
+    print(json.dumps(dict(seed=case_seed, steps=n, start_tick=start, resolution=res, ports=len(conf["ports"]), vessels=len(conf["vessels"]),
+                          order_mode=conf.get("order_generate_mode", "fixed"))))
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--worker":
+        worker(int(sys.argv[2]))
+        return
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    ok, skipped, bad, steps = 0, 0, [], 0
+    for s in range(first, first + count):
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", str(s)], capture_output=True, text=True, timeout=600)
+        if out.returncode == 0:
+            line = out.stdout.strip().splitlines()[-1]
+            r = json.loads(line)
+            steps += r.get("steps", 0)
+            if "skipped" in r:
+                skipped += 1
+            else:
+                ok += 1
+            print(line)
+        else:
+            bad.append(s)
+            print("FAILED seed", s, out.stderr.strip().splitlines()[-1][:300])
+    print(f"{ok} of {count} random topologies compared in full ({steps} decisions): the C oracle equals the reference (decisions, metrics, ports / vessels "
+          f"snapshot history); {skipped} configs the reference itself cannot run; failures: {bad}")
+
+
+if __name__ == "__main__":
+    main()
