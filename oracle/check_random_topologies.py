@@ -46,6 +46,12 @@ def worker(case_seed):
     rng = np.random.RandomState(case_seed)
     conf = plain(random_conf(rng))
     conf["stop_number"] = [max(2, int(x)) for x in conf["stop_number"]]   # the reference breaks on 1-slot stop lists (vessel.py:110)
+    if case_seed % 2:   # every other config: noise small enough that no noised ratio turns negative — the reference asserts that
+        for p in conf["ports"].values():   # every generated order is handed out (cim_data_container.py:396), which negative ratios break
+            od = p["order_distribution"]
+            od["source"]["noise"] = min(od["source"]["noise"], 0.45 * od["source"]["proportion"])
+            for t in od.get("targets", {}).values():
+                t["noise"] = min(t["noise"], 0.45 * t["proportion"])
     res, seed = int(rng.choice([1, 1, 3])), int(rng.randint(0, 10**6))
     start = int(rng.choice([0, 0, 0, 5, 13, 37]))
     durations = 120
