@@ -109,6 +109,10 @@ MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
 #define V_KRL(v) L.priv[KD(pv_krl) + (v)]  /* next_loc mod (route_len + 1) */
 #define V_PERIOD(v) L.priv[KD(pv_period) + (v)]  /* vessel_period_without_noise of this env's data */
 #define U(x) wave::uniform(x)
+// start_tick is not a multiple of the snapshot resolution: a frame's post_step snapshot then falls on an EARLY tick of the frame,
+// and the pre-decision snapshots (core.py:345) of its later ticks are what stays in the snapshot list — they can no longer be
+// aliased to the live frame, every decision writes one (and takes the full path: the fast path never stages the frame)
+#define MRX_UNALIGNED_FRAMES (KD(resolution) > 1 && KD(start_tick) % KD(resolution) != 0)
 #define RING_FULL(slot, k) L.priv[KD(pv_rfull) + (slot) * KD(NT) + (k)]
 #define RING_EMPTY(slot, p) L.priv[KD(pv_rempty) + (slot) * KD(P) + (p)]
 
@@ -1235,7 +1239,7 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
     if (lane == 0) *done_out = 1;
     return true;
   }
-  if (flags & FL_FRESH) return false;
+  if ((flags & FL_FRESH) || MRX_UNALIGNED_FRAMES) return false;
   const uint64_t pend = ((uint64_t)(uint32_t)wave::bcast(hdr, PH_PEND_HI) << 32) | (uint32_t)wave::bcast(hdr, PH_PEND_LO);
   const int cur = wave::bcast(hdr, PH_CUR_VESSEL);
   const uint64_t pend_after = pend & ~(1ull << (cur & 63));
@@ -1354,7 +1358,7 @@ MRX_DEV bool fast_step_lane(const CimParams& K, const CimObs& O, int env, const 
     *done_out = 1;
     return true;
   }
-  if (flags & FL_FRESH) return false;
+  if ((flags & FL_FRESH) || MRX_UNALIGNED_FRAMES) return false;
   const uint64_t pend = ((uint64_t)(uint32_t)h0.w << 32) | (uint32_t)h0.z;  // PH_PEND_HI, PH_PEND_LO
   const int cur = h1.x;                                                       // PH_CUR_VESSEL
   const uint64_t pend_after = pend & ~(1ull << (cur & 63));
@@ -1648,6 +1652,14 @@ MRX_DEV StepEnd body_run(const CimParams& K, const CimObs& O, int env, Lds& L, c
     }
   }
 
+  if (MRX_UNALIGNED_FRAMES && !finished) {  // the pre-decision snapshot of core.py:345, where it is not overwritten later
+    const int fi0 = (t - KD(start_tick)) / KD(resolution), lo = KD(start_tick) + fi0 * KD(resolution);
+    if (t > lo + (KD(resolution) - 1 - lo % KD(resolution))) {  // the frame's post_step snapshot (tick + 1) % resolution == 0 is already behind
+      wave::sync();
+      take_snapshot(K, O, env, L, fi0);
+      wave::sync();
+    }
+  }
   // ---- outputs (into registers; body_emit stores them)
   long long acc_b = 0, acc_s = 0;
   if (lane < P) { acc_b = FP(PA_ACC_BOOKING, lane); acc_s = FP(PA_ACC_SHORTAGE, lane); }
@@ -1714,7 +1726,7 @@ MRX_DEV StepEnd body_run(const CimParams& K, const CimObs& O, int env, Lds& L, c
   out.status = c.status;
   // the coming step of this env: fast path iff (Sequential mode and) answering dec_v leaves another decision of the
   // tick pending, or the episode is over (the fast path reports "finished"); else a tick will run -> full path
-  out.hint = (KD(decision_mode) == 0 && (finished || (pend & ~(1ull << (dec_v & 63))))) ? 0 : 1;
+  out.hint = (KD(decision_mode) == 0 && !MRX_UNALIGNED_FRAMES && (finished || (pend & ~(1ull << (dec_v & 63))))) ? 0 : 1;
   if (lane == 0) {
     L.priv[PH_TICK] = t;
     L.priv[PH_FLAGS] = finished ? FL_FINISHED : 0;

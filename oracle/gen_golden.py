@@ -83,6 +83,10 @@ CASES["toy5p_l05_sampler"] = ("toy.5p_ssddd_l0.5", dict(durations=160), [("run",
 CASES["gt22p_l08_full_rand0"] = ("global_trade.22p_l0.8", dict(durations=1120), [("run", "rand0", None)])
 # start_tick > 0 together with snapshot_resolution > 1 (frame_index = (tick - start_tick) // resolution, utils/common.py:81-93)
 CASES["gt22p_l08_start13_res2"] = ("global_trade.22p_l0.8", dict(start_tick=13, durations=90, snapshot_resolution=2), [("run", "rand0", None)])
+# small start ticks that are NOT multiples of the resolution and leave most vessels alive: the pre-decision snapshots (core.py:345)
+# of a frame's later ticks overwrite its post_step snapshot
+CASES["gt22p_l08_start1_res2"] = ("global_trade.22p_l0.8", dict(start_tick=1, durations=80, snapshot_resolution=2), [("run", "rand0", None)])
+CASES["toy5p_l05_start1_res3_ring5"] = ("toy.5p_ssddd_l0.5", dict(start_tick=1, durations=120, snapshot_resolution=3, max_snapshots=5), [("run", "rand0", None)])
 CASES["toy5p_l05_start40_res3_ring4"] = ("toy.5p_ssddd_l0.5", dict(start_tick=40, durations=100, snapshot_resolution=3, max_snapshots=4),
                                          [("run", "rand0", 50), ("reset", False), ("run", "rand0", None)])
 LIGHT = {"toy4p_l00_full", "gt22p_l00_full", "gt22p_l08_full_rand0"}  # only decisions/metrics kept (size)

@@ -28,12 +28,13 @@ def state_of(b):
     }
 
 
-def side_by_side(topology, modes, n=6, durations=45, obs=False, max_actions=1, steps=10**9, joint=0):
+def side_by_side(topology, modes, n=6, durations=45, obs=False, max_actions=1, steps=10**9, joint=0, start_tick=0, resolution=1):
     topo = load_topology(topology)
     seeds = np.arange(n, dtype=np.int64) * 7 + 3
     bs = []
     for m in modes:
-        kw = dict(n_envs=n, durations=durations, max_actions=max_actions, max_snapshots=4, decision_mode=joint)
+        kw = dict(n_envs=n, start_tick=start_tick, durations=durations, snapshot_resolution=resolution, max_actions=max_actions, max_snapshots=4,
+                  decision_mode=joint)
         if m == 3:
             kw.update(specialized=True, step_mode=3, pipe_waves=4, spec_obs=OBS if obs else ((), ()))
         elif m == 4:
@@ -137,3 +138,10 @@ def _make(mode):
 @pytest.mark.parametrize("name", ["gt22p_l08_rand0", "toy4p_l03_res7_ring5", "gt22p_l08_res3", "toy6p_l08_rand0", "syn_immediate_returns", "case_config_folder_kat", "real_csv_rand0", "gt22p_l08_reset_chain"])
 def test_goldens_replay_in_every_launch_form(name, mode):
     replay_case(_make(mode), name)
+
+
+@pytest.mark.parametrize("obs", [False, True])
+def test_launch_forms_agree_on_unaligned_frames(obs):
+    """start_tick not a multiple of the snapshot resolution: every decision materialises its pre-decision snapshot and takes the
+    full path (cim_device.h::MRX_UNALIGNED_FRAMES) — in every launch form."""
+    side_by_side("toy.5p_ssddd_l0.5", [1, 2, 3, 4], n=5, durations=60, obs=obs, start_tick=1, resolution=3)
