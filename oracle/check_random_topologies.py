@@ -52,9 +52,10 @@ def worker(case_seed):
             od["source"]["noise"] = min(od["source"]["noise"], 0.45 * od["source"]["proportion"])
             for t in od.get("targets", {}).values():
                 t["noise"] = min(t["noise"], 0.45 * t["proportion"])
-    res, seed = int(rng.choice([1, 1, 3])), int(rng.randint(0, 10**6))
+    res, seed = int(rng.choice([1, 1, 2, 3, 5])), int(rng.randint(0, 10**6))
     start = int(rng.choice([0, 0, 1, 2, 3, 13]))   # small start ticks: only SOME vessels' first departure falls before them ("zombie" vessels)
-    durations = 120
+    durations = int(rng.choice([120, 120, 200]))
+    ring = None if rng.rand() < 0.6 else int(rng.randint(2, 9))   # a small snapshot ring: eviction order
     folder = tempfile.mkdtemp(prefix="rnd_topo_")
     with open(os.path.join(folder, "config.yml"), "w") as fp:
         yaml.safe_dump(copy.deepcopy(conf), fp, sort_keys=False)
@@ -68,20 +69,20 @@ def worker(case_seed):
             raise RefRaised(f"{type(e).__name__}: {str(e)[:80]}")
 
     try:
-        env = ref(Env, scenario="cim", topology=folder, start_tick=start, durations=durations, snapshot_resolution=res)
+        env = ref(Env, scenario="cim", topology=folder, start_tick=start, durations=durations, snapshot_resolution=res, max_snapshots=ring)
         env.set_seed(seed)
         ref(env.reset, keep_seed=True)
     except RefRaised as e:
         print(json.dumps(dict(seed=case_seed, skipped="the reference raises on this config: " + str(e))))
         return
-    o = CimOracle(parse_config(copy.deepcopy(conf), name="rnd"), start_tick=start, durations=durations, snapshot_resolution=res)
+    o = CimOracle(parse_config(copy.deepcopy(conf), name="rnd"), start_tick=start, durations=durations, snapshot_resolution=res, max_snapshots=ring)
     o.set_seed(seed)
     o.reset(keep_seed=True)
     mode = [0, 0, 1, 2][case_seed % 4]   # Sequential twice as often as each Joint mode
     if mode:
         from maro.simulator import DecisionMode
         try:
-            env = ref(Env, scenario="cim", topology=folder, start_tick=start, durations=durations, snapshot_resolution=res, decision_mode=DecisionMode(mode))
+            env = ref(Env, scenario="cim", topology=folder, start_tick=start, durations=durations, snapshot_resolution=res, max_snapshots=ring, decision_mode=DecisionMode(mode))
             env.set_seed(seed)
             ref(env.reset, keep_seed=True)
         except RefRaised as e:

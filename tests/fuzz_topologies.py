@@ -66,9 +66,10 @@ def run_case(case_seed, durations=70, backend=None):
     rng = np.random.RandomState(case_seed)
     conf = random_conf(rng)
     try:
-        res, seed = int(rng.choice([1, 1, 3])), int(rng.randint(0, 10**6))
+        res, seed = int(rng.choice([1, 1, 2, 3, 5])), int(rng.randint(0, 10**6))
         start = int(rng.choice([0, 0, 1, 2, 3, 13]))   # start_tick > 0: departures before it never ran ("zombie" vessels); small ones keep some alive
-        return run_pair(copy.deepcopy(conf), durations=durations, resolution=res, seed=seed, min_steps=0, backend=backend or EmuBackend,
+        ring = None if rng.rand() < 0.6 else int(rng.randint(2, 9))   # a small snapshot ring: eviction order
+        return run_pair(copy.deepcopy(conf), durations=durations, resolution=res, ring=ring, seed=seed, min_steps=0, backend=backend or EmuBackend,
                         start_tick=start)
     except Exception:
         import json
