@@ -94,23 +94,33 @@ def worker(case_seed):
         print(json.dumps(dict(seed=case_seed, skipped="the reference raises on this config: " + str(e))))
         return
     n = 0
+    segments = 2 if (mode == 0 and case_seed % 3 == 0) else 1   # Sequential, every third config: a second episode after reset(keep_seed=False)
     if mode == 0:
+      for seg in range(segments):
+        if seg:   # cim_data_container_helpers.py:58-60: the new seed is drawn from the route stream as the first episode left it
+            try:
+                ref(env.reset, keep_seed=False)
+                m, de, done = ref(env.step, None)
+            except RefRaised as e:
+                print(json.dumps(dict(seed=case_seed, steps=n, skipped="the reference raises after reset (compared equal until then): " + str(e))))
+                return
+            o.reset(keep_seed=False)
         om, od, odone = o.step(None)
         while True:
-            assert done == odone, (n, done, odone)
-            assert [m["order_requirements"], m["container_shortage"], m["operation_number"]] == [int(x) for x in om], (n, m, om)
-            if done:
-                break
-            row = [de.tick, de.port_idx, de.vessel_idx, de.action_scope.load, de.action_scope.discharge, de.early_discharge, env.frame_index, 1]
-            assert row == [int(x) for x in od], (n, row, od)
-            a = hash_policy_action(seed, n, od)
-            try:
-                m, de, done = ref(env.step, Action(int(a[0]), int(a[1]), int(a[2]), ActionType.LOAD if a[3] == 0 else ActionType.DISCHARGE))
-            except RefRaised as e:
-                print(json.dumps(dict(seed=case_seed, steps=n, skipped="the reference raises mid-episode (compared equal until then): " + str(e))))
-                return
-            om, od, odone = o.step([a])
-            n += 1
+              assert done == odone, (n, done, odone)
+              assert [m["order_requirements"], m["container_shortage"], m["operation_number"]] == [int(x) for x in om], (n, m, om)
+              if done:
+                  break
+              row = [de.tick, de.port_idx, de.vessel_idx, de.action_scope.load, de.action_scope.discharge, de.early_discharge, env.frame_index, 1]
+              assert row == [int(x) for x in od], (n, row, od)
+              a = hash_policy_action(seed, n, od)
+              try:
+                  m, de, done = ref(env.step, Action(int(a[0]), int(a[1]), int(a[2]), ActionType.LOAD if a[3] == 0 else ActionType.DISCHARGE))
+              except RefRaised as e:
+                  print(json.dumps(dict(seed=case_seed, steps=n, skipped="the reference raises mid-episode (compared equal until then): " + str(e))))
+                  return
+              om, od, odone = o.step([a])
+              n += 1
     else:
         # Joint / JointWithSequentialAction (core.py:354-366), as oracle/gen_golden_joint.py drives it: the first k events answered,
         # DISCHARGE-only wherever a cached scope could be stale (the reference asserts on quantities beyond the live scope)
