@@ -70,7 +70,7 @@ def run_case(case_seed, durations=70, backend=None):
         start = int(rng.choice([0, 0, 1, 2, 3, 13]))   # start_tick > 0: departures before it never ran ("zombie" vessels); small ones keep some alive
         ring = None if rng.rand() < 0.6 else int(rng.randint(2, 9))   # a small snapshot ring: eviction order
         return run_pair(copy.deepcopy(conf), durations=durations, resolution=res, ring=ring, seed=seed, min_steps=0, backend=backend or EmuBackend,
-                        start_tick=start)
+                        start_tick=start, segments=2 if case_seed % 3 == 0 else 1)
     except Exception:
         import json
         print("FAILING CASE seed", case_seed, json.dumps(conf)[:2000])

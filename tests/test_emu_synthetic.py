@@ -82,7 +82,7 @@ def variants():
 VARIANTS = variants()
 
 
-def run_pair(conf, durations, resolution=1, ring=None, seed=5, policy=True, min_steps=11, backend=EmuBackend, start_tick=0):
+def run_pair(conf, durations, resolution=1, ring=None, seed=5, policy=True, min_steps=11, backend=EmuBackend, start_tick=0, segments=1):
     topo = parse_config(copy.deepcopy(conf), name="synthetic")
     o = CimOracle(topo, start_tick=start_tick, durations=durations, snapshot_resolution=resolution, max_snapshots=ring)
     o.set_seed(seed)
@@ -93,6 +93,13 @@ def run_pair(conf, durations, resolution=1, ring=None, seed=5, policy=True, min_
     n = 0
     while True:
         assert odone == edone and np.array_equal(om, em), (n, om, em)
+        if odone and segments > 1:   # a second episode after Env.reset(keep_seed=False): the seed is re-drawn from the route stream
+            segments -= 1
+            o.reset(keep_seed=False)
+            e.reset(keep_seed=False)
+            om, od, odone = o.step(None)
+            em, ed, edone = e.step(None)
+            continue
         if odone:
             break
         assert np.array_equal(od, ed), (n, od, ed)
