@@ -114,12 +114,15 @@ def worker(case_seed):
               row = [de.tick, de.port_idx, de.vessel_idx, de.action_scope.load, de.action_scope.discharge, de.early_discharge, env.frame_index, 1]
               assert row == [int(x) for x in od], (n, row, od)
               a = hash_policy_action(seed, n, od)
+              acts = [a]
+              if n % 5 == 0:   # several actions on one decision: the quantity split in two (the same kind of action twice is always legal)
+                  acts = [(a[0], a[1], a[2] // 2, a[3]), (a[0], a[1], a[2] - a[2] // 2, a[3])]
               try:
-                  m, de, done = ref(env.step, Action(int(a[0]), int(a[1]), int(a[2]), ActionType.LOAD if a[3] == 0 else ActionType.DISCHARGE))
+                  m, de, done = ref(env.step, [Action(int(x[0]), int(x[1]), int(x[2]), ActionType.LOAD if x[3] == 0 else ActionType.DISCHARGE) for x in acts])
               except RefRaised as e:
                   print(json.dumps(dict(seed=case_seed, steps=n, skipped="the reference raises mid-episode (compared equal until then): " + str(e))))
                   return
-              om, od, odone = o.step([a])
+              om, od, odone = o.step(acts)
               n += 1
     else:
         # Joint / JointWithSequentialAction (core.py:354-366), as oracle/gen_golden_joint.py drives it: the first k events answered,
