@@ -3,7 +3,8 @@
 (needs oracle/build_ref.sh; log committed next to this file).  A random config of tests/fuzz_topologies.py is dumped with the
 reference's own `dump_from_config` (cim_data_dump.py:259-278), the dump folder is run through the reference's `Env` (data_from_dumps,
 cim_data_container_helpers.py:73-123) and through `maro_amd.cim.topology.load_data_folder` + the C oracle, and the two are
-compared decision by decision, metric by metric and on the ports / vessels snapshot history.
+compared decision by decision, metric by metric and on the ports / vessels snapshot history; then the engine's device code
+(host-compiled on the CPU wave emulator) replays the same compiled dump against the oracle.
 
     python oracle/check_random_dumps.py [first_seed=0] [count=30]
 """
@@ -90,7 +91,28 @@ def worker(case_seed):
     assert sl.get_frame_index_list() == o.frame_indices()
     assert np.array_equal(sl["ports"][::PORT_ATTRS], o.query("ports", [], [], PORT_ATTRS))
     assert np.array_equal(sl["vessels"][::VESSEL_ATTRS], o.query("vessels", [], [], VESSEL_ATTRS))
-    print(json.dumps(dict(seed=case_seed, steps=n, resolution=res, durations=durations, ports=len(conf["ports"]), vessels=len(conf["vessels"]))))
+    # ... and the DEVICE code (host-compiled, CPU wave emulator) on the same compiled dump: data_mode 1 of the engine
+    from tests.backend_adapter import SingleEnvAdapter
+    from tests.emu.emu import EmuBackend
+    from tests.golden_util import MATRIX_ATTRS
+    o2 = CimOracle(topo, durations=durations, snapshot_resolution=res)
+    e = SingleEnvAdapter(EmuBackend(topo, 1, durations=durations, snapshot_resolution=res, max_actions=2))
+    om, od, odone = o2.step(None)
+    em, ed, edone = e.step(None)
+    k = 0
+    while True:
+        assert odone == edone and np.array_equal(om, em), (k, om, em)
+        if odone:
+            break
+        assert np.array_equal(od, ed), (k, od, ed)
+        a = hash_policy_action(case_seed, k, od)
+        om, od, odone = o2.step([a])
+        em, ed, edone = e.step([a])
+        k += 1
+    assert k == n and e.frame_indices() == o2.frame_indices()
+    for node, attrs in (("ports", PORT_ATTRS), ("vessels", VESSEL_ATTRS), ("matrices", MATRIX_ATTRS)):
+        assert np.array_equal(e.query(node, [], [], attrs), o2.query(node, [], [], attrs)), node
+    print(json.dumps(dict(seed=case_seed, steps=n, resolution=res, durations=durations, ports=len(conf["ports"]), vessels=len(conf["vessels"]), device_code="equal")))
 
 
 def main():
@@ -111,7 +133,7 @@ def main():
         else:
             bad.append(s)
             print("FAILED seed", s, out.stderr.strip().splitlines()[-1][:300])
-    print(f"{ok} of {count} random dump folders compared in full ({steps} decisions): native reader + oracle equal the reference; {skipped} skipped; failures: {bad}")
+    print(f"{ok} of {count} random dump folders compared in full ({steps} decisions): native reader + oracle equal the reference, device code (emulator) equals the oracle; {skipped} skipped; failures: {bad}")
 
 
 if __name__ == "__main__":
