@@ -20,7 +20,10 @@ import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = {"toy5p_l05": ("toy.5p_ssddd_l0.5", 320, [60, 90, 45, None]), "gt22p_l08": ("global_trade.22p_l0.8", 230, [150, 200, None]),
          # episodes end INSIDE calls with num_steps given: emission at the episode end, cache cleared by _reset, sampling goes on
-         "toy5p_l05_rollover": ("toy.5p_ssddd_l0.5", 150, [100, 100, 60, None])}
+         "toy5p_l05_rollover": ("toy.5p_ssddd_l0.5", 150, [100, 100, 60, None]),
+         # other topology shapes: a hub with six ports (more downstream ports than the state keeps), and short calls that end
+         # between two decisions of one tick
+         "toy6p_l08": ("toy.6p_sssbdd_l0.8", 260, [7, 33, 120, 1, None]), "toy4p_l00_rollover": ("toy.4p_ssdd_l0.0", 120, [50, 50, 50, None])}
 
 
 def main():

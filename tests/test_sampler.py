@@ -108,13 +108,13 @@ def run_sample_case(engine_factory, case, n_envs=2):
     assert k[0] == len(inter)
 
 
-@pytest.mark.parametrize("case", ["toy5p_l05", "gt22p_l08", "toy5p_l05_rollover"])
+@pytest.mark.parametrize("case", ["toy5p_l05", "gt22p_l08", "toy5p_l05_rollover", "toy6p_l08", "toy4p_l00_rollover"])
 def test_batched_sample_matches_the_reference_sampler_on_emulator(case):
     run_sample_case(emu_factory, case)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["toy5p_l05", "gt22p_l08", "toy5p_l05_rollover"])
+@pytest.mark.parametrize("case", ["toy5p_l05", "gt22p_l08", "toy5p_l05_rollover", "toy6p_l08", "toy4p_l00_rollover"])
 def test_batched_sample_matches_the_reference_sampler_on_gpu(case):
     from maro_amd.cim.engine import CimBatchEngine
     run_sample_case(lambda topo, n, **kw: CimBatchEngine(topo, n, **kw), case, n_envs=7)
