@@ -99,8 +99,22 @@ class GpuVectorEnv:
                 raise NotImplementedError(
                     f"the GPU engines implement the 'cim' and 'citi_bike' scenarios; scenario={scenario!r} / a custom "
                     f"business_engine_cls needs the reference (maro.vector_env.VectorEnv), which is not importable: {e}") from None
-            drop = ("seeds", "device", "max_actions", "specialize", "_engine")
-            return VectorEnv(batch_num, scenario=scenario, *args, **{k: v for k, v in kwargs.items() if k not in drop})
+            # bind the positional arguments by name exactly as VectorEnv.__init__ declares them (vector_env.py:62-72): a
+            # positional topology must not land in the `scenario` slot, and the GPU-only keywords are dropped
+            names = ("topology", "start_tick", "durations", "snapshot_resolution", "max_snapshots", "decision_mode",
+                     "business_engine_cls", "disable_finished_events", "options")
+            if len(args) > len(names):
+                raise TypeError(f"GpuVectorEnv takes at most {len(names) + 2} positional arguments")
+            bound = dict(zip(names, args))
+            for k, v in kwargs.items():
+                if k in bound:
+                    raise TypeError(f"GpuVectorEnv got multiple values for argument {k!r}")
+                if k not in ("seeds", "device", "max_actions", "specialize", "_engine"):
+                    bound[k] = v
+            if "decision_mode" in bound and isinstance(bound["decision_mode"], int) and not isinstance(bound["decision_mode"], bool):
+                from maro.simulator.utils.common import DecisionMode   # the GPU path takes plain ints, the reference wants the enum
+                bound["decision_mode"] = {0: DecisionMode.Sequential, 1: DecisionMode.Joint, 2: DecisionMode.JointWithSequentialAction}[bound["decision_mode"]]
+            return VectorEnv(batch_num, scenario=scenario, **bound)
         return super().__new__(cls)
 
     def __init__(self, batch_num: int, scenario: str = "cim", topology: str = None, start_tick: int = 0,
@@ -401,3 +415,70 @@ class GpuEnvView:
 
     def get_pending_events(self, tick):
         return []
+
+    @property
+    def business_engine(self) -> "_BusinessEngineView":
+        """abs_core.py:71.  The reference hands out the business engine object; callers read its frame / snapshots / metrics /
+        agent list / node mapping (abs_business_engine.py:70-200).  Here that is a read-only view over this env of the batch."""
+        return _BusinessEngineView(self)
+
+    def get_ticks_frame_index_mapping(self) -> dict:
+        """abs_core.py:174-195: tick -> frame index for the frames currently held in the snapshot list."""
+        e = self._o.engine
+        held = set(self.snapshot_list.get_frame_index_list())
+        res, t0 = {}, e.start_tick
+        for t in range(t0, self.tick + 1):
+            fi = (t - t0) // e.snapshot_resolution
+            if fi in held:
+                res[t] = fi
+        return res
+
+
+class _BusinessEngineView:
+    """``AbsBusinessEngine``-shaped read-only view (abs_business_engine.py:70-200) of one env: ``frame_index(tick)``,
+    ``snapshots``, ``get_metrics()``, ``get_agent_idx_list()``, ``get_node_mapping()``, ``configs``, ``name``,
+    ``scenario_name``.  ``frame`` is the snapshot list's owner in the reference; code that only reads it through
+    ``frame.snapshots`` keeps working (``frame.snapshots is snapshots``)."""
+
+    def __init__(self, env: GpuEnvView):
+        self._env = env
+
+    @property
+    def frame(self):
+        return self
+
+    @property
+    def snapshots(self):
+        return self._env.snapshot_list
+
+    @property
+    def configs(self) -> dict:
+        return self._env.configs
+
+    @property
+    def name(self) -> str:
+        return self._env.name
+
+    @property
+    def scenario_name(self) -> str:
+        return self._env.name.split(":")[0]
+
+    def frame_index(self, tick: int) -> int:
+        e = self._env._o.engine
+        return (tick - e.start_tick) // e.snapshot_resolution
+
+    def calc_max_snapshots(self) -> int:
+        e = self._env._o.engine
+        return int(e.layout.ring_slots)
+
+    def get_metrics(self) -> dict:
+        return self._env.metrics
+
+    def get_agent_idx_list(self) -> List[int]:
+        return self._env.agent_idx_list
+
+    def get_node_mapping(self) -> dict:
+        return self._env.summary["node_mapping"]
+
+    def get_event_payload_detail(self) -> dict:
+        return self._env.summary.get("event_payload", {})

@@ -93,6 +93,14 @@ def check_env_view(engine_factory):
     cur = view.snapshot_list["ports"][view.frame_index::["empty", "booking"]]
     assert np.array_equal(cur, o.query("ports", [int(od[6])], [], ["empty", "booking"]))
     assert view.snapshot_list.get_frame_index_list() == o.frame_indices()
+    # env.business_engine (abs_core.py:71): the read-only view callers use for frame / snapshots / metrics / agent list
+    be = view.business_engine
+    assert be.snapshots is view.snapshot_list and be.frame.snapshots is view.snapshot_list
+    assert be.get_metrics() == view.metrics and be.get_agent_idx_list() == view.agent_idx_list
+    assert be.frame_index(view.tick) == view.frame_index and be.scenario_name == "cim" and be.configs is view.configs
+    assert set(be.get_node_mapping()) == {"ports", "vessels"}
+    mapping = view.get_ticks_frame_index_mapping()
+    assert mapping[view.tick] == view.frame_index and sorted(set(mapping.values())) == view.snapshot_list.get_frame_index_list()
     with pytest.raises(InvalidActionError):
         view.step(Action(ev.vessel_idx, ev.port_idx, ev.action_scope.discharge + 1, ActionType.DISCHARGE))
     # seed protocol: set_seed + reset(keep_seed=True) -> explicit seed; reset() -> redraw from the route stream
@@ -208,3 +216,19 @@ def test_unknown_scenario_dispatches_to_the_reference_vector_env(monkeypatch):
     assert isinstance(env, FakeVectorEnv) and seen == dict(batch_num=2, scenario="vm_scheduling", topology="azure.2019.10k", durations=10)
     env = GpuVectorEnv(1, "cim", topology="toy.4p_ssdd_l0.0", durations=10, business_engine_cls=object)
     assert isinstance(env, FakeVectorEnv) and seen["business_engine_cls"] is object
+    # positional arguments after `scenario` are bound by name (a positional topology must not land in the scenario slot),
+    # and an int decision_mode becomes the reference's enum
+    dm = types.ModuleType("maro.simulator.utils.common")
+
+    class DecisionMode:
+        Sequential, Joint, JointWithSequentialAction = "seq", "joint", "jwsa"
+    dm.DecisionMode = DecisionMode
+    for name in ("maro.simulator", "maro.simulator.utils"):
+        monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    monkeypatch.setitem(sys.modules, "maro.simulator.utils.common", dm)
+    seen.clear()
+    env = GpuVectorEnv(2, "vm_scheduling", "azure.2019.10k", 0, 25, decision_mode=1, seeds=[1, 2])
+    assert isinstance(env, FakeVectorEnv)
+    assert seen == dict(batch_num=2, scenario="vm_scheduling", topology="azure.2019.10k", start_tick=0, durations=25, decision_mode="joint")
+    with pytest.raises(TypeError, match="multiple values"):
+        GpuVectorEnv(2, "vm_scheduling", "azure.2019.10k", topology="x")
