@@ -40,17 +40,21 @@ def rollout(engine, n_steps: int, policy: Callable[[int, torch.Tensor, torch.Ten
         return {"decisions": torch.stack(D), "actions": torch.stack(A), "metrics": torch.stack(M), "done": torch.stack(Dn)}
 
 
-_SHARD_SIZES: Dict[tuple, list] = {}   # (group, world, local n) -> env count of every rank (exchanged once per sharding)
+_SHARD_SIZES: Dict[object, list] = {}   # sharding token (the caller's, identical on every rank) -> env count of every rank
 
 
-def gather_to_learner(traj: Dict[str, torch.Tensor], dst: int = 0, group=None, sizes: Optional[list] = None) -> Optional[Dict[str, torch.Tensor]]:
+def gather_to_learner(traj: Dict[str, torch.Tensor], dst: int = 0, group=None, sizes: Optional[list] = None,
+                      sharding_token=None) -> Optional[Dict[str, torch.Tensor]]:
     """Concatenate every rank's trajectory along the env axis (dim 1 of tensors shaped [T, n_local, ...]) on rank `dst`.
 
     ONE grouped exchange (`batch_isend_irecv`: a single RCCL group of point-to-point transfers over xGMI on GPUs, plain
     send/recv under gloo): every rank sends each tensor exactly as it is — no padding copy, no packing copy — and `dst`
     receives each rank's piece at its true size, then joins the pieces per key (the only copy, on the learner).  Shards may
-    differ in size; the per-rank env counts are `sizes` if given (e.g. from `shard_range`), else they are exchanged once
-    per (group, sharding) and cached, so steady-state calls issue no other collective.  Returns the dict on `dst`, None elsewhere.
+    differ in size.  The per-rank env counts come from, in this order: `sizes` (e.g. computed with `shard_range`: no
+    collective at all); a previous call with the same `sharding_token` (a value EVERY rank passes identically and changes
+    whenever ANY rank's shard changes — the cache is keyed on nothing a single rank could decide alone); otherwise they are
+    exchanged in this call (one small all_gather, which also checks that the step count T is the same on every rank).
+    Returns the dict on `dst`, None elsewhere.
     Replaces the reference's pickle-over-Pipe result collection (vector_env.py:186-217) and the zmq fan-in of
     BatchEnvSampler (rl/rollout/batch_env_sampler.py:150-190)."""
     import torch.distributed as dist
@@ -60,15 +64,20 @@ def gather_to_learner(traj: Dict[str, torch.Tensor], dst: int = 0, group=None, s
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     keys = sorted(traj)
     any_t = traj[keys[0]]
-    n_local = int(any_t.shape[1])
+    n_local, t_local = int(any_t.shape[1]), int(any_t.shape[0])
+    if sizes is None and sharding_token is not None and sharding_token in _SHARD_SIZES:
+        sizes = _SHARD_SIZES[sharding_token]
     if sizes is None:
-        ck = (id(group), world, n_local)
-        if ck not in _SHARD_SIZES:
-            mine = torch.tensor([n_local], dtype=torch.int64, device=any_t.device)
-            allsz = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(allsz, mine, group=group)
-            _SHARD_SIZES[ck] = [int(x.item()) for x in allsz]
-        sizes = _SHARD_SIZES[ck]
+        mine = torch.tensor([n_local, t_local], dtype=torch.int64, device=any_t.device)
+        if any_t.device.type == "cuda" and dist.get_backend(group) == "gloo":
+            mine = mine.cpu()
+        allsz = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allsz, mine, group=group)
+        got = [[int(v) for v in x.tolist()] for x in allsz]
+        assert all(g[1] == t_local for g in got), f"gather_to_learner: the step count T differs across ranks: {[g[1] for g in got]}"
+        sizes = [g[0] for g in got]
+        if sharding_token is not None:
+            _SHARD_SIZES[sharding_token] = sizes
     assert len(sizes) == world and sizes[rank] == n_local, "sizes must list every rank's env count"
     src = {k: traj[k].contiguous() for k in keys}   # (already contiguous in a rollout loop: no copy)
     dev = any_t.device

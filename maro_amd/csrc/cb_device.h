@@ -653,7 +653,7 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
           }
         }
         for (int i = 0; i < k; i++) dec[(size_t)i * 8 + 6] = k;
-        if (k < CD(S)) dec[(size_t)k * 8 + 5] = 0;
+        for (int i = k; i < CD(S); i++) dec[(size_t)i * 8 + 5] = 0;  // every row beyond the events: valid = 0 (the buffer is the caller's and may hold an earlier report)
         HDR(CH_NDEC) += k - 1;
       }
       P.mark(6);
@@ -677,6 +677,8 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
   if (finished || !(flags & CFL_PENDING)) {  // episode over, or (step budget) no decision reached yet
     dec[0] = t; dec[1] = -1; dec[2] = -1; dec[3] = (t - CD(start_tick)) / CD(res); dec[4] = 0; dec[5] = 0; dec[6] = 0; dec[7] = 0;
     for (int i = 0; i < CD(scope_cap); i++) { scope[2 * i] = -1; scope[2 * i + 1] = -1; }
+    if (CD(decision_mode) != 0)
+      for (int i = 1; i < CD(S); i++) dec[(size_t)i * 8 + 5] = 0;  // Joint modes: no row of an earlier report stays valid
   }
   met[0] = HDR(CH_TRIPS); met[1] = HDR(CH_SHORT); met[2] = HDR(CH_OPER);
   *done = finished ? 1 : 0;

@@ -52,7 +52,7 @@ enum { PF_LOAD, PF_ACTION, PF_POST_STEP, PF_MT_LOAD, PF_ORDER_GEN, PF_DEPART_RET
 // ------------------------------------------------------------------------------------------
 // serial-access topology tables: global (L2) by default, re-pointed at the LDS copy by the step kernel
 struct Tabs {
-  const uint16_t *tgt_off, *tgt_port, *route_port, *v_route_base, *v_route_len, *leg_off, *leg_time, *rec_off, *v_cbase,
+  const uint16_t *tgt_off, *route_port, *v_route_base, *v_route_len, *leg_off, *leg_time, *rec_off, *v_cbase,
       *route_cidx, *pair_src;  // 16-bit copies (cim_plan checks the ranges)
   const int32_t *er_delay, *fr_delay;
   const double *src_base, *src_noise, *er_base, *er_noise, *fr_base, *fr_noise;
@@ -83,7 +83,7 @@ MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
   L.oq = b + KD(l_oq);
   L.srcn = b + KD(l_srcn);
   L.misc = b + KD(l_misc);
-  L.tab.tgt_off = K.h_tgt_off; L.tab.tgt_port = K.h_tgt_port; L.tab.route_port = K.h_route_port;
+  L.tab.tgt_off = K.h_tgt_off; L.tab.route_port = K.h_route_port;
   L.tab.v_route_base = K.h_v_route_base; L.tab.v_route_len = K.h_v_route_len;
   L.tab.leg_off = K.h_leg_off; L.tab.leg_time = K.h_leg_time;
   L.tab.er_delay = K.er_delay; L.tab.fr_delay = K.fr_delay; L.tab.rec_off = K.h_rec_off;
@@ -126,7 +126,7 @@ MRX_DEV void copy_in_async(int32_t* lds_dst, const int32_t* gsrc, int n_words);
 MRX_DEV void stage_tables(const CimParams& K, Lds& L, int32_t* c) {
   copy_in_async(c, K.ctab, KD(ctab_words));
 #define MRX_HTAB(f) L.tab.f = (const uint16_t*)c + (K.h_##f - (const uint16_t*)K.ctab)
-  MRX_HTAB(tgt_off); MRX_HTAB(tgt_port); MRX_HTAB(route_port); MRX_HTAB(v_route_base); MRX_HTAB(v_route_len);
+  MRX_HTAB(tgt_off); MRX_HTAB(route_port); MRX_HTAB(v_route_base); MRX_HTAB(v_route_len);
   MRX_HTAB(leg_off); MRX_HTAB(leg_time); MRX_HTAB(rec_off); MRX_HTAB(v_cbase); MRX_HTAB(route_cidx); MRX_HTAB(pair_src);
 #undef MRX_HTAB
   L.tab.er_delay = c + (K.er_delay - K.ctab); L.tab.fr_delay = c + (K.fr_delay - K.ctab);

@@ -215,6 +215,7 @@ struct mrx_cim_engine {
   int loop_waves = 0;                     // grid of the looped full-path kernel (generic or specialised build in use)
   int step_mode = 0;                      // mrx_cim_set_step_mode (0 = automatic)
   bool order_ready = false;               // the order list of the coming step was built by the policy launch (no mask)
+  void* order_stream = nullptr;           // ... on this stream: a step issued on another stream is not ordered behind that launch
   // Kernels of a module may still be queued or running on the caller's stream(s): drain the device before unloading it.
   void unload_spec() {
     if (!spec_module) return;
@@ -401,7 +402,9 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
   const bool obs = h->obs.np > 0 || h->obs.nv > 0;  // (the _obs kernels are only needed for the fused observation; the retention rows are written by every build)
   const int mode = effective_step_mode(h);
   cim::StepBatch B = {d_actions, d_n_actions, d_n_answered, d_decisions, (long long*)d_metrics, d_done};
-  const bool have_order = h->order_ready && !d_env_mask;   // built by mrx_cim_random_policy for exactly this step
+  // built by mrx_cim_random_policy for exactly this step, on this very stream (a step issued on another stream has no ordering
+  // against that launch: it rebuilds the list from the hints with its own schedule kernel)
+  const bool have_order = h->order_ready && !d_env_mask && stream == h->order_stream;
   h->order_ready = false;
   if (mode >= 2 && !have_order) {
     const int per = ((K.n_envs + 1023) / 1024 + 15) / 16 * 16;  // envs per thread, whole 16-byte pieces
@@ -527,6 +530,7 @@ int mrx_cim_random_policy(mrx_handle h, const int32_t* d_decisions, int64_t step
                      d_decisions, (long long)step, d_actions, d_n_actions, (unsigned long long*)d_counter, sched_per);
   HIP_TRY(hipGetLastError());
   h->order_ready = sched_per > 0;
+  h->order_stream = stream;
   return MRX_OK;
 }
 

@@ -280,7 +280,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
       for (size_t i = 0; i < n; i++) { if (src[i] < 0 || src[i] > 65535) fits = false; h[i] = (uint16_t)src[i]; }
       binds.push_back({(size_t)((char*)&(k.*f) - (char*)&k), blob_put(B, h.data(), h.size(), 2)});
     };
-    put_h(&CimParams::h_tgt_off, t->target_offset, P + 1); put_h(&CimParams::h_tgt_port, t->target_port, NT);
+    put_h(&CimParams::h_tgt_off, t->target_offset, P + 1);  // (target_port is only read by the reset kernel, from the int32 original)
     put_h(&CimParams::h_route_port, t->route_port, NRP);
     put_h(&CimParams::h_v_route_base, v_route_base.data(), V); put_h(&CimParams::h_v_route_len, v_route_len.data(), V);
     put_h(&CimParams::h_leg_off, leg_off.data(), V + 1); put_h(&CimParams::h_leg_time, leg_time.data(), leg_time.size());

@@ -57,7 +57,7 @@ struct CimParams {
       *fr_delay, *rec_off, *v_route, *v_cbase, *route_cidx, *cidx_dense, *pair_dense;
   const int32_t* ctab;  // start of the contiguous block staged in LDS by the step kernel (ctab_words words):
                         // per-port fp64 tables, er/fr_delay, and 16-bit copies of the serial-access int tables
-  const uint16_t *h_tgt_off, *h_tgt_port, *h_route_port, *h_v_route_base, *h_v_route_len, *h_leg_off, *h_leg_time,
+  const uint16_t *h_tgt_off, *h_route_port, *h_v_route_base, *h_v_route_len, *h_leg_off, *h_leg_time,
       *h_rec_off, *h_v_cbase, *h_route_cidx, *h_pair_src;
   // ---- per-env state (device)
   int32_t *live, *ring, *ring_fi, *priv, *rec, *status, *tick, *nstops, *order_prop, *vperiod, *orders;

@@ -169,6 +169,34 @@ extern "C" __global__ void __launch_bounds__(64) k_pattern(Pat P, const int32_t*
   if (mixu((unsigned)env, (unsigned)step + 77u) % 3u == 0u) store_rows_nt(P.mt + ((size_t)env * 3 + 1) * P.MTW, l_mt, P.MTW);
 }
 
+
+// ---- dispatch / residency probes (no HBM traffic): `mode` 1 = empty workgroups, 2 = only the latency chain (`work` dependent
+// LDS round trips for the full-path share of the list).  Every workgroup registers on its CU (HW_ID / XCC_ID) so that the
+// peak number of co-resident workgroups per CU can be read back.
+extern "C" __global__ void __launch_bounds__(64) k_probe(const int32_t* __restrict__ order, int mode, int work, int32_t* cu_now, int32_t* cu_peak) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const int lane = lane_id();
+  const int e = order[blockIdx.x];
+  unsigned cu = 0;
+  if (cu_now) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+    cu = ((xcc & 15u) << 8) | ((hw >> 8) & 0xffu);   // xcc | se, sh, cu
+    if (lane == 0) { const int n = atomicAdd(&cu_now[cu], 1) + 1; atomicMax(&cu_peak[cu], n); }
+  }
+  if (mode == 2 && e >= 0 && (e & FULL_FLAG)) {
+    int acc = e;
+    lds[16 + lane] = lane;
+    for (int w = 0; w < work; w++) {
+      const int x = lds[16 + ((acc + lane) & 255)];
+      lds[16 + lane] = x + w;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      acc += x;
+    }
+    if (acc == 0x7fffffff) lds[0] = acc;
+  }
+  if (cu_now && lane == 0) atomicSub(&cu_now[cu], 1);
+}
+
 // pure gather: each wave reads `row_bytes` contiguous bytes at a random row of a region (TLB / small-piece reference)
 extern "C" __global__ void __launch_bounds__(64) k_gather(const int32_t* base, long long n_rows, int row_words, int rows_per_wave, int step, int32_t* sink) {
   const int lane = lane_id();
@@ -184,7 +212,7 @@ extern "C" __global__ void __launch_bounds__(64) k_gather(const int32_t* base, l
 struct Args {
   int envs = 5461, streams = 3, launches = 150, warm = 20, lds = 18128, order_bytes = 4, tiled = 0, work = 0, T = 1120;
   double full_frac = 0.41;
-  int gather = 0, shuffle = 0, fast_lanes = 0;
+  int gather = 0, shuffle = 0, fast_lanes = 0, probe = 0, residency = 0;
   long long gather_mb = 3900;
   int row_bytes = 640;
 };
@@ -210,6 +238,8 @@ int main(int argc, char** argv) {
     else if (is("--full-frac")) A.full_frac = atof(argv[++i]);
     else if (is("--gather")) A.gather = atoi(argv[++i]);
     else if (is("--shuffle")) A.shuffle = atoi(argv[++i]);
+    else if (is("--probe")) A.probe = atoi(argv[++i]);
+    else if (is("--residency")) A.residency = atoi(argv[++i]);
     else if (is("--fast-lanes")) A.fast_lanes = atoi(argv[++i]);
     else if (is("--gather-mb")) A.gather_mb = atoll(argv[++i]);
     else if (is("--row-bytes")) A.row_bytes = atoi(argv[++i]);
@@ -288,9 +318,18 @@ int main(int argc, char** argv) {
   CHECK(hipFuncSetAttribute((const void*)k_pattern, hipFuncAttributeMaxDynamicSharedMemorySize, A.lds));
   int per_cu = 0;
   CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_pattern, 64, (size_t)A.lds));
+  int32_t *cu_now = nullptr, *cu_peak = nullptr;
+  if (A.residency) {
+    CHECK(hipMalloc(&cu_now, 4 * 4096)); CHECK(hipMalloc(&cu_peak, 4 * 4096));
+    CHECK(hipMemset(cu_now, 0, 4 * 4096)); CHECK(hipMemset(cu_peak, 0, 4 * 4096));
+  }
+  if (A.probe) CHECK(hipFuncSetAttribute((const void*)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, A.lds > 2048 ? A.lds : 2048));
   auto run = [&](int n, int step0) {
     for (int s = 0; s < n; s++)
-      for (int g = 0; g < G; g++) hipLaunchKernelGGL(k_pattern, dim3(N), dim3(64), (size_t)A.lds, st[g], P[g], (const int32_t*)lists[g][(s + g) % n_lists], step0 + s);
+      for (int g = 0; g < G; g++) {
+        if (A.probe) hipLaunchKernelGGL(k_probe, dim3(N), dim3(64), (size_t)(A.lds > 2048 ? A.lds : 2048), st[g], (const int32_t*)lists[g][(s + g) % n_lists], A.probe, A.work, cu_now, cu_peak);
+        else hipLaunchKernelGGL(k_pattern, dim3(N), dim3(64), (size_t)A.lds, st[g], P[g], (const int32_t*)lists[g][(s + g) % n_lists], step0 + s);
+      }
   };
   run(A.warm, 0);
   CHECK(hipDeviceSynchronize());
@@ -300,7 +339,15 @@ int main(int argc, char** argv) {
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const double per_launch = full_steps * bytes_per_step_full(base, 1.115, 1.0 / 3.0) + fast_steps * bytes_per_step_fast(base);
   const double gbps = per_launch * G * A.launches / sec / 1e9;
-  printf("{\"bench\": \"pattern\", \"envs_per_launch\": %d, \"streams\": %d, \"lds_bytes\": %d, \"waves_per_cu\": %d, \"order_bytes\": %d, \"order_tiled\": %d, "
+  if (A.residency) {
+    std::vector<int32_t> pk(4096);
+    CHECK(hipMemcpy(pk.data(), cu_peak, 4 * 4096, hipMemcpyDeviceToHost));
+    int used = 0, mx = 0; long long sum = 0;
+    for (int v : pk) if (v > 0) { used++; sum += v; if (v > mx) mx = v; }
+    fprintf(stderr, "residency: %d CUs seen, peak workgroups per CU: max %d, mean %.2f\n", used, mx, used ? (double)sum / used : 0.0);
+  }
+  printf("{\"bench\": \"%s\",", A.probe == 1 ? "probe_empty" : A.probe == 2 ? "probe_work" : "pattern");
+  printf(" \"envs_per_launch\": %d, \"streams\": %d, \"lds_bytes\": %d, \"waves_per_cu\": %d, \"order_bytes\": %d, \"order_tiled\": %d, "
          "\"work\": %d, \"shuffle\": %d, \"fast_lanes\": %d, \"full_frac\": %.3f, \"bytes_per_launch\": %.0f, \"us_per_batch_step\": %.2f, \"env_steps_per_s\": %.4g, \"GBps\": %.1f, \"frac_of_8TBps\": %.3f}\n",
          N, G, A.lds, per_cu, A.order_bytes, A.tiled, A.work, A.shuffle, A.fast_lanes, A.full_frac, per_launch, sec / A.launches * 1e6, (double)N * G * A.launches / sec, gbps, gbps / 8000.0);
   return 0;

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Print the LDS plan (MRXC_l_* offsets, bytes per env, workgroups that fit a 160 KiB CU at 512-byte allocation granularity) of a CIM plan.
+
+    python tools/lds_plan.py [topology] [durations]      (host only: mrx_cim_plan_defines needs no device)
+"""
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import __graft_entry__ as ge
+    ge.build()
+    from maro_amd import _lib
+    from maro_amd.cim import specialize
+    from maro_amd.cim.topology import load_topology
+    topo = load_topology(sys.argv[1] if len(sys.argv) > 1 else "global_trade.22p_l0.8")
+    dur = int(sys.argv[2]) if len(sys.argv) > 2 else 1120
+    ts = topo.c_struct()
+    cfg = _lib.MrxCimConfig(5461, 0, 0, dur, 1, 4, 1, 0, 0, 0)
+    d = dict(re.findall(r"#define MRXC_(\w+) (-?\d+)", specialize.plan_defines(ts, cfg)))
+    d = {k: int(v) for k, v in d.items()}
+    order = sorted((v, k) for k, v in d.items() if k.startswith("l_") and k not in ("l_mt2", "l_mt3", "l_odelay"))
+    for off, k in order:
+        print(f"  {k:10s} word {off:6d}  byte {off * 4:6d}")
+    for name in ("lds_words", "lds_words_reset", "lds_words_gen"):
+        b = d[name] * 4
+        g = (b + 511) // 512 * 512
+        print(f"{name}: {b} B -> {g} B allocated -> {163840 // g} workgroups per CU")
+    print({k: d[k] for k in ("FW", "PW", "ctab_words", "NT", "NTP", "H", "P", "V", "NC", "SMAX", "REC_W", "misc_cap")})
+
+
+if __name__ == "__main__":
+    main()
