@@ -95,15 +95,15 @@ MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
 
 #define FP(a, p) L.frame[KD(f_ports) + (a) * KD(P) + (p)]
 #define FV(a, v) L.frame[KD(f_vessels) + (a) * KD(V) + (v)]
-#define FV_PAST(s, v) L.frame[KD(f_vessels) + (10 + (s)) * KD(V) + (v)]
-#define FV_PASTT(s, v) L.frame[KD(f_vessels) + (10 + KD(past_n) + (s)) * KD(V) + (v)]
-#define FV_FUT(s, v) L.frame[KD(f_vessels) + (10 + 2 * KD(past_n) + (s)) * KD(V) + (v)]
-#define FV_FUTT(s, v) L.frame[KD(f_vessels) + (10 + 2 * KD(past_n) + KD(future_n) + (s)) * KD(V) + (v)]
+// The four stop-list attributes of a vessel (past_stop_list / past_stop_tick_list / future_stop_list / future_stop_tick_list) are
+// NOT stored in the frame: they are functions of the frame's next_loc_idx / last_loc_idx, the env's stop table and the static
+// route tables (stop_list_value below; mrx_cim_query and the DQN state gather expand them on the fly), exactly like the constant
+// cells of the dense matrices.  The frame carries the 10 scalar vessel rows only: 8064 -> 5488 bytes for global_trade.22p, i.e.
+// a third less state to move per step and per snapshot, and a third less LDS per resident env.
 #define FOPK(k) L.frame[KD(f_fop) + (k)] /* full_on_ports of order pair k = (src, dst) */
 #define FOVC(v, c) L.frame[KD(f_fov) + T.v_cbase[v] + (c)]   /* full_on_vessels[v][c-th distinct route port] */
 #define PLANC(v, c) L.frame[KD(f_plans) + T.v_cbase[v] + (c)] /* vessel_plans, same indexing */
 #define V_EVT(v) L.priv[KD(pv_evt) + (v)]
-#define V_ARR(v) L.priv[KD(pv_arr) + (v)]
 #define V_NEXT(v) L.priv[KD(pv_next) + (v)]
 #define V_POS(v) L.priv[KD(pv_pos) + (v)]  /* (start + next_loc) mod route_len */
 #define V_KRL(v) L.priv[KD(pv_krl) + (v)]  /* next_loc mod (route_len + 1) */
@@ -277,18 +277,16 @@ MRX_DEV uint64_t zombie_mask(const Lds& L) {
 }
 
 // ------------------------------------------------------------------------------------------
-// predicted stops (vessel_future_stops_prediction.py:49-85): noise-free legs from `arrival`
-// at route position `pos`
-MRX_DEV void write_future_and_plans(const CimParams& K, Lds& L, int v, int pos, int arrival) {
+// vessel_plans of a vessel that is at route position `pos` since tick `arrival` (vessel_sailing_plan_wrapper.py:24-28 over the
+// noise-free legs of vessel_future_stops_prediction.py:49-85); the predicted stops themselves are derived at query time
+MRX_DEV void write_plans(const CimParams& K, Lds& L, int v, int pos, int arrival) {
   const Tabs& T = L.tab;
   const int Lr = T.v_route_len[v], rb = T.v_route_base[v], lo = T.leg_off[v];
   int tick = arrival, x = pos;  // x walks the route cyclically
-  for (int i = 0; i < Lr || i < KD(future_n); i++) {
+  for (int i = 0; i < Lr; i++) {
     tick += T.leg_time[lo + x];
     x = (x + 1 == Lr) ? 0 : x + 1;
-    const int port = T.route_port[rb + x];
-    if (i < KD(future_n)) { FV_FUT(i, v) = port; FV_FUTT(i, v) = tick; }
-    if (i < Lr) PLANC(v, T.route_cidx[rb + x]) = tick;  // vessel_sailing_plan_wrapper.py:24-28 (later stops overwrite earlier)
+    PLANC(v, T.route_cidx[rb + x]) = tick;  // (later stops overwrite earlier)
   }
 }
 
@@ -740,10 +738,8 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
     FV(VA_REMAINING_SPACE, v) = K.v_total_space[v] - K.v_init_empty[v];
     FV(VA_IS_PARKING, v) = 1;
     FV(VA_LOC_PORT_IDX, v) = K.route_port[K.v_route_base[v] + K.v_start[v]];
-    for (int s = 0; s < KD(past_n); s++) { FV_PAST(s, v) = -1; FV_PASTT(s, v) = -1; }
-    write_future_and_plans(K, L, v, K.v_start[v], 0);
+    write_plans(K, L, v, K.v_start[v], 0);
     V_EVT(v) = stop_parking(g_stops[(size_t)v * KD(SMAX)]);  // leave tick of stop 0 (arrival 0)
-    V_ARR(v) = 0;
     V_POS(v) = K.v_start[v];
     V_KRL(v) = 0;
     V_PERIOD(v) = K.vperiod[(size_t)env * V + v];
@@ -868,15 +864,8 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
     const int v = lane;
     const bool z = (zmask >> v) & 1ull;
     if ((z || FV(VA_IS_PARKING, v)) && V_EVT(v) == t) {
-      int app_port = FV(VA_LOC_PORT_IDX, v), app_tick = V_ARR(v);
+      // (the past-stop lists — shift + append of the stop that is being left — are derived from next_loc_idx: stop_list_value)
       const uint32_t* srow = K.stops + ((size_t)env * V + v) * KD(SMAX);
-      if (z) {  // vessel_past_stops[v, last, next] (vessel_past_stops_wrapper.py:23-38): the appended entry is stop next - 1 of the table
-        const int k_old = FV(VA_NEXT_LOC_IDX, v);
-        app_port = T.route_port[T.v_route_base[v] + V_POS(v)];
-        app_tick = stop_arrival(srow[k_old < KD(SMAX) ? k_old : KD(SMAX) - 1]);
-      }
-      for (int s = 0; s + 1 < KD(past_n); s++) { FV_PAST(s, v) = FV_PAST(s + 1, v); FV_PASTT(s, v) = FV_PASTT(s + 1, v); }
-      if (KD(past_n) > 0) { FV_PAST(KD(past_n) - 1, v) = app_port; FV_PASTT(KD(past_n) - 1, v) = app_tick; }
       FV(VA_NEXT_LOC_IDX, v) += 1;
       { const int Lr = T.v_route_len[v]; const int x = V_POS(v) + 1, y = V_KRL(v) + 1; V_POS(v) = x == Lr ? 0 : x; V_KRL(v) = y == Lr + 1 ? 0 : y; }
       FV(VA_IS_PARKING, v) = 0;
@@ -1104,15 +1093,10 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
       const uint32_t st_k1 = (uint32_t)wave::bcast((int)pf.stk1, a_idx);
       prof.mark(10);
       // lane i: the i-th stop after this one — route position, port, compact matrix column, predicted tick
-      const int nlan = Lr > KD(future_n) ? Lr : KD(future_n);
-      const bool act = lane < nlan;
+      const bool act = lane < Lr;
       int xi = pos + lane, xn = pos + 1 + lane;  // leg out of stop i-1, position of stop i
-      if (Lr >= KD(future_n)) {  // (wave-uniform) the usual case: lanes < nlan = Lr stay below 2 Lr — a conditional subtraction, no integer division
-        xi = act ? (xi >= Lr ? xi - Lr : xi) : 0;
-        xn = act ? (xn >= Lr ? xn - Lr : xn) : 0;
-      } else {
-        xi %= Lr; xn %= Lr;
-      }
+      xi = act ? (xi >= Lr ? xi - Lr : xi) : 0;   // lanes < Lr stay below 2 Lr: a conditional subtraction, no integer division
+      xn = act ? (xn >= Lr ? xn - Lr : xn) : 0;
       const int leg = act ? T.leg_time[T.leg_off[v] + xi] : 0;
       const int tick_i = t + wave::scan_incl_add(leg);  // vessel_future_stops_prediction.py:49-85
       const int port_i = T.route_port[rb + xn], c_i = T.route_cidx[rb + xn];
@@ -1125,7 +1109,6 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
           dup_earlier = dup_earlier || (j < lane && cj == c_i);
         }
       }
-      if (lane < KD(future_n)) { FV_FUT(lane, v) = port_i; FV_FUTT(lane, v) = tick_i; }
       if (lane < Lr && !dup_later) PLANC(v, c_i) = tick_i;  // vessel_sailing_plan_wrapper.py:24-28 (later stops overwrite)
       prof.mark(11);
       // load full (:551-587): the sequential hand-out of `acceptable` over the next Lr stops is a clamped prefix sum;
@@ -1157,7 +1140,6 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
         FV(VA_LAST_LOC_IDX, v) = k;
         FV(VA_IS_PARKING, v) = 1;
         FV(VA_LOC_PORT_IDX, v) = p;
-        V_ARR(v) = t;
         FP(PA_FULL, p) -= loaded_total;
         FP(PA_EMPTY, p) += early;
         FV(VA_FULL, v) = full;
@@ -2089,14 +2071,7 @@ MRX_DEV int attr_slots(const CimParams& K, int node_type, int a) {
 
 MRX_DEV int frame_word(const CimParams& K, int node_type, int a, int node, int s) {
   if (node_type == 0) return KD(f_ports) + a * KD(P) + node;
-  if (node_type == 1) {
-    int row = a;
-    if (a == VA_PAST_STOP_LIST) row = 10 + s;
-    else if (a == VA_PAST_STOP_TICK_LIST) row = 10 + KD(past_n) + s;
-    else if (a == VA_FUTURE_STOP_LIST) row = 10 + 2 * KD(past_n) + s;
-    else if (a == VA_FUTURE_STOP_TICK_LIST) row = 10 + 2 * KD(past_n) + KD(future_n) + s;
-    return KD(f_vessels) + row * KD(V) + node;
-  }
+  if (node_type == 1) return KD(f_vessels) + a * KD(V) + node;  // scalar attributes (a < VA_PAST_STOP_LIST); the lists: stop_list_value
   if (a == MA_FULL_ON_PORTS) {
     const int k = K.pair_dense[s];  // dense cell s = src * P + dst
     return k < 0 ? -1 : KD(f_fop) + k;
@@ -2104,6 +2079,39 @@ MRX_DEV int frame_word(const CimParams& K, int node_type, int a, int node, int s
   const int c = K.cidx_dense[s];  // dense cell s = vessel * P + port
   if (c < 0) return -1;          // port not on the vessel's route: constant cell
   return (a == MA_FULL_ON_VESSELS ? KD(f_fov) : KD(f_plans)) + c;
+}
+
+// Slot s of a vessel's stop-list attribute `a`, as of `frame` (a frame of `env`'s snapshot list or its live frame).
+//   past lists (vessel_past_stops_wrapper.py:23-38; business_engine.py:634-656 appends the stop that is being left): after n
+//   departures (n = next_loc_idx) the list holds stops n - past_n .. n - 1 of the vessel's unrolled stop table, -1 where that
+//   index is negative: (port of route position (start + j) mod L, arrival tick of stop j).  Stop 0 is "arrived at" tick 0 by
+//   construction of the episode (business_engine.py:371-379) — except for a vessel whose first departure fell before
+//   start_tick (zombie_mask), which reads the table's own entry.
+//   future lists (vessel_future_stops_prediction.py:49-85, refreshed at every arrival and at reset): the future_n stops after
+//   stop k = last_loc_idx, predicted with the noise-free legs from that stop's arrival tick (0 for k = 0).
+MRX_DEV int stop_list_value(const CimParams& K, int env, const int32_t* frame, int a, int v, int s) {
+  const int Lr = K.v_route_len[v], rb = K.v_route_base[v], start = K.v_start[v];
+  const uint32_t* srow = K.stops + ((size_t)env * KD(V) + v) * KD(SMAX);
+  if (a == VA_PAST_STOP_LIST || a == VA_PAST_STOP_TICK_LIST) {
+    const int j = frame[KD(f_vessels) + VA_NEXT_LOC_IDX * KD(V) + v] - KD(past_n) + s;
+    if (j < 0) return -1;
+    if (a == VA_PAST_STOP_LIST) return K.route_port[rb + (start + j) % Lr];
+    if (j == 0) {
+      const int32_t* hdr = K.priv + (size_t)env * KD(PW);
+      const uint64_t zm = ((uint64_t)(uint32_t)hdr[PH_ZOMBIE_HI] << 32) | (uint32_t)hdr[PH_ZOMBIE_LO];
+      if (!((zm >> v) & 1ull)) return 0;
+    }
+    return stop_arrival(srow[j < KD(SMAX) ? j : KD(SMAX) - 1]);
+  }
+  const int k = frame[KD(f_vessels) + VA_LAST_LOC_IDX * KD(V) + v];
+  int tick = k == 0 ? 0 : stop_arrival(srow[k < KD(SMAX) ? k : KD(SMAX) - 1]);
+  int x = (start + k) % Lr;
+  const int lo = K.leg_off[v];
+  for (int i = 0; i <= s; i++) {
+    tick += K.leg_time[lo + x];
+    x = (x + 1 == Lr) ? 0 : x + 1;
+  }
+  return a == VA_FUTURE_STOP_LIST ? K.route_port[rb + x] : tick;
 }
 
 // The frame a snapshot query for frame index `fi` of `env` reads, or nullptr when the ring does not hold it.
@@ -2140,6 +2148,7 @@ MRX_DEV double query_elem(const CimParams& K, int node_type, const int32_t* tick
   const int node = nodes[(size_t)env * nodes_per_env + ni];  // nodes_per_env = row stride (0: one shared row)
   const int n_nodes = node_type == 0 ? KD(P) : node_type == 1 ? KD(V) : 1;
   if (node < 0 || node >= n_nodes) return 0.0;  // e.g. the -1 padding of stop lists used as a node index
+  if (node_type == 1 && a >= VA_PAST_STOP_LIST) return (double)stop_list_value(K, env, frame, a, node, slot);
   const int w = frame_word(K, node_type, a, node, slot);
   if (w < 0) return a == MA_VESSEL_PLANS ? -1.0 : 0.0;  // never-written cells: plans are initialised to -1 (business_engine.py:344)
   const int32_t raw = frame[w];
@@ -2148,15 +2157,10 @@ MRX_DEV double query_elem(const CimParams& K, int node_type, const int32_t* tick
 
 #undef FP
 #undef FV
-#undef FV_PAST
-#undef FV_PASTT
-#undef FV_FUT
-#undef FV_FUTT
 #undef FOPK
 #undef FOVC
 #undef PLANC
 #undef V_EVT
-#undef V_ARR
 #undef V_NEXT
 #undef V_POS
 #undef V_KRL

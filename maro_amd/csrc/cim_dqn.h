@@ -232,7 +232,7 @@ mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__
       const int32_t* now = frame_of(K, env, d[0]);  // snapshots[tick : vessel : future_stop_list]
       r_node[t][0] = d[1];
       r_node[t][DQ_MAX_NODES - 1] = d[2];
-      for (int j = 1; j < M.n_nodes; j++) r_node[t][j] = now ? now[frame_word(K, 1, VA_FUTURE_STOP_LIST, d[2], j - 1)] : 0;
+      for (int j = 1; j < M.n_nodes; j++) r_node[t][j] = now ? stop_list_value(K, env, now, VA_FUTURE_STOP_LIST, d[2], j - 1) : 0;
     }
   }
   for (int i = t; i < DQ_TILE * n_ticks; i += blockDim.x) {

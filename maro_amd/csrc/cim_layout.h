@@ -96,7 +96,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   k.n_envs = c->n_envs; k.P = P; k.V = V; k.R = R; k.NT = NT; k.NRP = NRP;
   k.past_n = t->past_stop_number; k.future_n = t->future_stop_number;
   if (k.past_n < 0 || k.future_n < 0 || k.past_n > 16 || k.future_n > 16) return fail("stop_number out of range (0..16)");
-  k.vrows = 10 + 2 * k.past_n + 2 * k.future_n;
+  k.vrows = 10;  // the scalar vessel attributes; the four stop lists are derived at query time (cim::stop_list_value)
   k.start_tick = c->start_tick; k.T = c->start_tick + c->durations; k.resolution = c->snapshot_resolution;
   k.max_actions = c->max_actions > 0 ? c->max_actions : 1;
   if (c->decision_mode < 0 || c->decision_mode > 2) { if (err) *err = "decision_mode must be 0, 1 or 2"; return MRX_ERR_INVALID_ARG; }
@@ -178,7 +178,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   if (k.T >= (1 << 23)) return fail("engine limit: max_tick < 2^23");
   if (t->total_containers >= (1 << 24)) return fail("engine limit: total_containers < 2^24");
   // private state
-  k.pv_evt = PH_COUNT; k.pv_arr = k.pv_evt + V; k.pv_next = k.pv_arr + V; k.pv_pos = k.pv_next + V; k.pv_krl = k.pv_pos + V; k.pv_period = k.pv_krl + V; k.pv_rfull = k.pv_period + V; k.pv_rempty = k.pv_rfull + H * NT;
+  k.pv_evt = PH_COUNT; k.pv_next = k.pv_evt + V; k.pv_pos = k.pv_next + V; k.pv_krl = k.pv_pos + V; k.pv_period = k.pv_krl + V; k.pv_rfull = k.pv_period + V; k.pv_rempty = k.pv_rfull + H * NT;
   k.PW = (k.pv_rempty + H * P + 3) / 4 * 4;
   // derived integer tables
   std::vector<int32_t> pair_src(NT ? NT : 1), v_route_base(V), v_route_len(V), v_total_space(V), leg_off(V + 1), leg_time,

@@ -34,7 +34,7 @@ struct CimParams {
   int NC;  // compact matrix cells: sum over vessels of the distinct ports on its route (full_on_vessels / vessel_plans
            // are stored [vessel][route port] — every other cell of the dense V x P matrices is constant 0 / -1)
   // ---- private-state layout (words)
-  int PW, pv_evt, pv_arr, pv_next, pv_pos, pv_krl, pv_period, pv_rfull, pv_rempty;
+  int PW, pv_evt, pv_next, pv_pos, pv_krl, pv_period, pv_rfull, pv_rempty;
   int REC_W;
   // ---- LDS layout (word offsets)
   int l_frame, l_priv, l_mt0, l_mt1, l_dsrc, l_dtgt, l_oq, l_odelay, l_srcn, l_misc, lds_words;
@@ -111,7 +111,6 @@ struct CimParams {
   X(NC) \
   X(PW) \
   X(pv_evt) \
-  X(pv_arr) \
   X(pv_next) \
   X(pv_pos) \
   X(pv_krl) \

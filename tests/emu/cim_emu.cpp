@@ -183,7 +183,7 @@ extern "C" int emu_dump_dims(void* h, char* buf, int len) {
   D(P) D(V) D(R) D(NT) D(NRP) D(past_n) D(future_n) D(vrows) D(FW) D(S) D(H) D(SMAX) D(T) D(start_tick) D(resolution)
   D(max_actions) D(period) D(vol) D(total_containers) D(order_mode) D(use_order_rng) D(use_buffer_rng) D(has_order_init)
   D(idx_order_init) D(idx_route) D(idx_order_num) D(idx_buffer) D(f_ports) D(f_vessels) D(f_fop) D(f_fov) D(f_plans)
-  D(misc_cap) D(NC) D(PW) D(pv_evt) D(pv_arr) D(pv_next) D(pv_pos) D(pv_krl) D(pv_period) D(pv_rfull) D(pv_rempty) D(REC_W)
+  D(misc_cap) D(NC) D(PW) D(pv_evt) D(pv_next) D(pv_pos) D(pv_krl) D(pv_period) D(pv_rfull) D(pv_rempty) D(REC_W)
   D(l_frame) D(l_priv) D(l_mt0) D(l_mt1) D(l_dsrc) D(l_dtgt) D(l_oq) D(l_odelay) D(l_srcn) D(l_misc) D(lds_words) D(l_ctab)
   D(ctab_words) D(decision_mode) D(data_mode) D(data_T) D(pregen) D(NTP)
 #undef D

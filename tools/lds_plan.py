@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Print the LDS plan (MRXC_l_* offsets, bytes per env, workgroups that fit a 160 KiB CU at 512-byte allocation granularity) of a CIM plan.
+"""Print the LDS plan (MRXC_l_* offsets, bytes per env, workgroups that fit a 160 KiB CU at the measured 1280-byte allocation granularity) of a CIM plan.
 
     python tools/lds_plan.py [topology] [durations]      (host only: mrx_cim_plan_defines needs no device)
 """
@@ -27,7 +27,7 @@ def main():
         print(f"  {k:10s} word {off:6d}  byte {off * 4:6d}")
     for name in ("lds_words", "lds_words_reset", "lds_words_gen"):
         b = d[name] * 4
-        g = (b + 511) // 512 * 512
+        g = (b + 1279) // 1280 * 1280   # gfx950 allocates LDS in 1280-byte granules (measured: tools/hbm_pattern_bench --residency)
         print(f"{name}: {b} B -> {g} B allocated -> {163840 // g} workgroups per CU")
     print({k: d[k] for k in ("FW", "PW", "ctab_words", "NT", "NTP", "H", "P", "V", "NC", "SMAX", "REC_W", "misc_cap")})
 
