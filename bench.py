@@ -430,7 +430,7 @@ def main():
     ap.add_argument("--graphs", type=int, default=0, help="1: capture one step per group in a hipGraph and replay it (cim)")
     ap.add_argument("--groups", type=int, default=3, help="independent env groups per GPU, each on its own HIP stream (cim)")
     ap.add_argument("--step-mode", type=int, default=0, help="launch form of mrx_cim_step (mrx_cim_set_step_mode): 0 default (sorted), "
-                    "1 unsorted, 2 sorted, 3 persistent pipelined")
+                    "1 unsorted, 2 sorted, 4 split")
     ap.add_argument("--topology", default="global_trade.22p_l0.8")
     ap.add_argument("--step-budget", type=int, default=0, help="citi_bike: bounded steps for the main window (mrx_cb_set_step_budget; 0 = every call yields a decision)")
     ap.add_argument("--bounded-budget", type=int, default=24, help="citi_bike: budget of the extra bounded-steps leg (0: skip it)")
@@ -690,8 +690,7 @@ def main():
         F = frame_bytes(topo)
         b_step = (3.0 + tbar) * F + 4.0 * topo.n_targets * tbar + 40.0  # fixed per-env-step formula
         ng = n / G                                  # env-steps per launch
-        kernel = ("mrx_k_cim_step_pipe" if engines[0].step_mode == 3 else
-                  ("mrx_k_cim_step_tab" if engines[0].layout.order_table_on else "mrx_k_cim_step") + ("_obs" if bufs[0].get("obs") is not None else ""))
+        kernel = ("mrx_k_cim_step_tab" if engines[0].layout.order_table_on else "mrx_k_cim_step") + ("_obs" if bufs[0].get("obs") is not None else "")
         # HBM bytes one launch really moves: the committed PMC passes of this same workload (tools/refresh_pmc.py -> profiles/latest_pmc.json)
         traffic = pmc_src = None
         try:

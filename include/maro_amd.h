@@ -216,12 +216,10 @@ int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_acti
  *      runs a tick (full path: LDS-staged state, ~25 us) or only answers another decision of the same tick (fast path out
  *      of HBM); a small kernel (mrx_k_cim_schedule) puts the full-path envs first, so the long waves start first, the
  *      short ones fill the tail of the launch, and a full-path wave skips the header round trip;
- *   3  (plan-specialised code objects with the order table, mrx_cim_load_step_kernels) the persistent pipelined kernel:
- *      as many waves as the device holds at once walk that list; the next env's state is prefetched into registers while
- *      the current env is computed out of LDS, write-backs drain under the next env, fast-path envs go 64 per wave.
  *   4  the step split in two kernels: the fast-path envs one per LANE in a small kernel without LDS, then the full-path list
  *      walked by as many workgroups as the device holds at once;
- *   0  automatic (default): 2 (measured fastest on MI355X at the benchmark's batch sizes; 3 is opt-in).
+ *   0  automatic (default): 2 (measured fastest on MI355X at the benchmark's batch sizes).
+ * (3 was round 2's persistent pipelined kernel — measured slower than 2 and removed; the value is accepted and means 2.)
  * Returns the mode the next step will actually use (>= 1), or a negative mrx_status.
  */
 int mrx_cim_set_step_mode(mrx_handle h, int mode);

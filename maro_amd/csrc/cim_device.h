@@ -62,7 +62,8 @@ struct Tabs {
 struct Lds {
   Tabs tab;
   int32_t* frame;
-  int32_t* priv;
+  int32_t* priv;   // header, per-vessel rows, pending empty returns (PWH words)
+  int32_t* rfull;  // pending full returns [H][NT] (generic layout; a lean build keeps them in registers: RingRegs)
   uint32_t* mt_ord;
   uint32_t* mt_buf;
   double* dsrc;
@@ -76,6 +77,7 @@ MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
   Lds L;
   L.frame = b + KD(l_frame);
   L.priv = b + KD(l_priv);
+  L.rfull = b + KD(l_rfull);
   L.mt_ord = (uint32_t*)(b + KD(l_mt0));
   L.mt_buf = (uint32_t*)(b + KD(l_mt1));
   L.dsrc = (double*)(b + KD(l_dsrc));
@@ -92,6 +94,24 @@ MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
   L.tab.fr_base = K.fr_base; L.tab.fr_noise = K.fr_noise;
   return L;
 }
+
+// LEAN builds (plan-specialised, order table on, at most 192 order pairs and 4 return-ring slots: CimParams::lean_ok): the two
+// per-pair arrays that are only ever indexed by "my lane's pair" live in REGISTERS instead of LDS —
+//   rf[h][b]  pending full returns of pair 64 b + lane in ring slot h (RING_FULL), loaded / stored straight from / to the
+//             env's private HBM row,
+//   oq[b]     the tick's order quantity of that pair (the order-table row, already prefetched into registers)
+// — and the workgroup is launched with CimParams::lds_words_lean: 2.5 KB less LDS per env = 2 more resident envs per CU.
+#if defined(MRX_SPECIALIZED)
+#if MRXC_lean_ok
+#define MRX_LEAN 1
+#endif
+#endif
+#ifdef MRX_LEAN
+enum { RR_NB = (MRXC_NT + 63) / 64, RR_H = MRXC_H };
+struct RingRegs { int rf[RR_H][RR_NB]; };
+#else
+struct RingRegs {};
+#endif
 
 #define FP(a, p) L.frame[KD(f_ports) + (a) * KD(P) + (p)]
 #define FV(a, v) L.frame[KD(f_vessels) + (a) * KD(V) + (v)]
@@ -113,7 +133,7 @@ MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
 // and the pre-decision snapshots (core.py:345) of its later ticks are what stays in the snapshot list — they can no longer be
 // aliased to the live frame, every decision writes one (and takes the full path: the fast path never stages the frame)
 #define MRX_UNALIGNED_FRAMES (KD(resolution) > 1 && KD(start_tick) % KD(resolution) != 0)
-#define RING_FULL(slot, k) L.priv[KD(pv_rfull) + (slot) * KD(NT) + (k)]
+#define RING_FULL(slot, k) L.rfull[(slot) * KD(NT) + (k)]
 #define RING_EMPTY(slot, p) L.priv[KD(pv_rempty) + (slot) * KD(P) + (p)]
 
 MRX_DEV float bits_f(int32_t x) { union { int32_t i; float f; } u; u.i = x; return u.f; }
@@ -585,6 +605,8 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   Lds L = make_lds(K, lds);
   uint32_t* mt_route = (uint32_t*)(lds + KD(l_mt2));
   uint32_t* mt_oinit = (uint32_t*)(lds + KD(l_mt3));
+  L.mt_ord = (uint32_t*)(lds + KD(r_mt0));   // the reset kernel's own layout: four streams side by side; frame and private
+  L.mt_buf = (uint32_t*)(lds + KD(r_mt1));   // head are initialised in the same words once the streams are persisted
   const int lane = wave::lane();
   const int P = KD(P), V = KD(V), TT = KD(T);
   uint32_t* g_mt = K.mt + (size_t)env * MTS_COUNT * MT_WORDS;
@@ -720,11 +742,11 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   copy_words((int32_t*)(g_mt + MTS_ORDER * MT_WORDS), (const int32_t*)L.mt_ord, MT_WORDS);
   copy_words((int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), (const int32_t*)L.mt_buf, MT_WORDS);
   copy_words((int32_t*)(g_mt + MTS_ROUTE * MT_WORDS), (const int32_t*)mt_route, MT_WORDS);
-  wave::sync();  // (the route / order-init / order streams may alias the frame region initialised next: cim_layout.h)
+  wave::sync();  // (all four streams alias the frame / private-head region initialised next: cim_layout.h)
 
   // ---- frame (business_engine.py:321-356, 381-398) and private state
   for (int i = lane; i < KD(FW); i += 64) L.frame[i] = (i >= KD(f_plans) && i < KD(f_plans) + KD(NC)) ? -1 : 0;
-  for (int i = lane; i < KD(PW); i += 64) L.priv[i] = 0;
+  for (int i = lane; i < KD(PWH); i += 64) L.priv[i] = 0;
   wave::sync();
   if (lane < P) {
     FP(PA_CAPACITY, lane) = K.p_cap[lane];
@@ -773,7 +795,8 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
   }
   wave::sync();
   copy_words(g_live, L.frame, KD(FW));
-  copy_words(g_priv, L.priv, KD(PW));
+  copy_words(g_priv, L.priv, KD(PWH));
+  for (int i = KD(PWH) + lane; i < KD(PW); i += 64) g_priv[i] = 0;  // no pending full returns
   for (int i = lane; i < KD(S); i += 64) K.ring_fi[(size_t)env * KD(S) + i] = -1;
   int32_t* g_rec0 = K.rec + (size_t)env * KD(REC_W);
   for (int i = lane; i < KD(REC_W); i += 64) g_rec0[i] = 0;
@@ -826,7 +849,7 @@ MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {
 // One tick, phases A..B4.  Returns the mask of vessels that arrived (their decisions follow).
 template <bool PG>
 MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf, int& idx_ord, int& idx_buf, int& status, Prof& prof,
-                          bool& ord_twisted, bool& buf_twisted) {
+                          bool& ord_twisted, bool& buf_twisted, RingRegs& rr) {
   const int lane = wave::lane();
   const int P = KD(P), V = KD(V), NT = KD(NT), H = KD(H);
   const Tabs& T = L.tab;
@@ -834,10 +857,22 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
   // ---------------- A. orders of this tick -> L.oq[pair]
   const uint64_t arr_mask = pf.arr_mask;
   int32_t* g_rec = K.rec + (size_t)env * KD(REC_W);
+#ifdef MRX_LEAN
+  int oqr[RR_NB];  // order quantity of pair 64 b + lane (later | (buffer ticks + 1) << 24), in registers
+#pragma unroll
+  for (int b = 0; b < RR_NB; b++) oqr[b] = (b * 64 + lane < NT) ? pf.oqr[b] : 0;
+#define OQ_GET(b, k) oqr[b]
+#define OQ_SET(b, k, x) oqr[b] = (x)
+#else
+#define OQ_GET(b, k) L.oq[k]
+#define OQ_SET(b, k, x) L.oq[k] = (x)
+#endif
   if constexpr (PG) {
     // drawn at reset (order table): the row was requested one round trip ago (tick_prefetch)
+#ifndef MRX_LEAN
 #pragma unroll
     for (int b = 0; b < 3; b++) { const int k = b * 64 + lane; if (k < NT) L.oq[k] = pf.oqr[b]; }
+#endif
     if (NT > 192) {
       const int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t - KD(start_tick)) * KD(NTP);
       for (int k = 192 + lane; k < NT; k += 64) L.oq[k] = row[k];
@@ -886,17 +921,27 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
   // source port of pair k from the staged table: no global load inside these loops (its s_waitcnt would land behind a
   // control-flow merge as vmcnt(0), which on gfx950 also drains the snapshot stores issued just before)
 #define MRX_PAIR_SRC(k0, k) ((int)T.pair_src[(k)])
+#pragma unroll
   for (int k0 = 0; k0 < NT; k0 += 64) {  // RETURN_FULL :499-522, one lane per (src, dst) pair
     const int k = k0 + lane;
+#ifdef MRX_LEAN
+    int q = 0;
+#pragma unroll
+    for (int h = 0; h < RR_H; h++) { const bool mine = slot == h; q = mine ? rr.rf[h][k0 / 64] : q; rr.rf[h][k0 / 64] = mine ? 0 : rr.rf[h][k0 / 64]; }
+    if (k < NT && q) {
+#else
     if (k < NT) {
       const int q = RING_FULL(slot, k);
+      if (q) RING_FULL(slot, k) = 0;
       if (q) {
+#endif
         const int src = MRX_PAIR_SRC(k0, k);
-        RING_FULL(slot, k) = 0;
         FOPK(k) += q;  // the pair owns this cell
         wave::lds_add(&FP(PA_ON_SHIPPER, src), -q);
         wave::lds_add(&FP(PA_FULL, src), q);
+#ifndef MRX_LEAN
       }
+#endif
     }
   }
   wave::sync();
@@ -1002,9 +1047,10 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
     int carry = 0;
     bool any_imm = false;
     if (lane < P) L.srcn[lane] = 0;  // per-port sum of immediately returned containers
+#pragma unroll
     for (int k0 = 0; k0 < NT; k0 += 64) {
       const int k = k0 + lane;
-      const int q = k < NT ? L.oq[k] : 0;
+      const int q = k < NT ? OQ_GET(k0 / 64, k) : 0;
       const bool has = q > 0;
       int b = 0;
       if (KD(use_buffer_rng)) {
@@ -1017,14 +1063,15 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
       }
       const int incl = wave::scan_incl_add(q) + carry;
       carry = wave::bcast(incl, 63);
-      if (k < NT) { pre[k] = incl; if (has) L.oq[k] = q | ((b < 0 ? 0 : (b > 126 ? 127 : b + 1)) << 24); }
+      if (k < NT) { pre[k] = incl; if (has) OQ_SET(k0 / 64, k, q | ((b < 0 ? 0 : (b > 126 ? 127 : b + 1)) << 24)); }
       any_imm = any_imm || (wave::ballot(has && b == 0) != 0);
     }
     wave::sync();
     // exec_j = min(q_j, max(0, empty0 - sum of the port's earlier orders)): the sequential hand-out of :462-478
+#pragma unroll
     for (int k0 = 0; k0 < NT; k0 += 64) {
       const int k = k0 + lane;
-      const int qb = k < NT ? L.oq[k] : 0;
+      const int qb = k < NT ? OQ_GET(k0 / 64, k) : 0;
       const int q = qb & 0xffffff;
       if (q > 0) {
         const int src = MRX_PAIR_SRC(k0, k);
@@ -1034,7 +1081,16 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
         const int exec = avail <= 0 ? 0 : (q < avail ? q : avail);
         const int b = ((qb >> 24) & 0x7f) - 1;  // -1 = scheduled into the past: the containers never come back
         if (b == 0) { FOPK(k) += exec; wave::lds_add(&L.srcn[src], exec); }  // RETURN_FULL right away (:494-497)
-        else if (b > 0) { const int sl = slot + b; RING_FULL(sl >= H ? sl - H : sl, k) += exec; }
+        else if (b > 0) {
+          int sl = slot + b;
+          sl = sl >= H ? sl - H : sl;
+#ifdef MRX_LEAN
+#pragma unroll
+          for (int h = 0; h < RR_H; h++) rr.rf[h][k0 / 64] += (sl == h) ? exec : 0;
+#else
+          RING_FULL(sl, k) += exec;
+#endif
+        }
       }
     }
     wave::sync();
@@ -1060,6 +1116,8 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
     }
   }
 #undef MRX_PAIR_SRC
+#undef OQ_GET
+#undef OQ_SET
   wave::sync();
   prof.mark(PF_ORDERS);
 
@@ -1471,7 +1529,10 @@ template <bool PG>
 MRX_DEV void state_load_async(const CimParams& K, Lds& L, int env) {
   const uint32_t* g_mt = K.mt + (size_t)env * MTS_COUNT * MT_WORDS;
   copy_in_async(L.frame, K.live + (size_t)env * KD(FW), KD(FW));
-  copy_in_async(L.priv, K.priv + (size_t)env * KD(PW), KD(PW));
+  copy_in_async(L.priv, K.priv + (size_t)env * KD(PW), KD(PWH));
+#ifndef MRX_LEAN
+  copy_in_async(L.rfull, K.priv + (size_t)env * KD(PW) + KD(pv_rfull), KD(PW) - KD(pv_rfull));
+#endif
   // The RNG states are requested unconditionally: whether a tick will run is only known once the private
   // state has arrived, and a second LDS-DMA round trip would serialise behind every later LDS access.
   if (!PG && KD(use_order_rng)) copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(g_mt + MTS_ORDER * MT_WORDS), MT_WORDS);
@@ -1481,9 +1542,41 @@ template <bool PG>
 MRX_DEV void state_store(const CimParams& K, Lds& L, int env, const StepEnd& e) {
   uint32_t* g_mt = K.mt + (size_t)env * MTS_COUNT * MT_WORDS;
   copy_words(K.live + (size_t)env * KD(FW), L.frame, KD(FW));
-  copy_words(K.priv + (size_t)env * KD(PW), L.priv, KD(PW));
+  copy_words(K.priv + (size_t)env * KD(PW), L.priv, KD(PWH));
+#ifndef MRX_LEAN
+  copy_words(K.priv + (size_t)env * KD(PW) + KD(pv_rfull), L.rfull, KD(PW) - KD(pv_rfull));
+#endif
   if (!PG && KD(use_order_rng) && e.ord_dirty) copy_words((int32_t*)(g_mt + MTS_ORDER * MT_WORDS), (const int32_t*)L.mt_ord, MT_WORDS);
   if (KD(use_buffer_rng) && e.buf_dirty) copy_words((int32_t*)(g_mt + MTS_BUFFER * MT_WORDS), (const int32_t*)L.mt_buf, MT_WORDS);
+}
+
+// lean builds: the pending full returns of "my" pairs, HBM <-> registers (plain 4-byte accesses, lane = pair: coalesced rows)
+MRX_DEV void ring_load(const CimParams& K, int env, RingRegs& rr) {
+#ifdef MRX_LEAN
+  const int lane = wave::lane();
+  const int32_t* g = K.priv + (size_t)env * KD(PW) + KD(pv_rfull);
+#pragma unroll
+  for (int h = 0; h < RR_H; h++)
+#pragma unroll
+    for (int b = 0; b < RR_NB; b++) {
+      const int k = b * 64 + lane;
+      const int x = g[h * KD(NT) + (k < KD(NT) ? k : 0)];   // branch-free: clamped address, masked value
+      rr.rf[h][b] = k < KD(NT) ? x : 0;
+    }
+#endif
+}
+MRX_DEV void ring_store(const CimParams& K, int env, const RingRegs& rr) {
+#ifdef MRX_LEAN
+  const int lane = wave::lane();
+  int32_t* g = K.priv + (size_t)env * KD(PW) + KD(pv_rfull);
+#pragma unroll
+  for (int h = 0; h < RR_H; h++)
+#pragma unroll
+    for (int b = 0; b < RR_NB; b++) {
+      const int k = b * 64 + lane;
+      if (k < KD(NT)) g[h * KD(NT) + k] = rr.rf[h][b];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1594,7 +1687,7 @@ MRX_DEV void body_act(const CimParams& K, Lds& L, const int32_t* actions, StepCt
 }
 
 template <bool PG, bool OBS>
-MRX_DEV StepEnd body_run(const CimParams& K, const CimObs& O, int env, Lds& L, const StepIO& io, StepCtx& c, StepOut& out, Prof& prof) {
+MRX_DEV StepEnd body_run(const CimParams& K, const CimObs& O, int env, Lds& L, const StepIO& io, StepCtx& c, StepOut& out, Prof& prof, RingRegs& rr) {
   const int lane = wave::lane();
   const int P = KD(P), V = KD(V);
   StepEnd end = {true, false, false};
@@ -1627,7 +1720,7 @@ MRX_DEV StepEnd body_run(const CimParams& K, const CimObs& O, int env, Lds& L, c
     }
     prof.mark(PF_POST_STEP);
     fresh = false;
-    pend = run_tick<PG>(K, env, L, t, c.pf, c.idx_ord, c.idx_buf, c.status, prof, end.ord_dirty, end.buf_dirty);
+    pend = run_tick<PG>(K, env, L, t, c.pf, c.idx_ord, c.idx_buf, c.status, prof, end.ord_dirty, end.buf_dirty, rr);
     if (!pend && t + 1 < KD(T)) {  // another tick follows: its inputs, landed before that tick's snapshot stores are issued
       tick_prefetch<PG>(K, env, L, t + 1, c.pf);
       tick_prefetch_land(c.pf);
@@ -1768,7 +1861,7 @@ MRX_DEV void body_emit(const CimParams& K, const CimObs& O, int env, const StepI
 
 // the stages back to back (one env per workgroup kernels)
 template <bool PG, bool OBS>
-MRX_DEV StepEnd full_body(const CimParams& K, const CimObs& O, int env, Lds& L, const StepIO& io, int a0v, int a0p, int a0q, int a0t, Prof& prof) {
+MRX_DEV StepEnd full_body(const CimParams& K, const CimObs& O, int env, Lds& L, const StepIO& io, int a0v, int a0p, int a0q, int a0t, Prof& prof, RingRegs& rr) {
   StepCtx c;
   StepOut out;
   c.a0v = a0v; c.a0p = a0p; c.a0q = a0q; c.a0t = a0t;
@@ -1780,7 +1873,7 @@ MRX_DEV StepEnd full_body(const CimParams& K, const CimObs& O, int env, Lds& L, 
     prof.mark(PF_ACTION);
     tick_prefetch_land(c.pf);  // before the snapshot stores of post_step, so that nothing later waits behind them
     prof.mark(PF_MT_LOAD);
-    end = body_run<PG, OBS>(K, O, env, L, io, c, out, prof);
+    end = body_run<PG, OBS>(K, O, env, L, io, c, out, prof, rr);
   }
   body_emit<OBS>(K, O, env, io, out);
   return end;
@@ -1792,8 +1885,11 @@ enum { PATH_PROBE = 0,  // unsorted launch: read the hint with the fast rows, th
        PATH_FULL = 2 }; // sorted launch, full-hinted: no header round trip, straight to the state transfer
 
 // One env per workgroup (one wave): fast path out of HBM, or LDS-DMA in -> full_body -> write-back.
+// `lds`: this env's LDS block (l_ctab words); `lds_ctab`: where the topology tables are staged — behind the env's block, or
+// (multi-wave workgroups of the specialised build) one copy behind the blocks of all the workgroup's envs.  Every full-path
+// wave issues the copy itself and waits for its own transfer: waves of a workgroup write identical bytes, so they need no barrier.
 template <bool PG, bool OBS>
-MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds, const StepIO& io, int path) {
+MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds, const StepIO& io, int path, int32_t* lds_ctab = nullptr) {
   Lds L = make_lds(K, lds);
   Prof prof;
   // The 64-byte private header and the first action decide which path this step takes.
@@ -1817,12 +1913,14 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
   // Everything this step needs from HBM is requested before the first wait: hot frame, private state and
   // topology tables by LDS-DMA, the action words into registers.
   state_load_async<PG>(K, L, env);
-  stage_tables(K, L, lds + KD(l_ctab));
+  stage_tables(K, L, lds_ctab ? lds_ctab : lds + KD(l_ctab));
+  RingRegs rr;
+  ring_load(K, env, rr);
   int a0v = 0, a0p = 0, a0q = 0, a0t = 0;
   if (io.actions) { a0v = io.actions[0]; a0p = io.actions[1]; a0q = io.actions[2]; a0t = io.actions[3]; }
   wave::lds_dma_wait();
-  const StepEnd e = full_body<PG, OBS>(K, O, env, L, io, a0v, a0p, a0q, a0t, prof);
-  if (e.store) state_store<PG>(K, L, env, e);
+  const StepEnd e = full_body<PG, OBS>(K, O, env, L, io, a0v, a0p, a0q, a0t, prof, rr);
+  if (e.store) { state_store<PG>(K, L, env, e); ring_store(K, env, rr); }
   prof.mark(PF_STORE);
   prof.flush();
 }
@@ -1852,210 +1950,6 @@ MRX_DEV void step_loop(const CimParams& K, const CimObs& O, int32_t* lds, int w,
     wave::sync();
   }
 }
-
-// ==========================================================================================
-// PERSISTENT, PIPELINED STEP (plan-specialised builds with the order table): `W` resident waves walk the sorted order
-// list of the step (mrx_k_cim_schedule: full-path envs first).  Wave w takes full-path entries w, w + W, ...; while
-// env k is computed out of LDS, the state of env k+1 (frame | private state | buffer RNG state: one contiguous LDS
-// block, ST4 16-byte pieces) is already on its way from HBM into REGISTERS (56 VGPRs for 22p), requested right after
-// env k's tick inputs landed; at the end of env k its final state is read LDS -> registers, the prefetched state is
-// written registers -> LDS, and the write-back of env k is issued as fire-and-forget stores that drain under env k+1.
-// So in steady state a wave never waits for HBM, and there is no header round trip at all (the order list says which
-// path an env takes).  Fast-hinted envs are handled 64 per wave (one per lane, fast_step_lane) by the last waves.
-#if defined(MRX_SPECIALIZED)
-#if MRXC_pregen && MRXC_l_frame == 0 && MRXC_l_priv == MRXC_FW && MRXC_l_mt1 == MRXC_FW + MRXC_PW
-#define MRX_HAVE_PIPE 1
-enum { SF4 = MRXC_FW / 4, SP4 = MRXC_PW / 4, SM4 = MRXC_use_buffer_rng ? MT_WORDS / 4 : 0, ST4 = SF4 + SP4 + SM4, STN = (ST4 + 63) / 64 };
-struct EnvRegs {
-  wave::v4i r[STN];
-  int a0v, a0p, a0q, a0t, n_act, n_answered;
-};
-#ifdef __HIP_DEVICE_COMPILE__
-#define MRX_ASSUME(x) __builtin_assume(x)
-#else
-#define MRX_ASSUME(x) ((void)0)
-#endif
-// HBM address of 16-byte piece g of env's state block
-MRX_DEV int32_t* state_piece(const CimParams& K, int env, int g) {
-  int32_t* f = K.live + (size_t)env * MRXC_FW + 4 * g;
-  int32_t* p = K.priv + (size_t)env * MRXC_PW + 4 * (g - SF4);
-  int32_t* m = (int32_t*)(K.mt + ((size_t)env * MTS_COUNT + MTS_BUFFER) * MT_WORDS) + 4 * (g - SF4 - SP4);
-  return g < SF4 ? f : g < SF4 + SP4 ? p : m;
-}
-// `on` = false: there is no next env.  The loads are still issued — from one shared 16-byte dummy (the scheduling
-// block), i.e. an L2 hit and no HBM traffic — so that R is assigned UNCONDITIONALLY: a conditional prefetch would keep
-// the previous contents of all 56 registers alive across the whole step (the not-taken path's value of a phi).
-MRX_DEV void regs_load(const CimParams& K, const StepBatch& B, int env, bool on, EnvRegs& R) {
-  const int lane = wave::lane();
-  MRX_ASSUME(lane >= 0 && lane < 64);
-#pragma unroll
-  for (int c = 0; c < STN; c++) {
-    int g = c * 64 + lane;
-    g = g < ST4 ? g : ST4 - 1;
-    const int32_t* src = state_piece(K, env, g);
-    R.r[c] = wave::ld16(on ? src : K.sched);
-  }
-  const int32_t* a = (on && B.actions) ? B.actions + (size_t)env * MRXC_max_actions * 4 : K.sched + 4;  // (dummy: zeros)
-  const int32_t* na = (on && B.actions && B.n_actions) ? B.n_actions + env : K.sched + 4;
-  const int32_t* nw = (on && B.n_answered) ? B.n_answered + env : K.sched + 8;                          // (dummy: -1)
-  R.a0v = wave::ld_uniform_v(a); R.a0p = wave::ld_uniform_v(a + 1); R.a0q = wave::ld_uniform_v(a + 2); R.a0t = wave::ld_uniform_v(a + 3);
-  R.n_act = wave::ld_uniform_v(na);
-  R.n_answered = wave::ld_uniform_v(nw);
-}
-MRX_DEV void regs_to_lds(const EnvRegs& R, int32_t* lds) {
-  const int lane = wave::lane();
-  MRX_ASSUME(lane >= 0 && lane < 64);
-#pragma unroll
-  for (int c = 0; c < STN; c++) {
-    const int g = c * 64 + lane;
-    if (g < ST4) wave::lds_st16(lds + 4 * g, R.r[c]);
-  }
-}
-MRX_DEV void lds_to_regs(const int32_t* lds, EnvRegs& S) {
-  const int lane = wave::lane();
-  MRX_ASSUME(lane >= 0 && lane < 64);
-#pragma unroll
-  for (int c = 0; c < STN; c++) {
-    int g = c * 64 + lane;
-    g = g < ST4 ? g : ST4 - 1;
-    S.r[c] = wave::lds_ld16(lds + 4 * g);
-  }
-}
-// Exactly STN store instructions with a full exec mask, always (the caller counts on that number: s_waitcnt vmcnt).
-// Lanes behind the end of the block rewrite its last piece (same data).  Pieces that must not be written — the RNG state
-// when no twist regenerated it, everything when `on` is false — go to this wave's own 64-byte scratch line instead (all
-// lanes to one address: one line per instruction, and no line shared between waves).
-MRX_DEV void regs_store(const CimParams& K, int env, const EnvRegs& S, bool on, bool buf_dirty, int w) {
-  const int lane = wave::lane();
-  MRX_ASSUME(lane >= 0 && lane < 64);
-  int32_t* dummy = K.sched + 16 + 16 * (w & (MRX_PIPE_MAX_WAVES - 1));
-  // the two wave-uniform predicates as per-lane values the compiler cannot see through: address selects by arithmetic
-  // instead of branches around the stores — one straight line of STN stores on every path
-  int on_v = on ? 1 : 0, dirty_v = buf_dirty ? 1 : 0;
-  wave::opaque(on_v);
-  wave::opaque(dirty_v);
-#pragma unroll
-  for (int c = 0; c < STN; c++) {
-    int g = c * 64 + lane;
-    g = g < ST4 ? g : ST4 - 1;
-    int wr = (on_v != 0 && (g < SF4 + SP4 || dirty_v != 0)) ? 1 : 0;
-    wave::opaque(wr);
-    const uintptr_t pa = (uintptr_t)state_piece(K, env, g), da = (uintptr_t)dummy;
-    wave::st16_nt_addr(da + ((pa - da) & (uintptr_t)(-(long long)wr)), S.r[c]);
-  }
-}
-
-template <bool OBS>
-MRX_DEV void step_persistent(const CimParams& K, const CimObs& O, int32_t* lds, int w, int W, const StepBatch& B) {
-  Lds L = make_lds(K, lds);
-  Prof prof;
-  const int lane = wave::lane();
-  const int n = K.n_envs;
-  int i = w;
-  int e0 = i < n ? wave::ld_uniform_v(K.order + i) : -1;
-  int e1 = i + W < n ? wave::ld_uniform_v(K.order + i + W) : -1;
-  int n_tick = wave::ld_uniform_v(K.sched + 0), n_active = wave::ld_uniform_v(K.sched + 1);
-  stage_tables(K, L, lds + MRXC_l_ctab);
-  e0 = U(e0); e1 = U(e1); n_tick = U(n_tick); n_active = U(n_active);
-  EnvRegs R;
-  bool have_cur = e0 >= 0 && (e0 & MRX_ORDER_TICK);
-  int env_cur = e0 & (MRX_ORDER_TICK - 1);
-  regs_load(K, B, env_cur, have_cur, R);
-
-  // ---- fast-hinted envs: chunks of 64 entries behind the full-path ones, dealt to the LAST waves (which have the
-  // fewest full-path entries), one env per lane
-  {
-    const int n_fast = n_active - n_tick;
-    for (int q = W - 1 - w; q * 64 < n_fast; q += W) {  // wave-uniform
-      const int j = n_tick + q * 64 + lane;
-      const bool have = j < n_active;
-      bool handled = true;
-      int env = 0;
-      if (have) {
-        env = K.order[j] & (MRX_ORDER_TICK - 1);
-        const StepIO io = step_io(K, B, env);
-        handled = fast_step_lane<OBS>(K, O, env, io.actions, io.n_act > MRXC_max_actions ? MRXC_max_actions : io.n_act, io.dec_out, io.met_out,
-                                      io.done_out);
-      }
-      uint64_t todo = wave::ballot(have && !handled);
-      while (todo) {  // stale hint / several actions: the general path, one env at a time (LDS is still free here)
-        const int b = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int env_b = wave::bcast(env, b);
-        step_env<true, OBS>(K, O, env_b, lds, step_io(K, B, env_b), PATH_FULL);
-        wave::sync();
-      }
-    }
-  }
-
-  // ---- the pipelined loop over this wave's full-path entries.  Order of the memory traffic of one iteration (env k):
-  //   [k-1's end]  tick inputs of env k requested (loads L1), THEN the write-back of env k-1 (exactly STN stores)
-  //   body_act(k); wait for L1 only: s_waitcnt vmcnt(STN) — the stores stay in flight
-  //   outputs of env k-1 stored (they were held in registers), state of env k+1 requested (loads L2)
-  //   body_run(k): the tick phases — long enough for the stores and L2 to finish before the next wait:
-  //   state of env k: LDS -> registers; state of env k+1: registers -> LDS (L2 landed long ago)
-  wave::lds_dma_wait();  // tables staged, first state landed
-  StepCtx c;
-  StepOut out_prev, out;
-  out_prev.kind = 0;
-  StepIO io_prev = step_io(K, B, 0, false);
-  int env_prev = 0;
-  bool open_ok = false;
-  if (have_cur) {
-    regs_to_lds(R, lds);
-    wave::sync();
-    c.a0v = U(R.a0v); c.a0p = U(R.a0p); c.a0q = U(R.a0q); c.a0t = U(R.a0t); c.n_act = U(R.n_act); c.n_answered = U(R.n_answered);
-    open_ok = body_open<true>(K, env_cur, L, c, out);
-    // STN stores to the scratch area: on EVERY path into the loop the tick inputs requested by body_open are followed by
-    // exactly STN stores (here: dummies; later: the previous env's write-back), so one s_waitcnt vmcnt(STN) fits all
-    regs_store(K, 0, R, false, false, w);
-  }
-  while (have_cur) {  // wave-uniform
-    const bool have_next = e1 >= 0 && (e1 & MRX_ORDER_TICK);
-    const int env_next = e1 & (MRX_ORDER_TICK - 1);
-    const StepIO io = step_io(K, B, env_cur, false);  // (the counts and the first action were prefetched with the state)
-    StepEnd end = {false, false, false};
-    prof.mark(PF_LOAD);
-    if (open_ok) body_act(K, L, io.actions, c);
-    prof.mark(PF_ACTION);
-    // L1 was issued before the STN write-back stores of the previous env: with the in-order vmcnt, "at most STN
-    // operations outstanding" means L1 has landed while the stores may still be in flight
-    wave::wait_vm<STN>();
-    tick_prefetch_land(c.pf);
-    body_emit<OBS>(K, O, env_prev, io_prev, out_prev);  // the previous env's outputs, held back until here
-    regs_load(K, B, env_next, have_next, R);             // L2: the next env's state (dummy loads when there is none)
-    int e2 = wave::ld_uniform_v(i + 2 * W < n ? K.order + i + 2 * W : K.sched + 8);  // (the entry after that; dummy: -1)
-    prof.mark(PF_MT_LOAD);
-    if (open_ok) end = body_run<true, OBS>(K, O, env_cur, L, io, c, out, prof);
-    e2 = U(e2);  // (consumed here, with L2: a wait for it behind the stores below would wait for them as well)
-    prof.mark(12);  // (tools: wait for L2)
-    // env_cur's final state leaves LDS, the prefetched state of env_next enters
-    EnvRegs S;
-    lds_to_regs(lds, S);
-    wave::sync();
-    out_prev = out; io_prev = io; env_prev = env_cur;
-    open_ok = false;
-    if (have_next) {
-      regs_to_lds(R, lds);
-      wave::sync();
-      prof.mark(13);  // (tools: state swap through LDS)
-      c.a0v = U(R.a0v); c.a0p = U(R.a0p); c.a0q = U(R.a0q); c.a0t = U(R.a0t); c.n_act = U(R.n_act); c.n_answered = U(R.n_answered);
-      open_ok = body_open<true>(K, env_next, L, c, out);  // L1 of the next env: BEFORE the stores below
-      prof.mark(14);  // (tools: body_open of the next env)
-    }
-    // exactly STN store instructions, whatever the lane / dirty predicates (they redirect to a dummy address)
-    regs_store(K, env_cur, S, end.store, end.buf_dirty, w);
-    prof.mark(PF_STORE);
-    i += W; e0 = e1; e1 = e2;
-    have_cur = have_next;
-    env_cur = env_next;
-  }
-  body_emit<OBS>(K, O, env_prev, io_prev, out_prev);
-  prof.mark(PF_STORE);
-  prof.flush();
-}
-#endif
-#endif
 
 // ==========================================================================================
 // QUERY: snapshot_list[node][ticks:nodes:attrs] -> float64 (np_backend.pyx:520-549)

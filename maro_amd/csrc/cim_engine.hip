@@ -209,8 +209,6 @@ struct mrx_cim_engine {
   hipModule_t spec_module = nullptr;      // plan-specialised step kernels (mrx_cim_load_step_kernels), else the generic ones
   hipFunction_t spec_fn[4] = {nullptr, nullptr, nullptr, nullptr};  // [pregen * 2 + obs]
   hipFunction_t spec_reset = nullptr, spec_order_table = nullptr;
-  hipFunction_t spec_pipe = nullptr;      // mrx_k_cim_step_pipe (persistent pipelined step), when the code object has it
-  int pipe_waves = 0;                     // its grid: the number of waves that are resident at once
   hipFunction_t spec_fast = nullptr, spec_loop = nullptr;   // launch form 4 (mrx_k_cim_fast_lanes*, mrx_k_cim_step_loop*)
   int loop_waves = 0;                     // grid of the looped full-path kernel (generic or specialised build in use)
   int step_mode = 0;                      // mrx_cim_set_step_mode (0 = automatic)
@@ -227,10 +225,9 @@ struct mrx_cim_engine {
       if (cur != device && cur >= 0) hipSetDevice(cur);
     }
     spec_module = nullptr;
-    spec_pipe = spec_reset = spec_order_table = spec_fast = spec_loop = nullptr;
+    spec_reset = spec_order_table = spec_fast = spec_loop = nullptr;
     loop_waves = 0;
     for (auto& f : spec_fn) f = nullptr;
-    pipe_waves = 0;
   }
   ~mrx_cim_engine() { unload_spec(); }
 };
@@ -372,13 +369,13 @@ int mrx_cim_step_joint(mrx_handle h, const int32_t* d_actions, const int32_t* d_
   return launch_step(h, d_actions, d_n_actions, d_n_answered, d_env_mask, d_decisions, d_metrics, d_done, stream);
 }
 
-// The launch form a step uses: 1 unsorted (workgroup b = env b), 2 sorted by mrx_k_cim_schedule, 3 persistent pipelined
-// kernel (plan-specialised code objects with the order table).  0 / unset: the best one available.
+// The launch form a step uses: 1 unsorted (workgroup b = env b), 2 sorted by mrx_k_cim_schedule, 4 split (lane-parallel
+// fast-path kernel + looped full-path kernel).  0 / unset: the best one available (2).
 static int effective_step_mode(mrx_handle h) {
   static const int env_mode = getenv("MRX_CIM_STEP_MODE") ? atoi(getenv("MRX_CIM_STEP_MODE")) : 0;  // experiments
   int m = h->step_mode ? h->step_mode : env_mode;
   if (m < 1 || m > 4) m = 2;  // measured (profiles/r02_*): the sorted launch is the fastest form at 16384 envs per GPU
-  if (m == 3 && !(h->spec_module && h->spec_pipe && h->pipe_waves > 0)) m = 2;
+  if (m == 3) m = 2;  // (3 was the persistent pipelined kernel of round 2: measured slower than the sorted launch, removed in round 3)
   if (m == 4 && h->spec_module && !(h->spec_fast && h->spec_loop)) m = 2;
   return m;
 }
@@ -442,16 +439,11 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
   if (h->spec_module) {
     CimParams Kc = K;
     CimObs Oc = h->obs;
-    if (mode == 3) {
-      void* params[] = {&Kc, &Oc, &B};
-      HIP_TRY(hipModuleLaunchKernel(h->spec_pipe, (unsigned)(h->pipe_waves < K.n_envs ? h->pipe_waves : K.n_envs), 1, 1, 64, 1, 1,
-                                    (unsigned)((size_t)K.lds_words * 4 + lds_pad), (hipStream_t)stream, params, nullptr));
-      return MRX_OK;
-    }
     int srt = sorted;
     void* params[] = {&Kc, &Oc, &B, &d_env_mask, &srt};
-    HIP_TRY(hipModuleLaunchKernel(h->spec_fn[(K.pregen ? 2 : 0) + (obs ? 1 : 0)], (unsigned)K.n_envs, 1, 1, 64, 1, 1,
-                                  (unsigned)((size_t)K.lds_words * 4 + lds_pad), (hipStream_t)stream, params, nullptr));
+    const int kw = K.wg_waves > 0 ? K.wg_waves : 1;   // envs per workgroup: one staged copy of the topology tables for all of them
+    HIP_TRY(hipModuleLaunchKernel(h->spec_fn[(K.pregen ? 2 : 0) + (obs ? 1 : 0)], (unsigned)((K.n_envs + kw - 1) / kw), 1, 1, (unsigned)(64 * kw), 1, 1,
+                                  (unsigned)((K.lean_ok ? ((size_t)kw * K.l_ctab + K.ctab_words + 3) / 4 * 16 : (size_t)K.lds_words * 4) + lds_pad), (hipStream_t)stream, params, nullptr));
     return MRX_OK;
   }
   auto kern = K.pregen ? (obs ? mrx_k_cim_step_tab_obs : mrx_k_cim_step_tab) : (obs ? mrx_k_cim_step_obs : mrx_k_cim_step);
@@ -668,7 +660,11 @@ int mrx_cim_load_step_kernels(mrx_handle h, const void* image, int64_t bytes, co
       shared_module_release(mod);
       return set_err(MRX_ERR_INVALID_ARG, std::string("code object lacks kernel ") + names[i]);
     }
-    if ((size_t)h->plan.kp.lds_words * 4 > 64 * 1024) hipFuncSetAttribute((const void*)fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, h->plan.kp.lds_words * 4);
+    {
+      const CimParams& Kp = h->plan.kp;
+      const size_t wg_bytes = Kp.lean_ok ? ((size_t)(Kp.wg_waves > 0 ? Kp.wg_waves : 1) * Kp.l_ctab + Kp.ctab_words + 3) / 4 * 16 : (size_t)Kp.lds_words * 4;
+      if (wg_bytes > 64 * 1024) hipFuncSetAttribute((const void*)fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)wg_bytes);
+    }
   }
   hipFunction_t f_reset = nullptr, f_table = nullptr;
   if (hipModuleGetFunction(&f_reset, mod, "mrx_k_cim_reset") != hipSuccess || hipModuleGetFunction(&f_table, mod, "mrx_k_cim_order_table") != hipSuccess) {
@@ -695,21 +691,6 @@ int mrx_cim_load_step_kernels(mrx_handle h, const void* image, int64_t bytes, co
     } else {
       (void)hipGetLastError();
     }
-  }
-  // the persistent pipelined step, if this plan's code object has it (order table on): its grid is the number of waves the
-  // device holds at once for this kernel's registers + LDS
-  hipFunction_t f_pipe = nullptr;
-  if (hipModuleGetFunction(&f_pipe, mod, "mrx_k_cim_step_pipe") == hipSuccess && f_pipe) {
-    if ((size_t)h->plan.kp.lds_words * 4 > 64 * 1024) hipFuncSetAttribute((const void*)f_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, h->plan.kp.lds_words * 4);
-    int per_cu = 0, cus = 0;
-    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f_pipe, 64, (size_t)h->plan.kp.lds_words * 4) == hipSuccess &&
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && per_cu > 0 && cus > 0) {
-      if (getenv("MRX_CIM_PIPE_WAVES_PER_CU")) per_cu = atoi(getenv("MRX_CIM_PIPE_WAVES_PER_CU"));  // experiments
-      h->spec_pipe = f_pipe;
-      h->pipe_waves = per_cu * cus < MRX_PIPE_MAX_WAVES ? per_cu * cus : MRX_PIPE_MAX_WAVES;
-    }
-  } else {
-    (void)hipGetLastError();
   }
   return MRX_OK;
 }

@@ -4,6 +4,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -178,8 +179,10 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   if (k.T >= (1 << 23)) return fail("engine limit: max_tick < 2^23");
   if (t->total_containers >= (1 << 24)) return fail("engine limit: total_containers < 2^24");
   // private state
-  k.pv_evt = PH_COUNT; k.pv_next = k.pv_evt + V; k.pv_pos = k.pv_next + V; k.pv_krl = k.pv_pos + V; k.pv_period = k.pv_krl + V; k.pv_rfull = k.pv_period + V; k.pv_rempty = k.pv_rfull + H * NT;
-  k.PW = (k.pv_rempty + H * P + 3) / 4 * 4;
+  k.pv_evt = PH_COUNT; k.pv_next = k.pv_evt + V; k.pv_pos = k.pv_next + V; k.pv_krl = k.pv_pos + V; k.pv_period = k.pv_krl + V; k.pv_rempty = k.pv_period + V;
+  k.PWH = (k.pv_rempty + H * P + 3) / 4 * 4;   // the head: what every build stages in LDS (16-byte rows)
+  k.pv_rfull = k.PWH;                          // pending full returns [H][NT]: LDS in the generic layout, registers in a lean build
+  k.PW = (k.pv_rfull + H * NT + 3) / 4 * 4;
   // derived integer tables
   std::vector<int32_t> pair_src(NT ? NT : 1), v_route_base(V), v_route_len(V), v_total_space(V), leg_off(V + 1), leg_time,
       v_period(V), er_delay(P), fr_delay(P), rec_off(V + 1);
@@ -221,9 +224,9 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   const int dtgt_w = 2 * (NT + 1) > 3 * 64 ? 2 * (NT + 1) : 3 * 64;
   int w = 0;
   k.l_frame = w; w += k.FW;
-  k.l_priv = w; w += k.PW;
+  k.l_priv = w; w += k.PWH;
   if (!k.pregen) { k.l_mt0 = w; w += MT_WORDS; }  // with the order table the order stream and the generator's fp64
-  k.l_mt1 = w; w += MT_WORDS;                    // scratch live in the reset kernel's LDS only (see below)
+  k.l_mt1 = w; w += MT_WORDS;                    // scratch live in the reset / order-table kernels' LDS only (see below)
   w = (w + 1) / 2 * 2;
   if (!k.pregen) { k.l_dsrc = w; w += dsrc_w; }
   k.misc_cap = dtgt_w / 3;
@@ -232,11 +235,9 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
     const int mw = NT + 1 > 3 * 64 ? (NT + 2) / 2 * 2 : 3 * 64;
     k.l_misc = w; w += mw; k.misc_cap = mw / 3;
   }
-  k.l_oq = w; w += NT + 1;  // order quantity | (buffer ticks + 1) << 24
-  k.l_odelay = k.l_oq;
   k.l_srcn = w; w += P;
   w = (w + 1) / 2 * 2;
-  k.lds_words = (w + 3) / 4 * 4;
+  k.lds_words = (w + 3) / 4 * 4;   // (the staged tables and the two per-pair arrays follow: below, once ctab_words is known)
 
   // ---- constant blob
   std::vector<uint8_t>& B = pl->const_blob;
@@ -331,18 +332,41 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   }
   pl->ctab_rel = ctab_begin;
   k.ctab_words = (int)((ctab_end - ctab_begin) / 4);
-  k.l_ctab = (k.lds_words + 1) / 2 * 2;
-  k.lds_words = (k.l_ctab + k.ctab_words + 3) / 4 * 4;
-  // reset_env's extra RNG streams (route, order-init, and with the order table the order stream it only seeds): they are dead
-  // once the streams are persisted, BEFORE frame and private state are initialised in LDS, so when they fit they alias that
-  // region — the reset kernel is a latency chain (route unrolling: ~5000 sequential stops per env) and its throughput is its
-  // occupancy: 25.6 KB -> 18.1 KB of LDS = 6 -> 9 waves per CU for global_trade.22p
-  const bool alias_reset_streams = k.FW + k.PW >= (k.pregen ? 3 : 2) * MT_WORDS;
-  if (alias_reset_streams) { k.l_mt2 = k.l_frame; k.l_mt3 = k.l_mt2 + MT_WORDS; k.lds_words_reset = k.lds_words; }
-  else { k.l_mt2 = k.lds_words; k.l_mt3 = k.l_mt2 + MT_WORDS; k.lds_words_reset = k.l_mt3 + MT_WORDS; }
+  k.l_ctab = (k.lds_words + 3) / 4 * 4;   // (16-byte aligned: also the stride between the envs of a multi-wave workgroup)
+  // LEAN builds (cim_device.h MRX_LEAN) keep the two arrays that are only ever indexed by "my lane's order pair" — the pending
+  // full returns [H][NT] and the tick's order quantities [NT] — in registers; they come LAST in the LDS layout, so that a lean
+  // launch simply reserves lds_words_lean and every other offset is the same for both kinds of build.
+  k.lds_words_lean = (k.l_ctab + k.ctab_words + 3) / 4 * 4;
+  k.l_rfull = k.lds_words_lean;
+  k.l_oq = k.l_rfull + (H * NT + 3) / 4 * 4;  // order quantity | (buffer ticks + 1) << 24
+  k.l_odelay = k.l_oq;
+  k.lds_words = (k.l_oq + NT + 1 + 3) / 4 * 4;
+  k.lean_ok = (k.pregen && NT <= 192 && H <= 4) ? 1 : 0;
+  // Envs per workgroup of the plan-specialised step kernel.  Every wave still owns one env and never talks to another one,
+  // but the k waves of a workgroup share ONE staged copy of the topology tables: k * l_ctab + ctab_words words per workgroup.
+  // gfx950 hands out LDS in 1280-byte granules, 128 per CU (measured: tools/hbm_pattern_bench --residency); take the
+  // smallest k <= 4 that maximises the resident waves (global_trade.22p: 10 one-wave workgroups, or 4 x 3 waves = 12).
+  {
+    int best_k = 1, best_waves = 0;
+    for (int kk = 1; kk <= 4; kk++) {
+      const long long bytes = ((long long)kk * k.l_ctab + k.ctab_words + 3) / 4 * 4 * 4;
+      const long long gran = (bytes + 1279) / 1280;
+      const int waves = gran > 128 ? 0 : (int)(128 / gran) * kk;
+      if (waves > best_waves) { best_waves = waves; best_k = kk; }
+    }
+    // Measured on global_trade.22p (profiles/r03_lds_diet.md): 4 x 3 waves = 12 waves per CU run no faster than 10 one-wave
+    // workgroups (262 vs 261 M env-steps/s; 5 x 2 waves: 246 M) — a workgroup's LDS is only released when its slowest wave
+    // is done, which costs what the extra residency gains.  So the default stays one env per workgroup; the knob remains.
+    best_k = 1;
+    if (const char* ev = getenv("MRX_CIM_WG_WAVES")) { const int v = atoi(ev); if (v >= 1 && v <= 16 && k.lean_ok) best_k = v; }  // experiments (lean layout only: the envs' blocks must end at l_ctab)
+    k.wg_waves = best_k;
+  }
+  // reset_env: four RNG streams side by side (order-init, route, order, buffer: all seeded, the data generated, three of them
+  // persisted), and only THEN frame and private head are initialised in the same LDS words — the reset kernel is a latency chain
+  // (route unrolling: ~5000 sequential stops per env), its throughput is its occupancy: 10 KB of LDS = 16 waves per CU
+  k.l_mt2 = 0; k.l_mt3 = MT_WORDS; k.r_mt0 = 2 * MT_WORDS; k.r_mt1 = 3 * MT_WORDS;
+  k.lds_words_reset = 4 * MT_WORDS > k.FW + k.PWH ? 4 * MT_WORDS : (k.FW + k.PWH + 3) / 4 * 4;
   if (k.pregen) {
-    if (alias_reset_streams) k.l_mt0 = k.l_mt3 + MT_WORDS;
-    else { k.l_mt0 = k.lds_words_reset; k.lds_words_reset += MT_WORDS; }  // reset_env seeds the order stream here
     // the order-table kernel: order RNG state, generator scratch, staged tables
     int g = 0;
     k.g_mt0 = g; g += MT_WORDS;
@@ -355,7 +379,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
     k.g_ctab = (g + 3) / 4 * 4;
     k.lds_words_gen = (k.g_ctab + k.ctab_words + 3) / 4 * 4;
   }
-  if ((int64_t)k.lds_words_reset * 4 > 160 * 1024) return fail("engine limit: per-env state exceeds 160 KiB of LDS");
+  if ((int64_t)k.lds_words_reset * 4 > 160 * 1024 || (int64_t)k.lds_words * 4 > 160 * 1024) return fail("engine limit: per-env state exceeds 160 KiB of LDS");
 
   // ---- workspace carve-up
   Arena A;

@@ -34,12 +34,14 @@ struct CimParams {
   int NC;  // compact matrix cells: sum over vessels of the distinct ports on its route (full_on_vessels / vessel_plans
            // are stored [vessel][route port] — every other cell of the dense V x P matrices is constant 0 / -1)
   // ---- private-state layout (words)
-  int PW, pv_evt, pv_next, pv_pos, pv_krl, pv_period, pv_rfull, pv_rempty;
+  int PW, PWH /* the head staged in LDS: everything but the pending full returns */, pv_evt, pv_next, pv_pos, pv_krl, pv_period, pv_rfull, pv_rempty;
   int REC_W;
   // ---- LDS layout (word offsets)
   int l_frame, l_priv, l_mt0, l_mt1, l_dsrc, l_dtgt, l_oq, l_odelay, l_srcn, l_misc, lds_words;
   int l_ctab, ctab_words;  // serial-access int tables staged in LDS by the step kernel
-  int l_mt2, l_mt3, lds_words_reset;  // reset kernel only (placed after the step kernel's LDS)
+  int wg_waves;            // envs (= waves) per workgroup of the plan-specialised step kernel: they share ONE staged copy of the tables
+  int l_mt2, l_mt3, r_mt0, r_mt1, lds_words_reset;  // reset kernel only: route / order-init / order / buffer streams (its own layout)
+  int l_rfull, lds_words_lean, lean_ok;  // pending full returns in the generic LDS layout; what a lean launch reserves (cim_device.h MRX_LEAN)
   int decision_mode;  // 0 Sequential, 1 Joint, 2 JointWithSequentialAction (core.py:349-366)
   int data_mode;      // 0 generated at reset, 1 dump folder, 2 real data files (mrx_cim_topology.data_mode)
   int data_T;         // ticks covered by the fixed order proportion
@@ -110,6 +112,7 @@ struct CimParams {
   X(misc_cap) \
   X(NC) \
   X(PW) \
+  X(PWH) \
   X(pv_evt) \
   X(pv_next) \
   X(pv_pos) \
@@ -131,6 +134,7 @@ struct CimParams {
   X(lds_words) \
   X(l_ctab) \
   X(ctab_words) \
+  X(wg_waves) \
   X(decision_mode) \
   X(data_mode) \
   X(data_T) \
@@ -138,6 +142,11 @@ struct CimParams {
   X(NTP) \
   X(l_mt2) \
   X(l_mt3) \
+  X(r_mt0) \
+  X(r_mt1) \
+  X(l_rfull) \
+  X(lds_words_lean) \
+  X(lean_ok) \
   X(lds_words_reset) \
   X(g_mt0) \
   X(g_dsrc) \

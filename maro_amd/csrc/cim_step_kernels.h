@@ -21,23 +21,33 @@ mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const
 #ifndef MRX_STEP_WAVES
 #define MRX_STEP_WAVES 2  // generic build: ~197 VGPRs, 2 waves/SIMD
 #endif
-// One env per workgroup.  sorted = 0: workgroup b steps env b (the fast rows and the env's hint are read first);
-// sorted = 1: workgroup b steps entry b of the order list of this step (mrx_k_cim_schedule: full-path envs first, so the
-// long waves start first and the short ones fill the tail; a full-path entry skips the header round trip).
+// One env per WAVE, MRX_WG_WAVES waves per workgroup (1 in the generic build; the plan's wg_waves in a specialised one: the
+// waves share the staged topology tables and nothing else).  sorted = 0: wave s steps env s (the fast rows and the env's hint
+// are read first); sorted = 1: wave s steps entry s of the order list of this step (mrx_k_cim_schedule: full-path envs first,
+// so the long waves start first and the short ones fill the tail; a full-path entry skips the header round trip).
+#ifdef MRX_SPECIALIZED
+#define MRX_WG_WAVES MRXC_wg_waves
+#else
+#define MRX_WG_WAVES 1
+#endif
 #define MRX_STEP_KERNEL(NAME, PG, OBS, WAVES)                                                                            \
-  extern "C" __global__ void __launch_bounds__(64, WAVES)                                                               \
+  extern "C" __global__ void __launch_bounds__(64 * MRX_WG_WAVES, WAVES)                                                 \
   NAME(CimParams K, CimObs O, cim::StepBatch B, const uint8_t* __restrict__ mask, int sorted) {                          \
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];                                                       \
-    int env = blockIdx.x, path = cim::PATH_PROBE;                                                                       \
+    const int w = MRX_WG_WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;                        \
+    const int slot = (int)blockIdx.x * MRX_WG_WAVES + w;                                                                \
+    if (MRX_WG_WAVES > 1 && slot >= K.n_envs) return;                                                                   \
+    int env = slot, path = cim::PATH_PROBE;                                                                             \
     if (sorted) {                                                                                                       \
-      const int e = K.order[blockIdx.x];                                                                                \
+      const int e = K.order[slot];                                                                                      \
       if (e < 0) return;                                                                                                \
       env = e & (MRX_ORDER_TICK - 1);                                                                                   \
       path = (e & MRX_ORDER_TICK) ? cim::PATH_FULL : cim::PATH_FAST;                                                    \
     } else if (mask && !mask[env]) {                                                                                    \
       return;                                                                                                           \
     }                                                                                                                   \
-    cim::step_env<PG, OBS>(K, O, env, lds, cim::step_io(K, B, env), path);                                              \
+    cim::step_env<PG, OBS>(K, O, env, lds + w * KD(l_ctab), cim::step_io(K, B, env), path,                               \
+                           lds + MRX_WG_WAVES * KD(l_ctab));                                                            \
   }
 // a specialised build only needs the one kernel that matches its plan's order mode (CimParams::pregen) and whether a fused
 // observation is configured (mrx_cim_set_observation reloads the code object when that changes)
@@ -76,15 +86,3 @@ MRX_SPLIT_KERNELS(_tab_obs, true, true, MRX_STEP_WAVES)
 #undef MRX_WANT
 #undef MRX_STEP_KERNEL
 #undef MRX_SPLIT_KERNELS
-
-// The persistent, pipelined step (cim::step_persistent): gridDim.x resident waves walk the sorted order list.
-#ifdef MRX_HAVE_PIPE
-#ifndef MRX_PIPE_WAVES
-#define MRX_PIPE_WAVES 2  // the prefetched state of the next env lives in ~56 more VGPRs: 2 waves/SIMD = 8 waves/CU
-#endif
-extern "C" __global__ void __launch_bounds__(64, MRX_PIPE_WAVES)
-mrx_k_cim_step_pipe(CimParams K, CimObs O, cim::StepBatch B) {
-  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-  cim::step_persistent<(MRXC_obs_np | MRXC_obs_nv) != 0>(K, O, lds, (int)blockIdx.x, (int)gridDim.x, B);
-}
-#endif

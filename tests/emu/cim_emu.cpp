@@ -34,7 +34,7 @@ void* emu_create(const mrx_cim_topology* t, const mrx_cim_config* c, char* errbu
   memset(e->ws, 0xCD, (size_t)e->plan.workspace_bytes);  // poison: nothing may rely on zeroed HBM
   memcpy(e->ws + e->plan.const_off, e->plan.const_blob.data(), e->plan.const_blob.size());
   cim_plan_bind(&e->plan, e->ws);
-  e->lds = (int32_t*)aligned_alloc(256, (size_t)e->plan.kp.lds_words_reset * 4 + 256);
+  e->lds = (int32_t*)aligned_alloc(256, ((size_t)(e->plan.kp.lds_words_reset > e->plan.kp.lds_words ? e->plan.kp.lds_words_reset : e->plan.kp.lds_words) * 4 + 511) / 256 * 256);
   return e;
 }
 
@@ -77,8 +77,8 @@ static void emu_schedule(Emu* e, const uint8_t* mask) {
   for (int i = 0; i < 16; i++) K.sched[i] = i == 0 ? nt : i == 1 ? na : i >= 8 ? -1 : 0;
 }
 
-// mode 1: unsorted (workgroup b = env b, hint probed); 2: sorted one-env-per-workgroup launch; 3: persistent pipelined
-// kernel with `pipe_waves` resident waves (plan-specialised builds with the order table only)
+// mode 1: unsorted (workgroup b = env b, hint probed); 2: sorted one-env-per-workgroup launch; 4: split step, its looped
+// full-path kernel with `pipe_waves` waves
 void emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const uint8_t* mask, int32_t* dec,
               int64_t* met, uint8_t* done, int reverse, const int32_t* n_answered, int mode, int pipe_waves) {
   Emu* e = (Emu*)h;
@@ -101,21 +101,6 @@ void emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const u
       });
     }
     return;
-  }
-  if (mode == 3) {
-#ifdef MRX_HAVE_PIPE
-    memset(e->lds, 0xAB, (size_t)K.lds_words * 4);
-    for (int w = 0; w < pipe_waves; w++) {
-      wave::run_wave(e->wave, [&]() {
-        if (obs) cim::step_persistent<true>(K, e->obs, e->lds, w, pipe_waves, B);
-        else cim::step_persistent<false>(K, e->obs, e->lds, w, pipe_waves, B);
-      });
-    }
-    return;
-#else
-    fprintf(stderr, "emu_step: mode 3 needs a plan-specialised build with the order table\n");
-    abort();
-#endif
   }
   for (int b = 0; b < K.n_envs; b++) {
     int env = b, path = cim::PATH_PROBE;
@@ -183,8 +168,8 @@ extern "C" int emu_dump_dims(void* h, char* buf, int len) {
   D(P) D(V) D(R) D(NT) D(NRP) D(past_n) D(future_n) D(vrows) D(FW) D(S) D(H) D(SMAX) D(T) D(start_tick) D(resolution)
   D(max_actions) D(period) D(vol) D(total_containers) D(order_mode) D(use_order_rng) D(use_buffer_rng) D(has_order_init)
   D(idx_order_init) D(idx_route) D(idx_order_num) D(idx_buffer) D(f_ports) D(f_vessels) D(f_fop) D(f_fov) D(f_plans)
-  D(misc_cap) D(NC) D(PW) D(pv_evt) D(pv_next) D(pv_pos) D(pv_krl) D(pv_period) D(pv_rfull) D(pv_rempty) D(REC_W)
-  D(l_frame) D(l_priv) D(l_mt0) D(l_mt1) D(l_dsrc) D(l_dtgt) D(l_oq) D(l_odelay) D(l_srcn) D(l_misc) D(lds_words) D(l_ctab)
+  D(misc_cap) D(NC) D(PW) D(PWH) D(pv_evt) D(pv_next) D(pv_pos) D(pv_krl) D(pv_period) D(pv_rfull) D(pv_rempty) D(REC_W)
+  D(l_frame) D(l_priv) D(l_mt0) D(l_mt1) D(l_dsrc) D(l_dtgt) D(l_oq) D(l_odelay) D(l_srcn) D(l_misc) D(lds_words) D(l_ctab) D(wg_waves) D(l_rfull) D(lds_words_lean) D(lean_ok) D(l_mt2) D(l_mt3) D(r_mt0) D(r_mt1) D(lds_words_reset)
   D(ctab_words) D(decision_mode) D(data_mode) D(data_T) D(pregen) D(NTP)
 #undef D
   if ((int)o.size() + 1 > len) return -1;

@@ -1,7 +1,8 @@
-"""The three launch forms of mrx_cim_step on the CPU wave emulator (tests/emu): 1 = unsorted one-env-per-workgroup launch
+"""The launch forms of mrx_cim_step on the CPU wave emulator (tests/emu): 1 = unsorted one-env-per-workgroup launch
 (the hint is probed), 2 = sorted launch (the order list of mrx_k_cim_schedule: full-path envs first, no header round trip),
-3 = the persistent pipelined kernel of the plan-specialised builds (register-prefetched next env, lane-parallel fast
-path).  All three must produce the same outputs and the same engine state, step by step, and replay the goldens."""
+4 = split step (lane-parallel fast-path kernel + looped full-path kernel); "S" = the PLAN-SPECIALISED build (lean layout:
+return ring and order quantities in registers, cim_device.h MRX_LEAN) in the sorted launch.  All must produce the same
+outputs and the same engine state, step by step, and replay the goldens."""
 import numpy as np
 import pytest
 
@@ -35,8 +36,8 @@ def side_by_side(topology, modes, n=6, durations=45, obs=False, max_actions=1, s
     for m in modes:
         kw = dict(n_envs=n, start_tick=start_tick, durations=durations, snapshot_resolution=resolution, max_actions=max_actions, max_snapshots=4,
                   decision_mode=joint)
-        if m == 3:
-            kw.update(specialized=True, step_mode=3, pipe_waves=4, spec_obs=OBS if obs else ((), ()))
+        if m == "S":
+            kw.update(specialized=True, step_mode=2, spec_obs=OBS if obs else ((), ()))
         elif m == 4:
             kw.update(step_mode=4, pipe_waves=3)
         else:
@@ -99,12 +100,12 @@ def test_sorted_launch_with_observation_and_two_actions():
 
 
 @pytest.mark.parametrize("topology", ["global_trade.22p_l0.8", "toy.5p_ssddd_l0.5", "toy.4p_ssdd_l0.0"])
-def test_persistent_pipelined_kernel_equals_unsorted(topology):
-    assert side_by_side(topology, (1, 3)) > 30
+def test_specialised_lean_build_equals_generic_unsorted(topology):
+    assert side_by_side(topology, (1, "S")) > 30
 
 
-def test_persistent_pipelined_kernel_with_observation_and_two_actions():
-    side_by_side("global_trade.22p_l0.8", (1, 3), n=9, obs=True, max_actions=2, durations=30)
+def test_specialised_lean_build_with_observation_and_two_actions():
+    side_by_side("global_trade.22p_l0.8", (1, "S"), n=9, obs=True, max_actions=2, durations=30)
 
 
 @pytest.mark.parametrize("topology", ["global_trade.22p_l0.8", "toy.5p_ssddd_l0.5"])
@@ -120,21 +121,21 @@ def test_split_step_joint_mode():
     side_by_side("toy.5p_ssddd_l0.5", (1, 4), joint=1, durations=40)
 
 
-def test_persistent_pipelined_kernel_joint_mode():
-    side_by_side("toy.5p_ssddd_l0.5", (1, 3), joint=1, durations=40)
+def test_specialised_lean_build_joint_mode():
+    side_by_side("toy.5p_ssddd_l0.5", (1, "S"), joint=1, durations=40)
 
 
 def _make(mode):
     def make(topo, kwargs):
         kw = dict(n_envs=1, start_tick=kwargs.get("start_tick", 0), durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
-                  max_snapshots=kwargs.get("max_snapshots"), max_actions=2, step_mode=mode)
-        if mode == 3:
-            kw.update(specialized=True, pipe_waves=2)
+                  max_snapshots=kwargs.get("max_snapshots"), max_actions=2, step_mode=2 if mode == "S" else mode)
+        if mode == "S":
+            kw.update(specialized=True)
         return SingleEnvAdapter(EmuBackend(topo, **kw))
     return make
 
 
-@pytest.mark.parametrize("mode", [2, 3, 4])
+@pytest.mark.parametrize("mode", [2, "S", 4])
 @pytest.mark.parametrize("name", ["gt22p_l08_rand0", "toy4p_l03_res7_ring5", "gt22p_l08_res3", "toy6p_l08_rand0", "syn_immediate_returns", "case_config_folder_kat", "real_csv_rand0", "gt22p_l08_reset_chain"])
 def test_goldens_replay_in_every_launch_form(name, mode):
     replay_case(_make(mode), name)
@@ -144,4 +145,4 @@ def test_goldens_replay_in_every_launch_form(name, mode):
 def test_launch_forms_agree_on_unaligned_frames(obs):
     """start_tick not a multiple of the snapshot resolution: every decision materialises its pre-decision snapshot and takes the
     full path (cim_device.h::MRX_UNALIGNED_FRAMES) — in every launch form."""
-    side_by_side("toy.5p_ssddd_l0.5", [1, 2, 3, 4], n=5, durations=60, obs=obs, start_tick=1, resolution=3)
+    side_by_side("toy.5p_ssddd_l0.5", [1, 2, "S", 4], n=5, durations=60, obs=obs, start_tick=1, resolution=3)

@@ -25,11 +25,12 @@ def main():
     order = sorted((v, k) for k, v in d.items() if k.startswith("l_") and k not in ("l_mt2", "l_mt3", "l_odelay"))
     for off, k in order:
         print(f"  {k:10s} word {off:6d}  byte {off * 4:6d}")
-    for name in ("lds_words", "lds_words_reset", "lds_words_gen"):
+    print("lean build (registers for the return ring + order quantities):", bool(d.get("lean_ok")))
+    for name in ("lds_words", "lds_words_lean", "lds_words_reset", "lds_words_gen"):
         b = d[name] * 4
         g = (b + 1279) // 1280 * 1280   # gfx950 allocates LDS in 1280-byte granules (measured: tools/hbm_pattern_bench --residency)
         print(f"{name}: {b} B -> {g} B allocated -> {163840 // g} workgroups per CU")
-    print({k: d[k] for k in ("FW", "PW", "ctab_words", "NT", "NTP", "H", "P", "V", "NC", "SMAX", "REC_W", "misc_cap")})
+    print({k: d[k] for k in ("FW", "PW", "PWH", "ctab_words", "NT", "NTP", "H", "P", "V", "NC", "SMAX", "REC_W", "misc_cap")})
 
 
 if __name__ == "__main__":
