@@ -108,7 +108,7 @@ def cpu_baseline(topology, durations, budget_s):
             "sample": f"{episodes} full episodes of {topology} ({durations} ticks, reset+rollout in C, {steps} decisions, "
                       f"{dt:.1f} s on {cores} threads = one oracle per usable host core (affinity capped by the cgroup CPU quota); {ticks / dt:.0f} ticks/s); "
                       f"one core alone: {e1} episodes, {s1} decisions in {d1:.1f} s",
-            "note": "reference Python Env.step measured in the build container: ~311 env-steps/s (BASELINE.md §2)"}
+            "note": "a C port of the reference algorithm (oracle/cim_oracle.c); the reference's own Env.step is in cpu_baseline_reference"}
 
 
 def cpu_baseline_citi_bike(topology, durations, res, budget_s):
@@ -255,7 +255,7 @@ def bench_citi_bike(args):
             step_i += 1
         sync_all()
         tg = time.perf_counter()
-        out = gather_to_learner(traj, dst=0)
+        out = gather_to_learner(traj, dst=0, sizes=[n] * world)
         sync_all()
         gather_ms = (time.perf_counter() - tg) * 1e3
         if rank == 0:
@@ -443,6 +443,10 @@ def main():
     ap.add_argument("--no-query", action="store_true", help="skip the per-step snapshot slice")
     ap.add_argument("--no-episode", action="store_true", help="skip the end-to-end leg (reset + one full episode of the whole batch)")
     ap.add_argument("--parity-envs", type=int, default=64, help="envs replayed on the CPU oracle after the run (0: off)")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed window (exactly --steps steps between barrier + synchronize) is run this many "
+                    "times back to back; `value` is the median window, value_min / value_max the spread")
+    ap.add_argument("--gather-every", type=int, default=0, help="N > 1 ranks: additionally roll out K-step trajectories and gather each to the learner "
+                    "(gather_to_learner), reporting the gather's share of a rollout (0: only the single 32-step gather)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -464,7 +468,7 @@ def main():
     # other groups fill a group's launch gaps and tail.  Envs never interact, so this is pure scheduling.
     n, G = args.envs, max(1, args.groups)
     # the episode must outlast the run (finished envs would idle): ~0.45 ticks per env-step on 22p
-    need_ticks = args.preroll_ticks + int(0.55 * (args.warmup + args.steps + min(args.steps, 100) + 64)) + 64
+    need_ticks = args.preroll_ticks + int(0.55 * (args.warmup + args.steps * max(1, args.repeats) + min(args.steps, 100) + 64)) + 64
     sim_durations = max(args.durations, need_ticks)
     obs_mode = "none" if args.no_query else args.obs
     engines, streams, bufs, sizes, offs = build_cim_groups(args.topology, n, G, dev, rank, sim_durations, args.ring, args.specialize, args.step_mode,
@@ -536,6 +540,8 @@ def main():
 
     # ---- untimed: into mid-episode (vessels loaded, discharge records and return rings populated), then the warmup
     step_i = 0
+    torch.cuda.synchronize(dev)
+    t_pre = time.perf_counter()
     while True:
         for _ in range(64):
             for g in range(G):
@@ -568,23 +574,28 @@ def main():
                 one_step(step_i, g)
             step_i += 1
         sync_all()
-    for b in bufs:
-        b["counter"].zero_()
-    tick0 = total_ticks()
-    tick_mean0 = tick0 / n
-    # ---- the timed window: exactly --steps steps between barrier + synchronize on both sides
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        for g in range(G):
-            one_step(step_i, g)
-        step_i += 1
-    t_issued = time.perf_counter() - t0   # host time to enqueue every launch of the window (the loop never waits for the GPU)
-    sync_all()
-    dt = time.perf_counter() - t0
-    # decisions answered inside the timed window (K policy calls per group in the window)
-    resolved = sum(int(b["counter"].item()) for b in bufs)
-    ticks_adv = total_ticks() - tick0
+    # ---- the timed window: exactly --steps steps between barrier + synchronize on both sides; run --repeats times back to
+    # back (value = the median window), so that a driver run with a handful of steps is not a single 1-2 ms sample
+    gpu_busy_s = {"preroll_and_warmup": time.perf_counter() - t_pre, "timed_windows": 0.0}   # host clock around back-to-back GPU work
+    windows = []
+    for rep in range(max(1, args.repeats)):
+        for b in bufs:
+            b["counter"].zero_()
+        tick0 = total_ticks()
+        if rep == 0:
+            tick_mean0 = tick0 / n
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            for g in range(G):
+                one_step(step_i, g)
+            step_i += 1
+        t_issued = time.perf_counter() - t0   # host time to enqueue every launch of the window (the loop never waits for the GPU)
+        sync_all()
+        dt = time.perf_counter() - t0
+        gpu_busy_s["timed_windows"] += dt
+        # decisions answered inside the window (K policy calls per group in the window)
+        windows.append({"dt": dt, "resolved": sum(int(b["counter"].item()) for b in bufs), "ticks": total_ticks() - tick0, "t_issued": t_issued})
     n_done = sum(int(e.done.sum().item()) for e in engines)
     status_bad = sum(int((e.status != 0).sum().item()) for e in engines)
 
@@ -593,11 +604,13 @@ def main():
     reps = min(args.steps, 100)
     ev = [[tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(G)] for _ in range(reps)]
     sync_all()
+    t_ev = time.perf_counter()
     for r in range(reps):
         for g in range(G):
             one_step(step_i, g, timing=ev[r][g])
         step_i += 1
     torch.cuda.synchronize(dev)
+    gpu_busy_s["event_timed_steps"] = time.perf_counter() - t_ev
     durs = [a.elapsed_time(b) for row in ev for a, b, _ in row]
     policy_ms = sum(c.elapsed_time(a) for row in ev for a, _, c in row) / len(durs) if qnet is not None else None
     step_kernel_ms = sum(durs) / len(durs)                      # mean duration of one launch (ng envs; sorted launch: + the schedule kernel)
@@ -607,33 +620,66 @@ def main():
     # ---- the one exchange step of a sharded rollout (north_star: RCCL "only to gather trajectories to the learner"): 32 steps of
     # (decision, action, metrics, done, fused observation) per env from every rank to rank 0 in ONE collective
     # (maro_amd/cim/rollout.py::gather_to_learner); outside the timed env-step window
-    gather_ms = gather_bytes = None
+    gather_ms = gather_bytes = gather_every = None
     if dist is not None:
         from maro_amd.cim.rollout import gather_to_learner
-        T = 32
-        traj = {"decisions": torch.zeros((T, n, 8), dtype=torch.int32, device=dev), "actions": torch.zeros((T, n, 1, 4), dtype=torch.int32, device=dev),
-                "metrics": torch.zeros((T, n, 3), dtype=torch.int64, device=dev), "done": torch.zeros((T, n), dtype=torch.uint8, device=dev)}
-        if bufs[0].get("obs") is not None:
-            traj["obs_ports"] = torch.zeros((T, n, topo.n_ports * len(QUERY_ATTRS)), dtype=torch.float32, device=dev)
-        for k in range(T):
-            for g in range(G):
-                one_step(step_i, g, count=False)
-                with torch.cuda.stream(streams[g]):
-                    sl = slice(offs[g], offs[g] + sizes[g])
-                    traj["decisions"][k, sl], traj["actions"][k, sl] = engines[g].decisions, bufs[g]["actions"]
-                    traj["metrics"][k, sl], traj["done"][k, sl] = engines[g].metrics, engines[g].done
-                    if "obs_ports" in traj:
-                        traj["obs_ports"][k, sl] = bufs[g]["obs"][0].reshape(sizes[g], -1)
-            step_i += 1
+
+        def alloc_traj(T):
+            traj = {"decisions": torch.zeros((T, n, 8), dtype=torch.int32, device=dev), "actions": torch.zeros((T, n, 1, 4), dtype=torch.int32, device=dev),
+                    "metrics": torch.zeros((T, n, 3), dtype=torch.int64, device=dev), "done": torch.zeros((T, n), dtype=torch.uint8, device=dev)}
+            if bufs[0].get("obs") is not None:
+                traj["obs_ports"] = torch.zeros((T, n, topo.n_ports * len(QUERY_ATTRS)), dtype=torch.float32, device=dev)
+            return traj
+
+        def record_rollout(traj):
+            nonlocal step_i
+            for k in range(traj["done"].shape[0]):
+                for g in range(G):
+                    one_step(step_i, g, count=False)
+                    with torch.cuda.stream(streams[g]):
+                        sl = slice(offs[g], offs[g] + sizes[g])
+                        traj["decisions"][k, sl], traj["actions"][k, sl] = engines[g].decisions, bufs[g]["actions"]
+                        traj["metrics"][k, sl], traj["done"][k, sl] = engines[g].metrics, engines[g].done
+                        if "obs_ports" in traj:
+                            traj["obs_ports"][k, sl] = bufs[g]["obs"][0].reshape(sizes[g], -1)
+                step_i += 1
+
+        traj = alloc_traj(32)
+        record_rollout(traj)
         sync_all()
         tg = time.perf_counter()
-        gathered = gather_to_learner(traj, dst=0)
+        gathered = gather_to_learner(traj, dst=0, sizes=[n] * world)   # weak scaling: every rank owns n envs, no size exchange
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - tg) * 1e3
         gather_bytes = sum(t.numel() * t.element_size() for t in traj.values())
         if rank == 0:
             assert gathered["decisions"].shape[1] == n * world
         del gathered, traj
+        if args.gather_every > 0:
+            # the learner's view of a sharded rollout loop: K steps of stepping (+ recording), then ONE gather, repeated;
+            # max over ranks of each part, so the first real 8-GPU run reports the gather's share of a rollout, not one gather
+            K = args.gather_every
+            traj = alloc_traj(K)
+            t_roll = t_gath = 0.0
+            rounds = 4
+            for _ in range(rounds):
+                sync_all()
+                ta = time.perf_counter()
+                record_rollout(traj)
+                sync_all()
+                tb = time.perf_counter()
+                gathered = gather_to_learner(traj, dst=0, sizes=[n] * world)
+                sync_all()
+                tc = time.perf_counter()
+                t_roll += tb - ta
+                t_gath += tc - tb
+                del gathered
+            tt = torch.tensor([t_roll, t_gath], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_roll, t_gath = (float(x) / rounds for x in tt.tolist())
+            gather_every = {"steps_per_rollout": K, "rollout_ms": t_roll * 1e3, "gather_ms": t_gath * 1e3, "gather_share": t_gath / (t_roll + t_gath),
+                            "bytes_per_rank": sum(t.numel() * t.element_size() for t in traj.values()), "rounds": rounds}
+            del traj
 
     # ---- end to end (untimed window of its own): reset of the whole batch + one complete episode of every env, the same
     # agent; envs that finish early keep being stepped (they report done) until the slowest one is through
@@ -663,6 +709,7 @@ def main():
         t_ep = time.perf_counter() - t_e
         ep_steps = sum(int(b["counter"].item()) for b in bufs)
         episode = {"env_steps": ep_steps, "seconds": t_ep, "reset_ms": ep_reset_ms, "batch_steps": k}
+        gpu_busy_s["end_to_end_episode"] = t_ep
 
     # ---- parity (untimed): a sample of envs of THIS configuration replayed on the CPU oracle — every decision, metric,
     # fused observation and the final snapshot ring (tests/bench_parity.py; the oracle is the checker, never the thing measured)
@@ -672,16 +719,22 @@ def main():
         parity = replay_against_oracle(engines, bufs, streams, sizes, offs, rank * n, args.topology, engines[0].durations, args.parity_envs,
                                        obs=bufs[0].get("obs") is not None)
 
-    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+    R = len(windows)
+    t_max = torch.tensor([w["dt"] for w in windows], dtype=torch.float64, device=dev)
     ep_t = torch.tensor([episode["seconds"] if episode else 0.0], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(resolved), float(ticks_adv), float(n_done), float(status_bad), float(episode["env_steps"] if episode else 0)],
-                       dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(w["resolved"]) for w in windows] + [float(w["ticks"]) for w in windows] +
+                       [float(n_done), float(status_bad), float(episode["env_steps"] if episode else 0)], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(ep_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt = float(t_max.item())
-    resolved, ticks_adv, n_done, status_bad, ep_steps_all = (float(x) for x in tot.tolist())
+    dts = [float(x) for x in t_max.tolist()]
+    tl = [float(x) for x in tot.tolist()]
+    res_w, tick_w = tl[:R], tl[R:2 * R]
+    n_done, status_bad, ep_steps_all = tl[2 * R:]
+    vals = [res_w[i] / dts[i] for i in range(R)]
+    med = sorted(range(R), key=lambda i: vals[i])[R // 2]      # the median window (whole-job rate: max-over-ranks time, summed counts)
+    dt, resolved, ticks_adv, t_issued = dts[med], res_w[med], tick_w[med], windows[med]["t_issued"]
 
     if rank == 0:
         value = resolved / dt
@@ -691,14 +744,33 @@ def main():
         b_step = (3.0 + tbar) * F + 4.0 * topo.n_targets * tbar + 40.0  # fixed per-env-step formula
         ng = n / G                                  # env-steps per launch
         kernel = ("mrx_k_cim_step_tab" if engines[0].layout.order_table_on else "mrx_k_cim_step") + ("_obs" if bufs[0].get("obs") is not None else "")
-        # HBM bytes one launch really moves: the committed PMC passes of this same workload (tools/refresh_pmc.py -> profiles/latest_pmc.json)
+        # HBM bytes one launch really moves: the committed PMC passes of this same workload AND this same code object
+        # (tools/gpu_profile.sh -> tools/refresh_pmc.py -> profiles/latest_pmc.json, stamped with the step kernels' cache key =
+        # hash of plan text + device sources + flags + toolchain); any other build falls back to the algorithmic bytes
         traffic = pmc_src = None
+        pmc_state = "no profiles/latest_pmc.json"
+        code_key = getattr(engines[0], "code_object_key", None)
         try:
             with open(os.path.join(REPO, "profiles", "latest_pmc.json")) as fp:
                 pmc = json.load(fp)
-            if pmc["topology"] == args.topology and abs(pmc["envs_per_launch"] - ng) <= 1 and pmc.get("kernel") == kernel:
+            if not (pmc["topology"] == args.topology and abs(pmc["envs_per_launch"] - ng) <= 1 and pmc.get("kernel") == kernel):
+                pmc_state = "the record is of another configuration"
+            elif pmc.get("code_object_key") != code_key or code_key is None:
+                pmc_state = f"the record is of another build (code object {pmc.get('code_object_key')}, running {code_key})"
+            else:
                 traffic = (2.0 * pmc["fetch_size_kib"] + pmc["write_size_kib"]) * 1024.0
-                pmc_src = pmc.get("source")
+                pmc_src = {k: pmc.get(k) for k in ("source", "git_head", "code_object_key", "code_object_sha16", "bench_value", "date")}
+                pmc_state = "matched"
+        except Exception:
+            pass
+        # the measured ceiling of this access pattern (tools/hbm_pattern_bench: same grid, LDS reservation, pieces and streams, no
+        # simulation work), committed by the same profile run
+        ceiling = None
+        try:
+            with open(os.path.join(REPO, "profiles", "pattern_ceiling.json")) as fp:
+                pc = json.load(fp)
+            if pc.get("topology") == args.topology and abs(pc["envs_per_launch"] - ng) <= 1:
+                ceiling = pc
         except Exception:
             pass
         alg_per_launch = b_step * (resolved / world / args.steps / G)   # algorithmic bytes of one launch (its env-steps x B_step)
@@ -709,18 +781,21 @@ def main():
             basis = "measured HBM bytes (PMC: 2 x FETCH_SIZE + WRITE_SIZE per launch) x launches per step / ms_per_step of the timed window"
         else:
             achieved = alg_gbps
-            basis = "ALGORITHMIC bytes (no matching PMC record in profiles/latest_pmc.json for this configuration): see algorithmic_*"
+            basis = f"ALGORITHMIC bytes ({pmc_state}): see algorithmic_*"
         out = {
             "metric": "env-steps/sec (decision events/sec), CIM global_trade.22p",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
+            "repeats": R, "value_min": min(vals), "value_max": max(vals), "values": vals,
+            "value_note": f"the timed window of exactly {args.steps} steps was run {R} times back to back; value / ms_per_step are the median window",
+            "gpu_seconds_total": sum(v for v in gpu_busy_s.values() if v), "gpu_seconds": gpu_busy_s,
             "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {sim_durations}, "
                                    f"{'random legal agent' if args.policy == 'random' else 'per-port dueling DQN (f32 MFMA, greedy) + CIMEnvSampler state shaping (mrx_cim_dqn_act)'} on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step (' + args.obs + ')'}",
-                       "envs_per_gpu": n, "groups_per_gpu": G, "step_mode": engines[0].step_mode, "specialized_kernels": bool(engines[0].specialized), "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,
+                       "envs_per_gpu": n, "groups_per_gpu": G, "step_mode": engines[0].step_mode, "specialized_kernels": bool(engines[0].specialized), "code_object_key": code_key, "code_object_sha16": getattr(engines[0], "code_object_sha16", None), "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,
                        "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
                        "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms, "host_enqueue_ms_per_step": t_issued / args.steps * 1e3,
-                       "trajectory_gather_ms_32_steps": gather_ms, "trajectory_gather_bytes_per_rank": gather_bytes,
+                       "trajectory_gather_ms_32_steps": gather_ms, "trajectory_gather_bytes_per_rank": gather_bytes, "trajectory_gather_every": gather_every,
                        "untimed_preroll_steps": preroll_steps, "mean_tick_at_window_start": tick_mean0,
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -732,6 +807,12 @@ def main():
                                              "so algorithmic_frac may exceed 1 and is NOT a bandwidth fraction",
                          "kernel_ms": step_kernel_ms, "launches_in_flight": in_flight, "env_steps_per_launch": ng, "launches_per_step": G},
         }
+        if ceiling is not None:
+            # value / (env-steps/s the no-compute pattern reaches) — both whole-batch rates on one GPU
+            out["roofline"]["pattern_ceiling"] = {"env_steps_per_s": ceiling["env_steps_per_s"], "GBps": ceiling["GBps"], "frac_of_peak": ceiling["GBps"] / HBM_PEAK_GBPS,
+                                                  "value_over_ceiling": (value / world) / ceiling["env_steps_per_s"], "source": ceiling.get("source"),
+                                                  "what": "tools/hbm_pattern_bench: the step kernel's loads / stores per env-step (same grid, LDS reservation, piece sizes, "
+                                                          "sorted launch, 3 streams) with no simulation work"}
         if episode is not None:
             ep_s = float(ep_t.item())
             out["value_end_to_end"] = ep_steps_all / ep_s
@@ -743,6 +824,16 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.topology, args.durations, args.cpu_seconds)
             ref = cpu_baseline_reference(args.topology, args.durations, args.cpu_seconds)
+            if ref is None:
+                # the reference cannot travel to the GPU box: embed the record measured in the build container
+                # (tools/cpu_reference_baseline.py -> profiles/cpu_reference_baseline.json: the reference's own Env.step and VectorEnv)
+                try:
+                    with open(os.path.join(REPO, "profiles", "cpu_reference_baseline.json")) as fp:
+                        ref = json.load(fp)
+                    if ref.get("topology") != args.topology or ref.get("durations") != args.durations:
+                        ref = None
+                except Exception:
+                    ref = None
             if ref is not None:
                 out["cpu_baseline_reference"] = ref
         if qnet is not None:

@@ -105,4 +105,8 @@ def load_into(engine, defines: str, build: bool = True, scenario: str = "cim") -
     buf = ctypes.create_string_buffer(img, len(img))
     fn = getattr(_lib.load(), UNITS[scenario][3] + "_load_step_kernels")
     _lib.check(fn(engine._h, buf, len(img), defines.encode()), fn.__name__)
+    # identity of what is now running: the cache key (plan text + every source the unit includes + flags + toolchain) and the
+    # image's own hash — bench.py stamps its line with it, and a PMC record is only used for a run of the SAME code object
+    engine.code_object_key = _key(defines, scenario)
+    engine.code_object_sha16 = hashlib.sha256(img).hexdigest()[:16]
     LOADS += 1

@@ -7,11 +7,12 @@
 // global_trade.22p_l0.8 (sizes are command-line parameters; defaults = that plan):
 //   fast path  (59 %): 64-byte private header + 7 rows x (<= 46 lanes x 4 B) + 4 plan rows + 3 observation rows, one
 //                      wait, then ~20 scalar-sized stores from lane 0 (state words, decision, metrics, hint).
-//   full path  (41 %): LDS-DMA in 16-byte pieces of frame (8064 B) + private state (3328 B) + RNG state (2496 B) +
-//                      the shared topology table (2752 B, L2-resident), the action words; one wait; then per tick
-//                      (1.1 on average) the order-table row + stop-table / discharge-record words, one wait, and the
-//                      8064-byte snapshot as non-temporal stores out of LDS; then observation block, decision, metrics,
-//                      frame + private state (+ RNG state every third step) as non-temporal stores.
+//   full path  (41 %): LDS-DMA in 16-byte pieces of frame (--fw words; round 3: 1372 = 5488 B) + private head (--pwh: 312) +
+//                      RNG state (624) + the shared topology table (--ctw: 608, L2-resident), the pending-return ring as
+//                      plain 4-byte row loads into registers (--ringw: 471 words), the action words; one wait; then per
+//                      tick (1.1 on average) the order-table row + stop-table / discharge-record words, one wait, and the
+//                      frame-sized snapshot as non-temporal stores out of LDS; then observation block, decision, metrics,
+//                      frame + private head (+ RNG state every third step) as non-temporal stores, the ring as 4-byte rows.
 // `--work C` inserts C dependent LDS round trips between the load wait and the stores (a stand-in for the simulation's
 // latency chain) so that the effect of the wave lifetime / occupancy on the achieved rate can be read off as well.
 //
@@ -34,7 +35,7 @@
   } while (0)
 
 struct Pat {
-  int n_envs, FW, PW, MTW, CTW, S, NTP, T, order_bytes, order_tiled, REC_W, SROW, V, obs_words, work;
+  int n_envs, FW, PW, PWH, RINGW, MTW, CTW, S, NTP, T, order_bytes, order_tiled, REC_W, SROW, V, obs_words, work;
   int32_t *live, *ring, *ring_fi, *priv, *mt, *rec, *tick, *dec, *obsv;
   uint32_t* stops;
   const int32_t* ctab;
@@ -105,10 +106,13 @@ extern "C" __global__ void __launch_bounds__(64) k_pattern(Pat P, const int32_t*
   // ---------------- full path
   int32_t* l_frame = lds;
   int32_t* l_priv = l_frame + P.FW;
-  int32_t* l_mt = l_priv + P.PW;
+  int32_t* l_mt = l_priv + P.PWH;
   int32_t* l_ctab = l_mt + P.MTW;
   dma_rows(l_frame, g_live, P.FW);
-  dma_rows(l_priv, g_priv, P.PW);
+  dma_rows(l_priv, g_priv, P.PWH);
+  int ring[12];
+#pragma unroll
+  for (int r = 0; r < 12; r++) ring[r] = (r * 64 < P.RINGW) ? g_priv[P.PWH + (r * 64 + lane < P.RINGW ? r * 64 + lane : 0)] : 0;
   dma_rows(l_mt, P.mt + ((size_t)env * 3 + 1) * P.MTW, P.MTW);
   dma_rows(l_ctab, P.ctab, P.CTW);
   int a = P.act[(size_t)env * 4 + (lane & 3)];
@@ -165,7 +169,10 @@ extern "C" __global__ void __launch_bounds__(64) k_pattern(Pat P, const int32_t*
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   store_rows_nt(g_live, l_frame, P.FW);
-  store_rows_nt(g_priv, l_priv, P.PW);
+  store_rows_nt(g_priv, l_priv, P.PWH);
+#pragma unroll
+  for (int r = 0; r < 12; r++)
+    if (r * 64 + lane < P.RINGW) g_priv[P.PWH + r * 64 + lane] = ring[r] + acc;
   if (mixu((unsigned)env, (unsigned)step + 77u) % 3u == 0u) store_rows_nt(P.mt + ((size_t)env * 3 + 1) * P.MTW, l_mt, P.MTW);
 }
 
@@ -210,16 +217,18 @@ extern "C" __global__ void __launch_bounds__(64) k_gather(const int32_t* base, l
 }
 
 struct Args {
-  int envs = 5461, streams = 3, launches = 150, warm = 20, lds = 18128, order_bytes = 4, tiled = 0, work = 0, T = 1120;
+  int envs = 5461, streams = 3, launches = 150, warm = 20, lds = 12528, order_bytes = 4, tiled = 0, work = 0, T = 1120;
   double full_frac = 0.41;
   int gather = 0, shuffle = 0, fast_lanes = 0, probe = 0, residency = 0;
+  int fw = 1372, pwh = 312, ringw = 471, ctw = 608;
+  const char* json_out = nullptr;
   long long gather_mb = 3900;
   int row_bytes = 640;
 };
 
 static double bytes_per_step_full(const Pat& P, double mean_ticks, double mt_store_frac) {
-  const double rd = 4.0 * (P.FW + P.PW + P.MTW) + 16 + mean_ticks * (P.NTP * P.order_bytes + 16 + 4 * 64 * 4 * 2 * 0.25);
-  const double wr = mean_ticks * (4.0 * P.FW + 4) + 8.0 * P.obs_words + 32 + 12 + 24 + 6 + 4.0 * (P.FW + P.PW) + mt_store_frac * 4.0 * P.MTW;
+  const double rd = 4.0 * (P.FW + P.PWH + P.RINGW + P.MTW) + 16 + mean_ticks * (P.NTP * P.order_bytes + 16 + 4 * 64 * 4 * 2 * 0.25);
+  const double wr = mean_ticks * (4.0 * P.FW + 4) + 8.0 * P.obs_words + 32 + 12 + 24 + 6 + 4.0 * (P.FW + P.PWH + P.RINGW) + mt_store_frac * 4.0 * P.MTW;
   return rd + wr;
 }
 static double bytes_per_step_fast(const Pat& P) { return 64 + (7 + 3) * 46 * 4 + 4 * 256 + 16 + 5 * 4 + 5 * 4 + 8 + 12 + 24 + 2 + 32; }
@@ -239,6 +248,11 @@ int main(int argc, char** argv) {
     else if (is("--gather")) A.gather = atoi(argv[++i]);
     else if (is("--shuffle")) A.shuffle = atoi(argv[++i]);
     else if (is("--probe")) A.probe = atoi(argv[++i]);
+    else if (is("--fw")) A.fw = atoi(argv[++i]);
+    else if (is("--pwh")) A.pwh = atoi(argv[++i]);
+    else if (is("--ringw")) A.ringw = atoi(argv[++i]);
+    else if (is("--ctw")) A.ctw = atoi(argv[++i]);
+    else if (is("--json-out")) A.json_out = argv[++i];
     else if (is("--residency")) A.residency = atoi(argv[++i]);
     else if (is("--fast-lanes")) A.fast_lanes = atoi(argv[++i]);
     else if (is("--gather-mb")) A.gather_mb = atoll(argv[++i]);
@@ -270,7 +284,7 @@ int main(int argc, char** argv) {
   }
   Pat base;
   memset(&base, 0, sizeof(base));
-  base.n_envs = A.envs; base.FW = 2016; base.PW = 832; base.MTW = 624; base.CTW = 688; base.S = 4; base.NTP = 160; base.T = A.T;
+  base.n_envs = A.envs; base.FW = A.fw; base.PWH = A.pwh; base.RINGW = A.ringw < 768 ? A.ringw : 768; base.PW = (A.pwh + base.RINGW + 3) / 4 * 4; base.MTW = 624; base.CTW = A.ctw; base.S = 4; base.NTP = 160; base.T = A.T;
   base.order_bytes = A.order_bytes; base.order_tiled = A.tiled; base.REC_W = 4096; base.V = 46; base.SROW = 46 * 208; base.obs_words = 22 * 7;
   base.work = A.work;
   const int G = A.streams, N = A.envs;
@@ -350,5 +364,15 @@ int main(int argc, char** argv) {
   printf(" \"envs_per_launch\": %d, \"streams\": %d, \"lds_bytes\": %d, \"waves_per_cu\": %d, \"order_bytes\": %d, \"order_tiled\": %d, "
          "\"work\": %d, \"shuffle\": %d, \"fast_lanes\": %d, \"full_frac\": %.3f, \"bytes_per_launch\": %.0f, \"us_per_batch_step\": %.2f, \"env_steps_per_s\": %.4g, \"GBps\": %.1f, \"frac_of_8TBps\": %.3f}\n",
          N, G, A.lds, per_cu, A.order_bytes, A.tiled, A.work, A.shuffle, A.fast_lanes, A.full_frac, per_launch, sec / A.launches * 1e6, (double)N * G * A.launches / sec, gbps, gbps / 8000.0);
+  if (A.json_out) {
+    FILE* f = fopen(A.json_out, "w");
+    if (f) {
+      fprintf(f, "{\"topology\": \"global_trade.22p_l0.8\", \"envs_per_launch\": %d, \"streams\": %d, \"lds_bytes\": %d, \"waves_per_cu\": %d, \"frame_words\": %d, "
+                 "\"priv_head_words\": %d, \"ring_words\": %d, \"table_words\": %d, \"full_frac\": %.3f, \"bytes_per_launch\": %.0f, \"us_per_batch_step\": %.2f, "
+                 "\"env_steps_per_s\": %.6g, \"GBps\": %.1f, \"source\": \"tools/hbm_pattern_bench (no simulation work: the memory system's rate for the step kernel's pieces)\"}\n",
+              N, G, A.lds, per_cu, base.FW, base.PWH, base.RINGW, base.CTW, A.full_frac, per_launch, sec / A.launches * 1e6, (double)N * G * A.launches / sec, gbps);
+      fclose(f);
+    }
+  }
   return 0;
 }

@@ -12,7 +12,19 @@ import sqlite3
 import sys
 
 
-def summarise(path):
+def load_rows(path):
+    """(kernel, start, end, grid, wg, lds, {counter: value}) per dispatch, from a rocpd database or from the per-dispatch CSV
+    export tools/refresh_pmc.py leaves under gpurun_out/<tag>/ (`*_dispatches.csv.gz`)."""
+    if path.endswith(".csv") or path.endswith(".csv.gz"):
+        import csv
+        import gzip
+        with (gzip.open(path, "rt", newline="") if path.endswith(".gz") else open(path, newline="")) as fp:
+            rd = csv.reader(fp)
+            head = next(rd)
+            out = []
+            for r in rd:
+                out.append((r[0], int(r[1]), int(r[2]), int(r[3]), int(r[4]), int(r[5]), {k: float(v) for k, v in zip(head[6:], r[6:]) if v != ""}))
+            return out
     c = sqlite3.connect(path)
     names = dict(c.execute("select id, kernel_name from rocpd_info_kernel_symbol"))
     rows = c.execute("select kernel_id, event_id, start, end, grid_size_x, workgroup_size_x, group_segment_size "
@@ -22,20 +34,25 @@ def summarise(path):
     pmc = {}
     for ev, pid, val in c.execute("select event_id, pmc_id, value from rocpd_pmc_event"):
         pmc.setdefault(ev, {})[pmc_names.get(pid, str(pid))] = val
+    return [(names.get(kid, str(kid)), s, e, gx, wx, lds, pmc.get(ev, {})) for kid, ev, s, e, gx, wx, lds in rows]
+
+
+def summarise(path):
+    rows = load_rows(path)
     agg = {}
-    for kid, ev, s, e, gx, wx, lds in rows:
-        a = agg.setdefault(names.get(kid, str(kid)), dict(n=0, tot=0, mn=1 << 62, mx=0, grid=gx, wg=wx, lds=lds, pmc={}))
+    for name, s, e, gx, wx, lds, ctrs in rows:
+        a = agg.setdefault(name, dict(n=0, tot=0, mn=1 << 62, mx=0, grid=gx, wg=wx, lds=lds, pmc={}))
         d = e - s
         a["n"] += 1
         a["tot"] += d
         a["mn"] = min(a["mn"], d)
         a["mx"] = max(a["mx"], d)
-        for k, v in pmc.get(ev, {}).items():
+        for k, v in ctrs.items():
             a["pmc"][k] = a["pmc"].get(k, 0.0) + v
     # overlap of dispatches of the same kernel (several streams): sum of durations / union of their intervals
     spans = {}
-    for kid, ev, st, en, gx, wx, lds in rows:
-        spans.setdefault(names.get(kid, str(kid)), []).append((st, en))
+    for name, st, en, gx, wx, lds, ctrs in rows:
+        spans.setdefault(name, []).append((st, en))
     for name, iv in spans.items():
         iv.sort()
         union, cs, ce = 0, iv[0][0], iv[0][1]
