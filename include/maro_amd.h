@@ -161,9 +161,12 @@ typedef struct mrx_cim_layout {
   int64_t off_nstops;  /* int32 [n_envs][V] */
   int64_t off_order_prop; /* int32 [n_envs or 1][max_tick] */
   int64_t off_vessel_period; /* int32 [n_envs][V] vessel_period_without_noise */
-  int64_t off_orders;        /* int32 [n_envs][durations][order_row_words] pre-generated order quantities per
-                                (src, dst) pair in target_offset CSR order; 0 when the order table is off */
-  int32_t order_row_words, order_table_on;
+  int64_t off_orders;        /* [n_envs][durations][order_row_words] pre-generated order quantities per (src, dst) pair in
+                                target_offset CSR order, elements of order_elem_bytes bytes: uint16 when the plan proves every
+                                quantity fits (<= 65535: orders of a tick never exceed its order proportion), else int32;
+                                0 when the order table is off */
+  int32_t order_row_words, order_table_on;   /* (order_row_words = elements per row) */
+  int32_t order_elem_bytes, reserved0;
   int64_t workspace_bytes;
 } mrx_cim_layout;
 

@@ -403,15 +403,20 @@ MRX_DEV void tick_prefetch_arrivals(const CimParams& K, int env, Lds& L, uint64_
   }
 }
 
+// element `i` of row `r` (tick index) of env's order table: uint16 or int32 elements (CimParams::order_half)
+MRX_DEV int order_cell(const CimParams& K, int env, int r, int i) {
+  const size_t e = (size_t)env * (size_t)K.orders_stride + (size_t)r * KD(NTP) + i;
+  return KD(order_half) ? (int)((const uint16_t*)K.orders)[e] : K.orders[e];
+}
+
 // PG = the episode's orders were drawn by mrx_cim_reset (CimParams::pregen): the tick's row of the order table
 // replaces the order count and the generator's inputs.
 template <bool PG>
 MRX_DEV void tick_prefetch(const CimParams& K, int env, Lds& L, int t, TickPf& pf) {
   const int lane = wave::lane();
   if constexpr (PG) {
-    const int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t - KD(start_tick)) * KD(NTP);
 #pragma unroll
-    for (int b = 0; b < 3; b++) pf.oqr[b] = row[b * 64 + lane < KD(NTP) ? b * 64 + lane : 0];
+    for (int b = 0; b < 3; b++) pf.oqr[b] = order_cell(K, env, t - KD(start_tick), b * 64 + lane < KD(NTP) ? b * 64 + lane : 0);
     pf.otg = 0;
   } else {
     pf.otg = K.order_prop[(size_t)env * KD(T) + t];
@@ -839,8 +844,16 @@ MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {
       bool tw = false;
       gen_orders(K, L, (long long)wave::bcast(mine, j), idx_ord, pf, tw);
       wave::sync();
-      int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t0 + j) * KD(NTP);
-      for (int k = lane; k < KD(NTP); k += 64) row[k] = k < KD(NT) ? L.oq[k] : 0;
+      const size_t e0 = (size_t)env * (size_t)K.orders_stride + (size_t)(t0 + j) * KD(NTP);
+      if (KD(order_half)) {  // two uint16 quantities per lane and store (rows are multiples of 8 elements)
+        uint32_t* row2 = (uint32_t*)((uint16_t*)K.orders + e0);
+        for (int k2 = lane; k2 < KD(NTP) / 2; k2 += 64) {
+          const uint32_t lo = 2 * k2 < KD(NT) ? (uint32_t)L.oq[2 * k2] & 0xffffu : 0u, hi = 2 * k2 + 1 < KD(NT) ? (uint32_t)L.oq[2 * k2 + 1] & 0xffffu : 0u;
+          row2[k2] = lo | (hi << 16);
+        }
+      } else {
+        for (int k = lane; k < KD(NTP); k += 64) K.orders[e0 + k] = k < KD(NT) ? L.oq[k] : 0;
+      }
       wave::sync();
     }
   }
@@ -874,8 +887,7 @@ MRX_DEV uint64_t run_tick(const CimParams& K, int env, Lds& L, int t, TickPf& pf
     for (int b = 0; b < 3; b++) { const int k = b * 64 + lane; if (k < NT) L.oq[k] = pf.oqr[b]; }
 #endif
     if (NT > 192) {
-      const int32_t* row = K.orders + (size_t)env * (size_t)K.orders_stride + (size_t)(t - KD(start_tick)) * KD(NTP);
-      for (int k = 192 + lane; k < NT; k += 64) L.oq[k] = row[k];
+      for (int k = 192 + lane; k < NT; k += 64) L.oq[k] = order_cell(K, env, t - KD(start_tick), k);
     }
   } else {
     long long otg = (long long)pf.otg;

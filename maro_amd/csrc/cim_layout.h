@@ -219,7 +219,18 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
     if (c->order_table < 0) return fail("real data files need the order table (order_table >= 0)");
     k.pregen = NT > 0 ? 1 : 0;
   }
-  k.NTP = (NT + 3) / 4 * 4;
+  k.NTP = (NT + 7) / 8 * 8;   // (16-byte rows for either element size; padding uint16 rows to whole 128-byte lines measured no difference)
+  // uint16 elements when no quantity can come near 65535: a pair's orders of a tick never exceed the tick's order proportion
+  // (cim_data_container.py:354-393: min(..., remaining)), which is floor(clip(dist + noise, 0, 1) * total_containers) (parsers.py:57-106)
+  k.order_half = 0;
+  if (k.pregen && t->data_mode != 2) {
+    double mx = 0;
+    if (t->data_mode == 1) { for (int i = 0; i < t->data_max_tick; i++) if (t->fixed_order_prop[i] > mx) mx = t->fixed_order_prop[i]; }
+    else {
+      for (int i = 0; i < t->period; i++) { double c = t->order_dist[i] + fabs(t->sample_noise); c = c > 1 ? 1 : c; if (c * (double)t->total_containers > mx) mx = c * (double)t->total_containers; }
+    }
+    k.order_half = mx <= 32767.0 ? 1 : 0;   // (a factor 2 of headroom: with a NEGATIVE noised ratio the reference lets `remaining` grow, cim_data_container.py:354-375)
+  }
   const int dsrc_w = 2 * ((P + 1) / 2 * 2);
   const int dtgt_w = 2 * (NT + 1) > 3 * 64 ? 2 * (NT + 1) : 3 * 64;
   int w = 0;
@@ -403,7 +414,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   pl->o_sched = A.take(64 + 64 * MRX_PIPE_MAX_WAVES);  // counters + dummies of cim::regs_load, then the scratch pieces of cim::regs_store
   pl->shared_orders_rel = shared_orders_rel;
   k.orders_stride = shared_orders_rel >= 0 ? 0 : (long long)c->durations * k.NTP;
-  pl->o_orders = (k.pregen && shared_orders_rel < 0) ? A.take(N * (int64_t)c->durations * k.NTP * 4) : 0;
+  pl->o_orders = (k.pregen && shared_orders_rel < 0) ? A.take(N * (int64_t)c->durations * k.NTP * (k.order_half ? 2 : 4)) : 0;
   pl->workspace_bytes = align_up(A.top, 256);
 
   mrx_cim_layout& Lo = pl->layout;
@@ -415,7 +426,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   Lo.off_live = pl->o_live; Lo.off_ring = pl->o_ring; Lo.off_ring_fi = pl->o_ring_fi; Lo.off_status = pl->o_status;
   Lo.off_tick = pl->o_tick; Lo.off_seed = pl->o_seed; Lo.off_stops = pl->o_stops; Lo.off_nstops = pl->o_nstops;
   Lo.off_order_prop = pl->o_order_prop; Lo.off_vessel_period = pl->o_vperiod;  // per env: depends on how many stops were unrolled
-  Lo.off_orders = shared_orders_rel >= 0 ? pl->const_off + shared_orders_rel : pl->o_orders; Lo.order_row_words = k.NTP; Lo.order_table_on = k.pregen;
+  Lo.off_orders = shared_orders_rel >= 0 ? pl->const_off + shared_orders_rel : pl->o_orders; Lo.order_row_words = k.NTP; Lo.order_table_on = k.pregen; Lo.order_elem_bytes = k.pregen ? (k.order_half ? 2 : 4) : 0;
   Lo.workspace_bytes = pl->workspace_bytes;
   return MRX_OK;
 }

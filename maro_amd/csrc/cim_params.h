@@ -46,7 +46,8 @@ struct CimParams {
   int data_mode;      // 0 generated at reset, 1 dump folder, 2 real data files (mrx_cim_topology.data_mode)
   int data_T;         // ticks covered by the fixed order proportion
   long long data_seed;
-  long long orders_stride;  // words between two envs' order tables (0: one table shared by every env)
+  long long orders_stride;  // ELEMENTS between two envs' order tables (0: one table shared by every env)
+  int order_half;           // 1: the table holds uint16 elements (every quantity provably <= 65535), 0: int32
   const uint32_t* fx_stops;  // [V][SMAX] (arrival << 8 | parking)
   const int32_t *fx_nstops, *fx_vperiod, *fx_order_prop;
   int pregen, NTP;  // order table: rows of NTP (= NT rounded up to 4) words, one per tick of the episode
@@ -139,6 +140,7 @@ struct CimParams {
   X(data_mode) \
   X(data_T) \
   X(pregen) \
+  X(order_half) \
   X(NTP) \
   X(l_mt2) \
   X(l_mt3) \

@@ -24,7 +24,7 @@ class MrxCimLayout(ctypes.Structure):
                 + [(n, ctypes.c_int64) for n in ("off_live", "off_ring", "off_ring_fi", "off_status", "off_tick",
                                                  "off_seed", "off_stops", "off_nstops", "off_order_prop",
                                                  "off_vessel_period", "off_orders")]
-                + [(n, ctypes.c_int32) for n in ("order_row_words", "order_table_on")]
+                + [(n, ctypes.c_int32) for n in ("order_row_words", "order_table_on", "order_elem_bytes", "reserved0")]
                 + [("workspace_bytes", ctypes.c_int64)])
 
 
