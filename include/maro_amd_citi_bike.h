@@ -138,6 +138,18 @@ int mrx_cb_step_joint(mrx_cb_handle h, const int32_t* d_actions, const int32_t* 
 int mrx_cb_set_lanes_per_wave(mrx_cb_handle h, int lanes);
 
 /*
+ * The wave-cooperative decision step (no reference counterpart; maro_amd/csrc/cb_wave.h).  At the size of the reference's ny.*
+ * topologies (~800 stations, filter chain 80 -> 40 -> 20) a decision tick raises hundreds of decision events per env, so almost
+ * every env-step stays inside its tick: apply one action, take the next pending station, evaluate its action scope
+ * (decision_strategy.py:253-293).  With this on, mrx_cb_step first launches ONE WAVE PER ENV for exactly those steps — the
+ * candidate neighbours are ranked across the lanes (ballot / broadcast / prefix rank) instead of a per-lane selection sort —
+ * and then the general kernel for the envs that have to replay events.  Sequential mode, aligned frames, <= 2048 stations.
+ * mode: 0 = automatic (on from 96 stations), 1 = on, -1 = off.  Returns 1 / 0 (in effect or not) or a negative mrx_status.
+ * Results do not depend on it.
+ */
+int mrx_cb_set_wave_decisions(mrx_cb_handle h, int mode);
+
+/*
  * Bounded steps (no reference counterpart).  mrx_cb_step returns when EVERY env of the batch has its next decision, so a call
  * lasts as long as the batch's longest env-step — and env-steps differ by two orders of magnitude (another station deciding at
  * the same tick: nothing to simulate; the last decision of a tick: twenty ticks of trips, two snapshots, a rebalance sweep).

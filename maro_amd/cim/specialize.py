@@ -20,7 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"] + os.environ.get("MARO_AMD_SPEC_FLAGS", "").split()
 UNITS = {   # scenario -> (translation unit, generated dims header, the sources the cache key covers, ABI prefix)
     "cim": ("cim_spec.hip", "cim_spec_dims.h", ("cim_spec.hip", "cim_step_kernels.h", "cim_device.h", "cim_params.h", "cim_prof.h", "wave.h"), "mrx_cim"),
-    "citi_bike": ("cb_spec.hip", "cb_spec_dims.h", ("cb_spec.hip", "cb_step_kernels.h", "cb_device.h", "cb_params.h", "wave.h",
+    "citi_bike": ("cb_spec.hip", "cb_spec_dims.h", ("cb_spec.hip", "cb_step_kernels.h", "cb_device.h", "cb_wave.h", "cb_params.h", "wave.h",
                                                     "../../include/maro_amd_citi_bike.h"), "mrx_cb"),
 }
 

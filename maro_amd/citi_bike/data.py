@@ -66,9 +66,8 @@ class CitiBikeData:
         S = self.n_stations
         out = -np.ones((S, S), np.int32)
         for s in range(S):
-            nb = [(i, d) for i, d in enumerate(self.distance[s]) if d != 0.0]
-            nb.sort(key=lambda kv: kv[1])
-            out[s, :len(nb)] = [i for i, _ in nb]
+            idx = np.flatnonzero(self.distance[s] != 0.0)
+            out[s, :len(idx)] = idx[np.argsort(self.distance[s][idx], kind="stable")]   # stable: ties keep index order
         return out
 
     # ---- packaged form
@@ -159,6 +158,10 @@ def load_topology(name_or_path: str) -> CitiBikeData:
     if os.path.isfile(name_or_path):
         return CitiBikeData.load(name_or_path)
     p = os.path.join(_PKG_DIR, name_or_path + ".npz")
+    if not os.path.exists(p):
+        from .synthetic import GENERATED_ON_DEMAND, ensure_packaged
+        if name_or_path in GENERATED_ON_DEMAND:
+            ensure_packaged(name_or_path)   # seeded, ~2 s (too large to commit)
     if os.path.exists(p):
         return CitiBikeData.load(p)
     raise FileNotFoundError(f"unknown citi_bike topology {name_or_path!r}; packaged: {available_topologies()}")

@@ -133,6 +133,11 @@ class CitiBikeBatchEngine:
         control-flow divergence, more waves.  Results do not depend on it (include/maro_amd_citi_bike.h)."""
         _lib.check(self._L.mrx_cb_set_lanes_per_wave(self._h, int(lanes)), "mrx_cb_set_lanes_per_wave")
 
+    def set_wave_decisions(self, mode: int = 0) -> bool:
+        """mrx_cb_set_wave_decisions: env-steps that stay inside their tick on one wave per env (action scope ranked across the
+        lanes).  0 = automatic (on from 96 stations), 1 = on, -1 = off; returns whether it is in effect.  Results unchanged."""
+        return bool(_lib.check(self._L.mrx_cb_set_wave_decisions(self._h, int(mode)), "mrx_cb_set_wave_decisions"))
+
     def set_step_budget(self, max_records: int = 0) -> None:
         """Bounded steps: an env replays at most ~`max_records` events per `step()` call; envs that have not reached their
         next decision report `decisions[e, 5] == 0` (and `done[e] == 0`) and continue in the next call.  0 = off."""

@@ -11,7 +11,10 @@ import numpy as np
 from .data import _PKG_DIR, CitiBikeData
 
 
-def city_data(rng, S=180, T=480, trips_per_tick=5.0, name=None):
+NY_FILTERS = [dict(type=0, num=80, windows=0), dict(type=1, num=40, windows=0), dict(type=2, num=20, windows=10)]   # topologies/ny.201801/config.yml:21-26
+
+
+def city_data(rng, S=180, T=480, trips_per_tick=5.0, name=None, K=24, n_hubs=9, hub_weight=25.0, filters=None):
     """A city-shaped synthetic data set (the real NYC topologies are not shippable): a few hundred stations on a plane,
     distances = Euclidean to the K nearest stations only (the rest 0.0 = "not a neighbour", like distance_adj.csv rows with
     their 20 closest), trips drawn towards a handful of hubs with a rush-hour intensity, the reference's default filter
@@ -21,14 +24,13 @@ def city_data(rng, S=180, T=480, trips_per_tick=5.0, name=None):
     n_days = (T + day_len - 1) // day_len
     xy = rng.uniform(0, 10, (S, 2))
     d = np.sqrt(((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1))
-    K = 24
     dist = np.zeros((S, S))
     for s in range(S):
         nb = np.argsort(d[s], kind="stable")[1:K + 1]
         dist[s, nb] = np.round(d[s, nb], 4) + 1e-4
-    hubs = rng.choice(S, 9, replace=False)
+    hubs = rng.choice(S, n_hubs, replace=False)
     w = np.ones(S)
-    w[hubs] = 25.0
+    w[hubs] = hub_weight
     w /= w.sum()
     tod = np.arange(T) % day_len
     lam = trips_per_tick * (0.4 + 1.2 * np.exp(-((tod - day_len * 0.45) / (day_len * 0.18)) ** 2))
@@ -45,7 +47,7 @@ def city_data(rng, S=180, T=480, trips_per_tick=5.0, name=None):
         tick_day=(np.arange(T) // day_len).astype(np.int32), day_weekday=(np.arange(n_days) % 7).astype(np.int16), day_holiday=np.zeros(n_days, np.int16),
         day_weather=(np.arange(n_days) * 3 % 4).astype(np.int16), day_temperature=(21 - 9 * (np.arange(n_days) % 3)).astype(np.int16), resolution=20, time_mean=20.0, time_std=5.0,
         supply_water_mark_ratio=0.8, demand_water_mark_ratio=0.2, scope_low_ratio=0.0, scope_high_ratio=1.0, extra_cost_mode=0,
-        filters=[dict(type=0, num=20, windows=0), dict(type=1, num=10, windows=0), dict(type=2, num=6, windows=10)])
+        filters=filters or [dict(type=0, num=20, windows=0), dict(type=1, num=10, windows=0), dict(type=2, num=6, windows=10)])
 
 
 FILTER_NAME = {0: "distance", 1: "requirements", 2: "trip_window"}
@@ -99,7 +101,14 @@ def write_build_folder(data: CitiBikeData, build_dir: str, start_utc: int, weath
 
 
 # name -> generator arguments; start_utc 2019-06-03 04:00 UTC = Monday 00:00 in New York (EDT)
-PACKAGED = {"city.180s": dict(seed=20260924, S=180, T=1440 * 2, trips_per_tick=6.0, start_utc=1559534400)}
+PACKAGED = {"city.180s": dict(seed=20260924, S=180, T=1440 * 2, trips_per_tick=6.0, start_utc=1559534400),
+            # the SIZE of the reference's shipped ny.* topologies (topologies/ny.201801/config.yml): ~800 stations, a month of
+            # 1-minute ticks (44 640), ~1.5 M trips, the ny filter chain distance 80 -> requirements 40 -> trip_window 20 over 10
+            # windows, decision resolution 20.  6.8 MB as .npz: generated (seeded, ~2 s) by __graft_entry__.build() / on first
+            # use instead of being committed.
+            "city.800s": dict(seed=20260925, S=800, T=1440 * 31, trips_per_tick=43.0, start_utc=1559534400, K=100, n_hubs=40, hub_weight=8.0,
+                              filters=NY_FILTERS)}
+GENERATED_ON_DEMAND = ("city.800s",)
 
 
 def build_packaged(name: str, build_dir: str):
@@ -111,6 +120,23 @@ def build_packaged(name: str, build_dir: str):
     raw = city_data(rng, name=name, **kw)
     cfg = write_build_folder(raw, build_dir, start_utc, rng=rng)
     return cfg, load_build_folder(cfg, build_dir, name=name)
+
+
+def ensure_packaged(name: str) -> str:
+    """Path of the packaged .npz of `name`, generating it first when it is one of the on-demand topologies."""
+    path = os.path.join(_PKG_DIR, name + ".npz")
+    if not os.path.exists(path) and name in GENERATED_ON_DEMAND:
+        import shutil
+        import tempfile
+        tmp = tempfile.mkdtemp(prefix="mrx_city_")
+        try:
+            _, data = build_packaged(name, tmp)
+            part = path + f".{os.getpid()}.tmp.npz"
+            data.save(part)
+            os.replace(part, path)   # atomic: several ranks / test workers may get here together
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return path
 
 
 def main():

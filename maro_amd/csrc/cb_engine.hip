@@ -12,9 +12,10 @@
 #include <new>
 #include <string>
 
-#define MRX_DEV __device__ __forceinline__
+#include "wave.h"
 #include "cb_layout.h"
 #include "cb_device.h"
+#include "cb_wave.h"
 
 int mrx_set_error_(int code, const std::string& m);  // cim_engine.hip (thread-local message behind mrx_last_error)
 
@@ -59,7 +60,8 @@ struct mrx_cb_engine {
   int lanes = 64;  // envs per wave of the step kernel
   int step_budget = 0;  // mrx_cb_set_step_budget
   hipModule_t spec_module = nullptr;   // plan-specialised reset / step kernels (mrx_cb_load_step_kernels), else the generic ones
-  hipFunction_t spec_reset = nullptr, spec_step = nullptr;
+  hipFunction_t spec_reset = nullptr, spec_step = nullptr, spec_wave = nullptr;
+  int wave_mode = 0;    // mrx_cb_set_wave_decisions: 0 automatic, 1 on, -1 off
   // kernels of the module may still be queued or running on the caller's stream: drain the device before unloading
   void unload_spec() {
     if (!spec_module) return;
@@ -71,6 +73,7 @@ struct mrx_cb_engine {
       if (cur != device && cur >= 0) hipSetDevice(cur);
     }
     spec_module = nullptr;
+    spec_wave = nullptr;
   }
   ~mrx_cb_engine() { unload_spec(); }
 };
@@ -152,6 +155,26 @@ int mrx_cb_set_lanes_per_wave(mrx_cb_handle h, int lanes) {
   return MRX_OK;
 }
 
+// Whether Sequential-mode steps go through the wave-cooperative decision kernel first (cb_wave.h).  It needs aligned frames
+// (start_tick a multiple of the snapshot resolution: otherwise every decision materialises a snapshot) and at most 2048 stations.
+static bool cb_wave_applicable(const CbParams& K) {
+  return K.decision_mode == 0 && K.start_tick % K.res == 0 && K.mask_words <= 64;
+}
+static bool cb_wave_on(mrx_cb_handle h) {
+  const CbParams& K = h->plan.kp;
+  if (!cb_wave_applicable(K) || h->wave_mode < 0) return false;
+  // automatic: from ~100 stations on a decision tick raises dozens of decisions per env and the action scope dominates a step;
+  // on the toys (3-5 stations) the extra launch costs more than it saves
+  return h->wave_mode > 0 || K.S >= 96;
+}
+
+int mrx_cb_set_wave_decisions(mrx_cb_handle h, int mode) {
+  if (!h || mode < -1 || mode > 1) return set_err(MRX_ERR_INVALID_ARG, "null handle, or mode not in {-1 off, 0 automatic, 1 on}");
+  if (mode > 0 && !cb_wave_applicable(h->plan.kp)) return set_err(MRX_ERR_UNSUPPORTED, "the wave-cooperative decision step needs Sequential mode, aligned frames and <= 2048 stations");
+  h->wave_mode = mode;
+  return cb_wave_on(h) ? 1 : 0;
+}
+
 int mrx_cb_set_step_budget(mrx_cb_handle h, int max_records) {
   if (!h || max_records < 0) return set_err(MRX_ERR_INVALID_ARG, "null handle or negative budget");
   h->step_budget = max_records;
@@ -195,6 +218,18 @@ static int cb_launch_step(mrx_cb_handle h, const int32_t* d_actions, const int32
   const CbParams& K = h->plan.kp;
   CbParams Kc = K;
   Kc.step_budget = h->step_budget;
+  if (cb_wave_on(h)) {
+    // one env per wave: the steps that stay inside their tick; everything else is flagged in K.todo for the general kernel below
+    long long* metw = (long long*)d_metrics;
+    if (h->spec_wave) {
+      void* pw[] = {&Kc, &d_actions, &d_n_actions, &d_env_mask, &d_decisions, &d_scope, &metw, &d_done};
+      HIP_TRY(hipModuleLaunchKernel(h->spec_wave, (unsigned)K.n_envs, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, pw, nullptr));
+    } else {
+      hipLaunchKernelGGL(mrx_k_cb_step_wave, dim3(K.n_envs), dim3(64), 0, (hipStream_t)stream, Kc, d_actions, d_n_actions, d_env_mask, d_decisions, d_scope,
+                         metw, d_done);
+    }
+    d_env_mask = K.todo;
+  }
   if (h->spec_module) {
     long long* met = (long long*)d_metrics;
     // the specialised kernel keeps each env's working state in an LDS column of lds_words words (when one column fits at
@@ -273,6 +308,9 @@ int mrx_cb_load_step_kernels(mrx_cb_handle h, const void* image, int64_t bytes, 
   h->spec_module = mod;
   h->spec_reset = f_reset;
   h->spec_step = f_step;
+  hipFunction_t f_wave = nullptr;
+  if (hipModuleGetFunction(&f_wave, mod, "mrx_k_cb_step_wave") == hipSuccess && f_wave) h->spec_wave = f_wave;
+  else (void)hipGetLastError();
   return MRX_OK;
 }
 

@@ -46,6 +46,7 @@ struct CbParams {
   uint32_t* fulfilled;  // [w_words]  bit ring over trip index: RequireBike got a bike
   int32_t* prof;        // [16] phase cycle counters (MRX_CB_PROFILE builds only)
   uint32_t* decmask;    // [2 * mask_words] stations with a pending Supply / Demand decision this tick
+  uint8_t* todo;        // [n_envs] written by the wave-cooperative decision kernel (cb_wave.h): 1 = the general step must run for this env
   // ---- shared tables (trips restricted to [start_tick, max_tick), re-indexed from 0)
   const int32_t* trip_off;  // [durations + 1] CSR offsets of the trips by tick (trips_adj bound of a frame)
   const int32_t* ev_rec;    // [n_events + 16][4] the event stream every env replays, see cb_layout.h

@@ -10,4 +10,5 @@
 #define MRX_SPECIALIZED 1
 #include "cb_spec_dims.h"
 #include "cb_device.h"
+#include "cb_wave.h"
 #include "cb_step_kernels.h"

@@ -74,3 +74,22 @@ mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __
 #undef MRX_CB_LFX
 #endif
 }
+
+// The wave-cooperative decision step (cb_wave.h): ONE env per wave.  Handles the env-steps that stay inside their tick (apply the
+// action, next pending station, its action scope across the lanes) and writes todo[e] = 1 for every env it had to leave alone;
+// mrx_k_cb_step then runs with `todo` as its env mask.
+extern "C" __global__ void __launch_bounds__(64)
+mrx_k_cb_step_wave(CbParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions, const uint8_t* __restrict__ mask,
+                   int32_t* __restrict__ decisions, int32_t* __restrict__ scope, long long* __restrict__ metrics, uint8_t* __restrict__ done) {
+  __shared__ int32_t scr[2 * cb::CBW_MAX];
+  const int e = (int)blockIdx.x;
+  if (mask && !mask[e]) {
+    if (threadIdx.x == 0) K.todo[e] = 0;
+    return;
+  }
+  int na = (actions && n_actions) ? n_actions[e] : 0;
+  if (na > CD(max_actions)) na = CD(max_actions);
+  const bool ok = cb::decision_step_wave(K, e, actions ? actions + (size_t)e * CD(max_actions) * 3 : nullptr, na, decisions + (size_t)e * 8,
+                                         scope + (size_t)e * CD(scope_cap) * 2, (int64_t*)metrics + (size_t)e * 3, done + e, scr);
+  if (threadIdx.x == 0) K.todo[e] = ok ? 0 : 1;
+}

@@ -38,7 +38,8 @@ class CitiBikeOracle:
         self.start_tick, self.max_tick, self.res = start_tick, start_tick + durations, snapshot_resolution
         total = -(-durations // snapshot_resolution)
         self.ring_size = max_snapshots or total
-        self.neighbors = [[(int(i), float(data.distance[s][i])) for i in data.neighbors()[s] if i >= 0] for s in range(self.S)]
+        nb = data.neighbors()   # once: it sorts every station's row
+        self.neighbors = [[(int(i), float(data.distance[s][i])) for i in nb[s] if i >= 0] for s in range(self.S)]
         self.trip_off = data.trip_offsets(self.max_tick)
         self._transfer_times = list(transfer_times) if transfer_times is not None else []
         self.reset()

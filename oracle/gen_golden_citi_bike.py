@@ -47,6 +47,11 @@ CASES = {
     "cb_tight_start13_d600_r10_all": ("toy.3s_tight", dict(start_tick=13, durations=600, snapshot_resolution=10), "all"),
     "cb_city180_d1440_r10_ring16_half": ("city.180s", dict(durations=1440, snapshot_resolution=10, max_snapshots=16), "half"),
     "cb_city180_d2000_r20_ring9_all": ("city.180s", dict(durations=2000, snapshot_resolution=20, max_snapshots=9), "all"),
+    # city.800s: the SIZE of the reference's shipped ny.* topologies (800 stations, 100 neighbours each, the ny filter chain
+    # distance 80 -> requirements 40 -> trip_window 20 over 10 windows, a month of 1-minute ticks, 1.5 M trips); two windows of
+    # the month (the reference's pure-Python Env needs minutes per simulated day at this size)
+    "cb_city800_d300_r20_ring12_half": ("city.800s", dict(durations=300, snapshot_resolution=20, max_snapshots=12), "half"),
+    "cb_city800_start20160_d260_r10_ring3_all": ("city.800s", dict(start_tick=20160, durations=260, snapshot_resolution=10, max_snapshots=3), "all"),
 }
 
 
@@ -84,7 +89,7 @@ def worker(maro_root, stubs, case, out_path):
         scope = de.action_scope                      # reading it is what updates the trip-window cache
         items = [(int(k), int(v)) for k, v in scope.items()]
         decs.append([de.tick, de.station_idx, 0 if de.type == DecisionType.Supply else 1, de.frame_index, len(items)])
-        scopes.append(items + [(-1, -1)] * (8 - len(items)))
+        scopes.append(items)
         mets.append([m["trip_requirements"], m["bike_shortage"], m["operation_number"]])
         action, enc = None, (-1, -1, -1)
         others = [k for k, _ in items if k != de.station_idx]
@@ -97,7 +102,9 @@ def worker(maro_root, stubs, case, out_path):
         acts.append(enc)
         m, de, done = env.step(action)
     sl = env.snapshot_list
-    out = dict(decisions=np.array(decs, np.int32).reshape(-1, 5), scopes=np.array(scopes, np.int32).reshape(-1, 8, 2),
+    width = max([8] + [len(x) for x in scopes])   # (8 for every toy; the ny filter chain keeps 20 neighbours + the station itself)
+    scopes = [x + [(-1, -1)] * (width - len(x)) for x in scopes]
+    out = dict(decisions=np.array(decs, np.int32).reshape(-1, 5), scopes=np.array(scopes, np.int32).reshape(-1, width, 2),
                metrics=np.array(mets, np.int64).reshape(-1, 3), actions=np.array(acts, np.int32).reshape(-1, 3),
                final_metrics=np.array([m["trip_requirements"], m["bike_shortage"], m["operation_number"]], np.int64),
                frame_indices=np.array(sl.get_frame_index_list(), np.int32),

@@ -4,13 +4,18 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#define MRX_DEV static inline
+#include "wave_emu.h"   // 64-fiber wave emulation (defines MRX_DEV): only the wave-cooperative decision step (cb_wave.h) uses it
 #include "../../maro_amd/csrc/cb_layout.h"
 #include "../../maro_amd/csrc/cb_device.h"
+#include "../../maro_amd/csrc/cb_wave.h"
 
 struct CbEmu {
   CbHostPlan plan;
   uint8_t* ws = nullptr;
+  int wave_mode = 0;     // cb_emu_set_wave_decisions: 1 = steps go through cb::decision_step_wave first, like mrx_cb_step does
+  bool reverse = false;  // lane order of the wave emulator (forward / reverse exposes missing syncs)
+  long handled = 0, general = 0;
+  wave::EmuWave wave{};
 };
 
 extern "C" {
@@ -55,13 +60,30 @@ void cb_emu_step(void* h, const int32_t* actions, const int32_t* n_actions, cons
                  int64_t* met, uint8_t* done) {
   CbEmu* e = (CbEmu*)h;
   const CbParams& K = e->plan.kp;
+  static int32_t scr[2 * cb::CBW_MAX];
   for (int env = 0; env < K.n_envs; env++) {
     if (mask && !mask[env]) continue;
     const int na = n_actions ? n_actions[env] : 0;
-    cb::step_env(K, env, actions ? actions + (size_t)env * K.max_actions * 3 : nullptr, na < K.max_actions ? na : K.max_actions, nullptr,
-                 dec + (size_t)env * 8, scope + (size_t)env * K.scope_cap * 2, met + (size_t)env * 3, done + env);
+    const int nac = na < K.max_actions ? na : K.max_actions;
+    const int32_t* act = actions ? actions + (size_t)env * K.max_actions * 3 : nullptr;
+    if (e->wave_mode && K.decision_mode == 0 && K.start_tick % K.res == 0 && K.mask_words <= 64) {
+      bool ok = false;
+      e->wave.reverse = e->reverse;
+      wave::run_wave(e->wave, [&]() {
+        const bool r = cb::decision_step_wave(K, env, act, (actions && n_actions) ? nac : 0, dec + (size_t)env * 8, scope + (size_t)env * K.scope_cap * 2,
+                                              met + (size_t)env * 3, done + env, scr);
+        if (wave::lane() == 0) ok = r;
+      });
+      if (ok) { e->handled++; continue; }
+      e->general++;
+    }
+    cb::step_env(K, env, act, nac, nullptr, dec + (size_t)env * 8, scope + (size_t)env * K.scope_cap * 2, met + (size_t)env * 3, done + env);
   }
 }
+
+void cb_emu_set_wave_decisions(void* h, int on, int reverse) { ((CbEmu*)h)->wave_mode = on; ((CbEmu*)h)->reverse = reverse != 0; }
+long cb_emu_wave_handled(void* h) { return ((CbEmu*)h)->handled; }
+long cb_emu_wave_general(void* h) { return ((CbEmu*)h)->general; }
 
 // Joint modes (mrx_cb_step_joint): S rows per env
 void cb_emu_step_joint(void* h, const int32_t* actions, const int32_t* n_actions, const int32_t* n_answered, const uint8_t* mask, int32_t* dec,

@@ -15,8 +15,8 @@ LIB = os.path.join(HERE, "libcb_emu.so")
 
 def build():
     srcs = [os.path.join(HERE, "cb_emu.cpp")] + [os.path.join(REPO, "maro_amd", "csrc", f) for f in
-                                                 ("cb_device.h", "cb_layout.h", "cb_params.h")] + [
-        os.path.join(REPO, "include", "maro_amd_citi_bike.h")]
+                                                 ("cb_device.h", "cb_layout.h", "cb_params.h", "cb_wave.h")] + [
+        os.path.join(REPO, "include", "maro_amd_citi_bike.h"), os.path.join(HERE, "wave_emu.h")]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-g", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
                                "-Wno-unused-function", "-shared", "-o", LIB, srcs[0]])
@@ -30,8 +30,8 @@ def build_specialized(defines: str) -> str:
     import hashlib
     import tempfile
     key = hashlib.sha256(defines.encode() + b"".join(open(os.path.join(REPO, "maro_amd", "csrc", f), "rb").read() for f in
-                                                     ("cb_device.h", "cb_layout.h", "cb_params.h"))
-                         + open(os.path.join(HERE, "cb_emu.cpp"), "rb").read()).hexdigest()[:20]
+                                                     ("cb_device.h", "cb_layout.h", "cb_params.h", "cb_wave.h"))
+                         + open(os.path.join(HERE, "cb_emu.cpp"), "rb").read() + open(os.path.join(HERE, "wave_emu.h"), "rb").read()).hexdigest()[:20]
     d = os.path.join(tempfile.gettempdir(), "maro_amd_cb_emu_spec")
     os.makedirs(d, exist_ok=True)
     so = os.path.join(d, key + ".so")
@@ -63,6 +63,11 @@ def _declare(L):
     L.cb_emu_step_joint.argtypes = [vp] * 9
     L.cb_emu_query.argtypes = [vp, i32, vp, i32, i32, vp, i32, i32, vp, i32, vp]
     L.cb_emu_random_policy.argtypes = [vp, vp, vp, ctypes.c_int64, vp, vp]
+    L.cb_emu_set_wave_decisions.argtypes = [vp, i32, i32]
+    L.cb_emu_wave_handled.restype = ctypes.c_long
+    L.cb_emu_wave_handled.argtypes = [vp]
+    L.cb_emu_wave_general.restype = ctypes.c_long
+    L.cb_emu_wave_general.argtypes = [vp]
     return L
 
 
@@ -87,7 +92,7 @@ class CbEmuBackend:
     """numpy-facing batch backend; tests/cb_backend_adapter.py gives the GPU engine the same surface."""
 
     def __init__(self, data, n_envs=1, start_tick=0, durations=100, snapshot_resolution=1, max_snapshots=None, max_actions=1,
-                 delivery_capacity=0, transfer_times_cap=0, specialized=False, decision_mode=0):
+                 delivery_capacity=0, transfer_times_cap=0, specialized=False, decision_mode=0, wave_decisions=False, reverse=False):
         self.data = data
         if not delivery_capacity:   # same default as maro_amd.citi_bike.engine.CitiBikeBatchEngine
             delivery_capacity = data.n_stations * (int((data.time_mean + 6 * data.time_std) / max(data.resolution, 1)) + 2) + 4
@@ -115,6 +120,12 @@ class CbEmuBackend:
         self._scope = np.zeros((n_envs,) + rows + (self.layout.scope_cap, 2), np.int32)
         self._met = np.zeros((n_envs, 3), np.int64)
         self._done = np.zeros(n_envs, np.uint8)
+        if wave_decisions:   # steps go through the wave-cooperative decision step first (cb_wave.h on the 64-fiber wave emulator)
+            self._L.cb_emu_set_wave_decisions(ctypes.c_void_p(self._h), 1, int(reverse))
+
+    def wave_counts(self):
+        """(env-steps handled by the wave-cooperative decision step, env-steps that went to the general path)"""
+        return int(self._L.cb_emu_wave_handled(ctypes.c_void_p(self._h))), int(self._L.cb_emu_wave_general(ctypes.c_void_p(self._h)))
 
     def __del__(self):
         if getattr(self, "_h", None) and getattr(self, "_L", None) is not None:

@@ -55,3 +55,18 @@ def test_batch_matches_oracle_specialized_unaligned_frames(kwargs):
     data = load_topology("toy.5s_filters")
     b = functools.partial(CbEmuBackend, specialized=True)(data, n_envs=5, max_actions=1, **kwargs)
     run_batch_vs_oracle(b, data, kwargs, seeds=np.arange(5) + 11, episodes=2)
+
+
+@pytest.mark.parametrize("topology,kwargs,n", [
+    ("toy.5s_filters", dict(durations=700, snapshot_resolution=10), 6),
+    ("toy.3s_tight", dict(durations=900, snapshot_resolution=3, max_snapshots=9), 8),
+    ("city.180s", dict(durations=260, snapshot_resolution=20, max_snapshots=12), 3),
+])
+def test_batch_matches_oracle_with_wave_cooperative_decisions(topology, kwargs, n):
+    """Per-env actions and transfer times, two episodes: the wave-cooperative decision step (cb_wave.h) in front of the general
+    step, as mrx_cb_step runs them."""
+    data = load_topology(topology)
+    b = CbEmuBackend(data, n_envs=n, max_actions=1, wave_decisions=True, **kwargs)
+    steps = run_batch_vs_oracle(b, data, kwargs, seeds=np.arange(n) + 5, episodes=2)
+    handled, general = b.wave_counts()
+    assert steps > 20 and handled > 0 and general > 0

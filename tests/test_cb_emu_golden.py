@@ -31,3 +31,34 @@ def test_cb_device_code_reproduces_reference_joint_modes(case, specialized):
         b.reset(transfer_times=[tt[: b.layout.transfer_times_cap]] * n_envs)
         return CbBackendEnv(b, env=n_envs - 1)
     replay_citi_bike_joint(make_joint, case)
+
+
+# ---- the wave-cooperative decision step (maro_amd/csrc/cb_wave.h) on the 64-fiber wave emulator, in front of the general step
+# exactly as mrx_cb_step launches them; forward and reverse lane order (a missing wave::sync shows up as a difference)
+def _wave_cases():
+    """(case, reverse lane order): every toy golden in both lane orders; of the city-sized ones — slow on 64 fibers, and replayed in
+    full by the HIP build in test_gpu_citi_bike.py — one 180-station and one 800-station case, one lane order each.  Unaligned
+    frames (start13 / start27) never take this path."""
+    out = []
+    for c in CASES:
+        if "start13" in c or "start27" in c:
+            continue
+        if "city" not in c:
+            out += [(c, False), (c, True)]
+    return out + [("cb_city180_d1440_r10_ring16_half", False), ("cb_city800_d300_r20_ring12_half", True)]
+
+
+@pytest.mark.parametrize("case,reverse", _wave_cases())
+def test_wave_cooperative_decision_step_reproduces_reference(case, reverse):
+    made = []
+
+    def make_wave(data, kw, tt, n_envs=1):
+        b = CbEmuBackend(data, n_envs=n_envs, max_actions=1, wave_decisions=True, reverse=reverse, **kw)
+        b.reset(transfer_times=[tt[: b.layout.transfer_times_cap]] * n_envs)
+        made.append(b)
+        return CbBackendEnv(b, env=n_envs - 1)
+    replay_citi_bike(make_wave, case)
+    handled, general = made[0].wave_counts()
+    assert handled > 0 and general > 0, (handled, general)   # both paths ran (every tick ends on the general one)
+    if "city800" in case:
+        assert handled > 50 * general, (handled, general)    # hundreds of decisions per decision tick stay inside the tick
