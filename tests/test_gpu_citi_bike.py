@@ -131,3 +131,81 @@ def test_full_size_batch_properties():
     assert (q[..., 2].sum(axis=(1, 2)) == ntrips).all() and (q[..., 0].sum(axis=(1, 2)) == m[:, 1]).all()
     adj = eng.query("matrices", fis[-1:], np.zeros(1, np.int32), ["trips_adj"]).cpu().numpy()
     assert (adj.sum(axis=(1, 2, 3)) == ntrips).all()
+
+
+# ---- the reference's own size: city.800s = 800 stations, ny filter chain 80 -> 40 -> 20 over 10 windows, a month of ticks
+def test_city800_batch_matches_oracle():
+    """A 300-env batch of city.800s (wave-cooperative decision step + general kernel, as mrx_cb_step runs them at this size), per-env
+    actions and transfer times, three envs replayed on the oracle: every decision, scope, metric and the snapshot history."""
+    from tests.cb_gpu_backend import CbGpuBackend
+    data = load_topology("city.800s")
+    kw = dict(start_tick=1440, durations=130, snapshot_resolution=10, max_snapshots=6)
+    b = CbGpuBackend(data, n_envs=300, max_actions=1, **kw)
+    assert b.eng.set_wave_decisions(0)   # automatic = on at this size
+    steps = run_batch_vs_oracle(b, data, kw, seeds=np.arange(300) + 17, episodes=1, check_envs=[0, 151, 299])
+    assert steps > 1000
+
+
+@pytest.mark.parametrize("topology,kwargs", [("toy.5s_filters", dict(durations=1200, snapshot_resolution=10)),
+                                             ("toy.3s_tight", dict(durations=1000, snapshot_resolution=5, max_snapshots=11))])
+def test_wave_cooperative_decisions_on_small_topologies(topology, kwargs):
+    """Forced on (automatic only switches it on from 96 stations): same trajectories as the oracle."""
+    from tests.cb_gpu_backend import CbGpuBackend
+    data = load_topology(topology)
+    b = CbGpuBackend(data, n_envs=130, max_actions=1, **kwargs)
+    assert b.eng.set_wave_decisions(1)
+    run_batch_vs_oracle(b, data, kwargs, seeds=np.arange(130) + 3, episodes=2, check_envs=[0, 63, 64, 129])
+
+
+def test_city800_full_month_properties():
+    """The whole 44 640-tick horizon of city.800s (1.5 M trips) on a 128-env batch, on properties only.  Joint decision mode: a
+    step call reports every pending decision of a decision tick at once (~200 per env at this size) and the next call finishes
+    them; the first reported event of every tick is answered (half the scope to the nearest candidate).  Properties: every RequireBike is counted (trips
+    metric = trips of the month), shortage + fulfilment = requirement in every frame of the ring, envs that share a seed and act
+    alike stay identical, bikes only leave the system through deliveries still in flight, no status bit is raised."""
+    import dataclasses
+
+    import torch
+    from maro_amd.citi_bike.engine import CitiBikeBatchEngine
+    n, dur = 128, 44640
+    seeds = np.arange(n) % 64   # envs e and e + 64 share seed and actions
+    # one decision tick per DAY (31 of them, ~200 decision events each) instead of one every 20 ticks: the month's 3 M trip /
+    # return events, 744 frames through a 24-slot ring and the month-long shared tables are what this test is about — at the
+    # topology's own resolution the 450 000 decision events of a month would dominate it (the batch-vs-oracle test above and the
+    # goldens cover those at resolution 20)
+    data = dataclasses.replace(load_topology("city.800s"), resolution=1440)
+    eng = CitiBikeBatchEngine(data, n, durations=dur, snapshot_resolution=60, max_snapshots=24, seeds=seeds, decision_mode=1,
+                              transfer_times_cap=4096)
+    S = eng.data.n_stations
+    a = torch.zeros((n, S, 1, 3), dtype=torch.int32, device=eng.device)
+    na = torch.zeros((n, S), dtype=torch.int32, device=eng.device)
+    nans = torch.zeros(n, dtype=torch.int32, device=eng.device)
+    dec, scope, met, done = eng.step_joint()
+    calls = 0
+    while not bool(done.all()):
+        calls += 1
+        # answer the FIRST reported event of every env: move half of what the scope allows between the station and its first candidate
+        d0, s0 = dec[:, 0], scope[:, 0]
+        valid = (d0[:, 5] == 1) & (d0[:, 4] >= 2)
+        k = (d0[:, 4] - 1).clamp(min=0).long()
+        self_row = s0[torch.arange(n, device=eng.device), k]
+        num = torch.minimum(self_row[:, 1], s0[:, 0, 1]).clamp(min=0) // 2
+        supply = d0[:, 2] == 0
+        a[:, 0, 0, 0] = torch.where(supply, self_row[:, 0], s0[:, 0, 0])
+        a[:, 0, 0, 1] = torch.where(supply, s0[:, 0, 0], self_row[:, 0])
+        a[:, 0, 0, 2] = num
+        na[:, 0] = valid.to(torch.int32)
+        nans[:] = valid.to(torch.int32)
+        dec, scope, met, done = eng.step_joint(a, na, nans)
+        assert calls < 200
+    torch.cuda.synchronize()
+    assert calls >= dur // eng.data.resolution - 1
+    assert int(eng.status.abs().sum()) == 0
+    m = eng.metrics.cpu().numpy()
+    assert (m[:64] == m[64:]).all() and (m[:, 2] > 0).all()
+    assert (m[:, 0] == int((eng.data.trip_tick < dur).sum())).all()
+    fis = np.arange(dur // 60 - 24, dur // 60, dtype=np.int32)
+    q = eng.query("stations", fis, np.arange(S, dtype=np.int32), ["shortage", "fulfillment", "trip_requirement", "bikes"]).cpu().numpy()
+    assert (q[..., 0] + q[..., 1] == q[..., 2]).all() and q[..., 2].sum() > 0
+    total0 = int(eng.data.init_bikes.sum())
+    assert (q[:, -1, :, 3].sum(-1) <= total0).all() and (q[:, -1, :, 3].sum(-1) > 0.5 * total0).all()   # the rest is on trips / in delivery
