@@ -684,6 +684,325 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
   *done = finished ? 1 : 0;
 }
 
+// ==========================================================================================
+// WAVE-COOPERATIVE pieces (one env per wave64; written against wave::{lane, sync, ballot, bcast} — the includer brings wave.h or,
+// in tests/emu, the 64-fiber emulation).  See cb_wave.h for why: at the reference's own topology size a decision tick raises
+// hundreds of decision events per env, and the action scope's per-lane selection sort / the station sweeps dominate everything.
+enum { CBW_MAX = 128 };  // candidates ranked in registers (two per lane)
+
+// rank[a] = how many of the n candidates come before candidate (a, lane) — mode 0 / 2: (v, key) descending, 1: ascending
+MRX_DEV void cbw_rank(int n, int mode, const int* v, const int* key, int* rank) {
+  rank[0] = rank[1] = 0;
+  for (int j = 0; j < n; j++) {  // wave-uniform
+    const int vj = wave::bcast(j < 64 ? v[0] : v[1], j & 63), kj = wave::bcast(j < 64 ? key[0] : key[1], j & 63);
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+      const bool before = mode == 1 ? (vj < v[a] || (vj == v[a] && kj < key[a])) : (vj > v[a] || (vj == v[a] && kj > key[a]));
+      rank[a] += before ? 1 : 0;
+    }
+  }
+}
+
+// keep the n_out best of n candidates, best first: survivors move to position = rank through the LDS scratch (2 x CBW_MAX words)
+MRX_DEV void cbw_select(int32_t* scr, int n, int n_out, int mode, const int* v, int* key, int* val) {
+  const int lane = wave::lane();
+  int rank[2];
+  cbw_rank(n, mode, v, key, rank);
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+    if (a * 64 + lane < n && rank[a] < n_out) { scr[rank[a]] = key[a]; scr[CBW_MAX + rank[a]] = val[a]; }
+  wave::sync();
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+    const int i = a * 64 + lane;
+    key[a] = i < n_out ? scr[i] : -1;
+    val[a] = i < n_out ? scr[CBW_MAX + i] : 0;
+  }
+  wave::sync();
+}
+
+// candidates of station s after the leading distance filters (a prefix of the distance-sorted list); *nf0 = first other filter
+MRX_DEV int cbw_candidates(const CbParams& K, int s, int* nf0) {
+  int n = K.nb_cnt[s], f = 0;
+  while (f < CD(n_filters) && CDA(f_type, f) == MRX_CB_FILTER_DISTANCE) {
+    n = CDA(f_num, f) < n ? CDA(f_num, f) : n;
+    f++;
+  }
+  *nf0 = f;
+  return n;
+}
+
+// can scope_wave evaluate (s, t)?  At most CBW_MAX candidates, at most 64 frames in a trip window.
+MRX_DEV bool scope_wave_ok(const CbParams& K, int s, int t) {
+  int nf0;
+  if (cbw_candidates(K, s, &nf0) > CBW_MAX) return false;
+  const int fi_cur = (t - CD(start_tick)) / CD(res);
+  for (int f = nf0; f < CD(n_filters); f++)
+    if (CDA(f_type, f) == MRX_CB_FILTER_TRIP_WINDOW) {
+      const int avail = fi_cur + 1 < CD(ring_slots) ? fi_cur + 1 : CD(ring_slots);
+      const int aw = CDA(f_win, f) < avail ? CDA(f_win, f) : avail;
+      if ((aw > 0 ? aw : avail) > 64) return false;
+    }
+  return true;
+}
+
+// BikeDecisionStrategy.action_scope (decision_strategy.py:253-293) of station s at tick t, across the lanes of a wave: the same
+// values, order and cache side effects as cb::action_scope above.  bikes(station) = the env's current bikes; tag_get(slot, &fi,
+// &tick) / tag_set(slot, fi, tick) = the trip-window filter's per-slot cache words.  Writes `out`, returns the number of rows.
+template <class BK, class TG, class TS>
+MRX_DEV int scope_wave(const CbParams& K, int s, int type, int t, int32_t* scr, int32_t* out, BK bikes, TG tag_get, TS tag_set) {
+  const int lane = wave::lane();
+  const int S = CD(S);
+  int nf0;
+  int n = cbw_candidates(K, s, &nf0);
+  const int fi_cur = (t - CD(start_tick)) / CD(res);
+  int key[2], val[2];
+#pragma unroll
+  for (int a = 0; a < 2; a++) {  // candidate i = a * 64 + lane
+    const int i = a * 64 + lane;
+    const int nb = K.nb[(size_t)s * CD(nb_stride) + (i < n ? i : 0)];
+    const int bk = bikes(nb);
+    key[a] = i < n ? nb : -1;
+    val[a] = type == MRX_CB_SUPPLY ? K.capacity[nb] - bk : (int)floor((double)bk * K.scope_high);
+  }
+  for (int f = nf0; f < CD(n_filters); f++) {  // wave-uniform
+    const int n_out = CDA(f_num, f) < n ? CDA(f_num, f) : n;
+    if (CDA(f_type, f) == MRX_CB_FILTER_DISTANCE) {
+      // (cb_plan rejects a distance filter behind a reordering one; a later prefix cut of a still distance-ordered list)
+    } else if (CDA(f_type, f) == MRX_CB_FILTER_REQUIREMENTS) {
+      const int v0[2] = {val[0], val[1]};
+      cbw_select(scr, n, n_out, 0, v0, key, val);
+    } else {
+      // TripsWindowFilter :88-163 — see cb::action_scope: a frame's value is frozen at the tick it was last read as the
+      // current frame; the newest frame is re-read now (with windows == 0, Python's lst[-0:], only when it is new)
+      const int avail = fi_cur + 1 < CD(ring_slots) ? fi_cur + 1 : CD(ring_slots);
+      const int aw = CDA(f_win, f) < avail ? CDA(f_win, f) : avail;
+      const int cnt = aw > 0 ? aw : avail;
+      int hi_o = 0, lo_o = 0;
+      if (lane < cnt) {  // lane k: frame fi_cur - k
+        const int fi = fi_cur - lane, slot = fi % CD(ring_slots);
+        int tag_fi, tag_t;
+        tag_get(slot, &tag_fi, &tag_t);
+        if (lane == 0 && (aw > 0 || tag_fi != fi)) { tag_fi = fi; tag_t = t; tag_set(slot, fi, t); }
+        const int tb = tag_fi == fi ? tag_t : snapshot_tick(K, fi);
+        int w0 = tb / CD(res) * CD(res);
+        if (w0 < CD(start_tick)) w0 = CD(start_tick);
+        hi_o = (tb + 1 - CD(start_tick)) * S;
+        lo_o = (w0 - CD(start_tick)) * S;
+      }
+      int trips[2] = {0, 0};
+      for (int k = 0; k < cnt; k++) {  // wave-uniform
+        const int hi = wave::bcast(hi_o, k), lo = wave::bcast(lo_o, k);
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+          const int x = key[a] >= 0 ? key[a] : 0;
+          trips[a] += K.req_cum[hi + x] - K.req_cum[lo + x];
+        }
+      }
+      cbw_select(scr, n, n_out, type == MRX_CB_DEMAND ? 2 : 1, trips, key, val);
+    }
+    n = n_out;
+  }
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+    const int i = a * 64 + lane;
+    if (i < n) { out[2 * i] = key[a]; out[2 * i + 1] = val[a]; }
+  }
+  const int bs = bikes(s);
+  if (lane == 0) {
+    out[2 * n] = s;
+    out[2 * n + 1] = type == MRX_CB_SUPPLY ? (int)floor((double)bs * K.scope_low_keep) : K.capacity[s] - bs;
+  }
+  for (int i = n + 1 + lane; i < CD(scope_cap); i += 64) { out[2 * i] = -1; out[2 * i + 1] = -1; }
+  return n + 1;
+}
+
+#ifdef MRX_CB_LDSFRAME
+// ---- the GENERAL step of one env on one wave, state in the wave's LDS column (plan-specialised LDS-frame build launched with one
+// env per workgroup): the event replay, the delivery pool and the action stay scalar (lane 0 — they are strictly sequential),
+// the station sweeps (rebalance check, snapshot, frame reset), the scan for the next decision and the action scope run across
+// the 64 lanes.  Sequential decision mode, aligned frames (the host only launches it then).  Mirrors step_env above line by line.
+#ifdef __HIPCC__
+#define LW(w) mrx_cb_lds[CB_EV_BLOCK * 4 + (w)] /* lane-independent view of the wave's one column (LF() of lane 0, K.lsh = 0) */
+#else
+#define LW(w) mrx_cb_lds_host[CB_EV_BLOCK * 4 + (w)]
+#endif
+MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int n_actions, int32_t* dec, int32_t* scope, int64_t* met, uint8_t* done,
+                           int32_t* scr) {
+  const int lane = wave::lane();
+  const int S = CD(S), MW = CD(mask_words);
+  int32_t* hd = nullptr;
+  int32_t* ctl = scr + 2 * CBW_MAX;  // lane 0 -> wave: [0] w0 of the record it stopped at, [1] its a, [2] stream position, [3] budget left
+#ifndef __HIPCC__
+  if (lane == 0) {  // host harness: one env at a time through the static LDS stand-in
+    for (int w = 0; w < CH_WORDS; w++) HDR(w) = GHDR(w);
+    for (int w = 0; w < MRXC_FW; w++) LF(w) = K.live[(size_t)w * CD(stride) + e];
+    for (int w = 0; w < MRXC_S; w++) LF(LDS_CAP + w) = K.capacity[w];
+    for (int w = 0; w < MRXC_w_words; w++) LF(LDS_FUL + w) = (int32_t)GFUL(w);
+    for (int w = 0; w < 2 * MRXC_mask_words; w++) LF(LDS_DMK + w) = (int32_t)GDMK(w);
+#ifdef MRX_CB_TWC_LDS
+    for (int w = 0; w < MRXC_ring_slots; w++) { TWCF(w) = K.twc_fi[(size_t)w * CD(stride) + e]; TWCT(w) = K.twc_tick[(size_t)w * CD(stride) + e]; }
+#endif
+  }
+  wave::sync();
+#endif
+  int flags = LW(LDS_HDR + CH_FLAGS), t = LW(LDS_HDR + CH_TICK);
+  bool finished = (flags & CFL_FINISHED) != 0;
+  if (!finished) {
+    int pos = LW(LDS_HDR + CH_EV_POS);
+    bool resumed = (flags & CFL_PENDING) != 0;
+    if (resumed) {
+      if (lane == 0) apply_actions(K, e, hd, t, HDR(CH_CUR_STATION), actions, n_actions);
+      flags &= ~CFL_PENDING;
+      wave::sync();
+    }
+    flags &= ~CFL_FRESH;
+    int dec_s = -1, dec_type = 0;
+    int left = K.step_budget > 0 ? K.step_budget : 0x7fffffff;
+    for (;;) {
+      if (lane == 0) {  // ---- light records: strictly sequential
+        EvWin W;
+        W.open(K, pos);
+        EvWin::Rec r = W.rec(K);
+        while ((r.w0 & 7) != CB_EV_REBAL && (r.w0 & 7) != CB_EV_TICK_END && left > 0) {
+          light_event(K, e, hd, CD(start_tick) + (r.w0 >> 3), r.w0 & 7, r.a, r.b, r.c);
+          W.advance(K);
+          r = W.rec(K);
+          left--;
+        }
+        ctl[0] = r.w0; ctl[1] = r.a; ctl[2] = W.pos; ctl[3] = left;
+      }
+      wave::sync();
+      const int w0 = ctl[0], ra = ctl[1];
+      pos = ctl[2]; left = ctl[3];
+      wave::sync();
+      t = CD(start_tick) + (w0 >> 3);
+      if ((w0 & 7) != CB_EV_REBAL && (w0 & 7) != CB_EV_TICK_END) break;  // budget spent between two light records
+      left -= 4;
+      if ((w0 & 7) == CB_EV_REBAL) {
+        // rebalance_check :468-492 + decision_strategy.py:229-251, lane = station
+        if (lane == 0 && HDR(CH_POOL_MINLAND) <= t) pool_flush_at(K, e, hd, t);
+        wave::sync();
+        for (int c0 = 0; c0 < S; c0 += 64) {
+          const int s = c0 + lane;
+          bool sup = false, dem = false;
+          if (s < S) {
+            const double ratio = (double)LW(LV_BIKES * S + s) / (double)LW(LDS_CAP + s);
+            sup = ratio >= K.supply_wm;
+            dem = !sup && ratio <= K.demand_wm;
+          }
+          const uint64_t ms = wave::ballot(sup), md = wave::ballot(dem);
+          if (lane == 0) {
+            const int w = c0 >> 5;
+            LW(LDS_DMK + w) = (int32_t)(uint32_t)(ms & 0xffffffffull); LW(LDS_DMK + MW + w) = (int32_t)(uint32_t)(md & 0xffffffffull);
+            if (w + 1 < MW) { LW(LDS_DMK + w + 1) = (int32_t)(uint32_t)(ms >> 32); LW(LDS_DMK + MW + w + 1) = (int32_t)(uint32_t)(md >> 32); }
+          }
+        }
+        wave::sync();
+        pos++;
+        continue;
+      }
+      if (lane == 0 && !resumed && HDR(CH_POOL_MINLAND) <= t) pool_flush_at(K, e, hd, t);
+      resumed = false;
+      wave::sync();
+      {  // next_decision: lowest pending station, Supply wins; one mask word per lane (two rounds above 2048 stations)
+        dec_s = -1;
+        for (int w0m = 0; w0m < MW && dec_s < 0; w0m += 64) {
+          const int w = w0m + lane;
+          const uint32_t sup = w < MW ? (uint32_t)LW(LDS_DMK + w) : 0u, any = sup | (w < MW ? (uint32_t)LW(LDS_DMK + MW + w) : 0u);
+          const uint64_t pend = wave::ballot(any != 0u);
+          if (pend) {
+            const int l1 = __builtin_ctzll(pend);
+            const uint32_t wa = (uint32_t)wave::bcast((int)any, l1), ws = (uint32_t)wave::bcast((int)sup, l1);
+            const int j1 = __builtin_ctz(wa);
+            dec_s = (w0m + l1) * 32 + j1;
+            dec_type = (ws >> j1 & 1u) ? MRX_CB_SUPPLY : MRX_CB_DEMAND;
+          }
+        }
+      }
+      if (dec_s >= 0) break;
+      // ---- end_tick
+      if (lane == 0 && HDR(CH_LATE) > 0) {  // DeliverBike appended to this very tick (transfer time 0)
+        int p = HDR(CH_POOL_HEAD);
+        pool_exec_until(K, e, hd, t, CB_NO_LAND, p, HDR(CH_POOL_TAIL));
+        pool_compact(K, e, hd);
+        HDR(CH_LATE) = 0;
+      }
+      wave::sync();
+      const bool frame_end = (ra & 1) != 0;
+      if (frame_end || (ra & 2)) {  // take_snapshot: np_backend.pyx:481-518 (frame_end: post_step :130-147; last tick: core.py:371-375)
+        const int fi = (t - CD(start_tick)) / CD(res), slot = fi % CD(ring_slots);
+        int32_t* dst = K.ring + (size_t)slot * (CD(FW) + 1) * CD(stride) + e;
+        for (int w = lane; w < CD(FW); w += 64) dst[(size_t)w * CD(stride)] = LW(w);
+        if (lane == 0) { dst[(size_t)CD(FW) * CD(stride)] = t; K.ring_fi[(size_t)slot * CD(stride) + e] = fi; }
+        wave::sync();  // every lane has read its words of the frame before the reset below rewrites them
+      }
+      if (frame_end) {
+        for (int s = lane; s < S; s += 64) {
+          LW(LV_SHORTAGE * S + s) = 0; LW(LV_TRIP_REQUIREMENT * S + s) = 0; LW(LV_EXTRA_COST * S + s) = 0; LW(LV_TRANSFER_COST * S + s) = 0;
+          LW(LV_FULFILLMENT * S + s) = 0; LW(LV_FAILED_RETURN * S + s) = 0;
+          LW(LV_MIN_BIKES * S + s) = LW(LV_BIKES * S + s);
+        }
+        wave::sync();
+      }
+      if (ra & 2) {
+        flags |= CFL_FINISHED;
+        finished = true;
+        break;
+      }
+      pos++;
+    }
+    if (dec_s >= 0) {
+      flags |= CFL_PENDING;
+      if (lane == 0) { HDR(CH_CUR_STATION) = dec_s; HDR(CH_CUR_TYPE) = dec_type; HDR(CH_NDEC) += 1; }
+      int cnt;
+      if (scope_wave_ok(K, dec_s, t)) {
+        cnt = scope_wave(K, dec_s, dec_type, t, scr, scope,
+                         [&](int st) { return LW(LV_BIKES * S + st); },
+#ifdef MRX_CB_TWC_LDS
+                         [&](int slot, int* fi, int* tk) { *fi = LW(LDS_TWC + slot); *tk = LW(LDS_TWC + MRXC_ring_slots + slot); },
+                         [&](int slot, int fi, int tk) { LW(LDS_TWC + slot) = fi; LW(LDS_TWC + MRXC_ring_slots + slot) = tk; });
+#else
+                         [&](int slot, int* fi, int* tk) { *fi = K.twc_fi[(size_t)slot * CD(stride) + e]; *tk = K.twc_tick[(size_t)slot * CD(stride) + e]; },
+                         [&](int slot, int fi, int tk) { K.twc_fi[(size_t)slot * CD(stride) + e] = fi; K.twc_tick[(size_t)slot * CD(stride) + e] = tk; });
+#endif
+      } else {
+        Prof P;
+        if (lane == 0) ctl[0] = action_scope(K, e, hd, dec_s, dec_type, t, scope, P);
+        wave::sync();
+        cnt = ctl[0];
+      }
+      if (lane == 0) {
+        dec[0] = t; dec[1] = dec_s; dec[2] = dec_type; dec[3] = (t - CD(start_tick)) / CD(res); dec[4] = cnt; dec[5] = 1; dec[6] = 0; dec[7] = 0;
+      }
+    }
+    if (lane == 0) { HDR(CH_EV_POS) = pos; HDR(CH_TICK) = t; HDR(CH_FLAGS) = flags; }
+    wave::sync();
+#ifndef __HIPCC__
+    if (lane == 0) {
+      for (int w = 0; w < CH_WORDS; w++) GHDR(w) = HDR(w);
+      for (int w = 0; w < MRXC_FW; w++) K.live[(size_t)w * CD(stride) + e] = LF(w);
+      for (int w = 0; w < MRXC_w_words; w++) GFUL(w) = (uint32_t)LF(LDS_FUL + w);
+      for (int w = 0; w < 2 * MRXC_mask_words; w++) GDMK(w) = (uint32_t)LF(LDS_DMK + w);
+#ifdef MRX_CB_TWC_LDS
+      for (int w = 0; w < MRXC_ring_slots; w++) { K.twc_fi[(size_t)w * CD(stride) + e] = TWCF(w); K.twc_tick[(size_t)w * CD(stride) + e] = TWCT(w); }
+#endif
+    }
+    wave::sync();
+#endif
+  }
+  if (finished || !(flags & CFL_PENDING)) {  // episode over, or (step budget) no decision reached yet
+    if (lane == 0) { dec[0] = t; dec[1] = -1; dec[2] = -1; dec[3] = (t - CD(start_tick)) / CD(res); dec[4] = 0; dec[5] = 0; dec[6] = 0; dec[7] = 0; }
+    for (int i = lane; i < CD(scope_cap); i += 64) { scope[2 * i] = -1; scope[2 * i + 1] = -1; }
+  }
+  if (lane == 0) {
+    met[0] = LW(LDS_HDR + CH_TRIPS); met[1] = LW(LDS_HDR + CH_SHORT); met[2] = LW(LDS_HDR + CH_OPER);
+    *done = finished ? 1 : 0;
+  }
+}
+#undef LW
+#endif  // MRX_CB_LDSFRAME
+
 // Env.reset: citi_bike/business_engine.py:164-190, station.py:63-69
 MRX_DEV void reset_env(const CbParams& K, int e) {
   for (int w = 0; w < CH_WORDS; w++) GHDR(w) = 0;

@@ -88,7 +88,7 @@ struct mrx_cb_engine {
   int lanes = 64;  // envs per wave of the step kernel
   int step_budget = 0;  // mrx_cb_set_step_budget
   hipModule_t spec_module = nullptr;   // plan-specialised reset / step kernels (mrx_cb_load_step_kernels), else the generic ones
-  hipFunction_t spec_reset = nullptr, spec_step = nullptr, spec_wave = nullptr;
+  hipFunction_t spec_reset = nullptr, spec_step = nullptr, spec_wave = nullptr, spec_replay = nullptr;
   int wave_mode = 0;    // mrx_cb_set_wave_decisions: 0 automatic, 1 on, -1 off
   // kernels of the module may still be queued or running on the caller's stream: drain the device before unloading
   void unload_spec() {
@@ -101,7 +101,7 @@ struct mrx_cb_engine {
       if (cur != device && cur >= 0) hipSetDevice(cur);
     }
     spec_module = nullptr;
-    spec_wave = nullptr;
+    spec_wave = spec_replay = nullptr;
   }
   ~mrx_cb_engine() { unload_spec(); }
 };
@@ -257,6 +257,15 @@ static int cb_launch_step(mrx_cb_handle h, const int32_t* d_actions, const int32
                          metw, d_done);
     }
     d_env_mask = K.todo;
+    if (h->spec_replay && (int64_t)K.lds_words * 4 <= MRX_CB_LDS_BYTES) {
+      // ... and the general step for the flagged envs, also one env per wave: state in the wave's LDS column (cb::step_env_wave)
+      CbParams Kr = Kc;
+      Kr.lsh = 0;
+      const uint8_t* todo = K.todo;
+      void* pr[] = {&Kr, &d_actions, &d_n_actions, &todo, &d_decisions, &d_scope, &metw, &d_done};
+      HIP_TRY(hipModuleLaunchKernel(h->spec_replay, (unsigned)K.n_envs, 1, 1, 64, 1, 1, (unsigned)(K.lds_words * 4), (hipStream_t)stream, pr, nullptr));
+      return MRX_OK;
+    }
   }
   if (h->spec_module) {
     long long* met = (long long*)d_metrics;
@@ -338,6 +347,9 @@ int mrx_cb_load_step_kernels(mrx_cb_handle h, const void* image, int64_t bytes, 
   h->spec_step = f_step;
   hipFunction_t f_wave = nullptr;
   if (hipModuleGetFunction(&f_wave, mod, "mrx_k_cb_step_wave") == hipSuccess && f_wave) h->spec_wave = f_wave;
+  else (void)hipGetLastError();
+  hipFunction_t f_replay = nullptr;
+  if (hipModuleGetFunction(&f_replay, mod, "mrx_k_cb_replay_wave") == hipSuccess && f_replay) h->spec_replay = f_replay;
   else (void)hipGetLastError();
   return MRX_OK;
 }

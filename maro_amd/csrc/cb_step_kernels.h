@@ -93,3 +93,45 @@ mrx_k_cb_step_wave(CbParams K, const int32_t* __restrict__ actions, const int32_
                                          scope + (size_t)e * CD(scope_cap) * 2, (int64_t*)metrics + (size_t)e * 3, done + e, scr);
   if (threadIdx.x == 0) K.todo[e] = ok ? 0 : 1;
 }
+
+#ifdef MRX_CB_LDSFRAME
+// The GENERAL step on one wave per env (cb::step_env_wave): for the envs mrx_k_cb_step_wave flagged in K.todo.  The env's state is
+// moved HBM <-> the wave's LDS column by all 64 lanes (launched with K.lsh = 0: one column), the sequential parts run on lane 0
+// out of LDS, the station sweeps / snapshot / action scope across the lanes.
+extern "C" __global__ void __launch_bounds__(64)
+mrx_k_cb_replay_wave(CbParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions, const uint8_t* __restrict__ todo,
+                     int32_t* __restrict__ decisions, int32_t* __restrict__ scope, long long* __restrict__ metrics, uint8_t* __restrict__ done) {
+  __shared__ int32_t scr[2 * cb::CBW_MAX + 8];
+  const int e = (int)blockIdx.x, lane = (int)threadIdx.x;
+  if (!todo[e]) return;
+#define MRX_CB_LW(w) cb::mrx_cb_lds[CB_EV_BLOCK * 4 + (w)]
+  for (int w = lane; w < MRXC_FW; w += 64) MRX_CB_LW(w) = K.live[(size_t)w * CD(stride) + e];
+  for (int w = lane; w < MRXC_S; w += 64) MRX_CB_LW(LDS_CAP + w) = K.capacity[w];
+  for (int w = lane; w < CH_WORDS; w += 64) MRX_CB_LW(LDS_HDR + w) = K.hdr[(size_t)w * CD(stride) + e];
+#ifdef MRX_CB_TWC_LDS
+  for (int w = lane; w < MRXC_ring_slots; w += 64) {
+    MRX_CB_LW(LDS_TWC + w) = K.twc_fi[(size_t)w * CD(stride) + e];
+    MRX_CB_LW(LDS_TWC + MRXC_ring_slots + w) = K.twc_tick[(size_t)w * CD(stride) + e];
+  }
+#endif
+  for (int w = lane; w < MRXC_w_words; w += 64) MRX_CB_LW(LDS_FUL + w) = (int32_t)K.fulfilled[(size_t)w * CD(stride) + e];
+  for (int w = lane; w < 2 * MRXC_mask_words; w += 64) MRX_CB_LW(LDS_DMK + w) = (int32_t)K.decmask[(size_t)w * CD(stride) + e];
+  __syncthreads();
+  int na = (actions && n_actions) ? n_actions[e] : 0;
+  if (na > CD(max_actions)) na = CD(max_actions);
+  cb::step_env_wave(K, e, actions ? actions + (size_t)e * CD(max_actions) * 3 : nullptr, na, decisions + (size_t)e * 8, scope + (size_t)e * CD(scope_cap) * 2,
+                    (int64_t*)metrics + (size_t)e * 3, done + e, scr);
+  __syncthreads();
+  for (int w = lane; w < MRXC_FW; w += 64) K.live[(size_t)w * CD(stride) + e] = MRX_CB_LW(w);
+  for (int w = lane; w < CH_WORDS; w += 64) K.hdr[(size_t)w * CD(stride) + e] = MRX_CB_LW(LDS_HDR + w);
+#ifdef MRX_CB_TWC_LDS
+  for (int w = lane; w < MRXC_ring_slots; w += 64) {
+    K.twc_fi[(size_t)w * CD(stride) + e] = MRX_CB_LW(LDS_TWC + w);
+    K.twc_tick[(size_t)w * CD(stride) + e] = MRX_CB_LW(LDS_TWC + MRXC_ring_slots + w);
+  }
+#endif
+  for (int w = lane; w < MRXC_w_words; w += 64) K.fulfilled[(size_t)w * CD(stride) + e] = (uint32_t)MRX_CB_LW(LDS_FUL + w);
+  for (int w = lane; w < 2 * MRXC_mask_words; w += 64) K.decmask[(size_t)w * CD(stride) + e] = (uint32_t)MRX_CB_LW(LDS_DMK + w);
+#undef MRX_CB_LW
+}
+#endif

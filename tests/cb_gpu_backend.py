@@ -9,10 +9,10 @@ from maro_amd.citi_bike.engine import CitiBikeBatchEngine
 
 class CbGpuBackend:
     def __init__(self, data, n_envs=1, start_tick=0, durations=100, snapshot_resolution=1, max_snapshots=None, max_actions=1,
-                 delivery_capacity=0, transfer_times_cap=0, decision_mode=0):
+                 delivery_capacity=0, transfer_times_cap=0, decision_mode=0, specialize=None):
         self.eng = CitiBikeBatchEngine(data, n_envs, start_tick=start_tick, durations=durations, snapshot_resolution=snapshot_resolution,
                                        max_snapshots=max_snapshots, max_actions=max_actions, delivery_capacity=delivery_capacity,
-                                       transfer_times_cap=transfer_times_cap, decision_mode=decision_mode)
+                                       transfer_times_cap=transfer_times_cap, decision_mode=decision_mode, specialize=specialize)
         self.data, self.layout = data, self.eng.layout
         self.n_envs, self.max_actions = n_envs, max_actions
         self.start_tick, self.max_tick, self.res = start_tick, start_tick + durations, snapshot_resolution

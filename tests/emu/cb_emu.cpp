@@ -76,6 +76,15 @@ void cb_emu_step(void* h, const int32_t* actions, const int32_t* n_actions, cons
       });
       if (ok) { e->handled++; continue; }
       e->general++;
+#ifdef MRX_CB_LDSFRAME
+      if (e->wave_mode == 2) {  // the general step in its wave form too (plan-specialised LDS-frame builds: mrx_k_cb_replay_wave)
+        static int32_t scr2[2 * cb::CBW_MAX + 8];
+        wave::run_wave(e->wave, [&]() {
+          cb::step_env_wave(K, env, act, nac, dec + (size_t)env * 8, scope + (size_t)env * K.scope_cap * 2, met + (size_t)env * 3, done + env, scr2);
+        });
+        continue;
+      }
+#endif
     }
     cb::step_env(K, env, act, nac, nullptr, dec + (size_t)env * 8, scope + (size_t)env * K.scope_cap * 2, met + (size_t)env * 3, done + env);
   }

@@ -120,8 +120,9 @@ class CbEmuBackend:
         self._scope = np.zeros((n_envs,) + rows + (self.layout.scope_cap, 2), np.int32)
         self._met = np.zeros((n_envs, 3), np.int64)
         self._done = np.zeros(n_envs, np.uint8)
-        if wave_decisions:   # steps go through the wave-cooperative decision step first (cb_wave.h on the 64-fiber wave emulator)
-            self._L.cb_emu_set_wave_decisions(ctypes.c_void_p(self._h), 1, int(reverse))
+        if wave_decisions:   # steps go through the wave-cooperative decision step first (cb_wave.h on the 64-fiber wave emulator);
+            # 2 (specialised LDS-frame builds): the general step in its wave form as well (cb::step_env_wave)
+            self._L.cb_emu_set_wave_decisions(ctypes.c_void_p(self._h), int(wave_decisions), int(reverse))
 
     def wave_counts(self):
         """(env-steps handled by the wave-cooperative decision step, env-steps that went to the general path)"""

@@ -70,3 +70,22 @@ def test_batch_matches_oracle_with_wave_cooperative_decisions(topology, kwargs, 
     steps = run_batch_vs_oracle(b, data, kwargs, seeds=np.arange(n) + 5, episodes=2)
     handled, general = b.wave_counts()
     assert steps > 20 and handled > 0 and general > 0
+
+
+@pytest.mark.parametrize("topology,kwargs,n,budget", [
+    ("toy.5s_filters", dict(durations=700, snapshot_resolution=10), 5, 0),
+    ("toy.3s_tight", dict(durations=900, snapshot_resolution=3, max_snapshots=9), 6, 7),
+])
+def test_batch_matches_oracle_with_wave_form_general_step(topology, kwargs, n, budget):
+    """Plan-specialised LDS-frame build: decision step AND general step in their wave forms (mrx_k_cb_step_wave +
+    mrx_k_cb_replay_wave), with and without a step budget."""
+    from tests.cb_batch_check import run_bounded_vs_oracle
+    data = load_topology(topology)
+    b = CbEmuBackend(data, n_envs=n, max_actions=1, specialized=True, wave_decisions=2, **kwargs)
+    if budget:
+        calls, unready = run_bounded_vs_oracle(b, data, kwargs, seeds=np.arange(n) + 9, budget=budget)
+        assert unready > 0
+    else:
+        assert run_batch_vs_oracle(b, data, kwargs, seeds=np.arange(n) + 9, episodes=2) > 20
+    handled, general = b.wave_counts()
+    assert handled > 0 and general > 0

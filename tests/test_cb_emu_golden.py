@@ -62,3 +62,20 @@ def test_wave_cooperative_decision_step_reproduces_reference(case, reverse):
     assert handled > 0 and general > 0, (handled, general)   # both paths ran (every tick ends on the general one)
     if "city800" in case:
         assert handled > 50 * general, (handled, general)    # hundreds of decisions per decision tick stay inside the tick
+
+
+# ---- ... and the GENERAL step in its wave form as well (cb::step_env_wave: plan-specialised LDS-frame builds, what
+# mrx_k_cb_replay_wave runs for the envs the decision step leaves alone): lane 0 replays the events out of the LDS column, the
+# station sweeps / snapshot / next-decision scan / action scope run across the lanes
+@pytest.mark.parametrize("case,reverse", [(c, r) for c, r in _wave_cases() if "city800" not in c])
+def test_wave_form_general_step_reproduces_reference(case, reverse):
+    made = []
+
+    def make_wave(data, kw, tt, n_envs=1):
+        b = CbEmuBackend(data, n_envs=n_envs, max_actions=1, specialized=True, wave_decisions=2, reverse=reverse, **kw)
+        b.reset(transfer_times=[tt[: b.layout.transfer_times_cap]] * n_envs)
+        made.append(b)
+        return CbBackendEnv(b, env=n_envs - 1)
+    replay_citi_bike(make_wave, case)
+    handled, general = made[0].wave_counts()
+    assert handled > 0 and general > 0, (handled, general)

@@ -146,6 +146,19 @@ def test_city800_batch_matches_oracle():
     assert steps > 1000
 
 
+def test_city800_batch_matches_oracle_specialised():
+    """The same batch on the plan-specialised LDS-frame kernels: decision step AND general step one env per wave
+    (mrx_k_cb_step_wave + mrx_k_cb_replay_wave), with a step budget on top — what bench.py --topology city.800s runs."""
+    from tests.cb_batch_check import run_bounded_vs_oracle
+    from tests.cb_gpu_backend import CbGpuBackend
+    data = load_topology("city.800s")
+    kw = dict(start_tick=1440, durations=130, snapshot_resolution=10, max_snapshots=6)
+    b = CbGpuBackend(data, n_envs=300, max_actions=1, specialize=True, **kw)
+    assert b.eng.specialized and b.eng.set_wave_decisions(0)
+    calls, unready = run_bounded_vs_oracle(b, data, kw, seeds=np.arange(300) + 17, budget=96, check_envs=[0, 151, 299])
+    assert calls > 1000 and unready > 0
+
+
 @pytest.mark.parametrize("topology,kwargs", [("toy.5s_filters", dict(durations=1200, snapshot_resolution=10)),
                                              ("toy.3s_tight", dict(durations=1000, snapshot_resolution=5, max_snapshots=11))])
 def test_wave_cooperative_decisions_on_small_topologies(topology, kwargs):

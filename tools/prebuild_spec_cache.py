@@ -64,6 +64,14 @@ def main(which="bench"):
         cap = data.n_stations * (int((data.time_mean + 6 * data.time_std) / max(data.resolution, 1)) + 2) + 4
         todo[("citi_bike", spec.plan_defines(ts, MrxCbConfig(4096, 0, 0, 44000, 10, 16, 1, cap, 0), "citi_bike"))] = 1
         del np, keep
+        # ... and city.800s (the reference's own topology size): the bench line of profiles/ (4096 envs, two days) and the plan of
+        # tests/test_gpu_citi_bike.py::test_city800_batch_matches_oracle_specialised (300 envs)
+        data8 = load_cb("city.800s")
+        ts8, keep8 = topology_struct(data8)
+        cap8 = data8.n_stations * (int((data8.time_mean + 6 * data8.time_std) / max(data8.resolution, 1)) + 2) + 4
+        todo[("citi_bike", spec.plan_defines(ts8, MrxCbConfig(4096, 0, 0, 2880, 10, 16, 1, cap8, 0, 0), "citi_bike"))] = 1
+        todo[("citi_bike", spec.plan_defines(ts8, MrxCbConfig(300, 0, 1440, 130, 10, 6, 1, cap8, 0, 0), "citi_bike"))] = 1
+        del keep8
     if which in ("goldens", "all"):   # citi_bike golden replays on the GPU (tests/test_gpu_citi_bike.py, test_gpu_specialized.py: 70 envs)
         import json
 
