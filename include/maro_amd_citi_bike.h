@@ -68,10 +68,13 @@ typedef struct mrx_cb_config {
                                  2 JointWithSequentialAction (mrx_cb_step_joint) */
 } mrx_cb_config;
 
-/* Layout of the per-env arrays inside the workspace.  Every per-env array is struct-of-arrays
- * `int32 [words][env_stride]` (word-major, env-minor) so a wave's 64 envs touch 256 contiguous bytes. */
+/* Layout of the per-env arrays inside the workspace.  env_major = 0: every per-env array is struct-of-arrays
+ * `int32 [words][env_stride]` (word-major, env-minor: the general kernels own one env per lane, a wave's 64 envs touch 256
+ * contiguous bytes).  env_major = 1 (plans that step one env per WAVE: Sequential mode, aligned frames, >= 96 stations): every
+ * per-env array is `int32 [env][words]` — an env's rows are contiguous; read `[words][stride]` below as `[env][words]` then. */
 typedef struct mrx_cb_layout {
   int32_t n_envs, env_stride, n_stations, frame_words, ring_slots, scope_cap, delivery_capacity, transfer_times_cap;
+  int32_t env_major, reserved0;
   int64_t off_hdr;     /* int32 [16][stride]: tick, flags, ..., status (MRX_CB_HDR_*) */
   int64_t off_live;    /* int32 [frame_words][stride]: the 8 per-env station attrs x S (attr-major); trips_adj is a shared table */
   int64_t off_ring;    /* int32 [ring_slots][frame_words + 1][stride] (last word: tick of the snapshot) */

@@ -38,7 +38,7 @@ class MrxCbConfig(ctypes.Structure):
 
 class MrxCbLayout(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_int32) for n in ("n_envs", "env_stride", "n_stations", "frame_words", "ring_slots", "scope_cap",
-                                               "delivery_capacity", "transfer_times_cap")]
+                                               "delivery_capacity", "transfer_times_cap", "env_major", "reserved0")]
                 + [(n, ctypes.c_int64) for n in ("off_hdr", "off_live", "off_ring", "off_ring_fi", "off_transfer_times",
                                                  "workspace_bytes", "off_prof")])
 

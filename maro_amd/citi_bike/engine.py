@@ -76,11 +76,18 @@ class CitiBikeBatchEngine:
         _lib.check(self._L.mrx_cb_get_layout(self._h, ctypes.byref(self.layout)), "mrx_cb_get_layout")
         lay = self.layout
         st = lay.env_stride
-        # zero-copy views of engine state: struct-of-arrays [word, env]
-        self.hdr = self._view(lay.off_hdr, (HDR_WORDS, st))[:, :self.n_envs]
-        self.live = self._view(lay.off_live, (lay.frame_words, st))[:, :self.n_envs]
-        self.ring = self._view(lay.off_ring, (lay.ring_slots, lay.frame_words + 1, st))[:, :, :self.n_envs]
-        self.ring_fi = self._view(lay.off_ring_fi, (lay.ring_slots, st))[:, :self.n_envs]
+        # zero-copy views of engine state, indexed [word, env] whatever the layout in memory (struct-of-arrays [word][env stride],
+        # or — lay.env_major: plans that step one env per wave — [env][words], seen through a transpose)
+        if lay.env_major:
+            self.hdr = self._view(lay.off_hdr, (st, HDR_WORDS))[:self.n_envs].t()
+            self.live = self._view(lay.off_live, (st, lay.frame_words))[:self.n_envs].t()
+            self.ring = self._view(lay.off_ring, (st, lay.ring_slots, lay.frame_words + 1))[:self.n_envs].permute(1, 2, 0)
+            self.ring_fi = self._view(lay.off_ring_fi, (st, lay.ring_slots))[:self.n_envs].t()
+        else:
+            self.hdr = self._view(lay.off_hdr, (HDR_WORDS, st))[:, :self.n_envs]
+            self.live = self._view(lay.off_live, (lay.frame_words, st))[:, :self.n_envs]
+            self.ring = self._view(lay.off_ring, (lay.ring_slots, lay.frame_words + 1, st))[:, :, :self.n_envs]
+            self.ring_fi = self._view(lay.off_ring_fi, (lay.ring_slots, st))[:, :self.n_envs]
         self.ticks, self.status = self.hdr[HDR_TICK], self.hdr[HDR_STATUS]
         rows = (self.data.n_stations,) if self.decision_mode else ()
         self.decisions = torch.zeros((self.n_envs,) + rows + (8,), dtype=torch.int32, device=self.device)

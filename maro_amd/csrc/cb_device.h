@@ -57,7 +57,7 @@ struct Prof {
   __device__ __forceinline__ Prof() { for (int i = 0; i < 16; i++) acc[i] = 0; last = clock64(); }
   __device__ __forceinline__ void mark(int i) { const long long c = clock64(); acc[i] += (int)(c - last); last = c; }
   __device__ __forceinline__ void flush(const CbParams& K, int e) {
-    for (int i = 0; i < 16; i++) if (acc[i]) K.prof[(size_t)i * K.stride + e] += acc[i];
+    for (int i = 0; i < 16; i++) if (acc[i]) K.prof[CB_IX(CD(aos), CD(stride), 16, i, e)] += acc[i];
   }
 };
 #else
@@ -67,9 +67,9 @@ struct Prof {
 };
 #endif
 
-#define GHDR(w) K.hdr[(size_t)(w) * CD(stride) + e] /* header word in HBM */
+#define GHDR(w) K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, (w), e)] /* header word in HBM */
 // the live frame in HBM (reset, query, and the generic step)
-#define GST(a, s) K.live[((size_t)(a) * CD(S) + (size_t)(s)) * CD(stride) + e]
+#define GST(a, s) K.live[CB_IX(CD(aos), CD(stride), CD(FW), ((size_t)(a) * CD(S) + (size_t)(s)), e)]
 #ifdef __HIPCC__
 #define MRX_DEVM __device__ __forceinline__
 #else
@@ -124,16 +124,16 @@ static_assert(LDS_TWC + LDS_TWC_WORDS + CB_EV_BLOCK * 4 == MRXC_lds_words, "cb_l
 #define SCR(i) LF(LDS_SCR + (i))
 #else
 #define HDR(w) hd[(w)] /* header word of the env being stepped: a register copy (step_env) */
-#define LIVE(w) K.live[(size_t)(w) * CD(stride) + e]
+#define LIVE(w) K.live[CB_IX(CD(aos), CD(stride), CD(FW), (w), e)]
 #define ST(a, s) GST(a, s)
 #define CAP(s) K.capacity[s]
 #define FUL(i) GFUL(i)
 #define DMK(i) GDMK(i)
-#define SCR(i) K.scratch[(size_t)(i) * CD(stride) + e]
+#define SCR(i) K.scratch[CB_IX(CD(aos), CD(stride), (3 * CD(S)), (i), e)]
 #endif
 #ifndef MRX_CB_TWC_LDS
-#define TWCF(slot) K.twc_fi[(size_t)(slot) * CD(stride) + e]
-#define TWCT(slot) K.twc_tick[(size_t)(slot) * CD(stride) + e]
+#define TWCF(slot) K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), (slot), e)]
+#define TWCT(slot) K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), (slot), e)]
 #endif
 
 // The env's place in the shared event stream (4 words per record).  LDS build: records are consumed out of a block of
@@ -176,9 +176,10 @@ struct EvWin {
 #endif
 };
 
-#define GFUL(i) K.fulfilled[(size_t)(i) * CD(stride) + e]
-#define GDMK(i) K.decmask[(size_t)(i) * CD(stride) + e]
-#define POOL(i, w) K.pool[((size_t)(i) * CB_POOL_WORDS + (w)) * CD(stride) + e]
+#define RINGW(slot, w) K.ring[CB_IX(CD(aos), CD(stride), ((size_t)CD(ring_slots) * (CD(FW) + 1)), ((size_t)(slot) * (CD(FW) + 1) + (size_t)(w)), e)] /* word w of ring slot `slot` (w = FW: the tick it was taken at) */
+#define GFUL(i) K.fulfilled[CB_IX(CD(aos), CD(stride), CD(w_words), (i), e)]
+#define GDMK(i) K.decmask[CB_IX(CD(aos), CD(stride), (2 * CD(mask_words)), (i), e)]
+#define POOL(i, w) K.pool[CB_IX(CD(aos), CD(stride), (CD(pool_cap) * CB_POOL_WORDS), ((size_t)(i) * CB_POOL_WORDS + (w)), e)]
 
 MRX_DEV void set_bikes(const CbParams& K, int e, int32_t* hd, int s, int v) {  // station.py:71-75
   ST(LV_BIKES, s) = v;
@@ -343,10 +344,9 @@ MRX_DEV int snapshot_tick(const CbParams& K, int fi) {
 // np_backend.pyx:481-518 — frame `fi` goes to ring slot fi % ring_slots (frames are taken in increasing order)
 MRX_DEV void take_snapshot(const CbParams& K, int e, int32_t* hd, int t) {
   const int fi = (t - CD(start_tick)) / CD(res), slot = fi % CD(ring_slots);
-  int32_t* dst = K.ring + (size_t)slot * (CD(FW) + 1) * CD(stride) + e;
-  for (int w = 0; w < CD(FW); w++) dst[(size_t)w * CD(stride)] = LIVE(w);
-  dst[(size_t)CD(FW) * CD(stride)] = t;
-  K.ring_fi[(size_t)slot * CD(stride) + e] = fi;
+  for (int w = 0; w < CD(FW); w++) RINGW(slot, w) = LIVE(w);
+  RINGW(slot, CD(FW)) = t;
+  K.ring_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] = fi;
 }
 
 // the end of tick t (flags of its TICK_END record: 1 = a frame ends here, 2 = last tick); returns true when the episode is over
@@ -517,7 +517,7 @@ MRX_DEV void apply_actions(const CbParams& K, int e, int32_t* hd, int t, int s, 
     set_bikes(K, e, hd, frm, b - ex);
     const int pos = HDR(CH_TT_POS);
     int tt = 1;
-    if (pos < CD(tt_cap)) tt = K.tt[(size_t)pos * CD(stride) + e];
+    if (pos < CD(tt_cap)) tt = K.tt[CB_IX(CD(aos), CD(stride), CD(tt_cap), pos, e)];
     else HDR(CH_STATUS) |= MRX_CB_ENV_TRANSFER_TIMES_OUT;
     HDR(CH_TT_POS) = pos + 1;
     if (tt < 0 || t + tt >= CD(max_tick)) continue;  // lands in the past / after the episode: never executed
@@ -552,12 +552,12 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     EvWin W;
     W.open(K, HDR(CH_EV_POS));
 #if defined(MRX_CB_LDSFRAME) && !defined(__HIPCC__) /* (the HIP kernel moves the state with all 64 lanes: cb_step_kernels.h) */
-    for (int w = 0; w < MRXC_FW; w++) LF(w) = K.live[(size_t)w * CD(stride) + e];
+    for (int w = 0; w < MRXC_FW; w++) LF(w) = K.live[CB_IX(CD(aos), CD(stride), CD(FW), w, e)];
     for (int w = 0; w < MRXC_S; w++) LF(LDS_CAP + w) = K.capacity[w];
     for (int w = 0; w < MRXC_w_words; w++) LF(LDS_FUL + w) = (int32_t)GFUL(w);
     for (int w = 0; w < 2 * MRXC_mask_words; w++) LF(LDS_DMK + w) = (int32_t)GDMK(w);
 #ifdef MRX_CB_TWC_LDS
-    for (int w = 0; w < MRXC_ring_slots; w++) { TWCF(w) = K.twc_fi[(size_t)w * CD(stride) + e]; TWCT(w) = K.twc_tick[(size_t)w * CD(stride) + e]; }
+    for (int w = 0; w < MRXC_ring_slots; w++) { TWCF(w) = K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)]; TWCT(w) = K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)]; }
 #endif
 #endif
     P.mark(0);
@@ -666,11 +666,11 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     for (int w = 0; w < CH_WORDS; w++) GHDR(w) = HDR(w);
 #endif
 #if defined(MRX_CB_LDSFRAME) && !defined(__HIPCC__)
-    for (int w = 0; w < MRXC_FW; w++) K.live[(size_t)w * CD(stride) + e] = LF(w);
+    for (int w = 0; w < MRXC_FW; w++) K.live[CB_IX(CD(aos), CD(stride), CD(FW), w, e)] = LF(w);
     for (int w = 0; w < MRXC_w_words; w++) GFUL(w) = (uint32_t)LF(LDS_FUL + w);
     for (int w = 0; w < 2 * MRXC_mask_words; w++) GDMK(w) = (uint32_t)LF(LDS_DMK + w);
 #ifdef MRX_CB_TWC_LDS
-    for (int w = 0; w < MRXC_ring_slots; w++) { K.twc_fi[(size_t)w * CD(stride) + e] = TWCF(w); K.twc_tick[(size_t)w * CD(stride) + e] = TWCT(w); }
+    for (int w = 0; w < MRXC_ring_slots; w++) { K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)] = TWCF(w); K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)] = TWCT(w); }
 #endif
 #endif
   }
@@ -836,12 +836,12 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
 #ifndef __HIPCC__
   if (lane == 0) {  // host harness: one env at a time through the static LDS stand-in
     for (int w = 0; w < CH_WORDS; w++) HDR(w) = GHDR(w);
-    for (int w = 0; w < MRXC_FW; w++) LF(w) = K.live[(size_t)w * CD(stride) + e];
+    for (int w = 0; w < MRXC_FW; w++) LF(w) = K.live[CB_IX(CD(aos), CD(stride), CD(FW), w, e)];
     for (int w = 0; w < MRXC_S; w++) LF(LDS_CAP + w) = K.capacity[w];
     for (int w = 0; w < MRXC_w_words; w++) LF(LDS_FUL + w) = (int32_t)GFUL(w);
     for (int w = 0; w < 2 * MRXC_mask_words; w++) LF(LDS_DMK + w) = (int32_t)GDMK(w);
 #ifdef MRX_CB_TWC_LDS
-    for (int w = 0; w < MRXC_ring_slots; w++) { TWCF(w) = K.twc_fi[(size_t)w * CD(stride) + e]; TWCT(w) = K.twc_tick[(size_t)w * CD(stride) + e]; }
+    for (int w = 0; w < MRXC_ring_slots; w++) { TWCF(w) = K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)]; TWCT(w) = K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)]; }
 #endif
   }
   wave::sync();
@@ -932,9 +932,8 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
       const bool frame_end = (ra & 1) != 0;
       if (frame_end || (ra & 2)) {  // take_snapshot: np_backend.pyx:481-518 (frame_end: post_step :130-147; last tick: core.py:371-375)
         const int fi = (t - CD(start_tick)) / CD(res), slot = fi % CD(ring_slots);
-        int32_t* dst = K.ring + (size_t)slot * (CD(FW) + 1) * CD(stride) + e;
-        for (int w = lane; w < CD(FW); w += 64) dst[(size_t)w * CD(stride)] = LW(w);
-        if (lane == 0) { dst[(size_t)CD(FW) * CD(stride)] = t; K.ring_fi[(size_t)slot * CD(stride) + e] = fi; }
+        for (int w = lane; w < CD(FW); w += 64) RINGW(slot, w) = LW(w);
+        if (lane == 0) { RINGW(slot, CD(FW)) = t; K.ring_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] = fi; }
         wave::sync();  // every lane has read its words of the frame before the reset below rewrites them
       }
       if (frame_end) {
@@ -963,8 +962,8 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
                          [&](int slot, int* fi, int* tk) { *fi = LW(LDS_TWC + slot); *tk = LW(LDS_TWC + MRXC_ring_slots + slot); },
                          [&](int slot, int fi, int tk) { LW(LDS_TWC + slot) = fi; LW(LDS_TWC + MRXC_ring_slots + slot) = tk; });
 #else
-                         [&](int slot, int* fi, int* tk) { *fi = K.twc_fi[(size_t)slot * CD(stride) + e]; *tk = K.twc_tick[(size_t)slot * CD(stride) + e]; },
-                         [&](int slot, int fi, int tk) { K.twc_fi[(size_t)slot * CD(stride) + e] = fi; K.twc_tick[(size_t)slot * CD(stride) + e] = tk; });
+                         [&](int slot, int* fi, int* tk) { *fi = K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)]; *tk = K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)]; },
+                         [&](int slot, int fi, int tk) { K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] = fi; K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] = tk; });
 #endif
       } else {
         Prof P;
@@ -981,11 +980,11 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
 #ifndef __HIPCC__
     if (lane == 0) {
       for (int w = 0; w < CH_WORDS; w++) GHDR(w) = HDR(w);
-      for (int w = 0; w < MRXC_FW; w++) K.live[(size_t)w * CD(stride) + e] = LF(w);
+      for (int w = 0; w < MRXC_FW; w++) K.live[CB_IX(CD(aos), CD(stride), CD(FW), w, e)] = LF(w);
       for (int w = 0; w < MRXC_w_words; w++) GFUL(w) = (uint32_t)LF(LDS_FUL + w);
       for (int w = 0; w < 2 * MRXC_mask_words; w++) GDMK(w) = (uint32_t)LF(LDS_DMK + w);
 #ifdef MRX_CB_TWC_LDS
-      for (int w = 0; w < MRXC_ring_slots; w++) { K.twc_fi[(size_t)w * CD(stride) + e] = TWCF(w); K.twc_tick[(size_t)w * CD(stride) + e] = TWCT(w); }
+      for (int w = 0; w < MRXC_ring_slots; w++) { K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)] = TWCF(w); K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)] = TWCT(w); }
 #endif
     }
     wave::sync();
@@ -1009,9 +1008,9 @@ MRX_DEV void reset_env(const CbParams& K, int e) {
   GHDR(CH_TICK) = CD(start_tick);
   GHDR(CH_FLAGS) = CFL_FRESH;
   GHDR(CH_POOL_MINLAND) = CB_NO_LAND;
-  for (int w = 0; w < CD(FW); w++) K.live[(size_t)w * CD(stride) + e] = 0;
+  for (int w = 0; w < CD(FW); w++) K.live[CB_IX(CD(aos), CD(stride), CD(FW), w, e)] = 0;
   for (int s = 0; s < CD(S); s++) { GST(LV_BIKES, s) = K.init_bikes[s]; GST(LV_MIN_BIKES, s) = K.init_bikes[s]; }
-  for (int i = 0; i < CD(ring_slots); i++) { K.ring_fi[(size_t)i * CD(stride) + e] = -1; K.twc_fi[(size_t)i * CD(stride) + e] = -1; K.twc_tick[(size_t)i * CD(stride) + e] = 0; }
+  for (int i = 0; i < CD(ring_slots); i++) { K.ring_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), i, e)] = -1; K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), i, e)] = -1; K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), i, e)] = 0; }
   for (int w = 0; w < 2 * CD(mask_words); w++) GDMK(w) = 0;
   for (int w = 0; w < CD(w_words); w++) GFUL(w) = 0;
 }
@@ -1036,13 +1035,13 @@ MRX_DEV double query_elem(const CbParams& K, int node_type, const int32_t* ticks
   const bool paused = (flags & CFL_PENDING) != 0;
   const int t_cur = GHDR(CH_TICK);
   const int cur_fi = (t_cur - CD(start_tick)) / CD(res);
-  const int32_t* frame;
+  int from_ring;  // which frame holds fi: the live one (0) or ring slot `slot` (1)
   int t_frame;
-  if (paused && fi == cur_fi) { frame = K.live + e; t_frame = t_cur; }
+  if (paused && fi == cur_fi) { from_ring = 0; t_frame = t_cur; }
   else if (paused && slot == cur_fi % CD(ring_slots)) return 0.0;
-  else if (K.ring_fi[(size_t)slot * CD(stride) + e] == fi) {
-    frame = K.ring + (size_t)slot * (CD(FW) + 1) * CD(stride) + e;
-    t_frame = frame[(size_t)CD(FW) * CD(stride)];
+  else if (K.ring_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] == fi) {
+    from_ring = 1;
+    t_frame = RINGW(slot, CD(FW));
   } else return 0.0;  // padding for missing frames, np_backend.pyx:541-545
   int a = 0, sl = col;
   for (int i = 0; i < na; i++) {
@@ -1078,7 +1077,8 @@ MRX_DEV double query_elem(const CbParams& K, int node_type, const int32_t* ticks
     case SA_ID: return (double)K.station_id[node];
     default: return (double)K.cal[(size_t)K.tick_day[t_frame - CD(start_tick)] * 4 + (a - SA_WEEKDAY)];
   }
-  return (double)frame[((size_t)lv * CD(S) + node) * CD(stride)];
+  const size_t fw = (size_t)lv * CD(S) + node;
+  return (double)(from_ring ? RINGW(slot, fw) : LIVE(fw));
 }
 
 MRX_DEV uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
@@ -1109,6 +1109,7 @@ MRX_DEV int random_policy_env(const CbParams& K, int e, const int32_t* dec, cons
 
 #undef HDR
 #undef GHDR
+#undef RINGW
 #undef ST
 #undef POOL
 #undef SCR

@@ -47,6 +47,16 @@ mrx_k_cb_query_tiled(CbParams K, int node_type, const int32_t* __restrict__ tick
   }
 }
 
+// env-major layout (CbParams::aos): thread i computes result element i
+extern "C" __global__ void __launch_bounds__(256)
+mrx_k_cb_query_rows(CbParams K, int node_type, const int32_t* __restrict__ ticks, int nt, int ticks_per_env, const int32_t* __restrict__ nodes,
+                    int nn, int nodes_per_env, CbAttrList al, int row_slots, long long total, double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long row = i / row_slots;
+  out[i] = cb::query_elem(K, node_type, ticks, nt, ticks_per_env, nodes, nn, nodes_per_env, al.id, al.n, row, (int)(i - row * row_slots));
+}
+
 int mrx_set_error_(int code, const std::string& m);  // cim_engine.hip (thread-local message behind mrx_last_error)
 
 // ------------------------------------------------------------------------------------------ kernels
@@ -405,7 +415,11 @@ int mrx_cb_query(mrx_cb_handle h, int node_type, const int32_t* d_ticks, int nt,
   al.n = na;
   for (int i = 0; i < 16; i++) al.id[i] = i < na ? attrs[i] : 0;
   const long long width = (long long)nn * row_slots;
-  if (node_type == 0 && width >= 64 && nt <= 65535 && (width + 31) / 32 <= 65535) {
+  if (K.aos) {
+    // env-major state: an env's rows are contiguous, and so is its result row — consecutive threads take consecutive result elements
+    hipLaunchKernelGGL(mrx_k_cb_query_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K, node_type, d_ticks, nt,
+                       ticks_per_env, d_nodes, nn, nodes_per_env, al, row_slots, total, d_out);
+  } else if (node_type == 0 && width >= 64 && nt <= 65535 && (width + 31) / 32 <= 65535) {
     hipLaunchKernelGGL(mrx_k_cb_query_tiled, dim3((unsigned)((K.n_envs + 63) / 64), (unsigned)nt, (unsigned)((width + 31) / 32)), dim3(256), 0, (hipStream_t)stream, K,
                        node_type, d_ticks, nt, ticks_per_env, d_nodes, nn, nodes_per_env, al, row_slots, d_out);
   } else {

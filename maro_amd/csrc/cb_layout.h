@@ -3,6 +3,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -65,6 +66,9 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
   k.decision_mode = c->decision_mode;
   k.n_envs = c->n_envs;
   k.stride = (int)align_up(c->n_envs, 64);
+  // per-env state env-major for the plans that run one env per WAVE (cb_params.h CB_IX); MRX_CB_AOS = 0 / 1 forces it (tests)
+  k.aos = (c->decision_mode == 0 && c->start_tick % c->snapshot_resolution == 0 && S >= 96 && (S + 31) / 32 <= 64) ? 1 : 0;
+  if (const char* ev = getenv("MRX_CB_AOS")) k.aos = atoi(ev) ? 1 : 0;
   k.S = S; k.start_tick = c->start_tick; k.max_tick = max_tick; k.res = c->snapshot_resolution;
   const int total_frames = (c->durations + c->snapshot_resolution - 1) / c->snapshot_resolution;
   k.ring_slots = c->max_snapshots > 0 ? c->max_snapshots : total_frames;
@@ -228,7 +232,7 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
   L.off_prof = env_arr(&CbParams::prof, 16);
   env_arr(&CbParams::todo, 1);   // (one byte per env is used: written by the wave-cooperative decision kernel, read as the general kernel's mask)
   pl->workspace_bytes = align_up(top, 256);
-  L.n_envs = k.n_envs; L.env_stride = k.stride; L.n_stations = S; L.frame_words = k.FW; L.ring_slots = k.ring_slots;
+  L.n_envs = k.n_envs; L.env_stride = k.stride; L.env_major = k.aos; L.n_stations = S; L.frame_words = k.FW; L.ring_slots = k.ring_slots;
   L.scope_cap = k.scope_cap; L.delivery_capacity = k.pool_cap; L.transfer_times_cap = k.tt_cap;
   L.workspace_bytes = pl->workspace_bytes;
   return MRX_OK;

@@ -23,9 +23,18 @@ enum { CB_POOL_WORDS = 5 };  // land tick, scheduling tick, from, to, number (<0
 #define MRX_CB_LDS_BYTES 65536   /* LDS one workgroup (= one wave) of the step kernel may take */
 enum { CB_EV_RET, CB_EV_TRIP, CB_EV_REBAL, CB_EV_RETZ, CB_EV_TICK_END };  // kinds of CbParams::ev_rec records
 
+// Word w of env e in a per-env array of W words.  Two layouts (CbParams::aos, fixed at creation):
+//   0  struct-of-arrays [word][env stride]: the general kernels own one env per LANE — whenever the lanes of a wave agree on the
+//      word (every env replays the same trip table) an access is one contiguous run over the envs;
+//   1  env-major [env][W]: the wave-cooperative kernels own one env per WAVE — the env's rows are contiguous, so moving its state
+//      HBM <-> LDS, its snapshots and its snapshot queries are coalesced (with [word][env] every word of one env sits in its
+//      own 64-byte sector: measured 1.3 MB of traffic to move 40 KB of state).  Chosen for plans that run the wave-cooperative
+//      path (cb_layout.h: Sequential mode, aligned frames, >= 96 stations).
+#define CB_IX(aos, stride, W, w, e) ((aos) ? (size_t)(e) * (size_t)(W) + (size_t)(w) : (size_t)(w) * (size_t)(stride) + (size_t)(e))
+
 struct CbParams {
   // ---- dimensions / options
-  int32_t n_envs, stride, S, start_tick, max_tick, res, ring_slots, max_actions;
+  int32_t n_envs, stride, aos, S, start_tick, max_tick, res, ring_slots, max_actions;
   int32_t dres, extra_cost_mode, n_filters, f_type[4], f_num[4], f_win[4];
   int32_t decision_mode;  // 0 Sequential, 1 Joint, 2 JointWithSequentialAction (core.py:349-366)
   int32_t FW, w_mask, w_words, pool_cap, tt_cap, scope_cap, mask_words, nb_stride;
@@ -60,6 +69,7 @@ struct CbParams {
 // (cb_spec.hip) receives as MRXC_<field> macros (CD() in cb_device.h); the filter arrays become MRXC_f_type(i) etc.
 #define MRX_CB_DIM_FIELDS(X) \
   X(stride) \
+  X(aos) \
   X(S) \
   X(start_tick) \
   X(max_tick) \

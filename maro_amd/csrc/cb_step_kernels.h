@@ -5,7 +5,7 @@ mrx_k_cb_reset(CbParams K, const int32_t* __restrict__ tt, int n_times, const ui
   const int e = blockIdx.x * 64 + threadIdx.x;
   if (e >= K.n_envs || (mask && !mask[e])) return;
   if (tt)
-    for (int i = 0; i < CD(tt_cap); i++) K.tt[(size_t)i * CD(stride) + e] = i < n_times ? tt[(size_t)e * n_times + i] : 1;
+    for (int i = 0; i < CD(tt_cap); i++) K.tt[CB_IX(CD(aos), CD(stride), CD(tt_cap), i, e)] = i < n_times ? tt[(size_t)e * n_times + i] : 1;
   cb::reset_env(K, e);
 }
 
@@ -28,17 +28,17 @@ mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __
 #define MRX_CB_LFX(w) cb::mrx_cb_lds[((CB_EV_BLOCK * 4 + (w)) << K.lsh) + cl]
   if (cok) {
 #pragma unroll 4
-    for (int w = r0; w < MRXC_FW; w += rstep) MRX_CB_LFX(w) = K.live[(size_t)w * CD(stride) + cbase];
+    for (int w = r0; w < MRXC_FW; w += rstep) MRX_CB_LFX(w) = K.live[CB_IX(CD(aos), CD(stride), CD(FW), w, cbase)];
     for (int w = r0; w < MRXC_S; w += rstep) MRX_CB_LFX(LDS_CAP + w) = K.capacity[w];
-    for (int w = r0; w < CH_WORDS; w += rstep) MRX_CB_LFX(LDS_HDR + w) = K.hdr[(size_t)w * CD(stride) + cbase];
+    for (int w = r0; w < CH_WORDS; w += rstep) MRX_CB_LFX(LDS_HDR + w) = K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, w, cbase)];
 #ifdef MRX_CB_TWC_LDS
     for (int w = r0; w < MRXC_ring_slots; w += rstep) {
-      MRX_CB_LFX(LDS_TWC + w) = K.twc_fi[(size_t)w * CD(stride) + cbase];
-      MRX_CB_LFX(LDS_TWC + MRXC_ring_slots + w) = K.twc_tick[(size_t)w * CD(stride) + cbase];
+      MRX_CB_LFX(LDS_TWC + w) = K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, cbase)];
+      MRX_CB_LFX(LDS_TWC + MRXC_ring_slots + w) = K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, cbase)];
     }
 #endif
-    for (int w = r0; w < MRXC_w_words; w += rstep) MRX_CB_LFX(LDS_FUL + w) = (int32_t)K.fulfilled[(size_t)w * CD(stride) + cbase];
-    for (int w = r0; w < 2 * MRXC_mask_words; w += rstep) MRX_CB_LFX(LDS_DMK + w) = (int32_t)K.decmask[(size_t)w * CD(stride) + cbase];
+    for (int w = r0; w < MRXC_w_words; w += rstep) MRX_CB_LFX(LDS_FUL + w) = (int32_t)K.fulfilled[CB_IX(CD(aos), CD(stride), CD(w_words), w, cbase)];
+    for (int w = r0; w < 2 * MRXC_mask_words; w += rstep) MRX_CB_LFX(LDS_DMK + w) = (int32_t)K.decmask[CB_IX(CD(aos), CD(stride), (2 * CD(mask_words)), w, cbase)];
   }
   __syncthreads();
 #endif
@@ -60,16 +60,16 @@ mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __
   __syncthreads();
   if (cok) {
 #pragma unroll 4
-    for (int w = r0; w < MRXC_FW; w += rstep) K.live[(size_t)w * CD(stride) + cbase] = MRX_CB_LFX(w);
-    for (int w = r0; w < CH_WORDS; w += rstep) K.hdr[(size_t)w * CD(stride) + cbase] = MRX_CB_LFX(LDS_HDR + w);
+    for (int w = r0; w < MRXC_FW; w += rstep) K.live[CB_IX(CD(aos), CD(stride), CD(FW), w, cbase)] = MRX_CB_LFX(w);
+    for (int w = r0; w < CH_WORDS; w += rstep) K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, w, cbase)] = MRX_CB_LFX(LDS_HDR + w);
 #ifdef MRX_CB_TWC_LDS
     for (int w = r0; w < MRXC_ring_slots; w += rstep) {
-      K.twc_fi[(size_t)w * CD(stride) + cbase] = MRX_CB_LFX(LDS_TWC + w);
-      K.twc_tick[(size_t)w * CD(stride) + cbase] = MRX_CB_LFX(LDS_TWC + MRXC_ring_slots + w);
+      K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, cbase)] = MRX_CB_LFX(LDS_TWC + w);
+      K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, cbase)] = MRX_CB_LFX(LDS_TWC + MRXC_ring_slots + w);
     }
 #endif
-    for (int w = r0; w < MRXC_w_words; w += rstep) K.fulfilled[(size_t)w * CD(stride) + cbase] = (uint32_t)MRX_CB_LFX(LDS_FUL + w);
-    for (int w = r0; w < 2 * MRXC_mask_words; w += rstep) K.decmask[(size_t)w * CD(stride) + cbase] = (uint32_t)MRX_CB_LFX(LDS_DMK + w);
+    for (int w = r0; w < MRXC_w_words; w += rstep) K.fulfilled[CB_IX(CD(aos), CD(stride), CD(w_words), w, cbase)] = (uint32_t)MRX_CB_LFX(LDS_FUL + w);
+    for (int w = r0; w < 2 * MRXC_mask_words; w += rstep) K.decmask[CB_IX(CD(aos), CD(stride), (2 * CD(mask_words)), w, cbase)] = (uint32_t)MRX_CB_LFX(LDS_DMK + w);
   }
 #undef MRX_CB_LFX
 #endif
@@ -105,33 +105,33 @@ mrx_k_cb_replay_wave(CbParams K, const int32_t* __restrict__ actions, const int3
   const int e = (int)blockIdx.x, lane = (int)threadIdx.x;
   if (!todo[e]) return;
 #define MRX_CB_LW(w) cb::mrx_cb_lds[CB_EV_BLOCK * 4 + (w)]
-  for (int w = lane; w < MRXC_FW; w += 64) MRX_CB_LW(w) = K.live[(size_t)w * CD(stride) + e];
+  for (int w = lane; w < MRXC_FW; w += 64) MRX_CB_LW(w) = K.live[CB_IX(CD(aos), CD(stride), CD(FW), w, e)];
   for (int w = lane; w < MRXC_S; w += 64) MRX_CB_LW(LDS_CAP + w) = K.capacity[w];
-  for (int w = lane; w < CH_WORDS; w += 64) MRX_CB_LW(LDS_HDR + w) = K.hdr[(size_t)w * CD(stride) + e];
+  for (int w = lane; w < CH_WORDS; w += 64) MRX_CB_LW(LDS_HDR + w) = K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, w, e)];
 #ifdef MRX_CB_TWC_LDS
   for (int w = lane; w < MRXC_ring_slots; w += 64) {
-    MRX_CB_LW(LDS_TWC + w) = K.twc_fi[(size_t)w * CD(stride) + e];
-    MRX_CB_LW(LDS_TWC + MRXC_ring_slots + w) = K.twc_tick[(size_t)w * CD(stride) + e];
+    MRX_CB_LW(LDS_TWC + w) = K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)];
+    MRX_CB_LW(LDS_TWC + MRXC_ring_slots + w) = K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)];
   }
 #endif
-  for (int w = lane; w < MRXC_w_words; w += 64) MRX_CB_LW(LDS_FUL + w) = (int32_t)K.fulfilled[(size_t)w * CD(stride) + e];
-  for (int w = lane; w < 2 * MRXC_mask_words; w += 64) MRX_CB_LW(LDS_DMK + w) = (int32_t)K.decmask[(size_t)w * CD(stride) + e];
+  for (int w = lane; w < MRXC_w_words; w += 64) MRX_CB_LW(LDS_FUL + w) = (int32_t)K.fulfilled[CB_IX(CD(aos), CD(stride), CD(w_words), w, e)];
+  for (int w = lane; w < 2 * MRXC_mask_words; w += 64) MRX_CB_LW(LDS_DMK + w) = (int32_t)K.decmask[CB_IX(CD(aos), CD(stride), (2 * CD(mask_words)), w, e)];
   __syncthreads();
   int na = (actions && n_actions) ? n_actions[e] : 0;
   if (na > CD(max_actions)) na = CD(max_actions);
   cb::step_env_wave(K, e, actions ? actions + (size_t)e * CD(max_actions) * 3 : nullptr, na, decisions + (size_t)e * 8, scope + (size_t)e * CD(scope_cap) * 2,
                     (int64_t*)metrics + (size_t)e * 3, done + e, scr);
   __syncthreads();
-  for (int w = lane; w < MRXC_FW; w += 64) K.live[(size_t)w * CD(stride) + e] = MRX_CB_LW(w);
-  for (int w = lane; w < CH_WORDS; w += 64) K.hdr[(size_t)w * CD(stride) + e] = MRX_CB_LW(LDS_HDR + w);
+  for (int w = lane; w < MRXC_FW; w += 64) K.live[CB_IX(CD(aos), CD(stride), CD(FW), w, e)] = MRX_CB_LW(w);
+  for (int w = lane; w < CH_WORDS; w += 64) K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, w, e)] = MRX_CB_LW(LDS_HDR + w);
 #ifdef MRX_CB_TWC_LDS
   for (int w = lane; w < MRXC_ring_slots; w += 64) {
-    K.twc_fi[(size_t)w * CD(stride) + e] = MRX_CB_LW(LDS_TWC + w);
-    K.twc_tick[(size_t)w * CD(stride) + e] = MRX_CB_LW(LDS_TWC + MRXC_ring_slots + w);
+    K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)] = MRX_CB_LW(LDS_TWC + w);
+    K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)] = MRX_CB_LW(LDS_TWC + MRXC_ring_slots + w);
   }
 #endif
-  for (int w = lane; w < MRXC_w_words; w += 64) K.fulfilled[(size_t)w * CD(stride) + e] = (uint32_t)MRX_CB_LW(LDS_FUL + w);
-  for (int w = lane; w < 2 * MRXC_mask_words; w += 64) K.decmask[(size_t)w * CD(stride) + e] = (uint32_t)MRX_CB_LW(LDS_DMK + w);
+  for (int w = lane; w < MRXC_w_words; w += 64) K.fulfilled[CB_IX(CD(aos), CD(stride), CD(w_words), w, e)] = (uint32_t)MRX_CB_LW(LDS_FUL + w);
+  for (int w = lane; w < 2 * MRXC_mask_words; w += 64) K.decmask[CB_IX(CD(aos), CD(stride), (2 * CD(mask_words)), w, e)] = (uint32_t)MRX_CB_LW(LDS_DMK + w);
 #undef MRX_CB_LW
 }
 #endif

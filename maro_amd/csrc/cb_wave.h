@@ -24,10 +24,10 @@
 
 namespace cb {
 
-#define W_HDR(w) K.hdr[(size_t)(w) * CD(stride) + e]
-#define W_ST(a, s) K.live[((size_t)(a) * CD(S) + (size_t)(s)) * CD(stride) + e]
-#define W_DMK(i) K.decmask[(size_t)(i) * CD(stride) + e]
-#define W_POOL(i, w) K.pool[((size_t)(i) * CB_POOL_WORDS + (w)) * CD(stride) + e]
+#define W_HDR(w) K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, (w), e)]
+#define W_ST(a, s) K.live[CB_IX(CD(aos), CD(stride), CD(FW), ((size_t)(a) * CD(S) + (size_t)(s)), e)]
+#define W_DMK(i) K.decmask[CB_IX(CD(aos), CD(stride), (2 * CD(mask_words)), (i), e)]
+#define W_POOL(i, w) K.pool[CB_IX(CD(aos), CD(stride), (CD(pool_cap) * CB_POOL_WORDS), ((size_t)(i) * CB_POOL_WORDS + (w)), e)]
 
 // Env.step of env `e` when the step stays inside its tick.  Returns true when the env was handled (outputs written); false:
 // nothing was touched, the general path must run.
@@ -72,7 +72,7 @@ MRX_DEV bool decision_step_wave(const CbParams& K, int e, const int32_t* actions
             if (b - ex < W_ST(LV_MIN_BIKES, frm)) W_ST(LV_MIN_BIKES, frm) = b - ex;
           }
           int tt = 1;
-          if (tt_pos < CD(tt_cap)) tt = K.tt[(size_t)tt_pos * CD(stride) + e];
+          if (tt_pos < CD(tt_cap)) tt = K.tt[CB_IX(CD(aos), CD(stride), CD(tt_cap), tt_pos, e)];
           else status |= MRX_CB_ENV_TRANSFER_TIMES_OUT;
           tt_pos++;
           if (!(tt < 0 || t + tt >= CD(max_tick))) {  // (a delivery into the past / after the episode never runs)
@@ -105,8 +105,8 @@ MRX_DEV bool decision_step_wave(const CbParams& K, int e, const int32_t* actions
   // from `patch_s` come out of registers (lane 0's store above is not ordered against other lanes' loads)
   const int n_rows = scope_wave(K, s1, type, t, scr, out,
                                 [&](int st) { return st == patch_s ? patch_b : W_ST(LV_BIKES, st); },
-                                [&](int slot, int* fi, int* tk) { *fi = K.twc_fi[(size_t)slot * CD(stride) + e]; *tk = K.twc_tick[(size_t)slot * CD(stride) + e]; },
-                                [&](int slot, int fi, int tk) { K.twc_fi[(size_t)slot * CD(stride) + e] = fi; K.twc_tick[(size_t)slot * CD(stride) + e] = tk; });
+                                [&](int slot, int* fi, int* tk) { *fi = K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)]; *tk = K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)]; },
+                                [&](int slot, int fi, int tk) { K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] = fi; K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] = tk; });
   const int m0 = wave::bcast(h, CH_TRIPS), m1 = wave::bcast(h, CH_SHORT), m2 = wave::bcast(h, CH_OPER);
   if (lane == 0) {
     dec[0] = t; dec[1] = s1; dec[2] = type; dec[3] = fi_cur; dec[4] = n_rows; dec[5] = 1; dec[6] = 0; dec[7] = 0;

@@ -49,7 +49,7 @@ void cb_emu_reset(void* h, const int32_t* tt, int n_times, const uint8_t* mask) 
   const CbParams& K = e->plan.kp;
   for (int env = 0; env < K.n_envs; env++) {
     if (mask && !mask[env]) continue;
-    if (tt) for (int i = 0; i < K.tt_cap; i++) K.tt[(size_t)i * K.stride + env] = i < n_times ? tt[(size_t)env * n_times + i] : 1;
+    if (tt) for (int i = 0; i < K.tt_cap; i++) K.tt[CB_IX(CD(aos), CD(stride), CD(tt_cap), i, env)] = i < n_times ? tt[(size_t)env * n_times + i] : 1;
     cb::reset_env(K, env);
   }
 }

@@ -136,6 +136,8 @@ class CbEmuBackend:
     def view(self, off, words):
         """int32 [words, n_envs] view of a per-env SoA array."""
         st = self.layout.env_stride
+        if self.layout.env_major:   # [env][words] in memory: the same [word, env] indexing through a transpose
+            return self.ws[off:off + words * st * 4].view(np.int32).reshape(st, words)[:self.n_envs].T
         return self.ws[off:off + words * st * 4].view(np.int32).reshape(words, st)[:, :self.n_envs]
 
     def reset(self, transfer_times=None, mask=None):

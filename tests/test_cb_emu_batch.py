@@ -89,3 +89,15 @@ def test_batch_matches_oracle_with_wave_form_general_step(topology, kwargs, n, b
         assert run_batch_vs_oracle(b, data, kwargs, seeds=np.arange(n) + 9, episodes=2) > 20
     handled, general = b.wave_counts()
     assert handled > 0 and general > 0
+
+
+@pytest.mark.parametrize("specialized,wave", [(False, 0), (False, 1), (True, 2)])
+def test_env_major_layout_on_a_small_topology(monkeypatch, specialized, wave):
+    """CbParams::aos (per-env state [env][words] instead of [word][env]) is chosen from 96 stations on; forced here on a toy so
+    that every kernel form meets it on the CPU: general step, wave-cooperative decision step, wave-form general step."""
+    monkeypatch.setenv("MRX_CB_AOS", "1")
+    data = load_topology("toy.5s_filters")
+    kwargs = dict(durations=600, snapshot_resolution=10, max_snapshots=7)
+    b = CbEmuBackend(data, n_envs=5, max_actions=1, specialized=specialized, wave_decisions=wave, **kwargs)
+    assert b.layout.env_major == 1
+    assert run_batch_vs_oracle(b, data, kwargs, seeds=np.arange(5) + 21, episodes=2) > 20
