@@ -225,6 +225,7 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
   env_arr(&CbParams::twc_fi, k.ring_slots);
   env_arr(&CbParams::twc_tick, k.ring_slots);
   env_arr(&CbParams::pool, (int64_t)k.pool_cap * CB_POOL_WORDS);
+  env_arr(&CbParams::bkt, 2 * CB_LAND_SLOTS + CB_LAND_SLOTS / 32);
   L.off_transfer_times = env_arr(&CbParams::tt, k.tt_cap);
   env_arr(&CbParams::scratch, 3 * (int64_t)S);
   env_arr(&CbParams::fulfilled, k.w_words);

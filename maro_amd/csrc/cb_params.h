@@ -15,7 +15,8 @@ enum { LV_BIKES, LV_SHORTAGE, LV_TRIP_REQUIREMENT, LV_FULFILLMENT, LV_EXTRA_COST
 enum { CH_TICK, CH_FLAGS, CH_CUR_STATION, CH_CUR_TYPE, CH_TT_POS, CH_TRIPS, CH_SHORT, CH_OPER, CH_POOL_HEAD, CH_POOL_TAIL,
        CH_POOL_MINLAND, CH_LATE, CH_NDEC, CH_STATUS, CH_EV_POS, CH_RES1, CH_WORDS };  // CH_EV_POS: cursor into ev_rec
 enum { CFL_FRESH = 1, CFL_FINISHED = 2, CFL_PENDING = 4 };
-enum { CB_POOL_WORDS = 5 };  // land tick, scheduling tick, from, to, number (<0: executed)
+enum { CB_POOL_WORDS = 6 };  // land tick, scheduling tick, from, to, number (<0: executed), next entry landing at the same tick (-1: last)
+#define CB_LAND_SLOTS 128  /* landing-tick buckets of the delivery pool (power of two): a transfer may take at most 127 ticks */
 #define CB_NO_LAND 0x7fffffff
 #define CB_TWC_LDS 32            /* the trip-window filter's per-slot words ride in the LDS column when the ring has at most this many slots */
 #define CB_TWC_REG 12            /* trip-window frames whose table rows are kept in registers (cb_device.h::action_scope) */
@@ -50,6 +51,7 @@ struct CbParams {
   int32_t* twc_fi;    // [ring_slots] TripsWindowFilter cache: the frame a slot was read for ...
   int32_t* twc_tick;  // [ring_slots] ... and the tick it was last read at (the values come from req_cum)
   int32_t* pool;      // [pool_cap][CB_POOL_WORDS]  in-flight DeliverBike events, insertion order
+  int32_t* bkt;       // [2 * CB_LAND_SLOTS + CB_LAND_SLOTS / 32] first / last pool entry per landing-tick slot, occupancy mask
   int32_t* tt;        // [tt_cap] transfer times
   int32_t* scratch;   // [3 * S] action-scope work arrays
   uint32_t* fulfilled;  // [w_words]  bit ring over trip index: RequireBike got a bike

@@ -27,6 +27,7 @@ namespace cb {
 #define W_HDR(w) K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, (w), e)]
 #define W_ST(a, s) K.live[CB_IX(CD(aos), CD(stride), CD(FW), ((size_t)(a) * CD(S) + (size_t)(s)), e)]
 #define W_DMK(i) K.decmask[CB_IX(CD(aos), CD(stride), (2 * CD(mask_words)), (i), e)]
+#define W_BKT(i) K.bkt[CB_IX(CD(aos), CD(stride), (2 * CB_LAND_SLOTS + CB_LAND_SLOTS / 32), (i), e)]
 #define W_POOL(i, w) K.pool[CB_IX(CD(aos), CD(stride), (CD(pool_cap) * CB_POOL_WORDS), ((size_t)(i) * CB_POOL_WORDS + (w)), e)]
 
 // Env.step of env `e` when the step stays inside its tick.  Returns true when the env was handled (outputs written); false:
@@ -77,11 +78,18 @@ MRX_DEV bool decision_step_wave(const CbParams& K, int e, const int32_t* actions
           tt_pos++;
           if (!(tt < 0 || t + tt >= CD(max_tick))) {  // (a delivery into the past / after the episode never runs)
             if (tt == 0) late++;   // (another decision follows in the tick's list: the list tail is not stale, event_linked_list.py:86-108)
-            if (tail - head >= CD(pool_cap)) {
+            if (tail - head >= CD(pool_cap) || tt >= CB_LAND_SLOTS) {
               status |= MRX_CB_ENV_DELIVERY_OVERFLOW;
             } else {
               const int idx = tail % CD(pool_cap);
-              if (lane == 0) { W_POOL(idx, 0) = t + tt; W_POOL(idx, 1) = t; W_POOL(idx, 2) = frm; W_POOL(idx, 3) = to; W_POOL(idx, 4) = ex; }
+              if (lane == 0) {  // pool_push: append, and link behind the last entry landing at the same tick
+                W_POOL(idx, 0) = t + tt; W_POOL(idx, 1) = t; W_POOL(idx, 2) = frm; W_POOL(idx, 3) = to; W_POOL(idx, 4) = ex; W_POOL(idx, 5) = -1;
+                const int slot = (t + tt) & (CB_LAND_SLOTS - 1);
+                const int last = W_BKT(CB_LAND_SLOTS + slot);
+                if (last >= 0) W_POOL(last, 5) = idx;
+                else { W_BKT(slot) = idx; W_BKT(2 * CB_LAND_SLOTS + (slot >> 5)) |= (int32_t)(1u << (slot & 31)); }
+                W_BKT(CB_LAND_SLOTS + slot) = idx;
+              }
               tail++;
               if (t + tt < minland) minland = t + tt;
             }
@@ -120,5 +128,6 @@ MRX_DEV bool decision_step_wave(const CbParams& K, int e, const int32_t* actions
 #undef W_ST
 #undef W_DMK
 #undef W_POOL
+#undef W_BKT
 
 }  // namespace cb
