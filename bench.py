@@ -175,7 +175,13 @@ def bench_citi_bike(args):
     counter = torch.zeros((1,), dtype=torch.int64, device=dev)
     stations = torch.arange(S, dtype=torch.int32, device=dev)
     q_attrs = ["bikes", "shortage", "trip_requirement", "fulfillment", "capacity", "extra_cost", "min_bikes"]
-    q_out = None if args.no_query else torch.empty((n, 1, S, len(q_attrs)), dtype=torch.float64, device=dev)
+    # the per-step observation: on the toys every station; on city-sized topologies the stations of the decision's ACTION SCOPE (the
+    # deciding station + its filtered neighbours: what an agent can act on, 21 rows with the ny filter chain) — all 800 stations x
+    # 7 attributes per env and step would be 45 KB of float64 per env-step, several times the simulation's own traffic
+    scope_obs = S > 64
+    cap = eng.layout.scope_cap
+    q_nodes = torch.empty((n, cap), dtype=torch.int32, device=dev) if scope_obs else None
+    q_out = None if args.no_query else torch.empty((n, 1, cap if scope_obs else S, len(q_attrs)), dtype=torch.float64, device=dev)
 
     def one_step(i):
         if i == 0:
@@ -184,7 +190,11 @@ def bench_citi_bike(args):
         eng.random_policy(i, actions, n_actions, counter)
         eng.step(actions, n_actions)
         if q_out is not None:
-            eng.query("stations", eng.decisions[:, 3:4], stations, q_attrs, out=q_out)
+            if scope_obs:
+                q_nodes.copy_(eng.scope[:, :, 0])      # per-env node lists; -1 padding reads as zeros (query semantics)
+                eng.query("stations", eng.decisions[:, 3:4], q_nodes, q_attrs, out=q_out)
+            else:
+                eng.query("stations", eng.decisions[:, 3:4], stations, q_attrs, out=q_out)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -279,7 +289,7 @@ def bench_citi_bike(args):
             with open(os.path.join(REPO, "profiles", "latest_pmc_citi_bike.json")) as fp:
                 pmc = json.load(fp)
             for ent in pmc["entries"]:
-                if ent["topology"] == topology and ent["envs_per_launch"] == n and not args.step_budget:
+                if ent["topology"] == topology and ent["envs_per_launch"] == n and ent.get("step_budget", 0) == args.step_budget:
                     traffic = (2 * ent["fetch_size_kib"] + ent["write_size_kib"]) * 1024
                     achieved = traffic / (step_kernel_ms * 1e-3) / 1e9
                     basis = "measured HBM bytes (PMC: 2 x FETCH_SIZE + WRITE_SIZE per launch, " + pmc["source"] + ") / mean launch duration"
@@ -291,8 +301,9 @@ def bench_citi_bike(args):
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": f"citi_bike {topology}, {n} envs/GPU x {world} GPU, durations {durations}, resolution {res}, "
-                                   f"device policy, stations snapshot slice {'off' if args.no_query else 'every step'}",
-                       "envs_per_gpu": n, "specialized_kernels": bool(eng.specialized), "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective)",
+                                   f"device policy, stations snapshot slice {'off' if args.no_query else ('every step (stations of the action scope x 7 attrs)' if scope_obs else 'every step (all stations x 7 attrs)')}",
+                       "envs_per_gpu": n, "specialized_kernels": bool(eng.specialized), "wave_cooperative_step": bool(eng.set_wave_decisions(0)),
+                       "env_major_state": bool(eng.layout.env_major), "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective)",
                        "trajectory_gather_ms_32_steps": gather_ms, "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
             "roofline": {"bound": "hbm", "kernel": "mrx_k_cb_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "basis": basis, "algorithmic_GBps": algorithmic, "kernel_ms": step_kernel_ms,
@@ -415,6 +426,70 @@ with VectorEnv(batch_num=n, scenario="cim", topology=sys.argv[2], durations=int(
     return res
 
 
+def bench_collect(args, engines, qnet, n, G, dev, rank, world, dist, reset_ms):
+    """SURVEY.md 8(d) config 5 as the reference runs it: `AbsEnvSampler.sample(num_steps)` with on-device inference — here
+    CimBatchSampler.sample_fused over every group's engine: per step ONE fused call for sampler state + per-port DQN + action
+    translation (mrx_cim_dqn_act), the transition cache updated by masked tensor ops (no host sync on the step path), then
+    mrx_cim_step; per call the delayed rewards, per-agent next states, emission and episode roll-over.  One "step" of this
+    bench = one interaction of every env of the rank (all groups)."""
+    import torch
+
+    from maro_amd.cim.sampler import CimBatchSampler
+    samplers = [CimBatchSampler(e) for e in engines]
+    seeds_of = [(lambda ep, g=g, e=e: ep * 1000003 + torch.arange(e.n_envs, dtype=torch.int64) + rank * n + g * 131071 + 1) for g, e in enumerate(engines)]
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def one_call(k):
+        nexp = 0
+        for g, smp in enumerate(samplers):
+            res = smp.sample_fused(qnet[g], num_steps=k, seeds=seeds_of[g], reset_every=args.reset_every)
+            nexp += int(res["tick"].shape[0])
+        return nexp
+
+    # untimed: into mid-episode (the first reward window must have passed for experiences to flow), then the warmup
+    pre = 0
+    while pre < max(args.preroll_ticks * 3, 256):
+        one_call(128)
+        pre += 128
+    one_call(max(args.warmup, 1))
+    vals, exps, dts = [], [], []
+    for _ in range(max(1, args.repeats)):
+        i0 = sum(int(s.interactions.item()) for s in samplers)
+        sync_all()
+        t0 = time.perf_counter()
+        nexp = one_call(args.steps)
+        sync_all()
+        dt = time.perf_counter() - t0
+        steps_done = sum(int(s.interactions.item()) for s in samplers) - i0
+        t = torch.tensor([dt, float(steps_done), float(nexp)], dtype=torch.float64, device=dev)
+        if dist is not None:
+            tm = t[:1].clone()
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t[0] = tm[0]
+        dts.append(float(t[0])); vals.append(float(t[1]) / float(t[0])); exps.append(float(t[2]) / float(t[0]))
+    if rank == 0:
+        med = sorted(range(len(vals)), key=lambda i: vals[i])[len(vals) // 2]
+        out = {"metric": "env-steps/sec while collecting experiences (CimBatchSampler.sample_fused), CIM global_trade.22p",
+               "value": vals[med], "unit": "env-steps/s", "experiences_per_s": exps[med], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dts[med] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32+f64 (env), f32 MFMA (policy)",
+               "data": "synthetic", "repeats": len(vals), "value_min": min(vals), "value_max": max(vals),
+               "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {engines[0].durations}, maro.rl EnvSampler loop batched on device: per-port "
+                                      f"dueling DQN (random-init, exact-f32 MFMA) + CIMEnvSampler state / reward shaping + transition cache + roll-over",
+                          "envs_per_gpu": n, "groups_per_gpu": G, "reset_every": args.reset_every, "specialized_kernels": bool(engines[0].specialized),
+                          "reset_ms_whole_batch": reset_ms, "look_back": samplers[0].look_back, "reward_window": samplers[0].time_window,
+                          "what_a_step_is": "one sample_fused interaction of every env: mrx_cim_dqn_act (2 launches) + cache update (masked tensor ops) + mrx_cim_step"}}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scenario", default="cim", choices=["cim", "citi_bike"])
@@ -425,6 +500,10 @@ def main():
     ap.add_argument("--policy", default="random", choices=["random", "dqn"],
                     help="random: the device random legal agent (headline); dqn: CIMEnvSampler state + 22 per-port dueling DQNs "
                          "+ action translation, all on the device (SURVEY.md 8d config 5; use --ring 8 or more)")
+    ap.add_argument("--collect", action="store_true", help="with --policy dqn: time the EXPERIENCE-COLLECTING loop (CimBatchSampler.sample_fused: "
+                    "maro.rl's AbsEnvSampler.sample batched — transition cache, per-agent next states, delayed rewards, episode roll-over) "
+                    "instead of the bare act -> step loop; reports experiences/s next to env-steps/s")
+    ap.add_argument("--reset-every", type=int, default=32, help="--collect: envs whose episode ended are finalised / reset every this many steps")
     ap.add_argument("--obs", default="fused", choices=["fused", "query"],
                     help="how the per-step ports / deciding-vessel snapshot slices are produced: fused into the step kernel, or by mrx_cim_query")
     ap.add_argument("--graphs", type=int, default=0, help="1: capture one step per group in a hipGraph and replay it (cim)")
@@ -501,6 +580,10 @@ def main():
 
     reset_ms = reset_all()
     graphs = [None] * G
+    if args.collect:
+        if qnet is None:
+            raise SystemExit("--collect needs --policy dqn")
+        return bench_collect(args, engines, qnet, n, G, dev, rank, world, dist, reset_ms)
 
     def one_step(i, g, timing=None, count=True):
         eng, b, st = engines[g], bufs[g], streams[g]

@@ -78,7 +78,9 @@ class CimBatchSampler:
         self._count = torch.zeros(n, dtype=torch.int64, device=dev)
         self._last = torch.full((n, eng.layout.n_ports), -1, dtype=torch.int64, device=dev)   # _agent_last_index
         self._eoe = torch.ones(n, dtype=torch.bool, device=dev)                               # _end_of_episode
-        self._episodes = 0
+        self._episodes = 0                                   # reset_envs calls so far (diagnostics)
+        self.interactions = torch.zeros((), dtype=torch.int64, device=dev)
+        self._ep_env = torch.zeros(n, dtype=torch.int64, device='cpu')   # episodes each env has started: what its seed depends on
         self._cur_state = torch.zeros((n, self.state_dim), dtype=state_dtype, device=dev)
         # per-attribute retention: the whole episode of (fulfillment, shortage) per port, written by the step kernel at every
         # snapshot — the delayed reward reads up to time_window ticks ahead of decisions that may be an episode old
@@ -144,8 +146,8 @@ class CimBatchSampler:
 
         `policy(states [n, state_dim], decisions [n, 8]) -> model actions int64 [n]` (indices into the example's action
         space; rows of envs without a pending decision are ignored).  Every env performs `num_steps` interactions (None:
-        until the end of ITS episode); an env whose episode ends inside the call is reset (`seeds(episode_index) -> int64
-        [n]` explicit seeds, or the reference's seed re-draw) and goes on, exactly like the reference loop.  Transitions
+        until the end of ITS episode); an env whose episode ends inside the call is reset (`seeds(episode_index int64 [n]) -> int64
+        [n]`: explicit seeds from every env's OWN episode count, or the reference's seed re-draw) and goes on, exactly like the reference loop.  Transitions
         are emitted once they are `reward_eval_delay` (= time_window) ticks old — the delayed reward is evaluated after
         the loop on the per-attribute retention rows (mrx_cim_set_port_history), so the snapshot ring can stay a few
         frames deep (look_back) — and younger ones stay in the per-env cache for the next call, with the per-agent next
@@ -168,8 +170,11 @@ class CimBatchSampler:
         steps_to_go = num_steps
 
         def reset_envs(mask: torch.Tensor) -> None:   # AbsEnvSampler._reset for the envs in `mask`
-            cmd = seeds(self._episodes).to(torch.int64) if seeds is not None else torch.full((n,), SEED_REDRAW, dtype=torch.int64)
+            # `seeds` sees every env's OWN episode index (the reference runs one sampler loop per env: episode k of an env gets
+            # seed k of that env, whatever the rest of the batch is doing); only the masked envs' entries are used
+            cmd = seeds(self._ep_env.clone()).to(torch.int64) if seeds is not None else torch.full((n,), SEED_REDRAW, dtype=torch.int64)
             self._episodes += 1
+            self._ep_env += mask.cpu().to(torch.int64)
             eng.reset(cmd, mask.to(torch.uint8))
             rows = torch.nonzero(mask).view(-1)
             self._hist[rows] = 0
@@ -231,3 +236,125 @@ class CimBatchSampler:
             res["reward"] = torch.zeros(0, dtype=torch.float32, device=dev)
         res["env_metric"] = eng.metrics.clone()
         return res
+
+    def sample_fused(self, actor, num_steps: Optional[int], seeds: Optional[Callable[[int], torch.Tensor]] = None, reset_every: int = 1,
+                     state_dtype: torch.dtype = torch.float32) -> Dict[str, torch.Tensor]:
+        """``sample(num_steps)`` with the per-step work fused and the step path free of host synchronisation — the loop
+        ``bench.py --policy dqn --collect`` times (maro.rl's EnvSampler with on-device inference).
+
+        `actor.act(actions, n_actions, decisions=, state=, choice=)` answers every pending decision in ONE call: it writes the
+        env actions `step` reads, the sampler state of each deciding env into `state` [n, state_dim] and the model action
+        into `choice` int32 [n] — ``FusedPerPortDQN`` (mrx_cim_dqn_act: state gather + per-port DQN + translation, two
+        launches) instead of three snapshot queries, a policy call and the translation.  The transition cache is updated with
+        masked full-batch tensor ops (no ``nonzero`` / ``bool()`` / ``int()`` per step); the next state of an element is
+        filled in by the NEXT step's gather (one extra state evaluation after the loop).
+
+        `reset_every` = K: envs whose episode ended are finalised, emitted and reset at every K-th step only (and at the
+        start of a call); in between they sit the steps out.  K = 1 is ``sample`` exactly (every env performs `num_steps`
+        interactions; one flag read per step); K > 1 trades that alignment for a sync-free step path — each env's own stream
+        of experiences is unchanged, an env just contributes fewer than `num_steps` steps to a call in which it rolled over."""
+        from .engine import SEED_REDRAW
+        eng = self.eng
+        n, dev = eng.n_envs, eng.decisions.device
+        if not hasattr(self, "_c") or self.state_dtype != state_dtype:
+            self._sample_init(state_dtype)
+        if num_steps is not None:
+            need = int(self._count.max()) + num_steps + 1      # one read per CALL: the cache never has to grow inside the loop
+            if need > self._cap:
+                self._cache_alloc(max(need, 2 * self._cap))
+        c = self._c
+        out = {k: [] for k in ("state", "action", "env_action", "reward", "next_state", "next_agent_state", "terminal", "env_id", "tick", "agent")}
+        acts = torch.zeros((n, eng.max_actions, 4), dtype=torch.int32, device=dev)
+        nact = torch.zeros(n, dtype=torch.int32, device=dev)
+        st_buf = torch.zeros((n, self.state_dim), dtype=torch.float32, device=dev)
+        ch_buf = torch.zeros(n, dtype=torch.int32, device=dev)
+        ar = torch.arange(n, device=dev)
+
+        def reset_envs(mask: torch.Tensor) -> None:   # AbsEnvSampler._reset for the envs in `mask` (a sync point: rare)
+            cmd = seeds(self._ep_env.clone()).to(torch.int64) if seeds is not None else torch.full((n,), SEED_REDRAW, dtype=torch.int64)
+            self._episodes += 1
+            self._ep_env += mask.cpu().to(torch.int64)
+            eng.reset(cmd, mask.to(torch.uint8))
+            m64 = mask.to(torch.int64)
+            self._hist[mask] = 0
+            self._count.mul_(1 - m64)
+            self._last[mask] = -1
+            eng.step(mask=mask.to(torch.uint8))          # _step(None): the first decision event
+            self._eoe = torch.where(mask, eng.done.to(torch.bool), self._eoe)
+
+        def roll_over() -> None:
+            if bool(self._eoe.any()):
+                ended = self._eoe.clone()
+                self._finalize_and_emit(ended, out)
+                reset_envs(ended)
+
+        if bool(self._eoe.any()):
+            reset_envs(self._eoe.clone())
+        prev_j = None          # cache slot each env wrote in the previous step (its next_state is this step's state)
+        prev_active = None
+        k = -1
+        while True:
+            k += 1
+            if num_steps is None:                          # "until the end of every env's episode": one flag read per step
+                if bool(self._eoe.all()):
+                    break
+                if int(self._count.max()) >= self._cap:
+                    self._cache_alloc(2 * self._cap)
+                    c = self._c
+            else:
+                if k == num_steps:
+                    break
+                if k > 0 and k % max(1, reset_every) == 0:
+                    if prev_j is not None:                 # the envs about to be finalised need their last element complete
+                        self._fill_next_state(prev_j, prev_active, ar)
+                        prev_j = None
+                    roll_over()
+            active = ~self._eoe
+            dec = eng.decisions.clone()
+            actor.act(acts, nact, decisions=dec, state=st_buf, choice=ch_buf)
+            nact.mul_(active.to(torch.int32))
+            state = st_buf.to(self.state_dtype)
+            if prev_j is not None:                         # previous element: next_state = the state this step's gather produced,
+                still = prev_active & active               # or (episode over) the element's own state
+                pj = prev_j
+                cur = c["state"][ar, pj]
+                c["next_state"][ar, pj] = torch.where(still[:, None], state, torch.where(prev_active[:, None], cur, c["next_state"][ar, pj]))
+            a1 = active[:, None]
+            j = self._count.clamp(max=self._cap - 1)
+            agent = dec[:, 1].to(torch.int64).clamp(min=0)
+            c["tick"][ar, j] = torch.where(active, dec[:, 0], c["tick"][ar, j])
+            c["agent"][ar, j] = torch.where(active, agent, c["agent"][ar, j])
+            c["state"][ar, j] = torch.where(a1, state, c["state"][ar, j])
+            c["action"][ar, j] = torch.where(active, ch_buf.to(torch.int64), c["action"][ar, j])
+            c["env_action"][ar, j] = torch.where(a1, acts[:, 0], c["env_action"][ar, j])
+            c["terminal"][ar, j] = torch.where(active, torch.zeros_like(active), c["terminal"][ar, j])
+            prev = self._last[ar, agent]                 # this agent's previous element gets its next agent state
+            hp = active & (prev >= 0)
+            pz = prev.clamp(min=0)
+            c["next_agent_state"][ar, pz] = torch.where(hp[:, None], state, c["next_agent_state"][ar, pz])
+            c["terminal"][ar, pz] = torch.where(hp, torch.zeros_like(hp), c["terminal"][ar, pz])
+            self._last[ar, agent] = torch.where(active, j, self._last[ar, agent])
+            self._count += active.to(torch.int64)
+            self.interactions += active.sum()               # (device counter: env-steps this sampler has performed)
+            eng.step(acts, nact, mask=active.to(torch.uint8))
+            self._eoe = torch.where(active, eng.done.to(torch.bool), self._eoe)
+            prev_j, prev_active = j, active
+        if prev_j is not None:
+            self._fill_next_state(prev_j, prev_active, ar)
+        self._cur_state = torch.where((~self._eoe)[:, None], self.state().to(self.state_dtype), self._cur_state)
+        self._finalize_and_emit(torch.ones(n, dtype=torch.bool, device=dev), out)
+        res = {k: (torch.cat(v) if v else torch.zeros((0,) + tuple(c[k].shape[2:]) if k in c else (0,), dtype=(c[k].dtype if k in c else torch.int32), device=dev))
+               for k, v in out.items()}
+        if not out["reward"]:
+            res["reward"] = torch.zeros(0, dtype=torch.float32, device=dev)
+        res["env_metric"] = eng.metrics.clone()
+        return res
+
+    def _fill_next_state(self, pj: torch.Tensor, p_active: torch.Tensor, ar: torch.Tensor) -> None:
+        """next_state of the element every env wrote in its last step: the state of its now pending decision, or — episode
+        over — the element's own state (`_cur_state` is left unchanged by a final step in ``sample``)."""
+        c = self._c
+        new = self.state().to(self.state_dtype)
+        alive = p_active & ~self._eoe
+        own = c["state"][ar, pj]
+        c["next_state"][ar, pj] = torch.where(alive[:, None], new, torch.where(p_active[:, None], own, c["next_state"][ar, pj]))

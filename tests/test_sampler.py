@@ -61,7 +61,7 @@ def test_sampler_on_gpu():
 
 
 # ---- the batched sampling loop against the REAL maro.rl sampler (oracle/gen_golden_sampler.py)
-def run_sample_case(engine_factory, case, n_envs=2):
+def run_sample_case(engine_factory, case, n_envs=2, fused=False):
     """CimBatchSampler.sample(num_steps) called like the golden's CIMEnvSampler.sample: same seeds, the recorded model actions
     replayed as the policy; every emitted experience (tick, agent, state, action, reward, terminal, next_state,
     next_agent_state) of every env must equal the reference's, call by call."""
@@ -84,11 +84,27 @@ def run_sample_case(engine_factory, case, n_envs=2):
         k[0] += 1
         return torch.full((n_envs,), a, dtype=torch.int64, device=dev)
 
-    def seeds(ep):
-        return torch.full((n_envs,), meta["seed"] + ep, dtype=torch.int64)
+    def seeds(ep):   # ep: int64 [n_envs], every env's own episode index
+        return meta["seed"] + ep.to(torch.int64)
+
+    class RecordedActor:
+        """`actor.act` of CimBatchSampler.sample_fused (what FusedPerPortDQN does in one launch on the GPU), from the pieces the
+        unfused loop uses: the sampler state, the recorded model action, the example's action translation."""
+
+        def act(self, actions, n_actions, decisions=None, state=None, choice=None):
+            from maro_amd.cim.policy import translate_actions
+            st = smp.state(decisions)
+            ma = policy(st, decisions)
+            translate_actions(ma, decisions, st[:, -1].to(torch.float64), decisions[:, 5], out=actions)
+            n_actions[:] = (decisions[:, 7] == 1).to(torch.int32)
+            state[:] = st.to(torch.float32)
+            choice[:] = ma.to(torch.int32)
 
     for c, num_steps in enumerate(meta["calls"]):
-        res = smp.sample(policy, num_steps=num_steps, seeds=seeds, state_dtype=torch.float64)
+        if fused:
+            res = smp.sample_fused(RecordedActor(), num_steps=num_steps, seeds=seeds, reset_every=1, state_dtype=torch.float64)
+        else:
+            res = smp.sample(policy, num_steps=num_steps, seeds=seeds, state_dtype=torch.float64)
         assert k[0] == int(z[f"call{c}/interactions"][1]), (c, k[0])
         n_exp = len(z[f"call{c}/tick"])
         env_id = res["env_id"].cpu().numpy()
@@ -113,8 +129,61 @@ def test_batched_sample_matches_the_reference_sampler_on_emulator(case):
     run_sample_case(emu_factory, case)
 
 
+@pytest.mark.parametrize("case", ["toy5p_l05", "gt22p_l08", "toy5p_l05_rollover", "toy6p_l08", "toy4p_l00_rollover"])
+def test_fused_sample_loop_matches_the_reference_sampler_on_emulator(case):
+    """sample_fused (the sync-free loop bench.py --policy dqn --collect times), reset_every = 1: the same experiences."""
+    run_sample_case(emu_factory, case, fused=True)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["toy5p_l05", "gt22p_l08", "toy5p_l05_rollover", "toy6p_l08", "toy4p_l00_rollover"])
 def test_batched_sample_matches_the_reference_sampler_on_gpu(case):
     from maro_amd.cim.engine import CimBatchEngine
     run_sample_case(lambda topo, n, **kw: CimBatchEngine(topo, n, **kw), case, n_envs=7)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_divergent_episodes_in_one_batch_equal_single_env_runs(fused):
+    """Envs with different seeds reach their episode ends at different steps: each env's roll-over must use ITS OWN episode index
+    for the next seed (the reference runs one sampler loop per env), and the partial-mask reset / emit paths must leave the other
+    envs alone.  A 3-env batch against three 1-env samplers, with and without the fused loop."""
+    topo, dur, n = "toy.5p_ssddd_l0.5", 60, 3
+    base = [11, 500, 9001]
+
+    def policy(states, dec):
+        return ((dec[:, 0] + 3 * dec[:, 1]) % 21).to(torch.int64)
+
+    class Actor:
+        def __init__(self, smp):
+            self.smp = smp
+
+        def act(self, actions, n_actions, decisions=None, state=None, choice=None):
+            from maro_amd.cim.policy import translate_actions
+            st = self.smp.state(decisions)
+            ma = policy(st, decisions)
+            translate_actions(ma, decisions, st[:, -1].to(torch.float64), decisions[:, 5], out=actions)
+            n_actions[:] = (decisions[:, 7] == 1).to(torch.int32)
+            state[:] = st.to(torch.float32)
+            choice[:] = ma.to(torch.int32)
+
+    def run(env_bases):
+        m = len(env_bases)
+        eng = emu_factory(topo, m, durations=dur, max_actions=1, max_snapshots=16)
+        smp = CimBatchSampler(eng, time_window=20)
+        b = torch.tensor(env_bases, dtype=torch.int64)
+        res = []
+        for num_steps in (25, 40, 33):
+            if fused:
+                res.append(smp.sample_fused(Actor(smp), num_steps=num_steps, seeds=lambda ep: b + 7 * ep, reset_every=1, state_dtype=torch.float64))
+            else:
+                res.append(smp.sample(policy, num_steps=num_steps, seeds=lambda ep: b + 7 * ep, state_dtype=torch.float64))
+        return res
+
+    batch = run(base)
+    assert any(len(r["tick"]) for r in batch)
+    for e, s in enumerate(base):
+        single = run([s])
+        for rb, rs in zip(batch, single):
+            sel = np.flatnonzero(rb["env_id"].numpy() == e)
+            for key in ("tick", "agent", "state", "action", "env_action", "reward", "terminal", "next_state", "next_agent_state"):
+                assert np.array_equal(rb[key].numpy()[sel], rs[key].numpy()), (e, key)
