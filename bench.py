@@ -426,7 +426,7 @@ with VectorEnv(batch_num=n, scenario="cim", topology=sys.argv[2], durations=int(
     return res
 
 
-def bench_collect(args, engines, qnet, n, G, dev, rank, world, dist, reset_ms):
+def bench_collect(args, engines, streams, qnet, n, G, dev, rank, world, dist, reset_ms):
     """SURVEY.md 8(d) config 5 as the reference runs it: `AbsEnvSampler.sample(num_steps)` with on-device inference — here
     CimBatchSampler.sample_fused over every group's engine: per step ONE fused call for sampler state + per-port DQN + action
     translation (mrx_cim_dqn_act), the transition cache updated by masked tensor ops (no host sync on the step path), then
@@ -435,7 +435,10 @@ def bench_collect(args, engines, qnet, n, G, dev, rank, world, dist, reset_ms):
     import torch
 
     from maro_amd.cim.sampler import CimBatchSampler
-    samplers = [CimBatchSampler(e) for e in engines]
+    samplers = []
+    for g, e in enumerate(engines):
+        with torch.cuda.stream(streams[g]):
+            samplers.append(CimBatchSampler(e))
     seeds_of = [(lambda ep, g=g, e=e: ep * 1000003 + torch.arange(e.n_envs, dtype=torch.int64) + rank * n + g * 131071 + 1) for g, e in enumerate(engines)]
 
     def sync_all():
@@ -447,7 +450,8 @@ def bench_collect(args, engines, qnet, n, G, dev, rank, world, dist, reset_ms):
     def one_call(k):
         nexp = 0
         for g, smp in enumerate(samplers):
-            res = smp.sample_fused(qnet[g], num_steps=k, seeds=seeds_of[g], reset_every=args.reset_every)
+            with torch.cuda.stream(streams[g]):   # the sampler's tensor ops and its engine's kernels on ONE stream (the engine is bound to it)
+                res = smp.sample_fused(qnet[g], num_steps=k, seeds=seeds_of[g], reset_every=args.reset_every)
             nexp += int(res["tick"].shape[0])
         return nexp
 
@@ -583,7 +587,7 @@ def main():
     if args.collect:
         if qnet is None:
             raise SystemExit("--collect needs --policy dqn")
-        return bench_collect(args, engines, qnet, n, G, dev, rank, world, dist, reset_ms)
+        return bench_collect(args, engines, streams, qnet, n, G, dev, rank, world, dist, reset_ms)
 
     def one_step(i, g, timing=None, count=True):
         eng, b, st = engines[g], bufs[g], streams[g]

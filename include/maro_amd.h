@@ -365,6 +365,26 @@ int64_t mrx_cim_dqn_scratch_bytes(mrx_handle h);
 int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_decisions, void* d_scratch, int32_t* d_actions,
                     int32_t* d_n_actions, float* d_q, float* d_state, int32_t* d_choice, uint64_t* d_counter, void* stream);
 
+/*
+ * One step of the batched EnvSampler's transition cache (replaces the per-env Python bookkeeping of
+ * maro/rl/rollout/env_sampler.py:386-410, 472-512: `_append_cache_element` — the element of this decision, the previous
+ * element's next state, the deciding agent's previous element's next agent state and terminal flag).  Call it between the
+ * policy (mrx_cim_dqn_act, which produced d_state / d_choice / d_actions for d_decisions) and mrx_cim_step.  Per env e:
+ *   alive = prev_active[e] && !eoe[e]:  next_state[e][prev_j[e]] = alive ? state[e] : state element prev_j[e] itself (episode over)
+ *   active = !eoe[e]:  element j = count[e] <- (tick, deciding port, state[e], choice[e], first action row), terminal = 0;
+ *                      the port's previous element last[e][port] gets next_agent_state = state[e], terminal = 0;
+ *                      last[e][port] = j; count[e] += 1; n_actions[e] stays; inactive envs get n_actions[e] = 0
+ *   prev_j[e] = j, prev_active[e] = active; d_interactions[e] += 1 (int64 [n_envs]: interactions each env has performed).
+ * The cache is caller-owned device memory, rows of `cap` elements per env: c_tick int32 [n][cap], c_agent / c_action int64
+ * [n][cap], c_state / c_next_state / c_next_agent_state [n][cap][state_dim] of float32 (state_f64 = 0) or float64 (1),
+ * c_env_action int32 [n][cap][4], c_terminal uint8 [n][cap].  first != 0: no previous step in this call (prev_* are only written).
+ */
+int mrx_cim_sampler_record(int32_t n_envs, int32_t n_ports, int32_t state_dim, int32_t cap, int32_t max_actions, int32_t state_f64, int32_t first,
+                           const int32_t* d_decisions, const float* d_state, const int32_t* d_choice, const int32_t* d_actions, int32_t* d_n_actions,
+                           const uint8_t* d_eoe, int64_t* d_count, int64_t* d_last, int64_t* d_prev_j, uint8_t* d_prev_active,
+                           int32_t* c_tick, int64_t* c_agent, void* c_state, int64_t* c_action, int32_t* c_env_action, uint8_t* c_terminal,
+                           void* c_next_state, void* c_next_agent_state, int64_t* d_interactions, int32_t device, void* stream);
+
 /* Attribute name -> id and slot count for a node type; returns -1 for an unknown attribute
  * (reference raises BackendsInvalidAttributeException, frame.pyx:786-790). */
 int mrx_cim_attr_id(int node_type, const char* name);

@@ -79,7 +79,7 @@ class CimBatchSampler:
         self._last = torch.full((n, eng.layout.n_ports), -1, dtype=torch.int64, device=dev)   # _agent_last_index
         self._eoe = torch.ones(n, dtype=torch.bool, device=dev)                               # _end_of_episode
         self._episodes = 0                                   # reset_envs calls so far (diagnostics)
-        self.interactions = torch.zeros((), dtype=torch.int64, device=dev)
+        self._steps_env = torch.zeros(n, dtype=torch.int64, device=dev)   # interactions each env has performed (sample_fused)
         self._ep_env = torch.zeros(n, dtype=torch.int64, device='cpu')   # episodes each env has started: what its seed depends on
         self._cur_state = torch.zeros((n, self.state_dim), dtype=state_dtype, device=dev)
         # per-attribute retention: the whole episode of (fulfillment, shortage) per port, written by the step kernel at every
@@ -292,8 +292,39 @@ class CimBatchSampler:
             reset_envs(self._eoe.clone())
         prev_j = None          # cache slot each env wrote in the previous step (its next_state is this step's state)
         prev_active = None
+        # On the GPU the whole per-step cache update is ONE kernel (mrx_cim_sampler_record); the tensor-op sequence below is its
+        # specification (and what runs on the CPU emulator, pinned by the reference sampler's goldens)
+        rec = getattr(getattr(eng, "_L", None), "mrx_cim_sampler_record", None) if eng.decisions.is_cuda and num_steps is not None else None
+        if rec is not None:
+            import ctypes
+
+            from .. import _lib
+            pj_t = torch.zeros(n, dtype=torch.int64, device=dev)
+            pa_t = torch.zeros(n, dtype=torch.uint8, device=dev)
+            f64 = 1 if self.state_dtype == torch.float64 else 0
+            assert self.state_dtype in (torch.float32, torch.float64)
+            first = 1
+            for k in range(num_steps):
+                if k > 0 and k % max(1, reset_every) == 0:
+                    if not first:
+                        self._fill_next_state(pj_t, pa_t.to(torch.bool), ar)
+                        first = 1
+                    roll_over()
+                    c = self._c
+                actor.act(acts, nact, decisions=eng.decisions, state=st_buf, choice=ch_buf)
+                _lib.check(rec(n, eng.layout.n_ports, self.state_dim, self._cap, eng.max_actions, f64, first, eng.decisions.data_ptr(), st_buf.data_ptr(),
+                               ch_buf.data_ptr(), acts.data_ptr(), nact.data_ptr(), self._eoe.data_ptr(), self._count.data_ptr(), self._last.data_ptr(),
+                               pj_t.data_ptr(), pa_t.data_ptr(), c["tick"].data_ptr(), c["agent"].data_ptr(), c["state"].data_ptr(), c["action"].data_ptr(),
+                               c["env_action"].data_ptr(), c["terminal"].data_ptr(), c["next_state"].data_ptr(), c["next_agent_state"].data_ptr(),
+                               self._steps_env.data_ptr(), dev.index if dev.index is not None else torch.cuda.current_device(), eng._stream()),
+                           "mrx_cim_sampler_record")
+                first = 0
+                eng.step(acts, nact)                       # (finished envs just report `done` again: no mask needed)
+                torch.logical_or(self._eoe, eng.done, out=self._eoe)
+            if not first:
+                self._fill_next_state(pj_t, pa_t.to(torch.bool), ar)
         k = -1
-        while True:
+        while rec is None:
             k += 1
             if num_steps is None:                          # "until the end of every env's episode": one flag read per step
                 if bool(self._eoe.all()):
@@ -335,7 +366,7 @@ class CimBatchSampler:
             c["terminal"][ar, pz] = torch.where(hp, torch.zeros_like(hp), c["terminal"][ar, pz])
             self._last[ar, agent] = torch.where(active, j, self._last[ar, agent])
             self._count += active.to(torch.int64)
-            self.interactions += active.sum()               # (device counter: env-steps this sampler has performed)
+            self._steps_env += active.to(torch.int64)
             eng.step(acts, nact, mask=active.to(torch.uint8))
             self._eoe = torch.where(active, eng.done.to(torch.bool), self._eoe)
             prev_j, prev_active = j, active
@@ -349,6 +380,11 @@ class CimBatchSampler:
             res["reward"] = torch.zeros(0, dtype=torch.float32, device=dev)
         res["env_metric"] = eng.metrics.clone()
         return res
+
+    @property
+    def interactions(self) -> torch.Tensor:
+        """int64 scalar tensor: env-steps this sampler has performed through sample_fused."""
+        return self._steps_env.sum()
 
     def _fill_next_state(self, pj: torch.Tensor, p_active: torch.Tensor, ar: torch.Tensor) -> None:
         """next_state of the element every env wrote in its last step: the state of its now pending decision, or — episode

@@ -163,6 +163,54 @@ mrx_k_cim_random_policy(CimParams K, const int32_t* __restrict__ decisions, long
   }
 }
 
+// The batched EnvSampler's per-step cache update (mrx_cim_sampler_record): one wave per env, lanes over the state vector.
+template <class T>
+__global__ void __launch_bounds__(64)
+mrx_k_cim_sampler_record(int n, int P, int D, int cap, int A, int first, const int32_t* __restrict__ dec, const float* __restrict__ state,
+                         const int32_t* __restrict__ choice, const int32_t* __restrict__ acts, int32_t* __restrict__ nact, const uint8_t* __restrict__ eoe,
+                         long long* __restrict__ count, long long* __restrict__ last, long long* __restrict__ prev_j, uint8_t* __restrict__ prev_active,
+                         int32_t* __restrict__ c_tick, long long* __restrict__ c_agent, T* __restrict__ c_state, long long* __restrict__ c_action,
+                         int32_t* __restrict__ c_env_action, uint8_t* __restrict__ c_terminal, T* __restrict__ c_next_state, T* __restrict__ c_nas,
+                         long long* __restrict__ steps_env) {
+  const int e = (int)blockIdx.x, lane = (int)threadIdx.x;
+  const bool over = eoe[e] != 0;
+  const float* st = state + (size_t)e * D;
+  if (!first && prev_active[e]) {  // the element of the previous step: its next state is this state, or (episode over) its own
+    const long long pj = prev_j[e];
+    T* ns = c_next_state + ((size_t)e * cap + pj) * D;
+    const T* own = c_state + ((size_t)e * cap + pj) * D;
+    for (int d = lane; d < D; d += 64) ns[d] = over ? own[d] : (T)st[d];
+  }
+  if (over) {
+    if (lane == 0) { nact[e] = 0; prev_active[e] = 0; }
+    return;
+  }
+  long long j = count[e];
+  if (j > cap - 1) j = cap - 1;
+  int agent = dec[(size_t)e * 8 + 1];
+  agent = agent < 0 ? 0 : (agent >= P ? P - 1 : agent);
+  const long long prev = last[(size_t)e * P + agent];
+  T* cs = c_state + ((size_t)e * cap + j) * D;
+  for (int d = lane; d < D; d += 64) cs[d] = (T)st[d];
+  if (prev >= 0) {
+    T* na = c_nas + ((size_t)e * cap + prev) * D;
+    for (int d = lane; d < D; d += 64) na[d] = (T)st[d];
+  }
+  if (lane < 4) c_env_action[((size_t)e * cap + j) * 4 + lane] = acts[(size_t)e * A * 4 + lane];
+  if (lane == 0) {
+    c_tick[(size_t)e * cap + j] = dec[(size_t)e * 8];
+    c_agent[(size_t)e * cap + j] = agent;
+    c_action[(size_t)e * cap + j] = choice[e];
+    c_terminal[(size_t)e * cap + j] = 0;
+    if (prev >= 0) c_terminal[(size_t)e * cap + prev] = 0;
+    last[(size_t)e * P + agent] = j;
+    count[e] = count[e] + 1;
+    prev_j[e] = j;
+    prev_active[e] = 1;
+    steps_env[e] += 1;   // (per env: a single shared counter would serialise 16384 atomics per step)
+  }
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 // Plan-specialised code objects are shared between the engines of a process (one hipModule per (device, image)): the
 // groups of a batch — same plan, one engine each — then execute the SAME code addresses, so the instruction cache (64 KB per
@@ -706,6 +754,28 @@ int mrx_cim_read_kernel_global(mrx_handle h, const char* name, void* out, int64_
   if ((size_t)bytes > n) return set_err(MRX_ERR_INVALID_ARG, "the global is smaller than the requested size");
   HIP_TRY(hipMemcpy(out, (const void*)p, (size_t)bytes, hipMemcpyDeviceToHost));
   if (reset) HIP_TRY(hipMemset((void*)p, 0, (size_t)bytes));
+  return MRX_OK;
+}
+
+int mrx_cim_sampler_record(int32_t n_envs, int32_t n_ports, int32_t state_dim, int32_t cap, int32_t max_actions, int32_t state_f64, int32_t first,
+                           const int32_t* d_decisions, const float* d_state, const int32_t* d_choice, const int32_t* d_actions, int32_t* d_n_actions,
+                           const uint8_t* d_eoe, int64_t* d_count, int64_t* d_last, int64_t* d_prev_j, uint8_t* d_prev_active,
+                           int32_t* c_tick, int64_t* c_agent, void* c_state, int64_t* c_action, int32_t* c_env_action, uint8_t* c_terminal,
+                           void* c_next_state, void* c_next_agent_state, int64_t* d_interactions, int32_t device, void* stream) {
+  if (n_envs <= 0 || n_ports <= 0 || state_dim <= 0 || cap <= 0 || max_actions <= 0) return set_err(MRX_ERR_INVALID_ARG, "dimensions must be positive");
+  if (!d_decisions || !d_state || !d_choice || !d_actions || !d_n_actions || !d_eoe || !d_count || !d_last || !d_prev_j || !d_prev_active || !c_tick ||
+      !c_agent || !c_state || !c_action || !c_env_action || !c_terminal || !c_next_state || !c_next_agent_state || !d_interactions)
+    return set_err(MRX_ERR_INVALID_ARG, "null pointer");
+  int rc = use_device(device);
+  if (rc != MRX_OK) return rc;
+#define MRX_REC(T)                                                                                                                               \
+  hipLaunchKernelGGL(mrx_k_cim_sampler_record<T>, dim3((unsigned)n_envs), dim3(64), 0, (hipStream_t)stream, (int)n_envs, (int)n_ports, (int)state_dim,  \
+                     (int)cap, (int)max_actions, (int)first, d_decisions, d_state, d_choice, d_actions, d_n_actions, d_eoe, (long long*)d_count,            \
+                     (long long*)d_last, (long long*)d_prev_j, d_prev_active, c_tick, (long long*)c_agent, (T*)c_state, (long long*)c_action, c_env_action, \
+                     c_terminal, (T*)c_next_state, (T*)c_next_agent_state, (long long*)d_interactions)
+  if (state_f64) MRX_REC(double); else MRX_REC(float);
+#undef MRX_REC
+  HIP_TRY(hipGetLastError());
   return MRX_OK;
 }
 

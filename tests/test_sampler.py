@@ -187,3 +187,56 @@ def test_divergent_episodes_in_one_batch_equal_single_env_runs(fused):
             sel = np.flatnonzero(rb["env_id"].numpy() == e)
             for key in ("tick", "agent", "state", "action", "env_action", "reward", "terminal", "next_state", "next_agent_state"):
                 assert np.array_equal(rb[key].numpy()[sel], rs[key].numpy()), (e, key)
+
+
+@pytest.mark.gpu
+def test_fused_collect_loop_with_the_fused_dqn_on_gpu():
+    """bench.py --policy dqn --collect's loop (sample_fused + FusedPerPortDQN.act) against the unfused sample() driven by the SAME
+    network (its policy callable reads the fused kernel's model action): identical experiences with reset_every = 1; with
+    reset_every = 32 every env's own stream of experiences is a prefix-equal subsequence (only the alignment across the batch moves)."""
+    from maro_amd.cim.engine import CimBatchEngine
+    from maro_amd.cim.policy import ACTION_SPACE, FusedPerPortDQN, random_chains
+    topo, n, dur = "global_trade.22p_l0.8", 96, 160
+    seeds = lambda ep: 77 + 13 * ep + torch.arange(n, dtype=torch.int64)   # noqa: E731
+
+    def make():
+        eng = CimBatchEngine(topo, n, durations=dur, max_actions=1, max_snapshots=16)
+        smp = CimBatchSampler(eng, time_window=30)
+        chains = random_chains(eng.topo.n_ports, smp.state_dim, len(ACTION_SPACE), seed=3)
+        return eng, smp, FusedPerPortDQN(eng, chains)
+
+    def run(mode):
+        eng, smp, q = make()
+        a = torch.zeros((n, 1, 4), dtype=torch.int32, device=eng.device)
+        na = torch.zeros(n, dtype=torch.int32, device=eng.device)
+        ch = torch.zeros(n, dtype=torch.int32, device=eng.device)
+
+        def policy(states, dec):
+            q.act(a, na, decisions=dec, choice=ch)
+            return ch.to(torch.int64)
+        out = []
+        for k in (50, 70, 64, 90):
+            if mode == "unfused":
+                out.append(smp.sample(policy, num_steps=k, seeds=seeds, state_dtype=torch.float32))
+            else:
+                out.append(smp.sample_fused(q, num_steps=k, seeds=seeds, reset_every=mode, state_dtype=torch.float32))
+        return out
+
+    ref, f1, f32 = run("unfused"), run(1), run(32)
+    keys = ("env_id", "tick", "agent", "state", "action", "env_action", "reward", "terminal", "next_state", "next_agent_state")
+    total = 0
+    for r, f in zip(ref, f1):
+        for key in keys:
+            assert torch.equal(r[key], f[key]), key
+        total += len(r["tick"])
+    assert total > 1000
+
+    def per_env(res):
+        cat = {k: torch.cat([r[k] for r in res]).cpu().numpy() for k in keys}
+        return [{k: cat[k][cat["env_id"] == e] for k in keys} for e in range(n)]
+    a_env, b_env = per_env(ref), per_env(f32)
+    for e in range(n):
+        m = min(len(a_env[e]["tick"]), len(b_env[e]["tick"]))
+        assert m > 5
+        for key in keys:
+            assert np.array_equal(a_env[e][key][:m], b_env[e][key][:m]), (e, key)
