@@ -821,6 +821,11 @@ def main():
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(ep_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    # every rank's own contribution to every window (the line's value must be sum(env-steps) / max(seconds) over the ranks)
+    mine = torch.tensor([[w["dt"], float(w["resolved"])] for w in windows], dtype=torch.float64, device=dev)
+    per_rank = [mine.clone() for _ in range(world)] if dist is not None else [mine]
+    if dist is not None:
+        dist.all_gather(per_rank, mine)
     dts = [float(x) for x in t_max.tolist()]
     tl = [float(x) for x in tot.tolist()]
     res_w, tick_w = tl[:R], tl[R:2 * R]
@@ -883,6 +888,8 @@ def main():
             "repeats": R, "value_min": min(vals), "value_max": max(vals), "values": vals,
             "value_note": f"the timed window of exactly {args.steps} steps was run {R} times back to back; value / ms_per_step are the median window",
             "gpu_seconds_total": sum(v for v in gpu_busy_s.values() if v), "gpu_seconds": gpu_busy_s,
+            "ranks": {"env_steps": [float(p[med, 1]) for p in per_rank], "seconds": [float(p[med, 0]) for p in per_rank],
+                      "what": "each rank's env-steps and wall time of the median window: value = sum(env_steps) / max(seconds)"},
             "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {sim_durations}, "
                                    f"{'random legal agent' if args.policy == 'random' else 'per-port dueling DQN (f32 MFMA, greedy) + CIMEnvSampler state shaping (mrx_cim_dqn_act)'} on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step (' + args.obs + ')'}",
                        "envs_per_gpu": n, "groups_per_gpu": G, "step_mode": engines[0].step_mode, "specialized_kernels": bool(engines[0].specialized), "code_object_key": code_key, "code_object_sha16": getattr(engines[0], "code_object_sha16", None), "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,

@@ -44,7 +44,7 @@ def test_bench_line_contract(extra):
         assert j["config"]["mean_tick_at_window_start"] >= 300 and "algorithmic_frac" in r and "basis" in r
 
 
-@pytest.mark.parametrize("scenario,world", [("cim", 2), ("citi_bike", 4)])
+@pytest.mark.parametrize("scenario,world", [("cim", 2), ("citi_bike", 4), ("cim", 8), ("citi_bike", 8)])
 def test_bench_multi_rank_path_under_gloo(scenario, world):
     """`bench.py --gpus N` as the driver launches it (torch.distributed.run, one process per rank), with the test hooks
     MRX_BENCH_BACKEND=gloo + MRX_BENCH_DEVICE=0 so that a 1-GPU box can run it (RCCL refuses several ranks on one device):
@@ -59,7 +59,7 @@ def test_bench_multi_rank_path_under_gloo(scenario, world):
            "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(world), "--steps", "8", "--warmup", "3",
            "--scenario", scenario, "--envs", "256" if scenario == "cim" else "128", "--no-cpu"]
     if scenario == "cim":
-        cmd += ["--preroll-ticks", "20", "--durations", "200"]
+        cmd += ["--preroll-ticks", "20", "--durations", "260", "--repeats", "2", "--gather-every", "16", "--no-episode", "--parity-envs", "0"]
     out = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
@@ -67,3 +67,14 @@ def test_bench_multi_rank_path_under_gloo(scenario, world):
     j = json.loads(lines[0])
     assert j["n_gpus"] == world and j["value"] > 0 and j["scaling"] == "weak"
     assert j["config"]["trajectory_gather_ms_32_steps"] > 0
+    if scenario == "cim":
+        # whole-job aggregate: every rank's env-steps summed over the slowest rank's time
+        r = j["ranks"]
+        assert len(r["env_steps"]) == world and all(x > 0 for x in r["env_steps"])
+        assert abs(j["value"] - sum(r["env_steps"]) / max(r["seconds"])) <= 1e-6 * j["value"]
+        # per env and step (decision int32[8], action int32[4], metrics int64[3], done u8, observation f32[22 x 7]) ~ 700 B
+        n, T = 256, 32
+        assert j["config"]["trajectory_gather_bytes_per_rank"] == T * n * (8 * 4 + 4 * 4 + 3 * 8 + 1 + 22 * 7 * 4)
+        ge = j["config"]["trajectory_gather_every"]
+        assert ge["steps_per_rollout"] == 16 and ge["gather_ms"] > 0 and 0 < ge["gather_share"] < 1
+        assert ge["bytes_per_rank"] == 16 * n * (8 * 4 + 4 * 4 + 3 * 8 + 1 + 22 * 7 * 4)

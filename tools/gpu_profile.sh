@@ -22,4 +22,20 @@ timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o r -- $B > $
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o r -- $B > $O/write_line.json 2> $O/write.err; echo "write rc $?"
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/sq -o r -- $B > $O/sq_line.json 2> $O/sq.err; echo "sq rc $?"
 python tools/refresh_pmc.py $O profiles/${tag}_rocprofv3.md $O
+# ---- citi_bike (CB=1): the toy of BASELINE config 4 and city.800s (the reference's own topology size, sustained: a window that
+# spans several decision ticks, bounded steps), same passes, summarised into <tag>_citi_bike.md + latest_pmc_citi_bike.json
+if [ "${CB:-0}" = "1" ]; then
+  rm -f $O/${tag}_citi_bike.md $O/latest_pmc_citi_bike.json
+  cb_pass() {  # <name> <bench flags...>
+    name=$1; shift
+    C=$O/cb_$name; mkdir -p $C
+    timeout 200 python bench.py --scenario citi_bike --no-cpu "$@" > $C/bench_line.json 2> $C/bench_line.err; echo "cb $name bench rc $?"
+    timeout 200 rocprofv3 --kernel-trace --stats -d $C/trace -o r -- python bench.py --scenario citi_bike --no-cpu "$@" > $C/trace_line.json 2> $C/trace.err; echo "cb $name trace rc $?"
+    timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $C/fetch -o r -- python bench.py --scenario citi_bike --no-cpu "$@" > $C/fetch_line.json 2> $C/fetch.err; echo "cb $name fetch rc $?"
+    timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $C/write -o r -- python bench.py --scenario citi_bike --no-cpu "$@" > $C/write_line.json 2> $C/write.err; echo "cb $name write rc $?"
+    python tools/refresh_pmc_citi_bike.py $C $name $O
+  }
+  cb_pass toy3s --bounded-budget 0
+  cb_pass city800 --topology city.800s --envs 4096 --durations 2880 --steps 900 --warmup 300 --bounded-budget 0 --step-budget 64 --specialize 1
+fi
 find $O -name "*.db" -delete; find $O -type d -empty -delete; du -sh $O
