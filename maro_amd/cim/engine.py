@@ -10,6 +10,7 @@ Tensor conventions are those of the C ABI:
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 from typing import Optional, Sequence, Union
@@ -191,6 +192,13 @@ class CimBatchEngine:
                                                   self.metrics.data_ptr(), self.done.data_ptr(), self._stream()), "mrx_cim_step_joint")
             self._keep = (a, na, mk, nans)
         return self.decisions, self.metrics, self.done
+
+    def clear_status_bits(self, envs, bits: int) -> None:
+        """status[e] &= ~bits for the listed envs (the object API acknowledges MRX_ENV_INVALID_ACTION this way)."""
+        st = self._bound_stream
+        with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+            idx = torch.as_tensor(list(envs), dtype=torch.int64, device=self.status.device)
+            self.status[idx] = self.status[idx] & ~int(bits)
 
     def random_policy(self, step: int, actions: torch.Tensor, n_actions: torch.Tensor,
                       counter: Optional[torch.Tensor] = None) -> None:

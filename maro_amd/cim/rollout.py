@@ -9,6 +9,7 @@ zmq fan-out of ``BatchEnvSampler`` (rl/rollout/batch_env_sampler.py:53-97).
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
@@ -119,22 +120,37 @@ class PipelinedCimBatch:
         batch.synchronize()
     """
 
-    def __init__(self, topology, n_envs: int, groups: int = 3, seeds=None, device="cuda:0", **engine_kwargs):
-        from .engine import CimBatchEngine
-
+    def __init__(self, topology, n_envs: int, groups: int = 3, seeds=None, device="cuda:0", engine_factory=None, **engine_kwargs):
+        """engine_factory(topology, n, seeds=..., **engine_kwargs) -> engine: defaults to CimBatchEngine on `device`; the CPU
+        suite passes the wave-emulator engine (no streams then)."""
         self.device = torch.device(device)
         groups = max(1, min(int(groups), int(n_envs)))
+        self.n_envs = int(n_envs)
         self.sizes = [n_envs // groups + (1 if g < n_envs % groups else 0) for g in range(groups)]
         self.offsets = [sum(self.sizes[:g]) for g in range(groups)]
-        seeds = torch.arange(n_envs, dtype=torch.int64) if seeds is None else torch.as_tensor(seeds, dtype=torch.int64)
-        self.engines = [CimBatchEngine(topology, self.sizes[g], device=self.device,
-                                       seeds=seeds[self.offsets[g]:self.offsets[g] + self.sizes[g]], **engine_kwargs)
+        if isinstance(seeds, str):
+            assert seeds == "topology"      # every env starts from the topology's own seed, like a fresh reference Env
+            seeds = None
+        elif seeds is None and engine_factory is None:
+            seeds = torch.arange(n_envs, dtype=torch.int64)
+        if seeds is not None:
+            seeds = torch.as_tensor(seeds, dtype=torch.int64)
+        if engine_factory is None:
+            from .engine import CimBatchEngine
+
+            def engine_factory(topo, n, **kw):
+                return CimBatchEngine(topo, n, device=self.device, **kw)
+        self.engines = [engine_factory(topology, self.sizes[g],
+                                       seeds=None if seeds is None else seeds[self.offsets[g]:self.offsets[g] + self.sizes[g]], **engine_kwargs)
                         for g in range(groups)]
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(groups)]
+        on_gpu = self.device.type == "cuda" and hasattr(self.engines[0], "use_stream")
+        self.streams = [torch.cuda.Stream(device=self.device) if on_gpu else None for _ in range(groups)]
         for eng, st in zip(self.engines, self.streams):
-            eng.use_stream(st)   # engine calls go to the group's stream even outside for_each() (see CimBatchEngine.use_stream
-                                 # for the stream discipline: read outputs inside for_each() or after synchronize())
-        torch.cuda.synchronize(self.device)
+            if st is not None:
+                eng.use_stream(st)   # engine calls go to the group's stream even outside for_each() (see CimBatchEngine.use_stream
+                                     # for the stream discipline: read outputs inside for_each() or after synchronize())
+        if on_gpu:
+            torch.cuda.synchronize(self.device)
 
     def __len__(self) -> int:
         return len(self.engines)
@@ -143,13 +159,69 @@ class PipelinedCimBatch:
         """Run fn(group_index, engine) for every group with that group's stream current; returns the results."""
         out = []
         for g, (eng, st) in enumerate(zip(self.engines, self.streams)):
+            if st is None:
+                out.append(fn(g, eng))
+                continue
             with torch.cuda.stream(st):
                 out.append(fn(g, eng))
         return out
 
     def synchronize(self) -> None:
         for st in self.streams:
-            st.synchronize()
+            if st is not None:
+                st.synchronize()
+
+    # ------------------------------------------------------------------ the CimBatchEngine surface over the whole batch
+    # What GpuVectorEnv needs from "its engine" (maro_amd/cim/vector_env.py), so that the object API — VectorEnv.step / reset /
+    # snapshot_list of maro/vector_env/vector_env.py:95-217 — can run on the stream-pipelined groups: whole-batch inputs are
+    # split by env range, every group's call is issued on its own stream before any result is read, outputs are concatenated in
+    # env order.
+    topo = property(lambda self: self.engines[0].topo)
+    max_actions = property(lambda self: self.engines[0].max_actions)
+    start_tick = property(lambda self: self.engines[0].start_tick)
+    durations = property(lambda self: self.engines[0].durations)
+    snapshot_resolution = property(lambda self: self.engines[0].snapshot_resolution)
+    decision_mode = property(lambda self: self.engines[0].decision_mode)
+    ticks = property(lambda self: self.cat("ticks"))
+    status = property(lambda self: self.cat("status"))
+    ring_fi = property(lambda self: self.cat("ring_fi"))
+
+    def _rows(self, x, g: int):
+        """Group g's env rows of a whole-batch input (None stays None)."""
+        return None if x is None else x[self.offsets[g]:self.offsets[g] + self.sizes[g]]
+
+    def step(self, actions=None, n_actions=None, mask=None, n_answered=None):
+        if actions is not None and not isinstance(actions, torch.Tensor):
+            import numpy as np
+            actions = np.asarray(actions).reshape(self.n_envs, self.max_actions, -1)
+        elif actions is not None:
+            actions = actions.reshape(self.n_envs, self.max_actions, -1)
+
+        def one(g, eng):
+            if n_answered is None:
+                return eng.step(self._rows(actions, g), self._rows(n_actions, g), self._rows(mask, g))
+            return eng.step(self._rows(actions, g), self._rows(n_actions, g), self._rows(mask, g), n_answered=self._rows(n_answered, g))
+        self.for_each(one)
+        return self.cat("decisions"), self.cat("metrics"), self.cat("done")
+
+    def reset(self, seed_cmd=None, mask=None) -> None:
+        self.for_each(lambda g, eng: eng.reset(self._rows(seed_cmd, g), self._rows(mask, g)))
+
+    def query(self, node: str, ticks, nodes, attrs, out=None) -> torch.Tensor:
+        """As CimBatchEngine.query; per-env `ticks` [n_envs, nt] / `nodes` [n_envs, nn] are split by env range, shared ones
+        ([nt] / [nn]) go to every group."""
+        def part(x, g):
+            return self._rows(x, g) if getattr(x, "ndim", 1) == 2 else x
+        res = self.for_each(lambda g, eng: eng.query(node, part(ticks, g), part(nodes, g), attrs))
+        self.synchronize()
+        return torch.cat(res, dim=0)
+
+    def clear_status_bits(self, envs, bits: int) -> None:
+        """status[e] &= ~bits for the listed envs (the object API acknowledges MRX_ENV_INVALID_ACTION this way)."""
+        for e in envs:
+            g = max(i for i, o in enumerate(self.offsets) if o <= e)
+            with torch.cuda.stream(self.streams[g]) if self.streams[g] is not None else contextlib.nullcontext():
+                self.engines[g].status[e - self.offsets[g]] &= ~int(bits)
 
     def cat(self, name: str) -> torch.Tensor:
         """Concatenate a per-engine tensor attribute (decisions, metrics, done, ticks, status ...) in env order."""

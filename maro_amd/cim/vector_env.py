@@ -120,17 +120,26 @@ class GpuVectorEnv:
     def __init__(self, batch_num: int, scenario: str = "cim", topology: str = None, start_tick: int = 0,
                  durations: int = 100, snapshot_resolution: int = 1, max_snapshots: int = None, decision_mode=0,
                  options: Optional[dict] = None, seeds: Optional[Sequence[int]] = None, device="cuda:0",
-                 max_actions: int = 4, specialize=None, _engine=None):
-        """specialize: passed to the engine (CimBatchEngine / CitiBikeBatchEngine): True = kernels compiled for this plan."""
+                 max_actions: int = 4, specialize=None, groups: int = 1, _engine=None):
+        """specialize: passed to the engine (CimBatchEngine / CitiBikeBatchEngine): True = kernels compiled for this plan.
+        groups > 1 (CIM): the batch runs as that many independent engines on their own HIP streams (PipelinedCimBatch,
+        DESIGN.md section 2: the other groups' kernels fill a step kernel's tail) — same results, env order unchanged."""
         if scenario != "cim":
             raise NotImplementedError("the GPU engine implements the 'cim' and 'citi_bike' scenarios; use "
                                       "maro.simulator.Env for others")
         mode = int(getattr(decision_mode, "value", decision_mode))
         if mode not in (0, 1, 2):
             raise ValueError("decision_mode must be Sequential (0), Joint (1) or JointWithSequentialAction (2)")
-        self.engine = _engine if _engine is not None else CimBatchEngine(
-            topology, batch_num, start_tick=start_tick, durations=durations, snapshot_resolution=snapshot_resolution,
-            max_snapshots=max_snapshots, max_actions=max_actions, device=device, seeds=seeds, decision_mode=mode, specialize=specialize)
+        ekw = dict(start_tick=start_tick, durations=durations, snapshot_resolution=snapshot_resolution, max_snapshots=max_snapshots,
+                   max_actions=max_actions, seeds=seeds, decision_mode=mode, specialize=specialize)
+        if _engine is not None:
+            self.engine = _engine
+        elif int(groups) > 1:
+            from .rollout import PipelinedCimBatch
+            ekw["seeds"] = "topology" if seeds is None else seeds
+            self.engine = PipelinedCimBatch(topology, batch_num, groups=int(groups), device=device, **ekw)
+        else:
+            self.engine = CimBatchEngine(topology, batch_num, device=device, **ekw)
         self._mode = int(getattr(self.engine, "decision_mode", mode))
         self._init_state(batch_num)
 
@@ -264,8 +273,11 @@ class GpuVectorEnv:
                 # The whole masked batch has stepped (the engine skips an action the reference would reject with an
                 # AssertionError, cim/business_engine.py:731,736, and carries on); the bookkeeping above is complete for
                 # every env, only the INVALID_ACTION bit of the offenders is cleared, and all of them are named.
-                idx = torch.as_tensor(offenders, dtype=torch.int64, device=eng.status.device)
-                eng.status[idx] = eng.status[idx] & ~1
+                if hasattr(eng, "clear_status_bits"):
+                    eng.clear_status_bits(offenders, 1)
+                else:
+                    idx = torch.as_tensor(offenders, dtype=torch.int64, device=eng.status.device)
+                    eng.status[idx] = eng.status[idx] & ~1
                 raise InvalidActionError(f"env(s) {offenders}: invalid action (cim/business_engine.py:731,736); the action was skipped")
         return [out[e] for e in envs]
 

@@ -51,3 +51,29 @@ def test_pipelined_groups_equal_one_engine():
     torch.cuda.synchronize()
     assert torch.equal(bat.cat("decisions"), one.decisions) and torch.equal(bat.cat("metrics"), one.metrics)
     assert torch.equal(bat.cat("done"), one.done) and bool(one.done.all())
+
+
+def test_object_api_on_a_pipelined_batch_on_gpu():
+    """GpuVectorEnv over PipelinedCimBatch (3 HIP engines on 3 streams) == GpuVectorEnv over one engine: VectorEnv.step with
+    list / dict actions, snapshot_list slices, tick / frame_index, set_seed + reset, an invalid action in the last group."""
+    from maro_amd.cim.rollout import PipelinedCimBatch
+    from tests.test_vector_env_api import check_pipelined_object_api
+
+    def grouped(topology, n, **kw):
+        return PipelinedCimBatch(topology, n, groups=3, seeds="topology", **kw)
+    check_pipelined_object_api(gpu_factory, grouped)
+
+
+def test_vector_env_groups_argument_on_gpu():
+    """GpuVectorEnv(..., groups=3) builds the pipelined batch itself; a whole episode equals the single-engine env."""
+    from maro_amd.cim.rollout import PipelinedCimBatch
+    from maro_amd.cim.vector_env import GpuVectorEnv
+    kw = dict(durations=50, seeds=[3, 4, 5, 6, 7], max_actions=1)
+    a, b = GpuVectorEnv(5, "cim", "toy.4p_ssdd_l0.0", **kw), GpuVectorEnv(5, "cim", "toy.4p_ssdd_l0.0", groups=3, **kw)
+    assert isinstance(b.engine, PipelinedCimBatch) and b.engine.sizes == [2, 2, 1]
+    ra, rb = a.step(None), b.step(None)
+    while not ra[2]:
+        assert ra[0] == rb[0] and [None if e is None else (e.tick, e.port_idx, e.vessel_idx) for e in ra[1]] == \
+            [None if e is None else (e.tick, e.port_idx, e.vessel_idx) for e in rb[1]]
+        ra, rb = a.step(None), b.step(None)
+    assert rb[2] and ra[0] == rb[0]

@@ -232,3 +232,64 @@ def test_unknown_scenario_dispatches_to_the_reference_vector_env(monkeypatch):
     assert seen == dict(batch_num=2, scenario="vm_scheduling", topology="azure.2019.10k", start_tick=0, durations=25, decision_mode="joint")
     with pytest.raises(TypeError, match="multiple values"):
         GpuVectorEnv(2, "vm_scheduling", "azure.2019.10k", topology="x")
+
+
+# ---- the object API over a stream-pipelined batch (PipelinedCimBatch as GpuVectorEnv's engine: groups of envs, here 3 + 2 + 2
+# emulator engines; tests/test_gpu_vector_env.py runs the same on HIP engines with their streams)
+def pipelined_emu_factory(groups):
+    def factory(topology, n, **kw):
+        from maro_amd.cim.rollout import PipelinedCimBatch
+        return PipelinedCimBatch(topology, n, groups=groups, device="cpu", engine_factory=emu_factory, seeds="topology", **kw)
+    return factory
+
+
+def check_pipelined_object_api(single_factory, grouped_factory, n=7, steps=60):
+    """A grouped batch behaves exactly like one engine: dict / list actions, an invalid action, seeds, reset, snapshot slices."""
+    import random
+    envs = [GpuVectorEnv(n, "cim", TOPO, durations=80, _engine=f(TOPO, n, max_actions=2, durations=80)) for f in (single_factory, grouped_factory)]
+    rng = random.Random(5)
+
+    def key(ev):
+        return None if ev is None else (ev.tick, ev.port_idx, ev.vessel_idx, ev.action_scope.load, ev.action_scope.discharge)
+
+    def same(ra, rb):
+        assert ra[0] == rb[0] and ra[2] == rb[2] and [key(e) for e in ra[1]] == [key(e) for e in rb[1]]
+
+    last = [env.step(None) for env in envs]
+    same(*last)
+    cur = list(last[0][1])                  # the latest decision event of every env
+    for k in range(steps):
+        if last[0][2]:
+            break
+        acts = [None if ev is None else Action(ev.vessel_idx, ev.port_idx, rng.randint(0, ev.action_scope.load), ActionType.LOAD) for ev in cur]
+        if k % 5 == 4:      # dict form: a subset of the envs steps (one or two per group)
+            sub = sorted(e for e in range(n) if e % 2 == 0)
+            last = [env.step({e: acts[e] for e in sub}) for env in envs]
+            for e, ev in zip(sub, last[0][1]):
+                cur[e] = ev
+        else:
+            last = [env.step(list(acts)) for env in envs]
+            cur = list(last[0][1])
+        same(*last)
+        q = [env.snapshot_list["ports"][::["empty", "full", "shortage"]] for env in envs]
+        for x, y in zip(*q):
+            assert np.array_equal(x, y)
+        assert envs[0].tick == envs[1].tick and envs[0].frame_index == envs[1].frame_index
+    for env in envs:
+        for e in range(n):
+            env.set_seed(11 + e, [e])
+        env.reset(keep_seed=True)
+    a, b = (env.step(None) for env in envs)
+    same(a, b)
+    assert len({key(e) for e in a[1]}) > 1      # different seeds: the envs really diverge
+    # an invalid action in the LAST group is reported for that env only and acknowledged in that group's status word
+    ev = a[1][n - 1]
+    bad = {n - 1: Action(ev.vessel_idx, ev.port_idx, ev.action_scope.discharge + 5, ActionType.DISCHARGE)}
+    for env in envs:
+        with pytest.raises(InvalidActionError, match=str(n - 1)):
+            env.step(dict(bad))
+        assert int(env.engine.status[n - 1]) & 1 == 0
+
+
+def test_object_api_on_a_pipelined_batch_equals_a_single_engine():
+    check_pipelined_object_api(emu_factory, pipelined_emu_factory(3))
