@@ -371,11 +371,13 @@ int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_d
  * element's next state, the deciding agent's previous element's next agent state and terminal flag).  Call it between the
  * policy (mrx_cim_dqn_act, which produced d_state / d_choice / d_actions for d_decisions) and mrx_cim_step.  Per env e:
  *   alive = prev_active[e] && !eoe[e]:  next_state[e][prev_j[e]] = alive ? state[e] : state element prev_j[e] itself (episode over)
- *   active = !eoe[e]:  element j = count[e] <- (tick, deciding port, state[e], choice[e], first action row), terminal = 0;
- *                      the port's previous element last[e][port] gets next_agent_state = state[e], terminal = 0;
- *                      last[e][port] = j; count[e] += 1; n_actions[e] stays; inactive envs get n_actions[e] = 0
- *   prev_j[e] = j, prev_active[e] = active; d_interactions[e] += 1 (int64 [n_envs]: interactions each env has performed).
- * The cache is caller-owned device memory, rows of `cap` elements per env: c_tick int32 [n][cap], c_agent / c_action int64
+ *   active = !eoe[e]:  element number q = count[e] goes to slot j = q & (cap - 1) <- (tick, deciding port, state[e], choice[e],
+ *                      first action row), terminal = 0; the port's previous element last[e][port] (an element NUMBER, -1: none;
+ *                      slot = number & (cap - 1)) gets next_agent_state = state[e], terminal = 0;
+ *                      last[e][port] = q; count[e] += 1; n_actions[e] stays; inactive envs get n_actions[e] = 0
+ *   prev_j[e] = j (a slot), prev_active[e] = active; d_interactions[e] += 1 (int64 [n_envs]: interactions each env has performed).
+ * The cache is caller-owned device memory, a RING of `cap` slots per env (`cap` a power of two; count[e] only ever grows, the
+ * caller tracks how many of the oldest elements it has consumed and must keep count - consumed <= cap): c_tick int32 [n][cap], c_agent / c_action int64
  * [n][cap], c_state / c_next_state / c_next_agent_state [n][cap][state_dim] of float32 (state_f64 = 0) or float64 (1),
  * c_env_action int32 [n][cap][4], c_terminal uint8 [n][cap].  first != 0: no previous step in this call (prev_* are only written).
  */

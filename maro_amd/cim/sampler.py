@@ -54,7 +54,15 @@ class CimBatchSampler:
         return r.to(torch.float32)
 
     # ------------------------------------------------------------------ AbsEnvSampler.sample, batched
+    #: slots per env of a fresh transition cache (a power of two; it doubles when an env's live elements no longer fit)
+    INITIAL_CACHE_SLOTS = 256
+
     def _cache_alloc(self, cap: int) -> None:
+        """The per-env transition cache is a RING of `cap` slots (a power of two): element number q of an env (`_head` counts
+        the elements it has appended, `_tail` the ones it has emitted or dropped) lives in slot q & (cap - 1), so emitting
+        the oldest elements moves `_tail` and nothing else (a linear cache had to shift everything behind them: at 16384 envs
+        x 512 slots that was 17 GB per emission)."""
+        cap = 1 << max(1, int(cap - 1).bit_length())
         n, D, dev = self.eng.n_envs, self.state_dim, self.eng.decisions.device
         old = getattr(self, "_c", None)
         c = dict(tick=torch.zeros((n, cap), dtype=torch.int32, device=dev), agent=torch.zeros((n, cap), dtype=torch.int64, device=dev),
@@ -63,10 +71,14 @@ class CimBatchSampler:
                  next_state=torch.zeros((n, cap, D), dtype=self.state_dtype, device=dev),
                  next_agent_state=torch.zeros((n, cap, D), dtype=self.state_dtype, device=dev),
                  terminal=torch.zeros((n, cap), dtype=torch.bool, device=dev))
-        if old is not None:
+        if old is not None:      # growth: every live element moves to its slot in the larger ring
             k = old["tick"].shape[1]
+            sl = torch.arange(k, device=dev)[None, :]
+            seq = self._tail[:, None] + ((sl - self._tail[:, None]) & (k - 1))     # the element an old slot would hold
+            er, es = torch.nonzero(seq < self._head[:, None], as_tuple=True)
+            ns = seq[er, es] & (cap - 1)
             for key in c:
-                c[key][:, :k] = old[key]
+                c[key][er, ns] = old[key][er, es]
         self._c, self._cap = c, cap
 
     def _sample_init(self, state_dtype) -> None:
@@ -74,9 +86,11 @@ class CimBatchSampler:
         n, dev = eng.n_envs, eng.decisions.device
         assert eng.start_tick == 0 and eng.snapshot_resolution == 1, "the CIM example's shaping indexes snapshots by tick"
         self.state_dtype = state_dtype
-        self._cache_alloc(256)
-        self._count = torch.zeros(n, dtype=torch.int64, device=dev)
-        self._last = torch.full((n, eng.layout.n_ports), -1, dtype=torch.int64, device=dev)   # _agent_last_index
+        self._c = None
+        self._cache_alloc(self.INITIAL_CACHE_SLOTS)
+        self._head = torch.zeros(n, dtype=torch.int64, device=dev)      # elements appended so far (the next element's number)
+        self._tail = torch.zeros(n, dtype=torch.int64, device=dev)      # number of the oldest element still cached
+        self._last = torch.full((n, eng.layout.n_ports), -1, dtype=torch.int64, device=dev)   # _agent_last_index (element numbers)
         self._eoe = torch.ones(n, dtype=torch.bool, device=dev)                               # _end_of_episode
         self._episodes = 0                                   # reset_envs calls so far (diagnostics)
         self._steps_env = torch.zeros(n, dtype=torch.int64, device=dev)   # interactions each env has performed (sample_fused)
@@ -93,6 +107,7 @@ class CimBatchSampler:
         eng, c = self.eng, self._c
         n, cap = c["tick"].shape
         dev = c["tick"].device
+        ring = cap - 1
         rows = torch.nonzero(envs).view(-1)
         if rows.numel() == 0:
             return
@@ -100,14 +115,17 @@ class CimBatchSampler:
         li = self._last[rows]                                   # [m, P]
         has = li >= 0
         r_idx = rows[:, None].expand_as(li)[has]
-        j_idx = li[has]
+        j_idx = li[has] & ring
         c["terminal"][r_idx, j_idx] = self._eoe[r_idx]
         c["next_agent_state"][r_idx, j_idx] = c["state"][r_idx, j_idx]
         # elements old enough for their reward window: tick <= env.tick - reward_eval_delay (ticks are non-decreasing: a prefix)
         tick_now = eng.ticks.to(torch.int64)
         bound = tick_now[rows] - self.reward_eval_delay
         pos = torch.arange(cap, device=dev)[None, :]
-        emit = (pos < self._count[rows, None]) & (c["tick"][rows].to(torch.int64) <= bound[:, None])      # [m, cap]
+        tail = self._tail[rows]
+        slot_of = (tail[:, None] + pos) & ring                            # slot of an env's j-th oldest element   [m, cap]
+        tick_j = torch.gather(c["tick"][rows], 1, slot_of).to(torch.int64)
+        emit = (pos < (self._head[rows] - tail)[:, None]) & (tick_j <= bound[:, None])
         n_emit = emit.sum(dim=1)
         if int(n_emit.sum()) > 0:
             # the frame of the tick an env is paused at is its live frame (pre-decision snapshot, core.py:345): its retention
@@ -116,8 +134,9 @@ class CimBatchSampler:
             if paused.numel() > 0:
                 live = eng.query("ports", tick_now.to(torch.int32).view(n, 1), self._ports, ["fulfillment", "shortage"]).view(n, -1, 2)
                 self._hist[paused, tick_now[paused]] = live[paused].permute(0, 2, 1).to(torch.int32)
-            er, ej = torch.nonzero(emit, as_tuple=True)
+            er, ej = torch.nonzero(emit, as_tuple=True)            # ordered by env, then by age: the reference's emission order
             e_env = rows[er]
+            ej = slot_of[er, ej]
             tick = c["tick"][e_env, ej].to(torch.int64)
             agent = c["agent"][e_env, ej]
             frames = self._hist.shape[1]
@@ -129,15 +148,11 @@ class CimBatchSampler:
             out["reward"].append(reward)
             for key in ("state", "action", "env_action", "next_state", "next_agent_state", "terminal"):
                 out[key].append(c[key][e_env, ej])
-            # pop the emitted prefix
-            shift = (pos + n_emit[:, None]).clamp(max=cap - 1)
-            for key in c:
-                src = c[key][rows]
-                idx = shift if src.dim() == 2 else shift[:, :, None].expand(-1, -1, src.shape[2])
-                c[key][rows] = torch.gather(src, 1, idx)
-            self._count[rows] -= n_emit
+            # pop the emitted prefix: the ring's tail moves on; an agent whose last element went out has none
+            new_tail = tail + n_emit
+            self._tail[rows] = new_tail
             li = self._last[rows]
-            self._last[rows] = torch.where(li >= n_emit[:, None], li - n_emit[:, None], torch.full_like(li, -1))
+            self._last[rows] = torch.where(li >= new_tail[:, None], li, torch.full_like(li, -1))
 
     def sample(self, policy: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], num_steps: Optional[int] = None,
                seeds: Optional[Callable[[int], torch.Tensor]] = None, state_dtype: torch.dtype = torch.float32) -> Dict[str, torch.Tensor]:
@@ -178,7 +193,7 @@ class CimBatchSampler:
             eng.reset(cmd, mask.to(torch.uint8))
             rows = torch.nonzero(mask).view(-1)
             self._hist[rows] = 0
-            self._count[rows] = 0
+            self._tail[rows] = self._head[rows]
             self._last[rows] = -1
             eng.step(mask=mask.to(torch.uint8))          # _step(None): the first decision event
             self._eoe = torch.where(mask, eng.done.to(torch.bool), self._eoe)
@@ -204,11 +219,12 @@ class CimBatchSampler:
             model_action = policy(state, dec).to(torch.int64)
             translate_actions(model_action, dec, state[:, -1].to(torch.float64), dec[:, 5], out=acts)   # vessel remaining_space = last state entry
             nact[:] = active.to(torch.int32)
-            if int(self._count.max()) >= self._cap:
+            if int((self._head - self._tail).max()) >= self._cap:
                 self._cache_alloc(2 * self._cap)
                 c = self._c
             rows = torch.nonzero(active).view(-1)
-            j = self._count[rows]
+            seq = self._head[rows]
+            j = seq & (self._cap - 1)
             agent = dec[rows, 1].to(torch.int64)
             c["tick"][rows, j] = dec[rows, 0]
             c["agent"][rows, j] = agent
@@ -218,10 +234,11 @@ class CimBatchSampler:
             c["terminal"][rows, j] = False
             prev = self._last[rows, agent]               # this agent's previous element gets its next agent state
             hp = prev >= 0
-            c["next_agent_state"][rows[hp], prev[hp]] = state[rows[hp]]
-            c["terminal"][rows[hp], prev[hp]] = False
-            self._last[rows, agent] = j
-            self._count[rows] += 1
+            pslot = prev[hp] & (self._cap - 1)
+            c["next_agent_state"][rows[hp], pslot] = state[rows[hp]]
+            c["terminal"][rows[hp], pslot] = False
+            self._last[rows, agent] = seq
+            self._head[rows] += 1
             eng.step(acts, nact, mask=active.to(torch.uint8))
             self._eoe = torch.where(active, eng.done.to(torch.bool), self._eoe)
             st = self.state().to(self.state_dtype)
@@ -259,7 +276,7 @@ class CimBatchSampler:
         if not hasattr(self, "_c") or self.state_dtype != state_dtype:
             self._sample_init(state_dtype)
         if num_steps is not None:
-            need = int(self._count.max()) + num_steps + 1      # one read per CALL: the cache never has to grow inside the loop
+            need = int((self._head - self._tail).max()) + num_steps + 1      # one read per CALL: the cache never has to grow inside the loop
             if need > self._cap:
                 self._cache_alloc(max(need, 2 * self._cap))
         c = self._c
@@ -275,9 +292,8 @@ class CimBatchSampler:
             self._episodes += 1
             self._ep_env += mask.cpu().to(torch.int64)
             eng.reset(cmd, mask.to(torch.uint8))
-            m64 = mask.to(torch.int64)
             self._hist[mask] = 0
-            self._count.mul_(1 - m64)
+            self._tail.copy_(torch.where(mask, self._head, self._tail))
             self._last[mask] = -1
             eng.step(mask=mask.to(torch.uint8))          # _step(None): the first decision event
             self._eoe = torch.where(mask, eng.done.to(torch.bool), self._eoe)
@@ -313,7 +329,7 @@ class CimBatchSampler:
                     c = self._c
                 actor.act(acts, nact, decisions=eng.decisions, state=st_buf, choice=ch_buf)
                 _lib.check(rec(n, eng.layout.n_ports, self.state_dim, self._cap, eng.max_actions, f64, first, eng.decisions.data_ptr(), st_buf.data_ptr(),
-                               ch_buf.data_ptr(), acts.data_ptr(), nact.data_ptr(), self._eoe.data_ptr(), self._count.data_ptr(), self._last.data_ptr(),
+                               ch_buf.data_ptr(), acts.data_ptr(), nact.data_ptr(), self._eoe.data_ptr(), self._head.data_ptr(), self._last.data_ptr(),
                                pj_t.data_ptr(), pa_t.data_ptr(), c["tick"].data_ptr(), c["agent"].data_ptr(), c["state"].data_ptr(), c["action"].data_ptr(),
                                c["env_action"].data_ptr(), c["terminal"].data_ptr(), c["next_state"].data_ptr(), c["next_agent_state"].data_ptr(),
                                self._steps_env.data_ptr(), dev.index if dev.index is not None else torch.cuda.current_device(), eng._stream()),
@@ -329,7 +345,7 @@ class CimBatchSampler:
             if num_steps is None:                          # "until the end of every env's episode": one flag read per step
                 if bool(self._eoe.all()):
                     break
-                if int(self._count.max()) >= self._cap:
+                if int((self._head - self._tail).max()) >= self._cap:
                     self._cache_alloc(2 * self._cap)
                     c = self._c
             else:
@@ -351,7 +367,7 @@ class CimBatchSampler:
                 cur = c["state"][ar, pj]
                 c["next_state"][ar, pj] = torch.where(still[:, None], state, torch.where(prev_active[:, None], cur, c["next_state"][ar, pj]))
             a1 = active[:, None]
-            j = self._count.clamp(max=self._cap - 1)
+            j = self._head & (self._cap - 1)
             agent = dec[:, 1].to(torch.int64).clamp(min=0)
             c["tick"][ar, j] = torch.where(active, dec[:, 0], c["tick"][ar, j])
             c["agent"][ar, j] = torch.where(active, agent, c["agent"][ar, j])
@@ -361,11 +377,11 @@ class CimBatchSampler:
             c["terminal"][ar, j] = torch.where(active, torch.zeros_like(active), c["terminal"][ar, j])
             prev = self._last[ar, agent]                 # this agent's previous element gets its next agent state
             hp = active & (prev >= 0)
-            pz = prev.clamp(min=0)
+            pz = prev.clamp(min=0) & (self._cap - 1)
             c["next_agent_state"][ar, pz] = torch.where(hp[:, None], state, c["next_agent_state"][ar, pz])
             c["terminal"][ar, pz] = torch.where(hp, torch.zeros_like(hp), c["terminal"][ar, pz])
-            self._last[ar, agent] = torch.where(active, j, self._last[ar, agent])
-            self._count += active.to(torch.int64)
+            self._last[ar, agent] = torch.where(active, self._head, self._last[ar, agent])
+            self._head += active.to(torch.int64)
             self._steps_env += active.to(torch.int64)
             eng.step(acts, nact, mask=active.to(torch.uint8))
             self._eoe = torch.where(active, eng.done.to(torch.bool), self._eoe)

@@ -1382,7 +1382,7 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
     g_priv[PH_CUR_VESSEL] = v2;
     g_priv[PH_OPNUM_LO] = (int32_t)(uint32_t)((unsigned long long)opnum & 0xffffffffull);
     g_priv[PH_OPNUM_HI] = (int32_t)(opnum >> 32);
-    K.hint[env] = (pend_after & ~(1ull << v2)) ? 0 : 1;  // answering v2 leaves another decision of this tick pending: fast again
+    K.hint[env] = (pend_after & ~(1ull << v2)) ? 0 : ((flags & FL_LONG) ? 2 : 1);  // answering v2 leaves another decision of this tick pending: fast again
     if (status) wave::global_or(&K.status[env], status);  // fire-and-forget: a read-modify-write would wait for every store in flight
   }
   return true;
@@ -1491,7 +1491,7 @@ MRX_DEV bool fast_step_lane(const CimParams& K, const CimObs& O, int env, const 
   g_priv[PH_CUR_VESSEL] = v2;
   g_priv[PH_OPNUM_LO] = (int32_t)(uint32_t)((unsigned long long)opnum & 0xffffffffull);
   g_priv[PH_OPNUM_HI] = (int32_t)(opnum >> 32);
-  K.hint[env] = (pend_after & ~(1ull << v2)) ? 0 : 1;
+  K.hint[env] = (pend_after & ~(1ull << v2)) ? 0 : ((flags & FL_LONG) ? 2 : 1);
   if (status) wave::global_or(&K.status[env], status);
   return true;
 }
@@ -1814,9 +1814,19 @@ MRX_DEV StepEnd body_run(const CimParams& K, const CimObs& O, int env, Lds& L, c
   // the coming step of this env: fast path iff (Sequential mode and) answering dec_v leaves another decision of the
   // tick pending, or the episode is over (the fast path reports "finished"); else a tick will run -> full path
   out.hint = (KD(decision_mode) == 0 && !MRX_UNALIGNED_FRAMES && (finished || (pend & ~(1ull << (dec_v & 63))))) ? 0 : 1;
+  // ... and how long that full-path step will be: it runs to the next arrival (every arrival raises a decision), which the vessel
+  // schedule already holds — a sailing vessel's next event is its arrival, a parked one's next arrival is cached in V_NEXT.  Steps
+  // of two ticks or more (one in nine on global_trade.22p) are put at the head of the launch (hint 2; mrx_k_cim_schedule), and the
+  // flag travels in the header so the fast-path steps in between can hand it on.  Scheduling only: results do not depend on it.
+  bool long_next = false;
+  if (KD(start_tick) == 0 && !finished) {
+    const bool soon = lane < V && (FV(VA_IS_PARKING, lane) ? V_NEXT(lane) : V_EVT(lane)) <= t + 1;
+    long_next = wave::ballot(soon) == 0ull;
+  }
+  if (long_next && out.hint) out.hint = 2;
   if (lane == 0) {
     L.priv[PH_TICK] = t;
-    L.priv[PH_FLAGS] = finished ? FL_FINISHED : 0;
+    L.priv[PH_FLAGS] = finished ? FL_FINISHED : (long_next ? FL_LONG : 0);
     L.priv[PH_PEND_LO] = (int32_t)(uint32_t)(pend & 0xffffffffull);
     L.priv[PH_PEND_HI] = (int32_t)(uint32_t)(pend >> 32);
     L.priv[PH_CUR_VESSEL] = dec_v;

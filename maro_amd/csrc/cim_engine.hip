@@ -28,79 +28,85 @@
 
 #include "cim_dqn.h"
 
-// Order list of the coming step (CimParams::order / sched): the envs whose step needs the full path (hint = 1: a tick
+// Order list of the coming step (CimParams::order / sched): the envs whose step needs the full path (hint != 0: a tick
 // will run, or the episode starts) first — those are the long waves, so they start first and the short fast-path steps
-// fill the tail of the launch — then the fast-hinted ones, each class in env order; masked-out envs are left out and the
-// rest of the list is -1.  One workgroup: thread t owns envs [t * per, (t + 1) * per), a block-wide exclusive scan of
-// the two class counts gives its output offsets.  16384 envs: one 16-byte load per thread.
-// bit b of the result = byte b of the 16-byte piece is non-zero
-__device__ __forceinline__ unsigned mrx_nz16(uint4 v) {
-  auto nib = [](unsigned w) { return ((((w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u) * 0x01020408u) >> 24; };
+// fill the tail of the launch — and among them the ones that will run two ticks or more (hint 2) at the very head (longest
+// first; lpt = 0 folds them into the others), then the fast-hinted ones, each class in env order; masked-out envs are left out
+// and the rest of the list is -1.  One workgroup: thread t owns envs [t * per, (t + 1) * per), a block-wide exclusive scan of
+// the class counts gives its output offsets.  16384 envs: one 16-byte load per thread.
+// bit b of the result = byte b of the 16-byte piece has a bit of `m` (a byte mask repeated four times) set
+__device__ __forceinline__ unsigned mrx_nz16(uint4 v, unsigned m = 0xffffffffu) {
+  auto nib = [m](unsigned w) { w &= m; return ((((w | ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u) * 0x01020408u) >> 24; };
   return nib(v.x) | (nib(v.y) << 4) | (nib(v.z) << 8) | (nib(v.w) << 12);
 }
 
 __device__ __forceinline__ void mrx_schedule_block(const uint8_t* __restrict__ hint, const uint8_t* __restrict__ mask, int mask_vec, int n, int per,
-                                                   int32_t* __restrict__ order, int32_t* __restrict__ sched) {
-  __shared__ int s_t[16], s_f[16];
+                                                   int32_t* __restrict__ order, int32_t* __restrict__ sched, int lpt) {
+  __shared__ int s_l[16], s_t[16], s_f[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lo = tid * per, hi = lo + per < n ? lo + per : n;  // per is a multiple of 16; the hint array is padded to whole pieces
-  // the two classes of a 16-env piece as bit masks
-  auto piece = [&](int p0, unsigned& t, unsigned& f) {
+  // the three classes of a 16-env piece as bit masks
+  auto piece = [&](int p0, unsigned& l, unsigned& t, unsigned& f) {
     const unsigned valid = p0 + 16 <= n ? 0xffffu : ((1u << (n - p0)) - 1u);
-    const unsigned tk = mrx_nz16(*(const uint4*)(hint + p0));
+    const uint4 hv = *(const uint4*)(hint + p0);
+    const unsigned tk = mrx_nz16(hv), lg = lpt ? mrx_nz16(hv, 0x02020202u) : 0u;
     unsigned on = 0xffffu;
     if (mask) {
       if (mask_vec && p0 + 16 <= n) on = mrx_nz16(*(const uint4*)(mask + p0));
       else { on = 0; for (int b = 0; b < 16 && p0 + b < n; b++) on |= mask[p0 + b] ? (1u << b) : 0u; }
     }
-    t = tk & on & valid;
+    l = lg & on & valid;
+    t = tk & ~lg & on & valid;
     f = ~tk & on & valid;
   };
   // pass 1: class counts of this thread's envs (kept as bit masks when the thread owns at most 64 envs)
-  int ct = 0, cf = 0;
-  unsigned long long bt = 0, bf = 0;
+  int cl = 0, ct = 0, cf = 0;
+  unsigned long long bl = 0, bt = 0, bf = 0;
   const bool small = per <= 64;
   for (int p0 = lo; p0 < hi; p0 += 16) {
-    unsigned t, f;
-    piece(p0, t, f);
-    ct += __builtin_popcount(t); cf += __builtin_popcount(f);
-    if (small) { bt |= (unsigned long long)t << (p0 - lo); bf |= (unsigned long long)f << (p0 - lo); }
+    unsigned l, t, f;
+    piece(p0, l, t, f);
+    cl += __builtin_popcount(l); ct += __builtin_popcount(t); cf += __builtin_popcount(f);
+    if (small) { bl |= (unsigned long long)l << (p0 - lo); bt |= (unsigned long long)t << (p0 - lo); bf |= (unsigned long long)f << (p0 - lo); }
   }
   // block-wide exclusive scans
-  int it = ct, jf = cf;
+  int il = cl, it = ct, jf = cf;
   for (int d = 1; d < 64; d <<= 1) {
-    const int u = __shfl_up(it, d, 64), v = __shfl_up(jf, d, 64);
-    if (lane >= d) { it += u; jf += v; }
+    const int w = __shfl_up(il, d, 64), u = __shfl_up(it, d, 64), v = __shfl_up(jf, d, 64);
+    if (lane >= d) { il += w; it += u; jf += v; }
   }
-  if (lane == 63) { s_t[wid] = it; s_f[wid] = jf; }
+  if (lane == 63) { s_l[wid] = il; s_t[wid] = it; s_f[wid] = jf; }
   __syncthreads();
-  int base_t = 0, base_f = 0, tot_t = 0, tot_f = 0;
+  int base_l = 0, base_t = 0, base_f = 0, tot_l = 0, tot_t = 0, tot_f = 0;
   const int n_waves = (int)(blockDim.x >> 6);   // (any multiple of 64 threads up to 1024)
   for (int w = 0; w < n_waves; w++) {
-    if (w < wid) { base_t += s_t[w]; base_f += s_f[w]; }
-    tot_t += s_t[w]; tot_f += s_f[w];
+    if (w < wid) { base_l += s_l[w]; base_t += s_t[w]; base_f += s_f[w]; }
+    tot_l += s_l[w]; tot_t += s_t[w]; tot_f += s_f[w];
   }
-  int ot = base_t + it - ct, of = tot_t + base_f + jf - cf;
+  int ol = base_l + il - cl, ot = tot_l + base_t + it - ct, of = tot_l + tot_t + base_f + jf - cf;
   // pass 2: write the entries
   if (small) {
+    for (unsigned long long m = bl; m; m &= m - 1) order[ol++] = (lo + __builtin_ctzll(m)) | MRX_ORDER_TICK;
     for (unsigned long long m = bt; m; m &= m - 1) order[ot++] = (lo + __builtin_ctzll(m)) | MRX_ORDER_TICK;
     for (unsigned long long m = bf; m; m &= m - 1) order[of++] = lo + __builtin_ctzll(m);
   } else {
     for (int p0 = lo; p0 < hi; p0 += 16) {
-      unsigned t, f;
-      piece(p0, t, f);
+      unsigned l, t, f;
+      piece(p0, l, t, f);
+      for (; l; l &= l - 1) order[ol++] = (p0 + __builtin_ctz(l)) | MRX_ORDER_TICK;
       for (; t; t &= t - 1) order[ot++] = (p0 + __builtin_ctz(t)) | MRX_ORDER_TICK;
       for (; f; f &= f - 1) order[of++] = p0 + __builtin_ctz(f);
     }
   }
-  for (int i = tot_t + tot_f + tid; i < n; i += (int)blockDim.x) order[i] = -1;
-  if (tid < 16) sched[tid] = tid == 0 ? tot_t : tid == 1 ? tot_t + tot_f : tid >= 8 ? -1 : 0;  // [4..7] = 0, [8..11] = -1: dummies of cim::regs_load
+  const int n_full = tot_l + tot_t;
+  for (int i = n_full + tot_f + tid; i < n; i += (int)blockDim.x) order[i] = -1;
+  if (tid < 16) sched[tid] = tid == 0 ? n_full : tid == 1 ? n_full + tot_f : tid >= 8 ? -1 : 0;  // [4..7] = 0, [8..11] = -1: dummies of cim::regs_load
 }
 
 extern "C" __global__ void __launch_bounds__(1024)
 mrx_k_cim_schedule(const uint8_t* __restrict__ hint, const uint8_t* __restrict__ mask, int mask_vec, int n, int per, int32_t* __restrict__ order,
-                   int32_t* __restrict__ sched) {
-  mrx_schedule_block(hint, mask, mask_vec, n, per, order, sched);
+                   int32_t* __restrict__ sched, int lpt) {
+  mrx_schedule_block(hint, mask, mask_vec, n, per, order, sched, lpt);
 }
 
 struct AttrList { int n; int32_t id[16]; };
@@ -136,7 +142,7 @@ extern "C" __global__ void __launch_bounds__(256)
 mrx_k_cim_random_policy(CimParams K, const int32_t* __restrict__ decisions, long long step, int32_t* __restrict__ actions,
                         int32_t* __restrict__ n_actions, unsigned long long* __restrict__ counter, int sched_per) {
   if (sched_per > 0 && blockIdx.x == 0) {
-    mrx_schedule_block((const uint8_t*)K.hint, nullptr, 0, K.n_envs, sched_per, K.order, K.sched);
+    mrx_schedule_block((const uint8_t*)K.hint, nullptr, 0, K.n_envs, sched_per & 0xffffff, K.order, K.sched, sched_per >> 24);
     return;
   }
   const int env = (int)((blockIdx.x - (sched_per > 0 ? 1 : 0)) * blockDim.x + threadIdx.x);
@@ -164,17 +170,20 @@ mrx_k_cim_random_policy(CimParams K, const int32_t* __restrict__ decisions, long
 }
 
 // The batched EnvSampler's per-step cache update (mrx_cim_sampler_record): one wave per env, lanes over the state vector.
+// The cache of an env is a ring of `cap` slots (a power of two): `head[e]` numbers the elements the env has appended, element q
+// lives in slot q & (cap - 1); `last` holds element numbers (-1: none), `prev_j` the SLOT written by the previous step.
 template <class T>
 __global__ void __launch_bounds__(64)
 mrx_k_cim_sampler_record(int n, int P, int D, int cap, int A, int first, const int32_t* __restrict__ dec, const float* __restrict__ state,
                          const int32_t* __restrict__ choice, const int32_t* __restrict__ acts, int32_t* __restrict__ nact, const uint8_t* __restrict__ eoe,
-                         long long* __restrict__ count, long long* __restrict__ last, long long* __restrict__ prev_j, uint8_t* __restrict__ prev_active,
+                         long long* __restrict__ head, long long* __restrict__ last, long long* __restrict__ prev_j, uint8_t* __restrict__ prev_active,
                          int32_t* __restrict__ c_tick, long long* __restrict__ c_agent, T* __restrict__ c_state, long long* __restrict__ c_action,
                          int32_t* __restrict__ c_env_action, uint8_t* __restrict__ c_terminal, T* __restrict__ c_next_state, T* __restrict__ c_nas,
                          long long* __restrict__ steps_env) {
   const int e = (int)blockIdx.x, lane = (int)threadIdx.x;
   const bool over = eoe[e] != 0;
   const float* st = state + (size_t)e * D;
+  const long long ring = (long long)cap - 1;
   if (!first && prev_active[e]) {  // the element of the previous step: its next state is this state, or (episode over) its own
     const long long pj = prev_j[e];
     T* ns = c_next_state + ((size_t)e * cap + pj) * D;
@@ -185,15 +194,14 @@ mrx_k_cim_sampler_record(int n, int P, int D, int cap, int A, int first, const i
     if (lane == 0) { nact[e] = 0; prev_active[e] = 0; }
     return;
   }
-  long long j = count[e];
-  if (j > cap - 1) j = cap - 1;
+  const long long q = head[e], j = q & ring;
   int agent = dec[(size_t)e * 8 + 1];
   agent = agent < 0 ? 0 : (agent >= P ? P - 1 : agent);
-  const long long prev = last[(size_t)e * P + agent];
+  const long long prev = last[(size_t)e * P + agent], pslot = prev & ring;
   T* cs = c_state + ((size_t)e * cap + j) * D;
   for (int d = lane; d < D; d += 64) cs[d] = (T)st[d];
   if (prev >= 0) {
-    T* na = c_nas + ((size_t)e * cap + prev) * D;
+    T* na = c_nas + ((size_t)e * cap + pslot) * D;
     for (int d = lane; d < D; d += 64) na[d] = (T)st[d];
   }
   if (lane < 4) c_env_action[((size_t)e * cap + j) * 4 + lane] = acts[(size_t)e * A * 4 + lane];
@@ -202,9 +210,9 @@ mrx_k_cim_sampler_record(int n, int P, int D, int cap, int A, int first, const i
     c_agent[(size_t)e * cap + j] = agent;
     c_action[(size_t)e * cap + j] = choice[e];
     c_terminal[(size_t)e * cap + j] = 0;
-    if (prev >= 0) c_terminal[(size_t)e * cap + prev] = 0;
-    last[(size_t)e * P + agent] = j;
-    count[e] = count[e] + 1;
+    if (prev >= 0) c_terminal[(size_t)e * cap + pslot] = 0;
+    last[(size_t)e * P + agent] = q;
+    head[e] = q + 1;
     prev_j[e] = j;
     prev_active[e] = 1;
     steps_env[e] += 1;   // (per env: a single shared counter would serialise 16384 atomics per step)
@@ -261,6 +269,7 @@ struct mrx_cim_engine {
   int loop_waves = 0;                     // grid of the looped full-path kernel (generic or specialised build in use)
   int step_mode = 0;                      // mrx_cim_set_step_mode (0 = automatic)
   bool order_ready = false;               // the order list of the coming step was built by the policy launch (no mask)
+  int lpt = 1;                            // longest-first inside the full-path class of the sorted launch (MRX_CIM_LPT=0: off)
   void* order_stream = nullptr;           // ... on this stream: a step issued on another stream is not ordered behind that launch
   // Kernels of a module may still be queued or running on the caller's stream(s): drain the device before unloading it.
   void unload_spec() {
@@ -330,6 +339,7 @@ int mrx_cim_create(const mrx_cim_topology* topo, const mrx_cim_config* cfg, void
   std::string err;
   int rc = cim_plan(topo, cfg, &e->plan, &err);
   if (rc != MRX_OK) { delete e; return set_err(rc, err); }
+  if (const char* ev = getenv("MRX_CIM_LPT")) e->lpt = atoi(ev) ? 1 : 0;  // experiments
   if (!d_workspace || workspace_bytes < e->plan.workspace_bytes || ((uintptr_t)d_workspace & 255)) {
     delete e;
     return set_err(MRX_ERR_WORKSPACE, "workspace is null, smaller than mrx_cim_workspace_bytes() or not 256-byte aligned");
@@ -454,7 +464,7 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
   if (mode >= 2 && !have_order) {
     const int per = ((K.n_envs + 1023) / 1024 + 15) / 16 * 16;  // envs per thread, whole 16-byte pieces
     hipLaunchKernelGGL(mrx_k_cim_schedule, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const uint8_t*)K.hint, d_env_mask,
-                       ((uintptr_t)d_env_mask & 15) ? 0 : 1, K.n_envs, per, K.order, K.sched);
+                       ((uintptr_t)d_env_mask & 15) ? 0 : 1, K.n_envs, per, K.order, K.sched, h->lpt);
   }
   const int sorted = mode >= 2 ? 1 : 0;
   const size_t lds_bytes = (size_t)K.lds_words * 4 + lds_pad;
@@ -567,7 +577,7 @@ int mrx_cim_random_policy(mrx_handle h, const int32_t* d_decisions, int64_t step
   // (256-thread workgroups: a 1024-thread one needs 16 free wave slots on ONE CU at once and waits for them behind the step kernels)
   const int sched_per = (fuse && effective_step_mode(h) >= 2) ? ((K.n_envs + 255) / 256 + 15) / 16 * 16 : 0;
   hipLaunchKernelGGL(mrx_k_cim_random_policy, dim3((K.n_envs + 255) / 256 + (sched_per > 0 ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, K,
-                     d_decisions, (long long)step, d_actions, d_n_actions, (unsigned long long*)d_counter, sched_per);
+                     d_decisions, (long long)step, d_actions, d_n_actions, (unsigned long long*)d_counter, sched_per | (h->lpt << 24));
   HIP_TRY(hipGetLastError());
   h->order_ready = sched_per > 0;
   h->order_stream = stream;
@@ -763,6 +773,7 @@ int mrx_cim_sampler_record(int32_t n_envs, int32_t n_ports, int32_t state_dim, i
                            int32_t* c_tick, int64_t* c_agent, void* c_state, int64_t* c_action, int32_t* c_env_action, uint8_t* c_terminal,
                            void* c_next_state, void* c_next_agent_state, int64_t* d_interactions, int32_t device, void* stream) {
   if (n_envs <= 0 || n_ports <= 0 || state_dim <= 0 || cap <= 0 || max_actions <= 0) return set_err(MRX_ERR_INVALID_ARG, "dimensions must be positive");
+  if (cap & (cap - 1)) return set_err(MRX_ERR_INVALID_ARG, "cap (slots of an env's transition ring) must be a power of two");
   if (!d_decisions || !d_state || !d_choice || !d_actions || !d_n_actions || !d_eoe || !d_count || !d_last || !d_prev_j || !d_prev_active || !c_tick ||
       !c_agent || !c_state || !c_action || !c_env_action || !c_terminal || !c_next_state || !c_next_agent_state || !d_interactions)
     return set_err(MRX_ERR_INVALID_ARG, "null pointer");

@@ -15,7 +15,7 @@ enum { MA_FULL_ON_PORTS, MA_FULL_ON_VESSELS, MA_VESSEL_PLANS, MA_COUNT };
 enum { PH_TICK, PH_FLAGS, PH_PEND_LO, PH_PEND_HI, PH_CUR_VESSEL, PH_OPNUM_LO, PH_OPNUM_HI, PH_IDX_ORDER,
        PH_IDX_BUFFER, PH_IDX_ROUTE, PH_ZOMBIE_LO, PH_ZOMBIE_HI /* start_tick > 0: vessels whose first departure fell before start_tick */,
        PH_ACCB_LO, PH_ACCB_HI, PH_ACCS_LO, PH_ACCS_HI /* cached metrics: sums of acc_booking / acc_shortage */, PH_COUNT = 16 };
-enum { FL_FRESH = 1, FL_FINISHED = 2 };
+enum { FL_FRESH = 1, FL_FINISHED = 2, FL_LONG = 4 /* the env's next full-path step will advance two ticks or more (scheduling only) */ };
 
 #define MT_WORDS 624
 enum { MTS_ORDER = 0, MTS_BUFFER = 1, MTS_ROUTE = 2, MTS_COUNT = 3 };

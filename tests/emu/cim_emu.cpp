@@ -66,11 +66,13 @@ void emu_reset(void* h, const int64_t* seed_cmd, const uint8_t* mask, int revers
   }
 }
 
-// the host twin of mrx_k_cim_schedule (cim_engine.hip): full-path envs first, then the fast-hinted ones, -1 padded
+// the host twin of mrx_k_cim_schedule (cim_engine.hip): full-path envs first (the long ones, hint 2, at the head), then the
+// fast-hinted ones, -1 padded
 static void emu_schedule(Emu* e, const uint8_t* mask) {
   const CimParams& K = e->plan.kp;
   int nt = 0, na = 0;
-  for (int env = 0; env < K.n_envs; env++) if ((!mask || mask[env]) && K.hint[env]) K.order[nt++] = env | MRX_ORDER_TICK;
+  for (int env = 0; env < K.n_envs; env++) if ((!mask || mask[env]) && (K.hint[env] & 2)) K.order[nt++] = env | MRX_ORDER_TICK;
+  for (int env = 0; env < K.n_envs; env++) if ((!mask || mask[env]) && K.hint[env] && !(K.hint[env] & 2)) K.order[nt++] = env | MRX_ORDER_TICK;
   na = nt;
   for (int env = 0; env < K.n_envs; env++) if ((!mask || mask[env]) && !K.hint[env]) K.order[na++] = env;
   for (int i = na; i < K.n_envs; i++) K.order[i] = -1;

@@ -189,6 +189,23 @@ def test_divergent_episodes_in_one_batch_equal_single_env_runs(fused):
                 assert np.array_equal(rb[key].numpy()[sel], rs[key].numpy()), (e, key)
 
 
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("case,slots", [("toy5p_l05_rollover", 2), ("gt22p_l08", 8), ("toy4p_l00_rollover", 4)])
+def test_transition_ring_wraps_and_grows(case, slots, fused, monkeypatch):
+    """The per-env transition cache is a ring: started with a few slots it wraps around many times and doubles whenever an
+    env's live elements no longer fit — the emitted experiences stay the reference's."""
+    monkeypatch.setattr(CimBatchSampler, "INITIAL_CACHE_SLOTS", slots)
+    grown = []
+    orig = CimBatchSampler._cache_alloc
+
+    def spy(self, cap):
+        grown.append(cap)
+        return orig(self, cap)
+    monkeypatch.setattr(CimBatchSampler, "_cache_alloc", spy)
+    run_sample_case(emu_factory, case, fused=fused)
+    assert len(grown) >= 3 and grown[0] == slots, grown
+
+
 @pytest.mark.gpu
 def test_fused_collect_loop_with_the_fused_dqn_on_gpu():
     """bench.py --policy dqn --collect's loop (sample_fused + FusedPerPortDQN.act) against the unfused sample() driven by the SAME
@@ -223,11 +240,16 @@ def test_fused_collect_loop_with_the_fused_dqn_on_gpu():
         return out
 
     ref, f1, f32 = run("unfused"), run(1), run(32)
+    CimBatchSampler.INITIAL_CACHE_SLOTS, keep = 16, CimBatchSampler.INITIAL_CACHE_SLOTS
+    try:
+        small = run(1)            # the record kernel on a ring that wraps and is re-allocated between the calls
+    finally:
+        CimBatchSampler.INITIAL_CACHE_SLOTS = keep
     keys = ("env_id", "tick", "agent", "state", "action", "env_action", "reward", "terminal", "next_state", "next_agent_state")
     total = 0
-    for r, f in zip(ref, f1):
+    for r, f, g in zip(ref, f1, small):
         for key in keys:
-            assert torch.equal(r[key], f[key]), key
+            assert torch.equal(r[key], f[key]) and torch.equal(r[key], g[key]), key
         total += len(r["tick"])
     assert total > 1000
 
