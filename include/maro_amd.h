@@ -221,6 +221,8 @@ int mrx_cim_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_n_acti
  *      short ones fill the tail of the launch, and a full-path wave skips the header round trip;
  *   4  the step split in two kernels: the fast-path envs one per LANE in a small kernel without LDS, then the full-path list
  *      walked by as many workgroups as the device holds at once;
+ *   5  the fast-path kernel of 4, then one workgroup per entry of the full-path list as in 2 (fast-hinted envs never occupy an
+ *      LDS-carrying workgroup);
  *   0  automatic (default): 2 (measured fastest on MI355X at the benchmark's batch sizes).
  * (3 was round 2's persistent pipelined kernel — measured slower than 2 and removed; the value is accepted and means 2.)
  * Returns the mode the next step will actually use (>= 1), or a negative mrx_status.

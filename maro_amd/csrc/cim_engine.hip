@@ -432,9 +432,10 @@ int mrx_cim_step_joint(mrx_handle h, const int32_t* d_actions, const int32_t* d_
 static int effective_step_mode(mrx_handle h) {
   static const int env_mode = getenv("MRX_CIM_STEP_MODE") ? atoi(getenv("MRX_CIM_STEP_MODE")) : 0;  // experiments
   int m = h->step_mode ? h->step_mode : env_mode;
-  if (m < 1 || m > 4) m = 2;  // measured (profiles/r02_*): the sorted launch is the fastest form at 16384 envs per GPU
+  if (m < 1 || m > 5) m = 2;  // measured (profiles/r02_*): the sorted launch is the fastest form at 16384 envs per GPU
   if (m == 3) m = 2;  // (3 was the persistent pipelined kernel of round 2: measured slower than the sorted launch, removed in round 3)
   if (m == 4 && h->spec_module && !(h->spec_fast && h->spec_loop)) m = 2;
+  if (m == 5 && h->spec_module && !h->spec_fast) m = 2;
   return m;
 }
 
@@ -466,7 +467,7 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
     hipLaunchKernelGGL(mrx_k_cim_schedule, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const uint8_t*)K.hint, d_env_mask,
                        ((uintptr_t)d_env_mask & 15) ? 0 : 1, K.n_envs, per, K.order, K.sched, h->lpt);
   }
-  const int sorted = mode >= 2 ? 1 : 0;
+  const int sorted = mode == 5 ? 2 : mode >= 2 ? 1 : 0;
   const size_t lds_bytes = (size_t)K.lds_words * 4 + lds_pad;
   if (mode == 4) {
     // the fast-hinted envs, one per lane, no LDS; then the full-path list on as many workgroups as are resident at once
@@ -494,6 +495,23 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
     HIP_TRY(hipGetLastError());
     return MRX_OK;
   }
+  if (mode == 5) {
+    // launch form 5: the fast-hinted envs one per lane without LDS (as in form 4; what it cannot handle joins the full-path list),
+    // then one workgroup per entry of the full-path list (as in form 2)
+    const unsigned fast_blocks = (unsigned)((K.n_envs + 63) / 64);
+    if (h->spec_module) {
+      CimParams Kc = K;
+      CimObs Oc = h->obs;
+      void* pf[] = {&Kc, &Oc, &B, &d_env_mask};
+      HIP_TRY(hipModuleLaunchKernel(h->spec_fast, fast_blocks, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, pf, nullptr));
+    } else if (K.pregen) {
+      if (obs) hipLaunchKernelGGL(mrx_k_cim_fast_lanes_tab_obs, dim3(fast_blocks), dim3(64), 0, (hipStream_t)stream, K, h->obs, B, d_env_mask);
+      else hipLaunchKernelGGL(mrx_k_cim_fast_lanes_tab, dim3(fast_blocks), dim3(64), 0, (hipStream_t)stream, K, h->obs, B, d_env_mask);
+    } else {
+      if (obs) hipLaunchKernelGGL(mrx_k_cim_fast_lanes_obs, dim3(fast_blocks), dim3(64), 0, (hipStream_t)stream, K, h->obs, B, d_env_mask);
+      else hipLaunchKernelGGL(mrx_k_cim_fast_lanes, dim3(fast_blocks), dim3(64), 0, (hipStream_t)stream, K, h->obs, B, d_env_mask);
+    }
+  }
   if (h->spec_module) {
     CimParams Kc = K;
     CimObs Oc = h->obs;
@@ -512,7 +530,7 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
 
 int mrx_cim_set_step_mode(mrx_handle h, int mode) {
   if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
-  if (mode < 0 || mode > 4) return set_err(MRX_ERR_INVALID_ARG, "step mode must be 0 (automatic), 1, 2, 3 or 4");
+  if (mode < 0 || mode > 5) return set_err(MRX_ERR_INVALID_ARG, "step mode must be 0 (automatic), 1, 2, 4 or 5");
   h->step_mode = mode;
   return effective_step_mode(h);
 }

@@ -24,7 +24,8 @@ mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const
 // One env per WAVE, MRX_WG_WAVES waves per workgroup (1 in the generic build; the plan's wg_waves in a specialised one: the
 // waves share the staged topology tables and nothing else).  sorted = 0: wave s steps env s (the fast rows and the env's hint
 // are read first); sorted = 1: wave s steps entry s of the order list of this step (mrx_k_cim_schedule: full-path envs first,
-// so the long waves start first and the short ones fill the tail; a full-path entry skips the header round trip).
+// so the long waves start first and the short ones fill the tail; a full-path entry skips the header round trip); sorted = 2
+// (launch form 5): only the full-path entries [0, sched[0]) — the fast-hinted envs were stepped by mrx_k_cim_fast_lanes.
 #ifdef MRX_SPECIALIZED
 #define MRX_WG_WAVES MRXC_wg_waves
 #else
@@ -39,6 +40,7 @@ mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const
     if (MRX_WG_WAVES > 1 && slot >= K.n_envs) return;                                                                   \
     int env = slot, path = cim::PATH_PROBE;                                                                             \
     if (sorted) {                                                                                                       \
+      if (sorted == 2 && slot >= K.sched[0]) return; /* launch form 5: only the full-path list (the fast kernel ran) */  \
       const int e = K.order[slot];                                                                                      \
       if (e < 0) return;                                                                                                \
       env = e & (MRX_ORDER_TICK - 1);                                                                                   \

@@ -80,7 +80,7 @@ static void emu_schedule(Emu* e, const uint8_t* mask) {
 }
 
 // mode 1: unsorted (workgroup b = env b, hint probed); 2: sorted one-env-per-workgroup launch; 4: split step, its looped
-// full-path kernel with `pipe_waves` waves
+// full-path kernel with `pipe_waves` waves; 5: the fast kernel of 4 + one workgroup per full-path entry
 void emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const uint8_t* mask, int32_t* dec,
               int64_t* met, uint8_t* done, int reverse, const int32_t* n_answered, int mode, int pipe_waves) {
   Emu* e = (Emu*)h;
@@ -104,9 +104,17 @@ void emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const u
     }
     return;
   }
+  if (mode == 5) {  // the fast kernel of form 4, then one workgroup per entry of the full-path list
+    for (int b0 = 0; b0 < K.n_envs; b0 += 64)
+      wave::run_wave(e->wave, [&]() {
+        if (obs) cim::fast_lanes_env<true>(K, e->obs, B, mask, b0 + wave::lane());
+        else cim::fast_lanes_env<false>(K, e->obs, B, mask, b0 + wave::lane());
+      });
+  }
   for (int b = 0; b < K.n_envs; b++) {
     int env = b, path = cim::PATH_PROBE;
-    if (mode == 2) {
+    if (mode == 5 && b >= K.sched[0]) break;
+    if (mode == 2 || mode == 5) {
       const int en = K.order[b];
       if (en < 0) continue;
       env = en & (MRX_ORDER_TICK - 1);

@@ -117,6 +117,20 @@ def test_split_step_with_observation_and_two_actions():
     side_by_side("global_trade.22p_l0.8", (1, 4), n=70, obs=True, max_actions=2, durations=24)
 
 
+@pytest.mark.parametrize("topology", ["global_trade.22p_l0.8", "toy.5p_ssddd_l0.5"])
+def test_fast_kernel_plus_one_workgroup_per_full_entry_equals_unsorted(topology):
+    """launch form 5: the lane-parallel fast kernel of form 4, then the sorted launch restricted to the full-path list."""
+    assert side_by_side(topology, (1, 5)) > 30
+
+
+def test_launch_form_5_with_observation_and_two_actions():
+    side_by_side("global_trade.22p_l0.8", (1, 5), n=70, obs=True, max_actions=2, durations=24)
+
+
+def test_launch_form_5_joint_mode():
+    side_by_side("toy.5p_ssddd_l0.5", (1, 5), joint=1, durations=40)
+
+
 def test_split_step_joint_mode():
     side_by_side("toy.5p_ssddd_l0.5", (1, 4), joint=1, durations=40)
 
@@ -135,7 +149,7 @@ def _make(mode):
     return make
 
 
-@pytest.mark.parametrize("mode", [2, "S", 4])
+@pytest.mark.parametrize("mode", [2, "S", 4, 5])
 @pytest.mark.parametrize("name", ["gt22p_l08_rand0", "toy4p_l03_res7_ring5", "gt22p_l08_res3", "toy6p_l08_rand0", "syn_immediate_returns", "case_config_folder_kat", "real_csv_rand0", "gt22p_l08_reset_chain"])
 def test_goldens_replay_in_every_launch_form(name, mode):
     replay_case(_make(mode), name)

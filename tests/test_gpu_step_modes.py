@@ -1,5 +1,5 @@
 """The launch forms of mrx_cim_step on an MI355X (mrx_cim_set_step_mode): 1 unsorted, 2 sorted by mrx_k_cim_schedule, 4 split
-(plan-specialised kernels), and "S" = the plan-specialised LEAN build (return ring + order quantities in registers) in the
+(plan-specialised kernels), 5 = the fast kernel of 4 + one workgroup per full-path entry (generic and "S5" specialised), and "S" = the plan-specialised LEAN build (return ring + order quantities in registers) in the
 sorted launch.  Pure scheduling / pure code generation: outputs and engine state must be identical, and every form must
 replay the reference goldens."""
 import numpy as np
@@ -15,8 +15,9 @@ def _engines(topo, n, modes, **kw):
     seeds = torch.arange(n, dtype=torch.int64) * 3 + 1
     engs = []
     for m in modes:
-        e = CimBatchEngine(topo, n, seeds=seeds, specialize=(m in ("S", 4)), step_mode=2 if m == "S" else m, **kw)
-        assert e.step_mode == (2 if m == "S" else m) and e.specialized == (m in ("S", 4)), (e.step_mode, m)
+        sm = {"S": 2, "S5": 5}.get(m, m)
+        e = CimBatchEngine(topo, n, seeds=seeds, specialize=(m in ("S", 4, "S5")), step_mode=sm, **kw)
+        assert e.step_mode == sm and e.specialized == (m in ("S", 4, "S5")), (e.step_mode, m)
         engs.append(e)
     return engs
 
@@ -24,9 +25,9 @@ def _engines(topo, n, modes, **kw):
 @pytest.mark.parametrize("topo,n", [("global_trade.22p_l0.8", 3000), ("toy.5p_ssddd_l0.5", 777)])
 def test_step_modes_are_pure_scheduling(topo, n):
     import torch
-    engs = _engines(topo, n, (1, 2, "S", 4), durations=100, max_snapshots=5)
+    engs = _engines(topo, n, (1, 2, "S", 4, 5, "S5"), durations=100, max_snapshots=5)
     obs = [e.set_observation(["empty", "full", "shortage", "transfer_cost"], ["empty", "remaining_space"]) for e in engs]
-    assert [e.step_mode for e in engs] == [1, 2, 2, 4]
+    assert [e.step_mode for e in engs] == [1, 2, 2, 4, 5, 5]
     acts = [torch.zeros((n, 1, 4), dtype=torch.int32, device="cuda") for _ in engs]
     nact = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in engs]
     for e in engs:
@@ -57,7 +58,7 @@ def test_step_modes_are_pure_scheduling(topo, n):
     assert int(engs[0].status.max()) == 0
 
 
-@pytest.mark.parametrize("mode", [2, "S", 4])
+@pytest.mark.parametrize("mode", [2, "S", 4, "S5"])
 @pytest.mark.parametrize("name", ["gt22p_l08_rand0", "toy4p_l03_res7_ring5", "gt22p_l08_res3", "toy6p_l08_rand0", "case_config_folder_kat",
                                   "real_csv_rand0", "gt22p_l08_reset_chain", "syn_repeated_ports_noisy"])
 def test_goldens_replay_in_every_launch_form(name, mode):
@@ -69,8 +70,8 @@ def test_goldens_replay_in_every_launch_form(name, mode):
     def make(topo, kwargs):
         b = GpuBackend.__new__(GpuBackend)
         b.eng = CimBatchEngine(topo, 5, start_tick=kwargs.get("start_tick", 0), durations=kwargs["durations"], snapshot_resolution=kwargs.get("snapshot_resolution", 1),
-                               max_snapshots=kwargs.get("max_snapshots"), max_actions=2, specialize=(mode in ("S", 4)), step_mode=2 if mode == "S" else mode)
-        assert b.eng.step_mode == (2 if mode == "S" else mode)
+                               max_snapshots=kwargs.get("max_snapshots"), max_actions=2, specialize=(mode in ("S", 4, "S5")), step_mode={"S": 2, "S5": 5}.get(mode, mode))
+        assert b.eng.step_mode == {"S": 2, "S5": 5}.get(mode, mode)
         b.topo, b.layout, b.n_envs, b.max_actions, b.max_tick = b.eng.topo, b.eng.layout, 5, 2, kwargs.get("start_tick", 0) + kwargs["durations"]
         return SingleEnvAdapter(b, env=3)
     replay_case(make, name)
@@ -80,7 +81,7 @@ def test_joint_mode_uses_the_order_list_too():
     """Joint decision modes have no fast path: every env is a full-path entry of the order list (sorted launch forms)."""
     import torch
     topo, n = "toy.6p_sssbdd_l0.8", 200
-    engs = _engines(topo, n, (1, 2, "S", 4), durations=80, decision_mode=1, max_actions=6)
+    engs = _engines(topo, n, (1, 2, "S", 4, "S5"), durations=80, decision_mode=1, max_actions=6)
     for e in engs:
         e.step()
     for k in range(60):
