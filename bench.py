@@ -21,6 +21,9 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# (--groups above 3: the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues, default 4 — three groups
+# plus torch's own stream; a fourth group shares a queue and its kernels serialise: 178 M env-steps/s, against 286 M with
+# GPU_MAX_HW_QUEUES=8 in the environment.  Three groups on the default queues is what the default run uses: profiles/r03_lds_diet.md §5.)
 
 # reference-dtype frame bytes per env and targets per topology family
 FRAME_BYTES = {"global_trade.22p": 15412, "toy.4p_ssdd": 886}
@@ -434,7 +437,7 @@ def bench_collect(args, engines, streams, qnet, n, G, dev, rank, world, dist, re
     bench = one interaction of every env of the rank (all groups)."""
     import torch
 
-    from maro_amd.cim.sampler import CimBatchSampler
+    from maro_amd.cim.sampler import CimBatchSampler, sample_fused_groups
     samplers = []
     for g, e in enumerate(engines):
         with torch.cuda.stream(streams[g]):
@@ -448,12 +451,10 @@ def bench_collect(args, engines, streams, qnet, n, G, dev, rank, world, dist, re
             torch.cuda.synchronize(dev)
 
     def one_call(k):
-        nexp = 0
-        for g, smp in enumerate(samplers):
-            with torch.cuda.stream(streams[g]):   # the sampler's tensor ops and its engine's kernels on ONE stream (the engine is bound to it)
-                res = smp.sample_fused(qnet[g], num_steps=k, seeds=seeds_of[g], reset_every=args.reset_every)
-            nexp += int(res["tick"].shape[0])
-        return nexp
+        # the groups' step generators advanced in turn: every engine is bound to its group's stream (use_stream), the sampler puts
+        # its own tensor ops on that stream too, and a step is three C-ABI calls — the groups' kernels overlap like in the headline loop
+        res = sample_fused_groups(samplers, qnet, k, seeds=seeds_of, reset_every=args.reset_every)
+        return sum(int(r["tick"].shape[0]) for r in res)
 
     # untimed: into mid-episode (the first reward window must have passed for experiences to flow), then the warmup
     pre = 0

@@ -372,6 +372,8 @@ int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_d
  * maro/rl/rollout/env_sampler.py:386-410, 472-512: `_append_cache_element` — the element of this decision, the previous
  * element's next state, the deciding agent's previous element's next agent state and terminal flag).  Call it between the
  * policy (mrx_cim_dqn_act, which produced d_state / d_choice / d_actions for d_decisions) and mrx_cim_step.  Per env e:
+ *   eoe[e] |= done[e] first (d_done: the `done` output of the previous mrx_cim_step, or NULL when the caller keeps eoe current
+ *   itself): the end-of-episode flag then needs no launch of its own between the steps;
  *   alive = prev_active[e] && !eoe[e]:  next_state[e][prev_j[e]] = alive ? state[e] : state element prev_j[e] itself (episode over)
  *   active = !eoe[e]:  element number q = count[e] goes to slot j = q & (cap - 1) <- (tick, deciding port, state[e], choice[e],
  *                      first action row), terminal = 0; the port's previous element last[e][port] (an element NUMBER, -1: none;
@@ -385,9 +387,30 @@ int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_d
  */
 int mrx_cim_sampler_record(int32_t n_envs, int32_t n_ports, int32_t state_dim, int32_t cap, int32_t max_actions, int32_t state_f64, int32_t first,
                            const int32_t* d_decisions, const float* d_state, const int32_t* d_choice, const int32_t* d_actions, int32_t* d_n_actions,
-                           const uint8_t* d_eoe, int64_t* d_count, int64_t* d_last, int64_t* d_prev_j, uint8_t* d_prev_active,
+                           uint8_t* d_eoe, const uint8_t* d_done, int64_t* d_count, int64_t* d_last, int64_t* d_prev_j, uint8_t* d_prev_active,
                            int32_t* c_tick, int64_t* c_agent, void* c_state, int64_t* c_action, int32_t* c_env_action, uint8_t* c_terminal,
                            void* c_next_state, void* c_next_agent_state, int64_t* d_interactions, int32_t device, void* stream);
+
+/*
+ * The batched EnvSampler's EMISSION: the loop after AbsEnvSampler.sample's inner loop (maro/rl/rollout/env_sampler.py:514-530:
+ * every cached element old enough for its reward window is popped, `_get_reward` evaluated, the experience appended) together with
+ * the CIM example's reward (examples/cim/rl/env_sampler.py:65-80), in one launch: for each of the n_rows envs d_rows[r] (NULL:
+ * env r) the oldest d_n_emit[r] elements of its transition ring (element numbers d_tail[r] ..., slot = number & (cap - 1); the
+ * cache arrays of mrx_cim_sampler_record) are copied to rows d_out_offset[r] ... of the compact outputs, in age order, with
+ *   reward = float32( ff * sum_k decay[k] * fulfillment(port, tick + 1 + k) - sf * sum_k decay[k] * shortage(port, tick + 1 + k) ),
+ * k = 0 .. window - 1, summed in float64, read from d_port_history = the int32 [n_envs][frames][2][n_ports] array
+ * mrx_cim_set_port_history(fulfillment, shortage) maintains (ticks >= frames contribute zeros: the reference's snapshot padding).
+ * The caller advances its tail afterwards.  o_state / o_next_state / o_next_agent_state [K][state_dim] (float32, or float64 when
+ * state_f64), o_action int64 [K], o_env_action int32 [K][4], o_reward float32 [K], o_terminal uint8 [K], o_env_id / o_tick /
+ * o_agent int32 [K], K = sum of d_n_emit.
+ */
+int mrx_cim_sampler_emit(int32_t n_rows, int32_t n_ports, int32_t state_dim, int32_t cap, int32_t frames, int32_t window, int32_t state_f64,
+                         double fulfillment_factor, double shortage_factor, const double* d_decay, const int64_t* d_rows, const int64_t* d_tail,
+                         const int64_t* d_n_emit, const int64_t* d_out_offset, const int32_t* d_port_history, const int32_t* c_tick,
+                         const int64_t* c_agent, const void* c_state, const int64_t* c_action, const int32_t* c_env_action, const uint8_t* c_terminal,
+                         const void* c_next_state, const void* c_next_agent_state, void* o_state, int64_t* o_action, int32_t* o_env_action,
+                         float* o_reward, void* o_next_state, void* o_next_agent_state, uint8_t* o_terminal, int32_t* o_env_id, int32_t* o_tick,
+                         int32_t* o_agent, int32_t device, void* stream);
 
 /* Attribute name -> id and slot count for a node type; returns -1 for an unknown attribute
  * (reference raises BackendsInvalidAttributeException, frame.pyx:786-790). */

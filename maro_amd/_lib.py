@@ -46,7 +46,7 @@ class MrxCimDqnModel(ctypes.Structure):
 EXPORTS = ("mrx_last_error", "mrx_version", "mrx_cim_workspace_bytes", "mrx_cim_create", "mrx_cim_destroy",
            "mrx_cim_get_layout", "mrx_cim_reset", "mrx_cim_step", "mrx_cim_step_joint", "mrx_cim_query", "mrx_cim_attr_id",
            "mrx_cim_attr_slots", "mrx_cim_random_policy", "mrx_cim_set_observation", "mrx_cim_set_step_mode", "mrx_cim_set_port_history", "mrx_cim_dqn_net_floats",
-           "mrx_cim_dqn_pack_net", "mrx_cim_dqn_scratch_bytes", "mrx_cim_dqn_act", "mrx_cim_sampler_record", "mrx_cim_plan_defines", "mrx_cim_load_step_kernels", "mrx_cim_read_kernel_global",
+           "mrx_cim_dqn_pack_net", "mrx_cim_dqn_scratch_bytes", "mrx_cim_dqn_act", "mrx_cim_sampler_record", "mrx_cim_sampler_emit", "mrx_cim_plan_defines", "mrx_cim_load_step_kernels", "mrx_cim_read_kernel_global",
            # include/maro_amd_citi_bike.h
            "mrx_cb_workspace_bytes", "mrx_cb_create", "mrx_cb_destroy", "mrx_cb_get_layout", "mrx_cb_reset", "mrx_cb_step",
            "mrx_cb_query", "mrx_cb_random_policy", "mrx_cb_attr_id", "mrx_cb_attr_slots", "mrx_cb_plan_defines",
@@ -114,7 +114,9 @@ def load() -> ctypes.CDLL:
     L.mrx_cim_dqn_act.restype = i32
     L.mrx_cim_dqn_act.argtypes = [vp] * 11
     L.mrx_cim_sampler_record.restype = i32
-    L.mrx_cim_sampler_record.argtypes = [i32] * 7 + [vp] * 19 + [i32, vp]
+    L.mrx_cim_sampler_record.argtypes = [i32] * 7 + [vp] * 20 + [i32, vp]
+    L.mrx_cim_sampler_emit.restype = i32
+    L.mrx_cim_sampler_emit.argtypes = [i32] * 7 + [ctypes.c_double] * 2 + [vp] * 24 + [i32, vp]
     L.mrx_cim_attr_id.restype = i32
     L.mrx_cim_attr_id.argtypes = [i32, ctypes.c_char_p]
     L.mrx_cim_attr_slots.restype = i32

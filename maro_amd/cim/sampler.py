@@ -101,7 +101,7 @@ class CimBatchSampler:
         self._hist = eng.set_port_history(["fulfillment", "shortage"])
         self._ports = torch.arange(eng.layout.n_ports, dtype=torch.int32, device=dev)
 
-    def _finalize_and_emit(self, envs: torch.Tensor, out: Dict[str, list]) -> None:
+    def _finalize_and_emit(self, envs: torch.Tensor, out: Dict[str, list], kernel: bool = False) -> None:
         """`_append_cache_element(None)` + the emission loop of AbsEnvSampler.sample (rl/rollout/env_sampler.py:404-410,
         514-530) for the envs in the bool mask `envs`."""
         eng, c = self.eng, self._c
@@ -134,20 +134,49 @@ class CimBatchSampler:
             if paused.numel() > 0:
                 live = eng.query("ports", tick_now.to(torch.int32).view(n, 1), self._ports, ["fulfillment", "shortage"]).view(n, -1, 2)
                 self._hist[paused, tick_now[paused]] = live[paused].permute(0, 2, 1).to(torch.int32)
-            er, ej = torch.nonzero(emit, as_tuple=True)            # ordered by env, then by age: the reference's emission order
-            e_env = rows[er]
-            ej = slot_of[er, ej]
-            tick = c["tick"][e_env, ej].to(torch.int64)
-            agent = c["agent"][e_env, ej]
             frames = self._hist.shape[1]
-            t_idx = tick[:, None] + self._ahead.to(torch.int64)[None, :]                 # tick + 1 .. tick + window
-            ok = t_idx < frames                                                          # beyond the episode: zeros (snapshot padding)
-            vals = self._hist[e_env[:, None], t_idx.clamp(max=frames - 1), :, agent[:, None]].to(torch.float64) * ok[:, :, None]   # [K, window, 2]
-            reward = (self.ff * (vals[:, :, 0] @ self._decay) - self.sf * (vals[:, :, 1] @ self._decay)).to(torch.float32)
-            out["env_id"].append(e_env.to(torch.int32)); out["tick"].append(tick.to(torch.int32)); out["agent"].append(agent.to(torch.int32))
-            out["reward"].append(reward)
-            for key in ("state", "action", "env_action", "next_state", "next_agent_state", "terminal"):
-                out[key].append(c[key][e_env, ej])
+            emit_fn = getattr(getattr(eng, "_L", None), "mrx_cim_sampler_emit", None) if kernel and dev.type == "cuda" else None
+            if emit_fn is not None:
+                # ONE launch (mrx_cim_sampler_emit): an env's oldest n_emit elements copied out in age order, rewards evaluated
+                # on the way.  The tensor-op sequence of the other branch is its specification (rewards: same float64 sums in
+                # another order, so equal up to the last float32 bit).
+                from .. import _lib
+                K = int(n_emit.sum())
+                off = torch.cumsum(n_emit, 0) - n_emit
+                D = self.state_dim
+                o = dict(state=torch.empty((K, D), dtype=self.state_dtype, device=dev), action=torch.empty(K, dtype=torch.int64, device=dev),
+                         env_action=torch.empty((K, 4), dtype=torch.int32, device=dev), reward=torch.empty(K, dtype=torch.float32, device=dev),
+                         next_state=torch.empty((K, D), dtype=self.state_dtype, device=dev),
+                         next_agent_state=torch.empty((K, D), dtype=self.state_dtype, device=dev), terminal=torch.empty(K, dtype=torch.bool, device=dev),
+                         env_id=torch.empty(K, dtype=torch.int32, device=dev), tick=torch.empty(K, dtype=torch.int32, device=dev),
+                         agent=torch.empty(K, dtype=torch.int32, device=dev))
+                rows_c, tail_c, n_emit_c = rows.contiguous(), tail.contiguous(), n_emit.contiguous()
+                assert self._hist.is_contiguous() and self._hist.shape[2] == 2
+                _lib.check(emit_fn(int(rows_c.numel()), eng.layout.n_ports, D, cap, frames, self.time_window, 1 if self.state_dtype == torch.float64 else 0,
+                                   float(self.ff), float(self.sf), self._decay.data_ptr(), rows_c.data_ptr(), tail_c.data_ptr(), n_emit_c.data_ptr(),
+                                   off.data_ptr(), self._hist.data_ptr(), c["tick"].data_ptr(), c["agent"].data_ptr(), c["state"].data_ptr(),
+                                   c["action"].data_ptr(), c["env_action"].data_ptr(), c["terminal"].data_ptr(), c["next_state"].data_ptr(),
+                                   c["next_agent_state"].data_ptr(), o["state"].data_ptr(), o["action"].data_ptr(), o["env_action"].data_ptr(),
+                                   o["reward"].data_ptr(), o["next_state"].data_ptr(), o["next_agent_state"].data_ptr(), o["terminal"].data_ptr(),
+                                   o["env_id"].data_ptr(), o["tick"].data_ptr(), o["agent"].data_ptr(),
+                                   dev.index if dev.index is not None else torch.cuda.current_device(), eng._stream()), "mrx_cim_sampler_emit")
+                self._keep_emit = (rows_c, tail_c, n_emit_c, off)      # (inputs of an asynchronous launch)
+                for key, v in o.items():
+                    out[key].append(v)
+            else:
+                er, ej = torch.nonzero(emit, as_tuple=True)            # ordered by env, then by age: the reference's emission order
+                e_env = rows[er]
+                ej = slot_of[er, ej]
+                tick = c["tick"][e_env, ej].to(torch.int64)
+                agent = c["agent"][e_env, ej]
+                t_idx = tick[:, None] + self._ahead.to(torch.int64)[None, :]                 # tick + 1 .. tick + window
+                ok = t_idx < frames                                                          # beyond the episode: zeros (snapshot padding)
+                vals = self._hist[e_env[:, None], t_idx.clamp(max=frames - 1), :, agent[:, None]].to(torch.float64) * ok[:, :, None]   # [K, window, 2]
+                reward = (self.ff * (vals[:, :, 0] @ self._decay) - self.sf * (vals[:, :, 1] @ self._decay)).to(torch.float32)
+                out["env_id"].append(e_env.to(torch.int32)); out["tick"].append(tick.to(torch.int32)); out["agent"].append(agent.to(torch.int32))
+                out["reward"].append(reward)
+                for key in ("state", "action", "env_action", "next_state", "next_agent_state", "terminal"):
+                    out[key].append(c[key][e_env, ej])
             # pop the emitted prefix: the ring's tail moves on; an agent whose last element went out has none
             new_tail = tail + n_emit
             self._tail[rows] = new_tail
@@ -256,7 +285,21 @@ class CimBatchSampler:
 
     def sample_fused(self, actor, num_steps: Optional[int], seeds: Optional[Callable[[int], torch.Tensor]] = None, reset_every: int = 1,
                      state_dtype: torch.dtype = torch.float32) -> Dict[str, torch.Tensor]:
-        """``sample(num_steps)`` with the per-step work fused and the step path free of host synchronisation — the loop
+        """``sample_fused_steps`` run to the end (see there); returns its result."""
+        gen = self.sample_fused_steps(actor, num_steps, seeds=seeds, reset_every=reset_every, state_dtype=state_dtype)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as stop:
+                return stop.value
+
+    def sample_fused_steps(self, actor, num_steps: Optional[int], seeds: Optional[Callable[[int], torch.Tensor]] = None, reset_every: int = 1,
+                           state_dtype: torch.dtype = torch.float32):
+        """A GENERATOR over the interactions of one call (it yields after each step's work has been enqueued and returns the
+        result dict through StopIteration) — so that the samplers of several env groups, each on its own HIP stream, can be
+        advanced in turn and their kernels overlap (``sample_fused_groups``); ``sample_fused`` simply exhausts it.
+
+        ``sample(num_steps)`` with the per-step work fused and the step path free of host synchronisation — the loop
         ``bench.py --policy dqn --collect`` times (maro.rl's EnvSampler with on-device inference).
 
         `actor.act(actions, n_actions, decisions=, state=, choice=)` answers every pending decision in ONE call: it writes the
@@ -273,19 +316,20 @@ class CimBatchSampler:
         from .engine import SEED_REDRAW
         eng = self.eng
         n, dev = eng.n_envs, eng.decisions.device
-        if not hasattr(self, "_c") or self.state_dtype != state_dtype:
-            self._sample_init(state_dtype)
-        if num_steps is not None:
-            need = int((self._head - self._tail).max()) + num_steps + 1      # one read per CALL: the cache never has to grow inside the loop
-            if need > self._cap:
-                self._cache_alloc(max(need, 2 * self._cap))
-        c = self._c
-        out = {k: [] for k in ("state", "action", "env_action", "reward", "next_state", "next_agent_state", "terminal", "env_id", "tick", "agent")}
-        acts = torch.zeros((n, eng.max_actions, 4), dtype=torch.int32, device=dev)
-        nact = torch.zeros(n, dtype=torch.int32, device=dev)
-        st_buf = torch.zeros((n, self.state_dim), dtype=torch.float32, device=dev)
-        ch_buf = torch.zeros(n, dtype=torch.int32, device=dev)
-        ar = torch.arange(n, device=dev)
+        # An engine bound to a side stream (CimBatchEngine.use_stream): the sampler's own tensor ops go to that stream too.  The
+        # stream is switched per SEGMENT, never across a `yield` (another group's generator runs in between).
+        bound = getattr(eng, "_bound_stream", None)
+
+        def enter():
+            if bound is None:
+                return None
+            prev = torch.cuda.current_stream(bound.device)
+            torch.cuda.set_stream(bound)
+            return prev
+
+        def leave(prev) -> None:
+            if prev is not None:
+                torch.cuda.set_stream(prev)
 
         def reset_envs(mask: torch.Tensor) -> None:   # AbsEnvSampler._reset for the envs in `mask` (a sync point: rare)
             cmd = seeds(self._ep_env.clone()).to(torch.int64) if seeds is not None else torch.full((n,), SEED_REDRAW, dtype=torch.int64)
@@ -296,105 +340,144 @@ class CimBatchSampler:
             self._tail.copy_(torch.where(mask, self._head, self._tail))
             self._last[mask] = -1
             eng.step(mask=mask.to(torch.uint8))          # _step(None): the first decision event
-            self._eoe = torch.where(mask, eng.done.to(torch.bool), self._eoe)
+            self._eoe.copy_(torch.where(mask, eng.done.to(torch.bool), self._eoe))
 
         def roll_over() -> None:
             if bool(self._eoe.any()):
                 ended = self._eoe.clone()
-                self._finalize_and_emit(ended, out)
+                self._finalize_and_emit(ended, out, kernel=fused_kernels)
                 reset_envs(ended)
 
-        if bool(self._eoe.any()):
-            reset_envs(self._eoe.clone())
+        fused_kernels = bool(eng.decisions.is_cuda and num_steps is not None)   # the record / emit kernels (else: their tensor-op specification)
+        tok = enter()
+        try:
+            if not hasattr(self, "_c") or self.state_dtype != state_dtype:
+                self._sample_init(state_dtype)
+            if num_steps is not None:
+                need = int((self._head - self._tail).max()) + num_steps + 1      # one read per CALL: the cache never has to grow inside the loop
+                if need > self._cap:
+                    self._cache_alloc(max(need, 2 * self._cap))
+            c = self._c
+            out = {k: [] for k in ("state", "action", "env_action", "reward", "next_state", "next_agent_state", "terminal", "env_id", "tick", "agent")}
+            acts = torch.zeros((n, eng.max_actions, 4), dtype=torch.int32, device=dev)
+            nact = torch.zeros(n, dtype=torch.int32, device=dev)
+            st_buf = torch.zeros((n, self.state_dim), dtype=torch.float32, device=dev)
+            ch_buf = torch.zeros(n, dtype=torch.int32, device=dev)
+            ar = torch.arange(n, device=dev)
+            if bool(self._eoe.any()):
+                reset_envs(self._eoe.clone())
+            pj_t = torch.zeros(n, dtype=torch.int64, device=dev)
+            pa_t = torch.zeros(n, dtype=torch.uint8, device=dev)
+        finally:
+            leave(tok)
         prev_j = None          # cache slot each env wrote in the previous step (its next_state is this step's state)
         prev_active = None
         # On the GPU the whole per-step cache update is ONE kernel (mrx_cim_sampler_record); the tensor-op sequence below is its
         # specification (and what runs on the CPU emulator, pinned by the reference sampler's goldens)
         rec = getattr(getattr(eng, "_L", None), "mrx_cim_sampler_record", None) if eng.decisions.is_cuda and num_steps is not None else None
         if rec is not None:
-            import ctypes
-
             from .. import _lib
-            pj_t = torch.zeros(n, dtype=torch.int64, device=dev)
-            pa_t = torch.zeros(n, dtype=torch.uint8, device=dev)
             f64 = 1 if self.state_dtype == torch.float64 else 0
             assert self.state_dtype in (torch.float32, torch.float64)
+            dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
             first = 1
             for k in range(num_steps):
                 if k > 0 and k % max(1, reset_every) == 0:
-                    if not first:
-                        self._fill_next_state(pj_t, pa_t.to(torch.bool), ar)
-                        first = 1
-                    roll_over()
-                    c = self._c
+                    tok = enter()
+                    try:
+                        torch.logical_or(self._eoe, eng.done, out=self._eoe)   # (the record kernel folds this in; here the flags are READ)
+                        if not first:
+                            self._fill_next_state(pj_t, pa_t.to(torch.bool), ar)
+                            first = 1
+                        roll_over()
+                        c = self._c
+                    finally:
+                        leave(tok)
+                # the step itself: three C-ABI calls on the engine's stream, no tensor op, no host synchronisation.  eoe |= done
+                # of the previous step happens inside the record kernel.
                 actor.act(acts, nact, decisions=eng.decisions, state=st_buf, choice=ch_buf)
                 _lib.check(rec(n, eng.layout.n_ports, self.state_dim, self._cap, eng.max_actions, f64, first, eng.decisions.data_ptr(), st_buf.data_ptr(),
-                               ch_buf.data_ptr(), acts.data_ptr(), nact.data_ptr(), self._eoe.data_ptr(), self._head.data_ptr(), self._last.data_ptr(),
-                               pj_t.data_ptr(), pa_t.data_ptr(), c["tick"].data_ptr(), c["agent"].data_ptr(), c["state"].data_ptr(), c["action"].data_ptr(),
-                               c["env_action"].data_ptr(), c["terminal"].data_ptr(), c["next_state"].data_ptr(), c["next_agent_state"].data_ptr(),
-                               self._steps_env.data_ptr(), dev.index if dev.index is not None else torch.cuda.current_device(), eng._stream()),
+                               ch_buf.data_ptr(), acts.data_ptr(), nact.data_ptr(), self._eoe.data_ptr(), eng.done.data_ptr(), self._head.data_ptr(),
+                               self._last.data_ptr(), pj_t.data_ptr(), pa_t.data_ptr(), c["tick"].data_ptr(), c["agent"].data_ptr(), c["state"].data_ptr(),
+                               c["action"].data_ptr(), c["env_action"].data_ptr(), c["terminal"].data_ptr(), c["next_state"].data_ptr(),
+                               c["next_agent_state"].data_ptr(), self._steps_env.data_ptr(), dev_index, eng._stream()),
                            "mrx_cim_sampler_record")
                 first = 0
                 eng.step(acts, nact)                       # (finished envs just report `done` again: no mask needed)
+                yield k
+            tok = enter()
+            try:
                 torch.logical_or(self._eoe, eng.done, out=self._eoe)
-            if not first:
-                self._fill_next_state(pj_t, pa_t.to(torch.bool), ar)
+                if not first:
+                    self._fill_next_state(pj_t, pa_t.to(torch.bool), ar)
+            finally:
+                leave(tok)
         k = -1
         while rec is None:
             k += 1
-            if num_steps is None:                          # "until the end of every env's episode": one flag read per step
-                if bool(self._eoe.all()):
-                    break
-                if int((self._head - self._tail).max()) >= self._cap:
-                    self._cache_alloc(2 * self._cap)
-                    c = self._c
-            else:
-                if k == num_steps:
-                    break
-                if k > 0 and k % max(1, reset_every) == 0:
-                    if prev_j is not None:                 # the envs about to be finalised need their last element complete
-                        self._fill_next_state(prev_j, prev_active, ar)
-                        prev_j = None
-                    roll_over()
-            active = ~self._eoe
-            dec = eng.decisions.clone()
-            actor.act(acts, nact, decisions=dec, state=st_buf, choice=ch_buf)
-            nact.mul_(active.to(torch.int32))
-            state = st_buf.to(self.state_dtype)
-            if prev_j is not None:                         # previous element: next_state = the state this step's gather produced,
-                still = prev_active & active               # or (episode over) the element's own state
-                pj = prev_j
-                cur = c["state"][ar, pj]
-                c["next_state"][ar, pj] = torch.where(still[:, None], state, torch.where(prev_active[:, None], cur, c["next_state"][ar, pj]))
-            a1 = active[:, None]
-            j = self._head & (self._cap - 1)
-            agent = dec[:, 1].to(torch.int64).clamp(min=0)
-            c["tick"][ar, j] = torch.where(active, dec[:, 0], c["tick"][ar, j])
-            c["agent"][ar, j] = torch.where(active, agent, c["agent"][ar, j])
-            c["state"][ar, j] = torch.where(a1, state, c["state"][ar, j])
-            c["action"][ar, j] = torch.where(active, ch_buf.to(torch.int64), c["action"][ar, j])
-            c["env_action"][ar, j] = torch.where(a1, acts[:, 0], c["env_action"][ar, j])
-            c["terminal"][ar, j] = torch.where(active, torch.zeros_like(active), c["terminal"][ar, j])
-            prev = self._last[ar, agent]                 # this agent's previous element gets its next agent state
-            hp = active & (prev >= 0)
-            pz = prev.clamp(min=0) & (self._cap - 1)
-            c["next_agent_state"][ar, pz] = torch.where(hp[:, None], state, c["next_agent_state"][ar, pz])
-            c["terminal"][ar, pz] = torch.where(hp, torch.zeros_like(hp), c["terminal"][ar, pz])
-            self._last[ar, agent] = torch.where(active, self._head, self._last[ar, agent])
-            self._head += active.to(torch.int64)
-            self._steps_env += active.to(torch.int64)
-            eng.step(acts, nact, mask=active.to(torch.uint8))
-            self._eoe = torch.where(active, eng.done.to(torch.bool), self._eoe)
-            prev_j, prev_active = j, active
-        if prev_j is not None:
-            self._fill_next_state(prev_j, prev_active, ar)
-        self._cur_state = torch.where((~self._eoe)[:, None], self.state().to(self.state_dtype), self._cur_state)
-        self._finalize_and_emit(torch.ones(n, dtype=torch.bool, device=dev), out)
-        res = {k: (torch.cat(v) if v else torch.zeros((0,) + tuple(c[k].shape[2:]) if k in c else (0,), dtype=(c[k].dtype if k in c else torch.int32), device=dev))
-               for k, v in out.items()}
-        if not out["reward"]:
-            res["reward"] = torch.zeros(0, dtype=torch.float32, device=dev)
-        res["env_metric"] = eng.metrics.clone()
+            tok = enter()
+            try:
+                if num_steps is None:                          # "until the end of every env's episode": one flag read per step
+                    if bool(self._eoe.all()):
+                        break
+                    if int((self._head - self._tail).max()) >= self._cap:
+                        self._cache_alloc(2 * self._cap)
+                        c = self._c
+                else:
+                    if k == num_steps:
+                        break
+                    if k > 0 and k % max(1, reset_every) == 0:
+                        if prev_j is not None:                 # the envs about to be finalised need their last element complete
+                            self._fill_next_state(prev_j, prev_active, ar)
+                            prev_j = None
+                        roll_over()
+                active = ~self._eoe
+                dec = eng.decisions.clone()
+                actor.act(acts, nact, decisions=dec, state=st_buf, choice=ch_buf)
+                nact.mul_(active.to(torch.int32))
+                state = st_buf.to(self.state_dtype)
+                if prev_j is not None:                         # previous element: next_state = the state this step's gather produced,
+                    still = prev_active & active               # or (episode over) the element's own state
+                    pj = prev_j
+                    cur = c["state"][ar, pj]
+                    c["next_state"][ar, pj] = torch.where(still[:, None], state, torch.where(prev_active[:, None], cur, c["next_state"][ar, pj]))
+                a1 = active[:, None]
+                j = self._head & (self._cap - 1)
+                agent = dec[:, 1].to(torch.int64).clamp(min=0)
+                c["tick"][ar, j] = torch.where(active, dec[:, 0], c["tick"][ar, j])
+                c["agent"][ar, j] = torch.where(active, agent, c["agent"][ar, j])
+                c["state"][ar, j] = torch.where(a1, state, c["state"][ar, j])
+                c["action"][ar, j] = torch.where(active, ch_buf.to(torch.int64), c["action"][ar, j])
+                c["env_action"][ar, j] = torch.where(a1, acts[:, 0], c["env_action"][ar, j])
+                c["terminal"][ar, j] = torch.where(active, torch.zeros_like(active), c["terminal"][ar, j])
+                prev = self._last[ar, agent]                 # this agent's previous element gets its next agent state
+                hp = active & (prev >= 0)
+                pz = prev.clamp(min=0) & (self._cap - 1)
+                c["next_agent_state"][ar, pz] = torch.where(hp[:, None], state, c["next_agent_state"][ar, pz])
+                c["terminal"][ar, pz] = torch.where(hp, torch.zeros_like(hp), c["terminal"][ar, pz])
+                self._last[ar, agent] = torch.where(active, self._head, self._last[ar, agent])
+                self._head += active.to(torch.int64)
+                self._steps_env += active.to(torch.int64)
+                eng.step(acts, nact, mask=active.to(torch.uint8))
+                self._eoe.copy_(torch.where(active, eng.done.to(torch.bool), self._eoe))
+                prev_j, prev_active = j, active
+            finally:
+                leave(tok)
+            yield k
+        tok = enter()
+        try:
+            if prev_j is not None:
+                self._fill_next_state(prev_j, prev_active, ar)
+            self._cur_state = torch.where((~self._eoe)[:, None], self.state().to(self.state_dtype), self._cur_state)
+            self._finalize_and_emit(torch.ones(n, dtype=torch.bool, device=dev), out, kernel=fused_kernels)
+            res = {k: ((v[0] if len(v) == 1 else torch.cat(v)) if v else
+                       torch.zeros((0,) + tuple(c[k].shape[2:]) if k in c else (0,), dtype=(c[k].dtype if k in c else torch.int32), device=dev))
+                   for k, v in out.items()}
+            if not out["reward"]:
+                res["reward"] = torch.zeros(0, dtype=torch.float32, device=dev)
+            res["env_metric"] = eng.metrics.clone()
+        finally:
+            leave(tok)
         return res
 
     @property
@@ -410,3 +493,26 @@ class CimBatchSampler:
         alive = p_active & ~self._eoe
         own = c["state"][ar, pj]
         c["next_state"][ar, pj] = torch.where(alive[:, None], new, torch.where(p_active[:, None], own, c["next_state"][ar, pj]))
+
+
+def sample_fused_groups(samplers, actors, num_steps: int, seeds=None, reset_every: int = 1, state_dtype: torch.dtype = torch.float32,
+                        streams=None) -> list:
+    """``sample_fused`` for the samplers of several env groups AT ONCE: their step generators are advanced in turn, each under
+    its group's stream, so group g + 1's kernels are enqueued while group g's are running (a plain loop over
+    ``sample_fused`` calls would finish one group — its closing emission reads sizes back — before the next one starts).
+    `seeds`: one callable per group (or None).  Returns the per-group result dicts."""
+    import contextlib
+    G = len(samplers)
+    gens = [samplers[g].sample_fused_steps(actors[g], num_steps, seeds=None if seeds is None else seeds[g], reset_every=reset_every,
+                                           state_dtype=state_dtype) for g in range(G)]
+    results, live = [None] * G, list(range(G))
+    while live:
+        for g in list(live):
+            st = None if streams is None else streams[g]
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                try:
+                    next(gens[g])
+                except StopIteration as stop:
+                    results[g] = stop.value
+                    live.remove(g)
+    return results

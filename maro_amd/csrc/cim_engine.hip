@@ -175,13 +175,15 @@ mrx_k_cim_random_policy(CimParams K, const int32_t* __restrict__ decisions, long
 template <class T>
 __global__ void __launch_bounds__(64)
 mrx_k_cim_sampler_record(int n, int P, int D, int cap, int A, int first, const int32_t* __restrict__ dec, const float* __restrict__ state,
-                         const int32_t* __restrict__ choice, const int32_t* __restrict__ acts, int32_t* __restrict__ nact, const uint8_t* __restrict__ eoe,
-                         long long* __restrict__ head, long long* __restrict__ last, long long* __restrict__ prev_j, uint8_t* __restrict__ prev_active,
+                         const int32_t* __restrict__ choice, const int32_t* __restrict__ acts, int32_t* __restrict__ nact, uint8_t* __restrict__ eoe,
+                         const uint8_t* __restrict__ done, long long* __restrict__ head, long long* __restrict__ last, long long* __restrict__ prev_j, uint8_t* __restrict__ prev_active,
                          int32_t* __restrict__ c_tick, long long* __restrict__ c_agent, T* __restrict__ c_state, long long* __restrict__ c_action,
                          int32_t* __restrict__ c_env_action, uint8_t* __restrict__ c_terminal, T* __restrict__ c_next_state, T* __restrict__ c_nas,
                          long long* __restrict__ steps_env) {
   const int e = (int)blockIdx.x, lane = (int)threadIdx.x;
-  const bool over = eoe[e] != 0;
+  const bool was_over = eoe[e] != 0;
+  const bool over = was_over || (done && done[e] != 0);   // the previous step ended the episode: eoe |= done, folded in here
+  if (over && !was_over && lane == 0) eoe[e] = 1;
   const float* st = state + (size_t)e * D;
   const long long ring = (long long)cap - 1;
   if (!first && prev_active[e]) {  // the element of the previous step: its next state is this state, or (episode over) its own
@@ -216,6 +218,60 @@ mrx_k_cim_sampler_record(int n, int P, int D, int cap, int A, int first, const i
     prev_j[e] = j;
     prev_active[e] = 1;
     steps_env[e] += 1;   // (per env: a single shared counter would serialise 16384 atomics per step)
+  }
+}
+
+// The batched EnvSampler's EMISSION (mrx_cim_sampler_emit): the oldest n_emit[r] elements of env rows[r]'s transition ring are
+// copied out as compact experience rows and their delayed reward is evaluated on the way (examples/cim/rl/env_sampler.py:65-80:
+// sum over the `window` ticks after the decision of decay^k * (ff * fulfillment - sf * shortage) of the deciding port, from the
+// per-tick port history mrx_cim_set_port_history keeps: int32 [n][frames][2][P], attributes (fulfillment, shortage); ticks
+// beyond the episode contribute zeros like the reference's snapshot padding).  One 256-thread workgroup per env row — an env's
+// elements read overlapping pieces of ITS history rows, which then come out of the cache — its four waves take elements in
+// turn: lanes over the state vector for the three row copies, lanes over the window for the reward (float64, one reduction).
+template <class T>
+__global__ void __launch_bounds__(256)
+mrx_k_cim_sampler_emit(int P, int D, int cap, int frames, int window, double ff, double sf, const double* __restrict__ decay,
+                       const long long* __restrict__ rows, const long long* __restrict__ tail, const long long* __restrict__ n_emit,
+                       const long long* __restrict__ out_off, const int32_t* __restrict__ hist, const int32_t* __restrict__ c_tick,
+                       const long long* __restrict__ c_agent, const T* __restrict__ c_state, const long long* __restrict__ c_action,
+                       const int32_t* __restrict__ c_env_action, const uint8_t* __restrict__ c_terminal, const T* __restrict__ c_next_state,
+                       const T* __restrict__ c_nas, T* __restrict__ o_state, long long* __restrict__ o_action, int32_t* __restrict__ o_env_action,
+                       float* __restrict__ o_reward, T* __restrict__ o_next_state, T* __restrict__ o_nas, uint8_t* __restrict__ o_terminal,
+                       int32_t* __restrict__ o_env_id, int32_t* __restrict__ o_tick, int32_t* __restrict__ o_agent) {
+  const int r = (int)blockIdx.x, w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  const long long e = rows ? rows[r] : (long long)r;
+  const long long ne = n_emit[r], t0 = tail[r], o0 = out_off[r];
+  for (long long j = w; j < ne; j += 4) {
+    const long long slot = (t0 + j) & ((long long)cap - 1);
+    const size_t ci = (size_t)e * cap + (size_t)slot, oi = (size_t)(o0 + j);
+    for (int d = lane; d < D; d += 64) {
+      o_state[oi * D + d] = c_state[ci * D + d];
+      o_next_state[oi * D + d] = c_next_state[ci * D + d];
+      o_nas[oi * D + d] = c_nas[ci * D + d];
+    }
+    const int tick = c_tick[ci];
+    int agent = (int)c_agent[ci];
+    agent = agent < 0 ? 0 : (agent >= P ? P - 1 : agent);
+    double af = 0.0, as = 0.0;
+    for (int k = lane; k < window; k += 64) {
+      const int t = tick + 1 + k;
+      if (t < frames) {
+        const int32_t* h = hist + (((size_t)e * frames + (size_t)t) * 2) * P + agent;
+        const double dk = decay[k];
+        af += dk * (double)h[0];
+        as += dk * (double)h[P];
+      }
+    }
+    for (int off = 32; off; off >>= 1) { af += __shfl_down(af, off, 64); as += __shfl_down(as, off, 64); }
+    if (lane < 4) o_env_action[oi * 4 + lane] = c_env_action[ci * 4 + lane];
+    if (lane == 0) {
+      o_reward[oi] = (float)(ff * af - sf * as);
+      o_action[oi] = c_action[ci];
+      o_terminal[oi] = c_terminal[ci];
+      o_env_id[oi] = (int32_t)e;
+      o_tick[oi] = tick;
+      o_agent[oi] = agent;
+    }
   }
 }
 
@@ -595,7 +651,7 @@ int mrx_cim_random_policy(mrx_handle h, const int32_t* d_decisions, int64_t step
   // (256-thread workgroups: a 1024-thread one needs 16 free wave slots on ONE CU at once and waits for them behind the step kernels)
   const int sched_per = (fuse && effective_step_mode(h) >= 2) ? ((K.n_envs + 255) / 256 + 15) / 16 * 16 : 0;
   hipLaunchKernelGGL(mrx_k_cim_random_policy, dim3((K.n_envs + 255) / 256 + (sched_per > 0 ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, K,
-                     d_decisions, (long long)step, d_actions, d_n_actions, (unsigned long long*)d_counter, sched_per | (h->lpt << 24));
+                     d_decisions, (long long)step, d_actions, d_n_actions, (unsigned long long*)d_counter, sched_per > 0 ? (sched_per | (h->lpt << 24)) : 0);
   HIP_TRY(hipGetLastError());
   h->order_ready = sched_per > 0;
   h->order_stream = stream;
@@ -787,7 +843,7 @@ int mrx_cim_read_kernel_global(mrx_handle h, const char* name, void* out, int64_
 
 int mrx_cim_sampler_record(int32_t n_envs, int32_t n_ports, int32_t state_dim, int32_t cap, int32_t max_actions, int32_t state_f64, int32_t first,
                            const int32_t* d_decisions, const float* d_state, const int32_t* d_choice, const int32_t* d_actions, int32_t* d_n_actions,
-                           const uint8_t* d_eoe, int64_t* d_count, int64_t* d_last, int64_t* d_prev_j, uint8_t* d_prev_active,
+                           uint8_t* d_eoe, const uint8_t* d_done, int64_t* d_count, int64_t* d_last, int64_t* d_prev_j, uint8_t* d_prev_active,
                            int32_t* c_tick, int64_t* c_agent, void* c_state, int64_t* c_action, int32_t* c_env_action, uint8_t* c_terminal,
                            void* c_next_state, void* c_next_agent_state, int64_t* d_interactions, int32_t device, void* stream) {
   if (n_envs <= 0 || n_ports <= 0 || state_dim <= 0 || cap <= 0 || max_actions <= 0) return set_err(MRX_ERR_INVALID_ARG, "dimensions must be positive");
@@ -799,11 +855,39 @@ int mrx_cim_sampler_record(int32_t n_envs, int32_t n_ports, int32_t state_dim, i
   if (rc != MRX_OK) return rc;
 #define MRX_REC(T)                                                                                                                               \
   hipLaunchKernelGGL(mrx_k_cim_sampler_record<T>, dim3((unsigned)n_envs), dim3(64), 0, (hipStream_t)stream, (int)n_envs, (int)n_ports, (int)state_dim,  \
-                     (int)cap, (int)max_actions, (int)first, d_decisions, d_state, d_choice, d_actions, d_n_actions, d_eoe, (long long*)d_count,            \
+                     (int)cap, (int)max_actions, (int)first, d_decisions, d_state, d_choice, d_actions, d_n_actions, d_eoe, d_done, (long long*)d_count,            \
                      (long long*)d_last, (long long*)d_prev_j, d_prev_active, c_tick, (long long*)c_agent, (T*)c_state, (long long*)c_action, c_env_action, \
                      c_terminal, (T*)c_next_state, (T*)c_next_agent_state, (long long*)d_interactions)
   if (state_f64) MRX_REC(double); else MRX_REC(float);
 #undef MRX_REC
+  HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+int mrx_cim_sampler_emit(int32_t n_rows, int32_t n_ports, int32_t state_dim, int32_t cap, int32_t frames, int32_t window, int32_t state_f64,
+                         double fulfillment_factor, double shortage_factor, const double* d_decay, const int64_t* d_rows, const int64_t* d_tail,
+                         const int64_t* d_n_emit, const int64_t* d_out_offset, const int32_t* d_port_history, const int32_t* c_tick,
+                         const int64_t* c_agent, const void* c_state, const int64_t* c_action, const int32_t* c_env_action, const uint8_t* c_terminal,
+                         const void* c_next_state, const void* c_next_agent_state, void* o_state, int64_t* o_action, int32_t* o_env_action,
+                         float* o_reward, void* o_next_state, void* o_next_agent_state, uint8_t* o_terminal, int32_t* o_env_id, int32_t* o_tick,
+                         int32_t* o_agent, int32_t device, void* stream) {
+  if (n_rows < 0 || n_ports <= 0 || state_dim <= 0 || cap <= 0 || frames <= 0 || window <= 0) return set_err(MRX_ERR_INVALID_ARG, "dimensions must be positive");
+  if (cap & (cap - 1)) return set_err(MRX_ERR_INVALID_ARG, "cap (slots of an env's transition ring) must be a power of two");
+  if (!d_decay || !d_tail || !d_n_emit || !d_out_offset || !d_port_history || !c_tick || !c_agent || !c_state || !c_action || !c_env_action || !c_terminal ||
+      !c_next_state || !c_next_agent_state || !o_state || !o_action || !o_env_action || !o_reward || !o_next_state || !o_next_agent_state || !o_terminal ||
+      !o_env_id || !o_tick || !o_agent)
+    return set_err(MRX_ERR_INVALID_ARG, "null pointer");
+  if (n_rows == 0) return MRX_OK;
+  int rc = use_device(device);
+  if (rc != MRX_OK) return rc;
+#define MRX_EMIT(T)                                                                                                                                   \
+  hipLaunchKernelGGL(mrx_k_cim_sampler_emit<T>, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, (int)n_ports, (int)state_dim, (int)cap,      \
+                     (int)frames, (int)window, fulfillment_factor, shortage_factor, d_decay, (const long long*)d_rows, (const long long*)d_tail,        \
+                     (const long long*)d_n_emit, (const long long*)d_out_offset, d_port_history, c_tick, (const long long*)c_agent, (const T*)c_state,  \
+                     (const long long*)c_action, c_env_action, c_terminal, (const T*)c_next_state, (const T*)c_next_agent_state, (T*)o_state,           \
+                     (long long*)o_action, o_env_action, o_reward, (T*)o_next_state, (T*)o_next_agent_state, o_terminal, o_env_id, o_tick, o_agent)
+  if (state_f64) MRX_EMIT(double); else MRX_EMIT(float);
+#undef MRX_EMIT
   HIP_TRY(hipGetLastError());
   return MRX_OK;
 }
