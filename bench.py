@@ -650,7 +650,10 @@ def main():
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr, stream=streams[g]):
                 eng, b = engines[g], bufs[g]
-                eng.random_policy(-1, b["actions"], b["n_actions"], b["counter"])
+                if qnet is not None:
+                    qnet[g].act(b["actions"], b["n_actions"], counter=b["counter"])
+                else:
+                    eng.random_policy(-1, b["actions"], b["n_actions"], b["counter"])
                 eng.step(b["actions"], b["n_actions"])
                 if b["q_ports"] is not None:
                     eng.query("ports", eng.decisions[:, 6:7], ports, QUERY_ATTRS, out=b["q_ports"])
