@@ -39,7 +39,7 @@ def test_bench_line_contract(extra):
     if "dqn" in extra:
         assert j["roofline_policy"]["bound"] == "mfma" and j["roofline_policy"]["unit"] == "TFLOP/s"
     if extra[:2] == ("--envs", "192") and "dqn" not in extra:   # the CIM headline line: end-to-end leg + oracle parity replay
-        assert j["value_end_to_end"] > 0 and j["end_to_end"]["env_steps"] > 0 and j["end_to_end"]["reset_ms"] > 0
+        assert j["value_end_to_end"] > 0 and j["end_to_end"]["env_steps"] > 0 and j["end_to_end"]["reset_ms_synchronised"] > 0
         assert j["parity"]["ok"] is True and j["parity"]["envs_checked"] >= 60 and j["parity"]["env_steps_checked"] > 1000
         assert j["config"]["mean_tick_at_window_start"] >= 300 and "algorithmic_frac" in r and "basis" in r
 
