@@ -150,7 +150,13 @@ __device__ __forceinline__ unsigned long long dq_mix64(unsigned long long seed, 
 // n_actions (1 for a deciding env, else 0) and adds the number of deciding envs to *counter (may be NULL).
 extern "C" __global__ void __launch_bounds__(256)
 mrx_k_cim_dqn_bin(int n_envs, int P, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt, int32_t* __restrict__ lists,
-                  int32_t* __restrict__ n_actions, unsigned long long* __restrict__ counter) {
+                  int32_t* __restrict__ n_actions, unsigned long long* __restrict__ counter, const uint8_t* __restrict__ hint,
+                  int32_t* __restrict__ order, int32_t* __restrict__ sched, int sched_per) {
+  // sched_per > 0: the LAST workgroup builds the order list of the coming step instead (mrx_schedule_block, cim_engine.hip)
+  if (sched_per > 0 && blockIdx.x == gridDim.x - 1) {
+    mrx_schedule_block(hint, nullptr, 0, n_envs, sched_per & 0xffffff, order, sched, sched_per >> 24);
+    return;
+  }
   __shared__ int lcnt[64], base[64];
   const int t = threadIdx.x, e = blockIdx.x * blockDim.x + t;
   if (t < 64) lcnt[t] = 0;

@@ -26,7 +26,6 @@
 // generator's code nor its LDS (order RNG state, fp64 scratch).
 #include "cim_step_kernels.h"
 
-#include "cim_dqn.h"
 
 // Order list of the coming step (CimParams::order / sched): the envs whose step needs the full path (hint != 0: a tick
 // will run, or the episode starts) first — those are the long waves, so they start first and the short fast-path steps
@@ -108,6 +107,8 @@ mrx_k_cim_schedule(const uint8_t* __restrict__ hint, const uint8_t* __restrict__
                    int32_t* __restrict__ sched, int lpt) {
   mrx_schedule_block(hint, mask, mask_vec, n, per, order, sched, lpt);
 }
+
+#include "cim_dqn.h"   // (after the scheduler: mrx_k_cim_dqn_bin can carry the schedule block of the coming step)
 
 struct AttrList { int n; int32_t id[16]; };
 
@@ -984,8 +985,16 @@ int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_d
   if (rc != MRX_OK) return rc;
   int32_t* cnt = (int32_t*)d_scratch;
   int32_t* lists = cnt + 128;
-  hipLaunchKernelGGL(mrx_k_cim_dqn_bin, dim3((unsigned)((K.n_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K.n_envs, K.P, d_decisions, cnt, lists,
-                     d_n_actions, (unsigned long long*)d_counter);
+  // as in mrx_cim_random_policy: with a sorted launch form one extra workgroup of the binning launch builds the order list of the
+  // coming step (it only depends on the previous step's hints), so the mrx_cim_step that follows on this stream needs no
+  // schedule kernel of its own
+  static const bool fuse = !(getenv("MRX_CIM_FUSE_SCHEDULE") && atoi(getenv("MRX_CIM_FUSE_SCHEDULE")) == 0);
+  const int sched_per = (fuse && effective_step_mode(h) >= 2) ? ((K.n_envs + 255) / 256 + 15) / 16 * 16 : 0;
+  hipLaunchKernelGGL(mrx_k_cim_dqn_bin, dim3((unsigned)((K.n_envs + 255) / 256 + (sched_per > 0 ? 1 : 0))), dim3(256), 0, (hipStream_t)stream, K.n_envs, K.P,
+                     d_decisions, cnt, lists, d_n_actions, (unsigned long long*)d_counter, (const uint8_t*)K.hint, K.order, K.sched,
+                     sched_per > 0 ? (sched_per | (h->lpt << 24)) : 0);
+  h->order_ready = sched_per > 0;
+  h->order_stream = stream;
   hipLaunchKernelGGL(mrx_k_cim_dqn_forward, dim3((unsigned)dqn_max_tiles(K)), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, cnt, lists,
                      d_actions, d_q, d_state, d_choice);
   HIP_TRY(hipGetLastError());
