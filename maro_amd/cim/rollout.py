@@ -86,9 +86,10 @@ def gather_to_learner(traj: Dict[str, torch.Tensor], dst: int = 0, group=None, s
         # test hook only (bench.py under MRX_BENCH_BACKEND=gloo on a 1-GPU box): gloo's send / recv take host tensors
         src = {k: v.cpu() for k, v in src.items()}
     if rank != dst:
-        ops = [dist.P2POp(dist.isend, src[k], dst, group) for k in keys]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        if n_local > 0:                              # (an empty shard sends nothing; the learner posts no receive for it)
+            ops = [dist.P2POp(dist.isend, src[k], dst, group) for k in keys]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
         return None
     pieces = {k: [None] * world for k in keys}
     ops = []
@@ -100,10 +101,34 @@ def gather_to_learner(traj: Dict[str, torch.Tensor], dst: int = 0, group=None, s
                 shape = list(src[k].shape)
                 shape[1] = sizes[r]
                 pieces[k][r] = torch.empty(shape, dtype=src[k].dtype, device=src[k].device)
-                ops.append(dist.P2POp(dist.irecv, pieces[k][r], r, group))
-    for w in dist.batch_isend_irecv(ops):
-        w.wait()
+                if sizes[r] > 0:
+                    ops.append(dist.P2POp(dist.irecv, pieces[k][r], r, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
     return {k: torch.cat(pieces[k], dim=1).to(dev) for k in keys}
+
+
+def gather_experiences_to_learner(exp: Dict[str, torch.Tensor], env_offset: int = 0, dst: int = 0, group=None) -> Optional[Dict[str, torch.Tensor]]:
+    """The experiences ONE ``CimBatchSampler.sample`` / ``sample_fused`` call emitted on every rank, joined on `dst` — the
+    learner-side collection of config 5 (the reference: ``BatchEnvSampler.sample`` merging its workers' results,
+    maro/rl/rollout/batch_env_sampler.py:150-190).  The flat tensors over a rank's K emitted elements (state [K, D], action,
+    env_action, reward, next_state, next_agent_state, terminal, env_id, tick, agent) are concatenated rank by rank, `env_id`
+    shifted by the rank's `env_offset` into global env ids; with contiguous shards (``shard_range``) that is exactly the order a
+    single sampler over all envs emits.  "env_metric" [n_local, 3] is joined the same way.  K differs from rank to rank and call
+    to call, so the sizes are exchanged in the call (one small all_gather), then one grouped send / receive per key set as in
+    ``gather_to_learner``.  Returns the dict on `dst`, None elsewhere."""
+    per_elem = {k: v for k, v in exp.items() if k != "env_metric"}
+    if "env_id" in per_elem and env_offset:
+        per_elem["env_id"] = per_elem["env_id"] + int(env_offset)
+    out = gather_to_learner({k: v.unsqueeze(0) for k, v in per_elem.items()}, dst=dst, group=group)
+    met = gather_to_learner({"env_metric": exp["env_metric"].unsqueeze(0)}, dst=dst, group=group) if "env_metric" in exp else None
+    if out is None:
+        return None
+    res = {k: v.squeeze(0) for k, v in out.items()}
+    if met is not None:
+        res["env_metric"] = met["env_metric"].squeeze(0)
+    return res
 
 
 class PipelinedCimBatch:

@@ -89,3 +89,57 @@ def test_gloo_rollout_matches_oracle(tmp_path, world):
             assert tuple(act[t, e, 0]) == a
             om, od, odone = o.step([a])
             assert np.array_equal(traj["metrics"][t, e].numpy(), om)
+
+
+# ---- config 5's learner-side collection: every rank runs the batched EnvSampler over its shard, the emitted experiences are
+# joined on rank 0 (gather_experiences_to_learner) — and equal what ONE sampler over all envs emits, call by call
+S_TOPO, S_TOTAL, S_DUR, S_CALLS = "toy.5p_ssddd_l0.5", 5, 60, (25, 40, 33)
+
+
+class _Actor:
+    def __init__(self, smp):
+        self.smp = smp
+
+    def act(self, actions, n_actions, decisions=None, state=None, choice=None):
+        from maro_amd.cim.policy import translate_actions
+        st = self.smp.state(decisions)
+        ma = ((decisions[:, 0] + 3 * decisions[:, 1]) % 21).to(torch.int64)
+        translate_actions(ma, decisions, st[:, -1].to(torch.float64), decisions[:, 5], out=actions)
+        n_actions[:] = (decisions[:, 7] == 1).to(torch.int32)
+        state[:] = st.to(torch.float32)
+        choice[:] = ma.to(torch.int32)
+
+
+def _sample_shard(lo, hi):
+    from maro_amd.cim.sampler import CimBatchSampler
+    from tests.emu.emu_engine import EmuEngine
+    smp = CimBatchSampler(EmuEngine(S_TOPO, hi - lo, durations=S_DUR, max_actions=1, max_snapshots=16), time_window=20)
+    seeds = lambda ep: 1000 + 7 * ep + torch.arange(lo, hi, dtype=torch.int64)   # noqa: E731  (a function of the GLOBAL env id)
+    return [smp.sample_fused(_Actor(smp), num_steps=k, seeds=seeds, reset_every=4, state_dtype=torch.float64) for k in S_CALLS]
+
+
+def _sampler_worker(rank, world, port, result_path):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from maro_amd.cim.rollout import gather_experiences_to_learner, shard_range
+    lo, hi = shard_range(S_TOTAL, rank, world)
+    joined = [gather_experiences_to_learner(res, env_offset=lo, dst=0) for res in _sample_shard(lo, hi)]
+    if rank == 0:
+        torch.save(joined, result_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_experience_collection_equals_one_sampler(tmp_path, world):
+    path = str(tmp_path / "exp.pt")
+    mp.spawn(_sampler_worker, args=(world, _free_port(), path), nprocs=world, join=True)
+    joined = torch.load(path)
+    whole = _sample_shard(0, S_TOTAL)
+    total = 0
+    for a, b in zip(joined, whole):
+        assert set(a) == set(b)
+        for key in b:
+            assert a[key].dtype == b[key].dtype and torch.equal(a[key], b[key]), key
+        total += len(b["tick"])
+    assert total > 100
