@@ -478,6 +478,33 @@ def bench_collect(args, engines, streams, qnet, n, G, dev, rank, world, dist, re
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             t[0] = tm[0]
         dts.append(float(t[0])); vals.append(float(t[1]) / float(t[0])); exps.append(float(t[2]) / float(t[0]))
+    # ---- N > 1: the learner-side collection (outside the timed windows): one more call, its experiences joined on rank 0
+    # (gather_experiences_to_learner: ragged sizes, one grouped send / receive) — time and bytes of that exchange next to the
+    # time of the call that produced them
+    exp_gather = None
+    if dist is not None:
+        from maro_amd.cim.rollout import gather_experiences_to_learner
+        sync_all()
+        ta = time.perf_counter()
+        res = sample_fused_groups(samplers, qnet, args.steps, seeds=seeds_of, reset_every=args.reset_every)
+        sync_all()
+        tb = time.perf_counter()
+        mine = {k: torch.cat([r[k] for r in res]) for k in res[0] if k != "env_metric"}
+        goff = [0] + [sum(e.n_envs for e in engines[:g + 1]) for g in range(G - 1)]
+        mine["env_id"] = torch.cat([r["env_id"] + goff[g] for g, r in enumerate(res)])
+        nbytes = sum(t.numel() * t.element_size() for t in mine.values())
+        joined = gather_experiences_to_learner(mine, env_offset=rank * n, dst=0)
+        sync_all()
+        tc = time.perf_counter()
+        tt = torch.tensor([tb - ta, tc - tb, float(nbytes), float(mine["tick"].shape[0])], dtype=torch.float64, device=dev)
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            assert joined["tick"].shape[0] == int(tt[3].item())
+            exp_gather = {"sample_ms": float(tmax[0]) * 1e3, "gather_ms": float(tmax[1]) * 1e3, "gather_share": float(tmax[1] / (tmax[0] + tmax[1])),
+                          "bytes_all_ranks": float(tt[2]), "experiences": int(tt[3].item()), "steps_per_call": args.steps}
+        del joined, mine, res
     if rank == 0:
         med = sorted(range(len(vals)), key=lambda i: vals[i])[len(vals) // 2]
         out = {"metric": "env-steps/sec while collecting experiences (CimBatchSampler.sample_fused), CIM global_trade.22p",
@@ -488,7 +515,8 @@ def bench_collect(args, engines, streams, qnet, n, G, dev, rank, world, dist, re
                                       f"dueling DQN (random-init, exact-f32 MFMA) + CIMEnvSampler state / reward shaping + transition cache + roll-over",
                           "envs_per_gpu": n, "groups_per_gpu": G, "reset_every": args.reset_every, "specialized_kernels": bool(engines[0].specialized),
                           "reset_ms_whole_batch": reset_ms, "look_back": samplers[0].look_back, "reward_window": samplers[0].time_window,
-                          "what_a_step_is": "one sample_fused interaction of every env: mrx_cim_dqn_act (2 launches) + cache update (masked tensor ops) + mrx_cim_step"}}
+                          "experience_gather": exp_gather,
+                          "what_a_step_is": "one sample_fused interaction of every env: mrx_cim_dqn_act (2 launches) + mrx_cim_sampler_record + mrx_cim_step; per call: mrx_cim_sampler_emit"}}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

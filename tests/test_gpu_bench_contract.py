@@ -78,3 +78,27 @@ def test_bench_multi_rank_path_under_gloo(scenario, world):
         ge = j["config"]["trajectory_gather_every"]
         assert ge["steps_per_rollout"] == 16 and ge["gather_ms"] > 0 and 0 < ge["gather_share"] < 1
         assert ge["bytes_per_rank"] == 16 * n * (8 * 4 + 4 * 4 + 3 * 8 + 1 + 22 * 7 * 4)
+
+
+def test_bench_collect_multi_rank_path_under_gloo():
+    """`bench.py --policy dqn --collect --gpus 2`: every rank runs the batched EnvSampler loop over its env shard, the value is the
+    whole job's, and the learner-side collection (gather_experiences_to_learner) joins the ranks' experiences on rank 0."""
+    env = dict(os.environ, MRX_BENCH_BACKEND="gloo", MRX_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--policy", "dqn", "--collect", "--ring", "8", "--steps", "24",
+           "--warmup", "4", "--repeats", "1", "--envs", "192", "--durations", "260", "--preroll-ticks", "40", "--no-cpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    g = j["config"]["experience_gather"]
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["experiences_per_s"] > 0
+    assert g["experiences"] > 0 and g["gather_ms"] > 0 and 0 < g["gather_share"] < 1
+    # state + next_state + next_agent_state float32 [171] + action int64 + env_action int32 [4] + reward f32 + terminal + env_id / tick / agent int32
+    assert g["bytes_all_ranks"] == g["experiences"] * (3 * 171 * 4 + 8 + 16 + 4 + 1 + 12)
