@@ -114,7 +114,7 @@ def test_split_step_equals_unsorted(topology):
 
 
 def test_split_step_with_observation_and_two_actions():
-    side_by_side("global_trade.22p_l0.8", (1, 4), n=70, obs=True, max_actions=2, durations=24)
+    side_by_side("global_trade.22p_l0.8", (1, 4), n=66, obs=True, max_actions=2, durations=12)
 
 
 @pytest.mark.parametrize("topology", ["global_trade.22p_l0.8", "toy.5p_ssddd_l0.5"])
@@ -124,7 +124,7 @@ def test_fast_kernel_plus_one_workgroup_per_full_entry_equals_unsorted(topology)
 
 
 def test_launch_form_5_with_observation_and_two_actions():
-    side_by_side("global_trade.22p_l0.8", (1, 5), n=70, obs=True, max_actions=2, durations=24)
+    side_by_side("global_trade.22p_l0.8", (1, 5), n=66, obs=True, max_actions=2, durations=9)
 
 
 def test_launch_form_5_joint_mode():
