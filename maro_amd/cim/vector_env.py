@@ -422,6 +422,10 @@ class GpuEnvView:
     def summary(self) -> dict:
         return self._o._summary()
 
+    def dump(self) -> None:
+        """core.py:135-141: "Dump environment for restore.  NOTE: Not implemented." — a no-op there, a no-op here."""
+        return None
+
     def get_finished_events(self):
         return []
 
