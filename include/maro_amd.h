@@ -163,7 +163,8 @@ typedef struct mrx_cim_layout {
   int64_t off_vessel_period; /* int32 [n_envs][V] vessel_period_without_noise */
   int64_t off_orders;        /* [n_envs][durations][order_row_words] pre-generated order quantities per (src, dst) pair in
                                 target_offset CSR order, elements of order_elem_bytes bytes: uint16 when the plan proves every
-                                quantity fits (<= 65535: orders of a tick never exceed its order proportion), else int32;
+                                quantity fits (every source / target base >= |noise|, so no noised ratio is negative and a
+                                tick's orders never exceed its order proportion, itself <= 65535), else int32;
                                 0 when the order table is off */
   int32_t order_row_words, order_table_on;   /* (order_row_words = elements per row) */
   int32_t order_elem_bytes, reserved0;

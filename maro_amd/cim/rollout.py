@@ -210,12 +210,27 @@ class PipelinedCimBatch:
     ticks = property(lambda self: self.cat("ticks"))
     status = property(lambda self: self.cat("status"))
     ring_fi = property(lambda self: self.cat("ring_fi"))
+    layout = property(lambda self: self.engines[0].layout)   # per-env dimensions (ring slots, frame words ...) are the same in every group
 
     def _rows(self, x, g: int):
         """Group g's env rows of a whole-batch input (None stays None)."""
         return None if x is None else x[self.offsets[g]:self.offsets[g] + self.sizes[g]]
 
+    def _after_caller(self, *inputs) -> None:
+        """Stream discipline of the whole-batch calls: a DEVICE tensor the caller produced on torch's current stream is sliced and
+        handed to every group's engine, whose kernels run on the group's side stream — so each side stream first waits for the
+        caller's stream (one event wait per group, only when a device tensor is actually passed; host inputs are copied on the
+        group's stream by the engine itself)."""
+        if any(isinstance(x, torch.Tensor) and x.is_cuda for x in inputs):
+            cur = torch.cuda.current_stream(self.device)
+            for st in self.streams:
+                if st is not None:
+                    st.wait_stream(cur)
+
     def step(self, actions=None, n_actions=None, mask=None, n_answered=None):
+        """Whole-batch step.  Device-tensor inputs may come straight from the caller's current stream (see _after_caller); the
+        returned tensors are complete (cat() synchronises the groups)."""
+        self._after_caller(actions, n_actions, mask, n_answered)
         if actions is not None and not isinstance(actions, torch.Tensor):
             import numpy as np
             actions = np.asarray(actions).reshape(self.n_envs, self.max_actions, -1)
@@ -230,6 +245,7 @@ class PipelinedCimBatch:
         return self.cat("decisions"), self.cat("metrics"), self.cat("done")
 
     def reset(self, seed_cmd=None, mask=None) -> None:
+        self._after_caller(seed_cmd, mask)
         self.for_each(lambda g, eng: eng.reset(self._rows(seed_cmd, g), self._rows(mask, g)))
 
     def query(self, node: str, ticks, nodes, attrs, out=None) -> torch.Tensor:
@@ -237,6 +253,7 @@ class PipelinedCimBatch:
         ([nt] / [nn]) go to every group."""
         def part(x, g):
             return self._rows(x, g) if getattr(x, "ndim", 1) == 2 else x
+        self._after_caller(ticks, nodes)
         res = self.for_each(lambda g, eng: eng.query(node, part(ticks, g), part(nodes, g), attrs))
         self.synchronize()
         return torch.cat(res, dim=0)

@@ -184,14 +184,14 @@ class CimBatchSampler:
             self._last[rows] = torch.where(li >= new_tail[:, None], li, torch.full_like(li, -1))
 
     def sample(self, policy: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], num_steps: Optional[int] = None,
-               seeds: Optional[Callable[[int], torch.Tensor]] = None, state_dtype: torch.dtype = torch.float32) -> Dict[str, torch.Tensor]:
+               seeds: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, state_dtype: torch.dtype = torch.float32) -> Dict[str, torch.Tensor]:
         """``AbsEnvSampler.sample(num_steps)`` (rl/rollout/env_sampler.py:438-537) with the CIM example's shaping
         (examples/cim/rl/env_sampler.py:15-80) for every env of the engine at once, on device tensors.
 
         `policy(states [n, state_dim], decisions [n, 8]) -> model actions int64 [n]` (indices into the example's action
         space; rows of envs without a pending decision are ignored).  Every env performs `num_steps` interactions (None:
-        until the end of ITS episode); an env whose episode ends inside the call is reset (`seeds(episode_index int64 [n]) -> int64
-        [n]`: explicit seeds from every env's OWN episode count, or the reference's seed re-draw) and goes on, exactly like the reference loop.  Transitions
+        until the end of ITS episode); an env whose episode ends inside the call is reset (`seeds(episode_index: CPU int64 tensor [n]) -> int64
+        [n]` — see `_seed_fn`: explicit seeds from every env's OWN episode count, or the reference's seed re-draw) and goes on, exactly like the reference loop.  Transitions
         are emitted once they are `reward_eval_delay` (= time_window) ticks old — the delayed reward is evaluated after
         the loop on the per-attribute retention rows (mrx_cim_set_port_history), so the snapshot ring can stay a few
         frames deep (look_back) — and younger ones stay in the per-env cache for the next call, with the per-agent next
@@ -205,6 +205,7 @@ class CimBatchSampler:
         from .policy import translate_actions
         eng = self.eng
         n, dev = eng.n_envs, eng.decisions.device
+        seeds = _seed_fn(seeds, n)
         if not hasattr(self, "_c") or self.state_dtype != state_dtype:
             self._sample_init(state_dtype)
         c = self._c
@@ -283,7 +284,7 @@ class CimBatchSampler:
         res["env_metric"] = eng.metrics.clone()
         return res
 
-    def sample_fused(self, actor, num_steps: Optional[int], seeds: Optional[Callable[[int], torch.Tensor]] = None, reset_every: int = 1,
+    def sample_fused(self, actor, num_steps: Optional[int], seeds: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, reset_every: int = 1,
                      state_dtype: torch.dtype = torch.float32) -> Dict[str, torch.Tensor]:
         """``sample_fused_steps`` run to the end (see there); returns its result."""
         gen = self.sample_fused_steps(actor, num_steps, seeds=seeds, reset_every=reset_every, state_dtype=state_dtype)
@@ -293,7 +294,7 @@ class CimBatchSampler:
             except StopIteration as stop:
                 return stop.value
 
-    def sample_fused_steps(self, actor, num_steps: Optional[int], seeds: Optional[Callable[[int], torch.Tensor]] = None, reset_every: int = 1,
+    def sample_fused_steps(self, actor, num_steps: Optional[int], seeds: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, reset_every: int = 1,
                            state_dtype: torch.dtype = torch.float32):
         """A GENERATOR over the interactions of one call (it yields after each step's work has been enqueued and returns the
         result dict through StopIteration) — so that the samplers of several env groups, each on its own HIP stream, can be
@@ -309,6 +310,8 @@ class CimBatchSampler:
         masked full-batch tensor ops (no ``nonzero`` / ``bool()`` / ``int()`` per step); the next state of an element is
         filled in by the NEXT step's gather (one extra state evaluation after the loop).
 
+        `seeds`: as in ``sample`` — called with a CPU int64 tensor [n] of every env's own episode count (`_seed_fn`).
+
         `reset_every` = K: envs whose episode ended are finalised, emitted and reset at every K-th step only (and at the
         start of a call); in between they sit the steps out.  K = 1 is ``sample`` exactly (every env performs `num_steps`
         interactions; one flag read per step); K > 1 trades that alignment for a sync-free step path — each env's own stream
@@ -316,6 +319,7 @@ class CimBatchSampler:
         from .engine import SEED_REDRAW
         eng = self.eng
         n, dev = eng.n_envs, eng.decisions.device
+        seeds = _seed_fn(seeds, n)
         # An engine bound to a side stream (CimBatchEngine.use_stream): the sampler's own tensor ops go to that stream too.  The
         # stream is switched per SEGMENT, never across a `yield` (another group's generator runs in between).
         bound = getattr(eng, "_bound_stream", None)
@@ -493,6 +497,28 @@ class CimBatchSampler:
         alive = p_active & ~self._eoe
         own = c["state"][ar, pj]
         c["next_state"][ar, pj] = torch.where(alive[:, None], new, torch.where(p_active[:, None], own, c["next_state"][ar, pj]))
+
+
+def _seed_fn(seeds, n: int):
+    """The `seeds` argument of sample / sample_fused*: a callable `seeds(episode_index) -> seed commands`.  `episode_index` is a
+    CPU int64 tensor [n] — every env's OWN episode count (the reference runs one sampler loop per env: episode k of an env gets
+    seed k of that env, whatever the rest of the batch is doing).  It may return an int64 tensor [n] on any device, or — for
+    callers written against the single-env reference, `lambda ep: base + ep` style — anything that broadcasts to [n] on the CPU
+    (a Python int, a 0-d or 1-element tensor).  Only the entries of the envs being reset are used."""
+    if seeds is None:
+        return None
+
+    def fn(ep_env: torch.Tensor) -> torch.Tensor:
+        cmd = seeds(ep_env)
+        if not isinstance(cmd, torch.Tensor):
+            cmd = torch.as_tensor(cmd, dtype=torch.int64)
+        cmd = cmd.to(torch.int64)
+        if cmd.numel() == 1 and n != 1:
+            cmd = cmd.reshape(()).cpu().expand(n).contiguous()
+        if cmd.shape != (n,):
+            raise ValueError(f"seeds(episode_index int64 [{n}] on the CPU) must return {n} seed commands, got shape {tuple(cmd.shape)}")
+        return cmd
+    return fn
 
 
 def sample_fused_groups(samplers, actors, num_steps: int, seeds=None, reset_every: int = 1, state_dtype: torch.dtype = torch.float32,

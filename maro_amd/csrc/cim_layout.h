@@ -220,8 +220,13 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
     k.pregen = NT > 0 ? 1 : 0;
   }
   k.NTP = (NT + 7) / 8 * 8;   // (16-byte rows for either element size; padding uint16 rows to whole 128-byte lines measured no difference)
-  // uint16 elements when no quantity can come near 65535: a pair's orders of a tick never exceed the tick's order proportion
-  // (cim_data_container.py:354-393: min(..., remaining)), which is floor(clip(dist + noise, 0, 1) * total_containers) (parsers.py:57-106)
+  // uint16 elements only when the plan PROVES every quantity <= 65535.  The proof needs two facts:
+  //  (1) no noised ratio can be negative: apply_noise is base + uniform(-noise, noise) with no clipping (utils.py:30-42), so every
+  //      source and target base must be >= |noise|.  Then list_sum_normalize yields ratios in [0, 1], ceil(n * ratio) <= n, and
+  //      cim_data_container.py:354-393 gives cur_num <= cur_port_order_num <= remaining_orders <= orders_to_gen.  (With a negative
+  //      ratio `remaining_orders` GROWS and a later ratio can be far above 1: no bound exists, so those plans keep int32.)
+  //  (2) orders_to_gen = order_proportion[tick] <= max over the period of floor(clip(dist + noise, 0, 1) * total_containers)
+  //      (parsers.py:57-106) <= 65535.
   k.order_half = 0;
   if (k.pregen && t->data_mode != 2) {
     double mx = 0;
@@ -229,7 +234,10 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
     else {
       for (int i = 0; i < t->period; i++) { double c = t->order_dist[i] + fabs(t->sample_noise); c = c > 1 ? 1 : c; if (c * (double)t->total_containers > mx) mx = c * (double)t->total_containers; }
     }
-    k.order_half = mx <= 32767.0 ? 1 : 0;   // (a factor 2 of headroom: with a NEGATIVE noised ratio the reference lets `remaining` grow, cim_data_container.py:354-375)
+    bool nonneg = true;
+    for (int p = 0; p < P; p++) if (!(t->source_base[p] >= fabs(t->source_noise[p]))) nonneg = false;
+    for (int i = 0; i < NT; i++) if (!(t->target_base[i] >= fabs(t->target_noise[i]))) nonneg = false;
+    k.order_half = (nonneg && mx <= 65535.0) ? 1 : 0;
   }
   const int dsrc_w = 2 * ((P + 1) / 2 * 2);
   const int dtgt_w = 2 * (NT + 1) > 3 * 64 ? 2 * (NT + 1) : 3 * 64;

@@ -130,3 +130,17 @@ def test_synthetic_resolution_and_ring():
 
 def test_no_action_and_other_seed():
     run_pair(VARIANTS["repeated_ports_noisy"], durations=60, seed=123456789, policy=False)
+
+
+def test_order_table_width_follows_the_plan_proof():
+    """uint16 order-table elements only where the plan PROVES the bound (cim_layout.h: every source / target base >= |noise|, so
+    no noised ratio is negative, and max order proportion <= 65535); a topology whose ratios can go negative keeps int32, because
+    the reference then lets `remaining_orders` grow (cim_data_container.py:354-375) and a pair's quantity has no bound."""
+    def width(topo):
+        return EmuBackend(topo, 1, durations=30).layout.order_elem_bytes
+    assert width(load_topology("global_trade.22p_l0.8")) == 2
+    assert width(parse_config(copy.deepcopy(VARIANTS["repeated_ports_noisy"]), name="synthetic")) == 2
+    assert width(parse_config(copy.deepcopy(VARIANTS["negative_ratios"]), name="synthetic")) == 4
+    big = base_conf()
+    big["total_containers"] = 3_000_000      # 0.064 x 3e6 > 65535
+    assert width(parse_config(big, name="synthetic")) == 4

@@ -257,6 +257,7 @@ def check_pipelined_object_api(single_factory, grouped_factory, n=7, steps=60):
 
     last = [env.step(None) for env in envs]
     same(*last)
+    assert envs[0].env_view(0).business_engine.calc_max_snapshots() == envs[1].env_view(n - 1).business_engine.calc_max_snapshots() > 0   # (grouped: PipelinedCimBatch.layout)
     cur = list(last[0][1])                  # the latest decision event of every env
     for k in range(steps):
         if last[0][2]:
