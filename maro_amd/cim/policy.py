@@ -68,6 +68,60 @@ def dueling_chain(trunk: Chain, q_head: Chain, v_head: Chain) -> Chain:
     return out
 
 
+def chain_from_state_dict(sd, eps: float = 1e-5) -> Chain:
+    """A ``MyQNet`` state_dict (examples/cim/rl/algorithms/dqn.py:25-52 — what ``AbsNet.get_state()["network"]`` carries,
+    maro/rl/model/abs_net.py:65-74) -> the folded dense chain, without building the module: keys are
+    ``<_fc|_q|_v>._net.<i>.<batch_norm|linear>.<weight|bias|running_mean|running_var>`` (fc_block.py:112-133).  Eval-mode
+    BatchNorm is folded into the following Linear in float64 exactly as ``fold_fully_connected`` does; with ``_q`` / ``_v``
+    present the heads are laid side by side (``dueling_chain``)."""
+    def arr(k):
+        v = sd[k]
+        return (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)).astype(np.float64)
+
+    def block(prefix) -> Chain:
+        idx = sorted({int(k[len(prefix) + 6:].split(".")[0]) for k in sd if k.startswith(prefix + "._net.")})
+        out: Chain = []
+        for i in idx:
+            base = f"{prefix}._net.{i}."
+            w = arr(base + "linear.weight").T.copy()
+            b = arr(base + "linear.bias") if base + "linear.bias" in sd else np.zeros(w.shape[1])
+            if base + "batch_norm.running_var" in sd:
+                var, mean = arr(base + "batch_norm.running_var"), arr(base + "batch_norm.running_mean")
+                gamma = arr(base + "batch_norm.weight") if base + "batch_norm.weight" in sd else np.ones_like(var)
+                beta = arr(base + "batch_norm.bias") if base + "batch_norm.bias" in sd else np.zeros_like(var)
+                sc = gamma / np.sqrt(var + eps)
+                b = b + (beta - mean * sc) @ w
+                w = w * sc[:, None]
+            out.append((w.astype(np.float32), b.astype(np.float32)))
+        return out
+    trunk = block("_fc")
+    if any(k.startswith("_q._net.") for k in sd):
+        return dueling_chain(trunk, block("_q"), block("_v"))
+    return trunk
+
+
+def chains_from_policy_state(policy_state: dict) -> dict:
+    """The reference's ``policy_state`` — ``{policy_name: policy.get_state()}``, the dict ``BatchEnvSampler.sample`` ships to
+    every rollout worker with each call (maro/rl/rollout/batch_env_sampler.py:150-176, worker.py:56-67) and
+    ``AbsAgentWrapper.set_policy_state`` applies (env_sampler.py:37-46) — -> ``{port index: folded chain}``.  A policy's state
+    is ``{"net": {"network": state_dict, "optim": ...}, "policy": ...}`` (discrete_rl_policy.py:217-225); bare state_dicts and
+    ``{"network": ...}`` dicts are accepted too.  The port index is the agent index in the policy's name
+    (``f"{algorithm}_{agent}.policy"``, examples/cim/rl/rl_component_bundle.py:20), or the key itself when it is an int."""
+    out = {}
+    for name, st in policy_state.items():
+        if isinstance(name, (int, np.integer)):
+            port = int(name)
+        else:
+            digits = [t for t in str(name).replace(".", "_").split("_") if t.isdigit()]
+            if not digits:
+                raise KeyError(f"cannot tell which port policy {name!r} belongs to (expected '<algorithm>_<agent>.policy')")
+            port = int(digits[-1])
+        sd = st.get("net", st) if isinstance(st, dict) else st
+        sd = sd.get("network", sd) if isinstance(sd, dict) and "network" in sd else sd
+        out[port] = chain_from_state_dict(sd)
+    return out
+
+
 def random_chains(n_ports: int, state_dim: int, action_num: int = 21, hidden: Sequence[int] = (256, 128, 64, 32),
                   head_hidden: int = 128, seed: int = 0) -> List[Chain]:
     """Random-init per-port dueling networks of the example's architecture (there are no trained checkpoints offline)."""
@@ -83,6 +137,32 @@ def random_chains(n_ports: int, state_dim: int, action_num: int = 21, hidden: Se
         nets.append(dueling_chain(trunk, [lin(dims[-1], head_hidden), lin(head_hidden, action_num)],
                                   [lin(dims[-1], head_hidden), lin(head_hidden, 1)]))
     return nets
+
+
+def pack_policy(chains: Sequence[Chain], n_actions: int = len(ACTION_SPACE), dueling: bool = True) -> torch.Tensor:
+    """Host only (no GPU, no engine): folded chains -> the packed MFMA operand blob, float32 [len(chains), per] on the CPU
+    (mrx_cim_dqn_pack_net; the layout depends on the layer widths alone).  What a LEARNER rank — which owns no rollout engine —
+    hands to ``rollout.broadcast_policy``; ``FusedPerPortDQN.pack`` is the same call on an actor's own model struct."""
+    L = _lib.load()
+    m = _lib.MrxCimDqnModel()
+    dims = [chains[0][0][0].shape[0]] + [w.shape[1] for w, _ in chains[0]]
+    m.n_nets, m.n_layers, m.dueling, m.n_actions = len(chains), len(chains[0]), int(dueling), int(n_actions)
+    for i, d in enumerate(dims):
+        m.dims[i] = d
+    return _pack(L, m, chains, [tuple(w.shape) for w, _ in chains[0]])
+
+
+def _pack(L, m, chains: Sequence[Chain], shapes) -> torch.Tensor:
+    per = _lib.check(L.mrx_cim_dqn_net_floats(ctypes.byref(m)), "mrx_cim_dqn_net_floats")
+    host = np.zeros((len(chains), per), dtype=np.float32)
+    for p, chain in enumerate(chains):
+        assert [tuple(w.shape) for w, _ in chain] == list(shapes), "all ports share one architecture"
+        ws = [np.ascontiguousarray(w, dtype=np.float32) for w, _ in chain]
+        bs = [np.ascontiguousarray(b, dtype=np.float32) for _, b in chain]
+        wp = (ctypes.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+        bp = (ctypes.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
+        _lib.check(L.mrx_cim_dqn_pack_net(ctypes.byref(m), wp, bp, host[p].ctypes.data), "mrx_cim_dqn_pack_net")
+    return torch.from_numpy(host)
 
 
 class FusedPerPortDQN:
@@ -109,20 +189,52 @@ class FusedPerPortDQN:
         for i, a in enumerate(action_space):
             m.action_space[i] = float(a)
         self.state_dim, self.n_actions = dims[0], len(action_space)
-        per = _lib.check(self._L.mrx_cim_dqn_net_floats(ctypes.byref(m)), "mrx_cim_dqn_net_floats")
-        host = np.zeros((len(chains), per), dtype=np.float32)
-        for p, chain in enumerate(chains):
-            assert [w.shape for w, _ in chain] == [w.shape for w, _ in chains[0]], "all ports share one architecture"
-            ws = [np.ascontiguousarray(w, dtype=np.float32) for w, _ in chain]
-            bs = [np.ascontiguousarray(b, dtype=np.float32) for _, b in chain]
-            wp = (ctypes.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
-            bp = (ctypes.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
-            _lib.check(self._L.mrx_cim_dqn_pack_net(ctypes.byref(m), wp, bp, host[p].ctypes.data), "mrx_cim_dqn_pack_net")
-        self.weights = torch.from_numpy(host).to(engine.device)
+        self._m, self._shapes = m, [tuple(w.shape) for w, _ in chains[0]]
+        self._per = _lib.check(self._L.mrx_cim_dqn_net_floats(ctypes.byref(m)), "mrx_cim_dqn_net_floats")
+        # the packed blob lives in ONE device tensor for the actor's lifetime (m.d_weights points into it): a learner refreshes
+        # the policy by overwriting it in place (set_policy_state), never by re-allocating
+        self.weights = self.pack(chains).to(engine.device)
         m.d_weights = self.weights.data_ptr()
-        self._m = m
         self.scratch = torch.zeros(_lib.check(self._L.mrx_cim_dqn_scratch_bytes(engine._h), "mrx_cim_dqn_scratch_bytes"),
                                    dtype=torch.uint8, device=engine.device)
+
+    def pack(self, chains: Sequence[Chain]) -> torch.Tensor:
+        """Host side of a policy update: folded chains -> the MFMA operand layout (mrx_cim_dqn_pack_net), float32 [len(chains), per]
+        on the CPU.  What a learner broadcasts (`rollout.broadcast_policy`) and `set_policy_state` copies in."""
+        return _pack(self._L, self._m, chains, self._shapes)
+
+    def set_policy_state(self, state, ports: Optional[Sequence[int]] = None) -> None:
+        """Refresh the networks IN PLACE — the sampler side of the reference's ``set_policy_state``
+        (maro/rl/rollout/env_sampler.py:37-46; shipped with every ``sample`` request, batch_env_sampler.py:150-176).
+
+        `state`: a packed blob (float32 [n_nets, per], CPU or device — what `pack` / `broadcast_policy` hand over), a list of
+        folded chains (one per port, or per entry of `ports`), or the reference's ``{policy_name: policy.get_state()}`` dict
+        (only the ports it names are touched).  No re-allocation: `weights` keeps its address, so ``mrx_cim_dqn_model.d_weights``
+        stays valid.  Stream-ordered: the copy is enqueued on the engine's stream (the bound side stream, if any), after the
+        caller's current stream when `state` is a device tensor — every `act` issued after this call sees the new weights,
+        every `act` issued before it the old ones."""
+        if isinstance(state, dict):
+            by_port = chains_from_policy_state(state)
+            ports = sorted(by_port)
+            state = [by_port[p] for p in ports]
+        if not isinstance(state, torch.Tensor):
+            state = self.pack(state)
+        rows = list(range(self.weights.shape[0])) if ports is None else [int(p) for p in ports]
+        assert state.dtype == torch.float32 and tuple(state.shape) == (len(rows), self._per), \
+            f"packed policy state must be float32 [{len(rows)}, {self._per}], got {state.dtype} {tuple(state.shape)}"
+        bound = getattr(self.eng, "_bound_stream", None)
+        dev = self.weights.device
+        if state.is_cuda and bound is not None:
+            bound.wait_stream(torch.cuda.current_stream(dev))
+        import contextlib
+        with (torch.cuda.stream(bound) if bound is not None else contextlib.nullcontext()):
+            if ports is None:
+                self.weights.copy_(state, non_blocking=True)
+            else:
+                self.weights[torch.as_tensor(rows, dtype=torch.int64, device=dev)] = state.to(dev, non_blocking=True)
+            if not state.is_cuda and dev.type == "cuda":
+                # a pageable host source may be reused by the caller as soon as this returns
+                (bound or torch.cuda.current_stream(dev)).synchronize()
 
     def act(self, actions: torch.Tensor, n_actions: torch.Tensor, decisions: Optional[torch.Tensor] = None,
             q: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None, choice: Optional[torch.Tensor] = None,

@@ -131,6 +131,41 @@ def gather_experiences_to_learner(exp: Dict[str, torch.Tensor], env_offset: int 
     return res
 
 
+def broadcast_policy(packed: Optional[torch.Tensor], actors=(), src: int = 0, group=None, like: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The return half of config 5's loop: the learner's refreshed networks to every sampler rank — ONE ``dist.broadcast`` of the
+    packed weight blob (22 nets x ~90 k floats = ~8 MB for the CIM example; RCCL over xGMI on GPUs, gloo in the CPU tests), then
+    an in-place, stream-ordered ``set_policy_state`` on each of the rank's actors (one ``FusedPerPortDQN`` per env group).
+    Replaces the reference's ``policy_state`` dict pickled into every ``sample`` request and applied by each worker
+    (maro/rl/rollout/batch_env_sampler.py:150-176, worker.py:56-67, env_sampler.py:37-46).
+
+    `packed`: on `src` the new blob (``policy.pack_policy(chains)`` / ``actor.pack(chains)``, CPU or device); ignored on the
+    other ranks, which receive into a buffer shaped like their first actor's weights (or `like`).  Returns the blob every rank
+    now holds (on the actors' device).  With no process group (single rank) it is just the local update."""
+    import torch.distributed as dist
+
+    actors = list(actors)
+    ref = actors[0].weights if actors else like
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if not multi or rank == src:
+        assert packed is not None, "the source rank must pass the packed policy"
+        buf = packed if ref is None else packed.to(device=ref.device, dtype=torch.float32)
+    else:
+        assert ref is not None, "a receiving rank needs actors (or `like`) to know the blob's shape"
+        buf = torch.empty_like(ref)
+    buf = buf.contiguous()
+    if multi:
+        if buf.is_cuda and dist.get_backend(group) == "gloo":   # test hook only (see gather_to_learner)
+            host = buf.cpu()
+            dist.broadcast(host, src=src, group=group)
+            buf.copy_(host)
+        else:
+            dist.broadcast(buf, src=src, group=group)
+    for a in actors:
+        a.set_policy_state(buf)
+    return buf
+
+
 class PipelinedCimBatch:
     """A per-GPU env batch split into `groups` independent `CimBatchEngine`s, each on its own HIP stream.
 

@@ -143,3 +143,56 @@ def test_gloo_experience_collection_equals_one_sampler(tmp_path, world):
             assert a[key].dtype == b[key].dtype and torch.equal(a[key], b[key]), key
         total += len(b["tick"])
     assert total > 100
+
+
+# ---- the return half of config 5's loop: the learner's refreshed networks reach every sampler rank in ONE broadcast of the
+# packed blob (rollout.broadcast_policy) and are applied in place; every rank's next act then equals the learner's net
+class _PackedCpuActor:
+    """CPU stand-in for FusedPerPortDQN: owns a packed weight tensor (fixed address), evaluates the per-port nets from it."""
+
+    def __init__(self, chains):
+        from maro_amd.cim.policy import pack_policy
+        from tests.test_policy import unpack_index
+        self._like, self._pos = chains[0], unpack_index(chains[0])
+        self.weights = pack_policy(chains)
+
+    def set_policy_state(self, packed):
+        self.weights.copy_(packed)
+
+    def q(self, states, port):
+        from maro_amd.cim.policy import PerPortDuelingQNet
+        from tests.test_policy import unpack_policy
+        chains = [unpack_policy(self.weights[p].numpy(), self._like, self._pos) for p in range(self.weights.shape[0])]
+        return PerPortDuelingQNet(chains, 21)(states, port)
+
+
+def _policy_worker(rank, world, port, result_path):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from maro_amd.cim.policy import pack_policy, random_chains
+    from maro_amd.cim.rollout import broadcast_policy
+    arch = dict(hidden=(40, 24, 12), head_hidden=20)
+    actors = [_PackedCpuActor(random_chains(4, 45, 21, seed=100 + rank, **arch)) for _ in range(2)]   # two env groups per rank, stale nets
+    addr = [a.weights.data_ptr() for a in actors]
+    new = pack_policy(random_chains(4, 45, 21, seed=7, **arch)) if rank == 0 else None             # only the learner has the update
+    got = broadcast_policy(new, actors, src=0)
+    assert [a.weights.data_ptr() for a in actors] == addr                                          # in place
+    g = torch.Generator().manual_seed(3)
+    states, ports = torch.randn(32, 45, generator=g) * 5, torch.randint(0, 4, (32,), generator=g)
+    torch.save({"blob": got.clone(), "q": [a.q(states, ports) for a in actors]}, f"{result_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_policy_broadcast_reaches_every_rank(tmp_path):
+    from maro_amd.cim.policy import PerPortDuelingQNet, pack_policy, random_chains
+    path = str(tmp_path / "pol")
+    mp.spawn(_policy_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    learner = random_chains(4, 45, 21, seed=7, hidden=(40, 24, 12), head_hidden=20)
+    g = torch.Generator().manual_seed(3)
+    states, ports = torch.randn(32, 45, generator=g) * 5, torch.randint(0, 4, (32,), generator=g)
+    want_q, want_blob = PerPortDuelingQNet(learner, 21)(states, ports), pack_policy(learner)
+    for rank in range(2):
+        r = torch.load(f"{path}.{rank}")
+        assert torch.equal(r["blob"], want_blob)
+        assert all(torch.equal(q, want_q) for q in r["q"])

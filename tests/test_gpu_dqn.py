@@ -77,3 +77,91 @@ def test_fused_dqn_small_widths_and_few_ports():
 def test_fused_dqn_other_widths_and_epsilon():
     run_case("toy.5p_ssddd_l0.2", 130, 100, 40, 5, ["empty", "full", "booking"], ["empty", "full"], (192, 64, 17), 96, 9)
     run_case("toy.4p_ssdd_l0.0", 64, 100, 30, 4, ["transfer_cost", "empty"], ["early_discharge"], (48,), 20, 11, epsilon=0.5)
+
+
+def test_set_policy_state_refreshes_the_networks_in_place():
+    """A learner's update reaches a live actor without re-allocation (the reference: AbsAgentWrapper.set_policy_state,
+    maro/rl/rollout/env_sampler.py:37-46): after set_policy_state the fused q-values are those of the NEW chains (= a fresh
+    actor built from them, bit for bit), `weights` keeps its address, partial updates touch only the named ports, and the
+    update is stream-ordered on an engine bound to a side stream."""
+    from maro_amd.cim.engine import CimBatchEngine
+    from maro_amd.cim.policy import ACTION_SPACE, FusedPerPortDQN, random_chains
+    from maro_amd.cim.sampler import CimBatchSampler
+    n, A = 300, len(ACTION_SPACE)
+    eng = CimBatchEngine("toy.5p_ssddd_l0.5", n, durations=80, seeds=torch.arange(n, dtype=torch.int64) + 9)
+    sd = CimBatchSampler(eng).state_dim
+    arch = dict(hidden=(64, 32), head_hidden=16)
+    old, new = (random_chains(5, sd, A, seed=s, **arch) for s in (1, 2))
+    actor, fresh_new = FusedPerPortDQN(eng, old), FusedPerPortDQN(eng, new)
+    mixed = FusedPerPortDQN(eng, [new[p] if p in (1, 3) else old[p] for p in range(5)])
+    bufs = lambda: (torch.zeros((n, 1, 4), dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda"),  # noqa: E731
+                    torch.zeros((n, A), dtype=torch.float32, device="cuda"))
+    eng.step()
+    for _ in range(5):
+        a, na, q = bufs()
+        actor.act(a, na, q=q)
+        eng.step(a, na)
+    addr = actor.weights.data_ptr()
+    valid = eng.decisions[:, 7] == 1
+    assert int(valid.sum()) > 100
+
+    def qs(ac):
+        a, na, q = bufs()
+        ac.act(a, na, q=q)
+        torch.cuda.synchronize()
+        return q[valid].clone()
+    q_old = qs(actor)
+    actor.set_policy_state([new[1], new[3]], ports=[1, 3])                      # partial: chains for two ports
+    assert torch.equal(qs(actor), qs(mixed)) and actor.weights.data_ptr() == addr
+    actor.set_policy_state(actor.pack(new).cuda())                              # a device blob (what broadcast_policy hands over)
+    assert torch.equal(qs(actor), qs(fresh_new)) and not torch.equal(qs(actor), q_old)
+    actor.set_policy_state(old)                                                 # a list of chains
+    assert torch.equal(qs(actor), q_old) and actor.weights.data_ptr() == addr
+    # bound to a side stream: act issued right after the update sees the new weights without any explicit synchronisation
+    st = torch.cuda.Stream()
+    eng.use_stream(st)
+    blob = actor.pack(new).cuda() * 1.0       # produced on the current stream
+    actor.set_policy_state(blob)
+    a, na, q = bufs()
+    actor.act(a, na, q=q)
+    st.synchronize()
+    eng.use_stream(None)
+    assert torch.equal(q[valid], qs(fresh_new))
+
+
+def test_rccl_is_loaded_once_on_one_gpu():
+    """`init_process_group("nccl", world_size=1)` in a child process (own timeout): RCCL loads, a communicator is created, and the
+    device-tensor branches of broadcast_policy / gather_to_learner's size exchange run on it — so the first 8-GPU run is not the
+    first time this build meets RCCL."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2])
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+from maro_amd.cim.engine import CimBatchEngine
+from maro_amd.cim.policy import ACTION_SPACE, FusedPerPortDQN, random_chains
+from maro_amd.cim.rollout import broadcast_policy
+from maro_amd.cim.sampler import CimBatchSampler
+eng = CimBatchEngine("toy.4p_ssdd_l0.0", 64, durations=40, seeds=torch.arange(64))
+sd = CimBatchSampler(eng).state_dim
+old, new = (random_chains(4, sd, len(ACTION_SPACE), seed=s, hidden=(32, 16), head_hidden=8) for s in (1, 2))
+actor = FusedPerPortDQN(eng, old)
+want = actor.pack(new).cuda()
+x = want.clone()
+dist.broadcast(x, src=0)                       # RCCL collective on a device tensor
+t = torch.ones(4, device="cuda"); dist.all_reduce(t); sizes = [torch.zeros(2, dtype=torch.int64, device="cuda")]
+dist.all_gather(sizes, torch.tensor([64, 3], dtype=torch.int64, device="cuda"))
+got = broadcast_policy(want, [actor], src=0)    # world 1: the local, in-place update
+torch.cuda.synchronize()
+assert torch.equal(x, want) and torch.equal(actor.weights, want) and sizes[0].tolist() == [64, 3] and t.tolist() == [1.0] * 4
+print("RCCL_OK", dist.get_backend())
+dist.destroy_process_group()
+"""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code, repo, "29631"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "RCCL_OK nccl" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
