@@ -3,9 +3,10 @@
 
 Needs the reference built as for gen_golden.py, plus two stub modules on sys.path (the real packages are not
 installed here): `holidays` (US() that contains nothing) and `geopy.distance` (haversine) — see SURVEY.md §8c.
-The toy data (trips.bin etc.) is generated ONCE by the reference's own pipeline
+The toy data (trips.bin etc.) was generated ONCE by the reference's own pipeline
 (`CitiBikeProcess(is_temp=False).topologies[name].download/clean/build`, unseeded random) and compiled with
-tools/import_maro_citi_bike.py; the goldens and the packaged .npz must come from the same build folder.
+tools/import_maro_citi_bike.py into the packaged .npz; on a fresh reference build the folders and config.yml variants are written
+back from those .npz files (oracle/setup_toy_topologies.py, which also proves that all 15 toy goldens regenerate byte for byte).
 
     python oracle/gen_golden_citi_bike.py --maro /tmp/oracle/maro_src --stubs /tmp/oracle/stubs --out tests/golden
 """
@@ -56,13 +57,18 @@ CASES = {
 
 
 def ensure_synthetic(maro_root, topology):
-    """city.*: (re)generate the build folder + config.yml and register the topology with the reference checkout."""
+    """city.*: (re)generate the build folder + config.yml and register the topology with the reference checkout; toy.*: write them
+    back from the packaged data (oracle/setup_toy_topologies.py) — so every case runs on a fresh `oracle/build_ref.sh` build."""
     sys.path.insert(0, REPO)
+    sys.path.insert(0, HERE)
     import yaml
     from maro_amd.citi_bike.synthetic import PACKAGED, build_packaged
-    if topology not in PACKAGED:
-        return
     home = os.environ.get("MARO_ORACLE_HOME", "/tmp/oracle/home")
+    if topology not in PACKAGED:
+        # toy.*: the build folder + config.yml written back from the packaged .npz when a fresh reference build lacks them
+        from setup_toy_topologies import ensure_toy
+        ensure_toy(maro_root, home, topology)
+        return
     bd = os.path.join(home, ".maro", "data", "citi_bike", ".build", topology)
     cfg, _ = build_packaged(topology, bd)
     tdir = os.path.join(maro_root, "maro", "simulator", "scenarios", "citi_bike", "topologies", topology)
