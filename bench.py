@@ -142,27 +142,42 @@ def cpu_baseline_citi_bike(topology, durations, res, budget_s):
             "sample": f"{steps} decisions of {topology} ({episodes} episode(s), pure-Python oracle, {dt:.1f} s on 1 core)"}
 
 
-def bench_citi_bike(args):
+def measured_bytes_citi_bike(topology, n, step_budget, code_key):
+    """HBM bytes one batch step of this citi_bike configuration really moves (profiles/latest_pmc_citi_bike.json: separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes, all kernels of one batch step) -> (bytes or None, basis).  An entry of another build
+    (its code_object_key differs) or another batch size is NOT used: the fraction is then null, never a formula."""
+    try:
+        with open(os.path.join(REPO, "profiles", "latest_pmc_citi_bike.json")) as fp:
+            pmc = json.load(fp)
+    except (OSError, ValueError):
+        return None, "no profiles/latest_pmc_citi_bike.json"
+    state = "no PMC entry of this topology / batch size / step budget"
+    for ent in pmc.get("entries", []):
+        if ent["topology"] == topology and ent["envs_per_launch"] == n and ent.get("step_budget", 0) == step_budget:
+            if ent.get("code_object_key") is not None and ent.get("code_object_key") != code_key:
+                state = f"the PMC entry is of another build (code object {ent.get('code_object_key')}, running {code_key})"
+                continue
+            return (2 * ent["fetch_size_kib"] + ent["write_size_kib"]) * 1024, \
+                f"measured HBM bytes (PMC: 2 x FETCH_SIZE + WRITE_SIZE summed over every kernel of one batch step, {pmc['source']}; entry of git {ent.get('git_head')})"
+    return None, state
+
+
+def bench_citi_bike(args, dist, dev, rank, world):
     """BASELINE.json configs[3]: citi_bike toy.3s_4t, 4096 envs per GPU, shared trip table, per-env action seeds.
-    One step = device policy -> mrx_cb_step (action + ticks until the next decision) -> stations snapshot slice."""
+    One step = device policy -> mrx_cb_step (action + ticks until the next decision) -> stations snapshot slice.
+    Returns the JSON object on rank 0 (None elsewhere)."""
+    import numpy as np
     import torch
 
-    import __graft_entry__ as ge
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist, dev = init_dist(world, local_rank, build=ge.build)
-    torch.cuda.set_device(dev)
-    import numpy as np
-
+    from maro_amd.citi_bike.data import load_topology as load_cb
     from maro_amd.citi_bike.engine import CitiBikeBatchEngine
 
     n, res = args.envs, 10
     topology = args.topology if args.topology != "global_trade.22p_l0.8" else "toy.3s_4t"
     durations = args.durations if args.durations != 1120 else 44000
-    from maro_amd.citi_bike.data import load_topology as load_cb
     durations = min(durations, len(load_cb(topology).tick_day))   # (city.180s holds two days of trips, the toys a month)
-    kw = dict(durations=durations, snapshot_resolution=res, max_snapshots=16, max_actions=1, device=dev, seeds=np.arange(n) + rank * n + 1)
+    seeds = np.arange(n) + rank * n + 1
+    kw = dict(durations=durations, snapshot_resolution=res, max_snapshots=16, max_actions=1, device=dev, seeds=seeds)
     try:
         eng = CitiBikeBatchEngine(topology, n, specialize=bool(args.specialize), **kw)   # kernels compiled for this plan (cached in-tree)
     except (RuntimeError, OSError, subprocess.CalledProcessError) as e:
@@ -205,22 +220,25 @@ def bench_citi_bike(args):
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    t_leg = time.perf_counter()
     step_i = 0
     for _ in range(args.warmup):
         one_step(step_i)
         step_i += 1
     sync_all()
-    counter.zero_()
-    tick0 = eng.ticks.to(torch.int64).sum().item()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(step_i)
-        step_i += 1
-    sync_all()
-    dt = time.perf_counter() - t0
-    resolved = int(counter.item())
-    ticks_adv = eng.ticks.to(torch.int64).sum().item() - tick0
+    # the timed window: exactly --steps batch steps between barrier + synchronize, --repeats times back to back (value = median)
+    windows = []
+    for _ in range(max(1, args.repeats)):
+        counter.zero_()
+        tick0 = eng.ticks.to(torch.int64).sum().item()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(step_i)
+            step_i += 1
+        sync_all()
+        dt = time.perf_counter() - t0
+        windows.append((dt, float(counter.item()), float(eng.ticks.to(torch.int64).sum().item() - tick0)))
     n_done = int(eng.done.sum().item())
     status_bad = int((eng.status != 0).sum().item())
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 100))]
@@ -273,57 +291,59 @@ def bench_citi_bike(args):
         gather_ms = (time.perf_counter() - tg) * 1e3
         if rank == 0:
             assert out["decisions"].shape[1] == n * world
-    t_max = torch.tensor([dt, bounded[1] if bounded else 0.0], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(resolved), float(ticks_adv), float(n_done), float(status_bad), bounded[0] if bounded else 0.0], dtype=torch.float64, device=dev)
+    # parity (untimed, every rank's own engine; rank 0 reports): sampled envs of THIS engine replayed on the pure-Python oracle
+    parity = None
+    if args.parity_envs > 0 and rank == 0:
+        from tests.bench_parity import replay_citi_bike_against_oracle
+        parity = replay_citi_bike_against_oracle(eng, seeds, k=min(args.parity_envs, 8), steps=min(600, max(64, durations // 4)),
+                                                 obs_attrs=None if (args.no_query or scope_obs) else q_attrs)
+    gpu_s = time.perf_counter() - t_leg
+    R = len(windows)
+    t_max = torch.tensor([w[0] for w in windows] + [bounded[1] if bounded else 0.0], dtype=torch.float64, device=dev)
+    tot = torch.tensor([w[1] for w in windows] + [w[2] for w in windows] + [float(n_done), float(status_bad), bounded[0] if bounded else 0.0], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt, dtb = (float(x) for x in t_max.tolist())
-    resolved, ticks_adv, n_done, status_bad, resolved_b = (float(x) for x in tot.tolist())
-    if rank == 0:
-        tbar = ticks_adv / max(resolved, 1.0)
-        F = S * 48 + 4 * S * S                       # reference-dtype frame bytes (180 B for 3 stations)
-        n_trips = float((eng.data.trip_tick < durations).sum())
-        b_step = (3.0 + tbar / res) * F + 20.0 * (n_trips / durations) * tbar + 40.0   # SURVEY.md §8(d) general form
-        achieved = b_step * n / (step_kernel_ms * 1e-3) / 1e9
-        algorithmic = achieved
-        traffic, basis = None, "algorithmic bytes (SURVEY.md 8d general form): no PMC profile of this topology / batch size in profiles/latest_pmc_citi_bike.json"
-        try:
-            with open(os.path.join(REPO, "profiles", "latest_pmc_citi_bike.json")) as fp:
-                pmc = json.load(fp)
-            for ent in pmc["entries"]:
-                if ent["topology"] == topology and ent["envs_per_launch"] == n and ent.get("step_budget", 0) == args.step_budget:
-                    traffic = (2 * ent["fetch_size_kib"] + ent["write_size_kib"]) * 1024
-                    achieved = traffic / (step_kernel_ms * 1e-3) / 1e9
-                    basis = "measured HBM bytes (PMC: 2 x FETCH_SIZE + WRITE_SIZE per launch, " + pmc["source"] + ") / mean launch duration"
-        except (OSError, KeyError, ValueError):
-            pass
-        out = {
-            "metric": f"env-steps/sec (decision events/sec), citi_bike {topology}",
-            "value": resolved / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32+f64", "data": "synthetic",
-            "config": {"workload": f"citi_bike {topology}, {n} envs/GPU x {world} GPU, durations {durations}, resolution {res}, "
-                                   f"device policy, stations snapshot slice {'off' if args.no_query else ('every step (stations of the action scope x 7 attrs)' if scope_obs else 'every step (all stations x 7 attrs)')}",
-                       "envs_per_gpu": n, "specialized_kernels": bool(eng.specialized), "wave_cooperative_step": bool(eng.set_wave_decisions(0)),
-                       "env_major_state": bool(eng.layout.env_major), "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective)",
-                       "trajectory_gather_ms_32_steps": gather_ms, "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
-            "roofline": {"bound": "hbm", "kernel": "mrx_k_cb_step", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "basis": basis, "algorithmic_GBps": algorithmic, "kernel_ms": step_kernel_ms,
-                         "algorithmic_bytes_per_env_step": b_step, "env_steps_per_launch": n,
-                         "note": "latency-bound by construction (SURVEY.md §8d: ~1 KB per env-step); the roofline fraction is judged on the CIM 22p workload"},
-        }
-        out["config"]["step_budget"] = args.step_budget
-        if bounded:
-            out["bounded_steps"] = {"budget_records": args.bounded_budget, "value": resolved_b / dtb, "unit": "env-steps/s", "ms_per_call": dtb / args.steps * 1e3,
-                                    "decisions_per_call_per_env": resolved_b / (args.steps * n * world),
-                                    "what": "same loop with mrx_cb_set_step_budget: a call stops after ~budget events per env; envs without a decision yet continue in the next call (trajectories unchanged)"}
-        if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline_citi_bike(topology, min(durations, 1440), res, args.cpu_seconds)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    dts, dtb = [float(x) for x in t_max.tolist()[:R]], float(t_max[R])
+    tl = [float(x) for x in tot.tolist()]
+    res_w, tick_w = tl[:R], tl[R:2 * R]
+    n_done, status_bad, resolved_b = tl[2 * R:]
+    if rank != 0:
+        return None
+    vals = [res_w[i] / dts[i] for i in range(R)]
+    med = sorted(range(R), key=lambda i: vals[i])[R // 2]
+    dt, resolved, ticks_adv = dts[med], res_w[med], tick_w[med]
+    tbar = ticks_adv / max(resolved, 1.0)
+    ms_per_step = dt / args.steps * 1e3
+    code_key = getattr(eng, "code_object_key", None)
+    traffic, basis = measured_bytes_citi_bike(topology, n, args.step_budget, code_key)
+    achieved = None if traffic is None else traffic / (ms_per_step * 1e-3) / 1e9     # per GPU: bytes of one batch step / its wall time
+    out = {
+        "metric": f"env-steps/sec (decision events/sec), citi_bike {topology}",
+        "value": resolved / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32+f64", "data": "synthetic", "repeats": R, "value_min": min(vals), "value_max": max(vals), "gpu_seconds_total": gpu_s,
+        "config": {"workload": f"citi_bike {topology}, {n} envs/GPU x {world} GPU, durations {durations}, resolution {res}, "
+                               f"device policy, stations snapshot slice {'off' if args.no_query else ('every step (stations of the action scope x 7 attrs)' if scope_obs else 'every step (all stations x 7 attrs)')}",
+                   "envs_per_gpu": n, "specialized_kernels": bool(eng.specialized), "code_object_key": code_key, "wave_cooperative_step": bool(eng.set_wave_decisions(0)),
+                   "env_major_state": bool(eng.layout.env_major), "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective)",
+                   "trajectory_gather_ms_32_steps": gather_ms, "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad,
+                   "step_budget": args.step_budget},
+        "roofline": {"bound": "hbm", "kernel": "mrx_k_cb_step" if not eng.layout.env_major else "mrx_k_cb_step_wave + mrx_k_cb_replay_wave (+ query, policy)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None if achieved is None else achieved / HBM_PEAK_GBPS,
+                     "traffic": traffic, "basis": basis, "kernel_ms": step_kernel_ms, "env_steps_per_launch": n,
+                     "note": "latency-bound by construction (SURVEY.md 8d: ~1 KB per env-step): the batch step lasts as long as its longest env-step's dependent chain; "
+                             "frac is measured bytes / wall time of a batch step and is null when no PMC record of this exact build exists"},
+    }
+    if bounded:
+        out["bounded_steps"] = {"budget_records": args.bounded_budget, "value": resolved_b / dtb, "unit": "env-steps/s", "ms_per_call": dtb / args.steps * 1e3,
+                                "decisions_per_call_per_env": resolved_b / (args.steps * n * world),
+                                "what": "same loop with mrx_cb_set_step_budget: a call stops after ~budget events per env; envs without a decision yet continue in the next call (trajectories unchanged)"}
+    if parity is not None:
+        out["parity"] = parity
+    if world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline_citi_bike(topology, min(durations, 1440), res, args.cpu_seconds)
+    return out
 
 
 def build_cim_groups(topology, n, G, dev, rank=0, durations=1120, ring=4, specialize=True, step_mode=0, obs="fused", policy="random"):
@@ -363,21 +383,82 @@ def build_cim_groups(topology, n, G, dev, rank=0, durations=1120, ring=4, specia
     return engines, streams, bufs, sizes, offs
 
 
+_REF_RUNTIME = None
+
+
+def reference_runtime():
+    """Where the REAL reference (microsoft/maro built by oracle/build_ref.sh) can be imported from on THIS box, for the
+    cpu_baseline legs only: (maro root, stubs dir, HOME, description) or None.  Order: $MARO_REFERENCE_BUILD; the runtime archive
+    oracle/_ref/maro_ref.tgz (a build output of `oracle/build_ref.sh <dest> oracle/_ref`, git-ignored, shipped to the GPU box
+    with the snapshot like the built .so files) unpacked into a temp folder; the build container's /tmp/oracle."""
+    global _REF_RUNTIME
+    if _REF_RUNTIME is not None:
+        return _REF_RUNTIME or None
+
+    def built(root):
+        b = os.path.join(root, "maro", "backends")
+        return os.path.isdir(b) and any(f.startswith("frame.") and f.endswith(".so") for f in os.listdir(b))
+    import tempfile
+    env_root = os.environ.get("MARO_REFERENCE_BUILD")
+    tgz = os.path.join(REPO, "oracle", "_ref", "maro_ref.tgz")
+    res = False
+    if env_root and built(env_root):
+        res = (env_root, os.path.join(os.path.dirname(env_root), "stubs"), os.path.join(os.path.dirname(env_root), "home"), f"$MARO_REFERENCE_BUILD={env_root}")
+    elif os.path.exists(tgz):
+        import hashlib
+        import tarfile
+        tag = hashlib.sha256(f"{os.path.getsize(tgz)}:{os.path.getmtime(tgz)}".encode()).hexdigest()[:12]
+        dest = os.path.join(tempfile.gettempdir(), f"maro_amd_ref_{tag}")
+        if not built(os.path.join(dest, "maro_ref")):
+            tmp = dest + f".{os.getpid()}"
+            with tarfile.open(tgz) as tf:
+                tf.extractall(tmp)
+            os.makedirs(os.path.join(tmp, "maro_ref", "home"), exist_ok=True)
+            try:
+                os.replace(tmp, dest)
+            except OSError:
+                pass   # another rank / process got there first
+        root = os.path.join(dest, "maro_ref")
+        if built(root):
+            res = (root, os.path.join(root, "stubs"), os.path.join(root, "home"), "oracle/_ref/maro_ref.tgz (the reference built by oracle/build_ref.sh, unpacked on this box)")
+    elif built("/tmp/oracle/maro_src"):
+        res = ("/tmp/oracle/maro_src", "/tmp/oracle/stubs", "/tmp/oracle/home", "/tmp/oracle/maro_src (oracle/build_ref.sh in the build container)")
+    _REF_RUNTIME = res
+    return res or None
+
+
+def _run_reference(code, argv, timeout):
+    """Run `code` in a child interpreter that can import the built reference (never this process: the product must not)."""
+    root, stubs, home, _ = reference_runtime()
+    env = dict(os.environ, HOME=home, SKIP_DEPLOYMENT="TRUE", PYTHONPATH=os.pathsep.join([root, stubs]))
+    return subprocess.run([sys.executable, "-c", code] + [str(a) for a in argv], capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def box_description():
+    import platform
+    gpu = None
+    try:
+        import torch
+        gpu = torch.cuda.get_device_name(0) if torch.cuda.is_available() else None
+    except Exception:
+        pass
+    return {"host": platform.node(), "gpu": gpu, "host_cores_usable": host_cores(),
+            "where": ("the bench box itself (GPU host: " + gpu + ")") if gpu else "a box without a GPU (build container)"}
+
+
 def cpu_baseline_reference(topology, durations, budget_s):
-    """The REAL reference (microsoft/maro built by oracle/build_ref.sh, present in the build container only) timed on this
-    box: single-process Env.step with the same kind of random legal agent.  None when no built
-    reference is importable (e.g. on the GPU box)."""
-    root = os.environ.get("MARO_REFERENCE_BUILD", "/tmp/oracle/maro_src")
-    if not os.path.isdir(os.path.join(root, "maro")) or not any(f.startswith("frame.") and f.endswith(".so") for f in os.listdir(os.path.join(root, "maro", "backends"))):
+    """The REAL reference (microsoft/maro, built by oracle/build_ref.sh) timed on THIS box's host cores: single-process Env.step
+    with a random legal agent and the reference's own batch form, maro.vector_env.VectorEnv with
+    one process per usable core (step 3).  None when no built reference is reachable (see reference_runtime)."""
+    rt = reference_runtime()
+    if rt is None:
         return None
     code = r"""
-import os, sys, time, random
-os.environ.setdefault("HOME", "/tmp/oracle/home"); os.environ.setdefault("SKIP_DEPLOYMENT", "TRUE")
-sys.path.insert(0, sys.argv[1])
+import sys, time, random
 from maro.simulator import Env
 from maro.simulator.scenarios.cim.common import Action, ActionType
-env = Env("cim", sys.argv[2], durations=int(sys.argv[3]))
-budget = float(sys.argv[4]); rng = random.Random(0)
+env = Env("cim", sys.argv[1], durations=int(sys.argv[2]))
+budget = float(sys.argv[3]); rng = random.Random(0)
 steps = episodes = 0; t_step = 0.0; t_reset = 0.0
 t0 = time.perf_counter()
 while time.perf_counter() - t0 < budget:
@@ -393,7 +474,7 @@ while time.perf_counter() - t0 < budget:
 print(steps, episodes, t_step, t_reset)
 """
     try:
-        out = subprocess.run([sys.executable, "-c", code, root, topology, str(durations), str(budget_s)], capture_output=True, text=True, timeout=budget_s * 4 + 120)
+        out = _run_reference(code, [topology, durations, budget_s], budget_s * 4 + 120)
         steps, episodes, t_step, t_reset = out.stdout.split()[-4:]
         steps, episodes, t_step, t_reset = int(steps), int(episodes), float(t_step), float(t_reset)
     except Exception as e:   # the reference is a convenience leg, never a reason to fail the bench
@@ -401,26 +482,24 @@ print(steps, episodes, t_step, t_reset)
     res = {"value": steps / t_step, "unit": "env-steps/s", "cores": 1, "kind": "reference",
            "value_end_to_end": steps / (t_step + t_reset), "reset_s_per_episode": t_reset / max(episodes, 1),
            "sample": f"{episodes} full episode(s) of {topology} ({durations} ticks) on the reference's own Env (maro.simulator.Env, single process, "
-                     f"Python {sys.version_info.major}.{sys.version_info.minor}): {steps} decisions in {t_step:.1f} s of stepping + {t_reset:.1f} s of env.reset()"}
+                     f"Python {sys.version_info.major}.{sys.version_info.minor}): {steps} decisions in {t_step:.1f} s of stepping + {t_reset:.1f} s of env.reset()",
+           "measured": "live, in this run", "reference_from": rt[3], **box_description()}
     # the reference's own batch form, one process per env on every usable core, broadcast action=None
-    cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
+    cores = max(1, min(host_cores(), 16))
     vcode = r"""
-import os, sys, time
-os.environ.setdefault("HOME", "/tmp/oracle/home"); os.environ.setdefault("SKIP_DEPLOYMENT", "TRUE")
-sys.path.insert(0, sys.argv[1])
+import sys, time
 from maro.vector_env import VectorEnv
-n = int(sys.argv[4])
-with VectorEnv(batch_num=n, scenario="cim", topology=sys.argv[2], durations=int(sys.argv[3])) as env:
+n = int(sys.argv[3])
+with VectorEnv(batch_num=n, scenario="cim", topology=sys.argv[1], durations=int(sys.argv[2])) as env:
     t0 = time.perf_counter(); steps = 0
     metrics, des, done = env.step(None)
-    while not done and time.perf_counter() - t0 < float(sys.argv[5]):
+    while not done and time.perf_counter() - t0 < float(sys.argv[4]):
         steps += sum(1 for d in des if d is not None)
         metrics, des, done = env.step(None)
     print(steps, time.perf_counter() - t0)
 """
     try:
-        out = subprocess.run([sys.executable, "-c", vcode, root, topology, str(durations), str(cores), str(budget_s)], capture_output=True, text=True,
-                             timeout=budget_s * 4 + 180)
+        out = _run_reference(vcode, [topology, durations, cores, budget_s], budget_s * 4 + 180)
         vs, vt = out.stdout.split()[-2:]
         res["vector_env"] = {"value": int(vs) / float(vt), "unit": "env-steps/s", "processes": cores,
                              "sample": f"maro.vector_env.VectorEnv(batch_num={cores}), action=None broadcast, {int(vs)} decisions in {float(vt):.1f} s"}
@@ -429,15 +508,84 @@ with VectorEnv(batch_num=n, scenario="cim", topology=sys.argv[2], durations=int(
     return res
 
 
-def bench_collect(args, engines, streams, qnet, n, G, dev, rank, world, dist, reset_ms):
+DQN_FLOPS_PER_ENV = 2.0 * sum(a * b for a, b in ((171, 256), (256, 128), (128, 64), (64, 32), (32, 128), (32, 128), (128, 21), (128, 1)))   # the example's real layer sizes
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA (v_mfma_f32_16x16x4_f32)
+
+
+def measured_bytes_collect(n, G, code_key):
+    """HBM bytes one batch interaction of the collection loop really moves (profiles/latest_pmc_collect.json: separate --pmc
+    FETCH_SIZE / WRITE_SIZE passes, summed over EVERY kernel of the loop / interactions) -> (bytes or None, basis)."""
+    try:
+        with open(os.path.join(REPO, "profiles", "latest_pmc_collect.json")) as fp:
+            pmc = json.load(fp)
+    except (OSError, ValueError):
+        return None, "no profiles/latest_pmc_collect.json"
+    state = "no PMC entry of this batch size / group count"
+    for ent in pmc.get("entries", []):
+        if ent["envs_per_gpu"] == n and ent["groups_per_gpu"] == G:
+            if ent.get("code_object_key") != code_key or code_key is None:
+                state = f"the PMC entry is of another build (code object {ent.get('code_object_key')}, running {code_key})"
+                continue
+            return (2 * ent["fetch_size_kib"] + ent["write_size_kib"]) * 1024, \
+                f"measured HBM bytes (PMC: 2 x FETCH_SIZE + WRITE_SIZE summed over every kernel of the loop / batch interactions, {pmc['source']}; entry of git {ent.get('git_head')})"
+    return None, state
+
+
+def cpu_baseline_collect(topology, durations, budget_s):
+    """Config 5 on the host cores, the REAL reference: maro.rl's own CIMEnvSampler.sample(num_steps) (examples/cim/rl/env_sampler.py
+    over maro/rl/rollout/env_sampler.py) on the reference Env with the example's 22 random-init DQN policies (PyTorch CPU) — timed in
+    a child interpreter on the built reference (reference_runtime).  None where no built reference is reachable."""
+    if reference_runtime() is None:
+        return None
+    code = r"""
+import sys, time
+from unittest.mock import MagicMock
+for name in ["zmq", "zmq.asyncio", "zmq.eventloop", "zmq.eventloop.zmqstream", "tornado", "tornado.ioloop"]:
+    sys.modules[name] = MagicMock()
+import torch
+torch.set_num_threads(1)
+from maro.simulator import Env
+topo, dur, budget = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
+from examples.cim.rl.algorithms.dqn import get_dqn_policy
+from examples.cim.rl.config import action_shaping_conf, reward_shaping_conf, state_dim
+from examples.cim.rl.env_sampler import CIMEnvSampler
+learn_env, test_env = Env(scenario="cim", topology=topo, durations=dur), Env(scenario="cim", topology=topo, durations=dur)
+n_ports = len(learn_env.agent_idx_list)
+policies = [get_dqn_policy(state_dim, len(action_shaping_conf["action_space"]), f"dqn_{i}.policy") for i in range(n_ports)]
+sampler = CIMEnvSampler(learn_env=learn_env, test_env=test_env, policies=policies,
+                        agent2policy={agent: f"dqn_{agent}.policy" for agent in learn_env.agent_idx_list},
+                        reward_eval_delay=reward_shaping_conf["time_window"])
+sampler.sample(num_steps=50)
+steps = exps = 0
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < budget:
+    res = sampler.sample(num_steps=200)
+    steps += 200
+    exps += sum(len(b) for b in res["experiences"])
+print(steps, exps, time.perf_counter() - t0)
+"""
+    try:
+        out = _run_reference(code, [topology, durations, budget_s], budget_s * 4 + 180)
+        steps, exps, dt = out.stdout.split()[-3:]
+        steps, exps, dt = int(steps), int(exps), float(dt)
+    except Exception as e:
+        return {"error": (str(e) + " " + (out.stderr[-300:] if "out" in dir() else ""))[:400]}
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "reference", "experiences_per_s": exps / dt,
+            "sample": f"maro.rl CIMEnvSampler.sample(num_steps=200) x {steps // 200} on the reference Env of {topology} ({durations} ticks) with the example's "
+                      f"{'per-port'} dueling DQN policies on PyTorch CPU (1 thread), single process: {steps} interactions, {exps} experiences in {dt:.1f} s",
+            "measured": "live, in this run", "reference_from": reference_runtime()[3], **box_description()}
+
+
+def bench_collect(args, engines, streams, qnet, chains, n, G, dev, rank, world, dist, reset_ms):
     """SURVEY.md 8(d) config 5 as the reference runs it: `AbsEnvSampler.sample(num_steps)` with on-device inference — here
     CimBatchSampler.sample_fused over every group's engine: per step ONE fused call for sampler state + per-port DQN + action
-    translation (mrx_cim_dqn_act), the transition cache updated by masked tensor ops (no host sync on the step path), then
+    translation (mrx_cim_dqn_act), the transition cache updated by one kernel (no host sync on the step path), then
     mrx_cim_step; per call the delayed rewards, per-agent next states, emission and episode roll-over.  One "step" of this
-    bench = one interaction of every env of the rank (all groups)."""
+    bench = one interaction of every env of the rank (all groups).  Returns the JSON object on rank 0."""
     import torch
 
     from maro_amd.cim.sampler import CimBatchSampler, sample_fused_groups
+    t_leg = time.perf_counter()
     samplers = []
     for g, e in enumerate(engines):
         with torch.cuda.stream(streams[g]):
@@ -452,7 +600,7 @@ def bench_collect(args, engines, streams, qnet, n, G, dev, rank, world, dist, re
 
     def one_call(k):
         # the groups' step generators advanced in turn: every engine is bound to its group's stream (use_stream), the sampler puts
-        # its own tensor ops on that stream too, and a step is three C-ABI calls — the groups' kernels overlap like in the headline loop
+        # its own tensor ops on that stream too, and a step is a few C-ABI calls — the groups' kernels overlap like in the headline loop
         res = sample_fused_groups(samplers, qnet, k, seeds=seeds_of, reset_every=args.reset_every)
         return sum(int(r["tick"].shape[0]) for r in res)
 
@@ -478,12 +626,23 @@ def bench_collect(args, engines, streams, qnet, n, G, dev, rank, world, dist, re
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             t[0] = tm[0]
         dts.append(float(t[0])); vals.append(float(t[1]) / float(t[0])); exps.append(float(t[2]) / float(t[0]))
+    # the policy launches alone (act of every group, back to back, no record / step): its own MFMA roofline
+    b_act = [dict(a=torch.zeros((e.n_envs, 1, 4), dtype=torch.int32, device=dev), n=torch.zeros(e.n_envs, dtype=torch.int32, device=dev)) for e in engines]
+    sync_all()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for g in range(G):
+            qnet[g].act(b_act[g]["a"], b_act[g]["n"])
+    torch.cuda.synchronize(dev)
+    act_ms = (time.perf_counter() - t0) / reps * 1e3
+    deciding = sum(int((e.decisions[:, 7] == 1).sum().item()) for e in engines)
     # ---- N > 1: the learner-side collection (outside the timed windows): one more call, its experiences joined on rank 0
-    # (gather_experiences_to_learner: ragged sizes, one grouped send / receive) — time and bytes of that exchange next to the
-    # time of the call that produced them
-    exp_gather = None
+    # (gather_experiences_to_learner: ragged sizes, one grouped send / receive), and the return path: the learner's packed
+    # networks broadcast to every rank's actors (broadcast_policy)
+    exp_gather = policy_bcast = None
     if dist is not None:
-        from maro_amd.cim.rollout import gather_experiences_to_learner
+        from maro_amd.cim.rollout import broadcast_policy, gather_experiences_to_learner
         sync_all()
         ta = time.perf_counter()
         res = sample_fused_groups(samplers, qnet, args.steps, seeds=seeds_of, reset_every=args.reset_every)
@@ -505,22 +664,50 @@ def bench_collect(args, engines, streams, qnet, n, G, dev, rank, world, dist, re
             exp_gather = {"sample_ms": float(tmax[0]) * 1e3, "gather_ms": float(tmax[1]) * 1e3, "gather_share": float(tmax[1] / (tmax[0] + tmax[1])),
                           "bytes_all_ranks": float(tt[2]), "experiences": int(tt[3].item()), "steps_per_call": args.steps}
         del joined, mine, res
-    if rank == 0:
-        med = sorted(range(len(vals)), key=lambda i: vals[i])[len(vals) // 2]
-        out = {"metric": "env-steps/sec while collecting experiences (CimBatchSampler.sample_fused), CIM global_trade.22p",
-               "value": vals[med], "unit": "env-steps/s", "experiences_per_s": exps[med], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": dts[med] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32+f64 (env), f32 MFMA (policy)",
-               "data": "synthetic", "repeats": len(vals), "value_min": min(vals), "value_max": max(vals),
-               "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {engines[0].durations}, maro.rl EnvSampler loop batched on device: per-port "
-                                      f"dueling DQN (random-init, exact-f32 MFMA) + CIMEnvSampler state / reward shaping + transition cache + roll-over",
-                          "envs_per_gpu": n, "groups_per_gpu": G, "reset_every": args.reset_every, "specialized_kernels": bool(engines[0].specialized),
-                          "reset_ms_whole_batch": reset_ms, "look_back": samplers[0].look_back, "reward_window": samplers[0].time_window,
-                          "experience_gather": exp_gather,
-                          "what_a_step_is": "one sample_fused interaction of every env: mrx_cim_dqn_act (2 launches) + mrx_cim_sampler_record + mrx_cim_step; per call: mrx_cim_sampler_emit"}}
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        sync_all()
+        td = time.perf_counter()
+        blob = broadcast_policy(qnet[0].weights.clone() if rank == 0 else None, qnet, src=0)
+        sync_all()
+        policy_bcast = {"ms": (time.perf_counter() - td) * 1e3, "bytes": blob.numel() * 4, "what": "rollout.broadcast_policy: one broadcast of the packed "
+                        "networks + an in-place set_policy_state on every group's actor"}
+    # ---- parity (untimed; rank 0's own envs): the loop's own elements of a few envs replayed on the C oracle
+    parity = None
+    if args.parity_envs > 0 and rank == 0:
+        from tests.bench_parity import replay_collect_against_oracle
+        parity = replay_collect_against_oracle(samplers, qnet, seeds_of, None, args.topology, k=min(args.parity_envs, 6), num_steps=384,
+                                               reset_every=args.reset_every, chains=chains)
+    if rank != 0:
+        return None
+    med = sorted(range(len(vals)), key=lambda i: vals[i])[len(vals) // 2]
+    ms_per_step = dts[med] / args.steps * 1e3
+    code_key = getattr(engines[0], "code_object_key", None)
+    traffic, basis = measured_bytes_collect(n, G, code_key)
+    achieved = None if traffic is None else traffic / (ms_per_step * 1e-3) / 1e9
+    tf = DQN_FLOPS_PER_ENV * deciding / (act_ms * 1e-3) / 1e12
+    out = {"metric": "env-steps/sec while collecting experiences (CimBatchSampler.sample_fused), CIM global_trade.22p",
+           "value": vals[med], "unit": "env-steps/s", "experiences_per_s": exps[med], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32+f64 (env), f32 MFMA (policy)",
+           "data": "synthetic", "repeats": len(vals), "value_min": min(vals), "value_max": max(vals), "gpu_seconds_total": time.perf_counter() - t_leg,
+           "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {engines[0].durations}, maro.rl EnvSampler loop batched on device: per-port "
+                                  f"dueling DQN (random-init, exact-f32 MFMA) + CIMEnvSampler state / reward shaping + transition cache + roll-over",
+                      "envs_per_gpu": n, "groups_per_gpu": G, "reset_every": args.reset_every, "specialized_kernels": bool(engines[0].specialized), "code_object_key": code_key,
+                      "reset_ms_whole_batch": reset_ms, "look_back": samplers[0].look_back, "reward_window": samplers[0].time_window,
+                      "experience_gather": exp_gather, "policy_broadcast": policy_bcast,
+                      "what_a_step_is": "one sample_fused interaction of every env: mrx_cim_dqn_act + the transition-cache update + mrx_cim_step; per call: mrx_cim_sampler_emit"},
+           "roofline": {"bound": "hbm", "kernel": "the whole loop (mrx_k_cim_dqn_forward, mrx_k_cim_step_tab, mrx_k_cim_sampler_record, ...)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": None if achieved is None else achieved / HBM_PEAK_GBPS, "traffic": traffic, "basis": basis,
+                        "note": "bytes of one batch interaction (all kernels) / its wall time; null when no PMC record of this exact build exists"},
+           "roofline_policy": {"bound": "mfma", "kernel": "mrx_k_cim_dqn_forward (+ mrx_k_cim_dqn_bin)", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / MFMA_F32_PEAK_TFLOPS, "dtype": "f32 (v_mfma_f32_16x16x4_f32)", "kernel_ms": act_ms, "deciding_envs": deciding,
+                               "flops_per_env": DQN_FLOPS_PER_ENV, "basis": "algorithmic flops (2 x sum(in x out) of the example's layers x deciding envs) / wall time of the act "
+                               "launches of all groups issued back to back with nothing else on the GPU"}}
+    if parity is not None:
+        out["parity"] = parity
+    if world == 1 and not args.no_cpu:
+        ref = cpu_baseline_collect(args.topology, engines[0].durations if engines[0].durations <= 1120 else 1120, min(args.cpu_seconds, 12.0))
+        if ref is not None:
+            out["cpu_baseline"] = ref
+    return out
 
 
 def main():
@@ -561,11 +748,16 @@ def main():
                     "(gather_to_learner), reporting the gather's share of a rollout (0: only the single 32-step gather)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--secondary", type=int, default=-1, help="after the headline (cim, random agent), also run BASELINE configs 4 and 5 as short legs and embed "
+                    "them under `secondary` in the same JSON line (citi_bike toy.3s_4t 4096 envs; DQN collection loop 8192 envs), each with parity, "
+                    "cpu_baseline and a measured-bytes roofline.  -1 = auto: on for the default workload (what the driver runs), off when a flag selects another one")
     args = ap.parse_args()
+    explicit_envs = args.envs is not None
     if args.envs is None:
         args.envs = 16384 if args.scenario == "cim" else 4096
-    if args.scenario == "citi_bike":
-        return bench_citi_bike(args)
+    if args.secondary < 0:
+        args.secondary = int(args.scenario == "cim" and args.policy == "random" and not args.collect and not explicit_envs and not args.graphs
+                             and args.topology == "global_trade.22p_l0.8" and args.obs == "fused" and not args.no_query)
 
     import torch
 
@@ -575,6 +767,43 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist, dev = init_dist(world, local_rank, build=ge.build)
     torch.cuda.set_device(dev)
+    if args.scenario == "citi_bike":
+        out = bench_citi_bike(args, dist, dev, rank, world)
+    else:
+        out = bench_cim(args, dist, dev, rank, world)
+        if args.secondary:   # (every rank takes part: the legs hold collectives)
+            import copy
+            import gc
+            sec = {}
+            gc.collect()
+            torch.cuda.empty_cache()
+            # BASELINE.json configs[3]: citi_bike toy.3s_4t, 4096 envs per GPU (32768 over 8 GPUs)
+            a4 = copy.copy(args)
+            a4.scenario, a4.envs, a4.topology, a4.durations, a4.step_budget, a4.bounded_budget = "citi_bike", 4096, "toy.3s_4t", 1120, 0, 0
+            a4.parity_envs = min(args.parity_envs, 8)
+            r4 = bench_citi_bike(a4, dist, dev, rank, world)
+            gc.collect()
+            torch.cuda.empty_cache()
+            # BASELINE.json configs[4]: CIM 22p + the maro.rl DQN EnvSampler loop, 8192 envs per GPU (65536 over 8 GPUs), on-device inference
+            a5 = copy.copy(args)
+            a5.policy, a5.collect, a5.envs, a5.ring, a5.no_episode = "dqn", True, 8192, max(args.ring, 8), True
+            a5.parity_envs = min(args.parity_envs, 6)
+            r5 = bench_cim(a5, dist, dev, rank, world)
+            if out is not None:
+                sec["citi_bike_config4"], sec["collect_config5"] = r4, r5
+                out["secondary"] = sec
+                out["gpu_seconds_total"] += sum((r or {}).get("gpu_seconds_total", 0.0) for r in (r4, r5))
+    if rank == 0 and out is not None:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_cim(args, dist, dev, rank, world):
+    """The CIM legs: the headline (random legal agent), `--policy dqn` (act -> step) and `--policy dqn --collect` (the whole
+    experience-collecting loop).  Returns the JSON object on rank 0, None on the other ranks."""
+    import torch
 
     # The per-GPU batch is split into G independent groups, each with its own engine and HIP stream: the kernels of the
     # other groups fill a group's launch gaps and tail.  Envs never interact, so this is pure scheduling (DESIGN.md section 2).
@@ -616,7 +845,7 @@ def main():
     if args.collect:
         if qnet is None:
             raise SystemExit("--collect needs --policy dqn")
-        return bench_collect(args, engines, streams, qnet, n, G, dev, rank, world, dist, reset_ms)
+        return bench_collect(args, engines, streams, qnet, chains, n, G, dev, rank, world, dist, reset_ms)
 
     def one_step(i, g, timing=None, count=True):
         eng, b, st = engines[g], bufs[g], streams[g]
@@ -903,15 +1132,27 @@ def main():
                 ceiling = pc
         except Exception:
             pass
-        alg_per_launch = b_step * (resolved / world / args.steps / G)   # algorithmic bytes of one launch (its env-steps x B_step)
+        alg_per_launch = b_step * (resolved / world / args.steps / G)   # SURVEY formula bytes of one launch (its env-steps x B_step)
         alg_gbps = alg_per_launch * G / (ms_per_step * 1e-3) / 1e9
         if traffic is not None:
             # achieved = bytes the kernel really moves per launch x launches per step / the TIMED window's ms_per_step (per GPU)
             achieved = traffic * G / (ms_per_step * 1e-3) / 1e9
             basis = "measured HBM bytes (PMC: 2 x FETCH_SIZE + WRITE_SIZE per launch) x launches per step / ms_per_step of the timed window"
         else:
-            achieved = alg_gbps
-            basis = f"ALGORITHMIC bytes ({pmc_state}): see algorithmic_*"
+            # the record of the SAME code object at another batch size: its bytes per env-step carry over (the per-env access list
+            # does not depend on the batch); any other build has no measured bytes -> no fraction (never the SURVEY formula)
+            achieved = basis = None
+            try:
+                if pmc.get("code_object_key") == code_key and code_key is not None and pmc.get("kernel") == kernel and pmc["topology"] == args.topology:
+                    traffic = (2.0 * pmc["fetch_size_kib"] + pmc["write_size_kib"]) * 1024.0 / pmc["envs_per_launch"] * ng
+                    achieved = traffic * G / (ms_per_step * 1e-3) / 1e9
+                    pmc_src = {k: pmc.get(k) for k in ("source", "git_head", "code_object_key", "code_object_sha16", "bench_value", "date")}
+                    basis = (f"measured HBM bytes per env-step of the same code object (PMC record at {pmc['envs_per_launch']:.0f} envs per launch) scaled to "
+                             f"{ng:.0f} envs per launch x launches per step / ms_per_step of the timed window")
+            except Exception:
+                pass
+            if achieved is None:
+                basis = f"no measured bytes for this build ({pmc_state}): frac is null — run tools/gpu_profile.sh to refresh profiles/latest_pmc.json"
         out = {
             "metric": "env-steps/sec (decision events/sec), CIM global_trade.22p",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -931,13 +1172,14 @@ def main():
                        "untimed_preroll_steps": preroll_steps, "mean_tick_at_window_start": tick_mean0,
                        "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": pmc_src, "basis": basis,
-                         "algorithmic_GBps": alg_gbps, "algorithmic_frac": alg_gbps / HBM_PEAK_GBPS,
-                         "algorithmic_bytes_per_launch": alg_per_launch, "algorithmic_bytes_per_env_step": b_step,
-                         "algorithmic_note": "SURVEY.md 8(d)'s fixed formula (reference dtypes, every snapshot copy counted); it exceeds the measured traffic "
-                                             "because the engine eliminated copies (aliased pre-decision snapshot, compact matrices, HBM-direct fast path), "
-                                             "so algorithmic_frac may exceed 1 and is NOT a bandwidth fraction",
-                         "kernel_ms": step_kernel_ms, "launches_in_flight": in_flight, "env_steps_per_launch": ng, "launches_per_step": G},
+                         "frac": None if achieved is None else achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": pmc_src, "basis": basis,
+                         "bytes_per_env_step": None if traffic is None else traffic / ng,
+                         "kernel_ms": step_kernel_ms, "launches_in_flight": in_flight, "env_steps_per_launch": ng, "launches_per_step": G,
+                         "survey_formula": {"bytes_per_env_step": b_step, "bytes_per_launch": alg_per_launch, "GBps_if_the_engine_moved_them": alg_gbps,
+                                            "measured_over_formula_bytes": None if traffic is None else traffic / alg_per_launch,
+                                            "note": "SURVEY.md 8(d)'s fixed formula (reference dtypes, every snapshot copy counted).  The engine moves a fraction of these "
+                                                    "bytes (aliased pre-decision snapshot, compact frame, HBM-direct fast path), so this is a statement about eliminated "
+                                                    "copies, NOT a bandwidth figure, and it never feeds `frac`"}},
         }
         if ceiling is not None:
             # value / (env-steps/s the no-compute pattern reaches) — both whole-batch rates on one GPU
@@ -955,13 +1197,15 @@ def main():
             out["parity"] = parity
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.topology, args.durations, args.cpu_seconds)
+            # the reference's own Env.step / VectorEnv, timed live on this box's host cores from the shipped build (oracle/_ref)
             ref = cpu_baseline_reference(args.topology, args.durations, args.cpu_seconds)
-            if ref is None:
-                # the reference cannot travel to the GPU box: embed the record measured in the build container
-                # (tools/cpu_reference_baseline.py -> profiles/cpu_reference_baseline.json: the reference's own Env.step and VectorEnv)
+            if ref is None or "error" in ref:
+                # no built reference reachable: fall back to the committed record of the build container, and say so
+                err = None if ref is None else ref.get("error")
                 try:
                     with open(os.path.join(REPO, "profiles", "cpu_reference_baseline.json")) as fp:
                         ref = json.load(fp)
+                    ref["measured"] = "NOT in this run: embedded record (profiles/cpu_reference_baseline.json)" + (f"; the live leg failed: {err}" if err else "")
                     if ref.get("topology") != args.topology or ref.get("durations") != args.durations:
                         ref = None
                 except Exception:
@@ -976,10 +1220,8 @@ def main():
             out["roofline_policy"] = {"bound": "mfma", "kernel": "mrx_k_cim_dqn_forward (+ mrx_k_cim_dqn_bin)", "achieved": tf, "peak": 157.3,
                                       "unit": "TFLOP/s", "frac": tf / 157.3, "dtype": "f32 (v_mfma_f32_16x16x4_f32)", "kernel_ms": policy_ms,
                                       "flops_per_env": fl, "note": "launch latency bound: ~190 32-env tiles per launch on 256 CUs, sharing them with the other groups' step kernels"}
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == "__main__":

@@ -5,8 +5,8 @@
 # (scripts/compile_cython.sh:17 + setup.py:45-85 of the reference); ~60 s.
 # Usage: oracle/build_ref.sh [dest=/tmp/oracle] [pack_dir]
 #   pack_dir (e.g. oracle/_ref, git-ignored): additionally write pack_dir/maro_ref.tgz = the RUNTIME of that build only — the
-#   `maro` packages the timed path imports (simulator, backends with the compiled extension modules, data_lib, event_buffer,
-#   utils, vector_env) plus the import stubs — so that bench.py's `cpu_baseline_reference` leg can time the reference's own
+#   `maro` packages the timed paths import (simulator, backends with the compiled extension modules, data_lib, event_buffer,
+#   utils, vector_env, rl + examples/cim/rl for config 5's sampler) plus the import stubs — so that bench.py's `cpu_baseline_reference` leg can time the reference's own
 #   Env.step / VectorEnv ON THE GPU BOX's host cores (the archive travels with the snapshot like the built .so files; it is a
 #   build output, never committed, and only bench.py's cpu-baseline leg unpacks it, into a temp folder).
 set -euo pipefail
@@ -50,7 +50,7 @@ if [ -n "$PACK" ]; then
   STAGE=$(mktemp -d)
   mkdir -p "$STAGE/maro_ref/maro"
   ( cd "$DEST/maro_src/maro" && cp *.py "$STAGE/maro_ref/maro/" )
-  for sub in simulator backends data_lib event_buffer utils vector_env; do
+  for sub in simulator backends data_lib event_buffer utils vector_env rl; do
     ( cd "$DEST/maro_src/maro" && tar -cf - --exclude='*.cpp' --exclude='*.c' --exclude='*.pyx' --exclude='*.pxd' --exclude='__pycache__' \
         --exclude='raw' --exclude='vm_scheduling' "$sub" ) | tar -xf - -C "$STAGE/maro_ref/maro"
   done
@@ -58,6 +58,8 @@ if [ -n "$PACK" ]; then
   # pipeline's names, the streamit no-op client)
   ( cd "$DEST/maro_src/maro" && tar -cf - --exclude='__pycache__' cli/__init__.py cli/utils/__init__.py cli/utils/params.py cli/data_pipeline streamit ) \
       | tar -xf - -C "$STAGE/maro_ref/maro"
+  # config 5's CPU baseline runs the reference's own CIMEnvSampler: maro.rl (above) + the CIM RL example's shaping code
+  ( cd "$DEST/maro_src" && tar -cf - --exclude='__pycache__' examples/__init__.py examples/cim/rl ) | tar -xf - -C "$STAGE/maro_ref"
   cp -r "$DEST/stubs" "$STAGE/maro_ref/stubs"
   ( cd "$STAGE" && tar -czf "$PACK/maro_ref.tgz" maro_ref )
   rm -rf "$STAGE"

@@ -333,3 +333,25 @@ def test_fused_collect_loop_with_the_fused_dqn_on_gpu():
                 np.testing.assert_allclose(a_env[e][key][:m], b_env[e][key][:m], rtol=1e-6, atol=1e-6)
             else:
                 assert np.array_equal(a_env[e][key][:m], b_env[e][key][:m]), (e, key)
+
+
+def test_bench_collect_parity_helper_on_emulator():
+    """tests/bench_parity.py::replay_collect_against_oracle — the check bench.py's config-5 leg reports as `parity` — on two
+    emulator-backed groups: the loop's own elements drive the C oracle, states / translations / delayed rewards must agree; and a
+    corrupted element is caught."""
+    from tests.bench_parity import replay_collect_against_oracle
+    from tests.test_distributed_gloo import _Actor
+    topo, dur = "toy.5p_ssddd_l0.5", 600
+    engs = [emu_factory(topo, n, durations=dur, max_actions=1, max_snapshots=16) for n in (3, 2)]
+    smps = [CimBatchSampler(e) for e in engs]
+    actors = [_Actor(s) for s in smps]
+    seeds_of = [(lambda ep, g=g, n=e.n_envs: 500 + 13 * ep + torch.arange(n, dtype=torch.int64) + 10 * g) for g, e in enumerate(engs)]
+    rep = replay_collect_against_oracle(smps, actors, seeds_of, [0, 3], topo, k=4, num_steps=200, reset_every=8)
+    assert rep["ok"] and rep["envs_checked"] == 4 and rep["elements_checked"] == 800 and rep["rewards_checked"] > 100, rep
+
+    class Skewed(_Actor):      # a wrong translation (one container too many on every 7th tick) must be reported
+        def act(self, actions, n_actions, decisions=None, state=None, choice=None):
+            super().act(actions, n_actions, decisions=decisions, state=state, choice=choice)
+            actions[:, 0, 2] += ((decisions[:, 0] % 7 == 0) & (actions[:, 0, 2] > 0)).to(torch.int32) * -1
+    bad = replay_collect_against_oracle(smps, [Skewed(s) for s in smps], seeds_of, [0, 3], topo, k=2, num_steps=120, reset_every=8)
+    assert not bad["ok"] and bad["first_mismatch"] is not None

@@ -24,10 +24,11 @@ def per_step(path, counter):
     tot, calls = 0.0, {}
     for name, s, e, gx, wx, lds, ctrs in load_rows(path):
         name = name.replace(".kd", "")
-        if name in STEP_KERNELS and counter in ctrs:
+        if name.startswith("mrx_k_cb") and counter in ctrs:      # every kernel of the batch step: step kernels, policy, snapshot query
             tot += ctrs[counter]
             calls[name] = calls.get(name, 0) + 1
-    return tot / max(max(calls.values(), default=1), 1), calls
+    steps = max((v for k, v in calls.items() if k in STEP_KERNELS), default=1)
+    return tot / max(steps, 1), calls
 
 
 def main():
@@ -37,11 +38,11 @@ def main():
     write, _ = per_step(db(folder, "write"), "WRITE_SIZE")
     ent = {"topology": line["metric"].split()[-1], "envs_per_launch": line["config"]["envs_per_gpu"], "step_budget": line["config"].get("step_budget", 0),
            "fetch_size_kib": fetch, "write_size_kib": write, "kernels": calls, "bench_value": line["value"], "bench_ms_per_step": line["ms_per_step"],
-           "specialized_kernels": line["config"]["specialized_kernels"], "git_head": os.environ.get("GIT_HEAD")}
+           "specialized_kernels": line["config"]["specialized_kernels"], "code_object_key": line["config"].get("code_object_key"), "git_head": os.environ.get("GIT_HEAD")}
     path = os.path.join(out_dir, "latest_pmc_citi_bike.json")
     rec = json.load(open(path)) if os.path.exists(path) else {
-        "source": f"profiles/{os.path.basename(os.path.normpath(out_dir))}_citi_bike.md (tools/gpu_profile.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction; bytes per batch step = all step kernels of one mrx_cb_step call)",
-        "kernel": "mrx_k_cb_step (+ mrx_k_cb_step_wave, mrx_k_cb_replay_wave)", "entries": []}
+        "source": f"profiles/{os.path.basename(os.path.normpath(out_dir))}_citi_bike.md (tools/gpu_profile.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction; bytes per batch step = every mrx_k_cb_* kernel of one batch step: policy, step kernels, snapshot query)",
+        "kernel": "every kernel of one batch step (mrx_k_cb_random_policy, mrx_k_cb_step | mrx_k_cb_step_wave + mrx_k_cb_replay_wave, mrx_k_cb_query*)", "entries": []}
     rec["entries"] = [x for x in rec["entries"] if not (x["topology"] == ent["topology"] and x["envs_per_launch"] == ent["envs_per_launch"] and x.get("step_budget", 0) == ent["step_budget"])] + [ent]
     json.dump(rec, open(path, "w"), indent=1)
     buf = io.StringIO()
