@@ -14,10 +14,11 @@ export TMPDIR=/tmp
 tag=$1; shift
 O=gpurun_out/$tag
 mkdir -p $O
-timeout 600 python bench.py "$@" > $O/bench_line.json 2> $O/bench_line.err; echo "bench rc $?"
+timeout 900 python bench.py "$@" > $O/bench_line.json 2> $O/bench_line.err; echo "bench rc $?"
+[ -x tools/hbm_pattern_bench ] || hipcc -O3 --offload-arch=gfx950 -o tools/hbm_pattern_bench tools/hbm_pattern_bench.hip   # (built from source: the binary is not tracked)
 timeout 120 tools/hbm_pattern_bench --json-out $O/pattern_ceiling.json > $O/pattern_line.json 2> $O/pattern.err; echo "pattern rc $?"
-B="python bench.py --steps 60 --warmup 50 --repeats 1 --no-cpu --no-episode --parity-envs 0 $*"
-timeout 200 rocprofv3 --kernel-trace --stats -d $O/trace -o r -- python bench.py --steps 200 --warmup 50 --repeats 1 --no-cpu --no-episode --parity-envs 0 "$@" > $O/trace_line.json 2> $O/trace.err; echo "trace rc $?"
+B="python bench.py --steps 60 --warmup 50 --repeats 1 --no-cpu --no-episode --parity-envs 0 --secondary 0 $*"
+timeout 200 rocprofv3 --kernel-trace --stats -d $O/trace -o r -- python bench.py --steps 200 --warmup 50 --repeats 1 --no-cpu --no-episode --parity-envs 0 --secondary 0 "$@" > $O/trace_line.json 2> $O/trace.err; echo "trace rc $?"
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o r -- $B > $O/fetch_line.json 2> $O/fetch.err; echo "fetch rc $?"
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o r -- $B > $O/write_line.json 2> $O/write.err; echo "write rc $?"
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/sq -o r -- $B > $O/sq_line.json 2> $O/sq.err; echo "sq rc $?"
@@ -37,5 +38,27 @@ if [ "${CB:-0}" = "1" ]; then
   }
   cb_pass toy3s --bounded-budget 0
   cb_pass city800 --topology city.800s --envs 4096 --durations 2880 --steps 900 --warmup 300 --bounded-budget 0 --step-budget 64 --specialize 1
+fi
+# ---- config 5 (COLLECT=1): the DQN collection loop at 8192 envs per GPU — kernel trace + the two PMC passes over every kernel of the loop
+if [ "${COLLECT:-0}" = "1" ]; then
+  rm -f $O/${tag}_collect.md $O/latest_pmc_collect.json
+  for envs in ${COLLECT_ENVS:-8192}; do
+    C=$O/collect_$envs; mkdir -p $C
+    CF="--policy dqn --collect --ring 8 --envs $envs --no-cpu --parity-envs 0"
+    timeout 300 python bench.py $CF --steps 64 --warmup 16 > $C/bench_line.json 2> $C/bench_line.err; echo "collect $envs bench rc $?"
+    timeout 300 rocprofv3 --kernel-trace --stats -d $C/trace -o r -- python bench.py $CF --steps 64 --warmup 16 --repeats 2 > $C/trace_line.json 2> $C/trace.err; echo "collect $envs trace rc $?"
+    timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $C/fetch -o r -- python bench.py $CF --steps 64 --warmup 16 --repeats 1 > $C/fetch_line.json 2> $C/fetch.err; echo "collect $envs fetch rc $?"
+    timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $C/write -o r -- python bench.py $CF --steps 64 --warmup 16 --repeats 1 > $C/write_line.json 2> $C/write.err; echo "collect $envs write rc $?"
+    python tools/refresh_pmc_collect.py $C $envs $O
+  done
+fi
+# ---- BIG=1: the headline's PMC passes at 65536 envs per GPU (a working set 4x the Infinity Cache: are the bytes per env-step the same?)
+if [ "${BIG:-0}" = "1" ]; then
+  Bg=$O/big65536; mkdir -p $Bg
+  BB="python bench.py --envs 65536 --steps 60 --warmup 50 --repeats 1 --no-cpu --no-episode --parity-envs 0"
+  timeout 300 python bench.py --envs 65536 --steps 200 --warmup 50 --repeats 3 --no-cpu --no-episode --parity-envs 0 > $Bg/bench_line.json 2> $Bg/bench_line.err; echo "big bench rc $?"
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $Bg/fetch -o r -- $BB > $Bg/fetch_line.json 2> $Bg/fetch.err; echo "big fetch rc $?"
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $Bg/write -o r -- $BB > $Bg/write_line.json 2> $Bg/write.err; echo "big write rc $?"
+  mkdir -p $Bg/out; python tools/refresh_pmc.py $Bg profiles/${tag}_65536_rocprofv3.md $Bg/out; cp $Bg/out/latest_pmc.json $O/pmc_65536.json; cp $Bg/out/${tag}_65536_rocprofv3.md $O/ 2>/dev/null
 fi
 find $O -name "*.db" -delete; find $O -type d -empty -delete; du -sh $O
