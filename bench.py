@@ -142,7 +142,7 @@ def cpu_baseline_citi_bike(topology, durations, res, budget_s):
             "sample": f"{steps} decisions of {topology} ({episodes} episode(s), pure-Python oracle, {dt:.1f} s on 1 core)"}
 
 
-def measured_bytes_citi_bike(topology, n, step_budget, code_key):
+def measured_bytes_citi_bike(topology, n, step_budget, code_key, groups=1):
     """HBM bytes one batch step of this citi_bike configuration really moves (profiles/latest_pmc_citi_bike.json: separate
     --pmc FETCH_SIZE / WRITE_SIZE passes, all kernels of one batch step) -> (bytes or None, basis).  An entry of another build
     (its code_object_key differs) or another batch size is NOT used: the fraction is then null, never a formula."""
@@ -153,7 +153,7 @@ def measured_bytes_citi_bike(topology, n, step_budget, code_key):
         return None, "no profiles/latest_pmc_citi_bike.json"
     state = "no PMC entry of this topology / batch size / step budget"
     for ent in pmc.get("entries", []):
-        if ent["topology"] == topology and ent["envs_per_launch"] == n and ent.get("step_budget", 0) == step_budget:
+        if ent["topology"] == topology and ent["envs_per_launch"] == n and ent.get("step_budget", 0) == step_budget and ent.get("groups_per_gpu", 1) == groups:
             if ent.get("code_object_key") is not None and ent.get("code_object_key") != code_key:
                 state = f"the PMC entry is of another build (code object {ent.get('code_object_key')}, running {code_key})"
                 continue
@@ -176,49 +176,70 @@ def bench_citi_bike(args, dist, dev, rank, world):
     topology = args.topology if args.topology != "global_trade.22p_l0.8" else "toy.3s_4t"
     durations = args.durations if args.durations != 1120 else 44000
     durations = min(durations, len(load_cb(topology).tick_day))   # (city.180s holds two days of trips, the toys a month)
+    # Independent env GROUPS on their own HIP streams (as for CIM): a batch step of this path lasts as long as its longest
+    # env-step's dependent chain, whatever the batch size, until the chip fills — so G groups' chains overlap almost for free.
+    G = max(1, min(args.cb_groups, n))
+    sizes = [n // G + (1 if g < n % G else 0) for g in range(G)]
+    offs = [sum(sizes[:g]) for g in range(G)]
     seeds = np.arange(n) + rank * n + 1
-    kw = dict(durations=durations, snapshot_resolution=res, max_snapshots=16, max_actions=1, device=dev, seeds=seeds)
-    try:
-        eng = CitiBikeBatchEngine(topology, n, specialize=bool(args.specialize), **kw)   # kernels compiled for this plan (cached in-tree)
-    except (RuntimeError, OSError, subprocess.CalledProcessError) as e:
-        if not args.specialize:
-            raise
-        print(f"bench: specialised kernels unavailable ({e}); using the generic ones", file=sys.stderr)
-        eng = CitiBikeBatchEngine(topology, n, specialize=False, **kw)
+    engines, streams, bufs = [], [], []
+    for g in range(G):
+        kw = dict(durations=durations, snapshot_resolution=res, max_snapshots=16, max_actions=1, device=dev, seeds=seeds[offs[g]:offs[g] + sizes[g]])
+        try:
+            e = CitiBikeBatchEngine(topology, sizes[g], specialize=bool(args.specialize), **kw)   # kernels compiled for this plan (cached in-tree)
+        except (RuntimeError, OSError, subprocess.CalledProcessError) as err:
+            if not args.specialize:
+                raise
+            print(f"bench: specialised kernels unavailable ({err}); using the generic ones", file=sys.stderr)
+            e = CitiBikeBatchEngine(topology, sizes[g], specialize=False, **kw)
+        engines.append(e)
+        streams.append(torch.cuda.Stream(device=dev) if G > 1 else torch.cuda.current_stream(dev))
+    eng = engines[0]
     S = eng.data.n_stations
-    if args.step_budget:
-        eng.set_step_budget(args.step_budget)
-    actions = torch.zeros((n, 1, 3), dtype=torch.int32, device=dev)
-    n_actions = torch.zeros((n,), dtype=torch.int32, device=dev)
-    counter = torch.zeros((1,), dtype=torch.int64, device=dev)
-    stations = torch.arange(S, dtype=torch.int32, device=dev)
     q_attrs = ["bikes", "shortage", "trip_requirement", "fulfillment", "capacity", "extra_cost", "min_bikes"]
     # the per-step observation: on the toys every station; on city-sized topologies the stations of the decision's ACTION SCOPE (the
     # deciding station + its filtered neighbours: what an agent can act on, 21 rows with the ny filter chain) — all 800 stations x
     # 7 attributes per env and step would be 45 KB of float64 per env-step, several times the simulation's own traffic
     scope_obs = S > 64
     cap = eng.layout.scope_cap
-    q_nodes = torch.empty((n, cap), dtype=torch.int32, device=dev) if scope_obs else None
-    q_out = None if args.no_query else torch.empty((n, 1, cap if scope_obs else S, len(q_attrs)), dtype=torch.float64, device=dev)
+    stations = torch.arange(S, dtype=torch.int32, device=dev)
+    for g, e in enumerate(engines):
+        ng = sizes[g]
+        if args.step_budget:
+            e.set_step_budget(args.step_budget)
+        bufs.append(dict(actions=torch.zeros((ng, 1, 3), dtype=torch.int32, device=dev), n_actions=torch.zeros((ng,), dtype=torch.int32, device=dev),
+                         counter=torch.zeros((1,), dtype=torch.int64, device=dev),
+                         q_nodes=torch.empty((ng, cap), dtype=torch.int32, device=dev) if scope_obs else None,
+                         q_out=None if args.no_query else torch.empty((ng, 1, cap if scope_obs else S, len(q_attrs)), dtype=torch.float64, device=dev)))
+    torch.cuda.synchronize(dev)
+    if G > 1:
+        for e, st in zip(engines, streams):
+            e.use_stream(st)
 
-    def one_step(i):
-        if i == 0:
-            eng.step()
-            return
-        eng.random_policy(i, actions, n_actions, counter)
-        eng.step(actions, n_actions)
-        if q_out is not None:
-            if scope_obs:
-                q_nodes.copy_(eng.scope[:, :, 0])      # per-env node lists; -1 padding reads as zeros (query semantics)
-                eng.query("stations", eng.decisions[:, 3:4], q_nodes, q_attrs, out=q_out)
-            else:
-                eng.query("stations", eng.decisions[:, 3:4], stations, q_attrs, out=q_out)
+    def one_step(i, count=True):
+        for g, e in enumerate(engines):
+            b = bufs[g]
+            if i == 0:
+                e.step()
+                continue
+            e.random_policy(i, b["actions"], b["n_actions"], b["counter"] if count else None)
+            e.step(b["actions"], b["n_actions"])
+            if b["q_out"] is not None:
+                if scope_obs:
+                    with torch.cuda.stream(streams[g]):
+                        b["q_nodes"].copy_(e.scope[:, :, 0])      # per-env node lists; -1 padding reads as zeros (query semantics)
+                    e.query("stations", e.decisions[:, 3:4], b["q_nodes"], q_attrs, out=b["q_out"])
+                else:
+                    e.query("stations", e.decisions[:, 3:4], stations, q_attrs, out=b["q_out"])
 
     def sync_all():
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize(dev)
+
+    def total(name):
+        return sum(float(getattr(e, name).to(torch.int64).sum().item()) for e in engines)
 
     t_leg = time.perf_counter()
     step_i = 0
@@ -229,24 +250,26 @@ def bench_citi_bike(args, dist, dev, rank, world):
     # the timed window: exactly --steps batch steps between barrier + synchronize, --repeats times back to back (value = median)
     windows = []
     for _ in range(max(1, args.repeats)):
-        counter.zero_()
-        tick0 = eng.ticks.to(torch.int64).sum().item()
+        for b in bufs:
+            b["counter"].zero_()
+        tick0 = total("ticks")
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             one_step(step_i)
             step_i += 1
+        t_issued = time.perf_counter() - t0
         sync_all()
         dt = time.perf_counter() - t0
-        windows.append((dt, float(counter.item()), float(eng.ticks.to(torch.int64).sum().item() - tick0)))
-    n_done = int(eng.done.sum().item())
-    status_bad = int((eng.status != 0).sum().item())
+        windows.append((dt, sum(float(b["counter"].item()) for b in bufs), total("ticks") - tick0, t_issued))
+    n_done = int(total("done"))
+    status_bad = sum(int((e.status != 0).sum().item()) for e in engines)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 100))]
-    for a, b in ev:
-        eng.random_policy(step_i, actions, n_actions, None)
-        a.record()
-        eng.step(actions, n_actions)
-        b.record()
+    for a, b in ev:       # (group 0's step launch alone on its stream: informational)
+        eng.random_policy(step_i, bufs[0]["actions"], bufs[0]["n_actions"], None)
+        a.record(streams[0])
+        eng.step(bufs[0]["actions"], bufs[0]["n_actions"])
+        b.record(streams[0])
         step_i += 1
     torch.cuda.synchronize(dev)
     step_kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
@@ -254,12 +277,14 @@ def bench_citi_bike(args, dist, dev, rank, world):
     # without a decision yet are skipped by the policy and continue in the next call.  Reported beside `value`, not as it.
     bounded = None
     if args.bounded_budget and not args.step_budget:
-        eng.set_step_budget(args.bounded_budget)
+        for e in engines:
+            e.set_step_budget(args.bounded_budget)
         for _ in range(args.warmup):
             one_step(step_i)
             step_i += 1
         sync_all()
-        counter.zero_()
+        for b in bufs:
+            b["counter"].zero_()
         sync_all()
         tb = time.perf_counter()
         for _ in range(args.steps):
@@ -267,8 +292,9 @@ def bench_citi_bike(args, dist, dev, rank, world):
             step_i += 1
         sync_all()
         dtb = time.perf_counter() - tb
-        bounded = [float(counter.item()), dtb]
-        eng.set_step_budget(0)
+        bounded = [sum(float(b["counter"].item()) for b in bufs), dtb]
+        for e in engines:
+            e.set_step_budget(0)
         sync_all()
     # the one exchange step of a sharded rollout: 32 steps of (decision, action, metrics, done) per env gathered to the
     # learner rank over RCCL (maro_amd/cim/rollout.py::gather_to_learner); outside the timed env-step window
@@ -278,11 +304,14 @@ def bench_citi_bike(args, dist, dev, rank, world):
         T = 32
         traj = {"decisions": torch.zeros((T, n, 8), dtype=torch.int32, device=dev), "actions": torch.zeros((T, n, 1, 3), dtype=torch.int32, device=dev),
                 "metrics": torch.zeros((T, n, 3), dtype=torch.int64, device=dev), "done": torch.zeros((T, n), dtype=torch.uint8, device=dev)}
+        torch.cuda.synchronize(dev)   # (allocated on torch's current stream, written on the groups' streams)
         for k in range(T):
-            eng.random_policy(step_i, actions, n_actions, None)
-            traj["decisions"][k], traj["actions"][k] = eng.decisions, actions
-            eng.step(actions, n_actions)
-            traj["metrics"][k], traj["done"][k] = eng.metrics, eng.done
+            one_step(step_i, count=False)
+            for g, e in enumerate(engines):
+                with torch.cuda.stream(streams[g]):
+                    sl = slice(offs[g], offs[g] + sizes[g])
+                    traj["decisions"][k, sl], traj["actions"][k, sl] = e.decisions, bufs[g]["actions"]
+                    traj["metrics"][k, sl], traj["done"][k, sl] = e.metrics, e.done
             step_i += 1
         sync_all()
         tg = time.perf_counter()
@@ -295,12 +324,15 @@ def bench_citi_bike(args, dist, dev, rank, world):
     parity = None
     if args.parity_envs > 0 and rank == 0:
         from tests.bench_parity import replay_citi_bike_against_oracle
-        parity = replay_citi_bike_against_oracle(eng, seeds, k=min(args.parity_envs, 8), steps=min(600, max(64, durations // 4)),
+        torch.cuda.synchronize(dev)
+        eng.use_stream(None)      # (group 0's engine, on torch's current stream for the replay)
+        parity = replay_citi_bike_against_oracle(eng, seeds[:sizes[0]], k=min(args.parity_envs, 8), steps=min(600, max(64, durations // 4)),
                                                  obs_attrs=None if (args.no_query or scope_obs) else q_attrs)
     gpu_s = time.perf_counter() - t_leg
     R = len(windows)
     t_max = torch.tensor([w[0] for w in windows] + [bounded[1] if bounded else 0.0], dtype=torch.float64, device=dev)
     tot = torch.tensor([w[1] for w in windows] + [w[2] for w in windows] + [float(n_done), float(status_bad), bounded[0] if bounded else 0.0], dtype=torch.float64, device=dev)
+    t_issued = sorted(w[3] for w in windows)[len(windows) // 2]
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -316,7 +348,7 @@ def bench_citi_bike(args, dist, dev, rank, world):
     tbar = ticks_adv / max(resolved, 1.0)
     ms_per_step = dt / args.steps * 1e3
     code_key = getattr(eng, "code_object_key", None)
-    traffic, basis = measured_bytes_citi_bike(topology, n, args.step_budget, code_key)
+    traffic, basis = measured_bytes_citi_bike(topology, n, args.step_budget, code_key, G)
     achieved = None if traffic is None else traffic / (ms_per_step * 1e-3) / 1e9     # per GPU: bytes of one batch step / its wall time
     out = {
         "metric": f"env-steps/sec (decision events/sec), citi_bike {topology}",
@@ -325,8 +357,8 @@ def bench_citi_bike(args, dist, dev, rank, world):
         "dtype": "int32+f64", "data": "synthetic", "repeats": R, "value_min": min(vals), "value_max": max(vals), "gpu_seconds_total": gpu_s,
         "config": {"workload": f"citi_bike {topology}, {n} envs/GPU x {world} GPU, durations {durations}, resolution {res}, "
                                f"device policy, stations snapshot slice {'off' if args.no_query else ('every step (stations of the action scope x 7 attrs)' if scope_obs else 'every step (all stations x 7 attrs)')}",
-                   "envs_per_gpu": n, "specialized_kernels": bool(eng.specialized), "code_object_key": code_key, "wave_cooperative_step": bool(eng.set_wave_decisions(0)),
-                   "env_major_state": bool(eng.layout.env_major), "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective)",
+                   "envs_per_gpu": n, "groups_per_gpu": G, "host_enqueue_ms_per_step": t_issued / args.steps * 1e3, "specialized_kernels": bool(eng.specialized), "code_object_key": code_key, "wave_cooperative_step": bool(eng.set_wave_decisions(0)),
+                   "env_major_state": bool(eng.layout.env_major), "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective); {G} independent group(s) per GPU on separate HIP streams",
                    "trajectory_gather_ms_32_steps": gather_ms, "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad,
                    "step_budget": args.step_budget},
         "roofline": {"bound": "hbm", "kernel": "mrx_k_cb_step" if not eng.layout.env_major else "mrx_k_cb_step_wave + mrx_k_cb_replay_wave (+ query, policy)",
@@ -733,6 +765,7 @@ def main():
     ap.add_argument("--topology", default="global_trade.22p_l0.8")
     ap.add_argument("--step-budget", type=int, default=0, help="citi_bike: bounded steps for the main window (mrx_cb_set_step_budget; 0 = every call yields a decision)")
     ap.add_argument("--bounded-budget", type=int, default=24, help="citi_bike: budget of the extra bounded-steps leg (0: skip it)")
+    ap.add_argument("--cb-groups", type=int, default=1, help="citi_bike: independent env groups per GPU, each engine on its own HIP stream")
     ap.add_argument("--durations", type=int, default=1120)
     ap.add_argument("--preroll-ticks", type=int, default=300, help="untimed steps before the warmup until the batch's mean tick reaches this "
                     "(the timed window then measures mid-episode steady state, whatever --steps / --warmup are)")

@@ -413,6 +413,67 @@ int mrx_cim_sampler_emit(int32_t n_rows, int32_t n_ports, int32_t state_dim, int
                          float* o_reward, void* o_next_state, void* o_next_agent_state, uint8_t* o_terminal, int32_t* o_env_id, int32_t* o_tick,
                          int32_t* o_agent, int32_t device, void* stream);
 
+/*
+ * The batched EnvSampler's per-env transition cache — `_trans_cache` / `_agent_last_index` of AbsEnvSampler
+ * (maro/rl/rollout/env_sampler.py:404-410, 438-537) for n_envs envs at once — as one argument block: caller-owned device arrays,
+ * the same ones mrx_cim_sampler_record / mrx_cim_sampler_emit take one by one.  An env's cache is a ring of `cap` slots (a power of
+ * two): element number q lives in slot q & (cap - 1); d_head counts the elements appended, d_tail the ones emitted or dropped.
+ */
+typedef struct mrx_cim_sampler_cache {
+  int32_t n_envs, n_ports, state_dim, cap;
+  int32_t state_f64;           /* element type of c_state / c_next_state / c_next_agent_state: 0 float32, 1 float64 */
+  int32_t window;              /* reward window in ticks = reward_eval_delay (examples/cim/rl/config.py: time_window) */
+  int32_t frames, reserved0;   /* frames per env of d_port_history */
+  double fulfillment_factor, shortage_factor;
+  const double* d_decay;       /* [window] time_decay ^ k */
+  uint8_t* d_eoe;              /* [n] _end_of_episode */
+  int64_t *d_head, *d_tail;    /* [n] */
+  int64_t* d_last;             /* [n][n_ports] element number of each agent's last element (-1: none) */
+  int64_t* d_prev_j;           /* [n] slot written by the env's previous interaction */
+  uint8_t* d_prev_active;      /* [n] that element still waits for its next_state */
+  int64_t* d_interactions;     /* [n] interactions performed */
+  int32_t* c_tick;             /* [n][cap] */
+  int64_t* c_agent;            /* [n][cap] */
+  void* c_state;               /* [n][cap][state_dim] */
+  int64_t* c_action;           /* [n][cap] model action */
+  int32_t* c_env_action;       /* [n][cap][4] */
+  uint8_t* c_terminal;         /* [n][cap] */
+  void* c_next_state;          /* [n][cap][state_dim] */
+  void* c_next_agent_state;    /* [n][cap][state_dim] */
+  int32_t* d_port_history;     /* int32 [n][frames][2][n_ports]: mrx_cim_set_port_history(fulfillment, shortage) */
+} mrx_cim_sampler_cache;
+
+/*
+ * n_steps interactions of every env, enqueued in ONE call (the inner loop of AbsEnvSampler.sample,
+ * maro/rl/rollout/env_sampler.py:484-511): per interaction
+ *   mrx_cim_dqn_act (binning + forward kernel) with the transition-cache update of mrx_cim_sampler_record folded into those two
+ *   launches (the forward kernel appends each deciding env's transition from the state row it holds in LDS; the binning launch
+ *   retires envs whose episode is over: eoe |= done, the last element's next_state = its own state), then mrx_cim_step
+ * — three launches, no host round trip, no host work between interactions.  Envs whose episode ends sit the remaining steps out
+ * (the caller rolls them over between calls).  d_prev_active must be zero for envs without a pending element (after a reset).
+ * Results are those of the three separate calls, step by step.
+ */
+int mrx_cim_collect_steps(mrx_handle h, const mrx_cim_dqn_model* m, void* d_scratch, const mrx_cim_sampler_cache* cache, int32_t* d_actions,
+                          int32_t* d_n_actions, int32_t* d_decisions, int64_t* d_metrics, uint8_t* d_done, int32_t n_steps, void* stream);
+
+/*
+ * The end of a batched EnvSampler call (env_sampler.py:512-530) for every env, on the device.
+ * mrx_cim_sampler_finalize: eoe |= d_done; an env whose episode is over gets its last element's next_state (its own state); a
+ *   paused env's current tick gets its port-history row from the live frame (the pre-decision snapshot, core.py:345);
+ *   d_n_emit[e] = the env's cached elements, oldest first, with tick <= env.tick - window; d_out_offset = their exclusive prefix
+ *   over the envs; d_info int64 [4] = (experiences to emit, most elements any env keeps cached afterwards, envs at the end of
+ *   their episode, 0) — the call's one read-back.
+ * mrx_cim_sampler_emit_all: every env's d_n_emit[e] oldest elements -> rows d_out_offset[e] ... of the outputs (those of
+ *   mrx_cim_sampler_emit, K = d_info[0] rows) with the delayed reward; `_append_cache_element(None)` is applied on the way (an
+ *   emitted element that is still its agent's last one: terminal = end_of_episode, next_agent_state = its own state,
+ *   env_sampler.py:404-410); then the emitted prefix is popped (d_tail += d_n_emit, d_last entries below the new tail = -1).
+ */
+int mrx_cim_sampler_finalize(mrx_handle h, const mrx_cim_sampler_cache* cache, const uint8_t* d_done, int64_t* d_n_emit, int64_t* d_out_offset,
+                             int64_t* d_info, void* stream);
+int mrx_cim_sampler_emit_all(mrx_handle h, const mrx_cim_sampler_cache* cache, const int64_t* d_n_emit, const int64_t* d_out_offset, void* o_state,
+                             int64_t* o_action, int32_t* o_env_action, float* o_reward, void* o_next_state, void* o_next_agent_state,
+                             uint8_t* o_terminal, int32_t* o_env_id, int32_t* o_tick, int32_t* o_agent, void* stream);
+
 /* Attribute name -> id and slot count for a node type; returns -1 for an unknown attribute
  * (reference raises BackendsInvalidAttributeException, frame.pyx:786-790). */
 int mrx_cim_attr_id(int node_type, const char* name);

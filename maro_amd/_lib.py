@@ -43,10 +43,20 @@ class MrxCimDqnModel(ctypes.Structure):
                 ("action_space", ctypes.c_double * 32), ("d_weights", ctypes.c_void_p)]
 
 
+class MrxCimSamplerCache(ctypes.Structure):
+    """ctypes mirror of ``struct mrx_cim_sampler_cache`` (include/maro_amd.h)."""
+
+    _fields_ = ([(n, ctypes.c_int32) for n in ("n_envs", "n_ports", "state_dim", "cap", "state_f64", "window", "frames", "reserved0")]
+                + [("fulfillment_factor", ctypes.c_double), ("shortage_factor", ctypes.c_double)]
+                + [(n, ctypes.c_void_p) for n in ("d_decay", "d_eoe", "d_head", "d_tail", "d_last", "d_prev_j", "d_prev_active", "d_interactions", "c_tick",
+                                                  "c_agent", "c_state", "c_action", "c_env_action", "c_terminal", "c_next_state", "c_next_agent_state",
+                                                  "d_port_history")])
+
+
 EXPORTS = ("mrx_last_error", "mrx_version", "mrx_cim_workspace_bytes", "mrx_cim_create", "mrx_cim_destroy",
            "mrx_cim_get_layout", "mrx_cim_reset", "mrx_cim_step", "mrx_cim_step_joint", "mrx_cim_query", "mrx_cim_attr_id",
            "mrx_cim_attr_slots", "mrx_cim_random_policy", "mrx_cim_set_observation", "mrx_cim_set_step_mode", "mrx_cim_set_port_history", "mrx_cim_dqn_net_floats",
-           "mrx_cim_dqn_pack_net", "mrx_cim_dqn_scratch_bytes", "mrx_cim_dqn_act", "mrx_cim_sampler_record", "mrx_cim_sampler_emit", "mrx_cim_plan_defines", "mrx_cim_load_step_kernels", "mrx_cim_read_kernel_global",
+           "mrx_cim_dqn_pack_net", "mrx_cim_dqn_scratch_bytes", "mrx_cim_dqn_act", "mrx_cim_sampler_record", "mrx_cim_sampler_emit", "mrx_cim_collect_steps", "mrx_cim_sampler_finalize", "mrx_cim_sampler_emit_all", "mrx_cim_plan_defines", "mrx_cim_load_step_kernels", "mrx_cim_read_kernel_global",
            # include/maro_amd_citi_bike.h
            "mrx_cb_workspace_bytes", "mrx_cb_create", "mrx_cb_destroy", "mrx_cb_get_layout", "mrx_cb_reset", "mrx_cb_step",
            "mrx_cb_query", "mrx_cb_random_policy", "mrx_cb_attr_id", "mrx_cb_attr_slots", "mrx_cb_plan_defines",
@@ -117,6 +127,12 @@ def load() -> ctypes.CDLL:
     L.mrx_cim_sampler_record.argtypes = [i32] * 7 + [vp] * 20 + [i32, vp]
     L.mrx_cim_sampler_emit.restype = i32
     L.mrx_cim_sampler_emit.argtypes = [i32] * 7 + [ctypes.c_double] * 2 + [vp] * 24 + [i32, vp]
+    L.mrx_cim_collect_steps.restype = i32
+    L.mrx_cim_collect_steps.argtypes = [vp] * 9 + [i32, vp]
+    L.mrx_cim_sampler_finalize.restype = i32
+    L.mrx_cim_sampler_finalize.argtypes = [vp] * 7
+    L.mrx_cim_sampler_emit_all.restype = i32
+    L.mrx_cim_sampler_emit_all.argtypes = [vp] * 15
     L.mrx_cim_attr_id.restype = i32
     L.mrx_cim_attr_id.argtypes = [i32, ctypes.c_char_p]
     L.mrx_cim_attr_slots.restype = i32

@@ -249,6 +249,16 @@ class FusedPerPortDQN:
                                            self.eng._stream()), "mrx_cim_dqn_act")
 
 
+    def collect_steps(self, cache, actions: torch.Tensor, n_actions: torch.Tensor, n_steps: int) -> None:
+        """`n_steps` interactions of every env enqueued by ONE C call (mrx_cim_collect_steps): per interaction the two policy launches —
+        with the batched EnvSampler's transition-cache update folded in (`cache`: a ``_lib.MrxCimSamplerCache`` over the sampler's
+        device arrays) — and mrx_cim_step.  No host work between the interactions; results equal act -> record -> step."""
+        e = self.eng
+        _lib.check(self._L.mrx_cim_collect_steps(e._h, ctypes.byref(self._m), self.scratch.data_ptr(), ctypes.byref(cache), actions.data_ptr(),
+                                                 n_actions.data_ptr(), e.decisions.data_ptr(), e.metrics.data_ptr(), e.done.data_ptr(), int(n_steps),
+                                                 e._stream()), "mrx_cim_collect_steps")
+
+
 class PerPortDuelingQNet(torch.nn.Module):
     """Plain PyTorch float32 restatement (test reference): q[n, A] of the network that belongs to each env's deciding port,
     from the same folded chains ``FusedPerPortDQN`` packs.  Every network is evaluated on every state, then gathered."""

@@ -6,6 +6,8 @@ queries and a handful of tensor ops, no per-env Python loop and no host round tr
 """
 from __future__ import annotations
 
+import ctypes
+import os
 from typing import Callable, Dict, Optional, Sequence
 
 import torch
@@ -79,6 +81,8 @@ class CimBatchSampler:
             ns = seq[er, es] & (cap - 1)
             for key in c:
                 c[key][er, ns] = old[key][er, es]
+            if hasattr(self, "_pj"):   # the slot of every env's newest element in the larger ring (device-resident loop)
+                self._pj.copy_((self._head - 1).clamp(min=0) & (cap - 1))
         self._c, self._cap = c, cap
 
     def _sample_init(self, state_dtype) -> None:
@@ -96,6 +100,9 @@ class CimBatchSampler:
         self._steps_env = torch.zeros(n, dtype=torch.int64, device=dev)   # interactions each env has performed (sample_fused)
         self._ep_env = torch.zeros(n, dtype=torch.int64, device='cpu')   # episodes each env has started: what its seed depends on
         self._cur_state = torch.zeros((n, self.state_dim), dtype=state_dtype, device=dev)
+        self._pj = torch.zeros(n, dtype=torch.int64, device=dev)       # slot the env's previous interaction wrote (device-resident loop)
+        self._pa = torch.zeros(n, dtype=torch.uint8, device=dev)       # ... and whether that element still waits for its next state
+        self._max_cached, self._any_eoe = 0, True                     # host-side: bound on any env's cached elements; may an env need a reset
         # per-attribute retention: the whole episode of (fulfillment, shortage) per port, written by the step kernel at every
         # snapshot — the delayed reward reads up to time_window ticks ahead of decisions that may be an episode old
         self._hist = eng.set_port_history(["fulfillment", "shortage"])
@@ -320,6 +327,11 @@ class CimBatchSampler:
         eng = self.eng
         n, dev = eng.n_envs, eng.decisions.device
         seeds = _seed_fn(seeds, n)
+        if eng.decisions.is_cuda and num_steps is not None and hasattr(actor, "collect_steps") and state_dtype in (torch.float32, torch.float64) \
+                and os.environ.get("MRX_SAMPLER_V2", "1") != "0":
+            # the device-resident form of this loop (same results): one C call per segment of interactions, the end of the call
+            # (finalisation, emission) in three launches and one read-back
+            return (yield from self._sample_fused_device(actor, num_steps, seeds, reset_every, state_dtype))
         # An engine bound to a side stream (CimBatchEngine.use_stream): the sampler's own tensor ops go to that stream too.  The
         # stream is switched per SEGMENT, never across a `yield` (another group's generator runs in between).
         bound = getattr(eng, "_bound_stream", None)
@@ -477,6 +489,153 @@ class CimBatchSampler:
             res = {k: ((v[0] if len(v) == 1 else torch.cat(v)) if v else
                        torch.zeros((0,) + tuple(c[k].shape[2:]) if k in c else (0,), dtype=(c[k].dtype if k in c else torch.int32), device=dev))
                    for k, v in out.items()}
+            if not out["reward"]:
+                res["reward"] = torch.zeros(0, dtype=torch.float32, device=dev)
+            res["env_metric"] = eng.metrics.clone()
+        finally:
+            leave(tok)
+        return res
+
+    # ------------------------------------------------------------------ the device-resident collection loop
+    def _cache_struct(self):
+        """The cache as the C ABI's argument block (include/maro_amd.h: mrx_cim_sampler_cache); rebuilt whenever an array is re-allocated."""
+        from .. import _lib
+        c, eng = self._c, self.eng
+        key = tuple(int(v.data_ptr()) for v in c.values()) + (int(self._hist.data_ptr()), self._cap)
+        if getattr(self, "_cs_key", None) != key:
+            m = _lib.MrxCimSamplerCache()
+            m.n_envs, m.n_ports, m.state_dim, m.cap = eng.n_envs, eng.layout.n_ports, self.state_dim, self._cap
+            m.state_f64, m.window, m.frames = int(self.state_dtype == torch.float64), self.time_window, int(self._hist.shape[1])
+            m.fulfillment_factor, m.shortage_factor = float(self.ff), float(self.sf)
+            m.d_decay, m.d_eoe, m.d_head, m.d_tail, m.d_last = (t.data_ptr() for t in (self._decay, self._eoe, self._head, self._tail, self._last))
+            m.d_prev_j, m.d_prev_active, m.d_interactions = self._pj.data_ptr(), self._pa.data_ptr(), self._steps_env.data_ptr()
+            m.c_tick, m.c_agent, m.c_state, m.c_action = (c[k].data_ptr() for k in ("tick", "agent", "state", "action"))
+            m.c_env_action, m.c_terminal, m.c_next_state, m.c_next_agent_state = (c[k].data_ptr() for k in ("env_action", "terminal", "next_state", "next_agent_state"))
+            m.d_port_history = self._hist.data_ptr()
+            self._cs, self._cs_key = m, key
+        return self._cs
+
+    def _sample_fused_device(self, actor, num_steps: int, seeds, reset_every: int, state_dtype: torch.dtype):
+        """``sample_fused_steps`` with everything between two roll-over points on the device and nothing on the host:
+
+        * a SEGMENT of interactions (up to `reset_every`) is one C call, ``actor.collect_steps`` = mrx_cim_collect_steps: per
+          interaction the two policy launches — the transition-cache update rides in them — and the step launch;
+        * the end of the call is mrx_cim_sampler_finalize (emission counts, their prefix over the envs, a 32-byte read-back) and
+          mrx_cim_sampler_emit_all (block copies of the three state arrays, rewards from LDS-staged history rows); the generator
+          yields between the two so that ``sample_fused_groups`` enqueues every group's finalisation before it waits for any;
+        * ``_append_cache_element(None)`` and the last element's next state are applied where they become visible (emission, the
+          next interaction) instead of eagerly for every env at the end of every call.
+
+        Per call the host waits for the device once (the read-back), plus once per roll-over point that falls inside the call; the
+        mid-call roll-over itself (rare: an env's episode ended) runs the tensor-op specification of the emission for those envs."""
+        from .. import _lib
+        from .engine import SEED_REDRAW
+        eng, L = self.eng, self.eng._L
+        n, dev = eng.n_envs, eng.decisions.device
+        bound = getattr(eng, "_bound_stream", None)
+
+        def enter():
+            if bound is None:
+                return None
+            prev = torch.cuda.current_stream(bound.device)
+            torch.cuda.set_stream(bound)
+            return prev
+
+        def leave(prev) -> None:
+            if prev is not None:
+                torch.cuda.set_stream(prev)
+
+        def reset_envs(mask: torch.Tensor) -> None:   # AbsEnvSampler._reset for the envs in `mask` (a sync point: rare)
+            cmd = seeds(self._ep_env.clone()).to(torch.int64) if seeds is not None else torch.full((n,), SEED_REDRAW, dtype=torch.int64)
+            self._episodes += 1
+            self._ep_env += mask.cpu().to(torch.int64)
+            eng.reset(cmd, mask.to(torch.uint8))
+            self._hist[mask] = 0
+            self._tail.copy_(torch.where(mask, self._head, self._tail))
+            self._last[mask] = -1
+            self._pa[mask] = 0                           # no element waits for a next state
+            eng.step(mask=mask.to(torch.uint8))          # _step(None): the first decision event
+            self._eoe.copy_(torch.where(mask, eng.done.to(torch.bool), self._eoe))
+
+        def roll_over(out) -> None:
+            """Envs at the end of their episode: finalised, emitted (bound = final tick - delay), reset."""
+            ended = self._eoe.clone()
+            c = self._c
+            rows = torch.nonzero(ended & self._pa.to(torch.bool)).view(-1)
+            if rows.numel():   # their last element's next state is its own state (the binning launch does this at the next interaction)
+                pj = self._pj[rows]
+                c["next_state"][rows, pj] = c["state"][rows, pj]
+                self._pa[rows] = 0
+            self._finalize_and_emit(ended, out, kernel=True)
+            reset_envs(ended)
+
+        tok = enter()
+        try:
+            if not hasattr(self, "_c") or self.state_dtype != state_dtype:
+                self._sample_init(state_dtype)
+            if self._max_cached + num_steps + 1 > self._cap:      # host-side bound: no read-back
+                self._cache_alloc(max(self._max_cached + num_steps + 1, 2 * self._cap))
+            out = {k: [] for k in ("state", "action", "env_action", "reward", "next_state", "next_agent_state", "terminal", "env_id", "tick", "agent")}
+            if not hasattr(self, "_acts"):
+                self._acts = torch.zeros((n, eng.max_actions, 4), dtype=torch.int32, device=dev)
+                self._nact = torch.zeros(n, dtype=torch.int32, device=dev)
+                self._n_emit = torch.zeros(n, dtype=torch.int64, device=dev)
+                self._off = torch.zeros(n, dtype=torch.int64, device=dev)
+                self._info = torch.zeros(4, dtype=torch.int64, device=dev)
+                self._info_host = torch.zeros(4, dtype=torch.int64).pin_memory()
+            if self._any_eoe and bool(self._eoe.any()):          # (the flag is the previous call's read-back: usually no wait here)
+                roll_over(out)
+        finally:
+            leave(tok)
+        k = 0
+        while k < num_steps:
+            if k > 0 and k % max(1, reset_every) == 0:
+                tok = enter()
+                try:
+                    torch.logical_or(self._eoe, eng.done, out=self._eoe)
+                    if bool(self._eoe.any()):
+                        roll_over(out)
+                finally:
+                    leave(tok)
+            seg = min(num_steps - k, max(1, reset_every) - k % max(1, reset_every))
+            actor.collect_steps(self._cache_struct(), self._acts, self._nact, seg)
+            self._max_cached += seg
+            k += seg
+            yield k
+        tok = enter()
+        try:
+            cs = self._cache_struct()
+            _lib.check(L.mrx_cim_sampler_finalize(eng._h, ctypes.byref(cs), eng.done.data_ptr(), self._n_emit.data_ptr(), self._off.data_ptr(),
+                                                  self._info.data_ptr(), eng._stream()), "mrx_cim_sampler_finalize")
+            self._info_host.copy_(self._info, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+        finally:
+            leave(tok)
+        yield "finalized"     # (sample_fused_groups: the other groups enqueue their finalisation before anyone waits)
+        tok = enter()
+        try:
+            ev.synchronize()
+            K, max_cached, n_over = (int(x) for x in self._info_host[:3].tolist())
+            self._max_cached, self._any_eoe = max_cached, n_over > 0
+            D = self.state_dim
+            if K > 0:
+                o = dict(state=torch.empty((K, D), dtype=self.state_dtype, device=dev), action=torch.empty(K, dtype=torch.int64, device=dev),
+                         env_action=torch.empty((K, 4), dtype=torch.int32, device=dev), reward=torch.empty(K, dtype=torch.float32, device=dev),
+                         next_state=torch.empty((K, D), dtype=self.state_dtype, device=dev),
+                         next_agent_state=torch.empty((K, D), dtype=self.state_dtype, device=dev), terminal=torch.empty(K, dtype=torch.bool, device=dev),
+                         env_id=torch.empty(K, dtype=torch.int32, device=dev), tick=torch.empty(K, dtype=torch.int32, device=dev),
+                         agent=torch.empty(K, dtype=torch.int32, device=dev))
+                _lib.check(L.mrx_cim_sampler_emit_all(eng._h, ctypes.byref(cs), self._n_emit.data_ptr(), self._off.data_ptr(), o["state"].data_ptr(),
+                                                      o["action"].data_ptr(), o["env_action"].data_ptr(), o["reward"].data_ptr(), o["next_state"].data_ptr(),
+                                                      o["next_agent_state"].data_ptr(), o["terminal"].data_ptr(), o["env_id"].data_ptr(), o["tick"].data_ptr(),
+                                                      o["agent"].data_ptr(), eng._stream()), "mrx_cim_sampler_emit_all")
+                for key, v in o.items():
+                    out[key].append(v)
+            c = self._c
+            res = {k2: ((v[0] if len(v) == 1 else torch.cat(v)) if v else
+                        torch.zeros((0,) + tuple(c[k2].shape[2:]) if k2 in c else (0,), dtype=(c[k2].dtype if k2 in c else torch.int32), device=dev))
+                   for k2, v in out.items()}
             if not out["reward"]:
                 res["reward"] = torch.zeros(0, dtype=torch.float32, device=dev)
             res["env_metric"] = eng.metrics.clone()

@@ -107,15 +107,32 @@ class CitiBikeBatchEngine:
         n = int(np.prod(shape)) * 4
         return self.workspace[off:off + n].view(torch.int32).view(*shape)
 
+    def use_stream(self, stream: Optional[torch.cuda.Stream]) -> None:
+        """Bind every later call of this engine to `stream` (None: back to torch's current stream at call time) — the same stream
+        discipline as ``CimBatchEngine.use_stream``: kernels launch on it, host inputs are converted on it, device tensors passed as
+        they are must have been produced on it (or be complete), outputs are read on it or after ``stream.synchronize()``.  A rollout
+        loop that drives several env groups on their own streams overlaps their (latency-bound) batch steps this way."""
+        self._bound_stream = stream
+        self._bound_handle = None if stream is None else stream.cuda_stream
+
     def _stream(self) -> int:
-        return torch.cuda.current_stream(self.device).cuda_stream
+        h = getattr(self, "_bound_handle", None)
+        return torch.cuda.current_stream(self.device).cuda_stream if h is None else h
 
     def _dev(self, x, dtype) -> Optional[torch.Tensor]:
         if x is None:
             return None
+        if isinstance(x, torch.Tensor) and x.dtype == dtype and x.device == self.device and x.is_contiguous():
+            return x   # the usual case in a rollout loop: no conversion, no extra launch
         if not isinstance(x, torch.Tensor):
             x = torch.as_tensor(np.asarray(x), dtype=dtype)
-        return x.to(device=self.device, dtype=dtype).contiguous()
+        bound = getattr(self, "_bound_stream", None)
+        if bound is None:
+            return x.to(device=self.device, dtype=dtype).contiguous()
+        if x.is_cuda:
+            bound.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(bound):   # the copy / cast is ordered before the kernel on the bound stream
+            return x.to(device=self.device, dtype=dtype).contiguous()
 
     @staticmethod
     def _p(t: Optional[torch.Tensor]):

@@ -30,6 +30,32 @@ struct DqnParams {
   double action_space[32];
 };
 
+// The batched EnvSampler's transition cache as the policy launches see it (mrx_cim_collect_steps): when `on`, the binning launch
+// retires the envs whose episode is over and the forward kernel APPENDS each deciding env's transition — its state row is in LDS
+// anyway — instead of a separate cache-update launch reading the state back from HBM (mrx_cim_sampler_record, whose semantics
+// these two pieces reproduce exactly; maro/rl/rollout/env_sampler.py:404-410, 484-511).  An env's cache is a ring of `cap` slots
+// (a power of two): element number q lives in slot q & (cap - 1); `last` holds element numbers (-1: none), `prev_j` the SLOT the
+// env's previous step wrote, `prev_active` whether that element still waits for its next_state.
+struct SamplerRec {
+  int on, cap, D, f64, A, P;
+  uint8_t* eoe;
+  const uint8_t* done;
+  long long *head, *last, *prev_j;
+  uint8_t* prev_active;
+  int32_t* c_tick;
+  long long* c_agent;
+  void* c_state;
+  long long* c_action;
+  int32_t* c_env_action;
+  uint8_t* c_terminal;
+  void *c_next_state, *c_nas;
+  long long* steps_env;
+};
+
+__device__ __forceinline__ void rec_store(void* base, size_t i, float v, int f64) {
+  if (f64) ((double*)base)[i] = (double)v; else ((float*)base)[i] = v;
+}
+
 // padded widths: a layer's outputs are split over the 4 waves in 16-column MFMA tiles
 __host__ __device__ inline int dq_npad(int n) { return n <= 16 ? 16 : n <= 32 ? 32 : (n + 63) / 64 * 64; }
 __host__ __device__ inline int dq_kpad(int k) { return (k + 15) / 16 * 16; }
@@ -151,7 +177,7 @@ __device__ __forceinline__ unsigned long long dq_mix64(unsigned long long seed, 
 extern "C" __global__ void __launch_bounds__(256)
 mrx_k_cim_dqn_bin(int n_envs, int P, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt, int32_t* __restrict__ lists,
                   int32_t* __restrict__ n_actions, unsigned long long* __restrict__ counter, const uint8_t* __restrict__ hint,
-                  int32_t* __restrict__ order, int32_t* __restrict__ sched, int sched_per) {
+                  int32_t* __restrict__ order, int32_t* __restrict__ sched, int sched_per, cim::SamplerRec R) {
   // sched_per > 0: the LAST workgroup builds the order list of the coming step instead (mrx_schedule_block, cim_engine.hip)
   if (sched_per > 0 && blockIdx.x == gridDim.x - 1) {
     mrx_schedule_block(hint, nullptr, 0, n_envs, sched_per & 0xffffff, order, sched, sched_per >> 24);
@@ -164,7 +190,24 @@ mrx_k_cim_dqn_bin(int n_envs, int P, const int32_t* __restrict__ decisions, int3
   int port = -1, rank = 0;
   if (e < n_envs) {
     const int32_t* d = decisions + (size_t)e * 8;
-    if (d[7] == 1 && (unsigned)d[1] < (unsigned)P) {
+    bool over = false;
+    if (R.on) {
+      // the sampler's end-of-episode bookkeeping (eoe |= done of the previous step), and the last element of an env whose episode
+      // just ended: its next state is its own state (AbsEnvSampler keeps `_state` unchanged by a final step).  One thread copies
+      // the row: it happens once per env and episode.
+      const bool was_over = R.eoe[e] != 0;
+      over = was_over || R.done[e] != 0;
+      if (over) {
+        if (!was_over) R.eoe[e] = 1;
+        if (R.prev_active[e]) {
+          const size_t row = ((size_t)e * R.cap + (size_t)R.prev_j[e]) * R.D;
+          if (R.f64) for (int k = 0; k < R.D; k++) ((double*)R.c_next_state)[row + k] = ((const double*)R.c_state)[row + k];
+          else for (int k = 0; k < R.D; k++) ((float*)R.c_next_state)[row + k] = ((const float*)R.c_state)[row + k];
+          R.prev_active[e] = 0;
+        }
+      }
+    }
+    if (!over && d[7] == 1 && (unsigned)d[1] < (unsigned)P) {
       port = d[1];
       rank = atomicAdd(&lcnt[port], 1);
     }
@@ -182,10 +225,11 @@ mrx_k_cim_dqn_bin(int n_envs, int P, const int32_t* __restrict__ decisions, int3
 extern "C" __global__ void __launch_bounds__(256)
 mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
                       const int32_t* __restrict__ lists, int32_t* __restrict__ actions, float* __restrict__ q_out,
-                      float* __restrict__ state_out, int32_t* __restrict__ choice_out) {
+                      float* __restrict__ state_out, int32_t* __restrict__ choice_out, cim::SamplerRec R) {
   using namespace cim;
   __shared__ __attribute__((aligned(16))) float X[DQ_TILE * DQ_LD];
   __shared__ int r_env[DQ_TILE], r_node[DQ_TILE][DQ_MAX_NODES], c_info[DQ_MAX_WIDTH], s_tile[3];
+  __shared__ int r_slot[DQ_TILE][3];   // transition cache (R.on): the row's new slot, the slot waiting for its next_state, the agent's previous slot
   __shared__ const int32_t* r_frame[DQ_TILE][DQ_MAX_TICKS];
   const int t = threadIdx.x;
 
@@ -238,6 +282,14 @@ mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__
       const int32_t* now = frame_of(K, env, d[0]);  // snapshots[tick : vessel : future_stop_list]
       r_node[t][0] = d[1];
       r_node[t][DQ_MAX_NODES - 1] = d[2];
+      if (R.on) {
+        const long long ring = (long long)R.cap - 1;
+        const int agent = d[1] < 0 ? 0 : (d[1] >= R.P ? R.P - 1 : d[1]);
+        const long long prev = R.last[(size_t)env * R.P + agent];
+        r_slot[t][0] = (int)(R.head[env] & ring);
+        r_slot[t][1] = R.prev_active[env] ? (int)R.prev_j[env] : -1;
+        r_slot[t][2] = prev >= 0 ? (int)(prev & ring) : -1;
+      }
       for (int j = 1; j < M.n_nodes; j++) r_node[t][j] = now ? stop_list_value(K, env, now, VA_FUTURE_STOP_LIST, d[2], j - 1) : 0;
     }
   }
@@ -286,6 +338,14 @@ mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__
     for (int r = 0; r < DQ_TILE; r++) {
       const float v = !((okm >> r) & 1) ? 0.f : is_f32 ? bits_f(raw[r]) : (float)raw[r];
       if (state_out && r_env[r] >= 0 && info >= 0) state_out[(size_t)r_env[r] * M.state_dim + t] = v;
+      if (R.on && r_env[r] >= 0 && info >= 0) {
+        // the transition's state row, the previous element's next state, the agent's previous element's next agent state:
+        // consecutive threads write consecutive words of each row
+        const size_t base = (size_t)r_env[r] * R.cap;
+        rec_store(R.c_state, (base + r_slot[r][0]) * R.D + t, v, R.f64);
+        if (r_slot[r][1] >= 0) rec_store(R.c_next_state, (base + r_slot[r][1]) * R.D + t, v, R.f64);
+        if (r_slot[r][2] >= 0) rec_store(R.c_nas, (base + r_slot[r][2]) * R.D + t, v, R.f64);
+      }
       X[r * DQ_LD + t] = v;
     }
   }
@@ -339,6 +399,22 @@ mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__
     a[1] = d[1];
     a[2] = (int32_t)qty;
     a[3] = is_load ? MRX_ACTION_LOAD : MRX_ACTION_DISCHARGE;
+    if (R.on) {   // the scalar half of the transition (mrx_k_cim_sampler_record's lane 0)
+      const int agent = d[1] < 0 ? 0 : (d[1] >= R.P ? R.P - 1 : d[1]);
+      const long long q = R.head[env];
+      const size_t base = (size_t)env * R.cap, ci = base + r_slot[t][0];
+      R.c_tick[ci] = d[0];
+      R.c_agent[ci] = agent;
+      R.c_action[ci] = best;
+      R.c_terminal[ci] = 0;
+      if (r_slot[t][2] >= 0) R.c_terminal[base + r_slot[t][2]] = 0;
+      R.c_env_action[ci * 4 + 0] = a[0]; R.c_env_action[ci * 4 + 1] = a[1]; R.c_env_action[ci * 4 + 2] = a[2]; R.c_env_action[ci * 4 + 3] = a[3];
+      R.last[(size_t)env * R.P + agent] = q;
+      R.head[env] = q + 1;
+      R.prev_j[env] = r_slot[t][0];
+      R.prev_active[env] = 1;
+      R.steps_env[env] += 1;
+    }
   }
 #ifdef MRX_DQN_PROFILE
   DQ_MARK();

@@ -109,6 +109,7 @@ mrx_k_cim_schedule(const uint8_t* __restrict__ hint, const uint8_t* __restrict__
 }
 
 #include "cim_dqn.h"   // (after the scheduler: mrx_k_cim_dqn_bin can carry the schedule block of the coming step)
+#include "cim_sampler.h"
 
 struct AttrList { int n; int32_t id[16]; };
 
@@ -953,8 +954,8 @@ int64_t mrx_cim_dqn_scratch_bytes(mrx_handle h) {
   return 4 * (128 + (long long)K.P * K.n_envs);  // counters + ticket, then one env list per port
 }
 
-int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_decisions, void* d_scratch, int32_t* d_actions,
-                    int32_t* d_n_actions, float* d_q, float* d_state, int32_t* d_choice, uint64_t* d_counter, void* stream) {
+static int dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_decisions, void* d_scratch, int32_t* d_actions,
+                   int32_t* d_n_actions, float* d_q, float* d_state, int32_t* d_choice, uint64_t* d_counter, const cim::SamplerRec& R, void* stream) {
   using namespace cim;
   if (!h || !m || !d_decisions || !d_scratch || !d_actions || !d_n_actions || !m->d_weights) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
   const CimParams& K = h->plan.kp;
@@ -992,11 +993,104 @@ int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_d
   const int sched_per = (fuse && effective_step_mode(h) >= 2) ? ((K.n_envs + 255) / 256 + 15) / 16 * 16 : 0;
   hipLaunchKernelGGL(mrx_k_cim_dqn_bin, dim3((unsigned)((K.n_envs + 255) / 256 + (sched_per > 0 ? 1 : 0))), dim3(256), 0, (hipStream_t)stream, K.n_envs, K.P,
                      d_decisions, cnt, lists, d_n_actions, (unsigned long long*)d_counter, (const uint8_t*)K.hint, K.order, K.sched,
-                     sched_per > 0 ? (sched_per | (h->lpt << 24)) : 0);
+                     sched_per > 0 ? (sched_per | (h->lpt << 24)) : 0, R);
   h->order_ready = sched_per > 0;
   h->order_stream = stream;
   hipLaunchKernelGGL(mrx_k_cim_dqn_forward, dim3((unsigned)dqn_max_tiles(K)), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, cnt, lists,
-                     d_actions, d_q, d_state, d_choice);
+                     d_actions, d_q, d_state, d_choice, R);
+  HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+int mrx_cim_dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_decisions, void* d_scratch, int32_t* d_actions,
+                    int32_t* d_n_actions, float* d_q, float* d_state, int32_t* d_choice, uint64_t* d_counter, void* stream) {
+  cim::SamplerRec off = {};
+  return dqn_act(h, m, d_decisions, d_scratch, d_actions, d_n_actions, d_q, d_state, d_choice, d_counter, off, stream);
+}
+
+// ---- the batched EnvSampler's cache as one argument block (mrx_cim_sampler_cache)
+static int sampler_rec(mrx_handle h, const mrx_cim_sampler_cache* c, const uint8_t* d_done, cim::SamplerRec* R) {
+  if (!h || !c) return set_err(MRX_ERR_INVALID_ARG, "null handle / cache");
+  const CimParams& K = h->plan.kp;
+  if (c->n_envs != K.n_envs || c->n_ports != K.P) return set_err(MRX_ERR_INVALID_ARG, "the cache was laid out for another engine (n_envs / n_ports differ)");
+  if (c->cap <= 0 || (c->cap & (c->cap - 1))) return set_err(MRX_ERR_INVALID_ARG, "cap (slots of an env's transition ring) must be a power of two");
+  if (c->state_dim <= 0 || !c->d_eoe || !c->d_head || !c->d_tail || !c->d_last || !c->d_prev_j || !c->d_prev_active || !c->d_interactions || !c->c_tick ||
+      !c->c_agent || !c->c_state || !c->c_action || !c->c_env_action || !c->c_terminal || !c->c_next_state || !c->c_next_agent_state || !d_done)
+    return set_err(MRX_ERR_INVALID_ARG, "null pointer in mrx_cim_sampler_cache");
+  *R = cim::SamplerRec{1, c->cap, c->state_dim, c->state_f64 ? 1 : 0, K.max_actions, K.P, c->d_eoe, d_done, (long long*)c->d_head, (long long*)c->d_last,
+                       (long long*)c->d_prev_j, c->d_prev_active, c->c_tick, (long long*)c->c_agent, c->c_state, (long long*)c->c_action, c->c_env_action,
+                       c->c_terminal, c->c_next_state, c->c_next_agent_state, (long long*)c->d_interactions};
+  return MRX_OK;
+}
+
+static int sampler_end(mrx_handle h, const mrx_cim_sampler_cache* c, const uint8_t* d_done, cim::SamplerEnd* E) {
+  int rc = sampler_rec(h, c, d_done, &E->R);
+  if (rc != MRX_OK) return rc;
+  if (c->window <= 0 || c->frames <= 0 || !c->d_decay || !c->d_port_history) return set_err(MRX_ERR_INVALID_ARG, "reward window / port history missing");
+  if (h->obs.hist != c->d_port_history || h->obs.hist_n != 2 || h->obs.hist_frames != c->frames || h->obs.hist_attr[0] != PA_FULFILLMENT || h->obs.hist_attr[1] != PA_SHORTAGE)
+    return set_err(MRX_ERR_INVALID_ARG, "d_port_history must be the engine's mrx_cim_set_port_history(fulfillment, shortage) buffer");
+  E->tail = (long long*)c->d_tail;
+  E->window = c->window; E->frames = c->frames;
+  E->ff = c->fulfillment_factor; E->sf = c->shortage_factor;
+  E->decay = c->d_decay;
+  E->hist = c->d_port_history;
+  return MRX_OK;
+}
+
+int mrx_cim_collect_steps(mrx_handle h, const mrx_cim_dqn_model* m, void* d_scratch, const mrx_cim_sampler_cache* cache, int32_t* d_actions,
+                          int32_t* d_n_actions, int32_t* d_decisions, int64_t* d_metrics, uint8_t* d_done, int32_t n_steps, void* stream) {
+  cim::SamplerRec R;
+  int rc = sampler_rec(h, cache, d_done, &R);
+  if (rc != MRX_OK) return rc;
+  if (n_steps < 0 || !d_decisions || !d_metrics || !d_actions || !d_n_actions) return set_err(MRX_ERR_INVALID_ARG, "null pointer / negative step count");
+  for (int k = 0; k < n_steps; k++) {
+    rc = dqn_act(h, m, d_decisions, d_scratch, d_actions, d_n_actions, nullptr, nullptr, nullptr, nullptr, R, stream);
+    if (rc != MRX_OK) return rc;
+    rc = launch_step(h, d_actions, d_n_actions, nullptr, nullptr, d_decisions, d_metrics, d_done, stream);   // (finished envs just report `done` again)
+    if (rc != MRX_OK) return rc;
+  }
+  return MRX_OK;
+}
+
+int mrx_cim_sampler_finalize(mrx_handle h, const mrx_cim_sampler_cache* cache, const uint8_t* d_done, int64_t* d_n_emit, int64_t* d_out_offset,
+                             int64_t* d_info, void* stream) {
+  cim::SamplerEnd E;
+  int rc = sampler_end(h, cache, d_done, &E);
+  if (rc != MRX_OK) return rc;
+  if (!d_n_emit || !d_out_offset || !d_info) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
+  rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  const CimParams& K = h->plan.kp;
+  hipLaunchKernelGGL(mrx_k_cim_sampler_finalize, dim3((unsigned)K.n_envs), dim3(64), 0, (hipStream_t)stream, K, E, (long long*)d_n_emit);
+  hipLaunchKernelGGL(mrx_k_cim_sampler_scan, dim3(1), dim3(1024), 0, (hipStream_t)stream, K.n_envs, (const long long*)d_n_emit, (const long long*)cache->d_head,
+                     (const long long*)cache->d_tail, (const uint8_t*)cache->d_eoe, (long long*)d_out_offset, (long long*)d_info);
+  HIP_TRY(hipGetLastError());
+  return MRX_OK;
+}
+
+int mrx_cim_sampler_emit_all(mrx_handle h, const mrx_cim_sampler_cache* cache, const int64_t* d_n_emit, const int64_t* d_out_offset, void* o_state,
+                             int64_t* o_action, int32_t* o_env_action, float* o_reward, void* o_next_state, void* o_next_agent_state,
+                             uint8_t* o_terminal, int32_t* o_env_id, int32_t* o_tick, int32_t* o_agent, void* stream) {
+  cim::SamplerEnd E;
+  static const uint8_t dummy_done = 0;   // (the emission does not read `done`: sampler_rec only wants a non-null pointer)
+  int rc = sampler_end(h, cache, &dummy_done, &E);
+  if (rc != MRX_OK) return rc;
+  if (!d_n_emit || !d_out_offset || !o_state || !o_action || !o_env_action || !o_reward || !o_next_state || !o_next_agent_state || !o_terminal || !o_env_id ||
+      !o_tick || !o_agent)
+    return set_err(MRX_ERR_INVALID_ARG, "null pointer");
+  rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  const CimParams& K = h->plan.kp;
+  // history rows staged per chunk: as many ticks as fit 48 KB (>= one reward window)
+  int rows_cap = (48 * 1024) / (2 * K.P * 4);
+  if (rows_cap < cache->window) return set_err(MRX_ERR_UNSUPPORTED, "reward window does not fit the emission kernel's LDS rows");
+  const size_t lds = (size_t)rows_cap * 2 * K.P * 4;
+#define MRX_EMIT_ALL(T)                                                                                                                              \
+  hipLaunchKernelGGL(mrx_k_cim_sampler_emit_all<T>, dim3((unsigned)K.n_envs), dim3(256), lds, (hipStream_t)stream, E, rows_cap, (const long long*)d_n_emit, \
+                     (const long long*)d_out_offset, (T*)o_state, (long long*)o_action, o_env_action, o_reward, (T*)o_next_state, (T*)o_next_agent_state,   \
+                     o_terminal, o_env_id, o_tick, o_agent)
+  if (cache->state_f64) MRX_EMIT_ALL(double); else MRX_EMIT_ALL(float);
+#undef MRX_EMIT_ALL
   HIP_TRY(hipGetLastError());
   return MRX_OK;
 }

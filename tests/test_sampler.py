@@ -355,3 +355,43 @@ def test_bench_collect_parity_helper_on_emulator():
             actions[:, 0, 2] += ((decisions[:, 0] % 7 == 0) & (actions[:, 0, 2] > 0)).to(torch.int32) * -1
     bad = replay_collect_against_oracle(smps, [Skewed(s) for s in smps], seeds_of, [0, 3], topo, k=2, num_steps=120, reset_every=8)
     assert not bad["ok"] and bad["first_mismatch"] is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_device_resident_collection_loop_equals_the_tensor_path(dtype):
+    """sample_fused with a FusedPerPortDQN actor runs the device-resident loop (mrx_cim_collect_steps: cache update folded into the
+    policy launches; mrx_cim_sampler_finalize / emit_all at the end of the call).  It must emit exactly what the per-step path
+    (act -> mrx_cim_sampler_record -> step, tensor-op finalisation: pinned to the reference sampler's goldens above) emits — every
+    field of every experience, call by call, through several episode roll-overs, cache growth and mid-call roll-over points."""
+    import os
+    from maro_amd.cim.engine import CimBatchEngine
+    from maro_amd.cim.policy import ACTION_SPACE, FusedPerPortDQN, random_chains
+    topo, n, dur, calls = "toy.5p_ssddd_l0.5", 61, 230, (25, 90, 7, 160, 33, 1, 120)
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["MRX_SAMPLER_V2"] = mode
+        try:
+            eng = CimBatchEngine(topo, n, durations=dur, max_actions=1, max_snapshots=16)
+            smp = CimBatchSampler(eng, time_window=40)
+            smp.INITIAL_CACHE_SLOTS = 32          # (forces the ring to grow between calls)
+            actor = FusedPerPortDQN(eng, random_chains(5, smp.state_dim, len(ACTION_SPACE), hidden=(48, 16), head_hidden=8, seed=3), epsilon=0.3)
+            seeds = lambda ep: 4000 + 17 * ep + torch.arange(n, dtype=torch.int64)   # noqa: E731
+            res[mode] = [smp.sample_fused(actor, num_steps=k, seeds=seeds, reset_every=8, state_dtype=dtype) for k in calls]
+            torch.cuda.synchronize()
+            assert int(eng.status.abs().sum()) == 0
+            res[mode + "steps"] = int(smp.interactions.item())
+        finally:
+            os.environ.pop("MRX_SAMPLER_V2", None)
+    assert res["1steps"] == res["0steps"] > 0
+    total = 0
+    for c, (a, b) in enumerate(zip(res["1"], res["0"])):
+        assert set(a) == set(b)
+        for key in b:
+            assert a[key].shape == b[key].shape and a[key].dtype == b[key].dtype, (c, key, a[key].shape, b[key].shape)
+            if key == "reward":
+                torch.testing.assert_close(a[key], b[key], rtol=1e-6, atol=1e-6)
+            else:
+                assert torch.equal(a[key], b[key]), (c, key)
+        total += int(b["tick"].shape[0])
+    assert total > 20000 and bool(torch.cat([r["terminal"] for r in res["1"]]).any())
