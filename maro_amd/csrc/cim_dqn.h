@@ -18,7 +18,7 @@
 
 namespace cim {
 
-enum { DQ_MAX_LAYERS = 8, DQ_MAX_WIDTH = 256, DQ_TILE = 32, DQ_LD = DQ_MAX_WIDTH + 4, DQ_MAX_TICKS = 16, DQ_MAX_NODES = 8, DQ_PF = 4 };
+enum { DQ_MAX_LAYERS = 8, DQ_MAX_WIDTH = 256, DQ_TILE_MAX = 32, DQ_LD = DQ_MAX_WIDTH + 4, DQ_MAX_TICKS = 16, DQ_MAX_NODES = 8, DQ_PF = 4 };
 
 struct DqnParams {
   int n_layers, dueling, state_dim, look_back, n_nodes, n_pa, n_va, n_actions;
@@ -148,16 +148,28 @@ __device__ __forceinline__ void dq_dense(float* X, const float* __restrict__ Wp,
   __syncthreads();
 }
 
-// A layer for the 32-row tile (two 16-row MFMA tiles): the output columns are dealt to the 4 waves in 16-column tiles.
+// A layer for the TILE-row tile (TILE / 16 MFMA row tiles): the output columns are dealt to the 4 waves in 16-column tiles.
+template <int TILE>
 __device__ __forceinline__ void dq_layer(float* X, const float* Wp, const float* bias, int Kpad, int Npad, bool act, float slope) {
   const int w = threadIdx.x >> 6;
-  switch (Npad) {
-    case 16: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, w & 1, 0, 1, w >= 2, act, slope); break;   // 2 tiles: waves 2, 3 idle
-    case 32: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, w >> 1, w & 1, 1, false, act, slope); break;
-    case 64: dq_dense<2, 1>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-    case 128: dq_dense<2, 2>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-    case 192: dq_dense<2, 3>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-    default: dq_dense<2, 4>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+  if constexpr (TILE == 32) {
+    switch (Npad) {
+      case 16: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, w & 1, 0, 1, w >= 2, act, slope); break;   // 2 tiles: waves 2, 3 idle
+      case 32: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, w >> 1, w & 1, 1, false, act, slope); break;
+      case 64: dq_dense<2, 1>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+      case 128: dq_dense<2, 2>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+      case 192: dq_dense<2, 3>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+      default: dq_dense<2, 4>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+    }
+  } else {   // 16 rows: one MFMA row tile — half the matrix work per workgroup, twice the workgroups (finer balance over the CUs)
+    switch (Npad) {
+      case 16: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, 0, 0, 1, w >= 1, act, slope); break;
+      case 32: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, 0, w & 1, 1, w >= 2, act, slope); break;
+      case 64: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+      case 128: dq_dense<1, 2>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+      case 192: dq_dense<1, 3>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+      default: dq_dense<1, 4>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+    }
   }
 }
 
@@ -222,10 +234,10 @@ mrx_k_cim_dqn_bin(int n_envs, int P, const int32_t* __restrict__ decisions, int3
   if (port >= 0) lists[(size_t)port * n_envs + base[port] + rank] = e;
 }
 
-extern "C" __global__ void __launch_bounds__(256)
-mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
-                      const int32_t* __restrict__ lists, int32_t* __restrict__ actions, float* __restrict__ q_out,
-                      float* __restrict__ state_out, int32_t* __restrict__ choice_out, cim::SamplerRec R) {
+template <int DQ_TILE>
+__device__ __forceinline__ void mrx_dqn_forward_body(const CimParams& K, const cim::DqnParams& M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
+                                                     const int32_t* __restrict__ lists, int32_t* __restrict__ actions, float* __restrict__ q_out,
+                                                     float* __restrict__ state_out, int32_t* __restrict__ choice_out, const cim::SamplerRec& R) {
   using namespace cim;
   __shared__ __attribute__((aligned(16))) float X[DQ_TILE * DQ_LD];
   __shared__ int r_env[DQ_TILE], r_node[DQ_TILE][DQ_MAX_NODES], c_info[DQ_MAX_WIDTH], s_tile[3];
@@ -355,7 +367,7 @@ mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__
   const float* net = M.weights + (size_t)port * M.net_floats;
   DQ_MARK();
   for (int l = 0; l < M.n_layers; l++) {
-    dq_layer(X, net + M.w_off[l], net + M.b_off[l], M.kpad[l], M.npad[l], l + 1 < M.n_layers, M.slope);
+    dq_layer<DQ_TILE>(X, net + M.w_off[l], net + M.b_off[l], M.kpad[l], M.npad[l], l + 1 < M.n_layers, M.slope);
     DQ_MARK();
   }
 
@@ -421,4 +433,19 @@ mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__
   if (t == 0 && q_out) for (int i = 0; i + 1 < tmi; i++) q_out[(size_t)blockIdx.x * 16 + i] = (float)(tm[i + 1] - tm[i]);  // overwrites q rows: profiling build only
 #endif
 #undef DQ_MARK
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
+                      const int32_t* __restrict__ lists, int32_t* __restrict__ actions, float* __restrict__ q_out,
+                      float* __restrict__ state_out, int32_t* __restrict__ choice_out, cim::SamplerRec R) {
+  mrx_dqn_forward_body<32>(K, M, decisions, cnt, lists, actions, q_out, state_out, choice_out, R);
+}
+
+// 16-env tiles: the same kernel with one MFMA row tile per workgroup
+extern "C" __global__ void __launch_bounds__(256)
+mrx_k_cim_dqn_forward16(CimParams K, cim::DqnParams M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
+                        const int32_t* __restrict__ lists, int32_t* __restrict__ actions, float* __restrict__ q_out,
+                        float* __restrict__ state_out, int32_t* __restrict__ choice_out, cim::SamplerRec R) {
+  mrx_dqn_forward_body<16>(K, M, decisions, cnt, lists, actions, q_out, state_out, choice_out, R);
 }

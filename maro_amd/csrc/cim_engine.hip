@@ -108,6 +108,9 @@ mrx_k_cim_schedule(const uint8_t* __restrict__ hint, const uint8_t* __restrict__
   mrx_schedule_block(hint, mask, mask_vec, n, per, order, sched, lpt);
 }
 
+#ifndef MRX_DQN_TILE_DEFAULT
+#define MRX_DQN_TILE_DEFAULT 32
+#endif
 #include "cim_dqn.h"   // (after the scheduler: mrx_k_cim_dqn_bin can carry the schedule block of the coming step)
 #include "cim_sampler.h"
 
@@ -946,7 +949,15 @@ int mrx_cim_dqn_pack_net(const mrx_cim_dqn_model* m, const float* const* weights
   return MRX_OK;
 }
 
-static long long dqn_max_tiles(const CimParams& K) { return ((long long)K.n_envs + cim::DQ_TILE - 1) / cim::DQ_TILE + K.P; }
+// rows of one forward workgroup's tile: 32 (two MFMA row tiles) or 16 (one: half the matrix work per workgroup and twice the
+// workgroups, i.e. a finer balance over the CUs when a launch has about as many 32-row tiles as the chip has CUs).  MRX_DQN_TILE
+// overrides the choice (experiments).
+static int dqn_tile_rows(const CimParams& K) {
+  static const int env_tile = getenv("MRX_DQN_TILE") ? atoi(getenv("MRX_DQN_TILE")) : 0;
+  if (env_tile == 16 || env_tile == 32) return env_tile;
+  return MRX_DQN_TILE_DEFAULT;
+}
+static long long dqn_max_tiles(const CimParams& K, int tile) { return ((long long)K.n_envs + tile - 1) / tile + K.P; }
 
 int64_t mrx_cim_dqn_scratch_bytes(mrx_handle h) {
   if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
@@ -996,8 +1007,13 @@ static int dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_de
                      sched_per > 0 ? (sched_per | (h->lpt << 24)) : 0, R);
   h->order_ready = sched_per > 0;
   h->order_stream = stream;
-  hipLaunchKernelGGL(mrx_k_cim_dqn_forward, dim3((unsigned)dqn_max_tiles(K)), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, cnt, lists,
-                     d_actions, d_q, d_state, d_choice, R);
+  const int tile = dqn_tile_rows(K);
+  if (tile == 16)
+    hipLaunchKernelGGL(mrx_k_cim_dqn_forward16, dim3((unsigned)dqn_max_tiles(K, 16)), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, cnt, lists,
+                       d_actions, d_q, d_state, d_choice, R);
+  else
+    hipLaunchKernelGGL(mrx_k_cim_dqn_forward, dim3((unsigned)dqn_max_tiles(K, 32)), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, cnt, lists,
+                       d_actions, d_q, d_state, d_choice, R);
   HIP_TRY(hipGetLastError());
   return MRX_OK;
 }
