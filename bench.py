@@ -201,6 +201,7 @@ def bench_citi_bike(args, dist, dev, rank, world):
     # deciding station + its filtered neighbours: what an agent can act on, 21 rows with the ny filter chain) — all 800 stations x
     # 7 attributes per env and step would be 45 KB of float64 per env-step, several times the simulation's own traffic
     scope_obs = S > 64
+    fused_obs = args.obs == "fused" and not scope_obs and not args.no_query
     cap = eng.layout.scope_cap
     stations = torch.arange(S, dtype=torch.int32, device=dev)
     for g, e in enumerate(engines):
@@ -210,7 +211,9 @@ def bench_citi_bike(args, dist, dev, rank, world):
         bufs.append(dict(actions=torch.zeros((ng, 1, 3), dtype=torch.int32, device=dev), n_actions=torch.zeros((ng,), dtype=torch.int32, device=dev),
                          counter=torch.zeros((1,), dtype=torch.int64, device=dev),
                          q_nodes=torch.empty((ng, cap), dtype=torch.int32, device=dev) if scope_obs else None,
-                         q_out=None if args.no_query else torch.empty((ng, 1, cap if scope_obs else S, len(q_attrs)), dtype=torch.float64, device=dev)))
+                         q_out=None if (args.no_query or fused_obs) else torch.empty((ng, 1, cap if scope_obs else S, len(q_attrs)), dtype=torch.float64, device=dev)))
+        if fused_obs:   # the same slice written by the step kernel itself (mrx_cb_set_observation): no query launch
+            bufs[-1]["obs"] = e.set_observation(q_attrs)
     torch.cuda.synchronize(dev)
     if G > 1:
         for e, st in zip(engines, streams):
@@ -327,7 +330,7 @@ def bench_citi_bike(args, dist, dev, rank, world):
         torch.cuda.synchronize(dev)
         eng.use_stream(None)      # (group 0's engine, on torch's current stream for the replay)
         parity = replay_citi_bike_against_oracle(eng, seeds[:sizes[0]], k=min(args.parity_envs, 8), steps=min(600, max(64, durations // 4)),
-                                                 obs_attrs=None if (args.no_query or scope_obs) else q_attrs)
+                                                 obs_attrs=None if (args.no_query or scope_obs) else q_attrs, obs_buf=bufs[0].get("obs"))
     gpu_s = time.perf_counter() - t_leg
     R = len(windows)
     t_max = torch.tensor([w[0] for w in windows] + [bounded[1] if bounded else 0.0], dtype=torch.float64, device=dev)
@@ -356,7 +359,7 @@ def bench_citi_bike(args, dist, dev, rank, world):
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32+f64", "data": "synthetic", "repeats": R, "value_min": min(vals), "value_max": max(vals), "gpu_seconds_total": gpu_s,
         "config": {"workload": f"citi_bike {topology}, {n} envs/GPU x {world} GPU, durations {durations}, resolution {res}, "
-                               f"device policy, stations snapshot slice {'off' if args.no_query else ('every step (stations of the action scope x 7 attrs)' if scope_obs else 'every step (all stations x 7 attrs)')}",
+                               f"device policy, stations snapshot slice {'off' if args.no_query else ('every step (stations of the action scope x 7 attrs, mrx_cb_query)' if scope_obs else ('every step (all stations x 7 attrs, ' + ('fused into the step kernel)' if fused_obs else 'mrx_cb_query)')))}",
                    "envs_per_gpu": n, "groups_per_gpu": G, "host_enqueue_ms_per_step": t_issued / args.steps * 1e3, "specialized_kernels": bool(eng.specialized), "code_object_key": code_key, "wave_cooperative_step": bool(eng.set_wave_decisions(0)),
                    "env_major_state": bool(eng.layout.env_major), "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective); {G} independent group(s) per GPU on separate HIP streams",
                    "trajectory_gather_ms_32_steps": gather_ms, "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad,
@@ -820,6 +823,7 @@ def main():
             # BASELINE.json configs[4]: CIM 22p + the maro.rl DQN EnvSampler loop, 8192 envs per GPU (65536 over 8 GPUs), on-device inference
             a5 = copy.copy(args)
             a5.policy, a5.collect, a5.envs, a5.ring, a5.no_episode = "dqn", True, 8192, max(args.ring, 8), True
+            a5.groups = 2    # (a latency-bound three-launch chain per group: measured 1 / 2 / 3 groups = 59 / 65 / 62 M at this size)
             a5.parity_envs = min(args.parity_envs, 6)
             r5 = bench_cim(a5, dist, dev, rank, world)
             if out is not None:

@@ -167,6 +167,16 @@ class CitiBikeBatchEngine:
         next decision report `decisions[e, 5] == 0` (and `done[e] == 0`) and continue in the next call.  0 = off."""
         _lib.check(self._L.mrx_cb_set_step_budget(self._h, int(max_records)), "mrx_cb_set_step_budget")
 
+    def set_observation(self, station_attrs: Sequence[str] = ()) -> Optional[torch.Tensor]:
+        """Fuse an agent's per-decision snapshot slice into step() (mrx_cb_set_observation): returns float64 [n_envs, S, len(attrs)],
+        rewritten by every step() with `query("stations", decisions[:, 3:4], all stations, station_attrs)` of each env's new decision
+        — the same values, without the extra launch.  () switches it off.  Plans stepped by the one-env-per-lane kernel only."""
+        ids = self.attr_ids("stations", station_attrs)
+        self.obs = torch.zeros((self.n_envs, self.data.n_stations, len(ids)), dtype=torch.float64, device=self.device) if ids else None
+        arr = (ctypes.c_int32 * max(len(ids), 1))(*ids)
+        _lib.check(self._L.mrx_cb_set_observation(self._h, arr, len(ids), self._p(self.obs)), "mrx_cb_set_observation")
+        return self.obs
+
     def step(self, actions=None, n_actions=None, mask=None):
         a = self._dev(actions, torch.int32)
         na = self._dev(n_actions, torch.int32)

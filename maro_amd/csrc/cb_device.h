@@ -1044,6 +1044,42 @@ MRX_DEV void reset_env(const CbParams& K, int e) {
   for (int w = 0; w < CB_LAND_SLOTS / 32; w++) BKT_MASK(w) = 0;
 }
 
+// Observation fused into the step (mrx_cb_set_observation): what `mrx_cb_query("stations", decision frame, every station, attrs)`
+// returns for the env's NEW decision — the decision's frame is the live frame (the pre-decision snapshot of core.py:345), so the
+// values come straight out of the state the step holds (its LDS column in the LDS-frame build) and the agent's per-step snapshot
+// slice costs no launch of its own.  Rows of an env without a valid decision (finished, or out of step budget) are zeros, like the
+// query's padding for frame index -1.
+MRX_DEV void write_observation(const CbParams& K, int e, const int32_t* dec) {
+  double* o = K.obs + (size_t)e * CD(S) * K.obs_n;
+  const bool valid = dec[5] != 0;
+  const int t = dec[0];
+  for (int a = 0; a < K.obs_n; a++) {
+    const int attr = K.obs_attr[a];
+    int lv = -1;
+    switch (attr) {
+      case SA_BIKES: lv = LV_BIKES; break;
+      case SA_SHORTAGE: lv = LV_SHORTAGE; break;
+      case SA_TRIP_REQUIREMENT: lv = LV_TRIP_REQUIREMENT; break;
+      case SA_FULFILLMENT: lv = LV_FULFILLMENT; break;
+      case SA_EXTRA_COST: lv = LV_EXTRA_COST; break;
+      case SA_TRANSFER_COST: lv = LV_TRANSFER_COST; break;
+      case SA_FAILED_RETURN: lv = LV_FAILED_RETURN; break;
+      case SA_MIN_BIKES: lv = LV_MIN_BIKES; break;
+      default: break;
+    }
+    for (int s = 0; s < CD(S); s++) {
+      double v = 0.0;
+      if (valid) {
+        if (lv >= 0) v = (double)LIVE((size_t)lv * CD(S) + s);
+        else if (attr == SA_CAPACITY) v = (double)K.capacity[s];
+        else if (attr == SA_ID) v = (double)K.station_id[s];
+        else v = (double)K.cal[(size_t)K.tick_day[t - CD(start_tick)] * 4 + (attr - SA_WEEKDAY)];
+      }
+      o[(size_t)s * K.obs_n + a] = v;
+    }
+  }
+}
+
 MRX_DEV int attr_slots(const CbParams& K, int node_type, int attr) {
   if (node_type == 0) return attr >= 0 && attr < SA_COUNT ? 1 : 0;
   return attr == CB_MA_TRIPS_ADJ ? CD(S) * CD(S) : 0;

@@ -219,6 +219,24 @@ int mrx_cb_set_step_budget(mrx_cb_handle h, int max_records) {
   return MRX_OK;
 }
 
+int mrx_cb_set_observation(mrx_cb_handle h, const int32_t* station_attrs, int n_attrs, double* d_obs) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  CbParams& K = h->plan.kp;
+  if (n_attrs < 0 || n_attrs > 8 || (n_attrs > 0 && (!station_attrs || !d_obs))) return set_err(MRX_ERR_INVALID_ARG, "at most 8 station attributes, with an output buffer");
+  if (n_attrs > 0 && K.decision_mode != 0) return set_err(MRX_ERR_UNSUPPORTED, "the fused observation is defined for Sequential decision mode");
+  if (n_attrs > 0 && cb_wave_on(h)) return set_err(MRX_ERR_UNSUPPORTED, "the fused observation is written by the one-env-per-lane step kernel (plans below 96 stations)");
+  for (int i = 0; i < n_attrs; i++) {
+    if (station_attrs[i] < 0 || station_attrs[i] >= SA_COUNT) return set_err(MRX_ERR_INVALID_ARG, "unknown station attribute id");
+    K.obs_attr[i] = station_attrs[i];
+  }
+  int rc = use_device(h->device);
+  if (rc != MRX_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());   // (steps may be in flight with the previous configuration)
+  K.obs_n = n_attrs;
+  K.obs = n_attrs > 0 ? d_obs : nullptr;
+  return MRX_OK;
+}
+
 int mrx_cb_destroy(mrx_cb_handle h) {
   delete h;
   return MRX_OK;

@@ -58,6 +58,10 @@ struct CbParams {
   int32_t* prof;        // [16] phase cycle counters (MRX_CB_PROFILE builds only)
   uint32_t* decmask;    // [2 * mask_words] stations with a pending Supply / Demand decision this tick
   uint8_t* todo;        // [n_envs] written by the wave-cooperative decision kernel (cb_wave.h): 1 = the general step must run for this env
+  // ---- observation fused into the step (mrx_cb_set_observation; runtime configuration, not part of a specialised plan):
+  // obs [n_envs][S][obs_n] float64 = snapshot_list["stations"][decision frame :: obs_attr] of the env's new decision
+  double* obs;
+  int32_t obs_n, obs_attr[8];
   // ---- shared tables (trips restricted to [start_tick, max_tick), re-indexed from 0)
   const int32_t* trip_off;  // [durations + 1] CSR offsets of the trips by tick (trips_adj bound of a frame)
   const int32_t* ev_rec;    // [n_events + 16][4] the event stream every env replays, see cb_layout.h

@@ -48,6 +48,7 @@ mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __
       if (na > CD(max_actions)) na = CD(max_actions);
       cb::step_env(K, e, actions ? actions + (size_t)e * CD(max_actions) * 3 : nullptr, na, nullptr, decisions + (size_t)e * 8,
                    scope + (size_t)e * CD(scope_cap) * 2, (int64_t*)metrics + (size_t)e * 3, done + e);
+      if (K.obs) cb::write_observation(K, e, decisions + (size_t)e * 8);
     } else {  // Joint modes: S rows per env
       const size_t S = (size_t)CD(S);
       int nans = (actions && n_answered) ? n_answered[e] : 0;

@@ -109,7 +109,7 @@ mrx_k_cim_schedule(const uint8_t* __restrict__ hint, const uint8_t* __restrict__
 }
 
 #ifndef MRX_DQN_TILE_DEFAULT
-#define MRX_DQN_TILE_DEFAULT 32
+#define MRX_DQN_TILE_DEFAULT 16   /* measured (profiles/r04_collect.md): 16-row tiles are faster at every batch size tried */
 #endif
 #include "cim_dqn.h"   // (after the scheduler: mrx_k_cim_dqn_bin can carry the schedule block of the coming step)
 #include "cim_sampler.h"

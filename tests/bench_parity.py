@@ -115,7 +115,7 @@ def replay_against_oracle(engines, bufs, streams, sizes, offs, seed_base, topolo
                     "(oracle/cim_oracle.c), one complete episode of the timed configuration"}
 
 
-def replay_citi_bike_against_oracle(eng, seeds, k=6, steps=600, obs_attrs=None, obs_every=16):
+def replay_citi_bike_against_oracle(eng, seeds, k=6, steps=600, obs_attrs=None, obs_every=16, obs_buf=None):
     """Parity of the citi_bike configuration bench.py times (BASELINE config 4): the SAME engine (plan-specialised kernels, batch size,
     ring) is reset and stepped `steps` times with the device policy while `k` sampled envs are recorded on the device; each is then
     replayed on the pure-Python oracle: every decision event, action scope, metric triple, done flag, the policy's action (against
@@ -143,8 +143,8 @@ def replay_citi_bike_against_oracle(eng, seeds, k=6, steps=600, obs_attrs=None, 
 
     def record(i):
         rec["dec"][i], rec["scope"][i], rec["met"][i], rec["done"][i] = eng.decisions[idx], eng.scope[idx], eng.metrics[idx], eng.done[idx]
-        if obs is not None and i % obs_every == 0:
-            obs[i // obs_every] = eng.query("stations", eng.decisions[:, 3:4], stations, obs_attrs)[idx, 0]
+        if obs is not None and i % obs_every == 0:   # the slice the bench loop reads: the fused buffer (mrx_cb_set_observation) or the query
+            obs[i // obs_every] = obs_buf[idx] if obs_buf is not None else eng.query("stations", eng.decisions[:, 3:4], stations, obs_attrs)[idx, 0]
     eng.step()
     record(0)
     for i in range(1, steps + 1):
