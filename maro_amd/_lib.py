@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmaro_amd.so")
+LIB_PATH = os.environ.get("MARO_AMD_LIB") or os.path.join(_HERE, "csrc", "libmaro_amd.so")   # ($MARO_AMD_LIB: profiling builds, tools/)
 
 
 class MrxCimConfig(ctypes.Structure):

@@ -102,7 +102,16 @@ static int32_t mrx_cb_lds_host[MRXC_lds_words]; /* host harness: one env at a ti
 #define LDS_FUL (LDS_CAP + MRXC_S)
 #define LDS_DMK (LDS_FUL + MRXC_w_words)
 #define LDS_SCR (LDS_DMK + 2 * MRXC_mask_words)
-#define LDS_HDR (LDS_SCR + 3 * MRXC_S)
+// The action scope's three work arrays: in the LDS column for the lane kernel's plans; env-major plans (the wave-cooperative
+// kernels, which rank the candidates in registers) keep them in HBM — only the scalar fallback of a station with more candidates
+// than the wave path takes uses them there — so that a wave's column is 3 S words (9.6 KB at 800 stations) smaller and more envs
+// are resident per CU.
+#if MRXC_aos
+#define LDS_SCR_WORDS 0
+#else
+#define LDS_SCR_WORDS (3 * MRXC_S)
+#endif
+#define LDS_HDR (LDS_SCR + LDS_SCR_WORDS)
 #define LDS_TWC (LDS_HDR + CH_WORDS)
 #if MRXC_ring_slots <= CB_TWC_LDS
 #define MRX_CB_TWC_LDS 1 /* the trip-window filter's (frame, tick) tag of every ring slot: read at every decision */
@@ -121,7 +130,11 @@ static_assert(LDS_TWC + LDS_TWC_WORDS + CB_EV_BLOCK * 4 == MRXC_lds_words, "cb_l
 #define CAP(s) LF(LDS_CAP + (s))
 #define FUL(i) (*(uint32_t*)&LF(LDS_FUL + (i)))
 #define DMK(i) (*(uint32_t*)&LF(LDS_DMK + (i)))
+#if MRXC_aos
+#define SCR(i) K.scratch[CB_IX(CD(aos), CD(stride), (3 * CD(S)), (i), e)]
+#else
 #define SCR(i) LF(LDS_SCR + (i))
+#endif
 #else
 #define HDR(w) hd[(w)] /* header word of the env being stepped: a register copy (step_env) */
 #define LIVE(w) K.live[CB_IX(CD(aos), CD(stride), CD(FW), (w), e)]

@@ -138,8 +138,8 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
     while (w < span) w *= 2;
     k.w_mask = w - 1; k.w_words = w / 32;
   }
-  k.lds_words = k.FW + S + k.w_words + 2 * k.mask_words + 3 * S + CH_WORDS + (k.ring_slots <= CB_TWC_LDS ? 2 * k.ring_slots : 0) +
-                CB_EV_BLOCK * 4;  // cb_device.h: LDS_CAP .. LDS_TWC + the event block
+  k.lds_words = k.FW + S + k.w_words + 2 * k.mask_words + (k.aos ? 0 : 3 * S) + CH_WORDS + (k.ring_slots <= CB_TWC_LDS ? 2 * k.ring_slots : 0) +
+                CB_EV_BLOCK * 4;  // cb_device.h: LDS_CAP .. LDS_TWC + the event block (env-major plans keep the scope scratch in HBM)
   std::vector<int32_t> tick_day(D), cal((size_t)std::max(t->n_days, 1) * 4, 0);
   for (int d = 0; d < D; d++) {
     tick_day[d] = t->tick_day[c->start_tick + d];
