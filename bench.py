@@ -154,7 +154,7 @@ def measured_bytes_citi_bike(topology, n, step_budget, code_key, groups=1):
     state = "no PMC entry of this topology / batch size / step budget"
     for ent in pmc.get("entries", []):
         if ent["topology"] == topology and ent["envs_per_launch"] == n and ent.get("step_budget", 0) == step_budget and ent.get("groups_per_gpu", 1) == groups:
-            if ent.get("code_object_key") is not None and ent.get("code_object_key") != code_key:
+            if ent.get("code_object_key") != code_key:
                 state = f"the PMC entry is of another build (code object {ent.get('code_object_key')}, running {code_key})"
                 continue
             return (2 * ent["fetch_size_kib"] + ent["write_size_kib"]) * 1024, \
@@ -350,7 +350,8 @@ def bench_citi_bike(args, dist, dev, rank, world):
     dt, resolved, ticks_adv = dts[med], res_w[med], tick_w[med]
     tbar = ticks_adv / max(resolved, 1.0)
     ms_per_step = dt / args.steps * 1e3
-    code_key = getattr(eng, "code_object_key", None)
+    from maro_amd import _lib as mrx_lib
+    code_key = f"{getattr(eng, 'code_object_key', None)}+{mrx_lib.source_hash()}"   # step kernels' code object + the library's sources (policy / query kernels)
     traffic, basis = measured_bytes_citi_bike(topology, n, args.step_budget, code_key, G)
     achieved = None if traffic is None else traffic / (ms_per_step * 1e-3) / 1e9     # per GPU: bytes of one batch step / its wall time
     out = {
@@ -715,7 +716,8 @@ def bench_collect(args, engines, streams, qnet, chains, n, G, dev, rank, world, 
         return None
     med = sorted(range(len(vals)), key=lambda i: vals[i])[len(vals) // 2]
     ms_per_step = dts[med] / args.steps * 1e3
-    code_key = getattr(engines[0], "code_object_key", None)
+    from maro_amd import _lib as mrx_lib
+    code_key = f"{getattr(engines[0], 'code_object_key', None)}+{mrx_lib.source_hash()}"   # step kernels' code object + the library's sources (DQN / sampler kernels)
     traffic, basis = measured_bytes_collect(n, G, code_key)
     achieved = None if traffic is None else traffic / (ms_per_step * 1e-3) / 1e9
     tf = DQN_FLOPS_PER_ENV * deciding / (act_ms * 1e-3) / 1e12

@@ -176,6 +176,27 @@ def load() -> ctypes.CDLL:
     return L
 
 
+_SRC_HASH = None
+
+
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the library's sources (maro_amd/csrc/*.h, *.hip, include/*.h): the identity of the kernels
+    that are NOT plan-specialised code objects (DQN forward, sampler kernels, queries ...).  bench.py stamps its lines with it and
+    only uses a PMC record of the same sources."""
+    global _SRC_HASH
+    if _SRC_HASH is None:
+        import hashlib
+        h = hashlib.sha256()
+        inc = os.path.join(os.path.dirname(_HERE), "include")
+        files = sorted(os.path.join(d, f) for d in (os.path.join(_HERE, "csrc"), inc) for f in os.listdir(d) if f.endswith((".h", ".hip")))
+        for f in files:
+            h.update(os.path.basename(f).encode())
+            with open(f, "rb") as fp:
+                h.update(fp.read())
+        _SRC_HASH = h.hexdigest()[:16]
+    return _SRC_HASH
+
+
 def check(rc: int, what: str):
     if rc < 0:
         msg = load().mrx_last_error().decode(errors="replace")

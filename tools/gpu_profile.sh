@@ -44,7 +44,7 @@ if [ "${COLLECT:-0}" = "1" ]; then
   rm -f $O/${tag}_collect.md $O/latest_pmc_collect.json
   for envs in ${COLLECT_ENVS:-8192}; do
     C=$O/collect_$envs; mkdir -p $C
-    CF="--policy dqn --collect --ring 8 --envs $envs --no-cpu --parity-envs 0"
+    CF="--policy dqn --collect --ring 8 --envs $envs --groups 2 --no-cpu --parity-envs 0"
     timeout 300 python bench.py $CF --steps 64 --warmup 16 > $C/bench_line.json 2> $C/bench_line.err; echo "collect $envs bench rc $?"
     timeout 300 rocprofv3 --kernel-trace --stats -d $C/trace -o r -- python bench.py $CF --steps 64 --warmup 16 --repeats 2 > $C/trace_line.json 2> $C/trace.err; echo "collect $envs trace rc $?"
     timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $C/fetch -o r -- python bench.py $CF --steps 64 --warmup 16 --repeats 1 > $C/fetch_line.json 2> $C/fetch.err; echo "collect $envs fetch rc $?"
