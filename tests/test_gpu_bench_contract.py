@@ -110,6 +110,31 @@ def test_bench_multi_rank_path_under_gloo(scenario, world):
         assert ge["bytes_per_rank"] == 16 * n * (8 * 4 + 4 * 4 + 3 * 8 + 1 + 22 * 7 * 4)
 
 
+def test_bench_default_command_on_two_ranks_under_gloo():
+    """The driver's N > 1 command as it is issued (`bench.py --gpus N --steps K --warmup W`, nothing else): the headline AND both
+    secondary legs run on every rank (barriers, max-over-ranks times, summed counts, the trajectory / experience gathers and the
+    policy broadcast of config 5), and rank 0 prints one line whose secondary values are whole-job aggregates."""
+    env = dict(os.environ, MRX_BENCH_BACKEND="gloo", MRX_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO, timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["envs_per_gpu"] == 16384 and len(j["ranks"]["env_steps"]) == 2
+    c4, c5 = j["secondary"]["citi_bike_config4"], j["secondary"]["collect_config5"]
+    assert c4["n_gpus"] == 2 and c4["config"]["envs_per_gpu"] == 4096 and c4["value"] > 1e6 and c4["config"]["trajectory_gather_ms_32_steps"] > 0
+    assert c5["n_gpus"] == 2 and c5["config"]["envs_per_gpu"] == 8192 and c5["value"] > 1e6
+    assert c5["config"]["experience_gather"]["experiences"] > 0 and c5["config"]["policy_broadcast"]["bytes"] > 1e6
+    assert c4["parity"]["ok"] is True and c5["parity"]["ok"] is True
+
+
 def test_bench_collect_multi_rank_path_under_gloo():
     """`bench.py --policy dqn --collect --gpus 2`: every rank runs the batched EnvSampler loop over its env shard, the value is the
     whole job's, and the learner-side collection (gather_experiences_to_learner) joins the ranks' experiences on rank 0."""

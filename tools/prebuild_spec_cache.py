@@ -92,7 +92,13 @@ def main(which="bench"):
             todo[("citi_bike", spec.plan_defines(ts, cfg, "citi_bike"))] = 1
     with ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as ex:
         sizes = list(ex.map(lambda d: len(spec.code_object(d[1], scenario=d[0]) if isinstance(d, tuple) else spec.code_object(d)), todo))
-    print(f"spec cache: {len(sizes)} plan(s) ready in {spec.CACHE}", file=sys.stderr)   # stderr: bench.py's stdout is one JSON line
+    # code objects older than the newest source they were compiled from can never be loaded again (the cache key hashes the
+    # sources): drop them, so that a repo snapshot ships the live plans only
+    newest = max(os.path.getmtime(os.path.join(spec.CSRC, f)) for unit in spec.UNITS.values() for f in unit[2])
+    stale = [f for f in os.listdir(spec.CACHE) if f.endswith(".hsaco") and os.path.getmtime(os.path.join(spec.CACHE, f)) < newest]
+    for f in stale:
+        os.remove(os.path.join(spec.CACHE, f))
+    print(f"spec cache: {len(sizes)} plan(s) ready in {spec.CACHE}" + (f" ({len(stale)} stale code object(s) removed)" if stale else ""), file=sys.stderr)   # stderr: bench.py's stdout is one JSON line
 
 
 if __name__ == "__main__":
