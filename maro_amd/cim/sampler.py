@@ -328,7 +328,8 @@ class CimBatchSampler:
         n, dev = eng.n_envs, eng.decisions.device
         seeds = _seed_fn(seeds, n)
         if eng.decisions.is_cuda and num_steps is not None and hasattr(actor, "collect_steps") and state_dtype in (torch.float32, torch.float64) \
-                and os.environ.get("MRX_SAMPLER_V2", "1") != "0":
+                and 8 * eng.layout.n_ports * self.time_window <= 48 * 1024 and os.environ.get("MRX_SAMPLER_V2", "1") != "0":
+            # (the emission kernel stages one reward window of an env's history rows in 48 KB of LDS: 2 x n_ports words per tick)
             # the device-resident form of this loop (same results): one C call per segment of interactions, the end of the call
             # (finalisation, emission) in three launches and one read-back
             return (yield from self._sample_fused_device(actor, num_steps, seeds, reset_every, state_dtype))

@@ -22,6 +22,7 @@ enum { DQ_MAX_LAYERS = 8, DQ_MAX_WIDTH = 256, DQ_TILE_MAX = 32, DQ_LD = DQ_MAX_W
 
 struct DqnParams {
   int n_layers, dueling, state_dim, look_back, n_nodes, n_pa, n_va, n_actions;
+  int xcd_runs;  // 1: XCD-aware tile order (launch configuration, set by the host)
   int pa[8], va[8];
   int kpad[DQ_MAX_LAYERS], npad[DQ_MAX_LAYERS], n_out[DQ_MAX_LAYERS];
   long long w_off[DQ_MAX_LAYERS], b_off[DQ_MAX_LAYERS], net_floats;
@@ -255,8 +256,18 @@ __device__ __forceinline__ void mrx_dqn_forward_body(const CimParams& K, const c
       if (t >= o) incl += up;
     }
     if (t == 0) s_tile[0] = -1;
-    const int b = (int)blockIdx.x - (incl - nt);
-    if (b >= 0 && b < nt) {  // exactly one lane matches (or none: more workgroups than tiles)
+    // XCD-aware tile order: the dispatcher places block i on XCD i % 8 (observed, MI355X_MICROARCH.md: a speed assumption only),
+    // and each XCD has its own 4 MB L2 while the 22 networks are 8 MB.  The tile list (port 0's tiles, port 1's ...) is cut into
+    // 8 equal runs and XCD x works through run x: an XCD then streams about three ports' weights (1 MB) instead of all of them,
+    // and every XCD gets the same number of tiles.  (M.xcd_runs = 0: block i takes tile i, the round-3 order.)
+    const int total = __shfl(incl, 63);
+    int tile_idx = (int)blockIdx.x;
+    if (M.xcd_runs) {
+      const int run = (total + 7) >> 3, x = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+      tile_idx = slot < run ? x * run + slot : total;   // (past the list: no tile)
+    }
+    const int b = tile_idx - (incl - nt);
+    if (tile_idx < total && b >= 0 && b < nt) {  // exactly one lane matches (or none: more workgroups than tiles)
       s_tile[0] = t;
       s_tile[1] = b * DQ_TILE;
       s_tile[2] = min(DQ_TILE, c - b * DQ_TILE);

@@ -957,7 +957,7 @@ static int dqn_tile_rows(const CimParams& K) {
   if (env_tile == 16 || env_tile == 32) return env_tile;
   return MRX_DQN_TILE_DEFAULT;
 }
-static long long dqn_max_tiles(const CimParams& K, int tile) { return ((long long)K.n_envs + tile - 1) / tile + K.P; }
+static long long dqn_max_tiles(const CimParams& K, int tile) { return (((long long)K.n_envs + tile - 1) / tile + K.P + 7) / 8 * 8 + 8; }  // (8 runs of ceil(tiles / 8) slots)
 
 int64_t mrx_cim_dqn_scratch_bytes(mrx_handle h) {
   if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
@@ -1008,6 +1008,8 @@ static int dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_de
   h->order_ready = sched_per > 0;
   h->order_stream = stream;
   const int tile = dqn_tile_rows(K);
+  static const bool xcd_runs = !(getenv("MRX_DQN_XCD") && atoi(getenv("MRX_DQN_XCD")) == 0);   // (0: block i takes tile i — experiments)
+  D.xcd_runs = xcd_runs ? 1 : 0;
   if (tile == 16)
     hipLaunchKernelGGL(mrx_k_cim_dqn_forward16, dim3((unsigned)dqn_max_tiles(K, 16)), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, cnt, lists,
                        d_actions, d_q, d_state, d_choice, R);
