@@ -201,7 +201,7 @@ def bench_citi_bike(args, dist, dev, rank, world):
     # deciding station + its filtered neighbours: what an agent can act on, 21 rows with the ny filter chain) — all 800 stations x
     # 7 attributes per env and step would be 45 KB of float64 per env-step, several times the simulation's own traffic
     scope_obs = S > 64
-    fused_obs = args.obs == "fused" and not scope_obs and not args.no_query
+    fused_obs = args.obs == "fused" and not args.no_query and (not scope_obs or bool(eng.specialized))   # (scope rows: the wave kernels of a specialised plan)
     cap = eng.layout.scope_cap
     stations = torch.arange(S, dtype=torch.int32, device=dev)
     for g, e in enumerate(engines):
@@ -330,7 +330,7 @@ def bench_citi_bike(args, dist, dev, rank, world):
         torch.cuda.synchronize(dev)
         eng.use_stream(None)      # (group 0's engine, on torch's current stream for the replay)
         parity = replay_citi_bike_against_oracle(eng, seeds[:sizes[0]], k=min(args.parity_envs, 8), steps=min(600, max(64, durations // 4)),
-                                                 obs_attrs=None if (args.no_query or scope_obs) else q_attrs, obs_buf=bufs[0].get("obs"))
+                                                 obs_attrs=None if args.no_query else q_attrs, obs_buf=bufs[0].get("obs"), scope_rows=scope_obs)
     gpu_s = time.perf_counter() - t_leg
     R = len(windows)
     t_max = torch.tensor([w[0] for w in windows] + [bounded[1] if bounded else 0.0], dtype=torch.float64, device=dev)
@@ -360,7 +360,7 @@ def bench_citi_bike(args, dist, dev, rank, world):
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32+f64", "data": "synthetic", "repeats": R, "value_min": min(vals), "value_max": max(vals), "gpu_seconds_total": gpu_s,
         "config": {"workload": f"citi_bike {topology}, {n} envs/GPU x {world} GPU, durations {durations}, resolution {res}, "
-                               f"device policy, stations snapshot slice {'off' if args.no_query else ('every step (stations of the action scope x 7 attrs, mrx_cb_query)' if scope_obs else ('every step (all stations x 7 attrs, ' + ('fused into the step kernel)' if fused_obs else 'mrx_cb_query)')))}",
+                               f"device policy, stations snapshot slice {'off' if args.no_query else ('every step (' + ('stations of the action scope' if scope_obs else 'all stations') + ' x 7 attrs, ' + ('fused into the step kernels)' if fused_obs else 'mrx_cb_query)'))}",
                    "envs_per_gpu": n, "groups_per_gpu": G, "host_enqueue_ms_per_step": t_issued / args.steps * 1e3, "specialized_kernels": bool(eng.specialized), "code_object_key": code_key, "wave_cooperative_step": bool(eng.set_wave_decisions(0)),
                    "env_major_state": bool(eng.layout.env_major), "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective); {G} independent group(s) per GPU on separate HIP streams",
                    "trajectory_gather_ms_32_steps": gather_ms, "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad,

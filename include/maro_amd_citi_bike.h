@@ -164,12 +164,16 @@ int mrx_cb_set_wave_decisions(mrx_cb_handle h, int mode);
 int mrx_cb_set_step_budget(mrx_cb_handle h, int max_records);
 
 /*
- * Fuse an agent's per-decision snapshot slice into mrx_cb_step: d_obs float64 [n_envs][S][n_attrs] is rewritten by every step with
- *   snapshot_list["stations"][frame_index of the env's new decision :: station_attrs]      (citi_bike/business_engine.py:101-147;
- * the slice an agent reads after Env.step, examples/citi_bike) — exactly what mrx_cb_query("stations", decisions[:, 3], all
- * stations, station_attrs) returns, without the extra launch: the decision's frame is the live frame the step kernel holds.  Rows
- * of envs without a valid decision (finished; out of step budget) are zeros.  Sequential decision mode, plans stepped by the
- * one-env-per-lane kernel (below 96 stations); n_attrs = 0 switches it off.
+ * Fuse an agent's per-decision snapshot slice into mrx_cb_step: d_obs float64 [n_envs][rows][n_attrs] is rewritten by every step with
+ *   snapshot_list["stations"][frame_index of the env's new decision : nodes : station_attrs]   (citi_bike/business_engine.py:101-147;
+ * the slice an agent reads after Env.step, examples/citi_bike) — exactly what mrx_cb_query("stations", decisions[:, 3], nodes,
+ * station_attrs) returns, without the extra launch: the decision's frame is the live frame the step kernel holds.
+ *   plans stepped one env per LANE (below 96 stations): rows = S, nodes = every station;
+ *   plans stepped by the wave-cooperative kernels (mrx_cb_layout.env_major; needs the plan-specialised kernels): rows = scope_cap,
+ *   nodes = the stations of the decision's action scope, d_scope[e][i][0] (the deciding station and its filtered neighbours: what an
+ *   agent can act on; -1 padding rows are zeros) — at 800 stations the full slice would be 45 KB of float64 per env-step.
+ * Rows of envs without a valid decision (finished; out of step budget) are zeros.  Sequential decision mode; n_attrs = 0 switches
+ * it off.
  */
 int mrx_cb_set_observation(mrx_cb_handle h, const int32_t* station_attrs, int n_attrs, double* d_obs);
 

@@ -168,11 +168,14 @@ class CitiBikeBatchEngine:
         _lib.check(self._L.mrx_cb_set_step_budget(self._h, int(max_records)), "mrx_cb_set_step_budget")
 
     def set_observation(self, station_attrs: Sequence[str] = ()) -> Optional[torch.Tensor]:
-        """Fuse an agent's per-decision snapshot slice into step() (mrx_cb_set_observation): returns float64 [n_envs, S, len(attrs)],
-        rewritten by every step() with `query("stations", decisions[:, 3:4], all stations, station_attrs)` of each env's new decision
-        — the same values, without the extra launch.  () switches it off.  Plans stepped by the one-env-per-lane kernel only."""
+        """Fuse an agent's per-decision snapshot slice into step() (mrx_cb_set_observation): returns float64 [n_envs, rows, len(attrs)],
+        rewritten by every step() for each env's new decision — the same values as a `query("stations", decisions[:, 3:4], nodes, attrs)`,
+        without the extra launch.  Plans stepped one env per lane: rows = every station.  Plans stepped by the wave-cooperative kernels
+        (`layout.env_major`, plan-specialised): rows = the `scope_cap` stations of the decision's action scope, `scope[:, :, 0]`
+        (-1 padding: zeros).  () switches it off."""
         ids = self.attr_ids("stations", station_attrs)
-        self.obs = torch.zeros((self.n_envs, self.data.n_stations, len(ids)), dtype=torch.float64, device=self.device) if ids else None
+        rows = self.layout.scope_cap if self.set_wave_decisions(0) else self.data.n_stations
+        self.obs = torch.zeros((self.n_envs, rows, len(ids)), dtype=torch.float64, device=self.device) if ids else None
         arr = (ctypes.c_int32 * max(len(ids), 1))(*ids)
         _lib.check(self._L.mrx_cb_set_observation(self._h, arr, len(ids), self._p(self.obs)), "mrx_cb_set_observation")
         return self.obs

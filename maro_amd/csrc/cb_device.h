@@ -774,6 +774,34 @@ MRX_DEV int cbw_candidates(const CbParams& K, int s, int* nf0) {
 }
 
 // can scope_wave evaluate (s, t)?  At most CBW_MAX candidates, at most 64 frames in a trip window.
+// The wave kernels' form of the fused observation (env-major plans): row i of an env = the station of row i of the decision's ACTION
+// SCOPE (the deciding station and its filtered neighbours — what an agent can act on; -1 padding and envs without a decision: zeros),
+// i.e. what mrx_cb_query("stations", decision frame, scope[:, :, 0], attrs) returns.  live(lv, station) reads the env's current state.
+template <class LV>
+MRX_DEV void write_scope_observation_row(const CbParams& K, int e, int i, int st, int t, LV live) {
+  double* o = K.obs + ((size_t)e * CD(scope_cap) + (size_t)i) * K.obs_n;
+  for (int a = 0; a < K.obs_n; a++) {
+    const int attr = K.obs_attr[a];
+    double v = 0.0;
+    if (st >= 0 && st < CD(S)) {
+      switch (attr) {
+        case SA_BIKES: v = (double)live(LV_BIKES, st); break;
+        case SA_SHORTAGE: v = (double)live(LV_SHORTAGE, st); break;
+        case SA_TRIP_REQUIREMENT: v = (double)live(LV_TRIP_REQUIREMENT, st); break;
+        case SA_FULFILLMENT: v = (double)live(LV_FULFILLMENT, st); break;
+        case SA_EXTRA_COST: v = (double)live(LV_EXTRA_COST, st); break;
+        case SA_TRANSFER_COST: v = (double)live(LV_TRANSFER_COST, st); break;
+        case SA_FAILED_RETURN: v = (double)live(LV_FAILED_RETURN, st); break;
+        case SA_MIN_BIKES: v = (double)live(LV_MIN_BIKES, st); break;
+        case SA_CAPACITY: v = (double)K.capacity[st]; break;
+        case SA_ID: v = (double)K.station_id[st]; break;
+        default: v = (double)K.cal[(size_t)K.tick_day[t - CD(start_tick)] * 4 + (attr - SA_WEEKDAY)]; break;
+      }
+    }
+    o[a] = v;
+  }
+}
+
 MRX_DEV bool scope_wave_ok(const CbParams& K, int s, int t) {
   int nf0;
   if (cbw_candidates(K, s, &nf0) > CBW_MAX) return false;
@@ -790,8 +818,9 @@ MRX_DEV bool scope_wave_ok(const CbParams& K, int s, int t) {
 // BikeDecisionStrategy.action_scope (decision_strategy.py:253-293) of station s at tick t, across the lanes of a wave: the same
 // values, order and cache side effects as cb::action_scope above.  bikes(station) = the env's current bikes; tag_get(slot, &fi,
 // &tick) / tag_set(slot, fi, tick) = the trip-window filter's per-slot cache words.  Writes `out`, returns the number of rows.
-template <class BK, class TG, class TS>
-MRX_DEV int scope_wave(const CbParams& K, int s, int type, int t, int32_t* scr, int32_t* out, BK bikes, TG tag_get, TS tag_set) {
+// row(i, station) is called by the lane that writes scope row i (the fused observation of the wave kernels hooks in there).
+template <class BK, class TG, class TS, class RW>
+MRX_DEV int scope_wave(const CbParams& K, int s, int type, int t, int32_t* scr, int32_t* out, BK bikes, TG tag_get, TS tag_set, RW row) {
   const int lane = wave::lane();
   const int S = CD(S);
   int nf0;
@@ -847,14 +876,15 @@ MRX_DEV int scope_wave(const CbParams& K, int s, int type, int t, int32_t* scr, 
 #pragma unroll
   for (int a = 0; a < 2; a++) {
     const int i = a * 64 + lane;
-    if (i < n) { out[2 * i] = key[a]; out[2 * i + 1] = val[a]; }
+    if (i < n) { out[2 * i] = key[a]; out[2 * i + 1] = val[a]; row(i, key[a]); }
   }
   const int bs = bikes(s);
   if (lane == 0) {
     out[2 * n] = s;
     out[2 * n + 1] = type == MRX_CB_SUPPLY ? (int)floor((double)bs * K.scope_low_keep) : K.capacity[s] - bs;
+    row(n, s);
   }
-  for (int i = n + 1 + lane; i < CD(scope_cap); i += 64) { out[2 * i] = -1; out[2 * i + 1] = -1; }
+  for (int i = n + 1 + lane; i < CD(scope_cap); i += 64) { out[2 * i] = -1; out[2 * i + 1] = -1; row(i, -1); }
   return n + 1;
 }
 
@@ -1000,14 +1030,19 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
                          [&](int st) { return LW(LV_BIKES * S + st); },
 #ifdef MRX_CB_TWC_LDS
                          [&](int slot, int* fi, int* tk) { *fi = LW(LDS_TWC + slot); *tk = LW(LDS_TWC + MRXC_ring_slots + slot); },
-                         [&](int slot, int fi, int tk) { LW(LDS_TWC + slot) = fi; LW(LDS_TWC + MRXC_ring_slots + slot) = tk; });
+                         [&](int slot, int fi, int tk) { LW(LDS_TWC + slot) = fi; LW(LDS_TWC + MRXC_ring_slots + slot) = tk; },
 #else
                          [&](int slot, int* fi, int* tk) { *fi = K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)]; *tk = K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)]; },
-                         [&](int slot, int fi, int tk) { K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] = fi; K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] = tk; });
+                         [&](int slot, int fi, int tk) { K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] = fi; K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] = tk; },
 #endif
+                         [&](int i, int st) { if (K.obs) write_scope_observation_row(K, e, i, st, t, [&](int lv, int s2) { return LW(lv * S + s2); }); });
       } else {
         Prof P;
-        if (lane == 0) ctl[0] = action_scope(K, e, hd, dec_s, dec_type, t, scope, P);
+        if (lane == 0) {
+          ctl[0] = action_scope(K, e, hd, dec_s, dec_type, t, scope, P);
+          if (K.obs)   // (scalar fallback: the lane that wrote the scope rows reads them back)
+            for (int i = 0; i < CD(scope_cap); i++) write_scope_observation_row(K, e, i, scope[2 * i], t, [&](int lv, int s2) { return LW(lv * S + s2); });
+        }
         wave::sync();
         cnt = ctl[0];
       }
@@ -1032,7 +1067,10 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
   }
   if (finished || !(flags & CFL_PENDING)) {  // episode over, or (step budget) no decision reached yet
     if (lane == 0) { dec[0] = t; dec[1] = -1; dec[2] = -1; dec[3] = (t - CD(start_tick)) / CD(res); dec[4] = 0; dec[5] = 0; dec[6] = 0; dec[7] = 0; }
-    for (int i = lane; i < CD(scope_cap); i += 64) { scope[2 * i] = -1; scope[2 * i + 1] = -1; }
+    for (int i = lane; i < CD(scope_cap); i += 64) {
+      scope[2 * i] = -1; scope[2 * i + 1] = -1;
+      if (K.obs) write_scope_observation_row(K, e, i, -1, t, [&](int, int) { return 0; });
+    }
   }
   if (lane == 0) {
     met[0] = LW(LDS_HDR + CH_TRIPS); met[1] = LW(LDS_HDR + CH_SHORT); met[2] = LW(LDS_HDR + CH_OPER);

@@ -224,7 +224,9 @@ int mrx_cb_set_observation(mrx_cb_handle h, const int32_t* station_attrs, int n_
   CbParams& K = h->plan.kp;
   if (n_attrs < 0 || n_attrs > 8 || (n_attrs > 0 && (!station_attrs || !d_obs))) return set_err(MRX_ERR_INVALID_ARG, "at most 8 station attributes, with an output buffer");
   if (n_attrs > 0 && K.decision_mode != 0) return set_err(MRX_ERR_UNSUPPORTED, "the fused observation is defined for Sequential decision mode");
-  if (n_attrs > 0 && cb_wave_on(h)) return set_err(MRX_ERR_UNSUPPORTED, "the fused observation is written by the one-env-per-lane step kernel (plans below 96 stations)");
+  // (plans stepped one env per lane: rows = every station; plans stepped by the wave kernels: rows = the stations of the action scope)
+  if (n_attrs > 0 && cb_wave_on(h) && !(h->spec_replay && (int64_t)K.lds_words * 4 <= MRX_CB_LDS_BYTES))
+    return set_err(MRX_ERR_UNSUPPORTED, "on wave-stepped plans the fused observation needs the plan-specialised kernels (mrx_cb_load_step_kernels)");
   for (int i = 0; i < n_attrs; i++) {
     if (station_attrs[i] < 0 || station_attrs[i] >= SA_COUNT) return set_err(MRX_ERR_INVALID_ARG, "unknown station attribute id");
     K.obs_attr[i] = station_attrs[i];

@@ -56,18 +56,18 @@ MRX_DEV bool decision_step_wave(const CbParams& K, int e, const int32_t* actions
   int status = 0, tt_pos = wave::bcast(h, CH_TT_POS), tail = wave::bcast(h, CH_POOL_TAIL), minland = wave::bcast(h, CH_POOL_MINLAND),
       late = wave::bcast(h, CH_LATE);
   const int head = wave::bcast(h, CH_POOL_HEAD);
-  int patch_s = -1, patch_b = 0;  // the one station whose bikes this step changed (the scope below must see the new value)
+  int patch_s = -1, patch_b = 0, patch_min = 0;  // the one station whose bikes (and min_bikes) this step changed (the scope below must see the new values)
   if (n_actions == 1) {
     const int frm = actions[0], to = actions[1], number = actions[2];
     if (frm >= 0 && to >= 0) {
       if (frm >= S || to >= S) {
         status |= MRX_CB_ENV_INVALID_ACTION;
       } else {
-        const int b = W_ST(LV_BIKES, frm);
+        const int b = W_ST(LV_BIKES, frm), mb = W_ST(LV_MIN_BIKES, frm);
         wave::sync();  // every lane has read the station's bikes before lane 0 overwrites them below
         const int ex = b < number ? b : number;
         if (ex > 0) {
-          patch_s = frm; patch_b = b - ex;
+          patch_s = frm; patch_b = b - ex; patch_min = b - ex < mb ? b - ex : mb;
           if (lane == 0) {  // station.py:71-75
             W_ST(LV_BIKES, frm) = b - ex;
             if (b - ex < W_ST(LV_MIN_BIKES, frm)) W_ST(LV_MIN_BIKES, frm) = b - ex;
@@ -114,7 +114,11 @@ MRX_DEV bool decision_step_wave(const CbParams& K, int e, const int32_t* actions
   const int n_rows = scope_wave(K, s1, type, t, scr, out,
                                 [&](int st) { return st == patch_s ? patch_b : W_ST(LV_BIKES, st); },
                                 [&](int slot, int* fi, int* tk) { *fi = K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)]; *tk = K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)]; },
-                                [&](int slot, int fi, int tk) { K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] = fi; K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] = tk; });
+                                [&](int slot, int fi, int tk) { K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] = fi; K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), slot, e)] = tk; },
+                                [&](int i, int st) {   // the fused observation's row i (mrx_cb_set_observation, scope rows)
+                                  if (K.obs) write_scope_observation_row(K, e, i, st, t, [&](int lv, int s2) {
+                                    return (s2 == patch_s && lv == LV_BIKES) ? patch_b : (s2 == patch_s && lv == LV_MIN_BIKES) ? patch_min : (int)W_ST(lv, s2); });
+                                });
   const int m0 = wave::bcast(h, CH_TRIPS), m1 = wave::bcast(h, CH_SHORT), m2 = wave::bcast(h, CH_OPER);
   if (lane == 0) {
     dec[0] = t; dec[1] = s1; dec[2] = type; dec[3] = fi_cur; dec[4] = n_rows; dec[5] = 1; dec[6] = 0; dec[7] = 0;

@@ -115,7 +115,7 @@ def replay_against_oracle(engines, bufs, streams, sizes, offs, seed_base, topolo
                     "(oracle/cim_oracle.c), one complete episode of the timed configuration"}
 
 
-def replay_citi_bike_against_oracle(eng, seeds, k=6, steps=600, obs_attrs=None, obs_every=16, obs_buf=None):
+def replay_citi_bike_against_oracle(eng, seeds, k=6, steps=600, obs_attrs=None, obs_every=16, obs_buf=None, scope_rows=False):
     """Parity of the citi_bike configuration bench.py times (BASELINE config 4): the SAME engine (plan-specialised kernels, batch size,
     ring) is reset and stepped `steps` times with the device policy while `k` sampled envs are recorded on the device; each is then
     replayed on the pure-Python oracle: every decision event, action scope, metric triple, done flag, the policy's action (against
@@ -133,8 +133,8 @@ def replay_citi_bike_against_oracle(eng, seeds, k=6, steps=600, obs_attrs=None, 
                met=torch.zeros((steps + 1, len(picks), 3), dtype=torch.int64, device=dev), done=torch.zeros((steps + 1, len(picks)), dtype=torch.uint8, device=dev),
                act=torch.zeros((steps + 1, len(picks), 3), dtype=torch.int32, device=dev), nact=torch.zeros((steps + 1, len(picks)), dtype=torch.int32, device=dev))
     obs = None
-    if obs_attrs:
-        obs = torch.zeros((steps // obs_every + 1, len(picks), S, len(obs_attrs)), dtype=torch.float64, device=dev)
+    if obs_attrs:   # rows: every station, or (scope_rows: city-size plans) the stations of the decision's action scope
+        obs = torch.zeros((steps // obs_every + 1, len(picks), cap if scope_rows else S, len(obs_attrs)), dtype=torch.float64, device=dev)
         stations = torch.arange(S, dtype=torch.int32, device=dev)
     actions = torch.zeros((n, 1, 3), dtype=torch.int32, device=dev)
     n_actions = torch.zeros((n,), dtype=torch.int32, device=dev)
@@ -144,7 +144,8 @@ def replay_citi_bike_against_oracle(eng, seeds, k=6, steps=600, obs_attrs=None, 
     def record(i):
         rec["dec"][i], rec["scope"][i], rec["met"][i], rec["done"][i] = eng.decisions[idx], eng.scope[idx], eng.metrics[idx], eng.done[idx]
         if obs is not None and i % obs_every == 0:   # the slice the bench loop reads: the fused buffer (mrx_cb_set_observation) or the query
-            obs[i // obs_every] = obs_buf[idx] if obs_buf is not None else eng.query("stations", eng.decisions[:, 3:4], stations, obs_attrs)[idx, 0]
+            nodes = eng.scope[:, :, 0].contiguous() if scope_rows else stations
+            obs[i // obs_every] = obs_buf[idx] if obs_buf is not None else eng.query("stations", eng.decisions[:, 3:4], nodes, obs_attrs)[idx, 0]
     eng.step()
     record(0)
     for i in range(1, steps + 1):
@@ -169,7 +170,13 @@ def replay_citi_bike_against_oracle(eng, seeds, k=6, steps=600, obs_attrs=None, 
                 ok = d[:6].tolist() == [de["tick"], de["station_idx"], de["type"], de["frame_index"], len(de["action_scope"]), 1] and \
                     [tuple(x) for x in sc[: d[4]].tolist()] == [tuple(x) for x in de["action_scope"]]
                 if ok and hobs is not None and i % obs_every == 0:
-                    ok = np.array_equal(hobs[i // obs_every, j].reshape(-1), o.query("stations", [de["frame_index"]], list(range(S)), list(obs_attrs)))
+                    if scope_rows:   # row r = station of scope row r; padding rows are zeros
+                        nodes = [x[0] for x in de["action_scope"]]
+                        want = np.zeros((cap, len(obs_attrs)))
+                        want[:len(nodes)] = o.query("stations", [de["frame_index"]], nodes, list(obs_attrs)).reshape(len(nodes), -1)
+                        ok = np.array_equal(hobs[i // obs_every, j], want)
+                    else:
+                        ok = np.array_equal(hobs[i // obs_every, j].reshape(-1), o.query("stations", [de["frame_index"]], list(range(S)), list(obs_attrs)))
                     obs_checks += 1
             if not ok:
                 first = first or dict(env=e, step=i, gpu=[d.tolist(), host["met"][i, j].tolist(), bool(host["done"][i, j])], oracle=[de, dict(m), od])

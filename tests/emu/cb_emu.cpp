@@ -56,6 +56,14 @@ void cb_emu_reset(void* h, const int32_t* tt, int n_times, const uint8_t* mask) 
 
 void cb_emu_set_step_budget(void* h, int max_records) { ((CbEmu*)h)->plan.kp.step_budget = max_records; }
 
+// mrx_cb_set_observation for the harness: rows = every station (lane path) or the stations of the action scope (wave path)
+void cb_emu_set_observation(void* h, const int32_t* attrs, int n, double* obs) {
+  CbParams& K = ((CbEmu*)h)->plan.kp;
+  for (int i = 0; i < n && i < 8; i++) K.obs_attr[i] = attrs[i];
+  K.obs_n = n;
+  K.obs = n > 0 ? obs : nullptr;
+}
+
 void cb_emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const uint8_t* mask, int32_t* dec, int32_t* scope,
                  int64_t* met, uint8_t* done) {
   CbEmu* e = (CbEmu*)h;
@@ -87,6 +95,7 @@ void cb_emu_step(void* h, const int32_t* actions, const int32_t* n_actions, cons
 #endif
     }
     cb::step_env(K, env, act, nac, nullptr, dec + (size_t)env * 8, scope + (size_t)env * K.scope_cap * 2, met + (size_t)env * 3, done + env);
+    if (K.obs && !e->wave_mode) cb::write_observation(K, env, dec + (size_t)env * 8);   // (what mrx_k_cb_step does after step_env)
   }
 }
 

@@ -64,6 +64,7 @@ def _declare(L):
     L.cb_emu_query.argtypes = [vp, i32, vp, i32, i32, vp, i32, i32, vp, i32, vp]
     L.cb_emu_random_policy.argtypes = [vp, vp, vp, ctypes.c_int64, vp, vp]
     L.cb_emu_set_wave_decisions.argtypes = [vp, i32, i32]
+    L.cb_emu_set_observation.argtypes = [vp, vp, i32, vp]
     L.cb_emu_wave_handled.restype = ctypes.c_long
     L.cb_emu_wave_handled.argtypes = [vp]
     L.cb_emu_wave_general.restype = ctypes.c_long
@@ -120,9 +121,18 @@ class CbEmuBackend:
         self._scope = np.zeros((n_envs,) + rows + (self.layout.scope_cap, 2), np.int32)
         self._met = np.zeros((n_envs, 3), np.int64)
         self._done = np.zeros(n_envs, np.uint8)
+        self._wave = int(wave_decisions)
         if wave_decisions:   # steps go through the wave-cooperative decision step first (cb_wave.h on the 64-fiber wave emulator);
             # 2 (specialised LDS-frame builds): the general step in its wave form as well (cb::step_env_wave)
             self._L.cb_emu_set_wave_decisions(ctypes.c_void_p(self._h), int(wave_decisions), int(reverse))
+
+    def set_observation(self, attr_ids):
+        """mrx_cb_set_observation: float64 [n, rows, len(ids)] written by every step (rows: S, or scope_cap on the wave path)."""
+        ids = np.ascontiguousarray(attr_ids, np.int32)
+        rows = self.layout.scope_cap if self._wave else self.data.n_stations
+        self.obs = np.zeros((self.n_envs, rows, len(ids)), np.float64)
+        self._L.cb_emu_set_observation(ctypes.c_void_p(self._h), _ptr(ids), len(ids), _ptr(self.obs))
+        return self.obs
 
     def wave_counts(self):
         """(env-steps handled by the wave-cooperative decision step, env-steps that went to the general path)"""

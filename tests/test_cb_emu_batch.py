@@ -101,3 +101,53 @@ def test_env_major_layout_on_a_small_topology(monkeypatch, specialized, wave):
     b = CbEmuBackend(data, n_envs=5, max_actions=1, specialized=specialized, wave_decisions=wave, **kwargs)
     assert b.layout.env_major == 1
     assert run_batch_vs_oracle(b, data, kwargs, seeds=np.arange(5) + 21, episodes=2) > 20
+
+
+@pytest.mark.parametrize("topology,specialized,wave", [("toy.5s_6t", False, 0), ("toy.5s_6t", True, 0), ("city.180s", True, 2)])
+def test_fused_observation_equals_the_query_on_the_emulator(topology, specialized, wave):
+    """mrx_cb_set_observation on the host-compiled device code: every station's row (lane path, generic and LDS-frame builds) or the
+    rows of the action scope's stations (wave-cooperative kernels, forward and reverse lane order) equal the snapshot query of the
+    decision's frame at every step, with bounded steps on the way (rows of envs without a decision are zeros)."""
+    from maro_amd.citi_bike.abi import draw_transfer_times
+    from maro_amd.citi_bike.data import load_topology
+    from tests.emu.cb_emu import CbEmuBackend
+    data = load_topology(topology)
+    n, attrs = 3, [0, 1, 2, 3, 4, 10, 13, 6]      # bikes, shortage, trip_requirement, fulfillment, capacity, extra_cost, min_bikes, weekday
+    lv_row = {0: 0, 1: 1, 2: 2, 3: 3, 10: 4, 13: 7}    # station attribute id -> live-frame row (cb_params.h: SA_* -> LV_*)
+
+    def expected(be, e, nodes, t):
+        """The slice straight from the env's live frame in the workspace (the decision's frame IS the live frame) and the shared tables
+        — not through the harness's query, whose LDS-frame host build reads a static stand-in of the LDS column."""
+        live = be.view(be.layout.off_live, be.layout.frame_words)
+        S = data.n_stations
+        out = np.zeros((len(nodes), len(attrs)))
+        for r, st in enumerate(nodes):
+            if st < 0:
+                continue
+            for c, a in enumerate(attrs):
+                out[r, c] = live[lv_row[a] * S + st, e] if a in lv_row else data.capacity[st] if a == 4 else data.day_weekday[data.tick_day[t]]
+        return out
+    for reverse in ((False, True) if wave else (False,)):
+        be = CbEmuBackend(data, n, durations=260 if wave else 500, snapshot_resolution=10, max_snapshots=8, specialized=specialized, wave_decisions=wave, reverse=reverse)
+        be.reset(transfer_times=draw_transfer_times(data, np.arange(n) + 3, be.layout.transfer_times_cap))
+        obs = be.set_observation(attrs)
+        S, cap = data.n_stations, be.layout.scope_cap
+        dec, scope, met, done = be.step()
+        checked = 0
+        for budget in (0, 9):
+            be.set_step_budget(budget)
+            for i in range(1, 70 if wave else 120):
+                for e in range(n):
+                    valid = dec[e, 5] == 1 and not done[e]
+                    if not valid:
+                        assert not obs[e].any()
+                        continue
+                    nodes = scope[e, :, 0] if wave else np.arange(S)
+                    want = expected(be, e, nodes, int(dec[e, 0]))
+                    if not specialized:   # (generic build: the harness's query agrees as well)
+                        assert np.array_equal(want, be.query(0, dec[:, 3:4], np.broadcast_to(np.where(nodes < 0, S + 7, nodes), (n, len(nodes))).copy(), attrs, len(attrs))[e, 0])
+                    assert np.array_equal(obs[e], want), (topology, reverse, budget, i, e)
+                    checked += 1
+                a, na = be.random_policy(dec, scope, i)
+                dec, scope, met, done = be.step(a, na)
+        assert checked > 100

@@ -224,33 +224,35 @@ def test_city800_full_month_properties():
     assert (q[:, -1, :, 3].sum(-1) <= total0).all() and (q[:, -1, :, 3].sum(-1) > 0.5 * total0).all()   # the rest is on trips / in delivery
 
 
-@pytest.mark.parametrize("specialize", [False, True])
-def test_fused_observation_equals_the_query(specialize):
-    """mrx_cb_set_observation: the stations slice of every env's new decision, written by the step kernel itself, equals the
-    mrx_cb_query launch it replaces at every step — generic and LDS-frame (plan-specialised) kernels, with and without bounded
-    steps (rows of envs without a decision are zeros), through the end of the episode."""
+@pytest.mark.parametrize("topology,specialize", [("toy.5s_6t", False), ("toy.5s_6t", True), ("city.180s", True)])
+def test_fused_observation_equals_the_query(topology, specialize):
+    """mrx_cb_set_observation: the stations slice of every env's new decision, written by the step kernels themselves, equals the
+    mrx_cb_query launch it replaces at every step — every station's row on the one-env-per-lane kernels (generic and LDS-frame),
+    the rows of the action scope's stations on the wave-cooperative kernels (city.180s), with and without bounded steps (rows of envs
+    without a decision are zeros)."""
     import torch
     from maro_amd.citi_bike.engine import CitiBikeBatchEngine
     attrs = ["bikes", "shortage", "trip_requirement", "fulfillment", "capacity", "extra_cost", "min_bikes", "weekday"]
     n = 200
-    eng = CitiBikeBatchEngine("toy.5s_6t", n, durations=700, snapshot_resolution=10, max_snapshots=16, specialize=specialize, seeds=np.arange(n) + 5)
-    S = eng.data.n_stations
+    eng = CitiBikeBatchEngine(topology, n, durations=700, snapshot_resolution=10, max_snapshots=16, specialize=specialize, seeds=np.arange(n) + 5)
+    S, wave = eng.data.n_stations, eng.set_wave_decisions(0)
     obs = eng.set_observation(attrs)
+    assert obs.shape == (n, eng.layout.scope_cap if wave else S, len(attrs))
     stations = torch.arange(S, dtype=torch.int32, device=eng.device)
     a = torch.zeros((n, 1, 3), dtype=torch.int32, device=eng.device)
     na = torch.zeros(n, dtype=torch.int32, device=eng.device)
     eng.step()
-    steps = nonzero = 0
+    nonzero = 0
     for budget in (0, 7):
         eng.set_step_budget(budget)
         for i in range(1, 160):
-            want = eng.query("stations", eng.decisions[:, 3:4], stations, attrs)[:, 0]
+            nodes = eng.scope[:, :, 0].contiguous() if wave else stations      # (-1 padding reads as zeros: query semantics)
+            want = eng.query("stations", eng.decisions[:, 3:4], nodes, attrs)[:, 0]
             valid = (eng.decisions[:, 5] == 1) & (eng.done == 0)
             assert torch.equal(obs[valid], want[valid]), (budget, i)
             assert not bool(obs[~valid].any())
             nonzero += int(valid.sum())
             eng.random_policy(i, a, na)
             eng.step(a, na)
-            steps += 1
     assert nonzero > 10000 and int(eng.status.abs().sum()) == 0
     assert eng.set_observation(()) is None
