@@ -675,6 +675,8 @@ void cim_oracle_set_seed(cim_oracle* o, int64_t seed) { o->wrapper_random_seed =
 
 /* core.py:143-170 + business_engine.py:226-242 + cim_data_container_helpers.py:56-66 */
 void cim_oracle_reset(cim_oracle* o, int keep_seed) {
+  o->error &= ~1; /* the invalid-action flag describes ONE episode (the reference raises on the spot; the engine's per-env status word is
+                     rewritten by reset): without this a two-episode comparison differs on the flag alone — found by GPU fuzz seed 9099 */
   o->tick = o->start_tick; o->waiting_action = 0; o->finished = 0; o->stop_iteration = 0; o->pending0 = NULL;
   eb_reset(o);
   snapshots_reset(o);
