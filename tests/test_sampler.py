@@ -346,14 +346,14 @@ def test_bench_collect_parity_helper_on_emulator():
     smps = [CimBatchSampler(e) for e in engs]
     actors = [_Actor(s) for s in smps]
     seeds_of = [(lambda ep, g=g, n=e.n_envs: 500 + 13 * ep + torch.arange(n, dtype=torch.int64) + 10 * g) for g, e in enumerate(engs)]
-    rep = replay_collect_against_oracle(smps, actors, seeds_of, [0, 3], topo, k=4, num_steps=200, reset_every=8)
-    assert rep["ok"] and rep["envs_checked"] == 4 and rep["elements_checked"] == 800 and rep["rewards_checked"] > 100, rep
+    rep = replay_collect_against_oracle(smps, actors, seeds_of, [0, 3], topo, k=4, num_steps=140, reset_every=8)
+    assert rep["ok"] and rep["envs_checked"] == 4 and rep["elements_checked"] == 560 and rep["rewards_checked"] > 40, rep
 
     class Skewed(_Actor):      # a wrong translation (one container too many on every 7th tick) must be reported
         def act(self, actions, n_actions, decisions=None, state=None, choice=None):
             super().act(actions, n_actions, decisions=decisions, state=state, choice=choice)
             actions[:, 0, 2] += ((decisions[:, 0] % 7 == 0) & (actions[:, 0, 2] > 0)).to(torch.int32) * -1
-    bad = replay_collect_against_oracle(smps, [Skewed(s) for s in smps], seeds_of, [0, 3], topo, k=2, num_steps=120, reset_every=8)
+    bad = replay_collect_against_oracle(smps, [Skewed(s) for s in smps], seeds_of, [0, 3], topo, k=2, num_steps=60, reset_every=8)
     assert not bad["ok"] and bad["first_mismatch"] is not None
 
 
