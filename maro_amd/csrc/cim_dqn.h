@@ -182,31 +182,6 @@ __device__ __forceinline__ unsigned long long dq_mix64(unsigned long long seed, 
   return x;
 }
 
-// Everything the binning needs to know about one env, as every workgroup of the single-launch form computes it for itself: the
-// deciding port of its pending decision, or -1 (no valid decision, or — sampler on — an env whose episode is over).  `owner`
-// (workgroup 0 only) also performs the per-env side effects of the binning launch: n_actions, and the sampler's retirement of
-// envs whose episode just ended (eoe |= done; the last element's next state = its own state).
-__device__ __forceinline__ int dq_env_port(const int32_t* __restrict__ decisions, int e, int P, const SamplerRec& R, bool owner, int32_t* __restrict__ n_actions) {
-  const int32_t* d = decisions + (size_t)e * 8;
-  bool over = false;
-  if (R.on) {
-    const bool was_over = R.eoe[e] != 0;
-    over = was_over || R.done[e] != 0;
-    if (over && owner) {
-      if (!was_over) R.eoe[e] = 1;
-      if (R.prev_active[e]) {
-        const size_t row = ((size_t)e * R.cap + (size_t)R.prev_j[e]) * R.D;
-        if (R.f64) for (int k = 0; k < R.D; k++) ((double*)R.c_next_state)[row + k] = ((const double*)R.c_state)[row + k];
-        else for (int k = 0; k < R.D; k++) ((float*)R.c_next_state)[row + k] = ((const float*)R.c_state)[row + k];
-        R.prev_active[e] = 0;
-      }
-    }
-  }
-  const int port = (!over && d[7] == 1 && (unsigned)d[1] < (unsigned)P) ? d[1] : -1;
-  if (owner) n_actions[e] = port >= 0 ? 1 : 0;
-  return port;
-}
-
 }  // namespace cim
 
 // Bins the envs with a pending decision by deciding port: lists int32 [P][n_envs] (list p = the envs deciding for port p,
@@ -260,20 +235,11 @@ mrx_k_cim_dqn_bin(int n_envs, int P, const int32_t* __restrict__ decisions, int3
   if (port >= 0) lists[(size_t)port * n_envs + base[port] + rank] = e;
 }
 
-// FUSED = the single-launch form (mrx_k_cim_dqn_act16 / 32): no binning launch, no global lists or counters.  Every workgroup scans
-// the decisions of the whole engine itself — 16 B per env out of L2, a ballot per port and 64 envs — which gives it the per-port
-// counts (hence its own (port, tile)) and, in a second pass over its port's envs, the env ids of its tile, in an order every workgroup
-// agrees on (wave w of a workgroup owns the 64-env chunks w, w + 4, ...; ranks run wave by wave).  ~3 us of redundant work per
-// workgroup buys one launch and one launch gap (~14 us) per interaction.  Workgroup 0 owns the scan's side effects (n_actions, the
-// answered-decisions counter, the sampler's retirement of finished envs); the LAST workgroup builds the order list of the coming step
-// (mrx_schedule_block) as the binning launch used to.
-template <int DQ_TILE, bool FUSED>
+template <int DQ_TILE>
 __device__ __forceinline__ void mrx_dqn_forward_body(const CimParams& K, const cim::DqnParams& M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
                                                      const int32_t* __restrict__ lists, int32_t* __restrict__ actions, float* __restrict__ q_out,
-                                                     float* __restrict__ state_out, int32_t* __restrict__ choice_out, const cim::SamplerRec& R,
-                                                     int32_t* __restrict__ n_actions = nullptr, unsigned long long* __restrict__ counter = nullptr) {
+                                                     float* __restrict__ state_out, int32_t* __restrict__ choice_out, const cim::SamplerRec& R) {
   using namespace cim;
-  __shared__ int s_wcnt[4][64], s_list[DQ_TILE];
   __shared__ __attribute__((aligned(16))) float X[DQ_TILE * DQ_LD];
   __shared__ int r_env[DQ_TILE], r_node[DQ_TILE][DQ_MAX_NODES], c_info[DQ_MAX_WIDTH], s_tile[3];
   __shared__ int r_slot[DQ_TILE][3];   // transition cache (R.on): the row's new slot, the slot waiting for its next_state, the agent's previous slot
@@ -281,28 +247,8 @@ __device__ __forceinline__ void mrx_dqn_forward_body(const CimParams& K, const c
   const int t = threadIdx.x;
 
   // ---- which (port, tile) is this workgroup: prefix over the ports' tile counts (P <= 64: one wave)
-  if constexpr (FUSED) {   // pass 1: per-port counts of the whole engine, one ballot per port and 64-env chunk
-    const int w = t >> 6, lane = t & 63;
-    int acc = 0;
-    for (int c0 = w * 64; c0 < K.n_envs; c0 += 256) {
-      const int e = c0 + lane;
-      const int port = e < K.n_envs ? dq_env_port(decisions, e, K.P, R, blockIdx.x == 0, n_actions) : -1;
-      for (int p = 0; p < K.P; p++) {
-        const unsigned long long m = __ballot(port == p);
-        if (lane == p) acc += __popcll(m);
-      }
-    }
-    s_wcnt[w][lane] = acc;
-    __syncthreads();
-  }
   if (t < 64) {
-    int c;
-    if constexpr (FUSED) {
-      c = t < K.P ? s_wcnt[0][t] + s_wcnt[1][t] + s_wcnt[2][t] + s_wcnt[3][t] : 0;
-      if (blockIdx.x == 0 && counter && c > 0) atomicAdd(counter, (unsigned long long)c);
-    } else {
-      c = t < K.P ? cnt[t] : 0;
-    }
+    const int c = t < K.P ? cnt[t] : 0;
     const int nt = (c + DQ_TILE - 1) / DQ_TILE;
     int incl = nt;
     for (int o = 1; o < 64; o <<= 1) {
@@ -327,7 +273,7 @@ __device__ __forceinline__ void mrx_dqn_forward_body(const CimParams& K, const c
       s_tile[2] = min(DQ_TILE, c - b * DQ_TILE);
     }
     // every workgroup has now read the counters: the last one to say so clears them for the next call
-    if (!FUSED && t == 0) {
+    if (t == 0) {
       int32_t* done = cnt + 64;
       if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
         for (int p = 0; p < 64; p++) cnt[p] = 0;
@@ -340,21 +286,6 @@ __device__ __forceinline__ void mrx_dqn_forward_body(const CimParams& K, const c
   if (port < 0) return;
   const int rows = s_tile[2];
   const int32_t* list = lists + (size_t)port * K.n_envs + s_tile[1];
-  if constexpr (FUSED) {   // pass 2: the env ids of this tile = the port's envs of rank [s_tile[1], s_tile[1] + rows), wave-major order
-    const int w = t >> 6, lane = t & 63, lo = s_tile[1];
-    int running = 0;
-    for (int ww = 0; ww < w; ww++) running += s_wcnt[ww][port];
-    for (int c0 = w * 64; c0 < K.n_envs && running < lo + rows; c0 += 256) {   // (wave-uniform)
-      const int e = c0 + lane;
-      const bool mine = e < K.n_envs && dq_env_port(decisions, e, K.P, R, false, nullptr) == port;
-      const unsigned long long m = __ballot(mine);
-      const int r = running + __popcll(m & ((1ull << lane) - 1ull)) - lo;
-      if (mine && r >= 0 && r < rows) s_list[r] = e;
-      running += __popcll(m);
-    }
-    __syncthreads();
-    list = s_list;
-  }
   const int n_ticks = M.look_back - 1;
 #ifdef MRX_DQN_PROFILE
   long long tm[12]; int tmi = 0;
@@ -519,7 +450,7 @@ extern "C" __global__ void __launch_bounds__(256)
 mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
                       const int32_t* __restrict__ lists, int32_t* __restrict__ actions, float* __restrict__ q_out,
                       float* __restrict__ state_out, int32_t* __restrict__ choice_out, cim::SamplerRec R) {
-  mrx_dqn_forward_body<32, false>(K, M, decisions, cnt, lists, actions, q_out, state_out, choice_out, R);
+  mrx_dqn_forward_body<32>(K, M, decisions, cnt, lists, actions, q_out, state_out, choice_out, R);
 }
 
 // 16-env tiles: the same kernel with one MFMA row tile per workgroup
@@ -527,22 +458,5 @@ extern "C" __global__ void __launch_bounds__(256)
 mrx_k_cim_dqn_forward16(CimParams K, cim::DqnParams M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
                         const int32_t* __restrict__ lists, int32_t* __restrict__ actions, float* __restrict__ q_out,
                         float* __restrict__ state_out, int32_t* __restrict__ choice_out, cim::SamplerRec R) {
-  mrx_dqn_forward_body<16, false>(K, M, decisions, cnt, lists, actions, q_out, state_out, choice_out, R);
+  mrx_dqn_forward_body<16>(K, M, decisions, cnt, lists, actions, q_out, state_out, choice_out, R);
 }
-
-// The single-launch form of mrx_cim_dqn_act (binning folded into the forward kernel, see mrx_dqn_forward_body<.., true>): the last
-// workgroup of the grid builds the order list of the coming step when sched_per > 0.
-#define MRX_DQN_ACT_KERNEL(NAME, TILE)                                                                                              \
-  extern "C" __global__ void __launch_bounds__(256)                                                                                 \
-  NAME(CimParams K, cim::DqnParams M, const int32_t* __restrict__ decisions, int32_t* __restrict__ actions, int32_t* __restrict__ n_actions, \
-       float* __restrict__ q_out, float* __restrict__ state_out, int32_t* __restrict__ choice_out, unsigned long long* __restrict__ counter, \
-       int sched_per, cim::SamplerRec R) {                                                                                          \
-    if (sched_per > 0 && blockIdx.x == gridDim.x - 1) {                                                                             \
-      mrx_schedule_block((const uint8_t*)K.hint, nullptr, 0, K.n_envs, sched_per & 0xffffff, K.order, K.sched, sched_per >> 24);    \
-      return;                                                                                                                      \
-    }                                                                                                                              \
-    mrx_dqn_forward_body<TILE, true>(K, M, decisions, nullptr, nullptr, actions, q_out, state_out, choice_out, R, n_actions, counter); \
-  }
-MRX_DQN_ACT_KERNEL(mrx_k_cim_dqn_act16, 16)
-MRX_DQN_ACT_KERNEL(mrx_k_cim_dqn_act32, 32)
-#undef MRX_DQN_ACT_KERNEL

@@ -997,33 +997,19 @@ static int dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_de
   if (rc != MRX_OK) return rc;
   int32_t* cnt = (int32_t*)d_scratch;
   int32_t* lists = cnt + 128;
-  // as in mrx_cim_random_policy: with a sorted launch form one extra workgroup of the policy launch builds the order list of the
+  // as in mrx_cim_random_policy: with a sorted launch form one extra workgroup of the binning launch builds the order list of the
   // coming step (it only depends on the previous step's hints), so the mrx_cim_step that follows on this stream needs no
   // schedule kernel of its own
   static const bool fuse = !(getenv("MRX_CIM_FUSE_SCHEDULE") && atoi(getenv("MRX_CIM_FUSE_SCHEDULE")) == 0);
   const int sched_per = (fuse && effective_step_mode(h) >= 2) ? ((K.n_envs + 255) / 256 + 15) / 16 * 16 : 0;
-  const int tile = dqn_tile_rows(K);
-  static const bool xcd_runs = !(getenv("MRX_DQN_XCD") && atoi(getenv("MRX_DQN_XCD")) == 0);   // (0: block i takes tile i — experiments)
-  D.xcd_runs = xcd_runs ? 1 : 0;
-  // ONE launch (the binning folded into the forward kernel; MRX_DQN_FUSED_BIN=0: the two-launch form, binning kernel first)
-  static const bool one_launch = !(getenv("MRX_DQN_FUSED_BIN") && atoi(getenv("MRX_DQN_FUSED_BIN")) == 0);
-  h->order_ready = sched_per > 0;
-  h->order_stream = stream;
-  if (one_launch) {
-    const unsigned grid = (unsigned)dqn_max_tiles(K, tile) + (sched_per > 0 ? 1u : 0u);
-    const int sp = sched_per > 0 ? (sched_per | (h->lpt << 24)) : 0;
-    if (tile == 16)
-      hipLaunchKernelGGL(mrx_k_cim_dqn_act16, dim3(grid), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, d_actions, d_n_actions, d_q, d_state, d_choice,
-                         (unsigned long long*)d_counter, sp, R);
-    else
-      hipLaunchKernelGGL(mrx_k_cim_dqn_act32, dim3(grid), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, d_actions, d_n_actions, d_q, d_state, d_choice,
-                         (unsigned long long*)d_counter, sp, R);
-    HIP_TRY(hipGetLastError());
-    return MRX_OK;
-  }
   hipLaunchKernelGGL(mrx_k_cim_dqn_bin, dim3((unsigned)((K.n_envs + 255) / 256 + (sched_per > 0 ? 1 : 0))), dim3(256), 0, (hipStream_t)stream, K.n_envs, K.P,
                      d_decisions, cnt, lists, d_n_actions, (unsigned long long*)d_counter, (const uint8_t*)K.hint, K.order, K.sched,
                      sched_per > 0 ? (sched_per | (h->lpt << 24)) : 0, R);
+  h->order_ready = sched_per > 0;
+  h->order_stream = stream;
+  const int tile = dqn_tile_rows(K);
+  static const bool xcd_runs = !(getenv("MRX_DQN_XCD") && atoi(getenv("MRX_DQN_XCD")) == 0);   // (0: block i takes tile i — experiments)
+  D.xcd_runs = xcd_runs ? 1 : 0;
   if (tile == 16)
     hipLaunchKernelGGL(mrx_k_cim_dqn_forward16, dim3((unsigned)dqn_max_tiles(K, 16)), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, cnt, lists,
                        d_actions, d_q, d_state, d_choice, R);
