@@ -9,13 +9,19 @@ mrx_k_cim_reset(CimParams K, const long long* __restrict__ seed_cmd, const uint8
   cim::reset_env(K, env, lds, seed_cmd ? seed_cmd[env] : default_cmd);
 }
 
+// rows [r0, r1) of the order tables; workgroup w generates the envs w, w + gridDim.x, ... (grid = n_envs: one env per workgroup;
+// a smaller grid bounds the wave slots a background block takes while step kernels are running: mrx_cim_set_progressive_reset)
 extern "C" __global__ void __launch_bounds__(64)
-mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const uint8_t* __restrict__ mask, long long default_cmd) {
+mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const uint8_t* __restrict__ mask, long long default_cmd, int r0, int r1) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-  const int env = blockIdx.x;
-  if (mask && !mask[env]) return;
-  if ((seed_cmd ? seed_cmd[env] : default_cmd) == -1) return;  // reset(keep_seed=True): same seed, same table
-  cim::gen_order_table(K, env, lds);
+  cim::TableGen G;
+  bool staged = false;
+  for (int env = blockIdx.x; env < K.n_envs; env += gridDim.x) {
+    if (mask && !mask[env]) continue;
+    if ((seed_cmd ? seed_cmd[env] : default_cmd) == -1) continue;  // reset(keep_seed=True): same seed, same table
+    if (!staged) { cim::gen_table_setup(K, lds, G); staged = true; }
+    cim::gen_table_rows(K, G, env, r0, r1);
+  }
 }
 
 #ifndef MRX_STEP_WAVES
