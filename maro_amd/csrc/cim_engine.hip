@@ -154,6 +154,7 @@ __device__ __forceinline__ unsigned long long mrx_mix64(unsigned long long seed,
 extern "C" __global__ void __launch_bounds__(256)
 mrx_k_cim_random_policy(CimParams K, const int32_t* __restrict__ decisions, long long step, int32_t* __restrict__ actions,
                         int32_t* __restrict__ n_actions, unsigned long long* __restrict__ counter, int sched_per) {
+  __builtin_amdgcn_s_setprio(3);  // (a link of the step chain: ahead of background waves at the issue arbiter)
   if (sched_per > 0 && blockIdx.x == 0) {
     mrx_schedule_block((const uint8_t*)K.hint, nullptr, 0, K.n_envs, sched_per & 0xffffff, K.order, K.sched, sched_per >> 24);
     return;
@@ -543,6 +544,25 @@ int mrx_cim_set_progressive_reset(mrx_handle h, int32_t block_ticks, int32_t bac
   if (block_ticks > 0 && (D + block_ticks - 1) / block_ticks > MRX_TABLE_BLOCKS_MAX) block_ticks = (D + MRX_TABLE_BLOCKS_MAX - 1) / MRX_TABLE_BLOCKS_MAX;
   h->prog_block = block_ticks;
   h->prog_waves = background_workgroups;
+  if (block_ticks > 0 && K.tab_mt) {  // the side stream, events and buffers now: allocations synchronise the device, a reset must not
+    int rc = use_device(h->device);
+    if (rc != MRX_OK) return rc;
+    if (!h->side) {
+      int least = 0, greatest = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, least));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_reset, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_bounds, hipEventDisableTiming));
+      HIP_TRY(hipHostMalloc((void**)&h->need_host, sizeof(int32_t) * MRX_TABLE_BLOCKS_MAX, hipHostMallocDefault));
+      HIP_TRY(hipMalloc((void**)&h->cmd_copy, sizeof(int64_t) * (size_t)K.n_envs));
+    }
+    const int nb = (D + block_ticks - 1) / block_ticks;
+    while ((int)h->ev_block.size() < nb) {
+      hipEvent_t e = nullptr;
+      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      h->ev_block.push_back(e);
+    }
+  }
   return MRX_OK;
 }
 
@@ -565,22 +585,8 @@ int mrx_cim_reset(mrx_handle h, const int64_t* d_seed_cmd, const uint8_t* d_env_
   // In blocks behind the first steps: only a reset of the WHOLE batch in Sequential mode from tick 0 (the bound on the steps'
   // progress — cim::decision_bounds_env — and CimParams::rows_ready are per launch, not per env).
   const int nb = h->prog_block > 0 ? (D + h->prog_block - 1) / h->prog_block : 1;
-  const bool prog = table && nb > 1 && !d_env_mask && K.decision_mode == 0 && K.start_tick == 0 && K.tab_mt;
-  if (prog && !h->side) {
-    int least = 0, greatest = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, least));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_reset, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&h->ev_bounds, hipEventDisableTiming));
-    HIP_TRY(hipHostMalloc((void**)&h->need_host, sizeof(int32_t) * MRX_TABLE_BLOCKS_MAX, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void**)&h->cmd_copy, sizeof(int64_t) * (size_t)K.n_envs));
-  }
+  const bool prog = table && nb > 1 && !d_env_mask && K.decision_mode == 0 && K.start_tick == 0 && K.tab_mt && h->side && (int)h->ev_block.size() >= nb;
   if (prog) {
-    while ((int)h->ev_block.size() < nb) {
-      hipEvent_t e = nullptr;
-      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      h->ev_block.push_back(e);
-    }
     HIP_TRY(hipMemcpyAsync(h->cmd_copy, d_seed_cmd, sizeof(int64_t) * (size_t)K.n_envs, hipMemcpyDeviceToDevice, stream));
   }
   if (h->spec_module) {  // plan-specialised build of the reset kernel

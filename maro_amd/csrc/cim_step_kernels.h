@@ -41,6 +41,7 @@ mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const
   extern "C" __global__ void __launch_bounds__(64 * MRX_WG_WAVES, WAVES)                                                 \
   NAME(CimParams K, CimObs O, cim::StepBatch B, const uint8_t* __restrict__ mask, int sorted) {                          \
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];                                                       \
+    __builtin_amdgcn_s_setprio(3); /* ahead of background waves (order-table blocks of a progressive reset) at the issue arbiter */ \
     const int w = MRX_WG_WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;                        \
     const int slot = (int)blockIdx.x * MRX_WG_WAVES + w;                                                                \
     if (MRX_WG_WAVES > 1 && slot >= K.n_envs) return;                                                                   \
