@@ -778,9 +778,6 @@ def main():
                     "built by __graft_entry__.build() for the default workload, else ~3 s of hipcc at engine creation); 0: generic kernels")
     ap.add_argument("--ring", type=int, default=4, help="snapshot ring slots per env (max_snapshots)")
     ap.add_argument("--no-query", action="store_true", help="skip the per-step snapshot slice")
-    ap.add_argument("--table-block", type=int, default=128, help="end-to-end leg: the reset generates the order table in blocks of this many ticks behind the "
-                    "first steps (mrx_cim_set_progressive_reset); 0: the whole table before the first step")
-    ap.add_argument("--table-waves", type=int, default=512, help="... workgroups of a background block, per env group (0: one per env)")
     ap.add_argument("--no-episode", action="store_true", help="skip the end-to-end leg (reset + one full episode of the whole batch)")
     ap.add_argument("--parity-envs", type=int, default=64, help="envs replayed on the CPU oracle after the run (0: off)")
     ap.add_argument("--repeats", type=int, default=5, help="the timed window (exactly --steps steps between barrier + synchronize) is run this many "
@@ -1089,8 +1086,6 @@ def bench_cim(args, dist, dev, rank, world):
         # no batch-wide barrier between reset and the first step, so one group's order-table generation (VALU-bound, 7 KB of LDS
         # per env) runs under the other groups' step kernels (latency-bound).  The wall time of a synchronised whole-batch reset
         # is reported separately (config.reset_ms_whole_batch, measured at the start of the run).
-        for eng in engines:
-            eng.set_progressive_reset(args.table_block, args.table_waves)
         for g, eng in enumerate(engines):
             eng.reset(group_seeds(g))
         ep_reset_ms = None
@@ -1235,9 +1230,7 @@ def bench_cim(args, dist, dev, rank, world):
             ep_s = float(ep_t.item())
             out["value_end_to_end"] = ep_steps_all / ep_s
             out["end_to_end"] = {"definition": "env-steps of one COMPLETE episode of every env / wall time from the first reset launch until the slowest env is done (reset included)",
-                                 "env_steps": ep_steps_all, "seconds": ep_s, "reset_ms_synchronised": reset_ms, "reset": ("per group on its own stream; the order table in blocks of %d ticks on a low-priority side stream behind the first steps "
-                                           "(mrx_cim_set_progressive_reset, %d workgroups per background block and group)" % (args.table_block, args.table_waves)) if args.table_block > 0
-                                 else "per group on its own stream, the whole order table before the group's first step", "batch_steps": episode["batch_steps"],
+                                 "env_steps": ep_steps_all, "seconds": ep_s, "reset_ms_synchronised": reset_ms, "reset": "per group on its own stream, overlapped with the other groups' first steps", "batch_steps": episode["batch_steps"],
                                  "durations": engines[0].durations}
         if parity is not None:
             out["parity"] = parity

@@ -42,10 +42,8 @@ enum {
   MRX_ENV_INVALID_ACTION = 1, /* reference: AssertionError in _on_action_received,
                                  cim/business_engine.py:731,736 — action skipped */
   MRX_ENV_STOP_OVERFLOW = 2,  /* route unrolling exceeded max_stops (engine limit) */
-  MRX_ENV_OFFROUTE_ACTION = 32, /* an Action named a port that is not on the vessel's route: containers are moved
-                                   as in the reference but the vessel_plans[v,p] += period update is not representable */
-  MRX_ENV_TABLE_NOT_READY = 64  /* a step read a row of the order table that its launch was not ordered behind
-                                   (mrx_cim_set_progressive_reset): an engine fault, never expected — results invalid */
+  MRX_ENV_OFFROUTE_ACTION = 32 /* an Action named a port that is not on the vessel's route: containers are moved
+                                  as in the reference but the vessel_plans[v,p] += period update is not representable */
 };
 
 /* Action types, reference cim/common.py:18-22 (ActionType.LOAD / DISCHARGE). */
@@ -196,22 +194,6 @@ int mrx_cim_get_layout(mrx_handle h, mrx_cim_layout* out);
  * MT19937 seeding (sim_random.py:35-63) and frame initialisation all run on the device.
  */
 int mrx_cim_reset(mrx_handle h, const int64_t* d_seed_cmd, const uint8_t* d_env_mask, void* stream);
-
-/*
- * Env.reset overlapped with the first steps of the episode.  In `fixed` order mode a reset draws every order of the episode
- * (cim_data_container.py:309-398) into the order table — on global_trade.22p 11 ms per 5 461 envs, most of a reset.  With
- * block_ticks > 0, mrx_cim_reset of the WHOLE batch (d_env_mask NULL; Sequential mode, start_tick 0) generates the table in
- * blocks of block_ticks ticks on a low-priority stream of the engine, behind the reset kernel, and returns; block 0 on every
- * wave slot, the later ones on `background_workgroups` workgroups (0 = one per env) so that step kernels keep their slots.
- * Every step launch is ordered (hipStreamWaitEvent, no host wait) behind exactly the blocks it may read: the vessel schedule of
- * an episode is fixed by the reset and every step ends at the env's next arrival, so "step s stays below tick t" is known per
- * block right after the reset kernel (a 128-byte read-back: the FIRST step after such a reset waits on the host for it, i.e. for
- * the reset kernel).  Results are identical to a plain reset.  A masked reset, a reset in a Joint mode, or any later reset first
- * orders its stream behind the blocks still in flight.  Steps cannot be captured into a hipGraph while blocks are pending
- * (mrx_cim_table_blocks_pending: blocks the stepping stream has not been ordered behind yet).  block_ticks = 0: off (default).
- */
-int mrx_cim_set_progressive_reset(mrx_handle h, int32_t block_ticks, int32_t background_workgroups);
-int mrx_cim_table_blocks_pending(mrx_handle h);
 
 /*
  * Replaces Env.step(action) in Sequential decision mode (core.py:92-133, 317-381) for every

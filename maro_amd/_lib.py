@@ -54,7 +54,7 @@ class MrxCimSamplerCache(ctypes.Structure):
 
 
 EXPORTS = ("mrx_last_error", "mrx_version", "mrx_cim_workspace_bytes", "mrx_cim_create", "mrx_cim_destroy",
-           "mrx_cim_get_layout", "mrx_cim_reset", "mrx_cim_set_progressive_reset", "mrx_cim_table_blocks_pending", "mrx_cim_step", "mrx_cim_step_joint", "mrx_cim_query", "mrx_cim_attr_id",
+           "mrx_cim_get_layout", "mrx_cim_reset", "mrx_cim_step", "mrx_cim_step_joint", "mrx_cim_query", "mrx_cim_attr_id",
            "mrx_cim_attr_slots", "mrx_cim_random_policy", "mrx_cim_set_observation", "mrx_cim_set_step_mode", "mrx_cim_set_port_history", "mrx_cim_dqn_net_floats",
            "mrx_cim_dqn_pack_net", "mrx_cim_dqn_scratch_bytes", "mrx_cim_dqn_act", "mrx_cim_sampler_record", "mrx_cim_sampler_emit", "mrx_cim_collect_steps", "mrx_cim_sampler_finalize", "mrx_cim_sampler_emit_all", "mrx_cim_plan_defines", "mrx_cim_load_step_kernels", "mrx_cim_read_kernel_global",
            # include/maro_amd_citi_bike.h
@@ -95,10 +95,6 @@ def load() -> ctypes.CDLL:
     L.mrx_cim_get_layout.argtypes = [vp, vp]
     L.mrx_cim_reset.restype = i32
     L.mrx_cim_reset.argtypes = [vp, vp, vp, vp]
-    L.mrx_cim_set_progressive_reset.restype = i32
-    L.mrx_cim_set_progressive_reset.argtypes = [vp, i32, i32]
-    L.mrx_cim_table_blocks_pending.restype = i32
-    L.mrx_cim_table_blocks_pending.argtypes = [vp]
     L.mrx_cim_step.restype = i32
     L.mrx_cim_step.argtypes = [vp] * 8
     L.mrx_cim_step_joint.restype = i32

@@ -171,17 +171,6 @@ class CimBatchEngine:
         _lib.check(self._L.mrx_cim_reset(self._h, self._p(sc), self._p(mk), self._stream()), "mrx_cim_reset")
         self._keep = (sc, mk)
 
-    def set_progressive_reset(self, block_ticks: int = 128, background_workgroups: int = 1024) -> None:
-        """mrx_cim_set_progressive_reset: a whole-batch ``reset`` returns after the reset kernel; the episode's order table is
-        generated in blocks of `block_ticks` ticks on a low-priority stream of the engine while the first steps run, every step
-        launch ordered behind exactly the blocks it may read (same results as a plain reset).  `block_ticks` 0 turns it off."""
-        _lib.check(self._L.mrx_cim_set_progressive_reset(self._h, int(block_ticks), int(background_workgroups)), "mrx_cim_set_progressive_reset")
-
-    @property
-    def table_blocks_pending(self) -> int:
-        """Blocks of a progressive reset the stepping stream has not been ordered behind yet (0: the table is complete for it)."""
-        return _lib.check(self._L.mrx_cim_table_blocks_pending(self._h), "mrx_cim_table_blocks_pending")
-
     def step(self, actions=None, n_actions=None, mask=None, n_answered=None):
         """Sequential mode: decisions [n, 8].  Joint modes (decision_mode 1 / 2): decisions [n, V, 8], one row per pending
         event; `actions` is the flat list of the answered events' actions and `n_answered` (mode 2) how many events

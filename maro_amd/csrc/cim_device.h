@@ -812,25 +812,18 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
 // order_proportion[t] and the order_number stream alone (cim_data_container.py:309-398), so the whole episode is
 // drawn right after reset_env, in tick order, exactly as the reference would while stepping.  Runs as its own
 // kernel with a small LDS footprint (RNG state, generator scratch, tables: ~9 KB) so many envs are resident per CU.
-// A launch writes the rows [r0, r1) of its envs' tables: the whole episode at once, or — mrx_cim_set_progressive_reset — one
-// block of ticks, the order stream handed from block to block through CimParams::tab_mt / tab_idx.
-struct TableGen {
-  Lds L;
-  TickPf pf;
-};
-// once per workgroup: the env-independent tables
-MRX_DEV void gen_table_setup(const CimParams& K, int32_t* lds, TableGen& G) {
+MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {
   const int lane = wave::lane();
-  G.L = make_lds(K, lds);
-  Lds& L = G.L;
+  Lds L = make_lds(K, lds);
   L.mt_ord = (uint32_t*)(lds + KD(g_mt0));
   L.dsrc = (double*)(lds + KD(g_dsrc));
   L.dtgt = (double*)(lds + KD(g_dtgt));
   L.oq = lds + KD(g_oq);
   L.srcn = lds + KD(g_srcn);
   stage_tables(K, L, lds + KD(g_ctab));
-  G.pf = TickPf{};
-  tick_prefetch_static(K, G.pf, true);
+  copy_in_async((int32_t*)L.mt_ord, (const int32_t*)(K.mt + ((size_t)env * MTS_COUNT + MTS_ORDER) * MT_WORDS), MT_WORDS);
+  TickPf pf = {};
+  tick_prefetch_static(K, pf, true);
   // the source ratio tables into LDS: a global load inside the tick loop would wait (vmcnt) for the previous tick's
   // row stores every time
   {
@@ -838,30 +831,18 @@ MRX_DEV void gen_table_setup(const CimParams& K, int32_t* lds, TableGen& G) {
     if (lane < KD(P)) { sb[lane] = K.src_base[lane]; sb[KD(P) + lane] = K.src_noise[lane]; }
     L.tab.src_base = sb; L.tab.src_noise = sb + KD(P);
   }
-  wave::lds_dma_wait();
-  tick_prefetch_land(G.pf);  // no load may still be pending inside the tick loop (its wait would also drain the row stores)
-}
-// rows [r0, r1) of one env
-MRX_DEV void gen_table_rows(const CimParams& K, TableGen& G, int env, int r0, int r1) {
-  const int lane = wave::lane();
-  Lds& L = G.L;
-  const int D = KD(T) - KD(start_tick);
-  if (r1 > D) r1 = D;
-  if (r0 >= r1) return;
-  wave::sync();  // (a previous env of this workgroup: its stream has been stored)
-  copy_in_async((int32_t*)L.mt_ord, r0 == 0 ? (const int32_t*)(K.mt + ((size_t)env * MTS_COUNT + MTS_ORDER) * MT_WORDS)
-                                            : (const int32_t*)(K.tab_mt + (size_t)env * MT_WORDS), MT_WORDS);
   const int32_t* g_prop = K.order_prop + (size_t)env * KD(T);
-  int idx_ord = r0 == 0 ? MT_WORDS : K.tab_idx[env];  // r0 == 0: the stream as reset_env seeded it
-  idx_ord = wave::uniform(idx_ord);
+  const int D = KD(T) - KD(start_tick);
+  int idx_ord = MT_WORDS;  // the stream as reset_env seeded it
   wave::lds_dma_wait();
-  for (int t0 = r0; t0 < r1; t0 += 64) {
-    int mine = t0 + lane < r1 ? g_prop[KD(start_tick) + t0 + lane] : 0;  // 64 ticks of order_proportion per load
+  tick_prefetch_land(pf);  // no load may still be pending inside the tick loop (its wait would also drain the row stores)
+  for (int t0 = 0; t0 < D; t0 += 64) {
+    int mine = t0 + lane < D ? g_prop[KD(start_tick) + t0 + lane] : 0;  // 64 ticks of order_proportion per load
     wave::touch(mine);  // wait for it HERE: inside the tick loop the same wait would also drain the previous tick's row stores
-    const int n_here = r1 - t0 < 64 ? r1 - t0 : 64;
+    const int n_here = D - t0 < 64 ? D - t0 : 64;
     for (int j = 0; j < n_here; j++) {  // wave-uniform
       bool tw = false;
-      gen_orders(K, L, (long long)wave::bcast(mine, j), idx_ord, G.pf, tw);
+      gen_orders(K, L, (long long)wave::bcast(mine, j), idx_ord, pf, tw);
       wave::sync();
       const size_t e0 = (size_t)env * (size_t)K.orders_stride + (size_t)(t0 + j) * KD(NTP);
       if (KD(order_half)) {  // two uint16 quantities per lane and store (rows are multiples of 8 elements)
@@ -875,47 +856,6 @@ MRX_DEV void gen_table_rows(const CimParams& K, TableGen& G, int env, int r0, in
       }
       wave::sync();
     }
-  }
-  if (r1 < D) {  // the stream goes on in the env's next block
-    copy_words((int32_t*)(K.tab_mt + (size_t)env * MT_WORDS), (const int32_t*)L.mt_ord, MT_WORDS);
-    if (lane == 0) K.tab_idx[env] = idx_ord;
-  }
-}
-MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {  // the whole episode of one env
-  TableGen G;
-  gen_table_setup(K, lds, G);
-  gen_table_rows(K, G, env, 0, KD(T) - KD(start_tick));
-}
-
-// Which step of the episode may be the first to read a row of block b of the order table (rows [b * block, (b + 1) * block))?
-// Every arrival raises one decision event and every step of an env (Sequential mode) ends at its next decision event, so step s
-// of an env runs the ticks up to its s-th arrival: with c arrivals before tick b * block, the steps 1 .. c stay below that row and
-// step c + 1 is the first that may pass it.  The vessel schedule is fixed by reset_env (K.stops: actions do not move arrivals),
-// so the count is exact; a stop only counts while every leg before it took at least one tick (an arrival in the tick of the
-// departure is never raised — cim_device.h tick_prefetch — and the vessel stays put: counting less is the safe side).
-// One wave per env; need[b] = min over the envs of (c + 1), by atomic minimum.  start_tick == 0 only (the host checks).
-MRX_DEV void decision_bounds_env(const CimParams& K, int env, int block_ticks, int n_blocks) {
-  const int lane = wave::lane();
-  const int V = KD(V);
-  const uint32_t* st = K.stops + ((size_t)env * V + (lane < V ? lane : 0)) * KD(SMAX);
-  int good = 1;  // stops [1, good) raise decisions
-  if (lane < V) {
-    const int ns = K.nstops[(size_t)env * V + lane];
-    for (int k = 1; k < ns; k++) {
-      if (stop_arrival(st[k]) <= stop_arrival(st[k - 1]) + stop_parking(st[k - 1])) break;
-      good = k + 1;
-    }
-  }
-  for (int b = 1; b < n_blocks; b++) {
-    const int bound = b * block_ticks;
-    int c = 0;
-    if (lane < V) {  // arrivals ascend: the first stop in [1, good) at or after the bound
-      int lo = 1, hi = good;
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (stop_arrival(st[mid]) < bound) lo = mid + 1; else hi = mid; }
-      c = lo - 1;
-    }
-    const int tot = (int)wave::reduce_add((long long)c);
-    if (lane == 0) wave::global_min(&K.tab_need[b], tot + 1);
   }
 }
 
@@ -1719,7 +1659,6 @@ MRX_DEV bool body_open(const CimParams& K, int env, Lds& L, StepCtx& c, StepOut&
   const int tn = c.fresh ? c.t : c.t + 1;
   if (!pend_after && tn < KD(T)) {
     if constexpr (!PG) tick_prefetch_static(K, c.pf, true);
-    if constexpr (PG) { if (tn - KD(start_tick) >= K.rows_ready) c.status |= 64; }  // MRX_ENV_TABLE_NOT_READY
     tick_prefetch<PG>(K, env, L, tn, c.pf);
   }
   return true;
@@ -1795,7 +1734,6 @@ MRX_DEV StepEnd body_run(const CimParams& K, const CimObs& O, int env, Lds& L, c
     fresh = false;
     pend = run_tick<PG>(K, env, L, t, c.pf, c.idx_ord, c.idx_buf, c.status, prof, end.ord_dirty, end.buf_dirty, rr);
     if (!pend && t + 1 < KD(T)) {  // another tick follows: its inputs, landed before that tick's snapshot stores are issued
-      if constexpr (PG) { if (t + 1 - KD(start_tick) >= K.rows_ready) c.status |= 64; }  // MRX_ENV_TABLE_NOT_READY
       tick_prefetch<PG>(K, env, L, t + 1, c.pf);
       tick_prefetch_land(c.pf);
     }

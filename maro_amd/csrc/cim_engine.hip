@@ -108,14 +108,6 @@ mrx_k_cim_schedule(const uint8_t* __restrict__ hint, const uint8_t* __restrict__
   mrx_schedule_block(hint, mask, mask_vec, n, per, order, sched, lpt);
 }
 
-// first step of the episode that may read block b of the order table (cim::decision_bounds_env): one wave per env
-extern "C" __global__ void __launch_bounds__(256)
-mrx_k_cim_decision_bounds(CimParams K, int block_ticks, int n_blocks) {
-  const int env = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-  if (env >= K.n_envs) return;
-  cim::decision_bounds_env(K, env, block_ticks, n_blocks);
-}
-
 #ifndef MRX_DQN_TILE_DEFAULT
 #define MRX_DQN_TILE_DEFAULT 16   /* measured (profiles/r04_collect.md): 16-row tiles are faster at every batch size tried */
 #endif
@@ -154,7 +146,6 @@ __device__ __forceinline__ unsigned long long mrx_mix64(unsigned long long seed,
 extern "C" __global__ void __launch_bounds__(256)
 mrx_k_cim_random_policy(CimParams K, const int32_t* __restrict__ decisions, long long step, int32_t* __restrict__ actions,
                         int32_t* __restrict__ n_actions, unsigned long long* __restrict__ counter, int sched_per) {
-  __builtin_amdgcn_s_setprio(3);  // (a link of the step chain: ahead of background waves at the issue arbiter)
   if (sched_per > 0 && blockIdx.x == 0) {
     mrx_schedule_block((const uint8_t*)K.hint, nullptr, 0, K.n_envs, sched_per & 0xffffff, K.order, K.sched, sched_per >> 24);
     return;
@@ -341,26 +332,6 @@ struct mrx_cim_engine {
   bool order_ready = false;               // the order list of the coming step was built by the policy launch (no mask)
   int lpt = 1;                            // longest-first inside the full-path class of the sorted launch (MRX_CIM_LPT=0: off)
   void* order_stream = nullptr;           // ... on this stream: a step issued on another stream is not ordered behind that launch
-  // ---- order table in blocks of ticks behind the first steps of the episode (mrx_cim_set_progressive_reset)
-  int prog_block = 0, prog_waves = 0;     // ticks per block (0: off), workgroups of a background block
-  hipStream_t side = nullptr;             // low-priority stream of the blocks
-  hipEvent_t ev_reset = nullptr, ev_bounds = nullptr;
-  std::vector<hipEvent_t> ev_block;
-  int32_t* need_host = nullptr;           // pinned copy of CimParams::tab_need
-  int64_t* cmd_copy = nullptr;            // the reset's seed commands (the caller's buffer may be gone when the last block runs)
-  bool prog_active = false, prog_bounds = false;
-  int prog_nb = 0, prog_next = 0;         // blocks of the running generation; the first one the stepping stream has not waited for
-  long long prog_steps = 0;               // step launches since that reset
-  void release_progressive() {
-    if (side) { hipStreamSynchronize(side); hipStreamDestroy(side); side = nullptr; }
-    if (ev_reset) { hipEventDestroy(ev_reset); ev_reset = nullptr; }
-    if (ev_bounds) { hipEventDestroy(ev_bounds); ev_bounds = nullptr; }
-    for (auto e : ev_block) hipEventDestroy(e);
-    ev_block.clear();
-    if (need_host) { hipHostFree(need_host); need_host = nullptr; }
-    if (cmd_copy) { hipFree(cmd_copy); cmd_copy = nullptr; }
-    prog_active = false;
-  }
   // Kernels of a module may still be queued or running on the caller's stream(s): drain the device before unloading it.
   void unload_spec() {
     if (!spec_module) return;
@@ -376,7 +347,7 @@ struct mrx_cim_engine {
     loop_waves = 0;
     for (auto& f : spec_fn) f = nullptr;
   }
-  ~mrx_cim_engine() { release_progressive(); unload_spec(); }
+  ~mrx_cim_engine() { unload_spec(); }
 };
 
 static thread_local std::string g_err;
@@ -457,7 +428,7 @@ int mrx_cim_create(const mrx_cim_topology* topo, const mrx_cim_config* cfg, void
                      (long long)topo->seed);
   if (K.pregen && K.orders_stride)  // (real data files: the table is an input, uploaded with the constant tables)
     hipLaunchKernelGGL(mrx_k_cim_order_table, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_gen * 4, 0, K, nullptr, nullptr,
-                       (long long)topo->seed, 0, K.T - K.start_tick);
+                       (long long)topo->seed);
   he = hipDeviceSynchronize();
   if (he == hipSuccess) he = hipGetLastError();
   if (he != hipSuccess) { delete e; return set_err(MRX_ERR_HIP, std::string("initial reset kernel: ") + hipGetErrorString(he)); }
@@ -476,153 +447,29 @@ int mrx_cim_get_layout(mrx_handle h, mrx_cim_layout* out) {
   return MRX_OK;
 }
 
-// rows [r0, r1) of the order tables on `stream`, `grid` workgroups
-static int launch_table(mrx_handle h, const int64_t* d_seed_cmd, const uint8_t* d_env_mask, int r0, int r1, int grid, hipStream_t stream) {
-  const CimParams& K = h->plan.kp;
-  if (h->spec_module) {
-    CimParams Kc = K;
-    const long long* cmd = (const long long*)d_seed_cmd;
-    long long dflt = -1;
-    void* params[] = {&Kc, &cmd, &d_env_mask, &dflt, &r0, &r1};
-    HIP_TRY(hipModuleLaunchKernel(h->spec_order_table, (unsigned)grid, 1, 1, 64, 1, 1, (unsigned)((size_t)K.lds_words_gen * 4), stream, params, nullptr));
-    return MRX_OK;
-  }
-  hipLaunchKernelGGL(mrx_k_cim_order_table, dim3(grid), dim3(64), (size_t)K.lds_words_gen * 4, stream, K, (const long long*)d_seed_cmd, d_env_mask,
-                     (long long)-1, r0, r1);
-  HIP_TRY(hipGetLastError());
-  return MRX_OK;
-}
-
-// A progressive generation may still be running: `stream` waits for all of it (a reset rewrites the blocks' inputs; anything
-// that wants the whole table).
-static int table_drain(mrx_handle h, hipStream_t stream) {
-  if (!h->prog_active) return MRX_OK;
-  for (int b = h->prog_next; b < h->prog_nb; b++) HIP_TRY(hipStreamWaitEvent(stream, h->ev_block[b], 0));
-  h->prog_active = false;
-  h->plan.kp.rows_ready = 0x7fffffff;
-  return MRX_OK;
-}
-
-// Before a step launch on `stream`: the blocks of the order table this step may read are waited for (stream order, no host
-// wait), and CimParams::rows_ready of the launch says how far the table is complete.  The first step after the reset waits on the
-// HOST once, for the decision bounds (a 128-byte read-back that follows the reset kernel on the side stream).
-static int table_gate(mrx_handle h, hipStream_t stream) {
-  if (!h->prog_active) return MRX_OK;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-    return set_err(MRX_ERR_INVALID_ARG, "a progressive reset is still generating the order table: its steps cannot be captured into a graph "
-                                        "(step until mrx_cim_table_blocks_pending() is 0, or reset without mrx_cim_set_progressive_reset)");
-  const long long s = ++h->prog_steps;
-  const int D = h->plan.kp.T - h->plan.kp.start_tick;
-  if (h->prog_next == 0) {
-    HIP_TRY(hipStreamWaitEvent(stream, h->ev_block[0], 0));
-    h->prog_next = 1;
-  }
-  if (!h->prog_bounds) {
-    HIP_TRY(hipEventSynchronize(h->ev_bounds));
-    h->prog_bounds = true;
-  }
-  while (h->prog_next < h->prog_nb && (long long)h->need_host[h->prog_next] <= s) {
-    HIP_TRY(hipStreamWaitEvent(stream, h->ev_block[h->prog_next], 0));
-    h->prog_next++;
-  }
-  if (h->prog_next >= h->prog_nb) {
-    h->prog_active = false;
-    h->plan.kp.rows_ready = 0x7fffffff;
-  } else {
-    const long long rows = (long long)h->prog_next * h->prog_block;
-    h->plan.kp.rows_ready = rows < D ? (int)rows : 0x7fffffff;
-  }
-  return MRX_OK;
-}
-
-int mrx_cim_set_progressive_reset(mrx_handle h, int32_t block_ticks, int32_t background_workgroups) {
-  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
-  if (block_ticks < 0 || background_workgroups < 0) return set_err(MRX_ERR_INVALID_ARG, "block_ticks / background_workgroups must be >= 0");
-  const CimParams& K = h->plan.kp;
-  const int D = K.T - K.start_tick;
-  if (block_ticks > 0 && (D + block_ticks - 1) / block_ticks > MRX_TABLE_BLOCKS_MAX) block_ticks = (D + MRX_TABLE_BLOCKS_MAX - 1) / MRX_TABLE_BLOCKS_MAX;
-  h->prog_block = block_ticks;
-  h->prog_waves = background_workgroups;
-  if (block_ticks > 0 && K.tab_mt) {  // the side stream, events and buffers now: allocations synchronise the device, a reset must not
-    int rc = use_device(h->device);
-    if (rc != MRX_OK) return rc;
-    if (!h->side) {
-      int least = 0, greatest = 0;
-      HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, least));
-      HIP_TRY(hipEventCreateWithFlags(&h->ev_reset, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&h->ev_bounds, hipEventDisableTiming));
-      HIP_TRY(hipHostMalloc((void**)&h->need_host, sizeof(int32_t) * MRX_TABLE_BLOCKS_MAX, hipHostMallocDefault));
-      HIP_TRY(hipMalloc((void**)&h->cmd_copy, sizeof(int64_t) * (size_t)K.n_envs));
-    }
-    const int nb = (D + block_ticks - 1) / block_ticks;
-    while ((int)h->ev_block.size() < nb) {
-      hipEvent_t e = nullptr;
-      HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      h->ev_block.push_back(e);
-    }
-  }
-  return MRX_OK;
-}
-
-int mrx_cim_table_blocks_pending(mrx_handle h) {
-  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
-  return h->prog_active ? h->prog_nb - h->prog_next : 0;
-}
-
-int mrx_cim_reset(mrx_handle h, const int64_t* d_seed_cmd, const uint8_t* d_env_mask, void* stream_) {
+int mrx_cim_reset(mrx_handle h, const int64_t* d_seed_cmd, const uint8_t* d_env_mask, void* stream) {
   if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
   h->order_ready = false;  // (reset rewrites hints)
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
-  hipStream_t stream = (hipStream_t)stream_;
   const CimParams& K = h->plan.kp;
-  rc = table_drain(h, stream);
-  if (rc != MRX_OK) return rc;
   const bool table = K.pregen && K.orders_stride && d_seed_cmd && !K.data_mode;  // envs that keep their seed keep their order table
-  const int D = K.T - K.start_tick;
-  // In blocks behind the first steps: only a reset of the WHOLE batch in Sequential mode from tick 0 (the bound on the steps'
-  // progress — cim::decision_bounds_env — and CimParams::rows_ready are per launch, not per env).
-  const int nb = h->prog_block > 0 ? (D + h->prog_block - 1) / h->prog_block : 1;
-  const bool prog = table && nb > 1 && !d_env_mask && K.decision_mode == 0 && K.start_tick == 0 && K.tab_mt && h->side && (int)h->ev_block.size() >= nb;
-  if (prog) {
-    HIP_TRY(hipMemcpyAsync(h->cmd_copy, d_seed_cmd, sizeof(int64_t) * (size_t)K.n_envs, hipMemcpyDeviceToDevice, stream));
-  }
-  if (h->spec_module) {  // plan-specialised build of the reset kernel
+  if (h->spec_module) {  // plan-specialised builds of the same two kernels
     CimParams Kc = K;
     const long long* cmd = (const long long*)d_seed_cmd;
     long long dflt = -1;
     void* params[] = {&Kc, &cmd, &d_env_mask, &dflt};
-    HIP_TRY(hipModuleLaunchKernel(h->spec_reset, (unsigned)K.n_envs, 1, 1, 64, 1, 1, (unsigned)((size_t)K.lds_words_reset * 4), stream, params, nullptr));
-  } else {
-    hipLaunchKernelGGL(mrx_k_cim_reset, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_reset * 4, stream, K,
+    HIP_TRY(hipModuleLaunchKernel(h->spec_reset, (unsigned)K.n_envs, 1, 1, 64, 1, 1, (unsigned)((size_t)K.lds_words_reset * 4), (hipStream_t)stream, params, nullptr));
+    if (table)
+      HIP_TRY(hipModuleLaunchKernel(h->spec_order_table, (unsigned)K.n_envs, 1, 1, 64, 1, 1, (unsigned)((size_t)K.lds_words_gen * 4), (hipStream_t)stream, params, nullptr));
+    return MRX_OK;
+  }
+  hipLaunchKernelGGL(mrx_k_cim_reset, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_reset * 4, (hipStream_t)stream, K,
+                     (const long long*)d_seed_cmd, d_env_mask, (long long)-1);
+  if (table)
+    hipLaunchKernelGGL(mrx_k_cim_order_table, dim3(K.n_envs), dim3(64), (size_t)K.lds_words_gen * 4, (hipStream_t)stream, K,
                        (const long long*)d_seed_cmd, d_env_mask, (long long)-1);
-    HIP_TRY(hipGetLastError());
-  }
-  if (table && !prog) return launch_table(h, d_seed_cmd, d_env_mask, 0, D, K.n_envs, stream);
-  if (!prog) return MRX_OK;
-  // the blocks, on the side stream behind the reset kernel; the decision bounds first (the host reads them at the first step)
-  HIP_TRY(hipEventRecord(h->ev_reset, stream));
-  HIP_TRY(hipStreamWaitEvent(h->side, h->ev_reset, 0));
-  HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)K.tab_need, 0x7fffffff, MRX_TABLE_BLOCKS_MAX, h->side));
-  hipLaunchKernelGGL(mrx_k_cim_decision_bounds, dim3((unsigned)((K.n_envs + 3) / 4)), dim3(256), 0, h->side, K, h->prog_block, nb);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(h->need_host, K.tab_need, sizeof(int32_t) * MRX_TABLE_BLOCKS_MAX, hipMemcpyDeviceToHost, h->side));
-  HIP_TRY(hipEventRecord(h->ev_bounds, h->side));
-  const int bg = h->prog_waves > 0 && h->prog_waves < K.n_envs ? h->prog_waves : K.n_envs;
-  for (int b = 0; b < nb; b++) {
-    const int r0 = b * h->prog_block, r1 = (b + 1) * h->prog_block < D ? (b + 1) * h->prog_block : D;
-    rc = launch_table(h, h->cmd_copy, nullptr, r0, r1, b == 0 ? K.n_envs : bg, h->side);   // (block 0 holds up the first step: every wave slot)
-    if (rc != MRX_OK) return rc;
-    HIP_TRY(hipEventRecord(h->ev_block[b], h->side));
-  }
-  h->prog_active = true;
-  h->prog_bounds = false;
-  h->prog_nb = nb;
-  h->prog_next = 0;
-  h->prog_steps = 0;
-  h->plan.kp.rows_ready = 0;
   return MRX_OK;
 }
 
@@ -666,8 +513,6 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
                        const uint8_t* d_env_mask, int32_t* d_decisions, int64_t* d_metrics, uint8_t* d_done, void* stream) {
   if (!h || !d_decisions || !d_metrics || !d_done) return set_err(MRX_ERR_INVALID_ARG, "null handle/output pointer");
   int rc = use_device(h->device);
-  if (rc != MRX_OK) return rc;
-  rc = table_gate(h, (hipStream_t)stream);
   if (rc != MRX_OK) return rc;
   const CimParams& K = h->plan.kp;
   static const size_t lds_pad = getenv("MRX_DEBUG_LDS_PAD_BYTES") ? (size_t)atoi(getenv("MRX_DEBUG_LDS_PAD_BYTES")) : 0;  // occupancy experiments

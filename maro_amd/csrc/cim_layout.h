@@ -21,7 +21,7 @@ struct CimHostPlan {
   int64_t const_off = 0;
   int64_t workspace_bytes = 0;
   // byte offsets of per-env arrays inside the workspace
-  int64_t o_live, o_ring, o_ring_fi, o_priv, o_rec, o_status, o_tick, o_nstops, o_order_prop, o_mt, o_stops, o_seed, o_vperiod, o_orders, o_hint, o_order, o_sched, o_tab_mt, o_tab_idx, o_tab_need;
+  int64_t o_live, o_ring, o_ring_fi, o_priv, o_rec, o_status, o_tick, o_nstops, o_order_prop, o_mt, o_stops, o_seed, o_vperiod, o_orders, o_hint, o_order, o_sched;
   // relative offsets of const tables inside const_blob, in the order of CimParams' const pointers
   std::vector<std::pair<size_t, int64_t>> binds;  // (byte offset of a pointer field inside kp, offset in const_blob)
   int64_t ctab_rel = 0;
@@ -423,12 +423,6 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   pl->shared_orders_rel = shared_orders_rel;
   k.orders_stride = shared_orders_rel >= 0 ? 0 : (long long)c->durations * k.NTP;
   pl->o_orders = (k.pregen && shared_orders_rel < 0) ? A.take(N * (int64_t)c->durations * k.NTP * (k.order_half ? 2 : 4)) : 0;
-  // progressive generation (mrx_cim_set_progressive_reset): the order stream between two blocks, 2.5 KB per env
-  const bool own_table = k.pregen && shared_orders_rel < 0;
-  pl->o_tab_mt = own_table ? A.take(N * MT_WORDS * 4) : 0;
-  pl->o_tab_idx = own_table ? A.take(N * 4) : 0;
-  pl->o_tab_need = own_table ? A.take(MRX_TABLE_BLOCKS_MAX * 4) : 0;
-  k.rows_ready = 0x7fffffff;
   pl->workspace_bytes = align_up(A.top, 256);
 
   mrx_cim_layout& Lo = pl->layout;
@@ -460,8 +454,4 @@ inline void cim_plan_bind(CimHostPlan* pl, void* base_) {
   k.vperiod = (int32_t*)(base + pl->o_vperiod);
   k.hint = base + pl->o_hint; k.order = (int32_t*)(base + pl->o_order); k.sched = (int32_t*)(base + pl->o_sched);
   k.orders = !k.pregen ? nullptr : pl->shared_orders_rel >= 0 ? (int32_t*)(cb + pl->shared_orders_rel) : (int32_t*)(base + pl->o_orders);
-  const bool own_table = k.pregen && pl->shared_orders_rel < 0;
-  k.tab_mt = own_table ? (uint32_t*)(base + pl->o_tab_mt) : nullptr;
-  k.tab_idx = own_table ? (int32_t*)(base + pl->o_tab_idx) : nullptr;
-  k.tab_need = own_table ? (int32_t*)(base + pl->o_tab_need) : nullptr;
 }

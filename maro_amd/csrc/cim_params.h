@@ -71,14 +71,7 @@ struct CimParams {
                    // current tick (another vessel's decision is pending) or the episode is over -> fast path
   int32_t* order;  // [n_envs] env ids of the coming step, full-path envs first (MRX_ORDER_TICK set), -1 padded
   int32_t* sched;  // [4] n_tick, n_active (mrx_k_cim_schedule)
-  // ---- order table generated in blocks of ticks behind the first steps of the episode (mrx_cim_set_progressive_reset)
-  uint32_t* tab_mt;   // [n_envs][MT_WORDS] the order stream as the previous block of the env's table left it
-  int32_t* tab_idx;   // [n_envs] ... and its cursor
-  int32_t* tab_need;  // [MRX_TABLE_BLOCKS_MAX] first step of the episode at which some env may read a row of block b (mrx_k_cim_decision_bounds)
-  int rows_ready;     // rows of the order table (ticks from start_tick) that are complete for every env when THIS launch runs;
-                      // a step that reads beyond them raises MRX_ENV_TABLE_NOT_READY (never expected: the host orders the launches)
 };
-#define MRX_TABLE_BLOCKS_MAX 32
 #define MRX_ORDER_TICK 0x40000000  // order[] entry flag: full-path env
 #define MRX_PIPE_MAX_WAVES 4096    // persistent step kernel: at most this many waves (each owns a 64-byte scratch line behind sched[16])
 

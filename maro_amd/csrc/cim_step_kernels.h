@@ -9,19 +9,13 @@ mrx_k_cim_reset(CimParams K, const long long* __restrict__ seed_cmd, const uint8
   cim::reset_env(K, env, lds, seed_cmd ? seed_cmd[env] : default_cmd);
 }
 
-// rows [r0, r1) of the order tables; workgroup w generates the envs w, w + gridDim.x, ... (grid = n_envs: one env per workgroup;
-// a smaller grid bounds the wave slots a background block takes while step kernels are running: mrx_cim_set_progressive_reset)
 extern "C" __global__ void __launch_bounds__(64)
-mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const uint8_t* __restrict__ mask, long long default_cmd, int r0, int r1) {
+mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const uint8_t* __restrict__ mask, long long default_cmd) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-  cim::TableGen G;
-  bool staged = false;
-  for (int env = blockIdx.x; env < K.n_envs; env += gridDim.x) {
-    if (mask && !mask[env]) continue;
-    if ((seed_cmd ? seed_cmd[env] : default_cmd) == -1) continue;  // reset(keep_seed=True): same seed, same table
-    if (!staged) { cim::gen_table_setup(K, lds, G); staged = true; }
-    cim::gen_table_rows(K, G, env, r0, r1);
-  }
+  const int env = blockIdx.x;
+  if (mask && !mask[env]) return;
+  if ((seed_cmd ? seed_cmd[env] : default_cmd) == -1) return;  // reset(keep_seed=True): same seed, same table
+  cim::gen_order_table(K, env, lds);
 }
 
 #ifndef MRX_STEP_WAVES
@@ -41,7 +35,6 @@ mrx_k_cim_order_table(CimParams K, const long long* __restrict__ seed_cmd, const
   extern "C" __global__ void __launch_bounds__(64 * MRX_WG_WAVES, WAVES)                                                 \
   NAME(CimParams K, CimObs O, cim::StepBatch B, const uint8_t* __restrict__ mask, int sorted) {                          \
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];                                                       \
-    __builtin_amdgcn_s_setprio(3); /* ahead of background waves (order-table blocks of a progressive reset) at the issue arbiter */ \
     const int w = MRX_WG_WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;                        \
     const int slot = (int)blockIdx.x * MRX_WG_WAVES + w;                                                                \
     if (MRX_WG_WAVES > 1 && slot >= K.n_envs) return;                                                                   \

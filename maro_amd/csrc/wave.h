@@ -68,9 +68,6 @@ MRX_DEV int global_add(int32_t* p, int v) { return __hip_atomic_fetch_add(p, v, 
 // fire-and-forget OR into global memory (no return value, hence no s_waitcnt)
 MRX_DEV void global_or(int32_t* p, int v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// fire-and-forget minimum into global memory
-MRX_DEV void global_min(int32_t* p, int v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // inclusive prefix sum over the lanes (lane i gets v_0 + ... + v_i): six DPP adds — shifts inside the rows of 16 lanes, then
 // the gfx9 row broadcasts (row_bcast:15 into rows 1 / 3, row_bcast:31 into rows 2 / 3).  No trip through the LDS crossbar
 // (a __shfl_up scan is six dependent ds_bpermute round trips, ~10x the latency).  All 64 lanes must be active.

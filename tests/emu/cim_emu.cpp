@@ -66,38 +66,6 @@ void emu_reset(void* h, const int64_t* seed_cmd, const uint8_t* mask, int revers
   }
 }
 
-// mrx_cim_reset of the whole batch with mrx_cim_set_progressive_reset(block_ticks): the reset kernel for every env, the decision
-// bounds, then the table block by block (every env's block b before anybody's block b + 1: the order stream travels through
-// CimParams::tab_mt / tab_idx).  need_out[MRX_TABLE_BLOCKS_MAX] = CimParams::tab_need.
-int emu_reset_blocks(void* h, const int64_t* seed_cmd, int block_ticks, int reverse, int32_t* need_out) {
-  Emu* e = (Emu*)h;
-  const CimParams& K = e->plan.kp;
-  if (!(K.pregen && K.orders_stride && K.tab_mt) || K.data_mode || K.start_tick != 0 || K.decision_mode != 0 || block_ticks <= 0) return -1;
-  const int D = K.T - K.start_tick, nb = (D + block_ticks - 1) / block_ticks;
-  if (nb > MRX_TABLE_BLOCKS_MAX) return -1;
-  e->wave.reverse = reverse != 0;
-  for (int env = 0; env < K.n_envs; env++) {
-    memset(e->lds, 0xAB, (size_t)K.lds_words_reset * 4);
-    long long cmd = seed_cmd ? (long long)seed_cmd[env] : -1;
-    wave::run_wave(e->wave, [&]() { cim::reset_env(K, env, e->lds, cmd); });
-  }
-  for (int b = 0; b < MRX_TABLE_BLOCKS_MAX; b++) K.tab_need[b] = 0x7fffffff;
-  for (int env = 0; env < K.n_envs; env++) wave::run_wave(e->wave, [&]() { cim::decision_bounds_env(K, env, block_ticks, nb); });
-  for (int b = 0; b < nb; b++)
-    for (int env = 0; env < K.n_envs; env++) {
-      if (seed_cmd && seed_cmd[env] == -1) continue;
-      memset(e->lds, 0xAB, (size_t)K.lds_words_reset * 4);
-      wave::run_wave(e->wave, [&]() {
-        cim::TableGen G;
-        cim::gen_table_setup(K, e->lds, G);
-        cim::gen_table_rows(K, G, env, b * block_ticks, (b + 1) * block_ticks);
-      });
-    }
-  if (need_out) memcpy(need_out, K.tab_need, sizeof(int32_t) * MRX_TABLE_BLOCKS_MAX);
-  return nb;
-}
-void emu_set_rows_ready(void* h, int rows) { ((Emu*)h)->plan.kp.rows_ready = rows; }
-
 // the host twin of mrx_k_cim_schedule (cim_engine.hip): full-path envs first (the long ones, hint 2, at the head), then the
 // fast-hinted ones, -1 padded
 static void emu_schedule(Emu* e, const uint8_t* mask) {

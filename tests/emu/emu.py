@@ -85,9 +85,6 @@ def _declare(L):
         L.emu_workspace.restype = ctypes.c_void_p
         L.emu_workspace.argtypes = [ctypes.c_void_p]
         L.emu_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-        L.emu_reset_blocks.restype = ctypes.c_int
-        L.emu_reset_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-        L.emu_set_rows_ready.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.emu_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.emu_query.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
@@ -145,20 +142,6 @@ class EmuBackend:
         sc = None if seed_cmd is None else np.ascontiguousarray(seed_cmd, np.int64)
         mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         self._L.emu_reset(self._h, _ptr(sc), _ptr(mk), int(self.reverse))
-
-    def reset_blocks(self, seed_cmd, block_ticks):
-        """The whole-batch reset of mrx_cim_set_progressive_reset(block_ticks): returns (number of blocks, need[32]) —
-        need[b] = first step of the episode that may read a row of block b (cim::decision_bounds_env)."""
-        sc = np.ascontiguousarray(seed_cmd, np.int64)
-        need = np.zeros(32, np.int32)
-        nb = self._L.emu_reset_blocks(self._h, _ptr(sc), int(block_ticks), int(self.reverse), _ptr(need))
-        if nb < 0:
-            raise RuntimeError("configuration has no per-env order table to generate in blocks")
-        return nb, need
-
-    def set_rows_ready(self, rows):
-        """CimParams::rows_ready of the coming step launches (the engine's table_gate)."""
-        self._L.emu_set_rows_ready(self._h, int(rows))
 
     def step(self, actions=None, n_actions=None, mask=None, n_answered=None):
         a = None if actions is None else np.ascontiguousarray(actions, np.int32).reshape(self.n_envs, self.max_actions, 4)

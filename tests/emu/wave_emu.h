@@ -119,7 +119,6 @@ inline long long shfl(long long v, int src) { rendezvous(4, v); return cur_wave(
 inline int readlane(int v, int src) { return shfl(v, src); }
 inline int bcast(int v, int src) { return shfl(v, src); }
 inline void global_or(int32_t* p, int v) { *p |= v; }
-inline void global_min(int32_t* p, int v) { if (v < *p) *p = v; }
 inline int global_add(int32_t* p, int v) { const int o = *p; *p += v; return o; }
 
 inline long long reduce_add(long long v) {
