@@ -351,7 +351,7 @@ def bench_citi_bike(args, dist, dev, rank, world):
     tbar = ticks_adv / max(resolved, 1.0)
     ms_per_step = dt / args.steps * 1e3
     from maro_amd import _lib as mrx_lib
-    code_key = f"{getattr(eng, 'code_object_key', None)}+{mrx_lib.source_hash()}"   # step kernels' code object + the library's sources (policy / query kernels)
+    code_key = f"{getattr(eng, 'code_object_key', None)}+{mrx_lib.source_hash('cb')}"   # step kernels' code object + the library's sources (policy / query kernels)
     traffic, basis = measured_bytes_citi_bike(topology, n, args.step_budget, code_key, G)
     achieved = None if traffic is None else traffic / (ms_per_step * 1e-3) / 1e9     # per GPU: bytes of one batch step / its wall time
     out = {
@@ -717,7 +717,7 @@ def bench_collect(args, engines, streams, qnet, chains, n, G, dev, rank, world, 
     med = sorted(range(len(vals)), key=lambda i: vals[i])[len(vals) // 2]
     ms_per_step = dts[med] / args.steps * 1e3
     from maro_amd import _lib as mrx_lib
-    code_key = f"{getattr(engines[0], 'code_object_key', None)}+{mrx_lib.source_hash()}"   # step kernels' code object + the library's sources (DQN / sampler kernels)
+    code_key = f"{getattr(engines[0], 'code_object_key', None)}+{mrx_lib.source_hash('cim')}"   # step kernels' code object + the library's sources (DQN / sampler kernels)
     traffic, basis = measured_bytes_collect(n, G, code_key)
     achieved = None if traffic is None else traffic / (ms_per_step * 1e-3) / 1e9
     tf = DQN_FLOPS_PER_ENV * deciding / (act_ms * 1e-3) / 1e12

@@ -176,25 +176,30 @@ def load() -> ctypes.CDLL:
     return L
 
 
-_SRC_HASH = None
+_SRC_HASH = {}
 
 
-def source_hash() -> str:
+def source_hash(scope: str = "") -> str:
     """sha256 (first 16 hex digits) over the library's sources (maro_amd/csrc/*.h, *.hip, include/*.h): the identity of the kernels
     that are NOT plan-specialised code objects (DQN forward, sampler kernels, queries ...).  bench.py stamps its lines with it and
-    only uses a PMC record of the same sources."""
-    global _SRC_HASH
-    if _SRC_HASH is None:
+    only uses a PMC record of the same sources.  `scope` "cim" / "cb": only that scenario's translation unit — its own files
+    (cim_* + maro_amd.h, cb_* + maro_amd_citi_bike.h) and the shared wave.h — so that a change to one scenario's kernels does not
+    retire the other scenario's measurements."""
+    if scope not in _SRC_HASH:
         import hashlib
         h = hashlib.sha256()
         inc = os.path.join(os.path.dirname(_HERE), "include")
         files = sorted(os.path.join(d, f) for d in (os.path.join(_HERE, "csrc"), inc) for f in os.listdir(d) if f.endswith((".h", ".hip")))
+        own = {"cim": ("cim_", "maro_amd.h", "wave.h"), "cb": ("cb_", "maro_amd_citi_bike.h", "wave.h")}.get(scope)
         for f in files:
-            h.update(os.path.basename(f).encode())
+            b = os.path.basename(f)
+            if own is not None and not (b.startswith(own[0]) or b in own[1:]):
+                continue
+            h.update(b.encode())
             with open(f, "rb") as fp:
                 h.update(fp.read())
-        _SRC_HASH = h.hexdigest()[:16]
-    return _SRC_HASH
+        _SRC_HASH[scope] = h.hexdigest()[:16]
+    return _SRC_HASH[scope]
 
 
 def check(rc: int, what: str):
