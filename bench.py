@@ -425,8 +425,9 @@ _REF_RUNTIME = None
 def reference_runtime():
     """Where the REAL reference (microsoft/maro built by oracle/build_ref.sh) can be imported from on THIS box, for the
     cpu_baseline legs only: (maro root, stubs dir, HOME, description) or None.  Order: $MARO_REFERENCE_BUILD; the runtime archive
-    oracle/_ref/maro_ref.tgz (a build output of `oracle/build_ref.sh <dest> oracle/_ref`, git-ignored, shipped to the GPU box
-    with the snapshot like the built .so files) unpacked into a temp folder; the build container's /tmp/oracle."""
+    oracle/_ref/maro_ref.tgz (a build output of `oracle/build_ref.sh <dest> oracle/_ref` — written by __graft_entry__.build()
+    where /root/reference exists, git-ignored and NOT tracked, shipped to the GPU box with the snapshot like the built .so files)
+    unpacked into a private per-user cache folder; the build container's /tmp/oracle."""
     global _REF_RUNTIME
     if _REF_RUNTIME is not None:
         return _REF_RUNTIME or None
@@ -443,19 +444,41 @@ def reference_runtime():
     elif os.path.exists(tgz):
         import hashlib
         import tarfile
-        tag = hashlib.sha256(f"{os.path.getsize(tgz)}:{os.path.getmtime(tgz)}".encode()).hexdigest()[:12]
-        dest = os.path.join(tempfile.gettempdir(), f"maro_amd_ref_{tag}")
-        if not built(os.path.join(dest, "maro_ref")):
-            tmp = dest + f".{os.getpid()}"
+        # Unpacked under a directory only this user can write (0700), keyed by the archive's CONTENT hash, and trusted only when
+        # the completion marker written after a full extraction is there: a half-populated or foreign folder is never executed.
+        h = hashlib.sha256()
+        with open(tgz, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 20), b""):
+                h.update(chunk)
+        base = os.path.join(os.path.expanduser("~"), ".cache", "maro_amd")
+        try:
+            os.makedirs(base, mode=0o700, exist_ok=True)
+            if os.stat(base).st_uid != os.getuid() or (os.stat(base).st_mode & 0o077):
+                raise OSError("cache directory is not private")
+        except OSError:
+            base = tempfile.mkdtemp(prefix="maro_amd_ref_")   # private by construction (0700, fresh name)
+        dest = os.path.join(base, "ref_" + h.hexdigest()[:16])
+        marker = os.path.join(dest, ".complete")
+        if not os.path.exists(marker):
+            tmp = tempfile.mkdtemp(prefix="ref_unpack_", dir=base)
             with tarfile.open(tgz) as tf:
-                tf.extractall(tmp)
+                try:
+                    tf.extractall(tmp, filter="data")   # no absolute paths, links out of the tree, devices or setuid bits
+                except TypeError:                       # Python < 3.10.12 / 3.11.4: no extraction filters
+                    root_real = os.path.realpath(tmp)
+                    members = [m for m in tf.getmembers() if (m.isfile() or m.isdir())
+                               and os.path.realpath(os.path.join(tmp, m.name)).startswith(root_real + os.sep)]
+                    tf.extractall(tmp, members=members)
             os.makedirs(os.path.join(tmp, "maro_ref", "home"), exist_ok=True)
+            with open(os.path.join(tmp, ".complete"), "w") as f:
+                f.write(h.hexdigest())
             try:
                 os.replace(tmp, dest)
             except OSError:
-                pass   # another rank / process got there first
+                import shutil
+                shutil.rmtree(tmp, ignore_errors=True)   # another rank / process got there first
         root = os.path.join(dest, "maro_ref")
-        if built(root):
+        if os.path.exists(marker) and built(root):
             res = (root, os.path.join(root, "stubs"), os.path.join(root, "home"), "oracle/_ref/maro_ref.tgz (the reference built by oracle/build_ref.sh, unpacked on this box)")
     elif built("/tmp/oracle/maro_src"):
         res = ("/tmp/oracle/maro_src", "/tmp/oracle/stubs", "/tmp/oracle/home", "/tmp/oracle/maro_src (oracle/build_ref.sh in the build container)")

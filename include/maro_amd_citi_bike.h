@@ -176,6 +176,14 @@ int mrx_cb_set_step_budget(mrx_cb_handle h, int max_records);
  * it off.
  */
 int mrx_cb_set_observation(mrx_cb_handle h, const int32_t* station_attrs, int n_attrs, double* d_obs);
+/*
+ * Rows per env of the fused observation on the step path currently in effect (read-only): scope_cap on wave-stepped plans, the
+ * number of stations otherwise — the second dimension d_obs must have.  The buffer is sized for ONE row layout: while an
+ * observation is configured, mrx_cb_set_wave_decisions / mrx_cb_load_step_kernels refuse a change that would switch the layout
+ * (MRX_ERR_UNSUPPORTED; switch the observation off first, n_attrs = 0).  No reference counterpart (the reference returns
+ * whatever nodes the caller slices: maro/backends/np_backend.pyx:520-549).
+ */
+int mrx_cb_observation_rows(mrx_cb_handle h);
 
 /*
  * Replaces snapshot_list["stations" | "matrices"][ticks:nodes:attrs] (frame.pyx:754-801, np_backend.pyx:520-549).

@@ -103,6 +103,7 @@ class CimBatchSampler:
         self._pj = torch.zeros(n, dtype=torch.int64, device=dev)       # slot the env's previous interaction wrote (device-resident loop)
         self._pa = torch.zeros(n, dtype=torch.uint8, device=dev)       # ... and whether that element still waits for its next state
         self._max_cached, self._any_eoe = 0, True                     # host-side: bound on any env's cached elements; may an env need a reset
+        self._dev_pending = False                                      # a device-resident call left newest elements waiting for their next state
         # per-attribute retention: the whole episode of (fulfillment, shortage) per port, written by the step kernel at every
         # snapshot — the delayed reward reads up to time_window ticks ahead of decisions that may be an episode old
         self._hist = eng.set_port_history(["fulfillment", "shortage"])
@@ -215,6 +216,7 @@ class CimBatchSampler:
         seeds = _seed_fn(seeds, n)
         if not hasattr(self, "_c") or self.state_dtype != state_dtype:
             self._sample_init(state_dtype)
+        self._drain_device_pending()
         c = self._c
         out = {k: [] for k in ("state", "action", "env_action", "reward", "next_state", "next_agent_state", "terminal", "env_id", "tick", "agent")}
         acts = torch.zeros((n, eng.max_actions, 4), dtype=torch.int32, device=dev)
@@ -289,6 +291,7 @@ class CimBatchSampler:
         if not out["reward"]:
             res["reward"] = torch.zeros(0, dtype=torch.float32, device=dev)
         res["env_metric"] = eng.metrics.clone()
+        self._after_per_step_call()
         return res
 
     def sample_fused(self, actor, num_steps: Optional[int], seeds: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, reset_every: int = 1,
@@ -370,6 +373,7 @@ class CimBatchSampler:
         try:
             if not hasattr(self, "_c") or self.state_dtype != state_dtype:
                 self._sample_init(state_dtype)
+            self._drain_device_pending()
             if num_steps is not None:
                 need = int((self._head - self._tail).max()) + num_steps + 1      # one read per CALL: the cache never has to grow inside the loop
                 if need > self._cap:
@@ -493,6 +497,7 @@ class CimBatchSampler:
             if not out["reward"]:
                 res["reward"] = torch.zeros(0, dtype=torch.float32, device=dev)
             res["env_metric"] = eng.metrics.clone()
+            self._after_per_step_call()
         finally:
             leave(tok)
         return res
@@ -617,8 +622,15 @@ class CimBatchSampler:
         tok = enter()
         try:
             ev.synchronize()
-            K, max_cached, n_over = (int(x) for x in self._info_host[:3].tolist())
+            K, max_cached, n_over, n_pending_out = (int(x) for x in self._info_host[:4].tolist())
             self._max_cached, self._any_eoe = max_cached, n_over > 0
+            if n_pending_out:
+                # a running env's newest element goes out in THIS call (its tick is a whole reward window behind the pending decision)
+                # while its next state is still to come from the next interaction's gather: complete it now, as the reference does
+                # right after _step (env_sampler.py:494-497).  Rare (sparse topologies / short windows); one state evaluation.
+                self._fill_next_state(self._pj, self._pa.to(torch.bool), torch.arange(n, device=dev))
+                self._pa.zero_()
+            self._dev_pending = True   # (running envs' newest elements wait for their next state: see _drain_device_pending)
             D = self.state_dim
             if K > 0:
                 o = dict(state=torch.empty((K, D), dtype=self.state_dtype, device=dev), action=torch.empty(K, dtype=torch.int64, device=dev),
@@ -643,6 +655,25 @@ class CimBatchSampler:
         finally:
             leave(tok)
         return res
+
+    def _drain_device_pending(self) -> None:
+        """The device-resident loop (``_sample_fused_device``) ends a call with every running env's newest element still waiting for
+        its next state (`_pa`): the next interaction's gather completes it.  The per-step paths (``sample``, ``sample_fused`` with
+        `num_steps=None`, MRX_SAMPLER_V2=0, other state dtypes) neither read `_pa` nor had `_cur_state` maintained meanwhile — so
+        a call that takes one of them after a device-path call completes those elements and refreshes `_cur_state` first."""
+        if not getattr(self, "_dev_pending", False):
+            return
+        self._dev_pending = False
+        dev = self.eng.decisions.device
+        self._fill_next_state(self._pj, self._pa.to(torch.bool), torch.arange(self.eng.n_envs, device=dev))
+        self._pa.zero_()
+        self._cur_state = torch.where((~self._eoe)[:, None], self.state().to(self.state_dtype), self._cur_state)
+
+    def _after_per_step_call(self) -> None:
+        """The device-resident loop keeps two facts on the HOST between calls (so that a call needs no read-back before it starts): a
+        bound on any env's cached elements and whether an env may sit at the end of its episode.  A per-step call changes both."""
+        self._max_cached = int((self._head - self._tail).max())
+        self._any_eoe = True
 
     @property
     def interactions(self) -> torch.Tensor:

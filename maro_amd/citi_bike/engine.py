@@ -174,7 +174,7 @@ class CitiBikeBatchEngine:
         (`layout.env_major`, plan-specialised): rows = the `scope_cap` stations of the decision's action scope, `scope[:, :, 0]`
         (-1 padding: zeros).  () switches it off."""
         ids = self.attr_ids("stations", station_attrs)
-        rows = self.layout.scope_cap if self.set_wave_decisions(0) else self.data.n_stations
+        rows = _lib.check(self._L.mrx_cb_observation_rows(self._h), "mrx_cb_observation_rows")   # read-only: the wave mode the caller chose stays
         self.obs = torch.zeros((self.n_envs, rows, len(ids)), dtype=torch.float64, device=self.device) if ids else None
         arr = (ctypes.c_int32 * max(len(ids), 1))(*ids)
         _lib.check(self._L.mrx_cb_set_observation(self._h, arr, len(ids), self._p(self.obs)), "mrx_cb_set_observation")

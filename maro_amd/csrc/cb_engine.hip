@@ -100,6 +100,7 @@ struct mrx_cb_engine {
   hipModule_t spec_module = nullptr;   // plan-specialised reset / step kernels (mrx_cb_load_step_kernels), else the generic ones
   hipFunction_t spec_reset = nullptr, spec_step = nullptr, spec_wave = nullptr, spec_replay = nullptr;
   int wave_mode = 0;    // mrx_cb_set_wave_decisions: 0 automatic, 1 on, -1 off
+  bool obs_wave = false;  // the row layout the fused observation's buffer was sized for: scope_cap rows (wave path) or S rows (lane path)
   // kernels of the module may still be queued or running on the caller's stream: drain the device before unloading
   void unload_spec() {
     if (!spec_module) return;
@@ -206,11 +207,31 @@ static bool cb_wave_on(mrx_cb_handle h) {
   return h->wave_mode > 0 || K.S >= 96;
 }
 
+// Which kernels write the fused observation (mrx_cb_set_observation) on the path in effect: the wave kernels (rows = the action
+// scope's stations, scope_cap per env) or the one-env-per-lane kernel (rows = every station).
+static bool cb_replay_ok(mrx_cb_handle h, bool has_replay) { return has_replay && (int64_t)h->plan.kp.lds_words * 4 <= MRX_CB_LDS_BYTES; }
+// (wave-stepped plans write the observation from BOTH wave kernels, which needs the plan-specialised replay kernel: mrx_cb_set_observation)
+static bool cb_obs_consistent(mrx_cb_handle h, bool has_replay) {
+  return cb_wave_on(h) == h->obs_wave && (!h->obs_wave || cb_replay_ok(h, has_replay));
+}
+
 int mrx_cb_set_wave_decisions(mrx_cb_handle h, int mode) {
   if (!h || mode < -1 || mode > 1) return set_err(MRX_ERR_INVALID_ARG, "null handle, or mode not in {-1 off, 0 automatic, 1 on}");
   if (mode > 0 && !cb_wave_applicable(h->plan.kp)) return set_err(MRX_ERR_UNSUPPORTED, "the wave-cooperative decision step needs Sequential mode, aligned frames and <= 2048 stations");
+  const int before = h->wave_mode;
   h->wave_mode = mode;
+  // a fused observation is sized for ONE row layout: a switch that would change who writes it (and how many rows) is refused —
+  // the lane kernel writing S rows per env into a scope_cap-row buffer would run past it
+  if (h->plan.kp.obs && !cb_obs_consistent(h, h->spec_replay != nullptr)) {
+    h->wave_mode = before;
+    return set_err(MRX_ERR_UNSUPPORTED, "a fused observation is configured for the other step path: switch it off (mrx_cb_set_observation with n_attrs = 0) before changing the wave mode");
+  }
   return cb_wave_on(h) ? 1 : 0;
+}
+
+int mrx_cb_observation_rows(mrx_cb_handle h) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  return cb_wave_on(h) ? h->plan.layout.scope_cap : h->plan.kp.S;
 }
 
 int mrx_cb_set_step_budget(mrx_cb_handle h, int max_records) {
@@ -236,6 +257,7 @@ int mrx_cb_set_observation(mrx_cb_handle h, const int32_t* station_attrs, int n_
   HIP_TRY(hipDeviceSynchronize());   // (steps may be in flight with the previous configuration)
   K.obs_n = n_attrs;
   K.obs = n_attrs > 0 ? d_obs : nullptr;
+  h->obs_wave = cb_wave_on(h);   // d_obs holds mrx_cb_observation_rows(h) rows per env
   return MRX_OK;
 }
 
@@ -274,6 +296,8 @@ static int cb_launch_step(mrx_cb_handle h, const int32_t* d_actions, const int32
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
   const CbParams& K = h->plan.kp;
+  if (K.obs && !cb_obs_consistent(h, h->spec_replay != nullptr))   // (cannot happen through the setters; never write past the buffer)
+    return set_err(MRX_ERR_INVALID_ARG, "the fused observation was configured for the other step path: call mrx_cb_set_observation again");
   CbParams Kc = K;
   Kc.step_budget = h->step_budget;
   if (cb_wave_on(h)) {
@@ -370,6 +394,15 @@ int mrx_cb_load_step_kernels(mrx_cb_handle h, const void* image, int64_t bytes, 
   if (hipModuleGetFunction(&f_reset, mod, "mrx_k_cb_reset") != hipSuccess || hipModuleGetFunction(&f_step, mod, "mrx_k_cb_step") != hipSuccess) {
     hipModuleUnload(mod);
     return set_err(MRX_ERR_INVALID_ARG, "code object lacks mrx_k_cb_reset / mrx_k_cb_step");
+  }
+  if (h->plan.kp.obs) {  // would the new kernels change who writes the fused observation?
+    hipFunction_t probe = nullptr;
+    const bool has_replay = hipModuleGetFunction(&probe, mod, "mrx_k_cb_replay_wave") == hipSuccess && probe;
+    if (!has_replay) (void)hipGetLastError();
+    if (!cb_obs_consistent(h, has_replay)) {
+      hipModuleUnload(mod);
+      return set_err(MRX_ERR_UNSUPPORTED, "a fused observation is configured for the other step path: switch it off before loading step kernels, then set it again");
+    }
   }
   h->unload_spec();
   h->spec_module = mod;

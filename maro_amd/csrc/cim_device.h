@@ -106,11 +106,39 @@ MRX_DEV Lds make_lds(const CimParams& K, int32_t* b) {
 #define MRX_LEAN 1
 #endif
 #endif
+#if defined(MRX_LEAN) && !defined(MRX_NO_LEAN2)
+#define MRX_LEAN2 1  // the one-round-trip-per-phase tick (run_tick_lean) on top of the lean register layout
+#endif
 #ifdef MRX_LEAN
 enum { RR_NB = (MRXC_NT + 63) / 64, RR_H = MRXC_H };
 struct RingRegs { int rf[RR_H][RR_NB]; };
 #else
 struct RingRegs {};
+#endif
+
+// ... and so do the words a lane needs over and over (lean builds only):
+//   LeanStat  static words of "my" order pairs / vessel / port (CimParams::lean_tab), loaded once per step straight from L2
+//   VRows     the per-vessel scheduling words (lane = vessel), loaded once per step from the staged state and kept coherent with
+//             it: only a vessel's own departure (phase B1) and arrival (B4) change them
+// so that every phase of a tick starts with ONE LDS round trip (its gathers) instead of a chain of dependent table lookups.
+#ifdef MRX_LEAN2
+struct LeanStat {
+  int ps[RR_NB];            // pair 64 b + lane: source port | tgt_off[source] << 8
+  int vs0, vs1, vs2;  // lane = vessel: route length | distinct ports << 6 | route base << 12; leg_off | rec_off << 16; v_cbase
+  int pt;                   // lane = port: tgt_off[p] | number of its pairs << 16
+};
+struct VRows {
+  int evt, next;  // the vessel's next event tick, the cached arrival tick of its next stop
+  int w;          // next_loc_idx | route position << 16 | next_loc mod (L + 1) << 22 | is_parking << 28   (stop tables hold < 65536 stops)
+};
+MRX_DEV int vr_k(const VRows& W) { return W.w & 0xffff; }
+MRX_DEV int vr_pos(const VRows& W) { return (W.w >> 16) & 63; }
+MRX_DEV int vr_krl(const VRows& W) { return (W.w >> 22) & 63; }
+MRX_DEV int vr_park(const VRows& W) { return (W.w >> 28) & 1; }
+MRX_DEV void vr_set(VRows& W, int k_, int pos_, int krl_, int park_) { W.w = k_ | (pos_ << 16) | (krl_ << 22) | (park_ << 28); }
+struct Lean { LeanStat s; VRows w; };
+#else
+struct Lean {};
 #endif
 
 #define FP(a, p) L.frame[KD(f_ports) + (a) * KD(P) + (p)]
@@ -164,21 +192,28 @@ MRX_DEV uint32_t mt_temper(uint32_t y) {
   return y;
 }
 
-// In-place twist.  new[k] = x[(k+397)%624] ^ f(x[k], x[(k+1)%624]); processed 64 words per round,
-// reads-then-writes, which is dependency-safe because the recurrence distance (227) exceeds 64.
+// In-place twist.  new[k] = x[(k+397)%624] ^ f(x[k], x[(k+1)%624]); processed 208 words per round (three rounds),
+// reads-then-writes, which is dependency-safe because the recurrence distance (227) exceeds 208: a round reads old words at
+// k, k + 1 and (k < 227) k + 397, and new words at k - 227 that an EARLIER round wrote.  (Rounds of 64 words were ten dependent
+// LDS round trips per twist; a buffer-stream twist happens every second or third tick of global_trade.22p.)
 MRX_DEV void mt_twist(uint32_t* mt) {
   const int l = wave::lane();
-  for (int k0 = 0; k0 < MT_WORDS; k0 += 64) {
-    const int k = k0 + l;
-    uint32_t x = 0;
-    if (k < MT_WORDS) {
+  static_assert(MT_WORDS == 3 * 208, "round size");
+  for (int k0 = 0; k0 < MT_WORDS; k0 += 208) {
+    uint32_t x[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const bool on = j * 64 + l < 208;
+      const int k = on ? k0 + j * 64 + l : k0;  // (idle lanes of the last quarter read a valid word)
       const int k1 = (k + 1 == MT_WORDS) ? 0 : k + 1;
       const int km = (k + 397 >= MT_WORDS) ? k + 397 - MT_WORDS : k + 397;
       const uint32_t y = (mt[k] & 0x80000000U) | (mt[k1] & 0x7fffffffU);
-      x = mt[km] ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
+      x[j] = mt[km] ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
     }
     wave::sync();
-    if (k < MT_WORDS) mt[k] = x;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (j * 64 + l < 208) mt[k0 + j * 64 + l] = x[j];
     wave::sync();
   }
 }
@@ -204,6 +239,37 @@ MRX_DEV double mt_draw_batch(uint32_t* mt, int& idx, int rank, int n, bool& twis
     idx += 2 * n;
   }
   return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// The same for up to NB draws per lane in ONE LDS round trip: lane's b-th draw has rank[b] (-1: none) among the n draws this call
+// hands out (n wave-uniform, 2 n < MT_WORDS).  Stream order == rank order, exactly as NB successive mt_draw_batch calls.
+template <int NB>
+MRX_DEV void mt_draw_multi(uint32_t* mt, int& idx, const int (&rank)[NB], int n, bool& twisted, double (&r)[NB]) {
+  uint32_t a[NB], b[NB];
+#pragma unroll
+  for (int i = 0; i < NB; i++) {  // branch-free: clamped addresses, masked values (all reads in flight together)
+    const int w0 = idx + 2 * rank[i], w1 = w0 + 1;
+    const uint32_t ra = mt[(rank[i] >= 0 && w0 < MT_WORDS) ? w0 : 0], rb = mt[(rank[i] >= 0 && w1 < MT_WORDS) ? w1 : 0];
+    a[i] = (rank[i] >= 0 && w0 < MT_WORDS) ? mt_temper(ra) : 0u;
+    b[i] = (rank[i] >= 0 && w1 < MT_WORDS) ? mt_temper(rb) : 0u;
+  }
+  if (idx + 2 * n > MT_WORDS) {  // wave-uniform
+    wave::sync();
+    mt_twist(mt);
+    twisted = true;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      const int w0 = idx + 2 * rank[i], w1 = w0 + 1;
+      const uint32_t ra = mt[(rank[i] >= 0 && w0 >= MT_WORDS) ? w0 - MT_WORDS : 0], rb = mt[(rank[i] >= 0 && w1 >= MT_WORDS) ? w1 - MT_WORDS : 0];
+      if (rank[i] >= 0 && w0 >= MT_WORDS) a[i] = mt_temper(ra);
+      if (rank[i] >= 0 && w1 >= MT_WORDS) b[i] = mt_temper(rb);
+    }
+    idx = idx + 2 * n - MT_WORDS;
+  } else {
+    idx += 2 * n;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; i++) r[i] = ((double)(a[i] >> 5) * 67108864.0 + (double)(b[i] >> 6)) * (1.0 / 9007199254740992.0);
 }
 
 // one random() delivered to every lane (wave-uniform control flow)
@@ -323,6 +389,7 @@ struct TickPf {
   int src[3];
   int q[4], key[4];
   int kk[4];  // order pair (arrival port -> port of the i-th next stop) of the a-th arriving vessel, lane i; -1: none
+  int pa;     // lean builds: lane a holds the a-th arriving vessel's port | its compact matrix column << 8
   int ns, otg;
   int oqr[3];  // order table: quantities of pairs lane + 64 b of the coming tick
   uint32_t stk, stk1;
@@ -337,6 +404,9 @@ MRX_DEV void tick_prefetch_land(TickPf& pf) {
   for (int b = 0; b < 3; b++) { wave::touch(pf.tb[b]); wave::touch(pf.tn[b]); wave::touch(pf.src[b]); }
 #pragma unroll
   for (int a = 0; a < 4; a++) { wave::touch(pf.q[a]); wave::touch(pf.key[a]); wave::touch(pf.kk[a]); }
+#ifdef MRX_LEAN2
+  wave::touch(pf.pa);
+#endif
   wave::touch(pf.ns); wave::touch(pf.otg); wave::touch(pf.stk); wave::touch(pf.stk1);
 #pragma unroll
   for (int b = 0; b < 3; b++) wave::touch(pf.oqr[b]);
@@ -858,6 +928,425 @@ MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {
     }
   }
 }
+
+// ==========================================================================================
+// LEAN builds (plan-specialised, order table, <= 192 pairs): the same tick, written so that every phase starts with ONE LDS
+// round trip.  What made the generic tick a chain of ~90 dependent LDS round trips per step (each ~130 cycles with twelve
+// resident waves per CU) were table lookups feeding table lookups (pair -> source port -> its first pair -> prefix cell ...),
+// read-modify-writes that wait for their read, and per-vessel words re-read in every phase.  Here: static words come out of
+// registers (LeanStat), per-vessel words out of registers (VRows), every additive effect is a fire-and-forget ds_add, the
+// gathers a phase needs are issued together with clamped addresses (validity re-derived afterwards), the three batches of
+// phase B3 share one RNG hand-out (mt_draw_multi), and the discharge records are drawn by RANK instead of being sorted in place.
+// Same arithmetic, same RNG stream positions, same results (goldens / fuzz on the emulator and the GPU).
+#ifdef MRX_LEAN2
+MRX_DEV void lean_stat_load(const CimParams& K, LeanStat& S) {
+  const int lane = wave::lane();
+  const int32_t* g = K.lean_tab;
+#pragma unroll
+  for (int b = 0; b < RR_NB; b++) { const int k = b * 64 + lane; S.ps[b] = g[k < KD(NT) ? k : 0]; }
+  const int lv = lane < KD(V) ? lane : 0, lp = lane < KD(P) ? lane : 0;
+  S.vs0 = g[KD(NTP) + lv]; S.vs1 = g[KD(NTP) + 64 + lv]; S.vs2 = g[KD(NTP) + 128 + lv];
+  S.pt = g[KD(NTP) + 256 + lp];
+}
+MRX_DEV void vrows_load(const CimParams& K, const Lds& L, VRows& W) {
+  const int lane = wave::lane();
+  const int lv = lane < KD(V) ? lane : 0;
+  const int park = FV(VA_IS_PARKING, lv), pos = V_POS(lv), krl = V_KRL(lv), k = FV(VA_NEXT_LOC_IDX, lv);
+  W.evt = V_EVT(lv); W.next = V_NEXT(lv);
+  vr_set(W, k, pos, krl, park);
+}
+
+// tick_prefetch_arrivals without its per-vessel LDS reads and without ds_bpermute: one gather (route ports) feeds the pair lookup
+MRX_DEV void tick_prefetch_arrivals_lean(const CimParams& K, int env, Lds& L, uint64_t mask, TickPf& pf, const Lean& Z) {
+  const int lane = wave::lane();
+  const int V = KD(V), P = KD(P);
+  const Tabs& T = L.tab;
+  const int32_t* g_rec = K.rec + (size_t)env * KD(REC_W);
+  {  // lane a (< 4) fetches the stop-table entries of the a-th arriving vessel
+    uint64_t m = mask;
+    int v = 0, kq = 0;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      const int va = m ? __builtin_ctzll(m) : 0;
+      if (m) m &= m - 1;
+      const int ka = wave::readlane(Z.w.w, va) & 0xffff;
+      if (lane == a) { v = va; kq = ka; }
+    }
+    const size_t srow = ((size_t)env * V + v) * KD(SMAX);
+    pf.ns = K.nstops[(size_t)env * V + v];
+    pf.stk = K.stops[srow + (kq < KD(SMAX) ? kq : 0)];
+    pf.stk1 = K.stops[srow + (kq + 1 < KD(SMAX) ? kq + 1 : 0)];
+  }
+  uint64_t m = mask;
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    const int v = m ? __builtin_ctzll(m) : 0;  // wave-uniform; vessel 0 is a harmless stand-in when fewer arrive
+    if (m) m &= m - 1;
+    const int ww = wave::readlane(Z.w.w, v), k = ww & 0xffff, krl = (ww >> 22) & 63, pos = (ww >> 16) & 63;
+    const int vs0 = wave::readlane(Z.s.vs0, v), Lr = vs0 & 63, rb = (int)((unsigned)vs0 >> 12);
+    const int reco = (int)((unsigned)wave::readlane(Z.s.vs1, v) >> 16);
+    const int RL = Lr + 1;
+    const int sidx = k - Lr + lane;
+    int col = krl + 1 + lane;
+    if (col >= RL) col -= RL;
+    const bool ok = lane < Lr && sidx >= 0;
+    pf.q[a] = g_rec[reco + krl * RL + (ok ? col : 0)];
+    pf.key[a] = (int)K.stops[((size_t)env * V + v) * KD(SMAX) + (ok ? sidx : 0)];
+    int xn = pos + 1 + (lane < Lr ? lane : 0);  // < 2 Lr: one conditional subtraction instead of an integer modulo
+    if (xn >= Lr) xn -= Lr;
+    const int p_arr = T.route_port[rb + pos], c_arr = T.route_cidx[rb + pos];
+    pf.kk[a] = K.pair_dense[p_arr * P + (int)T.route_port[rb + xn]];
+    if (lane == a) pf.pa = p_arr | (c_arr << 8);
+  }
+}
+
+MRX_DEV void tick_prefetch_lean(const CimParams& K, int env, Lds& L, int t, TickPf& pf, const Lean& Z) {
+  const int lane = wave::lane();
+#pragma unroll
+  for (int b = 0; b < 3; b++) pf.oqr[b] = order_cell(K, env, t - KD(start_tick), b * 64 + lane < KD(NTP) ? b * 64 + lane : 0);
+  pf.otg = 0;
+  bool arr = lane < KD(V) && !vr_park(Z.w) && vr_k(Z.w) > 0 && Z.w.evt == t;
+  if (KD(start_tick) > 0) arr = arr && !((zombie_mask(L) >> lane) & 1ull);  // (their event is a departure; they never arrive)
+  pf.arr_mask = wave::ballot(arr);
+  tick_prefetch_arrivals_lean(K, env, L, pf.arr_mask, pf, Z);
+}
+
+MRX_DEV uint64_t run_tick_lean(const CimParams& K, int env, Lds& L, int t, TickPf& pf, int& idx_buf, int& status, Prof& prof,
+                               bool& buf_twisted, RingRegs& rr, Lean& Z) {
+  const int lane = wave::lane();
+  const int P = KD(P), V = KD(V), NT = KD(NT), H = KD(H);
+  const Tabs& T = L.tab;
+  LeanStat& S = Z.s;
+  VRows& W = Z.w;
+  const uint64_t arr_mask = pf.arr_mask;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  int32_t* g_rec = K.rec + (size_t)env * KD(REC_W);
+  int oqr[RR_NB];  // order quantity of pair 64 b + lane (later | (buffer ticks + 1) << 24)
+#pragma unroll
+  for (int b = 0; b < RR_NB; b++) oqr[b] = (b * 64 + lane < NT) ? pf.oqr[b] : 0;
+  const int slot = t % H;
+  // the empty returns that fall due now: nothing in this tick adds to ring slot `slot` (a delay of 0 is applied at once, delays
+  // are < H), so the row is read before anything else and consumed after the discharges
+  const int due_empty = RING_EMPTY(slot, lane < P ? lane : 0);
+  prof.mark(PF_ORDER_GEN);
+
+  // ---------------- B1. departures (business_engine.py:634-656): per-vessel words out of registers, written through
+  const uint64_t zmask = KD(start_tick) > 0 ? zombie_mask(L) : 0ull;
+  if (lane < V) {
+    const int v = lane;
+    const bool z = (zmask >> v) & 1ull;
+    if ((z || vr_park(W)) && W.evt == t) {
+      const int Lr = S.vs0 & 63;
+      const int k1 = vr_k(W) + 1;
+      FV(VA_NEXT_LOC_IDX, v) = k1;
+      int x = vr_pos(W) + 1, y = vr_krl(W) + 1;
+      x = x == Lr ? 0 : x; y = y == Lr + 1 ? 0 : y;
+      V_POS(v) = x; V_KRL(v) = y;
+      vr_set(W, k1, x, y, 0);
+      FV(VA_IS_PARKING, v) = 0;
+      FV(VA_LOC_PORT_IDX, v) = -1;
+      if (z) {  // the next scheduled departure event (see zombie_mask)
+        const uint32_t* srow = K.stops + ((size_t)env * V + v) * KD(SMAX);
+        const int ks = W.next + 1, ns = K.nstops[(size_t)env * V + v];
+        W.next = ks;
+        V_NEXT(v) = ks;
+        const uint32_t st = srow[ks < KD(SMAX) ? ks : KD(SMAX) - 1];
+        W.evt = ks < ns ? stop_arrival(st) + stop_parking(st) : 0x7fffffff;
+      } else {
+        W.evt = W.next;  // arrival tick of the next stop, cached at the previous arrival
+      }
+      V_EVT(v) = W.evt;
+    }
+  }
+
+  // ---------------- B2. returns / discharges scheduled for this tick: every effect is an addition (ds_add, no wait)
+#pragma unroll
+  for (int b = 0; b < RR_NB; b++) {  // RETURN_FULL :499-522, one lane per (src, dst) pair
+    const int k = b * 64 + lane;
+    int q = 0;
+#pragma unroll
+    for (int h = 0; h < RR_H; h++) { const bool mine = slot == h; q = mine ? rr.rf[h][b] : q; rr.rf[h][b] = mine ? 0 : rr.rf[h][b]; }
+    if (k < NT && q) {
+      const int src = S.ps[b] & 0xff;
+      wave::lds_add(&FOPK(k), q);
+      wave::lds_add(&FP(PA_ON_SHIPPER, src), -q);
+      wave::lds_add(&FP(PA_FULL, src), q);
+    }
+  }
+  if (arr_mask) {
+    // DISCHARGE_FULL :658-693.  One BUFFER draw per original event, in the order the events were scheduled: (tick of the load,
+    // vessel index) — SURVEY.md §9.2.  The records of all arriving vessels are compacted into a list (key, vessel | port << 6 |
+    // full_on_vessels cell << 12, quantity); entry i then takes the draw of its RANK in that order — the effects are additions,
+    // so only the hand-out of the draws depends on the order, and the list itself is never sorted.
+    int32_t* ent = L.misc;
+    int n_ent = 0, n_ves = 0, slot4 = 0;
+    for (uint64_t m = arr_mask; m; m &= m - 1, slot4++) {  // wave-uniform
+      if (slot4 == 4) {  // more than four arrivals in one tick (rare): fetch the next four now
+        tick_prefetch_arrivals_lean(K, env, L, m, pf, Z);
+        tick_prefetch_land(pf);
+        slot4 = 0;
+      }
+      const int v = __builtin_ctzll(m);
+      const int ww = wave::readlane(W.w, v), k = ww & 0xffff, krl = (ww >> 22) & 63;
+      const int Lr = wave::readlane(S.vs0, v) & 63, RL = Lr + 1;
+      const int reco = (int)((unsigned)wave::readlane(S.vs1, v) >> 16), cb = wave::readlane(S.vs2, v);
+      const int pa = wave::bcast(pf.pa, slot4);
+      const int sidx = k - Lr + lane;  // lane j looks at load stop k-Lr+j
+      int q = 0, key = 0;
+      int col = krl + 1 + lane;  // (k - Lr + lane) mod RL
+      if (col >= RL) col -= RL;
+      int32_t* cell = g_rec + reco + krl * RL + (lane < Lr ? col : 0);
+      if (lane < Lr && sidx >= 0) {  // prefetched (tick_prefetch_arrivals_lean)
+        q = slot4 == 0 ? pf.q[0] : slot4 == 1 ? pf.q[1] : slot4 == 2 ? pf.q[2] : pf.q[3];
+        key = stop_arrival((uint32_t)(slot4 == 0 ? pf.key[0] : slot4 == 1 ? pf.key[1] : slot4 == 2 ? pf.key[2] : pf.key[3]));
+      }
+      const bool has = q > 0;
+      const uint64_t hm = wave::ballot(has);
+      if (has) {
+        *cell = 0;
+        const int i = n_ent + __builtin_popcountll(hm & lt_mask);
+        if (i < KD(misc_cap)) { ent[3 * i] = key; ent[3 * i + 1] = v | ((pa & 0xff) << 6) | ((cb + (pa >> 8)) << 12); ent[3 * i + 2] = q; }
+      }
+      n_ent += __builtin_popcountll(hm);
+      n_ves++;
+    }
+    if (n_ent > KD(misc_cap)) { status |= 16; n_ent = KD(misc_cap); }
+    wave::sync();
+    if (n_ves > 1 && n_ent > 64) {  // more records than lanes (very rare): sort the list after all (serial insertion sort)
+      if (lane == 0) {
+        for (int i = 1; i < n_ent; i++) {
+          const int key = ent[3 * i], vv = ent[3 * i + 1], qq = ent[3 * i + 2];
+          int j = i;
+          while (j > 0 && ent[3 * (j - 1)] > key) { ent[3 * j] = ent[3 * (j - 1)]; ent[3 * j + 1] = ent[3 * (j - 1) + 1]; ent[3 * j + 2] = ent[3 * (j - 1) + 2]; j--; }
+          ent[3 * j] = key; ent[3 * j + 1] = vv; ent[3 * j + 2] = qq;
+        }
+      }
+      wave::sync();
+    }
+    for (int i0 = 0; i0 < n_ent; i0 += 64) {  // one lane per record
+      const int i = i0 + lane;
+      const bool has = i < n_ent;
+      const int nb = (n_ent - i0) < 64 ? (n_ent - i0) : 64;
+      const int key = has ? ent[3 * i] : 0x7fffffff, e1 = has ? ent[3 * i + 1] : 0, q = has ? ent[3 * i + 2] : 0;
+      int rank = lane;
+      if (n_ves > 1 && n_ent > 1 && n_ent <= 64) {  // stable rank by load tick (entries of one vessel are already in order)
+        rank = 0;
+        for (int j = 0; j < n_ent; j++) {  // wave-uniform
+          const int kj = wave::readlane(key, j);
+          rank += (kj < key || (kj == key && j < lane)) ? 1 : 0;
+        }
+      }
+      const int v = e1 & 63, p = (e1 >> 6) & 63, fcell = (int)((unsigned)e1 >> 12);
+      const double eb = T.er_base[p], en = T.er_noise[p];
+      const double r = KD(use_buffer_rng) ? mt_draw_batch(L.mt_buf, idx_buf, has ? rank : -1, nb, buf_twisted) : 0.0;
+      if (has) {
+        wave::lds_add(&FV(VA_FULL, v), -q);
+        wave::lds_add(&FV(VA_REMAINING_SPACE, v), q);
+        wave::lds_add(&L.frame[KD(f_fov) + fcell], -q);
+        const int b = KD(use_buffer_rng) ? (int)ceil(apply_noise(eb, en, r)) : T.er_delay[p];
+        if (b == 0) {  // immediate RETURN_EMPTY
+          wave::lds_add(&FP(PA_EMPTY, p), q);
+        } else {
+          wave::lds_add(&FP(PA_ON_CONSIGNEE, p), q);
+          if (b > 0) { const int sl = slot + b >= H ? slot + b - H : slot + b; wave::lds_add(&RING_EMPTY(sl, p), q); }
+        }
+      }
+    }
+  }
+  if (lane < P && due_empty) {  // RETURN_EMPTY :695-706
+    wave::lds_add(&FP(PA_ON_CONSIGNEE, lane), -due_empty);
+    wave::lds_add(&FP(PA_EMPTY, lane), due_empty);
+    RING_EMPTY(slot, lane) = 0;
+  }
+  wave::sync();
+  prof.mark(PF_DEPART_RETURNS);
+
+  // ---------------- B3. orders (:448-497) — one BUFFER draw per order, in generation order; one lane per pair
+  {
+    int32_t* pre = L.misc;  // inclusive prefix of the order quantities over all pairs (ent[] is dead by now)
+    if (lane < P) L.srcn[lane] = 0;  // per-port sum of immediately returned containers
+    int rank[RR_NB], cnt = 0;
+    double r[RR_NB];
+#pragma unroll
+    for (int b = 0; b < RR_NB; b++) {
+      const bool has = oqr[b] > 0;
+      const uint64_t m = wave::ballot(has);
+      rank[b] = has ? cnt + __builtin_popcountll(m & lt_mask) : -1;
+      cnt += __builtin_popcountll(m);
+      r[b] = 0.0;
+    }
+    if (KD(use_buffer_rng)) mt_draw_multi<RR_NB>(L.mt_buf, idx_buf, rank, cnt, buf_twisted, r);
+    int carry = 0, incl[RR_NB], bdv[RR_NB];
+    bool any_imm = false;
+#pragma unroll
+    for (int b = 0; b < RR_NB; b++) {  // the pairs' delay tables: one more round trip for all three batches
+      const int src = S.ps[b] & 0xff;
+      bdv[b] = 0;
+      if (KD(use_buffer_rng)) {
+        const double fb = T.fr_base[src], fn = T.fr_noise[src];
+        if (oqr[b] > 0) bdv[b] = (int)ceil(apply_noise(fb, fn, r[b]));
+      } else if (oqr[b] > 0) {
+        bdv[b] = T.fr_delay[src];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < RR_NB; b++) {
+      const int k = b * 64 + lane;
+      const int q = oqr[b];
+      const bool has = q > 0;
+      const int bd = bdv[b];
+      incl[b] = wave::scan_incl_add(q) + carry;
+      carry = wave::bcast(incl[b], 63);
+      if (k < NT) pre[k] = incl[b];
+      if (has) oqr[b] = q | ((bd < 0 ? 0 : (bd > 126 ? 127 : bd + 1)) << 24);
+      any_imm = any_imm || (wave::ballot(has && bd == 0) != 0);
+    }
+    wave::sync();
+    // exec_j = min(q_j, max(0, empty0 - sum of the port's earlier orders)): the sequential hand-out of :462-478
+    int pbase[RR_NB], emp[RR_NB];
+#pragma unroll
+    for (int b = 0; b < RR_NB; b++) {  // the gathers of all three batches in one round trip
+      const int src = S.ps[b] & 0xff, off = (int)((unsigned)S.ps[b] >> 8);
+      pbase[b] = pre[off > 0 ? off - 1 : 0];
+      emp[b] = FP(PA_EMPTY, src);
+    }
+#pragma unroll
+    for (int b = 0; b < RR_NB; b++) {
+      const int k = b * 64 + lane;
+      const int qb = oqr[b];
+      const int q = qb & 0xffffff;
+      if (q > 0) {
+        const int src = S.ps[b] & 0xff, off = (int)((unsigned)S.ps[b] >> 8);
+        const int excl = incl[b] - q - (off > 0 ? pbase[b] : 0);
+        const int avail = emp[b] - excl;
+        const int exec = avail <= 0 ? 0 : (q < avail ? q : avail);
+        const int bd = ((qb >> 24) & 0x7f) - 1;  // -1 = scheduled into the past: the containers never come back
+        if (bd == 0) { wave::lds_add(&FOPK(k), exec); wave::lds_add(&L.srcn[src], exec); }  // RETURN_FULL right away (:494-497)
+        else if (bd > 0) {
+          int sl = slot + bd;
+          sl = sl >= H ? sl - H : sl;
+#pragma unroll
+          for (int h = 0; h < RR_H; h++) rr.rf[h][b] += (sl == h) ? exec : 0;
+        }
+      }
+    }
+    wave::sync();
+    if (lane < P) {  // port totals in closed form
+      const int p = lane;
+      const int off = S.pt & 0xffff, cnt_p = (int)((unsigned)S.pt >> 16);
+      const int hi = pre[cnt_p > 0 ? off + cnt_p - 1 : 0], lo = pre[off > 0 ? off - 1 : 0];
+      const int empty0 = FP(PA_EMPTY, p), imm_v = L.srcn[p], bk = FP(PA_BOOKING, p), sh = FP(PA_SHORTAGE, p);
+      if (cnt_p > 0) {
+        const int sumq = hi - (off > 0 ? lo : 0);
+        if (sumq > 0) {
+          const int short_ = sumq > empty0 ? sumq - empty0 : 0;
+          const int exec = sumq - short_;
+          const int imm = any_imm ? imm_v : 0;
+          const int booking = bk + sumq, shortage = sh + short_;
+          FP(PA_BOOKING, p) = booking; wave::lds_add(&FP(PA_ACC_BOOKING, p), sumq);
+          FP(PA_SHORTAGE, p) = shortage; wave::lds_add(&FP(PA_ACC_SHORTAGE, p), short_);
+          FP(PA_FULFILLMENT, p) = booking - shortage;  // port.py:88-97
+          FP(PA_EMPTY, p) = empty0 - exec;
+          wave::lds_add(&FP(PA_ON_SHIPPER, p), exec - imm);
+          wave::lds_add(&FP(PA_FULL, p), imm);
+        }
+      }
+    }
+  }
+  wave::sync();
+  prof.mark(PF_ORDERS);
+
+  // ---------------- B4. arrivals + full loading, in vessel order (:600-632, :524-598); lane i = i-th next stop
+  if (arr_mask) {
+    int a_idx = 0;
+    if (__builtin_popcountll(arr_mask) > 4) {  // the discharge pass re-used the prefetch registers: fetch group 0 again
+      tick_prefetch_arrivals_lean(K, env, L, arr_mask, pf, Z);
+      tick_prefetch_land(pf);
+    }
+    const int lvv = lane < V ? lane : 0;
+    const int r_full = FV(VA_FULL, lvv), r_empty = FV(VA_EMPTY, lvv), r_cap = FV(VA_CAPACITY, lvv);  // (after the discharges; an arrival only changes its own vessel's words)
+    for (uint64_t m = arr_mask; m; m &= m - 1, a_idx++) {  // wave-uniform over the arriving vessels
+      if (a_idx == 4) {
+        tick_prefetch_arrivals_lean(K, env, L, m, pf, Z);
+        tick_prefetch_land(pf);
+        a_idx = 0;
+      }
+      const int v = __builtin_ctzll(m);
+      const int ww = wave::readlane(W.w, v), k = ww & 0xffff, pos = (ww >> 16) & 63, krl = (ww >> 22) & 63, cap = wave::readlane(r_cap, v);
+      int full = wave::readlane(r_full, v), empty = wave::readlane(r_empty, v);
+      const int full0 = full, empty0 = empty;
+      const int vs0 = wave::readlane(S.vs0, v), vs1 = wave::readlane(S.vs1, v), cb = wave::readlane(S.vs2, v);
+      const int Lr = vs0 & 63, n_distinct = (vs0 >> 6) & 63, rb = (int)((unsigned)vs0 >> 12), RL = Lr + 1;
+      const int lo = vs1 & 0xffff, reco = (int)((unsigned)vs1 >> 16);
+      const int p = wave::bcast(pf.pa, a_idx) & 0xff;
+      const int ns = wave::bcast(pf.ns, a_idx);  // prefetched by lane a_idx (tick_prefetch_arrivals_lean)
+      const uint32_t st_k = (uint32_t)wave::bcast((int)pf.stk, a_idx);
+      const uint32_t st_k1 = (uint32_t)wave::bcast((int)pf.stk1, a_idx);
+      prof.mark(10);
+      // lane i: the i-th stop after this one — route position, compact matrix column, predicted tick, pending orders to its port:
+      // one round trip for the three gathers
+      const bool act = lane < Lr;
+      int xi = pos + lane, xn = pos + 1 + lane;  // leg out of stop i-1, position of stop i
+      xi = act ? (xi >= Lr ? xi - Lr : xi) : 0;   // lanes < Lr stay below 2 Lr: a conditional subtraction, no integer division
+      xn = act ? (xn >= Lr ? xn - Lr : xn) : 0;
+      const int kk = a_idx == 0 ? pf.kk[0] : a_idx == 1 ? pf.kk[1] : a_idx == 2 ? pf.kk[2] : pf.kk[3];  // order pair (p -> port of stop i), -1: none
+      const int leg_raw = T.leg_time[lo + xi], c_i = T.route_cidx[rb + xn], pend_raw = FOPK(kk >= 0 ? kk : 0);
+      const int leg = act ? leg_raw : 0;
+      const int tick_i = t + wave::scan_incl_add(leg);  // vessel_future_stops_prediction.py:49-85
+      bool dup_later = false, dup_earlier = false;  // the route may visit a port twice ...
+      if (n_distinct != Lr) {  // ... (wave-uniform) but most routes do not: as many plan cells as stops
+        for (int j = 0; j < Lr; j++) {
+          const int cj = wave::bcast(c_i, j);
+          dup_later = dup_later || (j > lane && cj == c_i);
+          dup_earlier = dup_earlier || (j < lane && cj == c_i);
+        }
+      }
+      if (lane < Lr && !dup_later) L.frame[KD(f_plans) + cb + c_i] = tick_i;  // vessel_sailing_plan_wrapper.py:24-28 (later stops overwrite)
+      prof.mark(11);
+      // load full (:551-587): the sequential hand-out of `acceptable` over the next Lr stops is a clamped prefix sum;
+      // a second visit of the same port within the window gets nothing (first visit took all, or space ran out)
+      const int acceptable = (int)floor((double)(cap - full * KD(vol)) / (double)KD(vol));
+      const bool lv = lane < Lr && (k + 1 + lane) < ns && !dup_earlier;  // python slice truncation at the end of the stop list
+      const int pend = (lv && kk >= 0) ? pend_raw : 0;
+      const int incl = wave::scan_incl_add(pend);
+      int l = 0;
+      if (acceptable > 0 && pend > 0) { const int room = acceptable - (incl - pend); l = room <= 0 ? 0 : (pend < room ? pend : room); }
+      const int loaded_total = wave::bcast(incl < acceptable ? incl : (acceptable > 0 ? acceptable : 0), 63);
+      if (l > 0) {
+        FOPK(kk) = pend - l;
+        wave::lds_add(&L.frame[KD(f_fov) + cb + c_i], l);
+        int row = krl + 1 + lane;  // (k + 1 + lane) mod RL
+        if (row >= RL) row -= RL;
+        g_rec[reco + row * RL + krl] = l;  // cell is empty: (dst stop, load stop) pairs are unique
+      }
+      full += loaded_total;
+      int early = 0;
+      if ((long long)(full + empty) * KD(vol) > (long long)cap) {
+        early = (full + empty) - (int)ceil((double)cap / (double)KD(vol));
+        empty -= early;
+      }
+      const int evt_new = t + stop_parking(st_k), next_new = k + 1 < ns ? stop_arrival(st_k1) : 0x7fffffff;
+      if (lane == 0) {
+        FV(VA_LAST_LOC_IDX, v) = k;
+        FV(VA_IS_PARKING, v) = 1;
+        FV(VA_LOC_PORT_IDX, v) = p;
+        wave::lds_add(&FP(PA_FULL, p), -loaded_total);
+        wave::lds_add(&FP(PA_EMPTY, p), early);
+        FV(VA_FULL, v) = full;
+        FV(VA_EMPTY, v) = empty;
+        FV(VA_EARLY_DISCHARGE, v) = early;
+        wave::lds_add(&FV(VA_REMAINING_SPACE, v), (full0 + empty0) - (full + empty));  // vessel.py:113-120: total_space - full - empty
+        V_EVT(v) = evt_new;
+        V_NEXT(v) = next_new;
+      }
+      if (lane == v) { W.w |= 1 << 28; W.evt = evt_new; W.next = next_new; }
+      wave::sync();
+    }
+  }
+  prof.mark(PF_ARRIVALS);
+  return arr_mask;
+}
+#endif  // MRX_LEAN2
 
 // One tick, phases A..B4.  Returns the mask of vessels that arrived (their decisions follow).
 template <bool PG>
@@ -1635,7 +2124,10 @@ MRX_DEV int plan_cell(const Lds& L, int v, int p) {
 }
 
 template <bool PG>
-MRX_DEV bool body_open(const CimParams& K, int env, Lds& L, StepCtx& c, StepOut& out) {
+MRX_DEV bool body_open(const CimParams& K, int env, Lds& L, StepCtx& c, StepOut& out, Lean& Z) {
+#ifdef MRX_LEAN2
+  vrows_load(K, L, Z.w);  // (issued before the header words are waited for: one round trip for both)
+#endif
   const int flags0 = U(L.priv[PH_FLAGS]);
   out.kind = 0;
   out.obs_on = false;
@@ -1658,14 +2150,18 @@ MRX_DEV bool body_open(const CimParams& K, int env, Lds& L, StepCtx& c, StepOut&
   const uint64_t pend_after = c.fresh ? 0ull : consume_decisions(K, c.pend, L.priv[PH_CUR_VESSEL], c.n_answered);
   const int tn = c.fresh ? c.t : c.t + 1;
   if (!pend_after && tn < KD(T)) {
+#ifdef MRX_LEAN2
+    tick_prefetch_lean(K, env, L, tn, c.pf, Z);
+#else
     if constexpr (!PG) tick_prefetch_static(K, c.pf, true);
     tick_prefetch<PG>(K, env, L, tn, c.pf);
+#endif
   }
   return true;
 }
 
 // actions for the pending decision (core.py:301-315 -> business_engine.py:708-748)
-MRX_DEV void body_act(const CimParams& K, Lds& L, const int32_t* actions, StepCtx& c) {
+MRX_DEV void body_act(const CimParams& K, Lds& L, const int32_t* actions, StepCtx& c, const Lean& Z) {
   const int P = KD(P), V = KD(V);
   if (c.fresh) return;
   for (int i = 0; i < c.n_act; i++) {  // wave-uniform
@@ -1673,6 +2169,14 @@ MRX_DEV void body_act(const CimParams& K, Lds& L, const int32_t* actions, StepCt
     const int v = U(i == 0 ? c.a0v : a[0]), p = U(i == 0 ? c.a0p : a[1]), q = U(i == 0 ? c.a0q : a[2]), ty = U(i == 0 ? c.a0t : a[3]);
     if (v < 0 || v >= V || p < 0 || p >= P || q < 0 || (ty != 0 && ty != 1)) { c.status |= 1; continue; }
     // every word this action reads, requested back to back (one LDS round trip instead of one per word)
+#ifdef MRX_LEAN2
+    // ... including the vessel's route (lane = route position: port and compact matrix column), so that the plan cell of (v, p)
+    // needs no lookup chain of its own
+    const Tabs& T = L.tab;
+    const int a_vs0 = wave::readlane(Z.s.vs0, v), a_Lr = a_vs0 & 63, a_rb = (int)((unsigned)a_vs0 >> 12), a_cb = wave::readlane(Z.s.vs2, v);
+    const int a_lr = wave::lane() < a_Lr ? wave::lane() : 0;
+    const int a_rp = T.route_port[a_rb + a_lr], a_rc = T.route_cidx[a_rb + a_lr], a_per = V_PERIOD(v);
+#endif
     const int pe_v = FP(PA_EMPTY, p), ve_v = FV(VA_EMPTY, v), rs_v = FV(VA_REMAINING_SPACE, v), tc_v = FP(PA_TRANSFER_COST, p);
     const int pe = U(pe_v), ve = U(ve_v), rs = U(rs_v), tc = U(tc_v);
     int npe, nve;
@@ -1689,8 +2193,14 @@ MRX_DEV void body_act(const CimParams& K, Lds& L, const int32_t* actions, StepCt
     c.opnum += q;
     FP(PA_TRANSFER_COST, p) = f_bits((float)((double)bits_f(tc) + (double)q));
     {  // vessel_plans[v, p] += period (:748): the compact plan cell of (v, p), -1 if p is not on the vessel's route
+#ifdef MRX_LEAN2
+      const uint64_t hit = wave::ballot(wave::lane() < a_Lr && a_rp == p);
+      const int cc = hit ? a_cb + wave::readlane(a_rc, __builtin_ctzll(hit)) : -1;
+      if (cc >= 0) { const int pl = U(L.frame[KD(f_plans) + cc]); L.frame[KD(f_plans) + cc] = pl + U(a_per); }
+#else
       const int cc = plan_cell(L, v, p);
       if (cc >= 0) { const int pl = U(L.frame[KD(f_plans) + cc]); L.frame[KD(f_plans) + cc] = pl + U(V_PERIOD(v)); }
+#endif
       else c.status |= 32;  // MRX_ENV_OFFROUTE_ACTION
     }
   }
@@ -1699,7 +2209,7 @@ MRX_DEV void body_act(const CimParams& K, Lds& L, const int32_t* actions, StepCt
 }
 
 template <bool PG, bool OBS>
-MRX_DEV StepEnd body_run(const CimParams& K, const CimObs& O, int env, Lds& L, const StepIO& io, StepCtx& c, StepOut& out, Prof& prof, RingRegs& rr) {
+MRX_DEV StepEnd body_run(const CimParams& K, const CimObs& O, int env, Lds& L, const StepIO& io, StepCtx& c, StepOut& out, Prof& prof, RingRegs& rr, Lean& Z) {
   const int lane = wave::lane();
   const int P = KD(P), V = KD(V);
   StepEnd end = {true, false, false};
@@ -1732,9 +2242,17 @@ MRX_DEV StepEnd body_run(const CimParams& K, const CimObs& O, int env, Lds& L, c
     }
     prof.mark(PF_POST_STEP);
     fresh = false;
+#ifdef MRX_LEAN2
+    pend = run_tick_lean(K, env, L, t, c.pf, c.idx_buf, c.status, prof, end.buf_dirty, rr, Z);
+#else
     pend = run_tick<PG>(K, env, L, t, c.pf, c.idx_ord, c.idx_buf, c.status, prof, end.ord_dirty, end.buf_dirty, rr);
+#endif
     if (!pend && t + 1 < KD(T)) {  // another tick follows: its inputs, landed before that tick's snapshot stores are issued
+#ifdef MRX_LEAN2
+      tick_prefetch_lean(K, env, L, t + 1, c.pf, Z);
+#else
       tick_prefetch<PG>(K, env, L, t + 1, c.pf);
+#endif
       tick_prefetch_land(c.pf);
     }
   }
@@ -1820,7 +2338,11 @@ MRX_DEV StepEnd body_run(const CimParams& K, const CimObs& O, int env, Lds& L, c
   // flag travels in the header so the fast-path steps in between can hand it on.  Scheduling only: results do not depend on it.
   bool long_next = false;
   if (KD(start_tick) == 0 && !finished) {
+#ifdef MRX_LEAN2
+    const bool soon = lane < V && (vr_park(Z.w) ? Z.w.next : Z.w.evt) <= t + 1;
+#else
     const bool soon = lane < V && (FV(VA_IS_PARKING, lane) ? V_NEXT(lane) : V_EVT(lane)) <= t + 1;
+#endif
     long_next = wave::ballot(soon) == 0ull;
   }
   if (long_next && out.hint) out.hint = 2;
@@ -1883,19 +2405,19 @@ MRX_DEV void body_emit(const CimParams& K, const CimObs& O, int env, const StepI
 
 // the stages back to back (one env per workgroup kernels)
 template <bool PG, bool OBS>
-MRX_DEV StepEnd full_body(const CimParams& K, const CimObs& O, int env, Lds& L, const StepIO& io, int a0v, int a0p, int a0q, int a0t, Prof& prof, RingRegs& rr) {
+MRX_DEV StepEnd full_body(const CimParams& K, const CimObs& O, int env, Lds& L, const StepIO& io, int a0v, int a0p, int a0q, int a0t, Prof& prof, RingRegs& rr, Lean& Z) {
   StepCtx c;
   StepOut out;
   c.a0v = a0v; c.a0p = a0p; c.a0q = a0q; c.a0t = a0t;
   c.n_act = io.n_act; c.n_answered = io.n_answered;
   StepEnd end = {false, false, false};
-  if (body_open<PG>(K, env, L, c, out)) {
+  if (body_open<PG>(K, env, L, c, out, Z)) {
     prof.mark(PF_LOAD);
-    body_act(K, L, io.actions, c);
+    body_act(K, L, io.actions, c, Z);
     prof.mark(PF_ACTION);
     tick_prefetch_land(c.pf);  // before the snapshot stores of post_step, so that nothing later waits behind them
     prof.mark(PF_MT_LOAD);
-    end = body_run<PG, OBS>(K, O, env, L, io, c, out, prof, rr);
+    end = body_run<PG, OBS>(K, O, env, L, io, c, out, prof, rr, Z);
   }
   body_emit<OBS>(K, O, env, io, out);
   return end;
@@ -1938,10 +2460,14 @@ MRX_DEV void step_env(const CimParams& K, const CimObs& O, int env, int32_t* lds
   stage_tables(K, L, lds_ctab ? lds_ctab : lds + KD(l_ctab));
   RingRegs rr;
   ring_load(K, env, rr);
+  Lean Z;
+#ifdef MRX_LEAN2
+  lean_stat_load(K, Z.s);
+#endif
   int a0v = 0, a0p = 0, a0q = 0, a0t = 0;
   if (io.actions) { a0v = io.actions[0]; a0p = io.actions[1]; a0q = io.actions[2]; a0t = io.actions[3]; }
   wave::lds_dma_wait();
-  const StepEnd e = full_body<PG, OBS>(K, O, env, L, io, a0v, a0p, a0q, a0t, prof, rr);
+  const StepEnd e = full_body<PG, OBS>(K, O, env, L, io, a0v, a0p, a0q, a0t, prof, rr, Z);
   if (e.store) { state_store<PG>(K, L, env, e); ring_store(K, env, rr); }
   prof.mark(PF_STORE);
   prof.flush();

@@ -1061,6 +1061,9 @@ int mrx_cim_collect_steps(mrx_handle h, const mrx_cim_dqn_model* m, void* d_scra
   int rc = sampler_rec(h, cache, d_done, &R);
   if (rc != MRX_OK) return rc;
   if (n_steps < 0 || !d_decisions || !d_metrics || !d_actions || !d_n_actions) return set_err(MRX_ERR_INVALID_ARG, "null pointer / negative step count");
+  // the forward kernel writes the model's state row (dims[0] values) into the cache's ring slots, whose row stride is
+  // cache->state_dim: a mismatch would overwrite neighbouring slots / run past the arrays
+  if (!m || cache->state_dim != m->dims[0]) return set_err(MRX_ERR_INVALID_ARG, "mrx_cim_collect_steps: cache->state_dim must equal the model's input width (dims[0])");
   for (int k = 0; k < n_steps; k++) {
     rc = dqn_act(h, m, d_decisions, d_scratch, d_actions, d_n_actions, nullptr, nullptr, nullptr, nullptr, R, stream);
     if (rc != MRX_OK) return rc;
@@ -1081,7 +1084,8 @@ int mrx_cim_sampler_finalize(mrx_handle h, const mrx_cim_sampler_cache* cache, c
   const CimParams& K = h->plan.kp;
   hipLaunchKernelGGL(mrx_k_cim_sampler_finalize, dim3((unsigned)K.n_envs), dim3(64), 0, (hipStream_t)stream, K, E, (long long*)d_n_emit);
   hipLaunchKernelGGL(mrx_k_cim_sampler_scan, dim3(1), dim3(1024), 0, (hipStream_t)stream, K.n_envs, (const long long*)d_n_emit, (const long long*)cache->d_head,
-                     (const long long*)cache->d_tail, (const uint8_t*)cache->d_eoe, (long long*)d_out_offset, (long long*)d_info);
+                     (const long long*)cache->d_tail, (const uint8_t*)cache->d_eoe, (const uint8_t*)cache->d_prev_active, (long long*)d_out_offset,
+                     (long long*)d_info);
   HIP_TRY(hipGetLastError());
   return MRX_OK;
 }

@@ -325,6 +325,19 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
       for (int j = t->target_offset[p]; j < t->target_offset[p + 1]; j++) pair_dense[(size_t)p * P + t->target_port[j]] = j;
     put_i(&CimParams::pair_dense, pair_dense.data(), (size_t)P * P);
   }
+  {  // lean_tab (cim_params.h): what a lean step kernel keeps in registers for the whole step
+    std::vector<int32_t> lt((size_t)k.NTP + 5 * 64, 0);
+    for (int j = 0; j < NT; j++) lt[j] = pair_src[j] | ((t->target_offset[pair_src[j]] & 0xffffff) << 8);
+    for (int v = 0; v < V; v++) {
+      const int nd = (v + 1 < V ? v_cbase[v + 1] : k.NC) - v_cbase[v];
+      lt[(size_t)k.NTP + v] = v_route_len[v] | (nd << 6) | (v_route_base[v] << 12);
+      lt[(size_t)k.NTP + 64 + v] = leg_off[v] | (rec_off[v] << 16);
+      lt[(size_t)k.NTP + 128 + v] = v_cbase[v];
+      lt[(size_t)k.NTP + 192 + v] = t->vessel_capacity[v];
+    }
+    for (int p = 0; p < P; p++) lt[(size_t)k.NTP + 256 + p] = t->target_offset[p] | ((t->target_offset[p + 1] - t->target_offset[p]) << 16);
+    put_i(&CimParams::lean_tab, lt.data(), lt.size());
+  }
   int64_t shared_orders_rel = -1;
   if (t->data_mode) {
     std::vector<uint32_t> fx((size_t)V * k.SMAX, 0);
@@ -361,6 +374,8 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   k.l_odelay = k.l_oq;
   k.lds_words = (k.l_oq + NT + 1 + 3) / 4 * 4;
   k.lean_ok = (k.pregen && NT <= 192 && H <= 4) ? 1 : 0;
+  // (lean_tab packs route base / leg offset / record offset into 16-19 bit fields: checked by the 16-bit table copies above)
+  if (NRP >= (1 << 19) || rec_w >= (1 << 15)) k.lean_ok = 0;
   // Envs per workgroup of the plan-specialised step kernel.  Every wave still owns one env and never talks to another one,
   // but the k waves of a workgroup share ONE staged copy of the topology tables: k * l_ctab + ctab_words words per workgroup.
   // gfx950 hands out LDS in 1280-byte granules, 128 per CU (measured: tools/hbm_pattern_bench --residency); take the

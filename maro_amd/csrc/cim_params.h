@@ -58,6 +58,13 @@ struct CimParams {
   const int32_t *tgt_off, *tgt_port, *pair_src, *route_port, *v_route_base, *v_route_len, *v_start, *v_cap,
       *v_init_empty, *v_total_space, *p_cap, *p_init_empty, *leg_off, *leg_time, *v_period, *er_delay,
       *fr_delay, *rec_off, *v_route, *v_cbase, *route_cidx, *cidx_dense, *pair_dense;
+  const int32_t* lean_tab;  // per-lane static words of the lean step kernel, read ONCE per step into registers (cim_device.h LeanStat):
+                            //   [k]              k < NTP      order pair k: source port | tgt_off[source] << 8     (lean plans: NT <= 192)
+                            //   [NTP + v]        lane = vessel: route length | distinct route ports << 6 | route base << 12
+                            //   [NTP + 64 + v]   leg_off | rec_off << 16
+                            //   [NTP + 128 + v]  first compact matrix cell (v_cbase)
+                            //   [NTP + 192 + v]  vessel capacity
+                            //   [NTP + 256 + p]  lane = port: tgt_off[p] | number of its order pairs << 16
   const int32_t* ctab;  // start of the contiguous block staged in LDS by the step kernel (ctab_words words):
                         // per-port fp64 tables, er/fr_delay, and 16-bit copies of the serial-access int tables
   const uint16_t *h_tgt_off, *h_route_port, *h_v_route_base, *h_v_route_len, *h_leg_off, *h_leg_time,

@@ -66,31 +66,35 @@ mrx_k_cim_sampler_finalize(CimParams K, cim::SamplerEnd E, long long* __restrict
 
 // Exclusive scan of n_emit over the envs (one workgroup; n_envs up to a few hundred thousand) and the call's read-back:
 // info[0] = experiences emitted, info[1] = most elements any env keeps cached afterwards, info[2] = envs at the end of their
-// episode, info[3] = 0.
+// episode, info[3] = running envs whose NEWEST element is being emitted although it still waits for its next state (the gap to the
+// pending decision is >= the reward window: the reference sets next_state right after _step, env_sampler.py:494-497, so the host
+// completes those elements — one state evaluation, CimBatchSampler._fill_next_state — before it launches the emission).
 extern "C" __global__ void __launch_bounds__(1024)
 mrx_k_cim_sampler_scan(int n, const long long* __restrict__ n_emit, const long long* __restrict__ head, const long long* __restrict__ tail,
-                       const uint8_t* __restrict__ eoe, long long* __restrict__ out_off, long long* __restrict__ info) {
-  __shared__ long long part[1024], pmax[1024], pover[1024];
+                       const uint8_t* __restrict__ eoe, const uint8_t* __restrict__ prev_active, long long* __restrict__ out_off,
+                       long long* __restrict__ info) {
+  __shared__ long long part[1024], pmax[1024], pover[1024], ppend[1024];
   const int t = (int)threadIdx.x, per = (n + 1023) / 1024, lo = t * per, hi = min(n, lo + per);
-  long long s = 0, mx = 0, ov = 0;
+  long long s = 0, mx = 0, ov = 0, pe = 0;
   for (int e = lo; e < hi; e++) {
     s += n_emit[e];
     const long long left = head[e] - tail[e] - n_emit[e];
     mx = left > mx ? left : mx;
     ov += eoe[e] != 0;
+    pe += (n_emit[e] > 0 && left == 0 && eoe[e] == 0 && prev_active[e] != 0) ? 1 : 0;
   }
-  part[t] = s; pmax[t] = mx; pover[t] = ov;
+  part[t] = s; pmax[t] = mx; pover[t] = ov; ppend[t] = pe;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) {   // inclusive scan of the partial sums (Hillis-Steele)
     const long long v = t >= o ? part[t - o] : 0;
-    const long long m2 = t >= o ? pmax[t - o] : 0, o2 = t >= o ? pover[t - o] : 0;
+    const long long m2 = t >= o ? pmax[t - o] : 0, o2 = t >= o ? pover[t - o] : 0, p2 = t >= o ? ppend[t - o] : 0;
     __syncthreads();
-    part[t] += v; pmax[t] = m2 > pmax[t] ? m2 : pmax[t]; pover[t] += o2;
+    part[t] += v; pmax[t] = m2 > pmax[t] ? m2 : pmax[t]; pover[t] += o2; ppend[t] += p2;
     __syncthreads();
   }
   long long run = part[t] - s;
   for (int e = lo; e < hi; e++) { out_off[e] = run; run += n_emit[e]; }
-  if (t == 1023) { info[0] = part[t]; info[1] = pmax[t]; info[2] = pover[t]; info[3] = 0; }
+  if (t == 1023) { info[0] = part[t]; info[1] = pmax[t]; info[2] = pover[t]; info[3] = ppend[t]; }
 }
 
 // Emission: one 256-thread workgroup per env.  The env's n_emit oldest elements occupy CONSECUTIVE ring slots (two pieces when the

@@ -21,7 +21,14 @@ MRX_DEV void sync() {
   // LDS only: wait for this wave's outstanding LDS operations and stop the compiler from moving memory accesses
   // across this point.  Deliberately NOT a workgroup-scope fence: that would also drain vmcnt, i.e. stall on every
   // in-flight global load/store (prefetches, fire-and-forget stores) at each of the many syncs per tick.
+#ifdef MRX_SYNC_NOWAIT
+  // experiment: the LDS executes one wave's DS instructions in issue order, so a later ds_read of ANY lane sees an earlier
+  // ds_write / ds_add of any other lane of the same wave without waiting for its acknowledgement; values that travel through
+  // registers get their own s_waitcnt from the compiler.  Only the compiler barrier remains.
+  asm volatile("" ::: "memory");
+#else
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
   __builtin_amdgcn_wave_barrier();
 }
 

@@ -256,3 +256,40 @@ def test_fused_observation_equals_the_query(topology, specialize):
             eng.step(a, na)
     assert nonzero > 10000 and int(eng.status.abs().sum()) == 0
     assert eng.set_observation(()) is None
+
+
+def test_fused_observation_pins_the_step_path():
+    """the fused observation's buffer is sized for ONE row layout (every station on the lane path, the action scope's
+    stations on the wave path).  `set_observation` must not touch the wave mode the caller chose (it used to reset it to automatic),
+    and while an observation is configured a switch of the step path is refused instead of letting the other kernel write
+    S rows per env into a scope_cap-row buffer."""
+    import torch
+    from maro_amd.citi_bike.engine import CitiBikeBatchEngine
+    attrs = ["bikes", "capacity"]
+    n = 64
+    # a city-size plan, specialised: automatic = wave path.  The caller switches the wave kernels OFF, then asks for an observation
+    eng = CitiBikeBatchEngine("city.180s", n, durations=300, snapshot_resolution=10, max_snapshots=8, specialize=True, seeds=np.arange(n) + 1)
+    assert eng.set_wave_decisions(0) is True
+    assert eng.set_wave_decisions(-1) is False
+    obs = eng.set_observation(attrs)
+    assert obs.shape[1] == eng.data.n_stations                      # lane path: every station
+    assert eng.set_wave_decisions(-1) is False                      # ... and the caller's choice is still in force (no-op call)
+    with pytest.raises(RuntimeError, match="fused observation"):
+        eng.set_wave_decisions(1)                                   # would make the wave kernels write scope rows into this buffer
+    with pytest.raises(RuntimeError, match="fused observation"):
+        eng.set_wave_decisions(0)                                   # automatic = on at 180 stations: refused as well
+    a = torch.zeros((n, 1, 3), dtype=torch.int32, device=eng.device)
+    na = torch.zeros(n, dtype=torch.int32, device=eng.device)
+    stations = torch.arange(eng.data.n_stations, dtype=torch.int32, device=eng.device)
+    eng.step()
+    for i in range(1, 40):
+        want = eng.query("stations", eng.decisions[:, 3:4], stations, attrs)[:, 0]
+        valid = (eng.decisions[:, 5] == 1) & (eng.done == 0)
+        assert torch.equal(obs[valid], want[valid]), i
+        eng.random_policy(i, a, na)
+        eng.step(a, na)
+    assert eng.set_observation(()) is None
+    assert eng.set_wave_decisions(1) is True                        # with the observation off the switch is allowed again
+    obs2 = eng.set_observation(attrs)
+    assert obs2.shape[1] == eng.layout.scope_cap
+    assert int(eng.status.abs().sum()) == 0

@@ -395,3 +395,73 @@ def test_device_resident_collection_loop_equals_the_tensor_path(dtype):
                 assert torch.equal(a[key], b[key]), (c, key)
         total += int(b["tick"].shape[0])
     assert total > 20000
+
+
+def _compare_calls(res_a, res_b):
+    total = 0
+    for c, (a, b) in enumerate(zip(res_a, res_b)):
+        assert set(a) == set(b)
+        for key in b:
+            assert a[key].shape == b[key].shape and a[key].dtype == b[key].dtype, (c, key, a[key].shape, b[key].shape)
+            if key == "reward":
+                torch.testing.assert_close(a[key], b[key], rtol=1e-6, atol=1e-6)
+            else:
+                assert torch.equal(a[key], b[key]), (c, key)
+        total += int(b["tick"].shape[0])
+    return total
+
+
+@pytest.mark.gpu
+def test_per_step_paths_after_a_device_resident_call_complete_the_pending_elements():
+    """the device-resident loop ends a call with every running env's newest element waiting for its next state; a
+    later call on the SAME sampler through a per-step path (`num_steps=None`, `sample`) must complete it first.  One sampler
+    alternates device-resident and per-step calls, the other takes the per-step path throughout: identical experiences, call by call."""
+    import os
+    from maro_amd.cim.engine import CimBatchEngine
+    from maro_amd.cim.policy import ACTION_SPACE, FusedPerPortDQN, random_chains
+    topo, n, dur, calls = "toy.5p_ssddd_l0.5", 37, 150, (25, None, 40, 13, None, 60)
+    res = {}
+    for mode in ("1", "0"):
+        os.environ["MRX_SAMPLER_V2"] = mode
+        try:
+            eng = CimBatchEngine(topo, n, durations=dur, max_actions=1, max_snapshots=16)
+            smp = CimBatchSampler(eng, time_window=25)
+            actor = FusedPerPortDQN(eng, random_chains(5, smp.state_dim, len(ACTION_SPACE), hidden=(32, 16), head_hidden=8, seed=5), epsilon=0.3)
+            seeds = lambda ep: 700 + 13 * ep + torch.arange(n, dtype=torch.int64)   # noqa: E731
+            res[mode] = [smp.sample_fused(actor, num_steps=k, seeds=seeds, reset_every=8) for k in calls]
+            torch.cuda.synchronize()
+            assert int(eng.status.abs().sum()) == 0
+        finally:
+            os.environ.pop("MRX_SAMPLER_V2", None)
+    assert _compare_calls(res["1"], res["0"]) > 2000
+
+
+@pytest.mark.gpu
+def test_device_resident_loop_with_a_window_shorter_than_the_gaps_between_decisions():
+    """with a short reward window a running env's newest element can be old enough to be emitted in the call that wrote
+    it, before the next interaction has supplied its next state — the device path then completes it on the host before the
+    emission (mrx_k_cim_sampler_scan's info[3]).  toy.4p_ssdd_l0.0: decisions several ticks apart; window 2."""
+    import os
+    from maro_amd.cim.engine import CimBatchEngine
+    from maro_amd.cim.policy import ACTION_SPACE, FusedPerPortDQN, random_chains
+    topo, n, dur, calls = "toy.4p_ssdd_l0.0", 29, 200, (5, 1, 17, 3, 40, 2, 9)
+    res, late = {}, 0
+    for mode in ("1", "0"):
+        os.environ["MRX_SAMPLER_V2"] = mode
+        try:
+            eng = CimBatchEngine(topo, n, durations=dur, max_actions=1, max_snapshots=16)
+            smp = CimBatchSampler(eng, time_window=2)
+            actor = FusedPerPortDQN(eng, random_chains(4, smp.state_dim, len(ACTION_SPACE), hidden=(32, 16), head_hidden=8, seed=9), epsilon=0.3)
+            seeds = lambda ep: 90 + 7 * ep + torch.arange(n, dtype=torch.int64)   # noqa: E731
+            out = []
+            for k in calls:
+                out.append(smp.sample_fused(actor, num_steps=k, seeds=seeds, reset_every=4))
+                if mode == "1":
+                    late += int(smp._info_host[3])
+            res[mode] = out
+            torch.cuda.synchronize()
+            assert int(eng.status.abs().sum()) == 0
+        finally:
+            os.environ.pop("MRX_SAMPLER_V2", None)
+    assert late > 0, "the case this test is about did not occur"
+    assert _compare_calls(res["1"], res["0"]) > 300

@@ -36,6 +36,10 @@
 
 struct Pat {
   int n_envs, FW, PW, PWH, RINGW, MTW, CTW, S, NTP, T, order_bytes, order_tiled, REC_W, SROW, V, obs_words, work;
+  int rotate;     // 1: the live frame lives in ring slot fi % S (no post_step copy: the step's first snapshot is a 3-row patch; the write-back goes to the next slot)
+  int mt_load;    // words of the RNG state a full-path step loads (624 = all; by-need loading: ~384)
+  int fast_table; // 1: the fast path reads the header + a 256-byte decision table instead of 14 rows of the frame
+  int ring_half;  // 1: the pending-return ring is stored as uint16 (two pairs per word)
   int32_t *live, *ring, *ring_fi, *priv, *mt, *rec, *tick, *dec, *obsv;
   uint32_t* stops;
   const int32_t* ctab;
@@ -82,12 +86,16 @@ extern "C" __global__ void __launch_bounds__(64) k_pattern(Pat P, const int32_t*
   if (!(e & FULL_FLAG)) {  // ---------------- fast path: one trip, rows into registers
     const int v = lane < P.V ? lane : 0;
     int acc = lane < 16 ? g_priv[lane] : 0;
+    if (P.fast_table) {
+      acc += g_priv[16 + lane];   // 256-byte table of the tick's pending decisions (behind the header)
+    } else {
 #pragma unroll
-    for (int r = 0; r < 7; r++) acc += g_live[264 + r * P.V + v];
+      for (int r = 0; r < 7; r++) acc += g_live[264 + r * P.V + v];
 #pragma unroll
-    for (int k = 0; k < 4; k++) acc += g_live[P.FW - 256 + lane + 64 * k];
+      for (int k = 0; k < 4; k++) acc += g_live[P.FW - 256 + lane + 64 * k];
 #pragma unroll
-    for (int a = 0; a < 3; a++) acc += g_live[264 + (8 + a) * P.V + v];
+      for (int a = 0; a < 3; a++) acc += g_live[264 + (8 + a) * P.V + v];
+    }
     acc += P.act[(size_t)env * 4 + (lane & 3)];
     // the words the step changes (lane 0), decision / metrics / hint
     const int x = __builtin_amdgcn_readfirstlane(acc);
@@ -95,6 +103,7 @@ extern "C" __global__ void __launch_bounds__(64) k_pattern(Pat P, const int32_t*
       g_live[22 + (x & 15)] = x; g_live[264 - 22 + (x & 15)] = x; g_live[264 + P.V + (x & 31)] = x; g_live[264 + 3 * P.V + (x & 31)] = x;
       g_live[P.FW - 200 + (x & 127)] = x;
       g_priv[2] = x; g_priv[3] = x; g_priv[4] = x; g_priv[5] = x; g_priv[6] = x;
+      if (P.fast_table) { g_priv[16 + (x & 7) * 8] = x; g_priv[17 + (x & 7) * 8] = x; g_priv[18 + ((x >> 3) & 7) * 8] = x; }
       P.obs[(size_t)env * P.obs_words + (x & 63)] = (double)x;
       P.obsv[(size_t)env * 4] = x; P.obsv[(size_t)env * 4 + 1] = x; P.obsv[(size_t)env * 4 + 2] = x;
       P.met[(size_t)env * 3] = x; P.met[(size_t)env * 3 + 1] = x; P.met[(size_t)env * 3 + 2] = x;
@@ -108,12 +117,23 @@ extern "C" __global__ void __launch_bounds__(64) k_pattern(Pat P, const int32_t*
   int32_t* l_priv = l_frame + P.FW;
   int32_t* l_mt = l_priv + P.PWH;
   int32_t* l_ctab = l_mt + P.MTW;
+  int t0r = 0;
+  if (P.rotate) {  // the live frame's slot depends on the env's tick: one dependent word first
+    t0r = __builtin_amdgcn_readfirstlane(P.tick[env]) & 0x3ff;
+    g_live = P.ring + ((size_t)env * P.S + (t0r % P.S)) * P.FW;
+  }
   dma_rows(l_frame, g_live, P.FW);
   dma_rows(l_priv, g_priv, P.PWH);
   int ring[12];
+  if (P.ring_half) {
+    const uint16_t* gr = (const uint16_t*)(g_priv + P.PWH);
 #pragma unroll
-  for (int r = 0; r < 12; r++) ring[r] = (r * 64 < P.RINGW) ? g_priv[P.PWH + (r * 64 + lane < P.RINGW ? r * 64 + lane : 0)] : 0;
-  dma_rows(l_mt, P.mt + ((size_t)env * 3 + 1) * P.MTW, P.MTW);
+    for (int r = 0; r < 12; r++) ring[r] = (r * 64 < P.RINGW) ? (int)gr[r * 64 + lane < P.RINGW ? r * 64 + lane : 0] : 0;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 12; r++) ring[r] = (r * 64 < P.RINGW) ? g_priv[P.PWH + (r * 64 + lane < P.RINGW ? r * 64 + lane : 0)] : 0;
+  }
+  dma_rows(l_mt, P.mt + ((size_t)env * 3 + 1) * P.MTW, P.mt_load);
   dma_rows(l_ctab, P.ctab, P.CTW);
   int a = P.act[(size_t)env * 4 + (lane & 3)];
   __builtin_amdgcn_s_waitcnt(0);
@@ -154,7 +174,13 @@ extern "C" __global__ void __launch_bounds__(64) k_pattern(Pat P, const int32_t*
       acc += x;
     }
     // post_step snapshot (resolution 1: every tick)
-    store_rows_nt(P.ring + ((size_t)env * P.S + (tt % P.S)) * P.FW, l_frame, P.FW);
+    if (P.rotate && i == 0) {   // the slot already holds the frame as loaded: patch the rows the action / post_step changed
+      int32_t* slot = P.ring + ((size_t)env * P.S + (tt % P.S)) * P.FW;
+      if (lane < 22) { slot[22 + lane] = acc; slot[242 + lane] = acc; slot[220 + lane] = acc; }
+      if (lane == 0) { slot[264 + 46 + (acc & 31)] = acc; slot[264 + 3 * 46 + (acc & 31)] = acc; slot[P.FW - 200 + (acc & 127)] = acc; }
+    } else {
+      store_rows_nt(P.ring + ((size_t)env * P.S + (tt % P.S)) * P.FW, l_frame, P.FW);
+    }
     if (lane == 0) P.ring_fi[(size_t)env * P.S + (tt % P.S)] = tt;
   }
   t += nt;
@@ -168,11 +194,18 @@ extern "C" __global__ void __launch_bounds__(64) k_pattern(Pat P, const int32_t*
     l_priv[0] = t;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  store_rows_nt(g_live, l_frame, P.FW);
+  store_rows_nt(P.rotate ? P.ring + ((size_t)env * P.S + ((t0r + nt) % P.S)) * P.FW : g_live, l_frame, P.FW);
   store_rows_nt(g_priv, l_priv, P.PWH);
+  if (P.ring_half) {
+    uint16_t* gr = (uint16_t*)(g_priv + P.PWH);
 #pragma unroll
-  for (int r = 0; r < 12; r++)
-    if (r * 64 + lane < P.RINGW) g_priv[P.PWH + r * 64 + lane] = ring[r] + acc;
+    for (int r = 0; r < 12; r++)
+      if (r * 64 + lane < P.RINGW) gr[r * 64 + lane] = (uint16_t)(ring[r] + acc);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 12; r++)
+      if (r * 64 + lane < P.RINGW) g_priv[P.PWH + r * 64 + lane] = ring[r] + acc;
+  }
   if (mixu((unsigned)env, (unsigned)step + 77u) % 3u == 0u) store_rows_nt(P.mt + ((size_t)env * 3 + 1) * P.MTW, l_mt, P.MTW);
 }
 
@@ -221,17 +254,20 @@ struct Args {
   double full_frac = 0.41;
   int gather = 0, shuffle = 0, fast_lanes = 0, probe = 0, residency = 0;
   int fw = 1372, pwh = 312, ringw = 471, ctw = 608;
+  int rotate = 0, mt_load = 624, fast_table = 0, ring_half = 0;
   const char* json_out = nullptr;
   long long gather_mb = 3900;
   int row_bytes = 640;
 };
 
 static double bytes_per_step_full(const Pat& P, double mean_ticks, double mt_store_frac) {
-  const double rd = 4.0 * (P.FW + P.PWH + P.RINGW + P.MTW) + 16 + mean_ticks * (P.NTP * P.order_bytes + 16 + 4 * 64 * 4 * 2 * 0.25);
-  const double wr = mean_ticks * (4.0 * P.FW + 4) + 8.0 * P.obs_words + 32 + 12 + 24 + 6 + 4.0 * (P.FW + P.PWH + P.RINGW) + mt_store_frac * 4.0 * P.MTW;
+  const double ringb = (P.ring_half ? 2.0 : 4.0) * P.RINGW;
+  const double rd = 4.0 * (P.FW + P.PWH + P.mt_load) + ringb + 16 + (P.rotate ? 4 : 0) + mean_ticks * (P.NTP * P.order_bytes + 16 + 4 * 64 * 4 * 2 * 0.25);
+  const double snap = P.rotate ? (mean_ticks - 1.0) * (4.0 * P.FW) + 3 * 88 + 12 + 4 * mean_ticks : mean_ticks * (4.0 * P.FW + 4);
+  const double wr = snap + 8.0 * P.obs_words + 32 + 12 + 24 + 6 + 4.0 * (P.FW + P.PWH) + ringb + mt_store_frac * 4.0 * P.MTW;
   return rd + wr;
 }
-static double bytes_per_step_fast(const Pat& P) { return 64 + (7 + 3) * 46 * 4 + 4 * 256 + 16 + 5 * 4 + 5 * 4 + 8 + 12 + 24 + 2 + 32; }
+static double bytes_per_step_fast(const Pat& P) { return 64 + (P.fast_table ? 256 + 12 : (7 + 3) * 46 * 4 + 4 * 256) + 16 + 5 * 4 + 5 * 4 + 8 + 12 + 24 + 2 + 32; }
 
 int main(int argc, char** argv) {
   Args A;
@@ -252,6 +288,10 @@ int main(int argc, char** argv) {
     else if (is("--pwh")) A.pwh = atoi(argv[++i]);
     else if (is("--ringw")) A.ringw = atoi(argv[++i]);
     else if (is("--ctw")) A.ctw = atoi(argv[++i]);
+    else if (is("--rotate")) A.rotate = atoi(argv[++i]);
+    else if (is("--mt-load")) A.mt_load = atoi(argv[++i]);
+    else if (is("--fast-table")) A.fast_table = atoi(argv[++i]);
+    else if (is("--ring-half")) A.ring_half = atoi(argv[++i]);
     else if (is("--json-out")) A.json_out = argv[++i];
     else if (is("--residency")) A.residency = atoi(argv[++i]);
     else if (is("--fast-lanes")) A.fast_lanes = atoi(argv[++i]);
@@ -287,6 +327,7 @@ int main(int argc, char** argv) {
   base.n_envs = A.envs; base.FW = A.fw; base.PWH = A.pwh; base.RINGW = A.ringw < 768 ? A.ringw : 768; base.PW = (A.pwh + base.RINGW + 3) / 4 * 4; base.MTW = 624; base.CTW = A.ctw; base.S = 4; base.NTP = 160; base.T = A.T;
   base.order_bytes = A.order_bytes; base.order_tiled = A.tiled; base.REC_W = 4096; base.V = 46; base.SROW = 46 * 208; base.obs_words = 22 * 7;
   base.work = A.work;
+  base.rotate = A.rotate; base.mt_load = A.mt_load / 4 * 4; base.fast_table = A.fast_table; base.ring_half = A.ring_half;
   const int G = A.streams, N = A.envs;
   std::vector<Pat> P(G, base);
   std::vector<hipStream_t> st(G);
@@ -362,8 +403,8 @@ int main(int argc, char** argv) {
   }
   printf("{\"bench\": \"%s\",", A.probe == 1 ? "probe_empty" : A.probe == 2 ? "probe_work" : "pattern");
   printf(" \"envs_per_launch\": %d, \"streams\": %d, \"lds_bytes\": %d, \"waves_per_cu\": %d, \"order_bytes\": %d, \"order_tiled\": %d, "
-         "\"work\": %d, \"shuffle\": %d, \"fast_lanes\": %d, \"full_frac\": %.3f, \"bytes_per_launch\": %.0f, \"us_per_batch_step\": %.2f, \"env_steps_per_s\": %.4g, \"GBps\": %.1f, \"frac_of_8TBps\": %.3f}\n",
-         N, G, A.lds, per_cu, A.order_bytes, A.tiled, A.work, A.shuffle, A.fast_lanes, A.full_frac, per_launch, sec / A.launches * 1e6, (double)N * G * A.launches / sec, gbps, gbps / 8000.0);
+         "\"work\": %d, \"rotate\": %d, \"mt_load\": %d, \"fast_table\": %d, \"ring_half\": %d, \"shuffle\": %d, \"fast_lanes\": %d, \"full_frac\": %.3f, \"bytes_per_launch\": %.0f, \"us_per_batch_step\": %.2f, \"env_steps_per_s\": %.4g, \"GBps\": %.1f, \"frac_of_8TBps\": %.3f}\n",
+         N, G, A.lds, per_cu, A.order_bytes, A.tiled, A.work, A.rotate, base.mt_load, A.fast_table, A.ring_half, A.shuffle, A.fast_lanes, A.full_frac, per_launch, sec / A.launches * 1e6, (double)N * G * A.launches / sec, gbps, gbps / 8000.0);
   if (A.json_out) {
     FILE* f = fopen(A.json_out, "w");
     if (f) {
