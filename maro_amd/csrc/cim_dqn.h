@@ -71,40 +71,48 @@ __host__ __device__ inline long long dq_w_index(int k, int n, int N) {
 
 typedef float dq_f4 __attribute__((ext_vector_type(4)));
 
-template <int MT, int NT>
+// DQ_PFL k-blocks of weights are in flight per wave (the rotating buffer below).  A layer's time is (its k-blocks / DQ_PFL)
+// memory latencies — a workgroup is alone on its CU at the batch sizes of config 5, so nothing else hides them — and the
+// buffer costs DQ_PFL x NT x 4 registers: narrow layers (NT = 1, 2) therefore fetch deeper at the same register count
+// (DQ_PFL x NT = 16 for one MFMA row tile), e.g. all 16 k-blocks of the 256 -> 32 head at once instead of four rounds of four.
+template <int MT, int NT, int DQ_PFL>
 __device__ __forceinline__ void dq_dense(float* X, const float* __restrict__ Wp, const float* __restrict__ bias, int Kpad, int Npad,
                                          int m0, int nt0, int nt_step, bool idle, bool act, float slope) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  // the bias is requested with the first weights, not after the k loop (one memory latency per layer less)
+  float bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) bv[nt] = idle ? 0.f : bias[(nt0 + nt * nt_step) * 16 + r];
   dq_f4 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; mt++)
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) acc[mt][nt] = dq_f4{0.f, 0.f, 0.f, 0.f};
   const int nkb = idle ? 0 : Kpad >> 4;
-  // B operands (weights, L2) are fetched DQ_PF k-blocks ahead into a rotating register buffer: a narrow layer gives a wave
+  // B operands (weights, L2) are fetched DQ_PFL k-blocks ahead into a rotating register buffer: a narrow layer gives a wave
   // only a few MFMAs per k-block, far less than the L2 latency
-  dq_f4 bq[DQ_PF][NT];
+  dq_f4 bq[DQ_PFL][NT];
   const float* wlane = Wp + ((size_t)nt0 * 16 + r) * 16 + g * 4;
   const float* xlane = X + (m0 * 16 + r) * DQ_LD + g * 4;
-  const int nfull = nkb / DQ_PF, rem = nkb - nfull * DQ_PF;
+  const int nfull = nkb / DQ_PFL, rem = nkb - nfull * DQ_PFL;
   if (nkb > 0) {
 #pragma unroll
-    for (int p = 0; p < DQ_PF; p++)
+    for (int p = 0; p < DQ_PFL; p++)
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) bq[p][nt] = *(const dq_f4*)(wlane + ((size_t)min(p, nkb - 1) * Npad + (size_t)nt * nt_step * 16) * 16);
   }
   // Static register slots (a rotating buffer's moves would wait for the loads they move) and no control flow inside the
-  // loop (a branch merge makes the compiler drain every outstanding load): slot p is refilled with the block DQ_PF ahead
+  // loop (a branch merge makes the compiler drain every outstanding load): slot p is refilled with the block DQ_PFL ahead
   // right after it is consumed; past the end the last block is re-fetched and never used.
   for (int i = 0; i < nfull; i++) {
 #pragma unroll
-    for (int p = 0; p < DQ_PF; p++) {
-      const int kb = i * DQ_PF + p;
+    for (int p = 0; p < DQ_PFL; p++) {
+      const int kb = i * DQ_PFL + p;
       dq_f4 a[MT], b[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) {
         b[nt] = bq[p][nt];
-        bq[p][nt] = *(const dq_f4*)(wlane + ((size_t)min(kb + DQ_PF, nkb - 1) * Npad + (size_t)nt * nt_step * 16) * 16);
+        bq[p][nt] = *(const dq_f4*)(wlane + ((size_t)min(kb + DQ_PFL, nkb - 1) * Npad + (size_t)nt * nt_step * 16) * 16);
       }
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) a[mt] = *(const dq_f4*)(xlane + mt * 16 * DQ_LD + kb * 16);
@@ -117,9 +125,9 @@ __device__ __forceinline__ void dq_dense(float* X, const float* __restrict__ Wp,
     }
   }
 #pragma unroll
-  for (int p = 0; p + 1 < DQ_PF; p++)
+  for (int p = 0; p + 1 < DQ_PFL; p++)
     if (p < rem) {  // the tail blocks are already in their slots
-      const int kb = nfull * DQ_PF + p;
+      const int kb = nfull * DQ_PFL + p;
       dq_f4 a[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) a[mt] = *(const dq_f4*)(xlane + mt * 16 * DQ_LD + kb * 16);
@@ -135,12 +143,11 @@ __device__ __forceinline__ void dq_dense(float* X, const float* __restrict__ Wp,
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
       const int col = (nt0 + nt * nt_step) * 16 + r;
-      const float bv = bias[col];
 #pragma unroll
       for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          float v = acc[mt][nt][i] + bv;  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + i
+          float v = acc[mt][nt][i] + bv[nt];  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + i
           if (act) v = v > 0.f ? v : v * slope;
           X[((m0 + mt) * 16 + g * 4 + i) * DQ_LD + col] = v;
         }
@@ -155,21 +162,21 @@ __device__ __forceinline__ void dq_layer(float* X, const float* Wp, const float*
   const int w = threadIdx.x >> 6;
   if constexpr (TILE == 32) {
     switch (Npad) {
-      case 16: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, w & 1, 0, 1, w >= 2, act, slope); break;   // 2 tiles: waves 2, 3 idle
-      case 32: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, w >> 1, w & 1, 1, false, act, slope); break;
-      case 64: dq_dense<2, 1>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-      case 128: dq_dense<2, 2>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-      case 192: dq_dense<2, 3>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-      default: dq_dense<2, 4>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+      case 16: dq_dense<1, 1, 8>(X, Wp, bias, Kpad, Npad, w & 1, 0, 1, w >= 2, act, slope); break;   // 2 tiles: waves 2, 3 idle
+      case 32: dq_dense<1, 1, 8>(X, Wp, bias, Kpad, Npad, w >> 1, w & 1, 1, false, act, slope); break;
+      case 64: dq_dense<2, 1, 8>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+      case 128: dq_dense<2, 2, DQ_PF>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+      case 192: dq_dense<2, 3, DQ_PF>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+      default: dq_dense<2, 4, DQ_PF>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
     }
   } else {   // 16 rows: one MFMA row tile — half the matrix work per workgroup, twice the workgroups (finer balance over the CUs)
     switch (Npad) {
-      case 16: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, 0, 0, 1, w >= 1, act, slope); break;
-      case 32: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, 0, w & 1, 1, w >= 2, act, slope); break;
-      case 64: dq_dense<1, 1>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-      case 128: dq_dense<1, 2>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-      case 192: dq_dense<1, 3>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-      default: dq_dense<1, 4>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+      case 16: dq_dense<1, 1, 16>(X, Wp, bias, Kpad, Npad, 0, 0, 1, w >= 1, act, slope); break;
+      case 32: dq_dense<1, 1, 16>(X, Wp, bias, Kpad, Npad, 0, w & 1, 1, w >= 2, act, slope); break;
+      case 64: dq_dense<1, 1, 16>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+      case 128: dq_dense<1, 2, 8>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+      case 192: dq_dense<1, 3, 5>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+      default: dq_dense<1, 4, DQ_PF>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
     }
   }
 }
@@ -297,23 +304,52 @@ __device__ __forceinline__ void mrx_dqn_forward_body(const CimParams& K, const c
 
   // ---- per-row lookups: env, the node list [port] + future_stop_list, the frame of each look-back tick;
   //      per-column descriptors: which (tick, node, frame word) a state column reads
+  // what the LAST phase of row t needs (the decision row, two words of the live frame, the cache head, the env's seed) is
+  // requested here, by the thread that will use it: those were two more dependent memory latencies after the dense chain
+  int32_t dq_d[5] = {0, 0, 0, 0, 0};
+  int32_t dq_space = 0, dq_early = 0;
+  long long dq_head = 0, dq_seed = 0;
   if (t < DQ_TILE) {
     const int env = t < rows ? list[t] : -1;
     r_env[t] = env;
     if (env >= 0) {
       const int32_t* d = decisions + (size_t)env * 8;
-      const int32_t* now = frame_of(K, env, d[0]);  // snapshots[tick : vessel : future_stop_list]
+#pragma unroll
+      for (int i = 0; i < 5; i++) dq_d[i] = d[i];
+      {
+        const int32_t* live = K.live + (size_t)env * K.FW;  // the decision's frame is the live frame
+        const int v = (unsigned)dq_d[2] < (unsigned)K.V ? dq_d[2] : 0;
+        dq_space = live[frame_word(K, 1, VA_REMAINING_SPACE, v, 0)];
+        dq_early = live[frame_word(K, 1, VA_EARLY_DISCHARGE, v, 0)];
+        if (R.on) dq_head = R.head[env];
+        if (M.epsilon > 0.f) dq_seed = K.seed[env];
+      }
+      // snapshots[tick : vessel : future_stop_list] (cim::stop_list_value, slot by slot): the frame's last_loc_idx is requested
+      // from the live frame — which the decision's frame is — TOGETHER with frame_of's own loads and the route words
+      const int32_t* livef = K.live + (size_t)env * K.FW;
+      const int vv = (unsigned)dq_d[2] < (unsigned)K.V ? dq_d[2] : 0;
+      const int kw = frame_word(K, 1, VA_LAST_LOC_IDX, vv, 0);
+      const int k_live = livef[kw];
+      const int Lr = K.v_route_len[vv], rb = K.v_route_base[vv], start = K.v_start[vv];
+      const int32_t* now = frame_of(K, env, dq_d[0]);
       r_node[t][0] = d[1];
       r_node[t][DQ_MAX_NODES - 1] = d[2];
       if (R.on) {
         const long long ring = (long long)R.cap - 1;
         const int agent = d[1] < 0 ? 0 : (d[1] >= R.P ? R.P - 1 : d[1]);
         const long long prev = R.last[(size_t)env * R.P + agent];
-        r_slot[t][0] = (int)(R.head[env] & ring);
+        r_slot[t][0] = (int)(dq_head & ring);
         r_slot[t][1] = R.prev_active[env] ? (int)R.prev_j[env] : -1;
         r_slot[t][2] = prev >= 0 ? (int)(prev & ring) : -1;
       }
-      for (int j = 1; j < M.n_nodes; j++) r_node[t][j] = now ? stop_list_value(K, env, now, VA_FUTURE_STOP_LIST, d[2], j - 1) : 0;
+      {
+        const int k = now == livef ? k_live : now ? now[kw] : 0;
+        int x = (start + k) % Lr;
+        for (int j = 1; j < M.n_nodes; j++) {
+          x = (x + 1 == Lr) ? 0 : x + 1;
+          r_node[t][j] = now ? (int)K.route_port[rb + x] : 0;
+        }
+      }
     }
   }
   for (int i = t; i < DQ_TILE * n_ticks; i += blockDim.x) {
@@ -399,21 +435,20 @@ __device__ __forceinline__ void mrx_dqn_forward_body(const CimParams& K, const c
       if (q_out) q_out[(size_t)env * A + a] = q;
       if (q > bq) { bq = q; best = a; }
     }
-    const int32_t* d = decisions + (size_t)env * 8;
+    const int32_t* d = dq_d;  // (requested with the row lookups)
     if (M.epsilon > 0.f) {  // counter-based epsilon-greedy keyed on (env seed, tick, vessel)
-      const unsigned long long x = dq_mix64((unsigned long long)K.seed[env], (((unsigned long long)(unsigned)d[0] << 8) | (unsigned)d[2]) + 0x200000000ull);
+      const unsigned long long x = dq_mix64((unsigned long long)dq_seed, (((unsigned long long)(unsigned)d[0] << 8) | (unsigned)d[2]) + 0x200000000ull);
       if ((double)(x >> 11) * (1.0 / 9007199254740992.0) < (double)M.epsilon) best = (int)(dq_mix64(x, 1) % (unsigned long long)A);
     }
     if (choice_out) choice_out[env] = best;
-    const int32_t* live = K.live + (size_t)env * K.FW;  // the decision's frame is the live frame
     const double percent = fabs(M.action_space[best]);
     const double load = (double)d[3], discharge = (double)d[4];
     const bool is_load = 2 * best < A;  // model_action < len(action_space) / 2
     double qty;
     if (is_load) {
-      qty = fmin(rint(percent * load), (double)live[frame_word(K, 1, VA_REMAINING_SPACE, d[2], 0)]);
+      qty = fmin(rint(percent * load), (double)dq_space);
     } else {
-      const double early = (double)live[frame_word(K, 1, VA_EARLY_DISCHARGE, d[2], 0)];
+      const double early = (double)dq_early;
       const double plan = percent * (discharge + early) - early;
       qty = plan > 0 ? rint(plan) : rint(percent * discharge);
     }
@@ -424,7 +459,7 @@ __device__ __forceinline__ void mrx_dqn_forward_body(const CimParams& K, const c
     a[3] = is_load ? MRX_ACTION_LOAD : MRX_ACTION_DISCHARGE;
     if (R.on) {   // the scalar half of the transition (mrx_k_cim_sampler_record's lane 0)
       const int agent = d[1] < 0 ? 0 : (d[1] >= R.P ? R.P - 1 : d[1]);
-      const long long q = R.head[env];
+      const long long q = dq_head;
       const size_t base = (size_t)env * R.cap, ci = base + r_slot[t][0];
       R.c_tick[ci] = d[0];
       R.c_agent[ci] = agent;
