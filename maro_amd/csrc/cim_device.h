@@ -878,11 +878,228 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
 }
 
 // ==========================================================================================
+// ORDER TABLE, branch-free form (CimParams::order_fast; the plan proves what it needs: cim_layout.h).  Same draws, same fp64
+// operations in the same order as gen_orders (cim_data_container.py:309-398), organised so that a tick is ~350 vector
+// instructions instead of ~1100 — the generic generator saturates the chip's VALU issue for 30 ms per reset of 16 384 envs:
+//  * the stream lives in a TWO-block window (current block + the one after it, 1248 words): a tick's draws (<= 384 words)
+//    never straddle a regeneration, so every draw is one unconditional 8-byte LDS read; the next block is generated into the
+//    buffer that has just been used up, in four rounds (192 / 192 / 192 / 48 words: the recurrence distance is 227);
+//  * the P source draws and the NT target draws of a tick are handed out as ONE run of P + NT draws over three lane batches
+//    (the reference stops drawing targets at the port where the orders run out: those ports' quantities are 0 either way and
+//    the cursor advances by what the reference would have drawn);
+//  * the noised ratios go to LDS in per-list segments padded to four entries with +0.0, and P + 1 lanes add their list
+//    left to right (the P target lists and the source list) in lock step, four terms per round trip, no lane-dependent
+//    control flow: x + 0.0 == x for every non-negative x;
+//  * one reciprocal per PORT instead of one division per PAIR: the fp64 division the compiler emits is
+//    y = refine(refine(rcp(d))), q0 = n * y, r = fma(-d, q0, n), q = fma(r, y, q0) for operands that need no scaling
+//    (v_div_scale / v_div_fmas / v_div_fixup are the identity on [2^-40, 2^20], which the plan guarantees); y only depends on
+//    the denominator, so computing it once per port and finishing each pair with three operations gives the same bits;
+//  * all quantities fit int32 (the uint16 table's proof), the row is assembled as uint16 in LDS and leaves in 16-byte stores.
+MRX_DEV double of_recip(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(d);
+  y = fma(y, fma(-d, y, 1.0), y);
+  y = fma(y, fma(-d, y, 1.0), y);
+  return y;
+#else
+  return d;  // (host build of the same source: of_div divides)
+#endif
+}
+MRX_DEV double of_div(double n, double d, double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double q0 = n * y;
+  return fma(fma(-d, q0, n), y, q0);
+#else
+  (void)y;
+  return n / d;
+#endif
+}
+
+// next block of the MT19937 stream: nxt[k] = f(cur[k], cur[k + 1], k < 227 ? cur[k + 397] : nxt[k - 227]); cur / nxt are the two
+// halves of the window (word offsets 0 / 624 in either order)
+MRX_DEV void of_next_block(uint32_t* win, int cur, int nxt) {
+  const int l = wave::lane();
+#define MRX_OF_ROUND(K0, N)                                                                                  \
+  _Pragma("unroll") for (int j = 0; j < ((N) + 63) / 64; j++) {                                              \
+    const int k = (K0) + j * 64 + l;                                                                         \
+    const bool on = j * 64 + l < (N);                                                                        \
+    const int kc = on ? k : (K0);                                                                            \
+    const uint32_t a = win[cur + kc], b = win[kc + 1 == MT_WORDS ? nxt : cur + kc + 1];                      \
+    const uint32_t m = win[kc < 227 ? cur + kc + 397 : nxt + kc - 227];                                      \
+    const uint32_t y = (a & 0x80000000U) | (b & 0x7fffffffU);                                                \
+    x[j] = m ^ (y >> 1) ^ ((uint32_t)(-(int32_t)(y & 1U)) & 0x9908b0dfU);                                    \
+  }                                                                                                          \
+  wave::sync();                                                                                              \
+  _Pragma("unroll") for (int j = 0; j < ((N) + 63) / 64; j++)                                                \
+    if (j * 64 + l < (N)) win[nxt + (K0) + j * 64 + l] = x[j];                                               \
+  wave::sync();
+  uint32_t x[3];
+  MRX_OF_ROUND(0, 192)
+  MRX_OF_ROUND(192, 192)
+  MRX_OF_ROUND(384, 192)
+  MRX_OF_ROUND(576, 48)
+#undef MRX_OF_ROUND
+}
+
+MRX_DEV void gen_order_table_fast(const CimParams& K, int env, int32_t* lds) {
+  const int lane = wave::lane();
+  const int P = KD(P), NT = KD(NT), ND = P + NT;
+  uint32_t* win = (uint32_t*)(lds + KD(gf_win));
+  double* val = (double*)(lds + KD(gf_val));
+  int32_t* rec = lds + KD(gf_rec);
+  int32_t* pre1 = lds + KD(gf_pre);
+  uint16_t* row16 = (uint16_t*)(lds + KD(gf_row));
+  int32_t* seg = lds + KD(gf_seg);
+  const int ZERO = KD(gf_slots), TRASH = KD(gf_slots) + 4;
+  copy_in_async((int32_t*)win, (const int32_t*)(K.mt + ((size_t)env * MTS_COUNT + MTS_ORDER) * MT_WORDS), MT_WORDS);
+
+  // ---- static per-lane words (registers for the whole episode)
+  // summation lanes: lane p < P adds port p's target list, lane P the source list
+  const int cnt_p = lane < P ? K.tgt_off[lane + 1] - K.tgt_off[lane] : 0;
+  const int pad_p = (cnt_p + 3) & ~3;
+  const int Ppad = (P + 3) & ~3;
+  const int incl_p = wave::scan_incl_add(pad_p);
+  const int sum_seg = lane < P ? Ppad + incl_p - pad_p : 0;
+  const int sum_len = lane < P ? pad_p : lane == P ? Ppad : 0;
+  const int toff_l = K.tgt_off[lane <= P ? lane : P];  // lane p: first pair of port p; lane P: NT
+  if (lane < P) seg[lane] = sum_seg;
+  for (int i = lane; i < KD(gf_slots) + 6; i += 64) val[i] = 0.0;   // the pads stay +0.0 for good
+  for (int i = lane; i < KD(NTP) / 2; i += 64) ((uint32_t*)row16)[i] = 0u;
+  if (lane == 0) {
+    pre1[0] = 0;
+    double* r = (double*)(rec + P * 8);  // the record of the lanes that hold no pair: 0 orders of a list whose sum is 1
+    r[0] = 1.0; r[1] = 1.0;
+    rec[P * 8 + 4] = 0;
+  }
+  wave::sync();
+  // draw lanes: draw d = 64 b + lane of a tick's run is source port d (d < P) or order pair d - P
+  double base[3], negn[3], cm[3];
+  int slot[3], recw[3], prew[3], kk[3];
+  bool pair[3];
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    const int d = b * 64 + lane;
+    const bool valid = d < ND, src = d < P;
+    const int k = valid && !src ? d - P : 0;
+    const int sp = src ? d : K.pair_src[k];
+    const double bs = src ? K.src_base[d] : K.tgt_base[k], nz = src ? K.src_noise[d] : K.tgt_noise[k];
+    base[b] = bs;
+    negn[b] = -nz;
+    cm[b] = (nz - negn[b]) * (1.0 / 9007199254740992.0);  // (noise - a) * 2^-53: r = m * 2^-53 exactly, so (noise - a) * r == cm * m
+    const int off = K.tgt_off[sp];
+    slot[b] = !valid ? TRASH : src ? d : seg[sp] + (k - off);
+    recw[b] = (valid && !src ? sp : P) * 8;
+    prew[b] = off;
+    kk[b] = k;
+    pair[b] = valid && !src;
+    wave::touch(base[b]); wave::touch(negn[b]); wave::touch(cm[b]); wave::touch(slot[b]); wave::touch(recw[b]); wave::touch(prew[b]);
+  }
+  const int32_t* g_prop = K.order_prop + (size_t)env * KD(T);
+  const int D = KD(T) - KD(start_tick);
+  wave::lds_dma_wait();
+  // the stream as reset_env seeded it stands at the END of block 0 (cursor 624): block 1 = the first outputs
+  of_next_block(win, 0, MT_WORDS);
+  int cur = MT_WORDS, idx = 0;
+  of_next_block(win, MT_WORDS, 0);
+  for (int t0 = 0; t0 < D; t0 += 64) {
+    int mine = t0 + lane < D ? g_prop[KD(start_tick) + t0 + lane] : 0;  // 64 ticks of order_proportion per load
+    wave::touch(mine);  // wait for it HERE: inside the tick loop the same wait would also drain the previous tick's row stores
+    const int n_here = D - t0 < 64 ? D - t0 : 64;
+    for (int j = 0; j < n_here; j++) {  // wave-uniform
+      const int otg = wave::bcast(mine, j);
+      // ---- the tick's P + NT draws, noised ratios to their summation slots
+      double x[3];
+      const int wb = cur + idx;
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        int wi = wb + 2 * (b * 64 + lane);
+        wi = wi >= 2 * MT_WORDS ? wi - 2 * MT_WORDS : wi;  // (even, so the two words of a draw never straddle the wrap)
+        const uint32_t a = mt_temper(win[wi]), c = mt_temper(win[wi + 1]);
+        const double m = (double)(a >> 5) * 67108864.0 + (double)(c >> 6);
+        x[b] = base[b] + (negn[b] + cm[b] * m);
+        val[slot[b]] = x[b];
+      }
+      wave::sync();
+      // ---- list_sum_normalize's sums (utils.py:44-56), left to right, every list at once
+      double acc = 0.0;
+      for (int i = 0;; i += 4) {
+        const bool on = i < sum_len;
+        if (!wave::ballot(on)) break;
+        const double* q = val + (on ? sum_seg + i : ZERO);
+        const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        acc += q0; acc += q1; acc += q2; acc += q3;
+      }
+      // ---- sources (:340-375): c_p = ceil(orders * ratio_p), n_p = min(c_p, remaining), stop where remaining hits 0
+      double tot;
+      {
+        union { double d; int w[2]; } u, v;
+        u.d = acc;
+        v.w[0] = wave::bcast(u.w[0], P); v.w[1] = wave::bcast(u.w[1], P);
+        tot = v.d;
+      }
+      int c = 0;
+      if (lane < P) c = (int)ceil((double)otg * (x[0] / tot));
+      const int cq = c < otg ? c : otg;
+      const int incl = wave::scan_incl_add(lane < P ? cq : 0);
+      const int rem_top = otg - (incl - cq);  // remaining orders when port `lane` is reached
+      const int n_p = (lane < P && rem_top > 0) ? (c < rem_top ? c : rem_top) : 0;
+      const uint64_t zm = wave::ballot(lane < P && rem_top <= 0);
+      const int brk = zm ? (int)__builtin_ctzll(zm) : P;
+      const int NTb = wave::bcast(toff_l, brk);
+      if (lane < P) {
+        double* r = (double*)(rec + lane * 8);
+        r[0] = acc;
+        r[1] = of_recip(acc);
+        rec[lane * 8 + 4] = n_p;
+      }
+      wave::sync();
+      // ---- pairs (:376-393): raw = ceil(n_src * ratio), handed out in list order while the port's orders last
+      int qv[3], vv[3], np[3], inc[3];
+      int carry = 0;
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        const double* r = (const double*)(rec + recw[b]);
+        const double ts = r[0], y = r[1];
+        np[b] = rec[recw[b] + 4];
+        const int raw = (int)ceil((double)np[b] * of_div(x[b], ts, y));
+        qv[b] = (pair[b] && np[b] > 0) ? raw : 0;
+        vv[b] = qv[b] < np[b] ? qv[b] : np[b];
+        inc[b] = wave::scan_incl_add(vv[b]) + carry;
+        carry = wave::bcast(inc[b], 63);
+        if (pair[b]) pre1[kk[b] + 1] = inc[b];
+      }
+      wave::sync();
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        const int before = inc[b] - vv[b] - pre1[prew[b]];
+        const int rem = np[b] - before;
+        const int cur_q = rem <= 0 ? 0 : (qv[b] < rem ? qv[b] : rem);
+        if (pair[b]) row16[kk[b]] = (uint16_t)cur_q;
+      }
+      wave::sync();
+      {
+        const size_t e0 = (size_t)env * (size_t)K.orders_stride + (size_t)(t0 + j) * KD(NTP);
+        if (lane < KD(NTP) / 8) wave::st16_nt((int32_t*)((uint16_t*)K.orders + e0) + lane * 4, wave::lds_ld16((const int32_t*)row16 + lane * 4));
+      }
+      // ---- the cursor moves by what the reference drew: P sources + the targets of the ports before the break
+      idx += 2 * (P + NTb);
+      if (idx >= MT_WORDS) {  // wave-uniform: the current block is used up — the next one becomes current, its successor replaces it
+        idx -= MT_WORDS;
+        const int old = cur;
+        cur = MT_WORDS - cur;
+        of_next_block(win, cur, old);
+      }
+    }
+  }
+}
+
+// ==========================================================================================
 // ORDER TABLE (CimParams::pregen): in `fixed` order mode the orders of tick t are a function of
 // order_proportion[t] and the order_number stream alone (cim_data_container.py:309-398), so the whole episode is
 // drawn right after reset_env, in tick order, exactly as the reference would while stepping.  Runs as its own
 // kernel with a small LDS footprint (RNG state, generator scratch, tables: ~9 KB) so many envs are resident per CU.
 MRX_DEV void gen_order_table(const CimParams& K, int env, int32_t* lds) {
+  if (KD(order_fast)) { gen_order_table_fast(K, env, lds); return; }
   const int lane = wave::lane();
   Lds L = make_lds(K, lds);
   L.mt_ord = (uint32_t*)(lds + KD(g_mt0));

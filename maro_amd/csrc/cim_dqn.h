@@ -101,29 +101,29 @@ __device__ __forceinline__ void dq_dense(float* X, const float* __restrict__ Wp,
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) bq[p][nt] = *(const dq_f4*)(wlane + ((size_t)min(p, nkb - 1) * Npad + (size_t)nt * nt_step * 16) * 16);
   }
-  // Static register slots (a rotating buffer's moves would wait for the loads they move) and no control flow inside the
-  // loop (a branch merge makes the compiler drain every outstanding load): slot p is refilled with the block DQ_PFL ahead
-  // right after it is consumed; past the end the last block is re-fetched and never used.
-  for (int i = 0; i < nfull; i++) {
-#pragma unroll
-    for (int p = 0; p < DQ_PFL; p++) {
-      const int kb = i * DQ_PFL + p;
-      dq_f4 a[MT], b[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) {
-        b[nt] = bq[p][nt];
-        bq[p][nt] = *(const dq_f4*)(wlane + ((size_t)min(kb + DQ_PFL, nkb - 1) * Npad + (size_t)nt * nt_step * 16) * 16);
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++) a[mt] = *(const dq_f4*)(xlane + mt * 16 * DQ_LD + kb * 16);
-#pragma unroll
-      for (int s = 0; s < 4; s++)
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-          for (int nt = 0; nt < NT; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);
-    }
+  // Static register slots (a rotating buffer's moves would wait for the loads they move) and no control flow inside a pass
+  // (a branch merge makes the compiler drain every outstanding load): slot p is refilled with the block DQ_PFL ahead right
+  // after it is consumed.  The LAST full pass refills only when tail blocks follow it (then clamped: the last block may be
+  // fetched twice); a layer whose k-blocks are a whole number of passes issues no load it does not use — the barrier that
+  // ends the layer drains every load in flight, so a useless re-fetch late in the k loop cost the layer a memory latency.
+#define DQ_PASS(I, REFILL)                                                                                                  \
+  _Pragma("unroll") for (int p = 0; p < DQ_PFL; p++) {                                                                      \
+    const int kb = (I) * DQ_PFL + p;                                                                                        \
+    dq_f4 a[MT], b[NT];                                                                                                     \
+    _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {                                                                     \
+      b[nt] = bq[p][nt];                                                                                                    \
+      if (REFILL) bq[p][nt] = *(const dq_f4*)(wlane + ((size_t)min(kb + DQ_PFL, nkb - 1) * Npad + (size_t)nt * nt_step * 16) * 16); \
+    }                                                                                                                       \
+    _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[mt] = *(const dq_f4*)(xlane + mt * 16 * DQ_LD + kb * 16);           \
+    _Pragma("unroll") for (int s = 0; s < 4; s++)                                                                           \
+      _Pragma("unroll") for (int mt = 0; mt < MT; mt++)                                                                     \
+        _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                                                                   \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);                     \
   }
+  const int n_refill = rem > 0 ? nfull : nfull - 1;
+  for (int i = 0; i < n_refill; i++) { DQ_PASS(i, true) }
+  if (rem == 0 && nfull > 0) { DQ_PASS(nfull - 1, false) }
+#undef DQ_PASS
 #pragma unroll
   for (int p = 0; p + 1 < DQ_PFL; p++)
     if (p < rem) {  // the tail blocks are already in their slots

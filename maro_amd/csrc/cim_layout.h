@@ -412,6 +412,54 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
     k.g_srctab = g; g += 4 * P;  // source ratio tables (base, noise) as doubles
     k.g_ctab = (g + 3) / 4 * 4;
     k.lds_words_gen = (k.g_ctab + k.ctab_words + 3) / 4 * 4;
+    // cim::gen_order_table_fast (branch-free ticks, ~a third of the generic generator's instructions) relies on:
+    //  * the uint16 table's proof (order_half: no noised ratio can be negative, every quantity <= 65535 — so all integer work
+    //    fits int32 and `remaining` only shrinks), with a MARGIN: every noised ratio is exactly 0 or >= 2^-40 and every list's sum
+    //    is >= 2^-40, so no sum is zero and every quotient x / sum has x = 0 or both operands in [2^-40, 2^20] — the range in
+    //    which the hardware's fp64 division expansion applies no scaling and the per-port shared reciprocal reproduces it bit for bit;
+    //  * at most 192 draws per tick (three per lane) and a lane left for the source sum (P <= 63);
+    //  * the order stream in use (noise somewhere) and data generated on the device or from a dump (data_mode 0 / 1).
+    // MRX_ORDER_FAST=0 in the environment of the PLANNING process keeps the generic generator (tests compare the two).
+    k.order_fast = 0;
+    {
+      const char* ev = getenv("MRX_ORDER_FAST");
+      bool ok = k.order_half && k.use_order_rng && P <= 63 && P + NT <= 192 && !(ev && atoi(ev) == 0);
+      const double margin = 9.094947017729282e-13, cap = 1048576.0;  // 2^-40, 2^20
+      // (an entry may also be exactly zero — base 0, noise 0: a pure destination port — as long as its list's sum is not)
+      auto entry_ok = [&](double b, double n) { return (b == 0.0 && n == 0.0) || b - fabs(n) >= margin; };
+      double tot = 0, tot_min = 0;
+      for (int p = 0; p < P && ok; p++) {
+        if (!entry_ok(t->source_base[p], t->source_noise[p])) ok = false;
+        tot += t->source_base[p] + fabs(t->source_noise[p]);
+        tot_min += t->source_base[p] - fabs(t->source_noise[p]);
+      }
+      if (!(tot <= cap && tot_min >= margin)) ok = false;
+      for (int p = 0; p < P && ok; p++) {
+        double ts = 0, ts_min = 0;
+        for (int i = t->target_offset[p]; i < t->target_offset[p + 1]; i++) {
+          if (!entry_ok(t->target_base[i], t->target_noise[i])) ok = false;
+          ts += t->target_base[i] + fabs(t->target_noise[i]);
+          ts_min += t->target_base[i] - fabs(t->target_noise[i]);
+        }
+        if (t->target_offset[p + 1] > t->target_offset[p] && !(ts <= cap && ts_min >= margin)) ok = false;
+      }
+      if (ok) {
+        int slots = (P + 3) / 4 * 4;
+        for (int p = 0; p < P; p++) slots += (t->target_offset[p + 1] - t->target_offset[p] + 3) / 4 * 4;
+        k.gf_slots = slots;                  // [slots, slots + 4): zeros; [slots + 4, slots + 6): the idle lanes' scratch
+        int f = 0;
+        k.gf_win = f; f += 2 * MT_WORDS;
+        k.gf_val = f; f += 2 * (slots + 6);
+        f = (f + 3) / 4 * 4;
+        k.gf_rec = f; f += 8 * (P + 1);
+        k.gf_pre = f; f += NT + 2;
+        f = (f + 3) / 4 * 4;
+        k.gf_row = f; f += k.NTP / 2;
+        k.gf_seg = f; f += P + 1;
+        k.order_fast = 1;
+        k.lds_words_gen = (f + 3) / 4 * 4;
+      }
+    }
   }
   if ((int64_t)k.lds_words_reset * 4 > 160 * 1024 || (int64_t)k.lds_words * 4 > 160 * 1024) return fail("engine limit: per-env state exceeds 160 KiB of LDS");
 

@@ -52,6 +52,10 @@ struct CimParams {
   const int32_t *fx_nstops, *fx_vperiod, *fx_order_prop;
   int pregen, NTP;  // order table: rows of NTP (= NT rounded up to 4) words, one per tick of the episode
   int g_mt0, g_dsrc, g_dtgt, g_oq, g_srcn, g_srctab, g_ctab, lds_words_gen;  // LDS layout of the order-table kernel
+  // the branch-free order-table generator (cim::gen_order_table_fast): 1 when the plan proves what it relies on (cim_layout.h);
+  // its own LDS layout: a two-block MT window, the noised ratios in 4-padded summation segments, port records, the
+  // hand-out prefix, the uint16 row
+  int order_fast, gf_win, gf_val, gf_rec, gf_pre, gf_row, gf_seg, gf_slots;
   // ---- constant tables (device)
   const double *src_base, *src_noise, *tgt_base, *tgt_noise, *er_base, *er_noise, *fr_base, *fr_noise,
       *v_speed, *v_speed_noise, *v_dur, *v_dur_noise, *route_dist, *order_dist;
@@ -164,7 +168,15 @@ struct CimParams {
   X(g_srcn) \
   X(g_srctab) \
   X(g_ctab) \
-  X(lds_words_gen)
+  X(lds_words_gen) \
+  X(order_fast) \
+  X(gf_win) \
+  X(gf_val) \
+  X(gf_rec) \
+  X(gf_pre) \
+  X(gf_row) \
+  X(gf_seg) \
+  X(gf_slots)
 
 // Observation fused into the step kernel (mrx_cim_set_observation): per stepped env with a new decision,
 //   ports  [n_envs][P][np] = snapshot_list["ports"][decision frame :: port attrs]

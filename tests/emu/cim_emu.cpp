@@ -14,6 +14,7 @@ struct Emu {
   CimHostPlan plan;
   uint8_t* ws = nullptr;
   int32_t* lds = nullptr;
+  int lds_cap_words = 0;
   wave::EmuWave wave;
 };
 
@@ -34,7 +35,13 @@ void* emu_create(const mrx_cim_topology* t, const mrx_cim_config* c, char* errbu
   memset(e->ws, 0xCD, (size_t)e->plan.workspace_bytes);  // poison: nothing may rely on zeroed HBM
   memcpy(e->ws + e->plan.const_off, e->plan.const_blob.data(), e->plan.const_blob.size());
   cim_plan_bind(&e->plan, e->ws);
-  e->lds = (int32_t*)aligned_alloc(256, ((size_t)(e->plan.kp.lds_words_reset > e->plan.kp.lds_words ? e->plan.kp.lds_words_reset : e->plan.kp.lds_words) * 4 + 511) / 256 * 256);
+  {
+    const CimParams& kp = e->plan.kp;
+    int w = kp.lds_words_reset > kp.lds_words ? kp.lds_words_reset : kp.lds_words;
+    if (kp.lds_words_gen > w) w = kp.lds_words_gen;
+    e->lds_cap_words = w;
+    e->lds = (int32_t*)aligned_alloc(256, ((size_t)w * 4 + 511) / 256 * 256);
+  }
   return e;
 }
 
@@ -60,7 +67,7 @@ void emu_reset(void* h, const int64_t* seed_cmd, const uint8_t* mask, int revers
     long long cmd = seed_cmd ? (long long)seed_cmd[env] : -1;
     wave::run_wave(e->wave, [&]() { cim::reset_env(K, env, e->lds, cmd); });
     if (K.pregen && K.orders_stride && cmd != -1) {
-      memset(e->lds, 0xAB, (size_t)K.lds_words_reset * 4);
+      memset(e->lds, 0xAB, (size_t)e->lds_cap_words * 4);
       wave::run_wave(e->wave, [&]() { cim::gen_order_table(K, env, e->lds); });
     }
   }
@@ -180,7 +187,7 @@ extern "C" int emu_dump_dims(void* h, char* buf, int len) {
   D(idx_order_init) D(idx_route) D(idx_order_num) D(idx_buffer) D(f_ports) D(f_vessels) D(f_fop) D(f_fov) D(f_plans)
   D(misc_cap) D(NC) D(PW) D(PWH) D(pv_evt) D(pv_next) D(pv_pos) D(pv_krl) D(pv_period) D(pv_rfull) D(pv_rempty) D(REC_W)
   D(l_frame) D(l_priv) D(l_mt0) D(l_mt1) D(l_dsrc) D(l_dtgt) D(l_oq) D(l_odelay) D(l_srcn) D(l_misc) D(lds_words) D(l_ctab) D(wg_waves) D(l_rfull) D(lds_words_lean) D(lean_ok) D(l_mt2) D(l_mt3) D(r_mt0) D(r_mt1) D(lds_words_reset)
-  D(ctab_words) D(decision_mode) D(data_mode) D(data_T) D(pregen) D(NTP)
+  D(ctab_words) D(decision_mode) D(data_mode) D(data_T) D(pregen) D(NTP) D(order_half) D(order_fast) D(lds_words_gen)
 #undef D
   if ((int)o.size() + 1 > len) return -1;
   memcpy(buf, o.c_str(), o.size() + 1);

@@ -82,6 +82,7 @@ def _declare(L):
         L.emu_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         L.emu_destroy.argtypes = [ctypes.c_void_p]
         L.emu_get_layout.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.emu_dump_dims.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         L.emu_workspace.restype = ctypes.c_void_p
         L.emu_workspace.argtypes = [ctypes.c_void_p]
         L.emu_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
