@@ -14,7 +14,7 @@ import tempfile
 
 from .. import _lib
 
-CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+CSRC = os.environ.get("MARO_AMD_CSRC") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")   # ($MARO_AMD_CSRC: A/B experiments against another revision's device sources)
 CACHE = os.environ.get("MARO_AMD_SPEC_CACHE", os.path.join(CSRC, "spec_cache"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"] + os.environ.get("MARO_AMD_SPEC_FLAGS", "").split()

@@ -90,6 +90,15 @@ struct Prof {
 #if defined(MRX_SPECIALIZED) && (MRXC_lds_words * 4 <= MRX_CB_LDS_BYTES)
 #define MRX_CB_LDSFRAME 1
 #ifdef __HIPCC__
+// Read-modify-writes of the replay loop as fire-and-forget LDS operations (ds_add / ds_min / ds_or / ds_and without return): a
+// `+=` on an LDS word is a read, a wait for it, and a write — and since the station index is a runtime value the compiler keeps
+// every such triple in program order, i.e. one full LDS round trip per counter with the wave alone on its SIMD.  The LDS executes
+// one wave's operations in order, so later reads of the same word see them.
+#define CB_ADD(lv, v) ((void)__hip_atomic_fetch_add(&(lv), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#define CB_MIN(lv, v) ((void)__hip_atomic_fetch_min(&(lv), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#define CB_OR(lv, v) ((void)__hip_atomic_fetch_or(&(lv), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#define CB_AND(lv, v) ((void)__hip_atomic_fetch_and(&(lv), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#define CB_LAND(x) asm volatile("" : "+v"(x)) /* the value is needed HERE: keeps a group of independent reads in one round trip (the compiler would sink each into the branch that uses it) */
 extern __shared__ int32_t mrx_cb_lds[];
 #define LEV() (mrx_cb_lds + threadIdx.x * (CB_EV_BLOCK * 4)) /* the lane's event block: lane-major, so a record is one 16-byte read */
 #define LF(w) mrx_cb_lds[((CB_EV_BLOCK * 4 + (w)) << K.lsh) + threadIdx.x]
@@ -147,6 +156,14 @@ static_assert(LDS_TWC + LDS_TWC_WORDS + CB_EV_BLOCK * 4 == MRXC_lds_words, "cb_l
 #ifndef MRX_CB_TWC_LDS
 #define TWCF(slot) K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), (slot), e)]
 #define TWCT(slot) K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), (slot), e)]
+#endif
+
+#ifndef CB_ADD  /* state in HBM, or the host build: plain read-modify-writes */
+#define CB_ADD(lv, v) ((lv) += (v))
+#define CB_MIN(lv, v) ((lv) = (v) < (lv) ? (v) : (lv))
+#define CB_OR(lv, v) ((lv) |= (v))
+#define CB_AND(lv, v) ((lv) &= (v))
+#define CB_LAND(x) ((void)0)
 #endif
 
 // The env's place in the shared event stream (4 words per record).  LDS build: records are consumed out of a block of
@@ -338,21 +355,22 @@ MRX_DEV void light_event(const CbParams& K, int e, int32_t* hd, int t, int kind,
   const int st = trip ? b : (int)((uint32_t)c >> 16);  // the station whose dock changes
   const int fw = (a & CD(w_mask)) >> 5;
   const uint32_t bit = 1u << (a & 31);
-  const uint32_t ful = FUL(fw);
-  const int bikes = ST(LV_BIKES, st);
-  const int cap = CAP(st);
-  const int minb = ST(LV_MIN_BIKES, st);
-  if (trip) {
+  uint32_t ful = FUL(fw);
+  int bikes = ST(LV_BIKES, st);
+  int cap = CAP(st);
+  CB_LAND(ful); CB_LAND(bikes); CB_LAND(cap);
+  if (trip) {  // the only value a trip needs is the dock's bike count: everything else is an update that nobody waits for
     const int ok = bikes >= 1 ? 1 : 0;
-    ST(LV_TRIP_REQUIREMENT, st) += 1;
-    ST(LV_SHORTAGE, st) += 1 - ok;
-    ST(LV_FULFILLMENT, st) += ok;
-    HDR(CH_TRIPS) += 1;
-    HDR(CH_SHORT) += 1 - ok;
+    CB_ADD(ST(LV_TRIP_REQUIREMENT, st), 1);
+    CB_ADD(ST(LV_SHORTAGE, st), 1 - ok);
+    CB_ADD(ST(LV_FULFILLMENT, st), ok);
+    CB_ADD(HDR(CH_TRIPS), 1);
+    CB_ADD(HDR(CH_SHORT), 1 - ok);
     const int nb = bikes - ok;  // station.py:71-75 (min_bikes <= bikes always, so the min is a no-op when nothing left)
     ST(LV_BIKES, st) = nb;
-    ST(LV_MIN_BIKES, st) = nb < minb ? nb : minb;
-    FUL(fw) = ok ? ful | bit : ful & ~bit;
+    CB_MIN(ST(LV_MIN_BIKES, st), nb);
+    CB_OR(FUL(fw), ok ? bit : 0u);
+    CB_AND(FUL(fw), ok ? ~0u : ~bit);
   } else if (ful & bit) {  // the trip did get a bike: it comes back now
     if (bikes < cap) ST(LV_BIKES, st) = bikes + 1;
     else land_bikes(K, e, hd, false, c & 0xffff, st, 1);  // full dock: failed return, on to the neighbours

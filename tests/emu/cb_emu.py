@@ -18,8 +18,10 @@ def build():
                                                  ("cb_device.h", "cb_layout.h", "cb_params.h", "cb_wave.h")] + [
         os.path.join(REPO, "include", "maro_amd_citi_bike.h"), os.path.join(HERE, "wave_emu.h")]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
+        tmp = LIB + f".{os.getpid()}.tmp"   # built aside and renamed: concurrent test workers never load a half-written library
         subprocess.check_call(["g++", "-O2", "-g", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
-                               "-Wno-unused-function", "-shared", "-o", LIB, srcs[0]])
+                               "-Wno-unused-function", "-shared", "-o", tmp, srcs[0]])
+        os.replace(tmp, LIB)
     return LIB
 
 

@@ -32,8 +32,10 @@ def build():
     srcs = [os.path.join(HERE, "cim_emu.cpp"), os.path.join(HERE, "wave_emu.h")] + [
         os.path.join(REPO, "maro_amd", "csrc", f) for f in ("cim_device.h", "cim_layout.h", "cim_params.h")]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
+        tmp = LIB + f".{os.getpid()}.tmp"   # built aside and renamed: concurrent test workers never load a half-written library
         subprocess.check_call(["g++", "-O2", "-g", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall",
-                               "-Wno-unused-function", "-shared", "-o", LIB, srcs[0]])
+                               "-Wno-unused-function", "-shared", "-o", tmp, srcs[0]])
+        os.replace(tmp, LIB)
     return LIB
 
 
