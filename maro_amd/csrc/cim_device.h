@@ -755,61 +755,87 @@ MRX_DEV void reset_env(const CimParams& K, int env, int32_t* lds, long long cmd)
     }
   }
 
-  // ---- route unrolling (cim_data_generator.py:18-115): one sequential stream across vessels, two
-  // draws per stop; executed wave-uniformly (every lane computes the same values, lane 0 stores)
-  // the stream's draws are tempered 64 at a time (lane l holds draw l of the batch) and handed out by lane index: one
-  // batch call instead of two LDS reads + two temperings per draw, in a loop whose cost is its instruction latency.  A batch
-  // never reaches past the current state block (no twist on draws that may stay unused); the unused tail is given back below.
-  double rt_batch = 0.0;
-  int rt_j = 0, rt_n = 0;
-  auto route_draw = [&]() -> double {
-    if (rt_j == rt_n) {
-      const int left = (MT_WORDS - idx_route) / 2;
-      rt_n = (idx_route >= MT_WORDS || left > 64) ? 64 : left;
-      bool tw = false;
-      rt_batch = mt_draw_batch(mt_route, idx_route, lane < rt_n ? lane : -1, rt_n, tw);
-      rt_j = 0;
-    }
-    union { double d; int w[2]; } u, r;
-    u.d = rt_batch;
-    r.w[0] = wave::bcast(u.w[0], rt_j); r.w[1] = wave::bcast(u.w[1], rt_j);
-    rt_j++;
-    return r.d;
-  };
+  // ---- route unrolling (cim_data_generator.py:18-115): one sequential stream across vessels, two draws per stop (parking
+  // duration, then sailing speed), stops until future_stop_number + 1 of them lie past max_tick.  LANE-PARALLEL: a batch hands
+  // the stream's next draws out two per lane — lane j is the j-th stop of the batch — so parking and sailing times of up to 64
+  // stops are computed at once; arrival ticks are a prefix sum, "how many stops does the reference run" a ballot over
+  // "arrives past max_tick" (arrival ticks only grow).  The wave-uniform loop of ~5000 sequential stops per env (~70 dependent
+  // instructions each) was most of the reset kernel's time.  As before a batch never reaches past the current state block (draws
+  // that stay unused are given back, and nothing can be given back across a regeneration); a stop whose two draws fall into
+  // different batches carries its parking duration over.
   for (int v = 0; v < V; v++) {
-    const int Lr = K.v_route_len[v], rb = K.v_route_base[v];
+    const int Lr = K.v_route_len[v], rb = K.v_route_base[v], start = K.v_start[v];
     const double speed = K.v_speed[v], sn = K.v_speed_noise[v], dur = K.v_dur[v], dn = K.v_dur_noise[v];
-    int loc = K.v_start[v], tick = 0, extra = 0, k = 0, period = 0;
-    // the vessel's leg distances and leg times: lane l holds leg l (route length <= 62), one load per vessel; inside the
-    // loop they come out of registers by lane index — a global load per stop was a dependent L2 round trip in a loop of
-    // ~5000 sequential stops per env
+    // lane l holds leg l of the vessel's route (route length <= 62): distance and noise-free leg time
     union { double d; int w[2]; } my_dist;
     my_dist.d = lane < Lr ? K.route_dist[rb + lane] : 0.0;
     const int my_leg = lane < Lr ? K.leg_time[K.leg_off[v] + lane] : 0;
-    while (extra <= KD(future_n)) {
-      const double r1 = route_draw();
-      const int parking = (int)ceil(apply_noise(dur, dn, r1));
-      const double r2 = route_draw();
-      const double noised_speed = apply_noise(speed, sn, r2);
+    int tick = 0, extra = 0, k = 0;          // as in the reference loop, at the start of the batch
+    bool have_park = false, done = false;    // a parking duration drawn by the previous batch waits for its speed draw
+    int park_carry = 0;
+    while (!done) {  // wave-uniform
+      const int left = (MT_WORDS - idx_route) / 2;
+      // draws of this batch (>= 1).  (One word left in the block: the next draw straddles the regeneration anyway, and the
+      // cursor then stands far enough into the new block for anything that is given back.)
+      const int nd = (idx_route >= MT_WORDS - 1 || left > 126) ? 126 : left;
+      const int c = have_park ? 1 : 0;
+      // lane j: stop j of the batch.  Its parking draw is draw 2 j - c of the batch (stop 0 of a batch with a carried
+      // parking duration has none), its speed draw is draw 2 j - c + 1.
+      const int pi = 2 * lane - c, si = pi + 1;
+      const int rank[2] = {(pi >= 0 && pi < nd) ? pi : -1, si < nd ? si : -1};
+      double r[2];
+      bool tw = false;
+      mt_draw_multi<2>(mt_route, idx_route, rank, nd, tw, r);
+      const int n_full = (nd + c) / 2;                   // stops of the batch with both draws
+      const bool half = ((nd + c) & 1) != 0;             // ... and one more parking draw whose speed draw is in the next batch
+      int parking = (int)ceil(apply_noise(dur, dn, r[0]));
+      if (c && lane == 0) parking = park_carry;
+      const double noised_speed = apply_noise(speed, sn, r[1]);
+      int loc = start + k + lane;                        // route position of stop k + lane
+      loc = loc % Lr;
       union { double d; int w[2]; } dist;
-      dist.w[0] = wave::bcast(my_dist.w[0], loc); dist.w[1] = wave::bcast(my_dist.w[1], loc);
-      const int sailing = (int)ceil(dist.d / noised_speed);
-      if (parking <= 0 || parking > 255) status |= 8;  // reference: assert parking_duration > 0
-      if (k < KD(SMAX)) {
-        if (lane == 0) g_stops[(size_t)v * KD(SMAX) + k] = ((uint32_t)tick << 8) | (uint32_t)(parking & 0xff);
-      } else {
-        status |= 2;  // MRX_ENV_STOP_OVERFLOW
+      dist.w[0] = wave::shfl(my_dist.w[0], loc); dist.w[1] = wave::shfl(my_dist.w[1], loc);
+      const bool full = lane < n_full;
+      const int sailing = full ? (int)ceil(dist.d / noised_speed) : 0;
+      const int delta = full ? parking + sailing : 0;
+      const int incl = wave::scan_incl_add(delta);
+      const int t_before = tick + incl - delta, t_after = tick + incl;
+      // the reference runs stop j while extra <= future_n BEFORE it; extra counts the stops (so far) that end past max_tick
+      const uint64_t over = wave::ballot(full && t_after > TT);
+      const int extra_before = extra + __builtin_popcountll(over & ((1ull << lane) - 1ull));
+      bool run = full && extra_before <= KD(future_n);
+      int n_run = __builtin_popcountll(wave::ballot(run));
+      if (k + n_run >= 4 * KD(SMAX) + 1) {  // the reference has no such limit; a table this long is an error either way
+        n_run = 4 * KD(SMAX) + 1 - k;
+        run = run && lane < n_run;
+        status |= 2;
+        done = true;
       }
-      if (k < Lr) period += wave::bcast(my_leg, loc);  // cim_data_generator.py:93-101
-      tick += parking + sailing;
-      loc = (loc + 1 == Lr) ? 0 : loc + 1;
-      extra += (tick > TT) ? 1 : 0;
-      k++;
-      if (k > 4 * KD(SMAX)) { status |= 2; break; }
+      if (wave::ballot(run && (parking <= 0 || parking > 255))) status |= 8;  // reference: assert parking_duration > 0
+      if (wave::ballot(run && k + lane >= KD(SMAX))) status |= 2;            // MRX_ENV_STOP_OVERFLOW
+      if (run && k + lane < KD(SMAX)) g_stops[(size_t)v * KD(SMAX) + k + lane] = ((uint32_t)t_before << 8) | (uint32_t)(parking & 0xff);
+      // the loop is over once future_n + 1 of the stops run so far end past max_tick — possibly right after the batch's last full
+      // stop, in which case the half stop's parking draw was never drawn
+      if (extra + __builtin_popcountll(over & ((1ull << n_run) - 1ull)) > KD(future_n)) done = true;
+      if (done) {
+        idx_route -= 2 * (nd - (2 * n_run - c));  // the draws nobody asked for
+      } else {
+        have_park = half;
+        park_carry = wave::bcast(parking, n_full < 64 ? n_full : 0);  // (lane n_full holds the half stop's parking duration)
+        tick += wave::bcast(incl, 63);
+        extra += __builtin_popcountll(over);
+      }
+      k += n_run;
     }
+    // vessel_period_without_noise (:93-101): the noise-free leg times of the first route_length stops
+    const int n_per = k < Lr ? k : Lr;
+    int ploc = start + lane;
+    ploc = ploc % Lr;
+    const int leg_l = wave::shfl(my_leg, ploc);
+    const int period = wave::bcast(wave::scan_incl_add(lane < n_per ? leg_l : 0), 63);
     if (lane == 0) { K.nstops[(size_t)env * V + v] = k < KD(SMAX) ? k : KD(SMAX); K.vperiod[(size_t)env * V + v] = period; }
   }
-  idx_route -= 2 * (rt_n - rt_j);  // draws of the last batch nobody asked for
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);  // (the frame initialisation below reads the stop table back, other lanes than wrote it)
   }  // generated data
   wave::sync();
 
