@@ -948,7 +948,7 @@ MRX_DEV void of_next_block(uint32_t* win, int cur, int nxt) {
 #define MRX_OF_ROUND(K0, N)                                                                                  \
   _Pragma("unroll") for (int j = 0; j < ((N) + 63) / 64; j++) {                                              \
     const int k = (K0) + j * 64 + l;                                                                         \
-    const bool on = j * 64 + l < (N);                                                                        \
+    const bool on = (j + 1) * 64 <= (N) || l < (N) - j * 64;   /* (a whole batch: known at compile time) */      \
     const int kc = on ? k : (K0);                                                                            \
     const uint32_t a = win[cur + kc], b = win[kc + 1 == MT_WORDS ? nxt : cur + kc + 1];                      \
     const uint32_t m = win[kc < 227 ? cur + kc + 397 : nxt + kc - 227];                                      \
@@ -957,7 +957,7 @@ MRX_DEV void of_next_block(uint32_t* win, int cur, int nxt) {
   }                                                                                                          \
   wave::sync();                                                                                              \
   _Pragma("unroll") for (int j = 0; j < ((N) + 63) / 64; j++)                                                \
-    if (j * 64 + l < (N)) win[nxt + (K0) + j * 64 + l] = x[j];                                               \
+    if ((j + 1) * 64 <= (N) || l < (N) - j * 64) win[nxt + (K0) + j * 64 + l] = x[j];                        \
   wave::sync();
   uint32_t x[3];
   MRX_OF_ROUND(0, 192)
@@ -988,6 +988,9 @@ MRX_DEV void gen_order_table_fast(const CimParams& K, int env, int32_t* lds) {
   const int sum_seg = lane < P ? Ppad + incl_p - pad_p : 0;
   const int sum_len = lane < P ? pad_p : lane == P ? Ppad : 0;
   const int toff_l = K.tgt_off[lane <= P ? lane : P];  // lane p: first pair of port p; lane P: NT
+  int max_len = 4;  // the longest list (padded): the summation loop's trip count, the same for every tick
+  for (int len = 8; len <= 64; len += 4)
+    if (wave::ballot(sum_len >= len)) max_len = len;
   if (lane < P) seg[lane] = sum_seg;
   for (int i = lane; i < KD(gf_slots) + 6; i += 64) val[i] = 0.0;   // the pads stay +0.0 for good
   for (int i = lane; i < KD(NTP) / 2; i += 64) ((uint32_t*)row16)[i] = 0u;
@@ -1048,9 +1051,8 @@ MRX_DEV void gen_order_table_fast(const CimParams& K, int env, int32_t* lds) {
       wave::sync();
       // ---- list_sum_normalize's sums (utils.py:44-56), left to right, every list at once
       double acc = 0.0;
-      for (int i = 0;; i += 4) {
+      for (int i = 0; i < max_len; i += 4) {
         const bool on = i < sum_len;
-        if (!wave::ballot(on)) break;
         const double* q = val + (on ? sum_seg + i : ZERO);
         const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
         acc += q0; acc += q1; acc += q2; acc += q3;
