@@ -65,13 +65,9 @@ class CitiBikeBatchEngine:
                                              ctypes.byref(h)), "mrx_cb_create")
         self._h = h
         self.specialized = False
-        if specialize:
-            from ..cim import specialize as spec
-            try:
-                spec.load_into(self, spec.plan_defines(self._ts, self._cfg, "citi_bike"), build=specialize != "cached", scenario="citi_bike")
-                self.specialized = True
-            except KeyError:
-                pass   # "cached" and not in the cache: generic kernels
+        self._specialize = specialize
+        self._manual_lanes = bool(os.environ.get("MRX_CB_LANES"))   # (the C side reads it at create: an experiment's fixed split)
+        self._load_specialized()
         self.layout = MrxCbLayout()
         _lib.check(self._L.mrx_cb_get_layout(self._h, ctypes.byref(self.layout)), "mrx_cb_get_layout")
         lay = self.layout
@@ -152,10 +148,34 @@ class CitiBikeBatchEngine:
                    "mrx_cb_reset")
         self._keep = (tt, mk)
 
+    def _load_specialized(self) -> None:
+        """(Re)load the step kernels compiled for this plan.  The plan text carries the envs-per-wave shift of the automatic split
+        (MRXC_lsh_plan: folded into the kernel's LDS addresses); with a split chosen by hand the build that takes the shift as a kernel
+        argument is loaded instead (MRXC_lsh_plan -1)."""
+        self.specialized = False
+        if not self._specialize:
+            return
+        import re
+
+        from ..cim import specialize as spec
+        defines = spec.plan_defines(self._ts, self._cfg, "citi_bike")
+        if self._manual_lanes:
+            defines = re.sub(r"(#define MRXC_lsh_plan) -?\d+", r"\1 -1", defines)
+        try:
+            spec.load_into(self, defines, build=self._specialize != "cached", scenario="citi_bike")
+            self.specialized = True
+        except KeyError:
+            pass   # "cached" and not in the cache: generic kernels
+
     def set_lanes_per_wave(self, lanes: int = 0) -> None:
         """Envs per 64-lane wave of the step kernel (1, 2, ..., 64; 0 = the automatic choice): few envs per wave = less
-        control-flow divergence, more waves.  Results do not depend on it (include/maro_amd_citi_bike.h)."""
+        control-flow divergence, more waves.  Results do not depend on it (include/maro_amd_citi_bike.h).  A plan-specialised engine
+        reloads its step kernels when the choice switches between automatic and by hand (see _load_specialized)."""
         _lib.check(self._L.mrx_cb_set_lanes_per_wave(self._h, int(lanes)), "mrx_cb_set_lanes_per_wave")
+        manual = int(lanes) != 0
+        if self._specialize and manual != self._manual_lanes:
+            self._manual_lanes = manual
+            self._load_specialized()
 
     def set_wave_decisions(self, mode: int = 0) -> bool:
         """mrx_cb_set_wave_decisions: env-steps that stay inside their tick on one wave per env (action scope ranked across the

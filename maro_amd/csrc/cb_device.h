@@ -101,7 +101,14 @@ struct Prof {
 #define CB_LAND(x) asm volatile("" : "+v"(x)) /* the value is needed HERE: keeps a group of independent reads in one round trip (the compiler would sink each into the branch that uses it) */
 extern __shared__ int32_t mrx_cb_lds[];
 #define LEV() (mrx_cb_lds + threadIdx.x * (CB_EV_BLOCK * 4)) /* the lane's event block: lane-major, so a record is one 16-byte read */
-#define LF(w) mrx_cb_lds[((CB_EV_BLOCK * 4 + (w)) << K.lsh) + threadIdx.x]
+// envs per wave as a shift: a plan constant where the plan has one (CbParams::lsh_plan: the column addresses then fold into the
+// LDS instructions' offset fields — the per-access shift + add was a sixth of a replay iteration's instructions), else the launch's
+#if MRXC_lsh_plan >= 0
+#define CB_LSH MRXC_lsh_plan
+#else
+#define CB_LSH K.lsh
+#endif
+#define LF(w) mrx_cb_lds[((CB_EV_BLOCK * 4 + (w)) << CB_LSH) + threadIdx.x]
 #else
 static int32_t mrx_cb_lds_host[MRXC_lds_words]; /* host harness: one env at a time */
 #define LEV() mrx_cb_lds_host
@@ -341,9 +348,11 @@ MRX_DEV void pool_flush_at(const CbParams& K, int e, int32_t* hd, int t) {
 // :439-466 (a = trip index, b = the tick it was scheduled at, c = src | dst << 16).  Both touch one station's dock: everything
 // either may need is READ up front (independent LDS reads, one latency), the common outcomes are computed without branches
 // and only the writes differ — a lane alone on its SIMD pays every dependent LDS round trip in full.
-MRX_DEV void light_event(const CbParams& K, int e, int32_t* hd, int t, int kind, int a, int b, int c) {
+// `minland`: the caller's register copy of HDR(CH_POOL_MINLAND) — only the delivery pool's own operations change that word, so the
+// replay loop reads it from LDS once per run of light records instead of once per record.
+MRX_DEV void light_event(const CbParams& K, int e, int32_t* hd, int t, int kind, int a, int b, int c, int& minland) {
   const bool trip = kind == CB_EV_TRIP;
-  if (HDR(CH_POOL_MINLAND) <= t) {  // (rare) this env's DeliverBike events that run first
+  if (minland <= t) {  // (rare) this env's DeliverBike events that run first
     if (kind == CB_EV_RET) {
       // events queued by earlier ticks run by (scheduling tick, ReturnBike before DeliverBike, insertion order)
       pool_flush_before(K, e, hd, t);
@@ -351,6 +360,7 @@ MRX_DEV void light_event(const CbParams& K, int e, int32_t* hd, int t, int kind,
     } else {
       pool_flush_at(K, e, hd, t);
     }
+    minland = HDR(CH_POOL_MINLAND);
   }
   const int st = trip ? b : (int)((uint32_t)c >> 16);  // the station whose dock changes
   const int fw = (a & CD(w_mask)) >> 5;
@@ -651,8 +661,9 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     for (;;) {
       // ---- light records, one per iteration whatever their kind
       EvWin::Rec r = W.rec(K);
+      int minland = HDR(CH_POOL_MINLAND);  // (apply_actions / the heavy records below may have changed it)
       while ((r.w0 & 7) != CB_EV_REBAL && (r.w0 & 7) != CB_EV_TICK_END && left > 0) {
-        light_event(K, e, hd, CD(start_tick) + (r.w0 >> 3), r.w0 & 7, r.a, r.b, r.c);
+        light_event(K, e, hd, CD(start_tick) + (r.w0 >> 3), r.w0 & 7, r.a, r.b, r.c, minland);
         W.advance(K);
         r = W.rec(K);
         left--;
@@ -953,8 +964,9 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
         EvWin W;
         W.open(K, pos);
         EvWin::Rec r = W.rec(K);
+        int minland = HDR(CH_POOL_MINLAND);
         while ((r.w0 & 7) != CB_EV_REBAL && (r.w0 & 7) != CB_EV_TICK_END && left > 0) {
-          light_event(K, e, hd, CD(start_tick) + (r.w0 >> 3), r.w0 & 7, r.a, r.b, r.c);
+          light_event(K, e, hd, CD(start_tick) + (r.w0 >> 3), r.w0 & 7, r.a, r.b, r.c, minland);
           W.advance(K);
           r = W.rec(K);
           left--;

@@ -99,6 +99,7 @@ struct mrx_cb_engine {
   int step_budget = 0;  // mrx_cb_set_step_budget
   hipModule_t spec_module = nullptr;   // plan-specialised reset / step kernels (mrx_cb_load_step_kernels), else the generic ones
   hipFunction_t spec_reset = nullptr, spec_step = nullptr, spec_wave = nullptr, spec_replay = nullptr;
+  int spec_lsh = -1;  // envs-per-wave shift compiled into the loaded step kernel (MRXC_lsh_plan of its plan text); -1: a kernel argument
   int wave_mode = 0;    // mrx_cb_set_wave_decisions: 0 automatic, 1 on, -1 off
   bool obs_wave = false;  // the row layout the fused observation's buffer was sized for: scope_cap rows (wave path) or S rows (lane path)
   // kernels of the module may still be queued or running on the caller's stream: drain the device before unloading
@@ -141,16 +142,6 @@ int64_t mrx_cb_workspace_bytes(const mrx_cb_topology* topo, const mrx_cb_config*
   return pl.workspace_bytes;
 }
 
-// envs per wave of the step kernel when the caller does not say: a wave runs the union of its lanes' control flow, so a
-// small batch is spread over about a thousand waves (four per CU); below 8 envs per wave the extra waves stop paying
-// (profiles/r02_citi_bike.md: 4096 envs 62.5 / 64.1 / 66.7 / 64.4 / 54.2 M env-steps/s at 32 / 16 / 8 / 4 / 1 envs per wave;
-// 32768 envs 363 M at 64, 381 M at 32)
-static int auto_lanes(int n_envs) {
-  int lanes = 64;
-  while (lanes > 8 && n_envs / lanes < 1024) lanes /= 2;
-  return lanes;
-}
-
 int mrx_cb_create(const mrx_cb_topology* topo, const mrx_cb_config* cfg, void* d_workspace, int64_t workspace_bytes, mrx_cb_handle* out) {
   if (!out) return set_err(MRX_ERR_INVALID_ARG, "out handle is null");
   *out = nullptr;
@@ -180,7 +171,7 @@ int mrx_cb_create(const mrx_cb_topology* topo, const mrx_cb_config* cfg, void* d
   }
   if (he == hipSuccess) he = hipGetLastError();
   if (he != hipSuccess) { delete e; return set_err(MRX_ERR_HIP, std::string("initial reset kernel: ") + hipGetErrorString(he)); }
-  e->lanes = auto_lanes(K.n_envs);
+  e->lanes = cb_auto_lanes(K.n_envs);
   if (const char* v = getenv("MRX_CB_LANES")) mrx_cb_set_lanes_per_wave(e, atoi(v));
   *out = e;
   return MRX_OK;
@@ -188,7 +179,7 @@ int mrx_cb_create(const mrx_cb_topology* topo, const mrx_cb_config* cfg, void* d
 
 int mrx_cb_set_lanes_per_wave(mrx_cb_handle h, int lanes) {
   if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
-  if (lanes == 0) lanes = auto_lanes(h->plan.kp.n_envs);
+  if (lanes == 0) lanes = cb_auto_lanes(h->plan.kp.n_envs);
   if (lanes < 1 || lanes > 64 || (lanes & (lanes - 1))) return set_err(MRX_ERR_INVALID_ARG, "lanes per wave must be 1, 2, 4, ..., 64 (0 = automatic)");
   h->lanes = lanes;
   return MRX_OK;
@@ -331,10 +322,14 @@ static int cb_launch_step(mrx_cb_handle h, const int32_t* d_actions, const int32
     int lsh = 0;
     while ((1 << lsh) < lanes) lsh++;
     Kc.lsh = lsh;
-    const unsigned lds_bytes = lds_frame ? (unsigned)(K.lds_words * 4 * lanes) : 0u;
-    void* params[] = {&Kc, &d_actions, &d_n_actions, &d_env_mask, &d_decisions, &d_scope, &met, &d_done, &lanes, &d_n_answered};
-    HIP_TRY(hipModuleLaunchKernel(h->spec_step, (unsigned)((K.n_envs + lanes - 1) / lanes), 1, 1, 64, 1, 1, lds_bytes, (hipStream_t)stream, params, nullptr));
-    return MRX_OK;
+    // (a plan whose specialised step kernel has the envs-per-wave shift compiled in runs it with that shift only: another choice
+    // of mrx_cb_set_lanes_per_wave / MRX_CB_LANES goes to the generic kernel below)
+    if (h->spec_lsh < 0 || !lds_frame || lsh == h->spec_lsh) {
+      const unsigned lds_bytes = lds_frame ? (unsigned)(K.lds_words * 4 * lanes) : 0u;
+      void* params[] = {&Kc, &d_actions, &d_n_actions, &d_env_mask, &d_decisions, &d_scope, &met, &d_done, &lanes, &d_n_answered};
+      HIP_TRY(hipModuleLaunchKernel(h->spec_step, (unsigned)((K.n_envs + lanes - 1) / lanes), 1, 1, 64, 1, 1, lds_bytes, (hipStream_t)stream, params, nullptr));
+      return MRX_OK;
+    }
   }
   hipLaunchKernelGGL(mrx_k_cb_step, dim3((K.n_envs + h->lanes - 1) / h->lanes), dim3(64), 0, (hipStream_t)stream, Kc, d_actions, d_n_actions, d_env_mask,
                      d_decisions, d_scope, (long long*)d_metrics, d_done, h->lanes, d_n_answered);
@@ -385,7 +380,16 @@ int64_t mrx_cb_plan_defines(const mrx_cb_topology* topo, const mrx_cb_config* cf
 
 int mrx_cb_load_step_kernels(mrx_cb_handle h, const void* image, int64_t bytes, const char* defines) {
   if (!h || !image || bytes <= 0 || !defines) return set_err(MRX_ERR_INVALID_ARG, "null pointer");
-  if (cb_plan_defines(h->plan.kp) != defines) return set_err(MRX_ERR_INVALID_ARG, "the code object was built for a different plan (defines differ)");
+  // The plan text must be this plan's — except for MRXC_lsh_plan, which may also be -1: a build that takes the envs-per-wave shift
+  // as a kernel argument (what the host side loads when mrx_cb_set_lanes_per_wave asks for another split than the automatic one).
+  int spec_lsh = h->plan.kp.lsh_plan;
+  {
+    CbParams alt = h->plan.kp;
+    alt.lsh_plan = -1;
+    if (cb_plan_defines(h->plan.kp) == defines) spec_lsh = h->plan.kp.lsh_plan;
+    else if (cb_plan_defines(alt) == defines) spec_lsh = -1;
+    else return set_err(MRX_ERR_INVALID_ARG, "the code object was built for a different plan (defines differ)");
+  }
   int rc = use_device(h->device);
   if (rc != MRX_OK) return rc;
   hipModule_t mod = nullptr;
@@ -408,6 +412,7 @@ int mrx_cb_load_step_kernels(mrx_cb_handle h, const void* image, int64_t bytes, 
   h->spec_module = mod;
   h->spec_reset = f_reset;
   h->spec_step = f_step;
+  h->spec_lsh = spec_lsh;
   hipFunction_t f_wave = nullptr;
   if (hipModuleGetFunction(&f_wave, mod, "mrx_k_cb_step_wave") == hipSuccess && f_wave) h->spec_wave = f_wave;
   else (void)hipGetLastError();

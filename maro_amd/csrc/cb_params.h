@@ -22,6 +22,15 @@ enum { CB_POOL_WORDS = 6 };  // land tick, scheduling tick, from, to, number (<0
 #define CB_TWC_REG 12            /* trip-window frames whose table rows are kept in registers (cb_device.h::action_scope) */
 #define CB_EV_BLOCK 8            /* event records per look-ahead block (cb_device.h::EvWin) */
 #define MRX_CB_LDS_BYTES 65536   /* LDS one workgroup (= one wave) of the step kernel may take */
+// envs per wave of the step kernel when the caller does not say: a wave runs the union of its lanes' control flow, so a
+// small batch is spread over about a thousand waves (four per CU); below 8 envs per wave the extra waves stop paying
+// (profiles/r02_citi_bike.md: 4096 envs 62.5 / 64.1 / 66.7 / 64.4 / 54.2 M env-steps/s at 32 / 16 / 8 / 4 / 1 envs per wave;
+// 32768 envs 363 M at 64, 381 M at 32)
+static inline int cb_auto_lanes(int n_envs) {
+  int lanes = 64;
+  while (lanes > 8 && n_envs / lanes < 1024) lanes /= 2;
+  return lanes;
+}
 enum { CB_EV_RET, CB_EV_TRIP, CB_EV_REBAL, CB_EV_RETZ, CB_EV_TICK_END };  // kinds of CbParams::ev_rec records
 
 // Word w of env e in a per-env array of W words.  Two layouts (CbParams::aos, fixed at creation):
@@ -41,6 +50,9 @@ struct CbParams {
   int32_t FW, w_mask, w_words, pool_cap, tt_cap, scope_cap, mask_words, nb_stride;
   int32_t lds_words;  // a lane's LDS column in the specialised step kernel: frame, capacities, bit words, scope scratch, event block
   int32_t lsh;        // per launch: log2(envs per wave)
+  int32_t lsh_plan;   // plan constant: log2 of the envs per wave the automatic choice gives this plan's batch (cb_auto_lanes, capped by
+                      // the LDS column) — a plan-specialised step kernel folds it into its LDS addresses and is only launched with
+                      // that many envs per wave; -1: env-major plans (their wave kernels run with lsh 0), lsh stays a kernel argument
   int32_t step_budget;  // per launch: records an env may replay in one step call before it reports "no decision yet" (0: no limit)
   double supply_wm, demand_wm, scope_low_keep, scope_high;
   // ---- per-env struct-of-arrays state: X[word][stride]
@@ -94,5 +106,6 @@ struct CbParams {
   X(mask_words) \
   X(nb_stride) \
   X(lds_words) \
-  X(decision_mode)
+  X(decision_mode) \
+  X(lsh_plan)
 #define MRX_CB_DIM_ARRAYS(X) X(f_type) X(f_num) X(f_win)

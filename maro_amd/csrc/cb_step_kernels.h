@@ -16,16 +16,19 @@ mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __
   // `lanes` envs per wave (mrx_cb_set_lanes_per_wave): lane l < lanes owns env blockIdx.x * lanes + l.  A wave runs the UNION
   // of its lanes' control flow, and steps differ a lot in length, so a small batch is faster spread thin over many waves.
   const int lane = (int)threadIdx.x;
+#if defined(MRX_CB_LDSFRAME) && MRXC_lsh_plan >= 0
+  lanes = 1 << MRXC_lsh_plan;  // (the host launches this build with the plan's envs per wave only)
+#endif
   const int e0 = blockIdx.x * lanes;
   const int e = e0 + lane;
   const bool active = lane < lanes && e < K.n_envs && !(mask && !mask[e]);
 #ifdef MRX_CB_LDSFRAME
   // All 64 lanes move the wave's envs' state between HBM and the LDS columns (row w of the `lanes` envs = `lanes` consecutive
   // words): with a few envs per wave the owning lanes alone would issue one narrow load per word of the frame.
-  const int cl = lane & (lanes - 1), r0 = lane >> K.lsh, rstep = 64 >> K.lsh;
+  const int cl = lane & (lanes - 1), r0 = lane >> CB_LSH, rstep = 64 >> CB_LSH;
   const bool cok = e0 + cl < K.n_envs;
   const size_t cbase = (size_t)e0 + cl;
-#define MRX_CB_LFX(w) cb::mrx_cb_lds[((CB_EV_BLOCK * 4 + (w)) << K.lsh) + cl]
+#define MRX_CB_LFX(w) cb::mrx_cb_lds[((CB_EV_BLOCK * 4 + (w)) << CB_LSH) + cl]
   if (cok) {
 #pragma unroll 4
     for (int w = r0; w < MRXC_FW; w += rstep) MRX_CB_LFX(w) = K.live[CB_IX(CD(aos), CD(stride), CD(FW), w, cbase)];
@@ -95,7 +98,7 @@ mrx_k_cb_step_wave(CbParams K, const int32_t* __restrict__ actions, const int32_
   if (threadIdx.x == 0) K.todo[e] = ok ? 0 : 1;
 }
 
-#ifdef MRX_CB_LDSFRAME
+#if defined(MRX_CB_LDSFRAME) && MRXC_lsh_plan < 0   /* (plans with a compiled-in envs-per-wave shift have no wave kernels: they run with lsh 0) */
 // The GENERAL step on one wave per env (cb::step_env_wave): for the envs mrx_k_cb_step_wave flagged in K.todo.  The env's state is
 // moved HBM <-> the wave's LDS column by all 64 lanes (launched with K.lsh = 0: one column), the sequential parts run on lane 0
 // out of LDS, the station sweeps / snapshot / action scope across the lanes.

@@ -171,7 +171,10 @@ def test_specialized_citi_bike_bounded_steps(budget, lanes, monkeypatch):
     kw = dict(durations=700, snapshot_resolution=5)
     b = CbGpuBackend(data, n_envs=150, max_actions=1, **kw)
     assert b.eng.specialized
+    key_auto = b.eng.code_object_key
     b.eng.set_lanes_per_wave(lanes)
+    # a split chosen by hand runs the build that takes the envs-per-wave shift as a kernel argument (the automatic split's is compiled in)
+    assert b.eng.specialized and (b.eng.code_object_key != key_auto) == (lanes != 0)
     calls, unready = run_bounded_vs_oracle(b, data, kw, seeds=np.arange(150) + 3, budget=budget, check_envs=[0, 63, 64, 149])
     assert unready > 0
 
