@@ -802,6 +802,7 @@ def main():
     ap.add_argument("--ring", type=int, default=4, help="snapshot ring slots per env (max_snapshots)")
     ap.add_argument("--no-query", action="store_true", help="skip the per-step snapshot slice")
     ap.add_argument("--no-episode", action="store_true", help="skip the end-to-end leg (reset + one full episode of the whole batch)")
+    ap.add_argument("--episode-block", type=int, default=256, help="end-to-end leg: batch steps enqueued between two 'is every env done' read-backs")
     ap.add_argument("--parity-envs", type=int, default=64, help="envs replayed on the CPU oracle after the run (0: off)")
     ap.add_argument("--repeats", type=int, default=5, help="the timed window (exactly --steps steps between barrier + synchronize) is run this many "
                     "times back to back; `value` is the median window, value_min / value_max the spread")
@@ -1114,7 +1115,7 @@ def bench_cim(args, dist, dev, rank, world):
         ep_reset_ms = None
         k = 0
         while True:
-            for _ in range(128):
+            for _ in range(args.episode_block):
                 for g in range(G):
                     one_step(k, g)
                 k += 1
