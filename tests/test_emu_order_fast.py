@@ -69,3 +69,22 @@ def test_fast_generator_equals_generic_on_random_topologies():
         assert d0["order_fast"] == 0
         assert np.array_equal(t0, t1), case
     assert n_fast >= 15, n_fast
+
+
+def test_plans_that_do_not_qualify_keep_the_generic_generator():
+    """No order noise (nothing to draw), a ratio that can turn negative (no uint16 proof, `remaining` may grow), a ratio that can come
+    arbitrarily close to zero (no margin for the shared reciprocal): the plan says order_fast = 0 and the generic generator runs."""
+    from tests.test_emu_synthetic import base_conf
+    d, _ = _table(load_topology("global_trade.22p_l0.0"), 1, 20, [1], fast=True)
+    assert d["order_fast"] == 0 and d["order_half"] == 1
+    conf = base_conf()
+    conf["ports"]["pa"]["order_distribution"]["targets"]["pb"]["noise"] = 0.9   # > its proportion 0.5: the noised ratio can be negative
+    d, t = _table(parse_config(copy.deepcopy(conf), name="synthetic"), 1, 40, [5], fast=True)
+    assert d["order_fast"] == 0 and d["order_half"] == 0
+    conf = base_conf()
+    conf["ports"]["pa"]["order_distribution"]["targets"]["pb"]["noise"] = 0.5   # == its proportion: non-negative, but no margin above zero
+    d, t = _table(parse_config(copy.deepcopy(conf), name="synthetic"), 1, 40, [5], fast=True)
+    assert d["order_fast"] == 0 and d["order_half"] == 1
+    conf = base_conf()                                                           # as shipped: qualifies
+    d, t = _table(parse_config(copy.deepcopy(conf), name="synthetic"), 1, 40, [5], fast=True)
+    assert d["order_fast"] == 1
