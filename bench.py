@@ -58,6 +58,15 @@ def init_dist(world, local_rank, build=None):
     return dist, dev
 
 
+def exchange_transport():
+    """None on a real run (device tensors go to RCCL as they are).  Under the MRX_BENCH_BACKEND=gloo test hook the ranks share
+    one GPU and gloo's send / recv take host tensors: the test harness's host-staging transport (tests/transport.py)."""
+    if os.environ.get("MRX_BENCH_BACKEND", "nccl") == "nccl":
+        return None
+    from tests.transport import HostStaging
+    return HostStaging()
+
+
 def frame_bytes(topo):
     for k, v in FRAME_BYTES.items():
         if topo.name.startswith(k):
@@ -318,7 +327,7 @@ def bench_citi_bike(args, dist, dev, rank, world):
             step_i += 1
         sync_all()
         tg = time.perf_counter()
-        out = gather_to_learner(traj, dst=0, sizes=[n] * world)
+        out = gather_to_learner(traj, dst=0, sizes=[n] * world, transport=exchange_transport())
         sync_all()
         gather_ms = (time.perf_counter() - tg) * 1e3
         if rank == 0:
@@ -711,7 +720,7 @@ def bench_collect(args, engines, streams, qnet, chains, n, G, dev, rank, world, 
         goff = [0] + [sum(e.n_envs for e in engines[:g + 1]) for g in range(G - 1)]
         mine["env_id"] = torch.cat([r["env_id"] + goff[g] for g, r in enumerate(res)])
         nbytes = sum(t.numel() * t.element_size() for t in mine.values())
-        joined = gather_experiences_to_learner(mine, env_offset=rank * n, dst=0)
+        joined = gather_experiences_to_learner(mine, env_offset=rank * n, dst=0, transport=exchange_transport())
         sync_all()
         tc = time.perf_counter()
         tt = torch.tensor([tb - ta, tc - tb, float(nbytes), float(mine["tick"].shape[0])], dtype=torch.float64, device=dev)
@@ -725,7 +734,7 @@ def bench_collect(args, engines, streams, qnet, chains, n, G, dev, rank, world, 
         del joined, mine, res
         sync_all()
         td = time.perf_counter()
-        blob = broadcast_policy(qnet[0].weights.clone() if rank == 0 else None, qnet, src=0)
+        blob = broadcast_policy(qnet[0].weights.clone() if rank == 0 else None, qnet, src=0, transport=exchange_transport())
         sync_all()
         policy_bcast = {"ms": (time.perf_counter() - td) * 1e3, "bytes": blob.numel() * 4, "what": "rollout.broadcast_policy: one broadcast of the packed "
                         "networks + an in-place set_policy_state on every group's actor"}
@@ -1059,7 +1068,7 @@ def bench_cim(args, dist, dev, rank, world):
         record_rollout(traj)
         sync_all()
         tg = time.perf_counter()
-        gathered = gather_to_learner(traj, dst=0, sizes=[n] * world)   # weak scaling: every rank owns n envs, no size exchange
+        gathered = gather_to_learner(traj, dst=0, sizes=[n] * world, transport=exchange_transport())   # weak scaling: every rank owns n envs, no size exchange
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - tg) * 1e3
         gather_bytes = sum(t.numel() * t.element_size() for t in traj.values())
@@ -1079,7 +1088,7 @@ def bench_cim(args, dist, dev, rank, world):
                 record_rollout(traj)
                 sync_all()
                 tb = time.perf_counter()
-                gathered = gather_to_learner(traj, dst=0, sizes=[n] * world)
+                gathered = gather_to_learner(traj, dst=0, sizes=[n] * world, transport=exchange_transport())
                 sync_all()
                 tc = time.perf_counter()
                 t_roll += tb - ta

@@ -44,8 +44,30 @@ def rollout(engine, n_steps: int, policy: Callable[[int, torch.Tensor, torch.Ten
 _SHARD_SIZES: Dict[object, list] = {}   # sharding token (the caller's, identical on every rank) -> env count of every rank
 
 
+class Transport:
+    """What the exchanges below hand to ``torch.distributed``: the tensors themselves (device tensors go to RCCL as they
+    are — no staging copy).  The functions take a `transport` so that a harness whose process group cannot carry device
+    tensors supplies its own staging (tests/transport.py does, for N ranks sharing one GPU under gloo); this file holds
+    only the path a multi-GPU run takes."""
+
+    def outbound(self, t: torch.Tensor) -> torch.Tensor:
+        """The tensor a send / broadcast / all_gather is posted with."""
+        return t
+
+    def landing(self, shape, like: torch.Tensor) -> torch.Tensor:
+        """A receive buffer of `shape` for data that left its rank as `outbound(like)`."""
+        return torch.empty(shape, dtype=like.dtype, device=like.device)
+
+    def inbound(self, t: torch.Tensor, device: torch.device) -> torch.Tensor:
+        """A received (or joined) tensor as the caller wants it, on `device`."""
+        return t
+
+
+_DIRECT = Transport()
+
+
 def gather_to_learner(traj: Dict[str, torch.Tensor], dst: int = 0, group=None, sizes: Optional[list] = None,
-                      sharding_token=None) -> Optional[Dict[str, torch.Tensor]]:
+                      sharding_token=None, transport: Optional[Transport] = None) -> Optional[Dict[str, torch.Tensor]]:
     """Concatenate every rank's trajectory along the env axis (dim 1 of tensors shaped [T, n_local, ...]) on rank `dst`.
 
     ONE grouped exchange (`batch_isend_irecv`: a single RCCL group of point-to-point transfers over xGMI on GPUs, plain
@@ -63,15 +85,14 @@ def gather_to_learner(traj: Dict[str, torch.Tensor], dst: int = 0, group=None, s
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return traj
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    tp = transport or _DIRECT
     keys = sorted(traj)
     any_t = traj[keys[0]]
     n_local, t_local = int(any_t.shape[1]), int(any_t.shape[0])
     if sizes is None and sharding_token is not None and sharding_token in _SHARD_SIZES:
         sizes = _SHARD_SIZES[sharding_token]
     if sizes is None:
-        mine = torch.tensor([n_local, t_local], dtype=torch.int64, device=any_t.device)
-        if any_t.device.type == "cuda" and dist.get_backend(group) == "gloo":
-            mine = mine.cpu()
+        mine = tp.outbound(torch.tensor([n_local, t_local], dtype=torch.int64, device=any_t.device))
         allsz = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allsz, mine, group=group)
         got = [[int(v) for v in x.tolist()] for x in allsz]
@@ -80,11 +101,8 @@ def gather_to_learner(traj: Dict[str, torch.Tensor], dst: int = 0, group=None, s
         if sharding_token is not None:
             _SHARD_SIZES[sharding_token] = sizes
     assert len(sizes) == world and sizes[rank] == n_local, "sizes must list every rank's env count"
-    src = {k: traj[k].contiguous() for k in keys}   # (already contiguous in a rollout loop: no copy)
+    src = {k: tp.outbound(traj[k].contiguous()) for k in keys}   # (already contiguous in a rollout loop: no copy)
     dev = any_t.device
-    if dev.type == "cuda" and dist.get_backend(group) == "gloo":
-        # test hook only (bench.py under MRX_BENCH_BACKEND=gloo on a 1-GPU box): gloo's send / recv take host tensors
-        src = {k: v.cpu() for k, v in src.items()}
     if rank != dst:
         if n_local > 0:                              # (an empty shard sends nothing; the learner posts no receive for it)
             ops = [dist.P2POp(dist.isend, src[k], dst, group) for k in keys]
@@ -100,16 +118,17 @@ def gather_to_learner(traj: Dict[str, torch.Tensor], dst: int = 0, group=None, s
             else:
                 shape = list(src[k].shape)
                 shape[1] = sizes[r]
-                pieces[k][r] = torch.empty(shape, dtype=src[k].dtype, device=src[k].device)
+                pieces[k][r] = tp.landing(shape, src[k])
                 if sizes[r] > 0:
                     ops.append(dist.P2POp(dist.irecv, pieces[k][r], r, group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-    return {k: torch.cat(pieces[k], dim=1).to(dev) for k in keys}
+    return {k: tp.inbound(torch.cat(pieces[k], dim=1), dev) for k in keys}
 
 
-def gather_experiences_to_learner(exp: Dict[str, torch.Tensor], env_offset: int = 0, dst: int = 0, group=None) -> Optional[Dict[str, torch.Tensor]]:
+def gather_experiences_to_learner(exp: Dict[str, torch.Tensor], env_offset: int = 0, dst: int = 0, group=None,
+                                  transport: Optional[Transport] = None) -> Optional[Dict[str, torch.Tensor]]:
     """The experiences ONE ``CimBatchSampler.sample`` / ``sample_fused`` call emitted on every rank, joined on `dst` — the
     learner-side collection of config 5 (the reference: ``BatchEnvSampler.sample`` merging its workers' results,
     maro/rl/rollout/batch_env_sampler.py:150-190).  The flat tensors over a rank's K emitted elements (state [K, D], action,
@@ -121,8 +140,8 @@ def gather_experiences_to_learner(exp: Dict[str, torch.Tensor], env_offset: int 
     per_elem = {k: v for k, v in exp.items() if k != "env_metric"}
     if "env_id" in per_elem and env_offset:
         per_elem["env_id"] = per_elem["env_id"] + int(env_offset)
-    out = gather_to_learner({k: v.unsqueeze(0) for k, v in per_elem.items()}, dst=dst, group=group)
-    met = gather_to_learner({"env_metric": exp["env_metric"].unsqueeze(0)}, dst=dst, group=group) if "env_metric" in exp else None
+    out = gather_to_learner({k: v.unsqueeze(0) for k, v in per_elem.items()}, dst=dst, group=group, transport=transport)
+    met = gather_to_learner({"env_metric": exp["env_metric"].unsqueeze(0)}, dst=dst, group=group, transport=transport) if "env_metric" in exp else None
     if out is None:
         return None
     res = {k: v.squeeze(0) for k, v in out.items()}
@@ -131,7 +150,8 @@ def gather_experiences_to_learner(exp: Dict[str, torch.Tensor], env_offset: int 
     return res
 
 
-def broadcast_policy(packed: Optional[torch.Tensor], actors=(), src: int = 0, group=None, like: Optional[torch.Tensor] = None) -> torch.Tensor:
+def broadcast_policy(packed: Optional[torch.Tensor], actors=(), src: int = 0, group=None, like: Optional[torch.Tensor] = None,
+                     transport: Optional[Transport] = None) -> torch.Tensor:
     """The return half of config 5's loop: the learner's refreshed networks to every sampler rank — ONE ``dist.broadcast`` of the
     packed weight blob (22 nets x ~90 k floats = ~8 MB for the CIM example; RCCL over xGMI on GPUs, gloo in the CPU tests), then
     an in-place, stream-ordered ``set_policy_state`` on each of the rank's actors (one ``FusedPerPortDQN`` per env group).
@@ -155,12 +175,10 @@ def broadcast_policy(packed: Optional[torch.Tensor], actors=(), src: int = 0, gr
         buf = torch.empty_like(ref)
     buf = buf.contiguous()
     if multi:
-        if buf.is_cuda and dist.get_backend(group) == "gloo":   # test hook only (see gather_to_learner)
-            host = buf.cpu()
-            dist.broadcast(host, src=src, group=group)
-            buf.copy_(host)
-        else:
-            dist.broadcast(buf, src=src, group=group)
+        tp = transport or _DIRECT
+        wire = tp.outbound(buf)
+        dist.broadcast(wire, src=src, group=group)
+        buf = tp.inbound(wire, buf.device)
     for a in actors:
         a.set_policy_state(buf)
     return buf

@@ -5,11 +5,19 @@
 //
 // This is the one dense-contraction piece next to the simulator, so it runs on the matrix cores: exact-f32 MFMA
 // (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate — the reference networks are f32), envs binned by port so that a
-// workgroup multiplies a tile of envs by ONE port's weights:
-//   mrx_k_cim_dqn_bin      the deciding envs appended to their port's list (LDS histogram + one global atomic per port and workgroup)
-//   mrx_k_cim_dqn_forward  one workgroup (4 waves) per 32-env tile of one port's list: state gather -> LDS, the dense chain layer by layer with the
-//                          activations kept in one LDS buffer (written back in place between barriers), weights streamed
-//                          from L2 as coalesced 16-B loads in the packed layout below, then argmax + action translation.
+// workgroup multiplies a tile of envs by ONE port's weights.  Round 6 split the work by what bounds it:
+//   mrx_k_cim_dqn_prep     ONE launch, three kinds of workgroup:
+//                            bin     256 envs each: the deciding envs appended to their port's list (LDS histogram + one global
+//                                    atomic per port and workgroup), the sampler's end-of-episode bookkeeping
+//                            (sched) one workgroup builds the order list of the coming step's sorted launch (cim_engine.hip)
+//                            state   4 envs each, ONE WAVE PER ENV: the env's state row gathered from the snapshot ring — a chain
+//                                    of four dependent memory round trips (decision -> frames / route -> stops -> cells) that
+//                                    thousands of resident waves hide — written as a contiguous zero-padded f32 row, plus the
+//                                    transition cache's three copies of it
+//   mrx_k_cim_dqn_mlp      one workgroup (4 waves) per 16- or 32-env tile of one port's list: the rows arrive as 16-byte loads,
+//                          the dense chain runs layer by layer between two LDS activation buffers (one barrier per layer),
+//                          weights streamed from L2 as coalesced 16-byte loads in the packed layout below, 16 KB per wave
+//                          in flight, then argmax + action translation + the scalar half of the transition.
 // HIP only (not part of the CPU wave emulator build).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -18,7 +26,8 @@
 
 namespace cim {
 
-enum { DQ_MAX_LAYERS = 8, DQ_MAX_WIDTH = 256, DQ_TILE_MAX = 32, DQ_LD = DQ_MAX_WIDTH + 4, DQ_MAX_TICKS = 16, DQ_MAX_NODES = 8, DQ_PF = 4 };
+enum { DQ_MAX_LAYERS = 8, DQ_MAX_WIDTH = 256, DQ_TILE_MAX = 32, DQ_LD = DQ_MAX_WIDTH + 4, DQ_MAX_TICKS = 16, DQ_MAX_NODES = 8,
+       DQ_SLOTS = 16 /* 16-byte weight loads a wave keeps in flight (PF k-blocks x NT column tiles): 16 KB, several L2 latencies of MFMA work */ };
 
 struct DqnParams {
   int n_layers, dueling, state_dim, look_back, n_nodes, n_pa, n_va, n_actions;
@@ -31,12 +40,13 @@ struct DqnParams {
   double action_space[32];
 };
 
-// The batched EnvSampler's transition cache as the policy launches see it (mrx_cim_collect_steps): when `on`, the binning launch
-// retires the envs whose episode is over and the forward kernel APPENDS each deciding env's transition — its state row is in LDS
-// anyway — instead of a separate cache-update launch reading the state back from HBM (mrx_cim_sampler_record, whose semantics
-// these two pieces reproduce exactly; maro/rl/rollout/env_sampler.py:404-410, 484-511).  An env's cache is a ring of `cap` slots
-// (a power of two): element number q lives in slot q & (cap - 1); `last` holds element numbers (-1: none), `prev_j` the SLOT the
-// env's previous step wrote, `prev_active` whether that element still waits for its next_state.
+// The batched EnvSampler's transition cache as the policy launches see it (mrx_cim_collect_steps): when `on`, the binning
+// workgroups retire the envs whose episode is over, the state waves write each deciding env's state row into the cache — they
+// hold it in registers anyway — and the MLP kernel's last phase APPENDS the scalar half of the transition, instead of a separate
+// cache-update launch reading the state back from HBM (mrx_cim_sampler_record, whose semantics these pieces reproduce exactly;
+// maro/rl/rollout/env_sampler.py:404-410, 484-511).  An env's cache is a ring of `cap` slots (a power of two): element number q
+// lives in slot q & (cap - 1); `last` holds element numbers (-1: none), `prev_j` the SLOT the env's previous step wrote,
+// `prev_active` whether that element still waits for its next_state.
 struct SamplerRec {
   int on, cap, D, f64, A, P;
   uint8_t* eoe;
@@ -71,75 +81,111 @@ __host__ __device__ inline long long dq_w_index(int k, int n, int N) {
 
 typedef float dq_f4 __attribute__((ext_vector_type(4)));
 
-// DQ_PFL k-blocks of weights are in flight per wave (the rotating buffer below).  A layer's time is (its k-blocks / DQ_PFL)
-// memory latencies — a workgroup is alone on its CU at the batch sizes of config 5, so nothing else hides them — and the
-// buffer costs DQ_PFL x NT x 4 registers: narrow layers (NT = 1, 2) therefore fetch deeper at the same register count
-// (DQ_PFL x NT = 16 for one MFMA row tile), e.g. all 16 k-blocks of the 256 -> 32 head at once instead of four rounds of four.
-template <int MT, int NT, int DQ_PFL>
-__device__ __forceinline__ void dq_dense(float* X, const float* __restrict__ Wp, const float* __restrict__ bias, int Kpad, int Npad,
-                                         int m0, int nt0, int nt_step, bool idle, bool act, float slope) {
+// A 16-byte load from a WAVE-UNIFORM base + a per-lane byte offset, in the scalar-base form (global_load_dwordx4 v, v_off, s[base]):
+// the empty asm pins the base in scalar registers — left alone, hipcc folds the lane offset into a 64-bit vector address per
+// load (two address registers and two vector adds for each of the 32 slots a wave keeps in flight).
+__device__ __forceinline__ dq_f4 dq_ldw(const float* ubase, unsigned lane_off) {
+  const __attribute__((address_space(1))) char* b = (const __attribute__((address_space(1))) char*)ubase;
+  asm volatile("" : "+s"(b));
+  return *(const __attribute__((address_space(1))) dq_f4*)(b + lane_off);
+}
+
+// One dense layer for MT row tiles x NT column tiles of this wave: Y = X W (+ bias, LeakyReLU), X read from the LDS buffer `Xin`
+// (row stride DQ_LD), Y written to the OTHER buffer `Xout` — no barrier between reading and writing, one after the layer.
+// The wave's weights (B operands, L2) are fetched PF = DQ_SLOTS / NT k-blocks ahead into STATIC register slots: the prologue
+// requests the first PF blocks (every block of a layer with at most PF of them: no refill logic runs at all), each full pass
+// consumes slot p and refills it with the block PF ahead; the last full pass refills only where a tail block follows.  The
+// passes are straight-line code (a load is waited for with vmcnt(slots still in flight), never vmcnt(0)).
+#ifdef MRX_DQN_PROFILE
+__shared__ long long dq_prof[DQ_MAX_LAYERS][4][6];   // [layer][wave][entry, first block done, k loop done, epilogue written, barrier passed]
+__shared__ int dq_prof_layer;
+#define DQ_STAMP(I) do { if ((threadIdx.x & 63) == 0) dq_prof[dq_prof_layer][threadIdx.x >> 6][I] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DQ_STAMP(I) do {} while (0)
+#endif
+
+template <int MT, int NT>
+__device__ __forceinline__ void dq_dense(const float* __restrict__ Xin, float* __restrict__ Xout, const float* __restrict__ Wp,
+                                         const float* __restrict__ bias, int Kpad, int Npad, int m0, int nt0, int nt_step, bool idle,
+                                         bool act, float slope) {
+  constexpr int PF = DQ_SLOTS / NT;
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  // the bias is requested with the first weights, not after the k loop (one memory latency per layer less)
-  float bv[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; nt++) bv[nt] = idle ? 0.f : bias[(nt0 + nt * nt_step) * 16 + r];
-  dq_f4 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) acc[mt][nt] = dq_f4{0.f, 0.f, 0.f, 0.f};
-  const int nkb = idle ? 0 : Kpad >> 4;
-  // B operands (weights, L2) are fetched DQ_PFL k-blocks ahead into a rotating register buffer: a narrow layer gives a wave
-  // only a few MFMAs per k-block, far less than the L2 latency
-  dq_f4 bq[DQ_PFL][NT];
-  const float* wlane = Wp + ((size_t)nt0 * 16 + r) * 16 + g * 4;
-  const float* xlane = X + (m0 * 16 + r) * DQ_LD + g * 4;
-  const int nfull = nkb / DQ_PFL, rem = nkb - nfull * DQ_PFL;
-  if (nkb > 0) {
-#pragma unroll
-    for (int p = 0; p < DQ_PFL; p++)
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) bq[p][nt] = *(const dq_f4*)(wlane + ((size_t)min(p, nkb - 1) * Npad + (size_t)nt * nt_step * 16) * 16);
-  }
-  // Static register slots (a rotating buffer's moves would wait for the loads they move) and no control flow inside a pass
-  // (a branch merge makes the compiler drain every outstanding load): slot p is refilled with the block DQ_PFL ahead right
-  // after it is consumed.  The LAST full pass refills only when tail blocks follow it (then clamped: the last block may be
-  // fetched twice); a layer whose k-blocks are a whole number of passes issues no load it does not use — the barrier that
-  // ends the layer drains every load in flight, so a useless re-fetch late in the k loop cost the layer a memory latency.
-#define DQ_PASS(I, REFILL)                                                                                                  \
-  _Pragma("unroll") for (int p = 0; p < DQ_PFL; p++) {                                                                      \
-    const int kb = (I) * DQ_PFL + p;                                                                                        \
-    dq_f4 a[MT], b[NT];                                                                                                     \
-    _Pragma("unroll") for (int nt = 0; nt < NT; nt++) {                                                                     \
-      b[nt] = bq[p][nt];                                                                                                    \
-      if (REFILL) bq[p][nt] = *(const dq_f4*)(wlane + ((size_t)min(kb + DQ_PFL, nkb - 1) * Npad + (size_t)nt * nt_step * 16) * 16); \
-    }                                                                                                                       \
-    _Pragma("unroll") for (int mt = 0; mt < MT; mt++) a[mt] = *(const dq_f4*)(xlane + mt * 16 * DQ_LD + kb * 16);           \
-    _Pragma("unroll") for (int s = 0; s < 4; s++)                                                                           \
-      _Pragma("unroll") for (int mt = 0; mt < MT; mt++)                                                                     \
-        _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                                                                   \
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], b[nt][s], acc[mt][nt], 0, 0, 0);                     \
-  }
-  const int n_refill = rem > 0 ? nfull : nfull - 1;
-  for (int i = 0; i < n_refill; i++) { DQ_PASS(i, true) }
-  if (rem == 0 && nfull > 0) { DQ_PASS(nfull - 1, false) }
-#undef DQ_PASS
-#pragma unroll
-  for (int p = 0; p + 1 < DQ_PFL; p++)
-    if (p < rem) {  // the tail blocks are already in their slots
-      const int kb = nfull * DQ_PFL + p;
-      dq_f4 a[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++) a[mt] = *(const dq_f4*)(xlane + mt * 16 * DQ_LD + kb * 16);
-#pragma unroll
-      for (int s = 0; s < 4; s++)
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-          for (int nt = 0; nt < NT; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][s], bq[p][nt][s], acc[mt][nt], 0, 0, 0);
-    }
-  __syncthreads();  // every wave has read the layer's input: the buffer may be overwritten with its output
+  DQ_STAMP(0);
   if (!idle) {
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) bv[nt] = bias[(nt0 + nt * nt_step) * 16 + r];
+    dq_f4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[mt][nt] = dq_f4{0.f, 0.f, 0.f, 0.f};
+    const int nkb = Kpad >> 4;
+    dq_f4 bq[PF][NT];
+    // addresses: a wave-uniform base (scalar registers: nt0 / m0 come from the wave index through readfirstlane) + ONE per-lane
+    // byte offset shared by every load — 32 slots must not cost 64 address registers
+    const float* wbase = Wp + (size_t)nt0 * 256;
+    const unsigned lane_off = (unsigned)(r * 64 + g * 16);
+#define DQ_LDW(UBASE) dq_ldw((UBASE), lane_off)
+    const float* xlane = Xin + (m0 * 16 + r) * DQ_LD + g * 4;
+    const size_t kstep = (size_t)Npad * 16, nstep = (size_t)nt_step * 256;
+    const int nfull = nkb / PF, rem = nkb - nfull * PF;
+#pragma unroll
+    for (int p = 0; p < PF; p++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) bq[p][nt] = DQ_LDW(wbase + (size_t)min(p, nkb - 1) * kstep + nt * nstep);
+    // the A operand (activations, LDS) of block KB + 1 is requested before block KB's MFMAs: the LDS round trip hides behind them
+    dq_f4 acur[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) acur[mt] = *(const dq_f4*)(xlane + mt * 16 * DQ_LD);
+#define DQ_MFMA(KB, B)                                                                                      \
+  {                                                                                                         \
+    dq_f4 an_[MT];                                                                                          \
+    _Pragma("unroll") for (int mt = 0; mt < MT; mt++) an_[mt] = *(const dq_f4*)(xlane + mt * 16 * DQ_LD + min((KB) + 1, nkb - 1) * 16); \
+    _Pragma("unroll") for (int s = 0; s < 4; s++)                                                           \
+      _Pragma("unroll") for (int mt = 0; mt < MT; mt++)                                                     \
+        _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                                                   \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[mt][s], B[nt][s], acc[mt][nt], 0, 0, 0);  \
+    _Pragma("unroll") for (int mt = 0; mt < MT; mt++) acur[mt] = an_[mt];                                   \
+  }
+    for (int i = 0; i + 1 < nfull; i++) {   // full passes followed by another full pass: refill every slot
+      const float* wnext = wbase + (size_t)(i + 1) * PF * kstep;
+#pragma unroll
+      for (int p = 0; p < PF; p++) {
+        dq_f4 b_[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          b_[nt] = bq[p][nt];
+          bq[p][nt] = DQ_LDW(wnext + (size_t)p * kstep + nt * nstep);
+        }
+        DQ_MFMA(i * PF + p, b_)
+      }
+    }
+    if (nfull > 0) {   // the last full pass: refill the slots a tail block will use (clamped: slots past the tail re-fetch its last block)
+      const int i = nfull - 1;
+      if (rem > 0) {
+        const float* wnext = wbase + (size_t)nfull * PF * kstep;
+#pragma unroll
+        for (int p = 0; p < PF; p++) {
+          dq_f4 b_[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) {
+            b_[nt] = bq[p][nt];
+            if (p < PF - 1) bq[p][nt] = DQ_LDW(wnext + (size_t)min(p, rem - 1) * kstep + nt * nstep);
+          }
+          DQ_MFMA(i * PF + p, b_)
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < PF; p++) DQ_MFMA(i * PF + p, bq[p])
+      }
+    }
+#pragma unroll
+    for (int p = 0; p + 1 < PF; p++)
+      if (p < rem) DQ_MFMA(nfull * PF + p, bq[p])   // the tail blocks are already in their slots
+#undef DQ_MFMA
+#undef DQ_LDW
+    DQ_STAMP(2);
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
       const int col = (nt0 + nt * nt_step) * 16 + r;
@@ -149,35 +195,28 @@ __device__ __forceinline__ void dq_dense(float* X, const float* __restrict__ Wp,
         for (int i = 0; i < 4; i++) {
           float v = acc[mt][nt][i] + bv[nt];  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + i
           if (act) v = v > 0.f ? v : v * slope;
-          X[((m0 + mt) * 16 + g * 4 + i) * DQ_LD + col] = v;
+          Xout[((m0 + mt) * 16 + g * 4 + i) * DQ_LD + col] = v;
         }
     }
   }
-  __syncthreads();
+  DQ_STAMP(3);
+  __syncthreads();  // the layer's output is complete (and every wave has read its input: Xin may be overwritten by the next layer)
+  DQ_STAMP(4);
 }
 
-// A layer for the TILE-row tile (TILE / 16 MFMA row tiles): the output columns are dealt to the 4 waves in 16-column tiles.
+// A layer for the TILE-row tile (MT = TILE / 16 MFMA row tiles per wave): the output columns are dealt to the 4 waves in
+// 16-column tiles (wave w takes tiles w, w + 4, ...; layers narrower than 64 leave waves idle).
 template <int TILE>
-__device__ __forceinline__ void dq_layer(float* X, const float* Wp, const float* bias, int Kpad, int Npad, bool act, float slope) {
-  const int w = threadIdx.x >> 6;
-  if constexpr (TILE == 32) {
-    switch (Npad) {
-      case 16: dq_dense<1, 1, 8>(X, Wp, bias, Kpad, Npad, w & 1, 0, 1, w >= 2, act, slope); break;   // 2 tiles: waves 2, 3 idle
-      case 32: dq_dense<1, 1, 8>(X, Wp, bias, Kpad, Npad, w >> 1, w & 1, 1, false, act, slope); break;
-      case 64: dq_dense<2, 1, 8>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-      case 128: dq_dense<2, 2, DQ_PF>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-      case 192: dq_dense<2, 3, DQ_PF>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-      default: dq_dense<2, 4, DQ_PF>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-    }
-  } else {   // 16 rows: one MFMA row tile — half the matrix work per workgroup, twice the workgroups (finer balance over the CUs)
-    switch (Npad) {
-      case 16: dq_dense<1, 1, 16>(X, Wp, bias, Kpad, Npad, 0, 0, 1, w >= 1, act, slope); break;
-      case 32: dq_dense<1, 1, 16>(X, Wp, bias, Kpad, Npad, 0, w & 1, 1, w >= 2, act, slope); break;
-      case 64: dq_dense<1, 1, 16>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-      case 128: dq_dense<1, 2, 8>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-      case 192: dq_dense<1, 3, 5>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-      default: dq_dense<1, 4, DQ_PF>(X, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-    }
+__device__ __forceinline__ void dq_layer(const float* Xin, float* Xout, const float* Wp, const float* bias, int Kpad, int Npad, bool act, float slope) {
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the weight addresses stay in scalar registers
+  constexpr int MT = TILE / 16;
+  switch (Npad) {
+    case 16: dq_dense<MT, 1>(Xin, Xout, Wp, bias, Kpad, Npad, 0, 0, 1, w >= 1, act, slope); break;
+    case 32: dq_dense<MT, 1>(Xin, Xout, Wp, bias, Kpad, Npad, 0, w & 1, 1, w >= 2, act, slope); break;
+    case 64: dq_dense<MT, 1>(Xin, Xout, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+    case 128: dq_dense<MT, 2>(Xin, Xout, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
+    case 192: dq_dense<MT, 3>(Xin, Xout, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;   // (PF = 5: 15 of the 16 slots)
+    default: dq_dense<MT, 4>(Xin, Xout, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
   }
 }
 
@@ -189,18 +228,132 @@ __device__ __forceinline__ unsigned long long dq_mix64(unsigned long long seed, 
   return x;
 }
 
+__device__ __forceinline__ const int32_t* dq_shfl_ptr(const int32_t* p, int src) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = (unsigned)__shfl((int)(unsigned)u, src), hi = (unsigned)__shfl((int)(unsigned)(u >> 32), src);
+  return (const int32_t*)(((unsigned long long)hi << 32) | lo);
+}
+
+// ---- the state row of ONE env, built by one wave (mrx_k_cim_dqn_prep's state workgroups).  c_info[c] describes state column c
+// (built once per workgroup): tick index | node index << 8 (0x7f: the deciding vessel) | f32 flag << 15 | frame word << 16, -1 = padding.
+// Writes xrows[env][0 .. kp0) (float32, zero padded) and, for the real columns, state_out / the transition cache's rows.
+__device__ __forceinline__ void dq_state_wave(const CimParams& K, const DqnParams& M, int env, const int32_t* __restrict__ decisions,
+                                              const int* c_info, float* __restrict__ xrows, float* __restrict__ state_out, const SamplerRec& R) {
+  const int lane = threadIdx.x & 63;
+  // round trip 1: the decision row, the env's header words, the cache's cursors
+  const int dl = lane < 8 ? decisions[(size_t)env * 8 + lane] : 0;
+  const int32_t* hdr = K.priv + (size_t)env * K.PW;
+  const int flags = hdr[PH_FLAGS], htick = hdr[PH_TICK];
+  int over = 0, pact = 0, pj = 0;
+  long long head = 0;
+  if (R.on) {
+    over = (int)R.eoe[env] | (int)R.done[env];
+    head = R.head[env];
+    pact = R.prev_active[env];
+    pj = (int)R.prev_j[env];
+  }
+  const int tick = __builtin_amdgcn_readlane(dl, 0), port = __builtin_amdgcn_readlane(dl, 1), vessel = __builtin_amdgcn_readlane(dl, 2);
+  if (over || __builtin_amdgcn_readlane(dl, 7) != 1 || (unsigned)port >= (unsigned)K.P) return;   // (as the binning workgroups decide)
+  // round trip 2: which frame holds each look-back tick (cim::frame_of, lane = tick index), the vessel's route position
+  const int32_t* livef = K.live + (size_t)env * K.FW;
+  const int vv = (unsigned)vessel < (unsigned)K.V ? vessel : 0;
+  const int kw = K.f_vessels + VA_LAST_LOC_IDX * K.V + vv;
+  const int k_live = livef[kw];
+  const int Lr = K.v_route_len[vv], rb = K.v_route_base[vv], start = K.v_start[vv];
+  long long last = -1;
+  if (R.on) last = R.last[(size_t)env * R.P + port];
+  const int n_ticks = M.look_back - 1;
+  const int fi = max(0, tick - lane);   // ticks = [max(0, tick - rt) for rt in range(look_back - 1)]
+  const int slot = fi % K.S;
+  const int held = lane < n_ticks ? K.ring_fi[(size_t)env * K.S + slot] : -1;
+  const bool paused = (flags & (FL_FRESH | FL_FINISHED)) == 0;
+  const int cur_fi = (htick - K.start_tick) / K.resolution;
+  const int32_t* fptr = nullptr;
+  if (held == fi) fptr = K.ring + ((size_t)env * K.S + slot) * K.FW;
+  if (paused && slot == cur_fi % K.S) fptr = fi == cur_fi ? livef : nullptr;
+  if (lane >= n_ticks) fptr = nullptr;
+  // round trip 3: snapshots[tick : vessel : future_stop_list] (cim::stop_list_value), lane j = node j of [port] + future stops
+  const int32_t* now = dq_shfl_ptr(fptr, 0);
+  now = (const int32_t*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)now >> 32)) << 32) |
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)now));
+  const int k = now == livef ? k_live : now ? now[kw] : 0;
+  const int x0 = (start + k) % Lr;
+  int node = port;
+  if (lane >= 1 && lane < M.n_nodes) node = now ? (int)K.route_port[rb + (x0 + lane) % Lr] : 0;
+  // round trip 4: the cells.  Every load of the row is issued before the first conversion.
+  const int kp0 = M.kpad[0];
+  const size_t cbase = (size_t)env * R.cap;
+  const int s0 = (int)(head & ((long long)R.cap - 1)), s1 = pact ? pj : -1, s2 = last >= 0 ? (int)(last & ((long long)R.cap - 1)) : -1;
+  int32_t raw[4];
+  int inf[4];
+  unsigned okm = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = lane + 64 * i;
+    const int info = c < kp0 ? c_info[c] : -1;
+    inf[i] = info;
+    const int ti = info & 0xff, ni = (info >> 8) & 0x7f, word = info >> 16;
+    const bool vessel_col = ni == 0x7f;
+    const int32_t* f = dq_shfl_ptr(fptr, ti & 63);
+    const int nd = vessel_col ? vessel : __shfl(node, ni & 63);
+    const bool ok = info >= 0 && f != nullptr && (unsigned)nd < (unsigned)(vessel_col ? K.V : K.P);
+    const int w = vessel_col ? K.f_vessels + word * K.V + nd : word + nd;
+    raw[i] = *(ok ? f + w : K.live);  // always a valid address: no branch around the load
+    okm |= (unsigned)ok << i;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = lane + 64 * i;
+    if (c < kp0) {
+      const float v = !((okm >> i) & 1) ? 0.f : ((inf[i] >> 15) & 1) ? bits_f(raw[i]) : (float)raw[i];
+      xrows[(size_t)env * kp0 + c] = v;
+      if (inf[i] >= 0) {
+        if (state_out) state_out[(size_t)env * M.state_dim + c] = v;
+        if (R.on) {   // the transition's state row, the previous element's next state, the agent's previous element's next agent state
+          rec_store(R.c_state, (cbase + s0) * R.D + c, v, R.f64);
+          if (s1 >= 0) rec_store(R.c_next_state, (cbase + s1) * R.D + c, v, R.f64);
+          if (s2 >= 0) rec_store(R.c_nas, (cbase + s2) * R.D + c, v, R.f64);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace cim
 
-// Bins the envs with a pending decision by deciding port: lists int32 [P][n_envs] (list p = the envs deciding for port p,
-// any order), cnt int32 [64] = list lengths (zero on entry: the forward kernel's last workgroup resets them).  Also writes
-// n_actions (1 for a deciding env, else 0) and adds the number of deciding envs to *counter (may be NULL).
+// The policy's first launch.  Workgroups [0, n_bin): bin the envs with a pending decision by deciding port — lists int32 [P][n_envs]
+// (list p = the envs deciding for port p, any order), cnt int32 [64] = list lengths (zero on entry: the MLP kernel's last
+// workgroup resets them); also n_actions (1 for a deciding env, else 0) and the number of deciding envs added to *counter (may be
+// NULL).  sched_per > 0: workgroup n_bin builds the order list of the coming step (mrx_schedule_block, cim_engine.hip).  The
+// remaining workgroups build the state rows, one wave per env (cim::dq_state_wave).
 extern "C" __global__ void __launch_bounds__(256)
-mrx_k_cim_dqn_bin(int n_envs, int P, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt, int32_t* __restrict__ lists,
-                  int32_t* __restrict__ n_actions, unsigned long long* __restrict__ counter, const uint8_t* __restrict__ hint,
-                  int32_t* __restrict__ order, int32_t* __restrict__ sched, int sched_per, cim::SamplerRec R) {
-  // sched_per > 0: the LAST workgroup builds the order list of the coming step instead (mrx_schedule_block, cim_engine.hip)
-  if (sched_per > 0 && blockIdx.x == gridDim.x - 1) {
-    mrx_schedule_block(hint, nullptr, 0, n_envs, sched_per & 0xffffff, order, sched, sched_per >> 24);
+mrx_k_cim_dqn_prep(CimParams K, cim::DqnParams M, int n_bin, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
+                   int32_t* __restrict__ lists, int32_t* __restrict__ n_actions, unsigned long long* __restrict__ counter, int sched_per,
+                   float* __restrict__ xrows, float* __restrict__ state_out, cim::SamplerRec R) {
+  using namespace cim;
+  const int n_envs = K.n_envs, P = K.P;
+  const int first_state = n_bin + (sched_per > 0 ? 1 : 0);
+  if ((int)blockIdx.x >= first_state) {
+    __shared__ int c_info[DQ_MAX_WIDTH];
+    const int t = threadIdx.x, kp0 = M.kpad[0];
+    const int per_tick = M.n_nodes * M.n_pa, n_port_feats = (M.look_back - 1) * per_tick;
+    if (t < kp0) {
+      int info = -1;  // padding column
+      if (t < n_port_feats) {
+        const int ti = t / per_tick, rem = t - ti * per_tick, ni = rem / M.n_pa, a = M.pa[rem - ni * M.n_pa];
+        info = ti | (ni << 8) | ((a == PA_TRANSFER_COST ? 1 : 0) << 15) | ((K.f_ports + a * K.P) << 16);
+      } else if (t < M.state_dim) {
+        info = 0 | (0x7f << 8) | (M.va[t - n_port_feats] << 16);  // vessel attribute of the decision's frame
+      }
+      c_info[t] = info;
+    }
+    __syncthreads();
+    const int env = __builtin_amdgcn_readfirstlane(((int)blockIdx.x - first_state) * 4 + (t >> 6));
+    if (env < n_envs) dq_state_wave(K, M, env, decisions, c_info, xrows, state_out, R);
+    return;
+  }
+  if (sched_per > 0 && (int)blockIdx.x == n_bin) {
+    mrx_schedule_block((const uint8_t*)K.hint, nullptr, 0, n_envs, sched_per & 0xffffff, K.order, K.sched, sched_per >> 24);
     return;
   }
   __shared__ int lcnt[64], base[64];
@@ -214,7 +367,7 @@ mrx_k_cim_dqn_bin(int n_envs, int P, const int32_t* __restrict__ decisions, int3
     if (R.on) {
       // the sampler's end-of-episode bookkeeping (eoe |= done of the previous step), and the last element of an env whose episode
       // just ended: its next state is its own state (AbsEnvSampler keeps `_state` unchanged by a final step).  One thread copies
-      // the row: it happens once per env and episode.
+      // the row: it happens once per env and episode.  (The state waves of this launch read eoe | done, never eoe alone.)
       const bool was_over = R.eoe[e] != 0;
       over = was_over || R.done[e] != 0;
       if (over) {
@@ -243,14 +396,12 @@ mrx_k_cim_dqn_bin(int n_envs, int P, const int32_t* __restrict__ decisions, int3
 }
 
 template <int DQ_TILE>
-__device__ __forceinline__ void mrx_dqn_forward_body(const CimParams& K, const cim::DqnParams& M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
-                                                     const int32_t* __restrict__ lists, int32_t* __restrict__ actions, float* __restrict__ q_out,
-                                                     float* __restrict__ state_out, int32_t* __restrict__ choice_out, const cim::SamplerRec& R) {
+__device__ __forceinline__ void mrx_dqn_mlp_body(const CimParams& K, const cim::DqnParams& M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
+                                                 const int32_t* __restrict__ lists, const float* __restrict__ xrows, int32_t* __restrict__ actions,
+                                                 float* __restrict__ q_out, int32_t* __restrict__ choice_out, const cim::SamplerRec& R) {
   using namespace cim;
-  __shared__ __attribute__((aligned(16))) float X[DQ_TILE * DQ_LD];
-  __shared__ int r_env[DQ_TILE], r_node[DQ_TILE][DQ_MAX_NODES], c_info[DQ_MAX_WIDTH], s_tile[3];
-  __shared__ int r_slot[DQ_TILE][3];   // transition cache (R.on): the row's new slot, the slot waiting for its next_state, the agent's previous slot
-  __shared__ const int32_t* r_frame[DQ_TILE][DQ_MAX_TICKS];
+  __shared__ __attribute__((aligned(16))) float X[2][DQ_TILE * DQ_LD];
+  __shared__ int s_tile[3];
   const int t = threadIdx.x;
 
   // ---- which (port, tile) is this workgroup: prefix over the ports' tile counts (P <= 64: one wave)
@@ -266,7 +417,7 @@ __device__ __forceinline__ void mrx_dqn_forward_body(const CimParams& K, const c
     // XCD-aware tile order: the dispatcher places block i on XCD i % 8 (observed, MI355X_MICROARCH.md: a speed assumption only),
     // and each XCD has its own 4 MB L2 while the 22 networks are 8 MB.  The tile list (port 0's tiles, port 1's ...) is cut into
     // 8 equal runs and XCD x works through run x: an XCD then streams about three ports' weights (1 MB) instead of all of them,
-    // and every XCD gets the same number of tiles.  (M.xcd_runs = 0: block i takes tile i, the round-3 order.)
+    // and every XCD gets the same number of tiles.  (M.xcd_runs = 0: block i takes tile i.)
     const int total = __shfl(incl, 63);
     int tile_idx = (int)blockIdx.x;
     if (M.xcd_runs) {
@@ -289,139 +440,71 @@ __device__ __forceinline__ void mrx_dqn_forward_body(const CimParams& K, const c
     }
   }
   __syncthreads();
-  const int port = s_tile[0];
+  const int port = __builtin_amdgcn_readfirstlane(s_tile[0]);   // (scalar registers: every address derived from the tile is wave-uniform)
   if (port < 0) return;
-  const int rows = s_tile[2];
-  const int32_t* list = lists + (size_t)port * K.n_envs + s_tile[1];
-  const int n_ticks = M.look_back - 1;
+  const int rows = __builtin_amdgcn_readfirstlane(s_tile[2]);
+  const int32_t* list = lists + (size_t)port * K.n_envs + __builtin_amdgcn_readfirstlane(s_tile[1]);
 #ifdef MRX_DQN_PROFILE
   long long tm[12]; int tmi = 0;
+  const long long rt0 = (long long)__builtin_amdgcn_s_memrealtime();   // 100 MHz: what a s_memtime tick is worth under THIS launch
 #define DQ_MARK() do { __syncthreads(); tm[tmi++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DQ_MARK() do {} while (0)
 #endif
   DQ_MARK();
 
-  // ---- per-row lookups: env, the node list [port] + future_stop_list, the frame of each look-back tick;
-  //      per-column descriptors: which (tick, node, frame word) a state column reads
-  // what the LAST phase of row t needs (the decision row, two words of the live frame, the cache head, the env's seed) is
-  // requested here, by the thread that will use it: those were two more dependent memory latencies after the dense chain
+  // ---- what the LAST phase of row t needs (the decision row, two words of the live frame, the cache cursors, the env's seed) is
+  //      requested here, by the thread that will use it: nothing after the dense chain waits for memory
   int32_t dq_d[5] = {0, 0, 0, 0, 0};
-  int32_t dq_space = 0, dq_early = 0;
-  long long dq_head = 0, dq_seed = 0;
-  if (t < DQ_TILE) {
-    const int env = t < rows ? list[t] : -1;
-    r_env[t] = env;
-    if (env >= 0) {
-      const int32_t* d = decisions + (size_t)env * 8;
+  int32_t dq_space = 0, dq_early = 0, dq_env = -1;
+  long long dq_head = 0, dq_seed = 0, dq_last = -1;
+  if (t < rows) {
+    const int env = list[t];
+    dq_env = env;
+    const int32_t* d = decisions + (size_t)env * 8;
 #pragma unroll
-      for (int i = 0; i < 5; i++) dq_d[i] = d[i];
-      {
-        const int32_t* live = K.live + (size_t)env * K.FW;  // the decision's frame is the live frame
-        const int v = (unsigned)dq_d[2] < (unsigned)K.V ? dq_d[2] : 0;
-        dq_space = live[frame_word(K, 1, VA_REMAINING_SPACE, v, 0)];
-        dq_early = live[frame_word(K, 1, VA_EARLY_DISCHARGE, v, 0)];
-        if (R.on) dq_head = R.head[env];
-        if (M.epsilon > 0.f) dq_seed = K.seed[env];
-      }
-      // snapshots[tick : vessel : future_stop_list] (cim::stop_list_value, slot by slot): the frame's last_loc_idx is requested
-      // from the live frame — which the decision's frame is — TOGETHER with frame_of's own loads and the route words
-      const int32_t* livef = K.live + (size_t)env * K.FW;
-      const int vv = (unsigned)dq_d[2] < (unsigned)K.V ? dq_d[2] : 0;
-      const int kw = frame_word(K, 1, VA_LAST_LOC_IDX, vv, 0);
-      const int k_live = livef[kw];
-      const int Lr = K.v_route_len[vv], rb = K.v_route_base[vv], start = K.v_start[vv];
-      const int32_t* now = frame_of(K, env, dq_d[0]);
-      r_node[t][0] = d[1];
-      r_node[t][DQ_MAX_NODES - 1] = d[2];
-      if (R.on) {
-        const long long ring = (long long)R.cap - 1;
-        const int agent = d[1] < 0 ? 0 : (d[1] >= R.P ? R.P - 1 : d[1]);
-        const long long prev = R.last[(size_t)env * R.P + agent];
-        r_slot[t][0] = (int)(dq_head & ring);
-        r_slot[t][1] = R.prev_active[env] ? (int)R.prev_j[env] : -1;
-        r_slot[t][2] = prev >= 0 ? (int)(prev & ring) : -1;
-      }
-      {
-        const int k = now == livef ? k_live : now ? now[kw] : 0;
-        int x = (start + k) % Lr;
-        for (int j = 1; j < M.n_nodes; j++) {
-          x = (x + 1 == Lr) ? 0 : x + 1;
-          r_node[t][j] = now ? (int)K.route_port[rb + x] : 0;
-        }
-      }
+    for (int i = 0; i < 5; i++) dq_d[i] = d[i];
+    const int32_t* live = K.live + (size_t)env * K.FW;  // the decision's frame is the live frame
+    const int v = (unsigned)dq_d[2] < (unsigned)K.V ? dq_d[2] : 0;
+    dq_space = live[K.f_vessels + VA_REMAINING_SPACE * K.V + v];
+    dq_early = live[K.f_vessels + VA_EARLY_DISCHARGE * K.V + v];
+    if (R.on) {
+      dq_head = R.head[env];
+      const int agent = dq_d[1] < 0 ? 0 : (dq_d[1] >= R.P ? R.P - 1 : dq_d[1]);
+      dq_last = R.last[(size_t)env * R.P + agent];
     }
+    if (M.epsilon > 0.f) dq_seed = K.seed[env];
   }
-  for (int i = t; i < DQ_TILE * n_ticks; i += blockDim.x) {
-    const int r = i / n_ticks, ti = i - r * n_ticks;
-    const int env = r < rows ? list[r] : -1;
-    const int32_t* f = nullptr;
-    if (env >= 0) {
-      const int tick = decisions[(size_t)env * 8];
-      f = frame_of(K, env, max(0, tick - ti));  // ticks = [max(0, tick - rt) for rt in range(look_back - 1)]
+  // ---- the tile's state rows (written by the state waves of mrx_k_cim_dqn_prep): 16-byte loads, rows past the list zero
+  {
+    const int kp0 = M.kpad[0], q4 = kp0 >> 2;
+    for (int i = t; i < DQ_TILE * q4; i += 256) {
+      const int r = i / q4, c4 = i - r * q4;
+      dq_f4 v = dq_f4{0.f, 0.f, 0.f, 0.f};
+      if (r < rows) v = *(const dq_f4*)(xrows + (size_t)list[r] * kp0 + c4 * 4);
+      *(dq_f4*)(&X[0][r * DQ_LD + c4 * 4]) = v;
     }
-    r_frame[r][ti] = f;
-  }
-  const int kp0 = M.kpad[0], per_tick = M.n_nodes * M.n_pa, n_port_feats = n_ticks * per_tick;
-  if (t < kp0) {
-    int info = -1;  // padding column
-    if (t < n_port_feats) {
-      const int ti = t / per_tick, rem = t - ti * per_tick, ni = rem / M.n_pa, a = M.pa[rem - ni * M.n_pa];
-      info = ti | (ni << 8) | ((a == PA_TRANSFER_COST ? 1 : 0) << 15) | ((K.f_ports + a * K.P) << 16);
-    } else if (t < M.state_dim) {
-      info = 0 | (0x7f << 8) | (M.va[t - n_port_feats] << 16);  // vessel attribute of the decision's frame
-    }
-    c_info[t] = info;
   }
   __syncthreads();
   DQ_MARK();
 
-  // ---- state rows (float32, as FullyConnected.forward's x.float()): ports[ticks : nodes : port_attrs] then
-  //      vessels[tick : vessel : vessel_attrs]; thread = column, independent loads in flight per thread
-  if (t < kp0) {
-    const int info = c_info[t];
-    const int ti = info & 0xff, ni = (info >> 8) & 0x7f, word = info >> 16;
-    const bool is_f32 = (info >> 15) & 1, vessel_col = ni == 0x7f;
-    int32_t raw[DQ_TILE];
-    unsigned okm = 0;
-#pragma unroll
-    for (int r = 0; r < DQ_TILE; r++) {  // all the tile's loads of this column in flight at once
-      const int32_t* f = r_frame[r][ti];
-      const int node = vessel_col ? r_node[r][DQ_MAX_NODES - 1] : r_node[r][ni];  // last slot: the deciding vessel
-      const bool ok = r_env[r] >= 0 && info >= 0 && f != nullptr && (unsigned)node < (unsigned)(vessel_col ? K.V : K.P);
-      const int w = vessel_col ? frame_word(K, 1, word, node, 0) : word + node;
-      raw[r] = *(ok ? f + w : K.live);  // always a valid address: no branch around the load
-      okm |= (unsigned)ok << r;
-    }
-#pragma unroll
-    for (int r = 0; r < DQ_TILE; r++) {
-      const float v = !((okm >> r) & 1) ? 0.f : is_f32 ? bits_f(raw[r]) : (float)raw[r];
-      if (state_out && r_env[r] >= 0 && info >= 0) state_out[(size_t)r_env[r] * M.state_dim + t] = v;
-      if (R.on && r_env[r] >= 0 && info >= 0) {
-        // the transition's state row, the previous element's next state, the agent's previous element's next agent state:
-        // consecutive threads write consecutive words of each row
-        const size_t base = (size_t)r_env[r] * R.cap;
-        rec_store(R.c_state, (base + r_slot[r][0]) * R.D + t, v, R.f64);
-        if (r_slot[r][1] >= 0) rec_store(R.c_next_state, (base + r_slot[r][1]) * R.D + t, v, R.f64);
-        if (r_slot[r][2] >= 0) rec_store(R.c_nas, (base + r_slot[r][2]) * R.D + t, v, R.f64);
-      }
-      X[r * DQ_LD + t] = v;
-    }
-  }
-  __syncthreads();
-
-  // ---- the dense chain of this port's network
+  // ---- the dense chain of this port's network, ping-pong between the two activation buffers
   const float* net = M.weights + (size_t)port * M.net_floats;
-  DQ_MARK();
+  int cur = 0;
   for (int l = 0; l < M.n_layers; l++) {
-    dq_layer<DQ_TILE>(X, net + M.w_off[l], net + M.b_off[l], M.kpad[l], M.npad[l], l + 1 < M.n_layers, M.slope);
+#ifdef MRX_DQN_PROFILE
+    if (t == 0) dq_prof_layer = l;
+    __syncthreads();
+#endif
+    dq_layer<DQ_TILE>(X[cur], X[cur ^ 1], net + M.w_off[l], net + M.b_off[l], M.kpad[l], M.npad[l], l + 1 < M.n_layers, M.slope);
+    cur ^= 1;
     DQ_MARK();
   }
 
   // ---- q = adv - mean(adv) + v (dqn.py:48-52), greedy action, env_sampler.py:33-64 translation
   if (t < rows) {
-    const int env = r_env[t];
-    const float* y = X + t * DQ_LD;
+    const int env = dq_env;
+    const float* y = X[cur] + t * DQ_LD;
     const int A = M.n_actions;
     float mean = 0.f;
     if (M.dueling) {
@@ -435,7 +518,7 @@ __device__ __forceinline__ void mrx_dqn_forward_body(const CimParams& K, const c
       if (q_out) q_out[(size_t)env * A + a] = q;
       if (q > bq) { bq = q; best = a; }
     }
-    const int32_t* d = dq_d;  // (requested with the row lookups)
+    const int32_t* d = dq_d;
     if (M.epsilon > 0.f) {  // counter-based epsilon-greedy keyed on (env seed, tick, vessel)
       const unsigned long long x = dq_mix64((unsigned long long)dq_seed, (((unsigned long long)(unsigned)d[0] << 8) | (unsigned)d[2]) + 0x200000000ull);
       if ((double)(x >> 11) * (1.0 / 9007199254740992.0) < (double)M.epsilon) best = (int)(dq_mix64(x, 1) % (unsigned long long)A);
@@ -457,41 +540,60 @@ __device__ __forceinline__ void mrx_dqn_forward_body(const CimParams& K, const c
     a[1] = d[1];
     a[2] = (int32_t)qty;
     a[3] = is_load ? MRX_ACTION_LOAD : MRX_ACTION_DISCHARGE;
-    if (R.on) {   // the scalar half of the transition (mrx_k_cim_sampler_record's lane 0)
+    if (R.on) {   // the scalar half of the transition (mrx_k_cim_sampler_record's lane 0); its rows were written by the state wave
+      const long long ring = (long long)R.cap - 1;
       const int agent = d[1] < 0 ? 0 : (d[1] >= R.P ? R.P - 1 : d[1]);
       const long long q = dq_head;
-      const size_t base = (size_t)env * R.cap, ci = base + r_slot[t][0];
+      const int s0 = (int)(q & ring), s2 = dq_last >= 0 ? (int)(dq_last & ring) : -1;
+      const size_t base = (size_t)env * R.cap, ci = base + s0;
       R.c_tick[ci] = d[0];
       R.c_agent[ci] = agent;
       R.c_action[ci] = best;
       R.c_terminal[ci] = 0;
-      if (r_slot[t][2] >= 0) R.c_terminal[base + r_slot[t][2]] = 0;
+      if (s2 >= 0) R.c_terminal[base + s2] = 0;
       R.c_env_action[ci * 4 + 0] = a[0]; R.c_env_action[ci * 4 + 1] = a[1]; R.c_env_action[ci * 4 + 2] = a[2]; R.c_env_action[ci * 4 + 3] = a[3];
       R.last[(size_t)env * R.P + agent] = q;
       R.head[env] = q + 1;
-      R.prev_j[env] = r_slot[t][0];
+      R.prev_j[env] = s0;
       R.prev_active[env] = 1;
       R.steps_env[env] += 1;
     }
   }
 #ifdef MRX_DQN_PROFILE
   DQ_MARK();
-  if (t == 0 && q_out) for (int i = 0; i + 1 < tmi; i++) q_out[(size_t)blockIdx.x * 16 + i] = (float)(tm[i + 1] - tm[i]);  // overwrites q rows: profiling build only
+  if (t == 0 && q_out) {   // profiling build only: the caller's q buffer has room for 16 floats per workgroup behind the n_envs rows
+    float* qp = q_out + (size_t)K.n_envs * M.n_actions;
+    for (int i = 0; i + 1 < tmi; i++) qp[(size_t)blockIdx.x * 16 + i] = (float)(tm[i + 1] - tm[i]);
+    qp[(size_t)blockIdx.x * 16 + 10] = (float)(port * 64 + rows);
+    qp[(size_t)blockIdx.x * 16 + 12] = (float)(rt0 & 0xfffff);
+    qp[(size_t)blockIdx.x * 16 + 13] = (float)(tm[0] & 0xfffff);
+    qp[(size_t)blockIdx.x * 16 + 14] = (float)(tm[tmi - 1] - tm[0]);
+    qp[(size_t)blockIdx.x * 16 + 15] = (float)((long long)__builtin_amdgcn_s_memrealtime() - rt0);
+    // per-wave stamps of the layers behind the per-workgroup rows: [workgroup][layer][wave][4 deltas]
+    float* qw = qp + (size_t)gridDim.x * 16 + (size_t)blockIdx.x * (DQ_MAX_LAYERS * 16);
+    for (int l = 0; l < M.n_layers; l++)
+      for (int w = 0; w < 4; w++) {
+        qw[(l * 4 + w) * 4 + 0] = (float)(dq_prof[l][w][2] - dq_prof[l][w][0]);   // entry -> k loop done
+        qw[(l * 4 + w) * 4 + 1] = (float)(dq_prof[l][w][3] - dq_prof[l][w][2]);   // epilogue
+        qw[(l * 4 + w) * 4 + 2] = (float)(dq_prof[l][w][4] - dq_prof[l][w][3]);   // barrier wait
+        qw[(l * 4 + w) * 4 + 3] = (float)(dq_prof[l][w][0] - dq_prof[l][0][0]);   // entry skew vs wave 0
+      }
+  }
 #endif
 #undef DQ_MARK
 }
 
 extern "C" __global__ void __launch_bounds__(256)
-mrx_k_cim_dqn_forward(CimParams K, cim::DqnParams M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
-                      const int32_t* __restrict__ lists, int32_t* __restrict__ actions, float* __restrict__ q_out,
-                      float* __restrict__ state_out, int32_t* __restrict__ choice_out, cim::SamplerRec R) {
-  mrx_dqn_forward_body<32>(K, M, decisions, cnt, lists, actions, q_out, state_out, choice_out, R);
+mrx_k_cim_dqn_mlp32(CimParams K, cim::DqnParams M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
+                    const int32_t* __restrict__ lists, const float* __restrict__ xrows, int32_t* __restrict__ actions, float* __restrict__ q_out,
+                    int32_t* __restrict__ choice_out, cim::SamplerRec R) {
+  mrx_dqn_mlp_body<32>(K, M, decisions, cnt, lists, xrows, actions, q_out, choice_out, R);
 }
 
 // 16-env tiles: the same kernel with one MFMA row tile per workgroup
 extern "C" __global__ void __launch_bounds__(256)
-mrx_k_cim_dqn_forward16(CimParams K, cim::DqnParams M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
-                        const int32_t* __restrict__ lists, int32_t* __restrict__ actions, float* __restrict__ q_out,
-                        float* __restrict__ state_out, int32_t* __restrict__ choice_out, cim::SamplerRec R) {
-  mrx_dqn_forward_body<16>(K, M, decisions, cnt, lists, actions, q_out, state_out, choice_out, R);
+mrx_k_cim_dqn_mlp16(CimParams K, cim::DqnParams M, const int32_t* __restrict__ decisions, int32_t* __restrict__ cnt,
+                    const int32_t* __restrict__ lists, const float* __restrict__ xrows, int32_t* __restrict__ actions, float* __restrict__ q_out,
+                    int32_t* __restrict__ choice_out, cim::SamplerRec R) {
+  mrx_dqn_mlp_body<16>(K, M, decisions, cnt, lists, xrows, actions, q_out, choice_out, R);
 }

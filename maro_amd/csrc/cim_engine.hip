@@ -959,10 +959,14 @@ static int dqn_tile_rows(const CimParams& K) {
 }
 static long long dqn_max_tiles(const CimParams& K, int tile) { return (((long long)K.n_envs + tile - 1) / tile + K.P + 7) / 8 * 8 + 8; }  // (8 runs of ceil(tiles / 8) slots)
 
+// scratch layout: int32 counters [128] (cnt[64], ticket), the per-port env lists [P][n_envs], then — 16-byte aligned — the state
+// rows float32 [n_envs][kpad[0] <= 256] the prep launch's state waves write and the MLP kernel's tiles read
+static long long dqn_rows_offset(const CimParams& K) { return ((128 + (long long)K.P * K.n_envs + 3) / 4) * 4; }   // in int32 words
+
 int64_t mrx_cim_dqn_scratch_bytes(mrx_handle h) {
   if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
   const CimParams& K = h->plan.kp;
-  return 4 * (128 + (long long)K.P * K.n_envs);  // counters + ticket, then one env list per port
+  return 4 * (dqn_rows_offset(K) + (long long)K.n_envs * cim::DQ_MAX_WIDTH);
 }
 
 static int dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_decisions, void* d_scratch, int32_t* d_actions,
@@ -997,25 +1001,26 @@ static int dqn_act(mrx_handle h, const mrx_cim_dqn_model* m, const int32_t* d_de
   if (rc != MRX_OK) return rc;
   int32_t* cnt = (int32_t*)d_scratch;
   int32_t* lists = cnt + 128;
-  // as in mrx_cim_random_policy: with a sorted launch form one extra workgroup of the binning launch builds the order list of the
+  float* xrows = (float*)(cnt + dqn_rows_offset(K));
+  // as in mrx_cim_random_policy: with a sorted launch form one extra workgroup of the first launch builds the order list of the
   // coming step (it only depends on the previous step's hints), so the mrx_cim_step that follows on this stream needs no
   // schedule kernel of its own
   static const bool fuse = !(getenv("MRX_CIM_FUSE_SCHEDULE") && atoi(getenv("MRX_CIM_FUSE_SCHEDULE")) == 0);
   const int sched_per = (fuse && effective_step_mode(h) >= 2) ? ((K.n_envs + 255) / 256 + 15) / 16 * 16 : 0;
-  hipLaunchKernelGGL(mrx_k_cim_dqn_bin, dim3((unsigned)((K.n_envs + 255) / 256 + (sched_per > 0 ? 1 : 0))), dim3(256), 0, (hipStream_t)stream, K.n_envs, K.P,
-                     d_decisions, cnt, lists, d_n_actions, (unsigned long long*)d_counter, (const uint8_t*)K.hint, K.order, K.sched,
-                     sched_per > 0 ? (sched_per | (h->lpt << 24)) : 0, R);
+  const int n_bin = (K.n_envs + 255) / 256, n_state = (K.n_envs + 3) / 4;
+  hipLaunchKernelGGL(mrx_k_cim_dqn_prep, dim3((unsigned)(n_bin + (sched_per > 0 ? 1 : 0) + n_state)), dim3(256), 0, (hipStream_t)stream, K, D, n_bin,
+                     d_decisions, cnt, lists, d_n_actions, (unsigned long long*)d_counter, sched_per > 0 ? (sched_per | (h->lpt << 24)) : 0, xrows, d_state, R);
   h->order_ready = sched_per > 0;
   h->order_stream = stream;
   const int tile = dqn_tile_rows(K);
   static const bool xcd_runs = !(getenv("MRX_DQN_XCD") && atoi(getenv("MRX_DQN_XCD")) == 0);   // (0: block i takes tile i — experiments)
   D.xcd_runs = xcd_runs ? 1 : 0;
   if (tile == 16)
-    hipLaunchKernelGGL(mrx_k_cim_dqn_forward16, dim3((unsigned)dqn_max_tiles(K, 16)), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, cnt, lists,
-                       d_actions, d_q, d_state, d_choice, R);
+    hipLaunchKernelGGL(mrx_k_cim_dqn_mlp16, dim3((unsigned)dqn_max_tiles(K, 16)), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, cnt, lists, xrows,
+                       d_actions, d_q, d_choice, R);
   else
-    hipLaunchKernelGGL(mrx_k_cim_dqn_forward, dim3((unsigned)dqn_max_tiles(K, 32)), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, cnt, lists,
-                       d_actions, d_q, d_state, d_choice, R);
+    hipLaunchKernelGGL(mrx_k_cim_dqn_mlp32, dim3((unsigned)dqn_max_tiles(K, 32)), dim3(256), 0, (hipStream_t)stream, K, D, d_decisions, cnt, lists, xrows,
+                       d_actions, d_q, d_choice, R);
   HIP_TRY(hipGetLastError());
   return MRX_OK;
 }

@@ -51,3 +51,18 @@ def test_the_package_never_reaches_for_the_oracle_or_the_emulator():
                 if pat.search(line) and not line.lstrip().startswith("#") or (pat is inc and pat.search(line)):
                     hits.append(f"{os.path.relpath(os.path.join(root, f), REPO)}:{i}: {line.strip()}")
     assert not hits, hits
+
+
+def test_the_exchange_functions_hold_only_the_path_a_multi_gpu_run_takes():
+    """maro_amd/cim/rollout.py posts its tensors to torch.distributed as they are: no branch on the process group's backend and no
+    host staging copy (a harness that needs one injects tests/transport.py::HostStaging)."""
+    src = open(os.path.join(REPO, "maro_amd", "cim", "rollout.py")).read()
+    code = "\n".join(line.split("#")[0] for line in src.splitlines())
+    code = re.sub(r'"""(?s:.*?)"""', "", code)
+    assert "get_backend" not in code and ".cpu()" not in code
+    from maro_amd.cim.rollout import Transport
+    t = torch.arange(6).view(2, 3)
+    tp = Transport()
+    assert tp.outbound(t) is t and tp.inbound(t, t.device) is t
+    land = tp.landing([4, 3], t)
+    assert land.shape == (4, 3) and land.dtype == t.dtype and land.device == t.device

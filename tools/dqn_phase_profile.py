@@ -14,12 +14,15 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 5461
 eng = CimBatchEngine("global_trade.22p_l0.8", n, durations=1120, max_snapshots=8, order_table=1, seeds=torch.arange(n, dtype=torch.int64) + 1)
 fused = FusedPerPortDQN(eng, random_chains(22, CimBatchSampler(eng).state_dim, 21, seed=0))
 actions = torch.zeros((n, 1, 4), dtype=torch.int32, device="cuda"); n_actions = torch.zeros((n,), dtype=torch.int32, device="cuda")
-q = torch.zeros((max(n, 4096), 21), dtype=torch.float32, device="cuda")
+q = torch.zeros((n + 4096 + 8 * (n // 16 + 64), 21), dtype=torch.float32, device="cuda")   # profile rows (16 floats per workgroup) behind the n q rows
 eng.step()
 for i in range(60):
     fused.act(actions, n_actions, q=q)
     eng.step(actions, n_actions)
 q.zero_()
+if os.environ.get("MRX_DQN_PROFILE_WARM"):   # the measured call right after an identical one: the weights are L2-warm, nothing ran in between
+    fused.act(actions, n_actions, q=q)
+    q.zero_()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 torch.cuda.synchronize()
 ev[0].record()
@@ -27,9 +30,23 @@ fused.act(actions, n_actions, q=q)
 ev[1].record()
 torch.cuda.synchronize()
 print(f"n_envs {n}, tile rows {os.environ.get('MRX_DQN_TILE', 'default')}: bin + forward launch = {ev[0].elapsed_time(ev[1]) * 1e3:.1f} us (events)")
-t = q.view(-1)[: 16 * (n // 16 + 23)].view(-1, 16)
+t = q.view(-1)[n * 21: n * 21 + 16 * (n // 16 + 64)].view(-1, 16)
 t = t[t[:, 0] > 0]
-names = ["row lookups", "state gather"] + [f"layer {i}" for i in range(6)] + ["argmax+translate"]
-print("workgroups", t.shape[0], "s_memtime ticks; sum of the phase means =", float(t[:, :9].mean(dim=0).sum()))
+names = ["row loads"] + [f"layer {i}" for i in range(6)] + ["argmax+translate"]
+print("workgroups", t.shape[0], "s_memtime ticks; sum of the phase means =", float(t[:, :8].mean(dim=0).sum()))
 for i, nm in enumerate(names):
     print(f"  {nm:18s} mean {float(t[:, i].mean()):9.0f}  max {float(t[:, i].max()):9.0f}")
+print(f"  marked span: {float(t[:, 14].mean()):.0f} s_memtime ticks in {float(t[:, 15].mean()) * 10:.0f} ns (s_memrealtime) -> {float(t[:, 14].sum() / (t[:, 15].sum() * 10)):.3f} ticks per ns = shader GHz under this launch")
+grid = int(os.environ.get("MRX_DQN_GRID", 0)) or ((n + 15) // 16 + 22 + 7) // 8 * 8 + 8
+tw = q.view(-1)[n * 21 + grid * 16: n * 21 + grid * 16 + grid * 128].view(grid, 8, 4, 4)
+tw = tw[(q.view(-1)[n * 21: n * 21 + grid * 16].view(grid, 16)[:, 0] > 0)]
+print("per layer and wave (means over workgroups): entry->k loop done | epilogue | barrier wait | entry skew")
+for l in range(6):
+    print(f"  layer {l}: " + "  ".join("w%d %5.0f %4.0f %5.0f %4.0f" % (w, *[float(tw[:, l, w, j].mean()) for j in range(4)]) for w in range(4)))
+if os.environ.get("MRX_DQN_PROFILE_DUMP"):
+    import numpy as np
+    a = t.cpu().numpy()
+    t0 = a[:, 12].min()
+    print("per workgroup (sorted by start): start_us dur_us port rows | phases")
+    for i in np.argsort(a[:, 12]):
+        print(f"  {(a[i, 12] - t0) / 100:7.2f} {a[i, 15] / 100:7.2f}  p{int(a[i, 10]) // 64:2d} r{int(a[i, 10]) % 64:2d} | " + " ".join(f"{int(v):6d}" for v in a[i, :8]))
