@@ -15,9 +15,10 @@
 //                                    thousands of resident waves hide — written as a contiguous zero-padded f32 row, plus the
 //                                    transition cache's three copies of it
 //   mrx_k_cim_dqn_mlp      one workgroup (4 waves) per 16- or 32-env tile of one port's list: the rows arrive as 16-byte loads,
-//                          the dense chain runs layer by layer between two LDS activation buffers (one barrier per layer),
-//                          weights streamed from L2 as coalesced 16-byte loads in the packed layout below, 16 KB per wave
-//                          in flight, then argmax + action translation + the scalar half of the transition.
+//                          the dense chain runs layer by layer between two LDS activation buffers (one LDS-only barrier per
+//                          layer); each wave reads ITS share of the net's weights as one contiguous stream of 1 KB fragments
+//                          (packed in consumption order, below) through a register ring two passes deep that never stops at
+//                          a layer boundary; then argmax + action translation + the scalar half of the transition.
 // HIP only (not part of the CPU wave emulator build).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,14 +28,16 @@
 namespace cim {
 
 enum { DQ_MAX_LAYERS = 8, DQ_MAX_WIDTH = 256, DQ_TILE_MAX = 32, DQ_LD = DQ_MAX_WIDTH + 4, DQ_MAX_TICKS = 16, DQ_MAX_NODES = 8,
-       DQ_SLOTS = 16 /* 16-byte weight loads a wave keeps in flight (PF k-blocks x NT column tiles): 16 KB, several L2 latencies of MFMA work */ };
+       DQ_PASS = 8 /* weight fragments (16 bytes per lane, 1 KB per wave) a pass of the k loop consumes */,
+       DQ_SLOTS = 2 * DQ_PASS /* fragments a wave keeps in flight: 16 KB, two passes ahead of the MFMAs */ };
 
 struct DqnParams {
   int n_layers, dueling, state_dim, look_back, n_nodes, n_pa, n_va, n_actions;
   int xcd_runs;  // 1: XCD-aware tile order (launch configuration, set by the host)
   int pa[8], va[8];
   int kpad[DQ_MAX_LAYERS], npad[DQ_MAX_LAYERS], n_out[DQ_MAX_LAYERS];
-  long long w_off[DQ_MAX_LAYERS], b_off[DQ_MAX_LAYERS], net_floats;
+  long long s_off[4][DQ_MAX_LAYERS];   // where wave w's fragments of layer l start (floats from the net's first)
+  long long b_off[DQ_MAX_LAYERS], net_floats;
   float slope, epsilon;
   const float* weights;
   double action_space[32];
@@ -67,157 +70,121 @@ __device__ __forceinline__ void rec_store(void* base, size_t i, float v, int f64
   if (f64) ((double*)base)[i] = (double)v; else ((float*)base)[i] = v;
 }
 
-// padded widths: a layer's outputs are split over the 4 waves in 16-column MFMA tiles
-__host__ __device__ inline int dq_npad(int n) { return n <= 16 ? 16 : n <= 32 ? 32 : (n + 63) / 64 * 64; }
+// padded widths: a layer's outputs are split over the 4 waves in 16-column MFMA tiles — wave w takes tiles w, w + 4, ... (NT = 1, 2
+// or 4 of them); a 32-wide layer keeps waves 0 and 1 busy, a 16-wide one wave 0
+__host__ __device__ inline int dq_npad(int n) { return n <= 16 ? 16 : n <= 32 ? 32 : n <= 64 ? 64 : n <= 128 ? 128 : 256; }
 __host__ __device__ inline int dq_kpad(int k) { return (k + 15) / 16 * 16; }
+__host__ __device__ inline int dq_sh(int Npad) { return Npad <= 64 ? 0 : Npad == 128 ? 1 : 2; }   // log2(NT)
+__host__ __device__ inline bool dq_idle(int Npad, int w) { return Npad == 16 ? w >= 1 : Npad == 32 ? w >= 2 : false; }
+// fragments of a layer in wave w's stream: k-blocks x NT, rounded up to whole passes (the padding is never consumed)
+__host__ __device__ inline int dq_frags(int Kpad, int Npad, int w) {
+  return dq_idle(Npad, w) ? 0 : ((((Kpad >> 4) << dq_sh(Npad)) + DQ_PASS - 1) / DQ_PASS) * DQ_PASS;
+}
 
-// Packed weight layout of one layer (K = kpad inputs, N = npad outputs, zero padded): 16 inputs x 1 output column are
-// stored as 4 groups g of 4 consecutive floats, Wp[((kb * N + n) * 4 + g) * 4 + s] = W[kb * 16 + g * 4 + s][n], so that
-// MFMA lane (n & 15, g) fetches its B operands of four consecutive k-steps with one 16-byte load and a wave reads
-// 1 KB contiguous.  The A operand uses the same k permutation (one ds_read_b128 per lane from the activation row).
-__host__ __device__ inline long long dq_w_index(int k, int n, int N) {
-  return (((long long)(k >> 4) * N + n) * 4 + ((k >> 2) & 3)) * 4 + (k & 3);
+// Packed weight layout: a FRAGMENT is 16 inputs (k-block kb) x the 16 output columns of one tile, 256 floats, float
+// [(k >> 2) & 3][col & 15][k & 3] — MFMA lane (col & 15, g) fetches its operands of four consecutive k-steps with one 16-byte
+// load and a wave reads 1 KB contiguous (the activations use the same k permutation: one ds_read_b128 per lane).  A wave's
+// fragments of a layer are stored in the order it consumes them (k-block major, its column tiles minor), the layers one after
+// another, the four waves' streams one after another: a wave reads ONE contiguous stream from the first layer's first fragment
+// to the last layer's last, whatever the layer boundaries.  dq_w_slot: (wave, fragment within the layer, float within the fragment).
+__host__ __device__ inline void dq_w_slot(int k, int n, int Npad, int* w, int* frag, int* within) {
+  const int tile = n >> 4, sh = dq_sh(Npad);
+  int nt = 0;
+  if (Npad == 16) *w = 0; else if (Npad == 32) *w = tile; else { *w = tile & 3; nt = tile >> 2; }
+  *frag = ((k >> 4) << sh) + nt;
+  *within = ((k >> 2) & 3) * 64 + (n & 15) * 4 + (k & 3);   // = lane (g * 16 + col) * 4 + s: a wave's load is lane-contiguous
 }
 
 typedef float dq_f4 __attribute__((ext_vector_type(4)));
 
-// A 16-byte load from a WAVE-UNIFORM base + a per-lane byte offset, in the scalar-base form (global_load_dwordx4 v, v_off, s[base]):
-// the empty asm pins the base in scalar registers — left alone, hipcc folds the lane offset into a 64-bit vector address per
-// load (two address registers and two vector adds for each of the 32 slots a wave keeps in flight).
-__device__ __forceinline__ dq_f4 dq_ldw(const float* ubase, unsigned lane_off) {
-  const __attribute__((address_space(1))) char* b = (const __attribute__((address_space(1))) char*)ubase;
-  asm volatile("" : "+s"(b));
-  return *(const __attribute__((address_space(1))) dq_f4*)(b + lane_off);
+// A 16-byte load per lane from a WAVE-UNIFORM byte offset into the net + a per-lane byte offset, as a buffer load
+// (buffer_load_dwordx4 v, v_lane_off, s[rsrc], s_off offen): the descriptor and the stream offset stay in scalar registers, so a
+// fragment costs one scalar add and one load — hipcc turns the same thing written with pointers into a 64-bit vector address per load.
+typedef int dq_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dq_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);   // (raw buffer, no swizzle; gfx9 word 3)
+}
+__device__ __forceinline__ dq_f4 dq_ldw(__amdgpu_buffer_rsrc_t rs, int soff_bytes, unsigned lane_off) {
+  return __builtin_bit_cast(dq_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off, soff_bytes, 0));
 }
 
-// One dense layer for MT row tiles x NT column tiles of this wave: Y = X W (+ bias, LeakyReLU), X read from the LDS buffer `Xin`
-// (row stride DQ_LD), Y written to the OTHER buffer `Xout` — no barrier between reading and writing, one after the layer.
-// The wave's weights (B operands, L2) are fetched PF = DQ_SLOTS / NT k-blocks ahead into STATIC register slots: the prologue
-// requests the first PF blocks (every block of a layer with at most PF of them: no refill logic runs at all), each full pass
-// consumes slot p and refills it with the block PF ahead; the last full pass refills only where a tail block follows.  The
-// passes are straight-line code (a load is waited for with vmcnt(slots still in flight), never vmcnt(0)).
-#ifdef MRX_DQN_PROFILE
-__shared__ long long dq_prof[DQ_MAX_LAYERS][4][6];   // [layer][wave][entry, first block done, k loop done, epilogue written, barrier passed]
-__shared__ int dq_prof_layer;
-#define DQ_STAMP(I) do { if ((threadIdx.x & 63) == 0) dq_prof[dq_prof_layer][threadIdx.x >> 6][I] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define DQ_STAMP(I) do {} while (0)
-#endif
+// A workgroup barrier that orders LDS traffic only: __syncthreads() also drains every global load in flight (vmcnt(0)), which
+// would throw away the weights requested ahead for the next layer.
+__device__ __forceinline__ void dq_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- the dense chain of one wave.  The wave's share of the network's weights is ONE contiguous stream of fragments (layout
+// above), consumed in PASSES of DQ_PASS fragments: 8 / NT k-blocks of one layer (a layer's last pass may be partial: its padding
+// fragments are fetched and skipped).  The fragments live in a ring of 2 x DQ_PASS static register slots; consuming slot p of a pass
+// refills it with the fragment 2 passes further down the stream — the same layer's next k-blocks or the next layer's first:
+// weights do not depend on activations, so the stream never stops at a layer boundary, a layer starts with its weights in
+// registers, and a refill is one 64-bit pointer bump per pass + one load per fragment (immediate offsets).  Every load of a pass
+// is unconditional, so the compiler waits for a slot with vmcnt(number of younger loads), never vmcnt(0).
+//
+// One pass (template: MT row tiles, NT column tiles, H = which half of the ring): k-blocks of a layer whose input rows start at
+// `xk` (the lane's row, k group and the pass's first k-block), `nvalid` fragments to consume, `refill` = the stream 2 passes ahead.
+// The MFMA computes the TRANSPOSED tile (weights as the A operand, activations as B): a lane then holds four CONSECUTIVE output
+// columns of one row — one 16-byte LDS store per tile in the epilogue.  `acur` holds the activations of the pass's first k-block
+// on entry and of the next pass's first block on exit (requested from LDS one block ahead; the block after a layer's last is
+// read and dropped).
+template <int MT, int NT, int H, bool FULL>
+__device__ __forceinline__ void dq_pass(dq_f4 (&ring)[DQ_SLOTS], dq_f4 (&acc)[DQ_TILE_MAX / 16][4], dq_f4 (&acur)[DQ_TILE_MAX / 16], const float* xk, int nvalid,
+                                        __amdgpu_buffer_rsrc_t rs, int refill, unsigned lane_off) {
+  dq_f4 an_[MT];
+#pragma unroll
+  for (int p = 0; p < DQ_PASS; p++) {
+    const int kbl = p / NT, nt = p % NT;
+    if (nt == 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) an_[mt] = *(const dq_f4*)(xk + mt * 16 * DQ_LD + (kbl + 1) * 16);
+    }
+    const dq_f4 b_ = ring[H * DQ_PASS + p];
+    ring[H * DQ_PASS + p] = dq_ldw(rs, refill + p * 1024, lane_off);
+    if (FULL || p < nvalid) {   // (FULL: a pass of 8 valid fragments is straight-line code; the partial form branches per fragment)
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_[s], acur[mt][s], acc[mt][nt], 0, 0, 0);
+    }
+    if (nt == NT - 1) {
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) acur[mt] = an_[mt];
+    }
+  }
+}
+
+template <int MT, int NT, int H>
+__device__ __forceinline__ void dq_pass_any(dq_f4 (&ring)[DQ_SLOTS], dq_f4 (&acc)[DQ_TILE_MAX / 16][4], dq_f4 (&acur)[DQ_TILE_MAX / 16], const float* xk, int nvalid,
+                                            __amdgpu_buffer_rsrc_t rs, int refill, unsigned lane_off) {
+  if (nvalid >= DQ_PASS) dq_pass<MT, NT, H, true>(ring, acc, acur, xk, nvalid, rs, refill, lane_off);
+  else dq_pass<MT, NT, H, false>(ring, acc, acur, xk, nvalid, rs, refill, lane_off);
+}
+
+// bias + LeakyReLU, the tile rows written to the other activation buffer; D[i][j]: i = (lane >> 4) * 4 + e = the output column
+// within the tile, j = lane & 15 = the row.  Leaves the accumulators zero for the next layer.
 template <int MT, int NT>
-__device__ __forceinline__ void dq_dense(const float* __restrict__ Xin, float* __restrict__ Xout, const float* __restrict__ Wp,
-                                         const float* __restrict__ bias, int Kpad, int Npad, int m0, int nt0, int nt_step, bool idle,
-                                         bool act, float slope) {
-  constexpr int PF = DQ_SLOTS / NT;
+__device__ __forceinline__ void dq_epilogue(dq_f4 (&acc)[DQ_TILE_MAX / 16][4], const dq_f4 (&bv)[4], float* __restrict__ Xout, int col0, int colstep, bool act, float slope) {
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  DQ_STAMP(0);
-  if (!idle) {
-    float bv[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) bv[nt] = bias[(nt0 + nt * nt_step) * 16 + r];
-    dq_f4 acc[MT][NT];
+  for (int nt = 0; nt < NT; nt++) {
+    const int col = col0 + nt * colstep + g * 4;
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++)
+    for (int mt = 0; mt < MT; mt++) {
+      dq_f4 v = acc[mt][nt] + bv[nt];
+      if (act) {
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) acc[mt][nt] = dq_f4{0.f, 0.f, 0.f, 0.f};
-    const int nkb = Kpad >> 4;
-    dq_f4 bq[PF][NT];
-    // addresses: a wave-uniform base (scalar registers: nt0 / m0 come from the wave index through readfirstlane) + ONE per-lane
-    // byte offset shared by every load — 32 slots must not cost 64 address registers
-    const float* wbase = Wp + (size_t)nt0 * 256;
-    const unsigned lane_off = (unsigned)(r * 64 + g * 16);
-#define DQ_LDW(UBASE) dq_ldw((UBASE), lane_off)
-    const float* xlane = Xin + (m0 * 16 + r) * DQ_LD + g * 4;
-    const size_t kstep = (size_t)Npad * 16, nstep = (size_t)nt_step * 256;
-    const int nfull = nkb / PF, rem = nkb - nfull * PF;
-#pragma unroll
-    for (int p = 0; p < PF; p++)
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) bq[p][nt] = DQ_LDW(wbase + (size_t)min(p, nkb - 1) * kstep + nt * nstep);
-    // the A operand (activations, LDS) of block KB + 1 is requested before block KB's MFMAs: the LDS round trip hides behind them
-    dq_f4 acur[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++) acur[mt] = *(const dq_f4*)(xlane + mt * 16 * DQ_LD);
-#define DQ_MFMA(KB, B)                                                                                      \
-  {                                                                                                         \
-    dq_f4 an_[MT];                                                                                          \
-    _Pragma("unroll") for (int mt = 0; mt < MT; mt++) an_[mt] = *(const dq_f4*)(xlane + mt * 16 * DQ_LD + min((KB) + 1, nkb - 1) * 16); \
-    _Pragma("unroll") for (int s = 0; s < 4; s++)                                                           \
-      _Pragma("unroll") for (int mt = 0; mt < MT; mt++)                                                     \
-        _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                                                   \
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[mt][s], B[nt][s], acc[mt][nt], 0, 0, 0);  \
-    _Pragma("unroll") for (int mt = 0; mt < MT; mt++) acur[mt] = an_[mt];                                   \
-  }
-    for (int i = 0; i + 1 < nfull; i++) {   // full passes followed by another full pass: refill every slot
-      const float* wnext = wbase + (size_t)(i + 1) * PF * kstep;
-#pragma unroll
-      for (int p = 0; p < PF; p++) {
-        dq_f4 b_[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-          b_[nt] = bq[p][nt];
-          bq[p][nt] = DQ_LDW(wnext + (size_t)p * kstep + nt * nstep);
-        }
-        DQ_MFMA(i * PF + p, b_)
+        for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
       }
-    }
-    if (nfull > 0) {   // the last full pass: refill the slots a tail block will use (clamped: slots past the tail re-fetch its last block)
-      const int i = nfull - 1;
-      if (rem > 0) {
-        const float* wnext = wbase + (size_t)nfull * PF * kstep;
-#pragma unroll
-        for (int p = 0; p < PF; p++) {
-          dq_f4 b_[NT];
-#pragma unroll
-          for (int nt = 0; nt < NT; nt++) {
-            b_[nt] = bq[p][nt];
-            if (p < PF - 1) bq[p][nt] = DQ_LDW(wnext + (size_t)min(p, rem - 1) * kstep + nt * nstep);
-          }
-          DQ_MFMA(i * PF + p, b_)
-        }
-      } else {
-#pragma unroll
-        for (int p = 0; p < PF; p++) DQ_MFMA(i * PF + p, bq[p])
-      }
-    }
-#pragma unroll
-    for (int p = 0; p + 1 < PF; p++)
-      if (p < rem) DQ_MFMA(nfull * PF + p, bq[p])   // the tail blocks are already in their slots
-#undef DQ_MFMA
-#undef DQ_LDW
-    DQ_STAMP(2);
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-      const int col = (nt0 + nt * nt_step) * 16 + r;
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          float v = acc[mt][nt][i] + bv[nt];  // C/D layout: col = lane & 15, row = (lane >> 4) * 4 + i
-          if (act) v = v > 0.f ? v : v * slope;
-          Xout[((m0 + mt) * 16 + g * 4 + i) * DQ_LD + col] = v;
-        }
+      *(dq_f4*)(Xout + (mt * 16 + r) * DQ_LD + col) = v;
+      acc[mt][nt] = dq_f4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  DQ_STAMP(3);
-  __syncthreads();  // the layer's output is complete (and every wave has read its input: Xin may be overwritten by the next layer)
-  DQ_STAMP(4);
 }
 
-// A layer for the TILE-row tile (MT = TILE / 16 MFMA row tiles per wave): the output columns are dealt to the 4 waves in
-// 16-column tiles (wave w takes tiles w, w + 4, ...; layers narrower than 64 leave waves idle).
-template <int TILE>
-__device__ __forceinline__ void dq_layer(const float* Xin, float* Xout, const float* Wp, const float* bias, int Kpad, int Npad, bool act, float slope) {
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the weight addresses stay in scalar registers
-  constexpr int MT = TILE / 16;
-  switch (Npad) {
-    case 16: dq_dense<MT, 1>(Xin, Xout, Wp, bias, Kpad, Npad, 0, 0, 1, w >= 1, act, slope); break;
-    case 32: dq_dense<MT, 1>(Xin, Xout, Wp, bias, Kpad, Npad, 0, w & 1, 1, w >= 2, act, slope); break;
-    case 64: dq_dense<MT, 1>(Xin, Xout, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-    case 128: dq_dense<MT, 2>(Xin, Xout, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-    case 192: dq_dense<MT, 3>(Xin, Xout, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;   // (PF = 5: 15 of the 16 slots)
-    default: dq_dense<MT, 4>(Xin, Xout, Wp, bias, Kpad, Npad, 0, w, 4, false, act, slope); break;
-  }
+// the bias values lane (r, g) adds in a layer's epilogue: four consecutive columns of each of the wave's NT tiles
+__device__ __forceinline__ void dq_bias(dq_f4 (&bv)[4], const float* bias, int Npad, int w, int g) {
+  const int sh = dq_sh(Npad), col0 = (Npad == 16 ? 0 : Npad == 32 ? (w & 1) : w) * 16, colstep = Npad <= 32 ? 16 : 64;
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++) bv[nt] = *(const dq_f4*)(bias + col0 + min(nt, (1 << sh) - 1) * colstep + g * 4);
 }
 
 __device__ __forceinline__ unsigned long long dq_mix64(unsigned long long seed, unsigned long long key) {
@@ -400,37 +367,41 @@ __device__ __forceinline__ void mrx_dqn_mlp_body(const CimParams& K, const cim::
                                                  const int32_t* __restrict__ lists, const float* __restrict__ xrows, int32_t* __restrict__ actions,
                                                  float* __restrict__ q_out, int32_t* __restrict__ choice_out, const cim::SamplerRec& R) {
   using namespace cim;
-  __shared__ __attribute__((aligned(16))) float X[2][DQ_TILE * DQ_LD];
-  __shared__ int s_tile[3];
-  const int t = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float X[2][DQ_TILE * DQ_LD + 16];   // (+16: the k loop reads one block past a row's last)
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);   // wave-uniform: the weight addresses stay in scalar registers
 
-  // ---- which (port, tile) is this workgroup: prefix over the ports' tile counts (P <= 64: one wave)
-  if (t < 64) {
-    const int c = t < K.P ? cnt[t] : 0;
+  // ---- which (port, tile) is this workgroup: prefix over the ports' tile counts (P <= 64: one wave).  EVERY wave works it out for
+  //      itself (one load + a wave scan): no LDS round trip and no barrier stand between the kernel's start and its first weights.
+  int port, rows, first;
+  {
+    const int c = lane < K.P ? cnt[lane] : 0;
     const int nt = (c + DQ_TILE - 1) / DQ_TILE;
     int incl = nt;
     for (int o = 1; o < 64; o <<= 1) {
       const int up = __shfl_up(incl, o);
-      if (t >= o) incl += up;
+      if (lane >= o) incl += up;
     }
-    if (t == 0) s_tile[0] = -1;
     // XCD-aware tile order: the dispatcher places block i on XCD i % 8 (observed, MI355X_MICROARCH.md: a speed assumption only),
     // and each XCD has its own 4 MB L2 while the 22 networks are 8 MB.  The tile list (port 0's tiles, port 1's ...) is cut into
     // 8 equal runs and XCD x works through run x: an XCD then streams about three ports' weights (1 MB) instead of all of them,
     // and every XCD gets the same number of tiles.  (M.xcd_runs = 0: block i takes tile i.)
-    const int total = __shfl(incl, 63);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
     int tile_idx = (int)blockIdx.x;
     if (M.xcd_runs) {
       const int run = (total + 7) >> 3, x = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
       tile_idx = slot < run ? x * run + slot : total;   // (past the list: no tile)
     }
     const int b = tile_idx - (incl - nt);
-    if (tile_idx < total && b >= 0 && b < nt) {  // exactly one lane matches (or none: more workgroups than tiles)
-      s_tile[0] = t;
-      s_tile[1] = b * DQ_TILE;
-      s_tile[2] = min(DQ_TILE, c - b * DQ_TILE);
-    }
-    // every workgroup has now read the counters: the last one to say so clears them for the next call
+    const unsigned long long hit = __ballot(tile_idx < total && b >= 0 && b < nt);  // exactly one lane matches (or none: more workgroups than tiles)
+    port = hit ? __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit)) : -1;
+    const int src = port < 0 ? 0 : port;
+    first = __builtin_amdgcn_readfirstlane(__shfl(b * DQ_TILE, src));
+    rows = __builtin_amdgcn_readfirstlane(__shfl(min(DQ_TILE, c - b * DQ_TILE), src));
+  }
+  if (port < 0) {
+    // every wave of every workgroup has read the counters before the last workgroup to say so clears them for the next call
+    dq_barrier();
     if (t == 0) {
       int32_t* done = cnt + 64;
       if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
@@ -438,18 +409,36 @@ __device__ __forceinline__ void mrx_dqn_mlp_body(const CimParams& K, const cim::
         *done = 0;
       }
     }
+    return;
   }
-  __syncthreads();
-  const int port = __builtin_amdgcn_readfirstlane(s_tile[0]);   // (scalar registers: every address derived from the tile is wave-uniform)
-  if (port < 0) return;
-  const int rows = __builtin_amdgcn_readfirstlane(s_tile[2]);
-  const int32_t* list = lists + (size_t)port * K.n_envs + __builtin_amdgcn_readfirstlane(s_tile[1]);
+  const int32_t* list = lists + (size_t)port * K.n_envs + first;
+  const float* net = M.weights + (size_t)port * M.net_floats;
+  // ---- the weight stream starts before anything else does: the wave's first two passes
+  constexpr int MT = DQ_TILE / 16;
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const unsigned lane_off = (unsigned)lane * 16;
+  dq_f4 ring[DQ_SLOTS], bv[4], bvn[4];
+  const __amdgpu_buffer_rsrc_t rs = dq_rsrc(net);
+  int soff = (int)M.s_off[w][0] * 4;   // the stream (byte offset into the net) at the fragment that slot 0 of the coming pass holds
+#pragma unroll
+  for (int p = 0; p < DQ_SLOTS; p++) ring[p] = dq_ldw(rs, soff + p * 1024, lane_off);
+  int lw = 0;   // the layer the wave computes next (n_layers: none left)
+  while (lw < M.n_layers && dq_idle(M.npad[lw], w)) lw++;
+  dq_bias(bv, net + M.b_off[lw < M.n_layers ? lw : 0], M.npad[lw < M.n_layers ? lw : 0], w, g4);
 #ifdef MRX_DQN_PROFILE
   long long tm[12]; int tmi = 0;
   const long long rt0 = (long long)__builtin_amdgcn_s_memrealtime();   // 100 MHz: what a s_memtime tick is worth under THIS launch
-#define DQ_MARK() do { __syncthreads(); tm[tmi++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define DQ_MARK() do { dq_barrier(); tm[tmi++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+  __shared__ long long dq_tl[4][64];   // per-wave timeline: lane 0 stamps s_memtime at the points DQ_T marks (-DMRX_DQN_PROFILE_T)
+  int tli = 0;
+#ifdef MRX_DQN_PROFILE_T
+#define DQ_T() do { if (lane == 0 && tli < 64) dq_tl[w][tli] = (long long)__builtin_amdgcn_s_memtime(); tli++; } while (0)
+#else
+#define DQ_T() do {} while (0)
+#endif
 #else
 #define DQ_MARK() do {} while (0)
+#define DQ_T() do {} while (0)
 #endif
   DQ_MARK();
 
@@ -485,20 +474,72 @@ __device__ __forceinline__ void mrx_dqn_mlp_body(const CimParams& K, const cim::
       *(dq_f4*)(&X[0][r * DQ_LD + c4 * 4]) = v;
     }
   }
-  __syncthreads();
+  dq_barrier();
   DQ_MARK();
 
-  // ---- the dense chain of this port's network, ping-pong between the two activation buffers
-  const float* net = M.weights + (size_t)port * M.net_floats;
-  int cur = 0;
+  // ---- the dense chain of this port's network, ping-pong between the two activation buffers, one barrier per layer
+  int cur = 0, half = 0;
+  dq_f4 acc[DQ_TILE_MAX / 16][4], acur[DQ_TILE_MAX / 16];
+#pragma unroll
+  for (int mt = 0; mt < DQ_TILE_MAX / 16; mt++) {
+    acur[mt] = dq_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) acc[mt][nt] = dq_f4{0.f, 0.f, 0.f, 0.f};
+  }
   for (int l = 0; l < M.n_layers; l++) {
-#ifdef MRX_DQN_PROFILE
-    if (t == 0) dq_prof_layer = l;
-    __syncthreads();
-#endif
-    dq_layer<DQ_TILE>(X[cur], X[cur ^ 1], net + M.w_off[l], net + M.b_off[l], M.kpad[l], M.npad[l], l + 1 < M.n_layers, M.slope);
+    DQ_T();
+    if (l == lw) {
+      const int Npad = M.npad[l], sh = dq_sh(Npad), F = (M.kpad[l] >> 4) << sh;   // fragments to consume
+      // the layer after this one (for this wave): looked up now, its bias requested after the passes — used a layer from now
+      int ln = l + 1;
+      while (ln < M.n_layers && dq_idle(M.npad[ln], w)) ln++;
+      const int lb = ln < M.n_layers ? ln : l;
+      const int Nnext = M.npad[lb];
+      const float* bnext = net + M.b_off[lb];
+      const float* xlane = X[cur] + r16 * DQ_LD + g4 * 4;
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) acur[mt] = *(const dq_f4*)(xlane + mt * 16 * DQ_LD);
+      DQ_T();
+      for (int f0 = 0; f0 < F; f0 += DQ_PASS) {
+        const int nvalid = F - f0;
+        const float* xk = xlane + (f0 >> sh) * 16;
+        const int refill = soff + DQ_SLOTS * 1024;
+        if (half == 0) {
+          if (sh == 0) dq_pass_any<MT, 1, 0>(ring, acc, acur, xk, nvalid, rs, refill, lane_off);
+          else if (sh == 1) dq_pass_any<MT, 2, 0>(ring, acc, acur, xk, nvalid, rs, refill, lane_off);
+          else dq_pass_any<MT, 4, 0>(ring, acc, acur, xk, nvalid, rs, refill, lane_off);
+        } else {
+          if (sh == 0) dq_pass_any<MT, 1, 1>(ring, acc, acur, xk, nvalid, rs, refill, lane_off);
+          else if (sh == 1) dq_pass_any<MT, 2, 1>(ring, acc, acur, xk, nvalid, rs, refill, lane_off);
+          else dq_pass_any<MT, 4, 1>(ring, acc, acur, xk, nvalid, rs, refill, lane_off);
+        }
+        half ^= 1;
+        soff += DQ_PASS * 1024;
+        DQ_T();
+      }
+      dq_bias(bvn, bnext, Nnext, w, g4);
+      const bool act = l + 1 < M.n_layers;
+      const int col0 = (Npad == 16 ? 0 : Npad == 32 ? (w & 1) : w) * 16, colstep = Npad <= 32 ? 16 : 64;
+      if (sh == 0) dq_epilogue<MT, 1>(acc, bv, X[cur ^ 1], col0, colstep, act, M.slope);
+      else if (sh == 1) dq_epilogue<MT, 2>(acc, bv, X[cur ^ 1], col0, colstep, act, M.slope);
+      else dq_epilogue<MT, 4>(acc, bv, X[cur ^ 1], col0, colstep, act, M.slope);
+      DQ_T();
+      lw = ln;
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) bv[nt] = bvn[nt];
+    }
+    dq_barrier();  // the layer's output is complete (and every wave has read its input: the buffer may be overwritten by the next layer)
+    DQ_T();
     cur ^= 1;
     DQ_MARK();
+  }
+  // every wave of this workgroup is past its read of the counters: the last workgroup to say so clears them for the next call
+  if (t == 0) {
+    int32_t* done = cnt + 64;
+    if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
+      for (int p = 0; p < 64; p++) cnt[p] = 0;
+      *done = 0;
+    }
   }
 
   // ---- q = adv - mean(adv) + v (dqn.py:48-52), greedy action, env_sampler.py:33-64 translation
@@ -569,18 +610,13 @@ __device__ __forceinline__ void mrx_dqn_mlp_body(const CimParams& K, const cim::
     qp[(size_t)blockIdx.x * 16 + 13] = (float)(tm[0] & 0xfffff);
     qp[(size_t)blockIdx.x * 16 + 14] = (float)(tm[tmi - 1] - tm[0]);
     qp[(size_t)blockIdx.x * 16 + 15] = (float)((long long)__builtin_amdgcn_s_memrealtime() - rt0);
-    // per-wave stamps of the layers behind the per-workgroup rows: [workgroup][layer][wave][4 deltas]
-    float* qw = qp + (size_t)gridDim.x * 16 + (size_t)blockIdx.x * (DQ_MAX_LAYERS * 16);
-    for (int l = 0; l < M.n_layers; l++)
-      for (int w = 0; w < 4; w++) {
-        qw[(l * 4 + w) * 4 + 0] = (float)(dq_prof[l][w][2] - dq_prof[l][w][0]);   // entry -> k loop done
-        qw[(l * 4 + w) * 4 + 1] = (float)(dq_prof[l][w][3] - dq_prof[l][w][2]);   // epilogue
-        qw[(l * 4 + w) * 4 + 2] = (float)(dq_prof[l][w][4] - dq_prof[l][w][3]);   // barrier wait
-        qw[(l * 4 + w) * 4 + 3] = (float)(dq_prof[l][w][0] - dq_prof[l][0][0]);   // entry skew vs wave 0
-      }
+    // the per-wave timelines behind the per-workgroup rows: [workgroup][wave][64], ticks since the first mark
+    float* qw = qp + (size_t)gridDim.x * 16 + (size_t)blockIdx.x * 256;
+    for (int i = 0; i < 256; i++) qw[i] = (i & 63) < tli ? (float)(dq_tl[i >> 6][i & 63] - tm[0]) : -1.f;
   }
 #endif
 #undef DQ_MARK
+#undef DQ_T
 }
 
 extern "C" __global__ void __launch_bounds__(256)

@@ -918,11 +918,19 @@ static int dqn_plan(const mrx_cim_dqn_model* m, cim::DqnParams* D) {
     D->kpad[l] = l == 0 ? dq_kpad(m->dims[0]) : D->npad[l - 1];
     D->npad[l] = dq_npad(m->dims[l + 1]);
     D->n_out[l] = m->dims[l + 1];
-    D->w_off[l] = off;
-    off += (long long)D->kpad[l] * D->npad[l];
+  }
+  // one net: the four waves' fragment streams (cim_dqn.h: each wave's layers one after another), the biases, then DQ_SLOTS
+  // fragments of padding — the last two passes of a stream refill the ring from what follows it (nothing consumes that)
+  for (int w = 0; w < 4; w++)
+    for (int l = 0; l < m->n_layers; l++) {
+      D->s_off[w][l] = off;
+      off += 256LL * dq_frags(D->kpad[l], D->npad[l], w);
+    }
+  for (int l = 0; l < m->n_layers; l++) {
     D->b_off[l] = off;
     off += D->npad[l];
   }
+  off += 256LL * DQ_SLOTS;
   D->net_floats = off;
   for (int a = 0; a < m->n_actions; a++) D->action_space[a] = m->action_space[a];
   return MRX_OK;
@@ -943,7 +951,11 @@ int mrx_cim_dqn_pack_net(const mrx_cim_dqn_model* m, const float* const* weights
   for (int l = 0; l < m->n_layers; l++) {
     const int K = m->dims[l], N = m->dims[l + 1];
     for (int k = 0; k < K; k++)
-      for (int n = 0; n < N; n++) out[D.w_off[l] + cim::dq_w_index(k, n, D.npad[l])] = weights[l][(size_t)k * N + n];
+      for (int n = 0; n < N; n++) {
+        int w, frag, within;
+        cim::dq_w_slot(k, n, D.npad[l], &w, &frag, &within);
+        out[D.s_off[w][l] + 256LL * frag + within] = weights[l][(size_t)k * N + n];
+      }
     for (int n = 0; n < N; n++) out[D.b_off[l] + n] = biases[l][n];
   }
   return MRX_OK;

@@ -30,19 +30,21 @@ fused.act(actions, n_actions, q=q)
 ev[1].record()
 torch.cuda.synchronize()
 print(f"n_envs {n}, tile rows {os.environ.get('MRX_DQN_TILE', 'default')}: bin + forward launch = {ev[0].elapsed_time(ev[1]) * 1e3:.1f} us (events)")
-t = q.view(-1)[n * 21: n * 21 + 16 * (n // 16 + 64)].view(-1, 16)
+grid = int(os.environ.get("MRX_DQN_GRID", 0)) or ((n + 15) // 16 + 22 + 7) // 8 * 8 + 8
+t = q.view(-1)[n * 21: n * 21 + 16 * grid].view(-1, 16)
 t = t[t[:, 0] > 0]
 names = ["row loads"] + [f"layer {i}" for i in range(6)] + ["argmax+translate"]
 print("workgroups", t.shape[0], "s_memtime ticks; sum of the phase means =", float(t[:, :8].mean(dim=0).sum()))
 for i, nm in enumerate(names):
     print(f"  {nm:18s} mean {float(t[:, i].mean()):9.0f}  max {float(t[:, i].max()):9.0f}")
 print(f"  marked span: {float(t[:, 14].mean()):.0f} s_memtime ticks in {float(t[:, 15].mean()) * 10:.0f} ns (s_memrealtime) -> {float(t[:, 14].sum() / (t[:, 15].sum() * 10)):.3f} ticks per ns = shader GHz under this launch")
-grid = int(os.environ.get("MRX_DQN_GRID", 0)) or ((n + 15) // 16 + 22 + 7) // 8 * 8 + 8
-tw = q.view(-1)[n * 21 + grid * 16: n * 21 + grid * 16 + grid * 128].view(grid, 8, 4, 4)
-tw = tw[(q.view(-1)[n * 21: n * 21 + grid * 16].view(grid, 16)[:, 0] > 0)]
-print("per layer and wave (means over workgroups): entry->k loop done | epilogue | barrier wait | entry skew")
-for l in range(6):
-    print(f"  layer {l}: " + "  ".join("w%d %5.0f %4.0f %5.0f %4.0f" % (w, *[float(tw[:, l, w, j].mean()) for j in range(4)]) for w in range(4)))
+tl = q.view(-1)[n * 21 + grid * 16: n * 21 + grid * 16 + grid * 256].view(grid, 4, 64)
+tl = tl[(q.view(-1)[n * 21: n * 21 + grid * 16].view(grid, 16)[:, 0] > 0)]
+full = tl[tl[:, 0, 8] > 0] if tl.shape[0] else tl
+print("per-wave timelines (mean over workgroups, ticks since the first mark; -1: no stamp):")
+for wv in range(4):
+    m = tl[:, wv, :].mean(dim=0)
+    print(f"  wave {wv}: " + " ".join(f"{float(v):.0f}" for v in m if float(v) >= 0))
 if os.environ.get("MRX_DQN_PROFILE_DUMP"):
     import numpy as np
     a = t.cpu().numpy()
