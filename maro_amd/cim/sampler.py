@@ -294,6 +294,60 @@ class CimBatchSampler:
         self._after_per_step_call()
         return res
 
+    def eval(self, policy, num_episodes: int = 1, seeds: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, done_every: int = 32) -> dict:
+        """``AbsEnvSampler.eval(num_episodes)`` (rl/rollout/env_sampler.py:561-611) for every env of the engine at once: per
+        episode a reset, then the policy's EXPLOITING actions (greedy: ``agent_wrapper.exploit()``) until every env's episode is
+        over.  The reference builds cache elements here only to feed ``_post_eval_step``, which the CIM example leaves empty
+        (examples/cim/rl/env_sampler.py:85-86), so what an episode leaves behind is ``info["env_metric"]`` (``_post_step``).
+
+        `policy`: a ``FusedPerPortDQN`` of this engine (the on-device forward; its epsilon is ignored here) or a callable
+        ``(states [n, state_dim], decisions [n, 8]) -> model actions``.  `seeds` as in ``sample`` (default: the reference's
+        seed re-draw).  `done_every`: interactions enqueued between two reads of the done flags.
+
+        Returns ``{"info": [{"env_metric": int64 [n_envs, 3]}, ...]}`` — one entry per episode, one row per env (the reference
+        evaluates on its separate ``test_env``; here the sampler's own engine IS the test batch: keep one sampler over a test
+        engine for ``eval`` and another for ``sample``, as the reference keeps two envs — a ``sample`` after an ``eval`` on the
+        same sampler starts from fresh episodes)."""
+        from .engine import SEED_REDRAW
+        from .policy import translate_actions
+        eng = self.eng
+        n, dev = eng.n_envs, eng.decisions.device
+        seeds = _seed_fn(seeds, n)
+        fused = hasattr(policy, "act") and hasattr(policy, "_m")
+        acts = torch.zeros((n, eng.max_actions, 4), dtype=torch.int32, device=dev)
+        nact = torch.zeros(n, dtype=torch.int32, device=dev)
+        if hasattr(self, "_c"):
+            self._drain_device_pending()
+        ep_env = torch.zeros(n, dtype=torch.int64)
+        info_list = []
+        eps_saved = None
+        if fused:
+            eps_saved, policy._m.epsilon = policy._m.epsilon, 0.0   # exploit()
+        try:
+            for _ in range(int(num_episodes)):
+                cmd = seeds(ep_env.clone()).to(torch.int64) if seeds is not None else torch.full((n,), SEED_REDRAW, dtype=torch.int64)
+                ep_env += 1
+                eng.reset(cmd)
+                eng.step()                                   # _step(None): the first decision event
+                while not bool(eng.done.all()):
+                    for _k in range(max(1, int(done_every))):
+                        if fused:
+                            policy.act(acts, nact)           # finished envs have no pending decision: n_actions 0
+                        else:
+                            dec = eng.decisions.clone()
+                            state = self.state(dec)
+                            model_action = policy(state.to(torch.float32), dec).to(torch.int64)
+                            translate_actions(model_action, dec, state[:, -1].to(torch.float64), dec[:, 5], out=acts)
+                            nact[:] = (~eng.done.to(torch.bool)).to(torch.int32)
+                        eng.step(acts, nact)                 # (finished envs just report `done` again)
+                info_list.append({"env_metric": eng.metrics.clone()})
+        finally:
+            if fused:
+                policy._m.epsilon = eps_saved
+        if hasattr(self, "_c"):                              # the engine's episodes are over: the next sample() starts afresh
+            self._sample_init(self.state_dtype)
+        return {"info": info_list}
+
     def sample_fused(self, actor, num_steps: Optional[int], seeds: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, reset_every: int = 1,
                      state_dtype: torch.dtype = torch.float32) -> Dict[str, torch.Tensor]:
         """``sample_fused_steps`` run to the end (see there); returns its result."""

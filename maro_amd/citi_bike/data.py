@@ -88,16 +88,18 @@ class CitiBikeData:
         return CitiBikeData(**meta, **{k: z[k] for k in z.files if k != "meta"})
 
 
-def load_build_folder(config, build_dir: str, name: str = None, is_holiday=None) -> CitiBikeData:
+def load_build_folder(config, build_dir: str, name: str = None, is_holiday="us") -> CitiBikeData:
     """Compile a citi_bike topology natively: `config` = the topology's config.yml (path or dict: ``decision`` block,
     ``time_zone``), `build_dir` = the folder ``maro data build`` / the toy generator wrote (trips.bin, KNYC_daily.bin,
     station_meta.csv, distance_adj.csv).  Mirrors what ``CitibikeBusinessEngine`` reads at construction
     (``business_engine.py:205-260``): trips through ``ItemTickPicker`` with one tick per minute
     (``data_lib/binary_reader.py:80-112`` -> ``maro_amd.data_lib.pick_ticks``), stations (``stations_info.py:19-37``), the
     distance matrix (``adj_loader.py``, first row skipped), the weather table keyed by local date (``weather_table.py:29-41``),
-    and per tick the local date's weekday / holiday flag (``business_engine.py:367-392``).  `is_holiday(date) -> bool`:
-    the reference asks ``holidays.US()``; the default knows no holidays (the package is not available offline; the
-    packaged toy topologies and their goldens were generated the same way)."""
+    and per tick the local date's weekday / holiday flag (``business_engine.py:367-392``).  `is_holiday`: the reference asks
+    ``holidays.US()``; the default "us" is that calendar restated natively (``us_calendar.is_us_holiday``: the federal holidays
+    and their observed days).  A callable ``(date) -> bool`` replaces it; None knows no holidays — the mode the packaged toy
+    topologies and every citi_bike golden were generated in (the reference ran there with a `holidays` stand-in that contains
+    nothing: oracle/build_ref.sh), so regenerating or re-checking those passes None."""
     import csv
     from datetime import datetime, timedelta, timezone
 
@@ -105,6 +107,10 @@ def load_build_folder(config, build_dir: str, name: str = None, is_holiday=None)
     from dateutil.tz import gettz
 
     from ..data_lib import pick_ticks, read_binary
+    if isinstance(is_holiday, str):
+        if is_holiday != "us":
+            raise ValueError(f"is_holiday: unknown calendar {is_holiday!r} (\"us\", a callable, or None)")
+        from .us_calendar import is_us_holiday as is_holiday
     if not isinstance(config, dict):
         with open(config, "rt") as fp:
             config = yaml.safe_load(fp)

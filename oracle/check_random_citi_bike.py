@@ -49,7 +49,7 @@ def worker(case_seed):
     cfg = write_build_folder(raw, folder, start_utc=1559534400 + 3600 * int(rng.randint(0, 48)), rng=rng)
     with open(os.path.join(folder, "config.yml"), "wt") as fp:
         yaml.safe_dump(cfg, fp)
-    data = load_build_folder(cfg, folder, name="rnd")
+    data = load_build_folder(cfg, folder, name="rnd", is_holiday=None)   # the reference runs here with the `holidays` stand-in: no holidays
     np.random.seed(case_seed)
     env = Env("citi_bike", folder, **{"start_tick": 0, **kw}, decision_mode=DecisionMode(mode))
     o = CitiBikeOracle(data, transfer_times=draw_transfer_times(data, case_seed, 20000), **kw)

@@ -123,6 +123,8 @@ def test_citi_bike_build_folder_loader(tmp_path):
     assert np.allclose(data.distance, d) and data.filters == [dict(type=0, num=3, windows=0), dict(type=2, num=2, windows=10)]
     # calendar: ticks are minutes from the first trip, days are local (New York) dates; Jan 1st 2019 was a Tuesday
     assert data.day_weekday[:3].tolist() == [1, 2, 3] and data.day_weather[:3].tolist() == [1, 2, 0] and data.day_temperature[:3].tolist() == [3, -1, 10]
+    assert data.day_holiday[:3].tolist() == [1, 0, 0]      # New Year's Day: the default calendar is holidays.US() restated
+    assert not load_build_folder(CB_CONF, str(tmp_path / "b"), name="syn4", is_holiday=None).day_holiday.any()
     first_midnight = int(np.argmax(data.tick_day > 0))
     assert (ts.min() + 60 * first_midnight - t0) // 86400 == 1 and (ts.min() + 60 * (first_midnight - 1) - t0) // 86400 == 0
 
@@ -133,7 +135,7 @@ def test_citi_bike_packaged_topologies_are_what_the_native_loader_compiles(name)
     """The packaged maro_amd/citi_bike/topologies/<name>.npz were compiled in round 1 with the reference's BinaryReader /
     ItemTickPicker / WeatherTable; the native loader must produce the same arrays from the same build folder."""
     from maro_amd.citi_bike.data import load_build_folder, load_topology
-    d, g = load_build_folder(os.path.join(REF_CB_TOPO, name, "config.yml"), os.path.join(REF_CB_BUILD, name), name=name), load_topology(name)
+    d, g = load_build_folder(os.path.join(REF_CB_TOPO, name, "config.yml"), os.path.join(REF_CB_BUILD, name), name=name, is_holiday=None), load_topology(name)
     for k in ("trip_tick", "trip_src", "trip_dst", "trip_duration", "capacity", "init_bikes", "station_id", "distance", "tick_day", "day_weekday",
               "day_holiday", "day_weather", "day_temperature"):
         assert np.array_equal(getattr(d, k), getattr(g, k)), k

@@ -465,3 +465,71 @@ def test_device_resident_loop_with_a_window_shorter_than_the_gaps_between_decisi
             os.environ.pop("MRX_SAMPLER_V2", None)
     assert late > 0, "the case this test is about did not occur"
     assert _compare_calls(res["1"], res["0"]) > 300
+
+
+# ---- CimBatchSampler.eval against the REAL CIMEnvSampler.eval (oracle/gen_golden_sampler_eval.py)
+def run_eval_case(engine_factory, case, n_envs=2):
+    """eval(num_episodes) called like the golden's: same test-env seeds, the recorded exploiting model actions replayed as the
+    policy; every episode's env_metric of every env must equal the reference's ``info["env_metric"]``."""
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"sampler_eval_{case}.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    eng = engine_factory(meta["topology"], n_envs, durations=meta["durations"], max_actions=1, max_snapshots=16)
+    smp = CimBatchSampler(eng)
+    inter, k, dev = z["interactions"], [0], eng.decisions.device
+
+    def policy(states, dec):
+        d = dec.cpu().numpy()
+        live = d[:, 7] == 1
+        if not live.any():                      # (interactions enqueued past the batch's last decision)
+            return torch.zeros(n_envs, dtype=torch.int64, device=dev)
+        assert live.all() and (d[:, 1] == inter[k[0], 0]).all() and (d[:, 0] == inter[k[0], 6]).all(), k[0]
+        a = int(inter[k[0], 1])
+        k[0] += 1
+        return torch.full((n_envs,), a, dtype=torch.int64, device=dev)
+
+    res = smp.eval(policy, num_episodes=meta["episodes"], seeds=lambda ep: meta["seed"] + ep.to(torch.int64), done_every=1)
+    assert k[0] == len(inter) and len(res["info"]) == meta["episodes"]
+    for ep, info in enumerate(res["info"]):
+        m = info["env_metric"].cpu().numpy()
+        assert m.shape == (n_envs, 3) and (m == z["env_metric"][ep][None, :]).all(), (ep, m, z["env_metric"][ep])
+    # a sample() after the eval starts from fresh episodes (the engine's episodes are over)
+    out = smp.sample(lambda s, d: torch.zeros(n_envs, dtype=torch.int64, device=dev), num_steps=3)
+    assert out["env_metric"].shape == (n_envs, 3) and not bool(eng.done.any())
+
+
+@pytest.mark.parametrize("case", ["toy5p_l05", "gt22p_l08"])
+def test_batched_eval_matches_the_reference_sampler_on_emulator(case):
+    run_eval_case(emu_factory, case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["toy5p_l05", "gt22p_l08"])
+def test_batched_eval_matches_the_reference_sampler_on_gpu(case):
+    from maro_amd.cim.engine import CimBatchEngine
+    run_eval_case(lambda topo, n, **kw: CimBatchEngine(topo, n, **kw), case, n_envs=3)
+
+
+@pytest.mark.gpu
+def test_eval_with_the_fused_dqn_equals_a_greedy_loop_on_gpu():
+    """eval(FusedPerPortDQN) = reset, then act (epsilon ignored: exploit) -> step until every env is done."""
+    from maro_amd.cim.engine import CimBatchEngine
+    from maro_amd.cim.policy import FusedPerPortDQN, random_chains
+    n, dur = 48, 180
+    seeds = torch.arange(n, dtype=torch.int64) + 900
+    eng = CimBatchEngine("toy.5p_ssddd_l0.5", n, durations=dur, max_actions=1, max_snapshots=16)
+    smp = CimBatchSampler(eng)
+    actor = FusedPerPortDQN(eng, random_chains(5, smp.state_dim, 21, seed=3), epsilon=0.5)
+    res = smp.eval(actor, num_episodes=2, seeds=lambda ep: seeds + 1000 * ep)
+    assert actor._m.epsilon == 0.5
+    greedy = FusedPerPortDQN(eng, random_chains(5, smp.state_dim, 21, seed=3), epsilon=0.0)
+    acts = torch.zeros((n, 1, 4), dtype=torch.int32, device="cuda"); nact = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for ep in range(2):
+        eng.reset(seeds + 1000 * ep)
+        eng.step()
+        while not bool(eng.done.all()):
+            greedy.act(acts, nact)
+            eng.step(acts, nact)
+        assert torch.equal(res["info"][ep]["env_metric"], eng.metrics), ep
+    assert not torch.equal(res["info"][0]["env_metric"], res["info"][1]["env_metric"])

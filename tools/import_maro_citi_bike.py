@@ -5,8 +5,9 @@ distance_adj.csv are parsed by maro_amd itself, no MARO checkout needed.
 
     python tools/import_maro_citi_bike.py --config <topology>/config.yml --build ~/.maro/data/citi_bike/.build/toy.3s_4t --name toy.3s_4t
 
-`holidays` comes from whatever module is importable (none offline: day_holiday is then all zero, as in the packaged toy
-topologies and their goldens).
+day_holiday: the `holidays` package when it is importable, else the native restatement of holidays.US()
+(maro_amd/citi_bike/us_calendar.py); --no-holidays: all zero, as in the packaged toy topologies and their goldens (the reference
+generated those with a stand-in that contains nothing).
 """
 import argparse
 import os
@@ -22,14 +23,18 @@ def main():
     ap.add_argument("--build", required=True)
     ap.add_argument("--name")
     ap.add_argument("--out", default=os.path.join(REPO, "maro_amd", "citi_bike", "topologies"))
+    ap.add_argument("--no-holidays", action="store_true")
     args = ap.parse_args()
     from maro_amd.citi_bike.data import load_build_folder
-    try:
-        import holidays
-        us = holidays.US()
-        is_holiday = lambda d: d in us  # noqa: E731
-    except ImportError:
+    if args.no_holidays:
         is_holiday = None
+    else:
+        try:
+            import holidays
+            us = holidays.US()
+            is_holiday = (lambda d: d in us) if len(holidays.US(years=2019)) else "us"  # noqa: E731  (an empty stand-in: use the native calendar)
+        except ImportError:
+            is_holiday = "us"
     name = args.name or os.path.basename(os.path.normpath(args.build))
     data = load_build_folder(args.config, os.path.expanduser(args.build), name=name, is_holiday=is_holiday)
     os.makedirs(args.out, exist_ok=True)
