@@ -151,6 +151,63 @@ def cpu_baseline_citi_bike(topology, durations, res, budget_s):
             "sample": f"{steps} decisions of {topology} ({episodes} episode(s), pure-Python oracle, {dt:.1f} s on 1 core)"}
 
 
+def cpu_baseline_citi_bike_reference(topology, durations, res, budget_s):
+    """The REAL reference's citi_bike Env (maro/simulator/scenarios/citi_bike/business_engine.py:101-147) timed on THIS box, ONE
+    process, same agent as the port leg — in a child interpreter on the built reference (reference_runtime).  The toy topologies'
+    build folders are written back from the packaged .npz by the checker tooling (oracle/setup_toy_topologies.py: every array is
+    asserted to survive the round trip) into the runtime's private HOME.  None where no built reference is reachable or the
+    topology is not one of the toys."""
+    rt = reference_runtime()
+    if rt is None:
+        return None
+    try:
+        from oracle.setup_toy_topologies import TOYS, ensure_toy
+        if topology not in TOYS:
+            return None
+        ensure_toy(rt[0], rt[2], topology)
+    except Exception as e:
+        return {"error": f"toy write-back failed: {e}"[:300]}
+    code = r"""
+import sys, time
+from maro.simulator import Env
+from maro.simulator.scenarios.citi_bike.common import Action, DecisionType
+sys.path.insert(0, sys.argv[5])
+from tests.cb_batch_check import policy_action
+topo, dur, res, budget = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])
+env = Env(scenario="citi_bike", topology=topo, start_tick=0, durations=dur, snapshot_resolution=res)
+steps = episodes = 0
+t_step = t_reset = 0.0
+t_all = time.perf_counter()
+while time.perf_counter() - t_all < budget:
+    t0 = time.perf_counter()
+    if episodes:
+        env.reset()
+    t_reset += time.perf_counter() - t0
+    t0 = time.perf_counter()
+    m, de, done = env.step(None)
+    k = 0
+    while not done and time.perf_counter() - t_all < budget:
+        k += 1
+        d = {"type": 0 if de.type == DecisionType.Supply else 1, "action_scope": list(de.action_scope.items())}
+        a = policy_action(k, episodes, d)
+        m, de, done = env.step(Action(a[0], a[1], a[2]) if a else None)
+        steps += 1
+    t_step += time.perf_counter() - t0
+    episodes += 1
+print(steps, episodes, t_step, t_reset)
+"""
+    try:
+        out = _run_reference(code, [topology, durations, res, budget_s, REPO], budget_s * 4 + 120)
+        steps, episodes, t_step, t_reset = out.stdout.split()[-4:]
+        steps, episodes, t_step, t_reset = int(steps), int(episodes), float(t_step), float(t_reset)
+    except Exception as e:
+        return {"error": (str(e) + " " + (out.stderr[-300:] if "out" in dir() else ""))[:400]}
+    return {"value": steps / t_step, "unit": "env-steps/s", "cores": 1, "kind": "reference", "value_end_to_end": steps / (t_step + t_reset),
+            "sample": f"{steps} decisions of {topology} ({episodes} episode(s) of {durations} ticks, snapshot resolution {res}) on the reference's own Env "
+                      f"(maro.simulator.Env(scenario='citi_bike'), single process, same agent as the GPU leg's device policy): {t_step:.1f} s of stepping + {t_reset:.1f} s of env.reset()",
+            "measured": "live, in this run", "reference_from": rt[3], **box_description()}
+
+
 def measured_bytes_citi_bike(topology, n, step_budget, code_key, groups=1):
     """HBM bytes one batch step of this citi_bike configuration really moves (profiles/latest_pmc_citi_bike.json: separate
     --pmc FETCH_SIZE / WRITE_SIZE passes, all kernels of one batch step) -> (bytes or None, basis).  An entry of another build
@@ -387,7 +444,12 @@ def bench_citi_bike(args, dist, dev, rank, world):
     if parity is not None:
         out["parity"] = parity
     if world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline_citi_bike(topology, min(durations, 1440), res, args.cpu_seconds)
+        ref = cpu_baseline_citi_bike_reference(topology, min(durations, 1440), res, args.cpu_seconds)
+        port = cpu_baseline_citi_bike(topology, min(durations, 1440), res, args.cpu_seconds if ref is None or "error" in ref else min(args.cpu_seconds, 5.0))
+        if ref is not None and "error" not in ref:
+            out["cpu_baseline"] = dict(ref, port=port)       # the reference's own Env, live on this box; the Python port rides along
+        else:
+            out["cpu_baseline"] = port if ref is None else dict(port, reference_error=ref["error"])
     return out
 
 
@@ -763,10 +825,10 @@ def bench_collect(args, engines, streams, qnet, chains, n, G, dev, rank, world, 
                       "reset_ms_whole_batch": reset_ms, "look_back": samplers[0].look_back, "reward_window": samplers[0].time_window,
                       "experience_gather": exp_gather, "policy_broadcast": policy_bcast,
                       "what_a_step_is": "one sample_fused interaction of every env: mrx_cim_dqn_act + the transition-cache update + mrx_cim_step; per call: mrx_cim_sampler_emit"},
-           "roofline": {"bound": "hbm", "kernel": "the whole loop (mrx_k_cim_dqn_forward, mrx_k_cim_step_tab, mrx_k_cim_sampler_record, ...)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+           "roofline": {"bound": "hbm", "kernel": "the whole loop (mrx_k_cim_dqn_prep, mrx_k_cim_dqn_mlp16, mrx_k_cim_step_tab, mrx_k_cim_sampler_emit_all, ...)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": None if achieved is None else achieved / HBM_PEAK_GBPS, "traffic": traffic, "basis": basis,
                         "note": "bytes of one batch interaction (all kernels) / its wall time; null when no PMC record of this exact build exists"},
-           "roofline_policy": {"bound": "mfma", "kernel": "mrx_k_cim_dqn_forward (+ mrx_k_cim_dqn_bin)", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "roofline_policy": {"bound": "mfma", "kernel": "mrx_k_cim_dqn_mlp16 (+ mrx_k_cim_dqn_prep: binning + state rows)", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf / MFMA_F32_PEAK_TFLOPS, "dtype": "f32 (v_mfma_f32_16x16x4_f32)", "kernel_ms": act_ms, "deciding_envs": deciding,
                                "flops_per_env": DQN_FLOPS_PER_ENV, "basis": "algorithmic flops (2 x sum(in x out) of the example's layers x deciding envs) / wall time of the act "
                                "launches of all groups issued back to back with nothing else on the GPU"}}
@@ -820,7 +882,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--secondary", type=int, default=-1, help="after the headline (cim, random agent), also run BASELINE configs 4 and 5 as short legs and embed "
-                    "them under `secondary` in the same JSON line (citi_bike toy.3s_4t 4096 envs; DQN collection loop 8192 envs), each with parity, "
+                    "them under `secondary` in the same JSON line (citi_bike toy.3s_4t 4096 envs — and, on one GPU, all 32768 of config 4; DQN collection loop 8192 envs), each with parity, "
                     "cpu_baseline and a measured-bytes roofline.  -1 = auto: on for the default workload (what the driver runs), off when a flag selects another one")
     args = ap.parse_args()
     explicit_envs = args.envs is not None
@@ -855,6 +917,14 @@ def main():
             r4 = bench_citi_bike(a4, dist, dev, rank, world)
             gc.collect()
             torch.cuda.empty_cache()
+            # the WHOLE of configs[3] (32768 envs) on one GPU: it fits, and 4096 envs put 512 one-wave workgroups on 1024 SIMDs
+            r4w = None
+            if world == 1:
+                a4w = copy.copy(a4)
+                a4w.envs, a4w.no_cpu = 32768, True
+                r4w = bench_citi_bike(a4w, dist, dev, rank, world)
+                gc.collect()
+                torch.cuda.empty_cache()
             # BASELINE.json configs[4]: CIM 22p + the maro.rl DQN EnvSampler loop, 8192 envs per GPU (65536 over 8 GPUs), on-device inference
             a5 = copy.copy(args)
             a5.policy, a5.collect, a5.envs, a5.ring, a5.no_episode = "dqn", True, 8192, max(args.ring, 8), True
@@ -863,8 +933,11 @@ def main():
             r5 = bench_cim(a5, dist, dev, rank, world)
             if out is not None:
                 sec["citi_bike_config4"], sec["collect_config5"] = r4, r5
+                if r4w is not None:
+                    r4w["config"]["what"] = "BASELINE.json configs[3] whole (32768 envs) on ONE GPU; cpu_baseline: see citi_bike_config4"
+                    sec["citi_bike_config4_one_gpu"] = r4w
                 out["secondary"] = sec
-                out["gpu_seconds_total"] += sum((r or {}).get("gpu_seconds_total", 0.0) for r in (r4, r5))
+                out["gpu_seconds_total"] += sum((r or {}).get("gpu_seconds_total", 0.0) for r in (r4, r4w, r5))
     if rank == 0 and out is not None:
         print(json.dumps(out))
     if dist is not None:
@@ -1289,7 +1362,7 @@ def bench_cim(args, dist, dev, rank, world):
             # of the example's real layer sizes x the deciding envs of one launch; mrx_cim_dqn_act = bin + forward kernels
             fl = 2.0 * sum(a * b for a, b in ((171, 256), (256, 128), (128, 64), (64, 32), (32, 128), (32, 128), (128, 21), (128, 1)))
             tf = fl * (resolved / max(args.steps * world * G, 1)) / (policy_ms * 1e-3) / 1e12
-            out["roofline_policy"] = {"bound": "mfma", "kernel": "mrx_k_cim_dqn_forward (+ mrx_k_cim_dqn_bin)", "achieved": tf, "peak": 157.3,
+            out["roofline_policy"] = {"bound": "mfma", "kernel": "mrx_k_cim_dqn_mlp16 (+ mrx_k_cim_dqn_prep: binning + state rows)", "achieved": tf, "peak": 157.3,
                                       "unit": "TFLOP/s", "frac": tf / 157.3, "dtype": "f32 (v_mfma_f32_16x16x4_f32)", "kernel_ms": policy_ms,
                                       "flops_per_env": fl, "note": "launch latency bound: ~190 32-env tiles per launch on 256 CUs, sharing them with the other groups' step kernels"}
         return out

@@ -329,6 +329,17 @@ class CimBatchSampler:
                 ep_env += 1
                 eng.reset(cmd)
                 eng.step()                                   # _step(None): the first decision event
+                # a finished env answers further steps with (None, None, True) — metrics zero — so its metrics are kept from the
+                # step that ended its episode (no host sync: two selects per interaction)
+                final = torch.zeros_like(eng.metrics)
+                seen = torch.zeros(n, dtype=torch.bool, device=dev)
+
+                def keep_final():
+                    over = eng.done.to(torch.bool)
+                    final.copy_(torch.where((over & ~seen)[:, None], eng.metrics, final))
+                    seen.logical_or_(over)
+
+                keep_final()
                 while not bool(eng.done.all()):
                     for _k in range(max(1, int(done_every))):
                         if fused:
@@ -340,7 +351,8 @@ class CimBatchSampler:
                             translate_actions(model_action, dec, state[:, -1].to(torch.float64), dec[:, 5], out=acts)
                             nact[:] = (~eng.done.to(torch.bool)).to(torch.int32)
                         eng.step(acts, nact)                 # (finished envs just report `done` again)
-                info_list.append({"env_metric": eng.metrics.clone()})
+                        keep_final()
+                info_list.append({"env_metric": final})
         finally:
             if fused:
                 policy._m.epsilon = eps_saved

@@ -59,7 +59,9 @@ if [ -n "$PACK" ]; then
   ( cd "$DEST/maro_src/maro" && tar -cf - --exclude='__pycache__' cli/__init__.py cli/utils/__init__.py cli/utils/params.py cli/data_pipeline streamit ) \
       | tar -xf - -C "$STAGE/maro_ref/maro"
   # config 5's CPU baseline runs the reference's own CIMEnvSampler: maro.rl (above) + the CIM RL example's shaping code
-  ( cd "$DEST/maro_src" && tar -cf - --exclude='__pycache__' examples/__init__.py examples/cim/rl ) | tar -xf - -C "$STAGE/maro_ref"
+  # ... and the two examples the GPU drop-in tests run unchanged against the HIP engine (tests/test_gpu_dropin.py)
+  ( cd "$DEST/maro_src" && tar -cf - --exclude='__pycache__' examples/__init__.py examples/cim/rl examples/vector_env/hello.py \
+        examples/citi_bike/greedy ) | tar -xf - -C "$STAGE/maro_ref"
   cp -r "$DEST/stubs" "$STAGE/maro_ref/stubs"
   ( cd "$STAGE" && tar -czf "$PACK/maro_ref.tgz" maro_ref )
   rm -rf "$STAGE"

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--durations", type=int, default=2880)
     ap.add_argument("--resolution", type=int, default=10)
     ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--backend", default="emu", choices=["emu", "gpu"], help="what backs GpuVectorEnv: the host-compiled device code (build container) or libmaro_amd.so on cuda:0")
     args = ap.parse_args()
     os.environ["HOME"] = os.environ.get("MARO_ORACLE_HOME", "/tmp/oracle/home")
     sys.path.insert(0, args.stubs)
@@ -32,12 +33,14 @@ def main():
     import numpy as np
     from maro.simulator import Env
 
+    from oracle.setup_toy_topologies import ensure_toy
+    ensure_toy(args.maro, os.environ["HOME"], args.topology)   # the packaged toy written back (left alone, the reference generates OTHER random toy data)
+
     spec = importlib.util.spec_from_file_location("greedy_launcher", os.path.join(args.maro, "examples/citi_bike/greedy/launcher.py"))
     greedy = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(greedy)   # class + config only; the script body is under __main__
 
     from maro_amd.cim.vector_env import GpuVectorEnv
-    from tests.emu.cb_emu_engine import CbEmuEngine
     kw = dict(durations=args.durations, snapshot_resolution=args.resolution)
 
     def drive(env):
@@ -54,14 +57,18 @@ def main():
 
     np.random.seed(args.seed)
     ref = drive(Env(scenario="citi_bike", topology=args.topology, start_tick=0, **kw))
-    eng = CbEmuEngine(args.topology, 1, max_actions=1, seeds=[args.seed], **kw)
-    ours = drive(GpuVectorEnv(1, "citi_bike", args.topology, _engine=eng, **kw).env_view(0))
+    if args.backend == "gpu":            # the product path: the HIP engine behind the env view
+        ours = drive(GpuVectorEnv(1, "citi_bike", args.topology, max_actions=1, seeds=[args.seed], **kw).env_view(0))
+    else:
+        from tests.emu.cb_emu_engine import CbEmuEngine
+        eng = CbEmuEngine(args.topology, 1, max_actions=1, seeds=[args.seed], **kw)
+        ours = drive(GpuVectorEnv(1, "citi_bike", args.topology, _engine=eng, **kw).env_view(0))
     assert len(ref[0]) == len(ours[0]), (len(ref[0]), len(ours[0]))
     for i, (a, b) in enumerate(zip(ref[0], ours[0])):
         assert a == b, (i, a, b)
     assert {k: int(v) for k, v in ref[1].items()} == {k: int(v) for k, v in ours[1].items()}, (ref[1], ours[1])
     assert np.array_equal(np.asarray(ref[2]), np.asarray(ours[2]))
-    print(f"OK: GreedyPolicy on {args.topology} ({args.durations} ticks, resolution {args.resolution}, seed {args.seed}): "
+    print(f"OK [{args.backend}]: GreedyPolicy on {args.topology} ({args.durations} ticks, resolution {args.resolution}, seed {args.seed}): "
           f"{len(ref[0])} decision events / actions identical, full stations snapshot history identical, metrics {ref[1]}")
 
 

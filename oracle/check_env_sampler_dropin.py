@@ -25,9 +25,13 @@ def main():
     ap.add_argument("--topology", default="toy.5p_ssddd_l0.5")
     ap.add_argument("--durations", type=int, default=150)
     ap.add_argument("--episodes", type=int, default=2)
+    ap.add_argument("--backend", default="emu", choices=["emu", "gpu"], help="what backs GpuVectorEnv: the CPU wave emulator (build container) or libmaro_amd.so on cuda:0")
+    ap.add_argument("--stubs", default=None, help="folder of import stand-ins for packages the reference wants and the box lacks (holidays, geopy)")
     args = ap.parse_args()
     os.environ.setdefault("HOME", "/tmp/oracle/home")
     sys.path.insert(0, args.maro)
+    if args.stubs:
+        sys.path.insert(1, args.stubs)
     sys.path.insert(0, REPO)
     for name in ["zmq", "zmq.asyncio", "zmq.eventloop", "zmq.eventloop.zmqstream", "tornado", "tornado.ioloop"]:
         sys.modules[name] = MagicMock()
@@ -44,12 +48,14 @@ def main():
     from examples.cim.rl.env_sampler import CIMEnvSampler
 
     from maro_amd.cim.vector_env import GpuVectorEnv
-    from tests.emu.emu_engine import EmuEngine
 
     def make_ref():
         return Env(scenario="cim", topology=args.topology, durations=args.durations)
 
     def make_ours():
+        if args.backend == "gpu":        # the product path: the HIP engine behind the env view
+            return GpuVectorEnv(1, "cim", args.topology, durations=args.durations, max_actions=1).env_view(0)
+        from tests.emu.emu_engine import EmuEngine
         eng = EmuEngine(args.topology, 1, durations=args.durations, max_actions=1)
         return GpuVectorEnv(1, "cim", args.topology, durations=args.durations, _engine=eng).env_view(0)
 
@@ -116,7 +122,7 @@ def main():
                 n_exp += 1
                 n_rows += sum(len(np.atleast_1d(v)) for v in getattr(x, "action_dict", {}).values())
     assert flat(ref_eval["info"]) == flat(ours_eval["info"]), (ref_eval["info"], ours_eval["info"])
-    print(f"OK: {args.episodes} sampled episode(s) + 1 evaluation episode of {args.topology} ({args.durations} ticks): "
+    print(f"OK [{args.backend}]: {args.episodes} sampled episode(s) + 1 evaluation episode of {args.topology} ({args.durations} ticks): "
           f"{n_exp} experience elements ({n_rows} action rows) identical (states, actions, rewards, terminals, next states), "
           f"env metrics identical: {ref[-1][1]}; eval metrics {ref_eval['info']}")
 

@@ -17,15 +17,18 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--maro", default="/tmp/oracle/maro_src")
+    ap.add_argument("--backend", default="emu", choices=["emu", "gpu"], help="what backs GpuVectorEnv: the CPU wave emulator (build container) or libmaro_amd.so on cuda:0")
+    ap.add_argument("--stubs", default=None)
     args = ap.parse_args()
     os.environ.setdefault("HOME", "/tmp/oracle/home")
     sys.path.insert(0, args.maro)
+    if args.stubs:
+        sys.path.insert(1, args.stubs)
     sys.path.insert(0, REPO)
     import numpy as np
     from maro.vector_env import VectorEnv as RefVectorEnv
 
     from maro_amd.cim.vector_env import GpuVectorEnv
-    from tests.emu.emu_engine import EmuEngine
 
     src = open(os.path.join(args.maro, "examples/vector_env/hello.py")).read()
     body = src[src.index('if __name__ == "__main__":'):].replace('if __name__ == "__main__":', "if True:")
@@ -49,6 +52,9 @@ def main():
         return trace
 
     def ours(batch_num, scenario, topology, durations):
+        if args.backend == "gpu":        # the product path: the HIP engine
+            return GpuVectorEnv(batch_num, scenario, topology, durations=durations, max_actions=1)
+        from tests.emu.emu_engine import EmuEngine
         eng = EmuEngine(topology, batch_num, durations=durations, max_actions=1)
         return GpuVectorEnv(batch_num, scenario, topology, durations=durations, _engine=eng)
 
@@ -57,7 +63,7 @@ def main():
     assert len(ref) == len(got), (len(ref), len(got))
     for i, (a, b) in enumerate(zip(ref, got)):
         assert a == b, (i, a, b)
-    print(f"OK: examples/vector_env/hello.py, both usage modes: {len(ref)} VectorEnv.step calls with identical metrics, decision "
+    print(f"OK [{args.backend}]: examples/vector_env/hello.py, both usage modes: {len(ref)} VectorEnv.step calls with identical metrics, decision "
           f"events of all 4 envs, ticks, frame indices and snapshot slices")
 
 

@@ -66,6 +66,8 @@ def write_back(name, maro_root, home, quiet=False):
     for k in ("resolution", "time_mean", "time_std", "supply_water_mark_ratio", "demand_water_mark_ratio", "scope_low_ratio",
               "scope_high_ratio", "extra_cost_mode", "filters"):
         assert getattr(data, k) == getattr(back, k), f"{name}: {k}"
+    with open(os.path.join(bd, ".written_back_from_npz"), "wt") as fp:   # (ensure_toy: a folder the reference's own unseeded toy generator made is other data)
+        fp.write(name + "\n")
     if maro_root:
         tdir = os.path.join(maro_root, "maro", "simulator", "scenarios", "citi_bike", "topologies", name)
         os.makedirs(tdir, exist_ok=True)
@@ -82,7 +84,7 @@ def ensure_toy(maro_root, home, name):
         return
     bd = os.path.join(home, ".maro", "data", "citi_bike", ".build", name)
     cfg = os.path.join(maro_root, "maro", "simulator", "scenarios", "citi_bike", "topologies", name, "config.yml")
-    if not (os.path.exists(os.path.join(bd, "trips.bin")) and os.path.exists(cfg)):
+    if not (os.path.exists(os.path.join(bd, "trips.bin")) and os.path.exists(os.path.join(bd, ".written_back_from_npz")) and os.path.exists(cfg)):
         write_back(name, maro_root, home, quiet=True)
 
 

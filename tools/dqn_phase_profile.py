@@ -1,4 +1,4 @@
-"""Phase timing of mrx_k_cim_dqn_forward (s_memtime deltas per workgroup).  Needs the profiling build, kept apart from the product:
+"""Phase timing of mrx_k_cim_dqn_mlp16 (s_memtime deltas per workgroup).  Needs the profiling build, kept apart from the product:
    (cd maro_amd/csrc && hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -fPIC -shared -DMRX_DQN_PROFILE \
        -o /tmp/libmaro_amd_prof.so cim_engine.hip cb_engine.hip) && MARO_AMD_LIB=/tmp/libmaro_amd_prof.so python tools/dqn_phase_profile.py [n_envs]
    MRX_DQN_TILE=16|32 selects the tile rows.  Prints the phases in s_memtime ticks and, from the event-timed duration of the same
