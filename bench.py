@@ -841,6 +841,117 @@ def bench_collect(args, engines, streams, qnet, chains, n, G, dev, rank, world, 
     return out
 
 
+def bench_object_api(args, dev, n=16384, groups=3, steps=12, warmup=3, view_seconds=1.5):
+    """What a MARO user gets from the reference-shaped OBJECT API: ``GpuVectorEnv(n, groups=3).step(list of
+    Action) -> (metrics list, DecisionEvent list, done)`` — the counterpart of maro/vector_env/vector_env.py:116-144 — with the
+    agent in Python reading every DecisionEvent and building one Action object per env, and ``env_view(0).step(Action)`` — what
+    ``AbsEnvSampler(learn_env=view)`` calls (maro/rl/rollout/env_sampler.py:340-352).  env-steps/s of the whole loop (agent
+    included), next to the tensor C-ABI's number in the headline.  Parity: sampled envs replayed on the C oracle with the very
+    actions the agent took (every event, metric and done flag)."""
+    import numpy as np
+    import torch
+
+    from maro_amd.cim.payloads import Action, ActionType
+    from maro_amd.cim.vector_env import GpuVectorEnv
+    topo, dur = args.topology, args.durations
+    seeds = np.arange(n, dtype=np.int64) + 31
+    env = GpuVectorEnv(n, "cim", topo, durations=dur, max_actions=1, seeds=seeds, groups=groups, device=dev, specialize=bool(args.specialize))
+    LOAD, DISCHARGE = ActionType.LOAD, ActionType.DISCHARGE
+
+    def agent(events, k):
+        # a legal deterministic rule of the event alone: alternate a half load / half discharge by (step + port) parity
+        out = []
+        for ev in events:
+            if ev is None:
+                out.append(None)
+            elif (k + ev.port_idx) & 1:
+                out.append(Action(ev.vessel_idx, ev.port_idx, ev.action_scope.load >> 1, LOAD))
+            else:
+                out.append(Action(ev.vessel_idx, ev.port_idx, ev.action_scope.discharge >> 1, DISCHARGE))
+        return out
+
+    checked = sorted({0, 1, n // 2, n - 1})
+    log = {e: [] for e in checked}
+    metrics, events, done = env.step(None)
+    t_agent = t_step = 0.0
+    resolved = 0
+    tuned = None
+    for k in range(warmup + 2 * steps):
+        if k == warmup + steps:
+            # the same loop once more with the interpreter's cyclic collector out of the way of the agent's own object traffic
+            # (gc.freeze() + a young-generation threshold above a step's allocations: two lines a user adds around a rollout)
+            default_gc = (resolved, t_agent, t_step)
+            from maro_amd.cim.vector_env import object_api_gc
+            tuned = object_api_gc(n)
+            tuned.__enter__()
+        if k == warmup or k == warmup + steps:
+            torch.cuda.synchronize(dev)
+            t_agent = t_step = 0.0
+            resolved = 0
+        ta = time.perf_counter()
+        actions = agent(events, k)
+        tb = time.perf_counter()
+        for e in checked:
+            a, ev = actions[e], events[e]
+            log[e].append(((ev.tick, ev.port_idx, ev.vessel_idx, ev.action_scope.load, ev.action_scope.discharge, ev.early_discharge), dict(metrics[e]),
+                           None if a is None else (a.vessel_idx, a.port_idx, a.quantity, 0 if a.action_type is LOAD else 1)))
+        tb2 = time.perf_counter()
+        metrics, events, done = env.step(actions)
+        tc = time.perf_counter()
+        t_agent += tb - ta
+        t_step += tc - tb2
+        resolved += sum(1 for ev in events if ev is not None)
+    if tuned:
+        tuned.__exit__()
+        tuned = {"value": resolved / (t_agent + t_step), "unit": "env-steps/s", "ms_agent_per_step": t_agent / steps * 1e3, "ms_env_step_per_step": t_step / steps * 1e3,
+                 "what": "the same loop inside `with maro_amd.cim.vector_env.object_api_gc(n):` (gc.freeze() + a young-generation threshold of 8 x envs): the agent's Action / ActionScope objects no longer trigger collections"}
+        resolved, t_agent, t_step = default_gc
+    dt = t_agent + t_step        # (the parity log of the 4 sampled envs is not part of the loop)
+    out = {"value": resolved / dt, "value_gc_tuned": tuned, "unit": "env-steps/s", "envs": n, "groups": groups, "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "ms_agent_per_step": t_agent / steps * 1e3, "ms_env_step_per_step": t_step / steps * 1e3,
+           "what": "GpuVectorEnv(n, groups).step(list of Action): per step the Python agent reads every DecisionEvent (port, vessel, action_scope) and builds one Action "
+                   "per env; step() encodes them, runs mrx_cim_step on every group, reads the results back once and builds the metrics dicts and DecisionEvents",
+           "floor": "every env-step creates a DecisionEvent, a metrics dict and an Action and is touched by three Python loops (agent, encode, build): "
+                    "~0.3-1 us of interpreter time per object, whatever the GPU does"}
+    # parity: the sampled envs on the C oracle, driven by the agent's own actions
+    from oracle.cim_oracle import CimOracle
+    ok, first = True, None
+    for e in checked:
+        o = CimOracle(topo, durations=dur)
+        o.set_seed(int(seeds[e]))
+        o.reset(keep_seed=True)
+        om, od, odone = o.step(None)
+        for i, (evt, met, act) in enumerate(log[e]):
+            want = tuple(int(x) for x in od[:6])
+            if odone or want != evt or (int(om[0]), int(om[1]), int(om[2])) != (met["order_requirements"], met["container_shortage"], met["operation_number"]):
+                ok, first = False, first or {"env": e, "step": i, "oracle": want, "object_api": evt}
+                break
+            om, od, odone = o.step([act] if act is not None else None)
+    out["parity"] = {"ok": ok, "envs_checked": len(checked), "env_steps_checked": sum(len(v) for v in log.values()), "first_mismatch": first,
+                     "what": "every DecisionEvent (tick, port, vessel, action scope, early discharge) and metrics dict the agent saw for the sampled envs vs the C oracle driven by the agent's own actions"}
+    # ---- one env through its view: what AbsEnvSampler(learn_env=env_view(0)) does per interaction
+    one = GpuVectorEnv(1, "cim", topo, durations=dur, max_actions=1, seeds=[7], device=dev, specialize=bool(args.specialize))
+    view = one.env_view(0)
+    m, ev, d = view.step(None)
+    k = steps_v = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < view_seconds:
+        if d:
+            view.reset()
+            m, ev, d = view.step(None)
+            continue
+        a = Action(ev.vessel_idx, ev.port_idx, ev.action_scope.load >> 1, LOAD) if k & 1 else Action(ev.vessel_idx, ev.port_idx, ev.action_scope.discharge >> 1, DISCHARGE)
+        _ = view.tick, view.frame_index
+        m, ev, d = view.step(a)
+        k += 1
+        steps_v += 1
+    dtv = time.perf_counter() - t0
+    out["env_view"] = {"value": steps_v / dtv, "unit": "env-steps/s", "envs": 1, "us_per_step": dtv / max(steps_v, 1) * 1e6,
+                       "what": "GpuVectorEnv(1).env_view(0).step(Action) + tick + frame_index per interaction: one launch and one read-back per step (latency-bound: a single env cannot fill a GPU)"}
+    del env, one
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scenario", default="cim", choices=["cim", "citi_bike"])
@@ -881,6 +992,7 @@ def main():
                     "(gather_to_learner), reporting the gather's share of a rollout (0: only the single 32-step gather)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--object-api", action="store_true", help="run ONLY the object-API leg (GpuVectorEnv.step(list of Action), env_view stepping) and print it")
     ap.add_argument("--secondary", type=int, default=-1, help="after the headline (cim, random agent), also run BASELINE configs 4 and 5 as short legs and embed "
                     "them under `secondary` in the same JSON line (citi_bike toy.3s_4t 4096 envs — and, on one GPU, all 32768 of config 4; DQN collection loop 8192 envs), each with parity, "
                     "cpu_baseline and a measured-bytes roofline.  -1 = auto: on for the default workload (what the driver runs), off when a flag selects another one")
@@ -900,7 +1012,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist, dev = init_dist(world, local_rank, build=ge.build)
     torch.cuda.set_device(dev)
-    if args.scenario == "citi_bike":
+    if args.object_api:
+        ge.build()
+        out = bench_object_api(args, dev, n=args.envs, groups=args.groups)
+    elif args.scenario == "citi_bike":
         out = bench_citi_bike(args, dist, dev, rank, world)
     else:
         out = bench_cim(args, dist, dev, rank, world)
@@ -931,8 +1046,20 @@ def main():
             a5.groups = 2    # (a latency-bound three-launch chain per group: measured 1 / 2 / 3 groups = 59 / 65 / 62 M at this size)
             a5.parity_envs = min(args.parity_envs, 6)
             r5 = bench_cim(a5, dist, dev, rank, world)
+            r_obj = None
+            if world == 1:
+                gc.collect()
+                torch.cuda.empty_cache()
+                try:
+                    r_obj = bench_object_api(args, dev)
+                except Exception as e:      # a convenience leg, never a reason to fail the bench
+                    r_obj = {"error": repr(e)[:300]}
             if out is not None:
                 sec["citi_bike_config4"], sec["collect_config5"] = r4, r5
+                if r_obj is not None:
+                    if "value" in r_obj and "cpu_baseline_reference" in out and isinstance(out["cpu_baseline_reference"].get("vector_env"), dict):
+                        r_obj["cpu_baseline"] = dict(out["cpu_baseline_reference"]["vector_env"], kind="reference", note="maro.vector_env.VectorEnv on this box's cores (headline's cpu_baseline_reference.vector_env)")
+                    sec["object_api"] = r_obj
                 if r4w is not None:
                     r4w["config"]["what"] = "BASELINE.json configs[3] whole (32768 envs) on ONE GPU; cpu_baseline: see citi_bike_config4"
                     sec["citi_bike_config4_one_gpu"] = r4w

@@ -63,10 +63,20 @@ except Exception:  # maro is not installed (e.g. the GPU box)
             self._action_scope_func = action_scope_func
             self._early_discharge_func = early_discharge_func
 
+        @classmethod
+        def _from_row(cls, tick, port_idx, vessel_idx, snapshot_list, load, discharge, early):
+            """The engine's decision row -> event without the two closures of the reference's constructor form (one dict literal;
+            the ActionScope object is made when it is read).  Same attributes, same pickled state."""
+            ev = cls.__new__(cls)
+            ev.__dict__ = {"tick": tick, "port_idx": port_idx, "vessel_idx": vessel_idx, "snapshot_list": snapshot_list, "_action_scope": None,
+                           "_early_discharge": early, "_action_scope_func": None, "_early_discharge_func": None, "_scope": (load, discharge)}
+            return ev
+
         @property
         def action_scope(self) -> ActionScope:
             if self._action_scope is None:
-                self._action_scope = self._action_scope_func(self.port_idx, self.vessel_idx)
+                f = self._action_scope_func
+                self._action_scope = ActionScope(*self._scope) if f is None else f(self.port_idx, self.vessel_idx)
             return self._action_scope
 
         @property
@@ -98,7 +108,20 @@ def encode_action(a) -> tuple:
     return (int(a.vessel_idx), int(a.port_idx), int(a.quantity), 1 if name.endswith("DISCHARGE") else 0)
 
 
+_ACTION_CODE = {ActionType.LOAD: 0, ActionType.DISCHARGE: 1}
+
+
+def action_code(t) -> int:
+    """ActionType -> the C ABI's 0 = LOAD | 1 = DISCHARGE (a foreign enum with the same member names is accepted)."""
+    c = _ACTION_CODE.get(t)
+    if c is None:
+        c = 1 if getattr(t, "name", str(t)).upper().endswith("DISCHARGE") else 0
+    return c
+
+
 def make_decision_event(row, snapshot_list) -> "DecisionEvent":
     """Decision row of the C ABI -> DecisionEvent (scope / early discharge already evaluated at the pause)."""
     tick, port, vessel, load, discharge, early = (int(x) for x in row[:6])
+    if not HAVE_MARO:
+        return DecisionEvent._from_row(tick, port, vessel, snapshot_list, load, discharge, early)
     return DecisionEvent(tick, port, vessel, snapshot_list, lambda p, v: ActionScope(load, discharge), lambda v: early)

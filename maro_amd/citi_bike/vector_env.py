@@ -18,6 +18,7 @@ class CitiBikeVectorEnv(GpuVectorEnv):
     what a fresh reference process with the same seed would see."""
 
     ACTION_WIDTH = 3
+    _WHOLE_BATCH_STEP = False   # (events carry per-env scope rows: the per-env path builds them)
     METRIC_KEYS = ("trip_requirements", "bike_shortage", "operation_number")
     NODE_ATTRS = NODE_ATTRS
 
@@ -48,6 +49,7 @@ class CitiBikeVectorEnv(GpuVectorEnv):
             self._last_met[e] = 0
             self._n_pending[e] = 0
             self._last_dec[e] = None
+        self._host_ticks = None
         self.engine.reset(mask=mask)
 
     def set_seed(self, seed: int, envs: Optional[Sequence[int]] = None):
@@ -82,6 +84,7 @@ class CitiBikeVectorEnv(GpuVectorEnv):
                 nact[e, i] = len(alist)
         if mask.any():
             dec, scope, met, done = (x.cpu().numpy() for x in eng.step_joint(acts, nact, nans, mask))
+            self._host_ticks = None
             for e in envs:
                 if not mask[e]:
                     continue
@@ -114,6 +117,7 @@ class CitiBikeVectorEnv(GpuVectorEnv):
 
     def _engine_step(self, acts, nact, mask, n_answered=None):
         dec, scope, met, done = self.engine.step(acts, nact, mask)
+        self._host_ticks = None
         return dec.cpu().numpy(), met.cpu().numpy(), done.cpu().numpy(), scope.cpu().numpy()
 
     def _make_event(self, e: int, row, extra):

@@ -77,3 +77,8 @@ def test_vector_env_groups_argument_on_gpu():
             [None if e is None else (e.tick, e.port_idx, e.vessel_idx) for e in rb[1]]
         ra, rb = a.step(None), b.step(None)
     assert rb[2] and ra[0] == rb[0]
+
+
+def test_whole_batch_step_equals_the_per_env_path_on_gpu():
+    from tests.test_vector_env_api import check_whole_batch_step_equals_the_per_env_path
+    check_whole_batch_step_equals_the_per_env_path(gpu_factory)

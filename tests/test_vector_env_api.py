@@ -294,3 +294,40 @@ def check_pipelined_object_api(single_factory, grouped_factory, n=7, steps=60):
 
 def test_object_api_on_a_pipelined_batch_equals_a_single_engine():
     check_pipelined_object_api(emu_factory, pipelined_emu_factory(3))
+
+
+def check_whole_batch_step_equals_the_per_env_path(engine_factory):
+    """step(list) of the whole batch takes the array-form path (_step_all), step(dict) the per-env path (_step_envs): same
+    metrics, events, done flags, ticks and frame indices step by step; `tick` / `frame_index` come from the step's own read-back."""
+    n = 5
+    a, b = make_env(n, engine_factory, durations=50), make_env(n, engine_factory, durations=50)
+    ra, rb = a.step(None), b.step({e: None for e in range(n)})
+    k = 0
+    while True:
+        (ma, ea, da), (mb, eb, db) = ra, rb
+        assert da == db and ma == mb and a.tick == b.tick and a.frame_index == b.frame_index
+        assert a.tick == a.engine.ticks.cpu().tolist()
+        for x, y in zip(ea, eb):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert (x.tick, x.port_idx, x.vessel_idx, x.action_scope.load, x.action_scope.discharge, x.early_discharge) == \
+                       (y.tick, y.port_idx, y.vessel_idx, y.action_scope.load, y.action_scope.discharge, y.early_discharge)
+                assert x.snapshot_list["ports"][x.tick:x.port_idx:"empty"].tolist() == y.snapshot_list["ports"][y.tick:y.port_idx:"empty"].tolist()
+        if da:
+            break
+        acts = [None if ev is None or (e + k) % 3 == 0 else Action(ev.vessel_idx, ev.port_idx, ev.action_scope.load // 2, ActionType.LOAD) if (e + k) % 3 == 1
+                else [Action(ev.vessel_idx, ev.port_idx, ev.action_scope.discharge // 2, ActionType.DISCHARGE)] for e, ev in enumerate(ea)]
+        ra, rb = a.step(acts), b.step(dict(enumerate(acts)))
+        k += 1
+    assert k > 10
+    # a finished batch: (None, None, True) for every env, in both forms; a single broadcast Action
+    assert a.step(None) == ([None] * n, [None] * n, True) and b.step({0: None})[0] == [None]
+    a.reset(), b.reset()
+    ra, rb = a.step(None), b.step({e: None for e in range(n)})
+    one = Action(ra[1][0].vessel_idx, ra[1][0].port_idx, 0, ActionType.DISCHARGE)   # (every env is at the same first decision)
+    ra, rb = a.step(one), b.step({e: one for e in range(n)})
+    assert ra[0] == rb[0] and a.tick == b.tick
+
+
+def test_whole_batch_step_equals_the_per_env_path_on_emulator():
+    check_whole_batch_step_equals_the_per_env_path(emu_factory)
