@@ -148,7 +148,9 @@ int mrx_cb_set_lanes_per_wave(mrx_cb_handle h, int lanes);
  * candidate neighbours are ranked across the lanes (ballot / broadcast / prefix rank) instead of a per-lane selection sort —
  * and then the general kernel for the envs that have to replay events.  Sequential mode, aligned frames, <= 2048 stations.
  * mode: 0 = automatic (on from 96 stations), 1 = on, -1 = off.  Returns 1 / 0 (in effect or not) or a negative mrx_status.
- * Results do not depend on it.
+ * Results do not depend on it.  Plan-specialised step kernels: a code object built with the envs-per-wave shift compiled in
+ * (MRXC_lsh_plan >= 0: plans whose state fits LDS one env per lane) contains the speculative wave kernel but NOT the wave replay
+ * kernel; forcing the mode on wants the runtime-shift build (MRXC_lsh_plan -1) loaded first — the Python engine does that.
  */
 int mrx_cb_set_wave_decisions(mrx_cb_handle h, int mode);
 

@@ -18,6 +18,12 @@ CSRC = os.environ.get("MARO_AMD_CSRC") or os.path.join(os.path.dirname(os.path.d
 CACHE = os.environ.get("MARO_AMD_SPEC_CACHE", os.path.join(CSRC, "spec_cache"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"] + os.environ.get("MARO_AMD_SPEC_FLAGS", "").split()
+# the device code's results are bit-exact against the reference because fp64 arithmetic is compiled as written: flags that let
+# the compiler re-associate, contract or approximate it are refused outright (they would also change the code-object key)
+_UNSAFE = ("-ffast-math", "-Ofast", "-funsafe-math-optimizations", "-freciprocal-math", "-fassociative-math", "-fno-signed-zeros", "-ffp-contract=fast",
+           "-fapprox-func", "-ffinite-math-only", "-ffp-model=fast", "-ffp-model=aggressive")
+if any(f in _UNSAFE for f in FLAGS):
+    raise ValueError(f"MARO_AMD_SPEC_FLAGS: {[f for f in FLAGS if f in _UNSAFE]} would break bit-exact fp64 (order generator, transfer times)")
 UNITS = {   # scenario -> (translation unit, generated dims header, the sources the cache key covers, ABI prefix)
     "cim": ("cim_spec.hip", "cim_spec_dims.h", ("cim_spec.hip", "cim_step_kernels.h", "cim_device.h", "cim_params.h", "cim_prof.h", "wave.h"), "mrx_cim"),
     "citi_bike": ("cb_spec.hip", "cb_spec_dims.h", ("cb_spec.hip", "cb_step_kernels.h", "cb_device.h", "cb_wave.h", "cb_params.h", "wave.h",

@@ -66,6 +66,7 @@ class CitiBikeBatchEngine:
         self._h = h
         self.specialized = False
         self._specialize = specialize
+        self._forced_wave = False
         self._manual_lanes = bool(os.environ.get("MRX_CB_LANES"))   # (the C side reads it at create: an experiment's fixed split)
         self._load_specialized()
         self.layout = MrxCbLayout()
@@ -148,39 +149,63 @@ class CitiBikeBatchEngine:
                    "mrx_cb_reset")
         self._keep = (tt, mk)
 
-    def _load_specialized(self) -> None:
+    def _load_specialized(self, runtime_shift: Optional[bool] = None) -> None:
         """(Re)load the step kernels compiled for this plan.  The plan text carries the envs-per-wave shift of the automatic split
-        (MRXC_lsh_plan: folded into the kernel's LDS addresses); with a split chosen by hand the build that takes the shift as a kernel
-        argument is loaded instead (MRXC_lsh_plan -1)."""
-        self.specialized = False
+        (MRXC_lsh_plan: folded into the kernel's LDS addresses); with a split chosen by hand — or the wave-cooperative kernels forced
+        on, which only the other build contains — the build that takes the shift as a kernel argument is loaded instead
+        (MRXC_lsh_plan -1).  Raises what the load raises (the previously loaded kernels stay in place); in "cached" mode a build that
+        is not in the cache leaves everything as it was, `specialized` included."""
         if not self._specialize:
+            self.specialized = False
             return
         import re
 
         from ..cim import specialize as spec
+        if runtime_shift is None:
+            runtime_shift = self._manual_lanes or self._forced_wave
         defines = spec.plan_defines(self._ts, self._cfg, "citi_bike")
-        if self._manual_lanes:
+        if runtime_shift:
             defines = re.sub(r"(#define MRXC_lsh_plan) -?\d+", r"\1 -1", defines)
         try:
             spec.load_into(self, defines, build=self._specialize != "cached", scenario="citi_bike")
             self.specialized = True
         except KeyError:
-            pass   # "cached" and not in the cache: generic kernels
+            pass   # "cached" and not in the cache: whatever was loaded before (generic kernels at creation) stays
 
     def set_lanes_per_wave(self, lanes: int = 0) -> None:
         """Envs per 64-lane wave of the step kernel (1, 2, ..., 64; 0 = the automatic choice): few envs per wave = less
         control-flow divergence, more waves.  Results do not depend on it (include/maro_amd_citi_bike.h).  A plan-specialised engine
-        reloads its step kernels when the choice switches between automatic and by hand (see _load_specialized)."""
-        _lib.check(self._L.mrx_cb_set_lanes_per_wave(self._h, int(lanes)), "mrx_cb_set_lanes_per_wave")
+        reloads its step kernels when the choice switches between automatic and by hand (see _load_specialized): the matching build
+        is loaded FIRST, so a refused load leaves the split and the kernels as they were; a refused split reloads the old build."""
         manual = int(lanes) != 0
-        if self._specialize and manual != self._manual_lanes:
-            self._manual_lanes = manual
-            self._load_specialized()
+        switch = bool(self._specialize) and (manual or self._forced_wave) != (self._manual_lanes or self._forced_wave)
+        if switch:
+            self._load_specialized(manual or self._forced_wave)
+        try:
+            _lib.check(self._L.mrx_cb_set_lanes_per_wave(self._h, int(lanes)), "mrx_cb_set_lanes_per_wave")
+        except Exception:
+            if switch:
+                self._load_specialized()
+            raise
+        self._manual_lanes = manual
 
     def set_wave_decisions(self, mode: int = 0) -> bool:
         """mrx_cb_set_wave_decisions: env-steps that stay inside their tick on one wave per env (action scope ranked across the
-        lanes).  0 = automatic (on from 96 stations), 1 = on, -1 = off; returns whether it is in effect.  Results unchanged."""
-        return bool(_lib.check(self._L.mrx_cb_set_wave_decisions(self._h, int(mode)), "mrx_cb_set_wave_decisions"))
+        lanes).  0 = automatic (on from 96 stations), 1 = on, -1 = off; returns whether it is in effect.  Results unchanged.
+        Forcing it ON for a plan-specialised engine whose plan fits LDS (compiled-in envs-per-wave shift) loads the runtime-shift
+        build first: only that one contains the wave kernels (cb_step_kernels.h)."""
+        forced = int(mode) == 1
+        switch = bool(self._specialize) and (self._manual_lanes or forced) != (self._manual_lanes or self._forced_wave)
+        if switch:
+            self._load_specialized(self._manual_lanes or forced)
+        try:
+            on = bool(_lib.check(self._L.mrx_cb_set_wave_decisions(self._h, int(mode)), "mrx_cb_set_wave_decisions"))
+        except Exception:
+            if switch:
+                self._load_specialized()
+            raise
+        self._forced_wave = forced
+        return on
 
     def set_step_budget(self, max_records: int = 0) -> None:
         """Bounded steps: an env replays at most ~`max_records` events per `step()` call; envs that have not reached their

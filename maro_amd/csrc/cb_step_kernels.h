@@ -98,7 +98,7 @@ mrx_k_cb_step_wave(CbParams K, const int32_t* __restrict__ actions, const int32_
   if (threadIdx.x == 0) K.todo[e] = ok ? 0 : 1;
 }
 
-#if defined(MRX_CB_LDSFRAME) && MRXC_lsh_plan < 0   /* (plans with a compiled-in envs-per-wave shift have no wave kernels: they run with lsh 0) */
+#if defined(MRX_CB_LDSFRAME) && MRXC_lsh_plan < 0   /* (the wave REPLAY kernel runs with lsh 0: a build with the envs-per-wave shift compiled in has the speculative wave kernel only — forcing wave mode on loads the runtime-shift build, citi_bike/engine.py) */
 // The GENERAL step on one wave per env (cb::step_env_wave): for the envs mrx_k_cb_step_wave flagged in K.todo.  The env's state is
 // moved HBM <-> the wave's LDS column by all 64 lanes (launched with K.lsh = 0: one column), the sequential parts run on lane 0
 // out of LDS, the station sweeps / snapshot / action scope across the lanes.

