@@ -984,6 +984,8 @@ def main():
     ap.add_argument("--ring", type=int, default=4, help="snapshot ring slots per env (max_snapshots)")
     ap.add_argument("--no-query", action="store_true", help="skip the per-step snapshot slice")
     ap.add_argument("--no-episode", action="store_true", help="skip the end-to-end leg (reset + one full episode of the whole batch)")
+    ap.add_argument("--sustained-episodes", type=int, default=6, help="sustained leg (after the end-to-end leg): whole episodes per group run back to back, "
+                    "resets overlapped with the other groups' steps (0: skip)")
     ap.add_argument("--episode-block", type=int, default=256, help="end-to-end leg: batch steps enqueued between two 'is every env done' read-backs")
     ap.add_argument("--parity-envs", type=int, default=64, help="envs replayed on the CPU oracle after the run (0: off)")
     ap.add_argument("--repeats", type=int, default=5, help="the timed window (exactly --steps steps between barrier + synchronize) is run this many "
@@ -1337,6 +1339,64 @@ def bench_cim(args, dist, dev, rank, world):
         episode = {"env_steps": ep_steps, "seconds": t_ep, "reset_ms": ep_reset_ms, "batch_steps": k}
         gpu_busy_s["end_to_end_episode"] = t_ep
 
+    # ---- sustained: >= 1 s of whole episodes back to back, resets included and OVERLAPPED — what a rollout user gets.  Each group
+    # runs episode after episode on its own stream and is reset (next seeds) as soon as a polled flag says its envs are all done;
+    # the groups are staggered by a third of an episode (untimed pre-roll), so one group's reset kernels (order table: VALU-bound)
+    # run under the other groups' step kernels (latency-bound).  No device-wide synchronisation inside the window: the done flag
+    # of block k is read when block k + 1 has been enqueued.
+    sustained = None
+    if episode is not None and args.sustained_episodes > 0:
+        nominal, blk = episode["batch_steps"], 32
+        per_group_steps = args.sustained_episodes * nominal
+        sync_all()
+        for g, eng in enumerate(engines):
+            eng.reset(group_seeds(g))
+        kk = [0] * G                      # step index within the group's current episode
+        ep_n = [0] * G                    # episodes the group has started after the first
+        for g in range(1, G):
+            for _ in range(g * nominal // G):
+                one_step(kk[g], g, count=False)
+                kk[g] += 1
+        flags = [torch.zeros(2, dtype=torch.uint8).pin_memory() for _ in range(G)]
+        evs = [[torch.cuda.Event(), torch.cuda.Event()] for _ in range(G)]
+        pending = [None] * G              # which of the group's two flag slots holds an unread poll
+        sync_all()
+        for b in bufs:
+            b["counter"].zero_()
+        sync_all()
+        t_s = time.perf_counter()
+        done_steps = [0] * G
+        resets_in_window = 0
+        slot = 0
+        while min(done_steps) < per_group_steps:
+            for g in range(G):
+                if done_steps[g] >= per_group_steps:
+                    continue
+                for _ in range(blk):
+                    one_step(kk[g], g)
+                    kk[g] += 1
+                done_steps[g] += blk
+                # read the PREVIOUS poll of this group (its event has long fired: a whole block of every group was enqueued since)
+                if pending[g] is not None:
+                    evs[g][pending[g]].synchronize()
+                    if flags[g][pending[g]].item():
+                        ep_n[g] += 1
+                        resets_in_window += 1
+                        engines[g].reset(group_seeds(g) + 1000003 * ep_n[g])
+                        kk[g] = 0
+                        pending[g] = None
+                        continue
+                with torch.cuda.stream(streams[g]):
+                    flags[g][slot].copy_(engines[g].done.min().to(torch.uint8), non_blocking=True)
+                    evs[g][slot].record(streams[g])
+                pending[g] = slot
+            slot ^= 1
+        sync_all()
+        t_sus = time.perf_counter() - t_s
+        sus_steps = sum(int(b["counter"].item()) for b in bufs)
+        sustained = {"env_steps": sus_steps, "seconds": t_sus, "resets": resets_in_window, "batch_steps_per_group": per_group_steps, "poll_every": blk}
+        gpu_busy_s["sustained_episodes"] = t_sus
+
     # ---- parity (untimed): a sample of envs of THIS configuration replayed on the CPU oracle — every decision, metric,
     # fused observation and the final snapshot ring (tests/bench_parity.py; the oracle is the checker, never the thing measured)
     parity = None
@@ -1465,6 +1525,15 @@ def bench_cim(args, dist, dev, rank, world):
             out["end_to_end"] = {"definition": "env-steps of one COMPLETE episode of every env / wall time from the first reset launch until the slowest env is done (reset included)",
                                  "env_steps": ep_steps_all, "seconds": ep_s, "reset_ms_synchronised": reset_ms, "reset": "per group on its own stream, overlapped with the other groups' first steps", "batch_steps": episode["batch_steps"],
                                  "durations": engines[0].durations}
+        if sustained is not None:
+            # (per rank: every rank runs the same window on its own GPU; the line carries rank 0's, scaled by the world size)
+            out["value_sustained"] = sustained["env_steps"] * world / sustained["seconds"]
+            out["sustained"] = dict(sustained, definition="env-steps of %d staggered groups running whole episodes back to back for %d batch steps each (resets included, "
+                                    "a group is reset as soon as its polled done flag says so; envs that finish early idle until their group's slowest one is through) / wall time"
+                                    % (G, sustained["batch_steps_per_group"]), over_steady_state=out["value_sustained"] / value)
+            out["config"]["value_sustained"] = out["value_sustained"]
+        if episode is not None:
+            out["config"]["value_end_to_end"] = out["value_end_to_end"]
         if parity is not None:
             out["parity"] = parity
         if world == 1 and not args.no_cpu:
