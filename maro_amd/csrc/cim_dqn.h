@@ -490,12 +490,12 @@ __device__ __forceinline__ void mrx_dqn_mlp_body(const CimParams& K, const cim::
     DQ_T();
     if (l == lw) {
       const int Npad = M.npad[l], sh = dq_sh(Npad), F = (M.kpad[l] >> 4) << sh;   // fragments to consume
-      // the layer after this one (for this wave): looked up now, its bias requested after the passes — used a layer from now
+      // the layer after this one (for this wave): its bias is requested NOW — it arrives under this layer's passes and moves into
+      // place after the epilogue without a wait
       int ln = l + 1;
       while (ln < M.n_layers && dq_idle(M.npad[ln], w)) ln++;
       const int lb = ln < M.n_layers ? ln : l;
-      const int Nnext = M.npad[lb];
-      const float* bnext = net + M.b_off[lb];
+      dq_bias(bvn, net + M.b_off[lb], M.npad[lb], w, g4);
       const float* xlane = X[cur] + r16 * DQ_LD + g4 * 4;
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) acur[mt] = *(const dq_f4*)(xlane + mt * 16 * DQ_LD);
@@ -517,7 +517,6 @@ __device__ __forceinline__ void mrx_dqn_mlp_body(const CimParams& K, const cim::
         soff += DQ_PASS * 1024;
         DQ_T();
       }
-      dq_bias(bvn, bnext, Nnext, w, g4);
       const bool act = l + 1 < M.n_layers;
       const int col0 = (Npad == 16 ? 0 : Npad == 32 ? (w & 1) : w) * 16, colstep = Npad <= 32 ? 16 : 64;
       if (sh == 0) dq_epilogue<MT, 1>(acc, bv, X[cur ^ 1], col0, colstep, act, M.slope);
