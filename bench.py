@@ -855,7 +855,7 @@ def bench_object_api(args, dev, n=16384, groups=3, steps=12, warmup=3, view_seco
     from maro_amd.cim.vector_env import GpuVectorEnv
     topo, dur = args.topology, args.durations
     seeds = np.arange(n, dtype=np.int64) + 31
-    env = GpuVectorEnv(n, "cim", topo, durations=dur, max_actions=1, seeds=seeds, groups=groups, device=dev, specialize=bool(args.specialize))
+    env = GpuVectorEnv(n, "cim", topo, durations=dur, max_snapshots=args.ring, max_actions=1, seeds=seeds, groups=groups, device=dev, specialize=bool(args.specialize))
     LOAD, DISCHARGE = ActionType.LOAD, ActionType.DISCHARGE
 
     def agent(events, k):
@@ -930,7 +930,7 @@ def bench_object_api(args, dev, n=16384, groups=3, steps=12, warmup=3, view_seco
     out["parity"] = {"ok": ok, "envs_checked": len(checked), "env_steps_checked": sum(len(v) for v in log.values()), "first_mismatch": first,
                      "what": "every DecisionEvent (tick, port, vessel, action scope, early discharge) and metrics dict the agent saw for the sampled envs vs the C oracle driven by the agent's own actions"}
     # ---- one env through its view: what AbsEnvSampler(learn_env=env_view(0)) does per interaction
-    one = GpuVectorEnv(1, "cim", topo, durations=dur, max_actions=1, seeds=[7], device=dev, specialize=bool(args.specialize))
+    one = GpuVectorEnv(1, "cim", topo, durations=dur, max_snapshots=args.ring, max_actions=1, seeds=[7], device=dev, specialize=bool(args.specialize))
     view = one.env_view(0)
     m, ev, d = view.step(None)
     k = steps_v = 0

@@ -38,7 +38,7 @@ if [ "${CB:-0}" = "1" ]; then
   }
   cb_pass toy3s --bounded-budget 0
   cb_pass toy3s_32768 --envs 32768 --bounded-budget 0
-  cb_pass city800 --topology city.800s --envs 4096 --durations 2880 --steps 900 --warmup 300 --bounded-budget 0 --step-budget 64 --specialize 1
+  cb_pass city800 --topology city.800s --envs 4096 --durations 2880 --steps 900 --warmup 300 --bounded-budget 0 --step-budget 24 --specialize 1
 fi
 # ---- config 5 (COLLECT=1): the DQN collection loop at 8192 envs per GPU — kernel trace + the two PMC passes over every kernel of the loop
 if [ "${COLLECT:-0}" = "1" ]; then
@@ -61,5 +61,12 @@ if [ "${BIG:-0}" = "1" ]; then
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $Bg/fetch -o r -- $BB > $Bg/fetch_line.json 2> $Bg/fetch.err; echo "big fetch rc $?"
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $Bg/write -o r -- $BB > $Bg/write_line.json 2> $Bg/write.err; echo "big write rc $?"
   mkdir -p $Bg/out; python tools/refresh_pmc.py $Bg profiles/${tag}_65536_rocprofv3.md $Bg/out; cp $Bg/out/latest_pmc.json $O/pmc_65536.json; cp $Bg/out/${tag}_65536_rocprofv3.md $O/ 2>/dev/null
+fi
+# ---- ISA=1: what the ISA budget (profiles/<tag>_isa_budget.md) needs of the headline step kernel: wave cycles per phase of the plan-specialised
+# kernel (a code object built with -DMRX_PROFILE_PHASES) and a second set of SQ counters
+if [ "${ISA:-0}" = "1" ]; then
+  timeout 300 python tools/phase_profile.py --specialized --envs 16384 > $O/phase_profile_spec.txt 2> $O/phase_profile_spec.err; echo "phase profile rc $?"
+  timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_VALU -d $O/sq2 -o r -- $B > $O/sq2_line.json 2> $O/sq2.err; echo "sq2 rc $?"
+  python tools/rocprof_summary.py $(find $O/sq2 -name "*_results.db" | head -1) 2> /dev/null | grep -E "kernel|mrx_k_cim" | cut -c1-600 > $O/sq2_summary.md
 fi
 find $O -name "*.db" -delete; find $O -type d -empty -delete; du -sh $O

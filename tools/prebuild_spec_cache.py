@@ -63,6 +63,7 @@ def main(which="bench"):
         ts, keep = topology_struct(data)
         cap = data.n_stations * (int((data.time_mean + 6 * data.time_std) / max(data.resolution, 1)) + 2) + 4
         todo[("citi_bike", spec.plan_defines(ts, MrxCbConfig(4096, 0, 0, 44000, 10, 16, 1, cap, 0), "citi_bike"))] = 1
+        todo[("citi_bike", spec.plan_defines(ts, MrxCbConfig(32768, 0, 0, 44000, 10, 16, 1, cap, 0), "citi_bike"))] = 1   # config 4 whole on one GPU
         del np, keep
         # ... and city.800s (the reference's own topology size): the bench line of profiles/ (4096 envs, two days) and the plan of
         # tests/test_gpu_citi_bike.py::test_city800_batch_matches_oracle_specialised (300 envs)
