@@ -453,7 +453,21 @@ def bench_citi_bike(args, dist, dev, rank, world):
     return out
 
 
-def build_cim_groups(topology, n, G, dev, rank=0, durations=1120, ring=4, specialize=True, step_mode=0, obs="fused", policy="random"):
+class _EnvCounts:
+    """The per-env answered-decision counters of the device agent (mrx_cim_set_device_agent) behind the two calls bench.py makes on a
+    group's counter: zero_() and item() (= the sum)."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def zero_(self):
+        self.t.zero_()
+
+    def item(self):
+        return int(self.t.sum().item())
+
+
+def build_cim_groups(topology, n, G, dev, rank=0, durations=1120, ring=4, specialize=True, step_mode=0, obs="fused", policy="random", agent="launch"):
     """The per-GPU configuration bench.py times: the batch split into G independent groups (engine + HIP stream each), fused
     observation, snapshot ring.  Shared with tests/test_gpu_bench_parity.py so that the parity test runs EXACTLY this setup."""
     import torch
@@ -485,6 +499,11 @@ def build_cim_groups(topology, n, G, dev, rank=0, durations=1120, ring=4, specia
         if obs == "fused" and policy != "dqn":
             # the same two slices, written by the step kernel itself (mrx_cim_set_observation) instead of two more launches
             bufs[-1]["obs"] = eng.set_observation(QUERY_ATTRS, VESSEL_QUERY_ATTRS)
+        if agent == "fused":
+            # the random legal agent answered inside the step kernel (mrx_cim_set_device_agent): no policy launch at all
+            bufs[-1]["counts"] = torch.zeros((ng,), dtype=torch.int32, device=dev)
+            bufs[-1]["counter"] = _EnvCounts(bufs[-1]["counts"])
+            eng.set_device_agent(bufs[-1]["actions"], bufs[-1]["n_actions"], bufs[-1]["counts"], next_key=1)
     for eng, st in zip(engines, streams):
         eng.use_stream(st)   # every engine call goes to its group's stream without a per-call stream switch
     return engines, streams, bufs, sizes, offs
@@ -968,6 +987,8 @@ def main():
     ap.add_argument("--reset-every", type=int, default=32, help="--collect: envs whose episode ended are finalised / reset every this many steps")
     ap.add_argument("--obs", default="fused", choices=["fused", "query"],
                     help="how the per-step ports / deciding-vessel snapshot slices are produced: fused into the step kernel, or by mrx_cim_query")
+    ap.add_argument("--agent", default="launch", choices=["fused", "launch"], help="cim, random agent: a mrx_cim_random_policy launch before every step (default), or answered inside "
+                    "the step kernel (mrx_cim_set_device_agent: one launch per batch step — measured 3-5 %% slower, profiles/r06_experiments.md)")
     ap.add_argument("--graphs", type=int, default=0, help="1: capture one step per group in a hipGraph and replay it (cim)")
     ap.add_argument("--groups", type=int, default=3, help="independent env groups per GPU, each on its own HIP stream (cim)")
     ap.add_argument("--step-mode", type=int, default=0, help="launch form of mrx_cim_step (mrx_cim_set_step_mode): 0 default (sorted), "
@@ -1086,8 +1107,12 @@ def bench_cim(args, dist, dev, rank, world):
     need_ticks = args.preroll_ticks + int(0.55 * (args.warmup + args.steps * max(1, args.repeats) + min(args.steps, 100) + 64)) + 64
     sim_durations = max(args.durations, need_ticks)
     obs_mode = "none" if args.no_query else args.obs
-    engines, streams, bufs, sizes, offs = build_cim_groups(args.topology, n, G, dev, rank, sim_durations, args.ring, args.specialize, args.step_mode,
-                                                           obs_mode, args.policy)
+    # --agent fused: the random legal agent answered inside the step kernel (one launch per batch step and group); no policy launch
+    # carries the sorted launch's order list then, so the step takes the unsorted form
+    agent = "fused" if (args.agent == "fused" and args.policy == "random" and not args.graphs) else "launch"
+    step_mode = 1 if (agent == "fused" and args.step_mode == 0) else args.step_mode
+    engines, streams, bufs, sizes, offs = build_cim_groups(args.topology, n, G, dev, rank, sim_durations, args.ring, args.specialize, step_mode,
+                                                           obs_mode, args.policy, agent)
     topo = engines[0].topo
     ports = torch.arange(topo.n_ports, dtype=torch.int32, device=dev)
     qnet = None
@@ -1124,7 +1149,17 @@ def bench_cim(args, dist, dev, rank, world):
     def one_step(i, g, timing=None, count=True):
         eng, b, st = engines[g], bufs[g], streams[g]
         if i == 0:
+            if agent == "fused":   # (the agent's key restarts with the episode: the first answered decision is keyed 1)
+                eng.set_device_agent(b["actions"], b["n_actions"], b["counts"], next_key=1)
             eng.step()  # first step of the episode: action=None
+            return
+        if agent == "fused":
+            if timing is not None:
+                timing[2].record(st)
+                timing[0].record(st)
+            eng.step(b["actions"], b["n_actions"])   # answers the decisions it raises: the next step's actions are in place
+            if timing is not None:
+                timing[1].record(st)
             return
         if graphs[g] is not None and timing is None:
             with torch.cuda.stream(st):
@@ -1311,7 +1346,7 @@ def bench_cim(args, dist, dev, rank, world):
             del engines[:]
             torch.cuda.empty_cache()
             ep_engines, streams, bufs, sizes, offs = build_cim_groups(args.topology, n, G, dev, rank, args.durations, args.ring, args.specialize,
-                                                                      args.step_mode, obs_mode, args.policy)
+                                                                      step_mode, obs_mode, args.policy, agent)
             engines.extend(ep_engines)
         for b in bufs:
             b["counter"].zero_()
@@ -1497,7 +1532,7 @@ def bench_cim(args, dist, dev, rank, world):
                       "what": "each rank's env-steps and wall time of the median window: value = sum(env_steps) / max(seconds)"},
             "config": {"workload": f"CIM {args.topology}, {n} envs/GPU x {world} GPU, durations {sim_durations}, "
                                    f"{'random legal agent' if args.policy == 'random' else 'per-port dueling DQN (f32 MFMA, greedy) + CIMEnvSampler state shaping (mrx_cim_dqn_act)'} on device, ports + deciding-vessel snapshot slices {'off' if args.no_query else 'every step (' + args.obs + ')'}",
-                       "envs_per_gpu": n, "groups_per_gpu": G, "step_mode": engines[0].step_mode, "specialized_kernels": bool(engines[0].specialized), "code_object_key": code_key, "code_object_sha16": getattr(engines[0], "code_object_sha16", None), "hip_graphs": bool(args.graphs), "envs_per_launch": ng, "ring_slots": args.ring,
+                       "envs_per_gpu": n, "groups_per_gpu": G, "step_mode": engines[0].step_mode, "specialized_kernels": bool(engines[0].specialized), "code_object_key": code_key, "code_object_sha16": getattr(engines[0], "code_object_sha16", None), "hip_graphs": bool(args.graphs), "agent": ("random legal agent answered inside the step kernel (mrx_cim_set_device_agent): one launch per batch step and group" if agent == "fused" else "mrx_cim_random_policy launch before every step"), "envs_per_launch": ng, "ring_slots": args.ring,
                        "parallelism": f"env-shard x{world} (no data-path collective); {G} independent groups per GPU on separate HIP streams",
                        "order_table": bool(engines[0].layout.order_table_on), "reset_ms_whole_batch": reset_ms, "host_enqueue_ms_per_step": t_issued / args.steps * 1e3,
                        "trajectory_gather_ms_32_steps": gather_ms, "trajectory_gather_bytes_per_rank": gather_bytes, "trajectory_gather_every": gather_every,

@@ -301,6 +301,16 @@ int mrx_cim_query(mrx_handle h, int node_type, const int32_t* d_ticks, int nt, i
  */
 int mrx_cim_random_policy(mrx_handle h, const int32_t* d_decisions, int64_t step, int32_t* d_actions,
                           int32_t* d_n_actions, uint64_t* d_counter, void* stream);
+/*
+ * The same agent ANSWERED INSIDE mrx_cim_step (Sequential mode): with mode 1 every step writes, for each env it leaves at a new
+ * decision, the action mrx_cim_random_policy(step = key) would write for that decision into d_actions[e][0] / d_n_actions[e]
+ * (0 for an env whose episode is over) and adds 1 to d_counts[e] (int32 [n_envs], may be NULL) — so a rollout with this agent is ONE
+ * launch per batch step: pass the same d_actions / d_n_actions to the next mrx_cim_step.  `next_key` >= 0: the key of the first
+ * answering step; every mrx_cim_step call that follows uses the next integer (call it again after a reset to restart the count);
+ * < 0: every draw is keyed on its decision's (tick, vessel), as mrx_cim_random_policy(step < 0).  mode 0 switches it off.  Runtime
+ * configuration (not part of a specialised plan); the buffers must stay valid while it is on.
+ */
+int mrx_cim_set_device_agent(mrx_handle h, int mode, int32_t* d_actions, int32_t* d_n_actions, int32_t* d_counts, int64_t next_key);
 
 /*
  * Plan-specialised step kernels.  The generic kernels read the plan's ~65 integer dimensions / layout offsets from the kernel

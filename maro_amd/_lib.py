@@ -55,7 +55,7 @@ class MrxCimSamplerCache(ctypes.Structure):
 
 EXPORTS = ("mrx_last_error", "mrx_version", "mrx_cim_workspace_bytes", "mrx_cim_create", "mrx_cim_destroy",
            "mrx_cim_get_layout", "mrx_cim_reset", "mrx_cim_step", "mrx_cim_step_joint", "mrx_cim_query", "mrx_cim_attr_id",
-           "mrx_cim_attr_slots", "mrx_cim_random_policy", "mrx_cim_set_observation", "mrx_cim_set_step_mode", "mrx_cim_set_port_history", "mrx_cim_dqn_net_floats",
+           "mrx_cim_attr_slots", "mrx_cim_random_policy", "mrx_cim_set_device_agent", "mrx_cim_set_observation", "mrx_cim_set_step_mode", "mrx_cim_set_port_history", "mrx_cim_dqn_net_floats",
            "mrx_cim_dqn_pack_net", "mrx_cim_dqn_scratch_bytes", "mrx_cim_dqn_act", "mrx_cim_sampler_record", "mrx_cim_sampler_emit", "mrx_cim_collect_steps", "mrx_cim_sampler_finalize", "mrx_cim_sampler_emit_all", "mrx_cim_plan_defines", "mrx_cim_load_step_kernels", "mrx_cim_read_kernel_global",
            # include/maro_amd_citi_bike.h
            "mrx_cb_workspace_bytes", "mrx_cb_create", "mrx_cb_destroy", "mrx_cb_get_layout", "mrx_cb_reset", "mrx_cb_step",
@@ -103,6 +103,8 @@ def load() -> ctypes.CDLL:
     L.mrx_cim_query.argtypes = [vp, i32, vp, i32, i32, vp, i32, i32, vp, i32, vp, vp]
     L.mrx_cim_random_policy.restype = i32
     L.mrx_cim_random_policy.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    L.mrx_cim_set_device_agent.restype = i32
+    L.mrx_cim_set_device_agent.argtypes = [vp, i32, vp, vp, vp, i64]
     L.mrx_cim_set_observation.restype = i32
     L.mrx_cim_set_observation.argtypes = [vp, vp, i32, vp, i32, vp, vp]
     L.mrx_cim_set_port_history.restype = i32

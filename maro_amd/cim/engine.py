@@ -208,6 +208,21 @@ class CimBatchEngine:
                                                  n_actions.data_ptr(), self._p(counter), self._stream()),
                    "mrx_cim_random_policy")
 
+    def set_device_agent(self, actions: Optional[torch.Tensor] = None, n_actions: Optional[torch.Tensor] = None,
+                         counts: Optional[torch.Tensor] = None, next_key: int = -1) -> None:
+        """mrx_cim_set_device_agent: the random legal agent answered INSIDE step() — every step writes the action
+        ``random_policy(next_key, ...)`` would write for the decision it has just raised into `actions` / `n_actions` (the tensors
+        the next ``step(actions, n_actions)`` is given) and adds 1 to `counts[e]` (int32 [n_envs]).  `next_key` >= 0 counts up
+        with every step() call that follows (set it again after a reset); < 0: keyed on the decision's (tick, vessel).
+        ``set_device_agent()`` switches it off.  The tensors must outlive the setting."""
+        on = actions is not None
+        if on:
+            assert actions.dtype == torch.int32 and n_actions.dtype == torch.int32 and actions.numel() == self.n_envs * self.max_actions * 4
+            assert counts is None or (counts.dtype == torch.int32 and counts.numel() == self.n_envs)
+        _lib.check(self._L.mrx_cim_set_device_agent(self._h, 1 if on else 0, self._p(actions), self._p(n_actions), self._p(counts), int(next_key)),
+                   "mrx_cim_set_device_agent")
+        self._agent_keep = (actions, n_actions, counts)
+
     def set_observation(self, port_attrs: Sequence[str] = (), vessel_attrs: Sequence[str] = ()):
         """Fuse an agent's per-decision snapshot slices into step(): returns (obs_ports float64 [n, P, len(port_attrs)],
         obs_vessel float64 [n, len(vessel_attrs)]), rewritten by every step() for the envs that pause at a new decision —

@@ -1973,6 +1973,29 @@ MRX_DEV void take_snapshot(const CimParams& K, const CimObs& O, int env, Lds& L,
 }
 
 // ==========================================================================================
+// DEVICE AGENT (CimObs::agent_*, mrx_cim_set_device_agent): the answer to the decision this step has raised, written by the wave /
+// lane that wrote the decision row.  Same rule and same draw as mrx_k_cim_random_policy (cim_engine.hip): h = mix(seed, key);
+// even and load > 0 -> LOAD h' % (load + 1), else DISCHARGE h' % (discharge + 1).
+MRX_DEV unsigned long long mix64(unsigned long long seed, unsigned long long step) {
+  unsigned long long x = seed * 0x9E3779B97F4A7C15ull + step * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+MRX_DEV void agent_answer(const CimParams& K, const CimObs& O, int env, long long seed, int t, int port, int vessel, int load, int dis) {
+  const unsigned long long key = O.agent_key >= 0 ? (unsigned long long)O.agent_key : (((unsigned long long)(unsigned)t << 8) | (unsigned)vessel) + 0x100000000ull;
+  const unsigned long long x = mix64((unsigned long long)seed, key), r = x >> 1;
+  int32_t* a = O.agent_actions + (size_t)env * KD(max_actions) * 4;
+  a[0] = vessel; a[1] = port;
+  if ((x & 1ull) == 0 && load > 0) { a[2] = (int)(r % (unsigned long long)(load + 1)); a[3] = 0; }   // MRX_ACTION_LOAD
+  else { a[2] = (int)(r % (unsigned long long)(dis + 1)); a[3] = 1; }                               // MRX_ACTION_DISCHARGE
+  O.agent_n_actions[env] = 1;
+  if (O.agent_count) wave::global_add_nr(&O.agent_count[env], 1);
+}
+MRX_DEV void agent_none(const CimObs& O, int env) { O.agent_n_actions[env] = 0; }   // no decision to answer (episode over)
+
+// ==========================================================================================
 // FAST PATH of a step that cannot advance time: another vessel of the current tick is still waiting for its
 // decision (2.2 vessels arrive per tick on global_trade.22p, so this is more than half of all env-steps).
 // Such a step touches a dozen words — the acting port / vessel, one plan cell, the next vessel.  It never stages
@@ -2022,10 +2045,11 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
   if (flags & FL_FINISHED) {  // reference: (None, None, True) once the generator is exhausted (core.py:128-133)
     if (lane < 8) dec_out[lane] = lane == 7 ? -1 : 0;
     if (lane < 3) met_out[lane] = 0;
-    if (lane == 0) *done_out = 1;
+    if (lane == 0) { *done_out = 1; if (O.agent_mode) agent_none(O, env); }
     return true;
   }
   if ((flags & FL_FRESH) || MRX_UNALIGNED_FRAMES) return false;
+  const long long agent_seed = O.agent_mode ? K.seed[env] : 0;   // (requested with the step's other loads, used at its end)
   const uint64_t pend = ((uint64_t)(uint32_t)wave::bcast(hdr, PH_PEND_HI) << 32) | (uint32_t)wave::bcast(hdr, PH_PEND_LO);
   const int cur = wave::bcast(hdr, PH_CUR_VESSEL);
   const uint64_t pend_after = pend & ~(1ull << (cur & 63));
@@ -2109,6 +2133,7 @@ MRX_DEV bool fast_step(const CimParams& K, const CimObs& O, int env, const FastR
     dec_out[3] = pe2 < rs2 ? pe2 : rs2;
     dec_out[4] = ve2; dec_out[5] = ed2;
     dec_out[6] = (t - KD(start_tick)) / KD(resolution); dec_out[7] = 1;
+    if (O.agent_mode) agent_answer(K, O, env, agent_seed, t, lp2, v2, pe2 < rs2 ? pe2 : rs2, ve2);
     met_out[0] = acc_b; met_out[1] = acc_s; met_out[2] = opnum;
     *done_out = 0;
     g_priv[PH_PEND_LO] = (int32_t)(uint32_t)(pend_after & 0xffffffffull);
@@ -2142,9 +2167,11 @@ MRX_DEV bool fast_step_lane(const CimParams& K, const CimObs& O, int env, const 
     for (int j = 0; j < 8; j++) dec_out[j] = j == 7 ? -1 : 0;
     for (int j = 0; j < 3; j++) met_out[j] = 0;
     *done_out = 1;
+    if (O.agent_mode) agent_none(O, env);
     return true;
   }
   if ((flags & FL_FRESH) || MRX_UNALIGNED_FRAMES) return false;
+  const long long agent_seed = O.agent_mode ? K.seed[env] : 0;
   const uint64_t pend = ((uint64_t)(uint32_t)h0.w << 32) | (uint32_t)h0.z;  // PH_PEND_HI, PH_PEND_LO
   const int cur = h1.x;                                                       // PH_CUR_VESSEL
   const uint64_t pend_after = pend & ~(1ull << (cur & 63));
@@ -2218,6 +2245,7 @@ MRX_DEV bool fast_step_lane(const CimParams& K, const CimObs& O, int env, const 
   dec_out[3] = pe2 < rs2 ? pe2 : rs2;
   dec_out[4] = ve2; dec_out[5] = ed2;
   dec_out[6] = (t - KD(start_tick)) / KD(resolution); dec_out[7] = 1;
+  if (O.agent_mode) agent_answer(K, O, env, agent_seed, t, lp2, v2, pe2 < rs2 ? pe2 : rs2, ve2);
   met_out[0] = acc_b; met_out[1] = acc_s; met_out[2] = opnum;
   *done_out = 0;
   g_priv[PH_PEND_LO] = (int32_t)(uint32_t)(pend_after & 0xffffffffull);
@@ -2610,14 +2638,18 @@ MRX_DEV StepEnd body_run(const CimParams& K, const CimObs& O, int env, Lds& L, c
 }
 
 template <bool OBS>
-MRX_DEV void body_emit(const CimParams& K, const CimObs& O, int env, const StepIO& io, const StepOut& out) {
+MRX_DEV void body_emit(const CimParams& K, const CimObs& O, int env, const StepIO& io, const StepOut& out, long long agent_seed) {
   const int lane = wave::lane();
   if (out.kind == 0) return;
   if (out.kind == 2) {  // the episode was over before this step: (None, None, True)
     if (lane < 8) io.dec_out[lane] = lane == 7 ? -1 : 0;
     if (lane < 3) io.met_out[lane] = 0;
-    if (lane == 0) *io.done_out = 1;
+    if (lane == 0) { *io.done_out = 1; if (O.agent_mode) agent_none(O, env); }
     return;
+  }
+  if (O.agent_mode && KD(decision_mode) == 0 && lane == 0) {   // the device agent answers the decision this step has raised
+    if (out.dec[7] == 1 && !out.done) agent_answer(K, O, env, agent_seed, out.dec[0], out.dec[1], out.dec[2], out.dec[3], out.dec[4]);
+    else agent_none(O, env);
   }
   if (KD(decision_mode) == 0) {
     if (lane == 0) {
@@ -2656,6 +2688,7 @@ MRX_DEV StepEnd full_body(const CimParams& K, const CimObs& O, int env, Lds& L, 
   c.a0v = a0v; c.a0p = a0p; c.a0q = a0q; c.a0t = a0t;
   c.n_act = io.n_act; c.n_answered = io.n_answered;
   StepEnd end = {false, false, false};
+  const long long agent_seed = O.agent_mode ? K.seed[env] : 0;   // (requested before the step's work, used by body_emit)
   if (body_open<PG>(K, env, L, c, out, Z)) {
     prof.mark(PF_LOAD);
     body_act(K, L, io.actions, c, Z);
@@ -2664,7 +2697,7 @@ MRX_DEV StepEnd full_body(const CimParams& K, const CimObs& O, int env, Lds& L, 
     prof.mark(PF_MT_LOAD);
     end = body_run<PG, OBS>(K, O, env, L, io, c, out, prof, rr, Z);
   }
-  body_emit<OBS>(K, O, env, io, out);
+  body_emit<OBS>(K, O, env, io, out, agent_seed);
   return end;
 }
 

@@ -330,6 +330,7 @@ struct mrx_cim_engine {
   int loop_waves = 0;                     // grid of the looped full-path kernel (generic or specialised build in use)
   int step_mode = 0;                      // mrx_cim_set_step_mode (0 = automatic)
   bool order_ready = false;               // the order list of the coming step was built by the policy launch (no mask)
+  long long agent_key = -1;               // mrx_cim_set_device_agent: the key of the next answering step (< 0: decision-keyed)
   int lpt = 1;                            // longest-first inside the full-path class of the sorted launch (MRX_CIM_LPT=0: off)
   void* order_stream = nullptr;           // ... on this stream: a step issued on another stream is not ordered behind that launch
   // Kernels of a module may still be queued or running on the caller's stream(s): drain the device before unloading it.
@@ -557,6 +558,10 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
   const bool obs = h->obs.np > 0 || h->obs.nv > 0;  // (the _obs kernels are only needed for the fused observation; the retention rows are written by every build)
   const int mode = effective_step_mode(h);
   cim::StepBatch B = {d_actions, d_n_actions, d_n_answered, d_decisions, (long long*)d_metrics, d_done};
+  if (h->obs.agent_mode) {   // the device agent's key of THIS step (the launches below copy h->obs)
+    h->obs.agent_key = h->agent_key;
+    if (h->agent_key >= 0) h->agent_key++;
+  }
   // built by mrx_cim_random_policy for exactly this step, on this very stream (a step issued on another stream has no ordering
   // against that launch: it rebuilds the list from the hints with its own schedule kernel)
   const bool have_order = h->order_ready && !d_env_mask && stream == h->order_stream;
@@ -627,6 +632,19 @@ static int launch_step(mrx_handle h, const int32_t* d_actions, const int32_t* d_
   return MRX_OK;
 }
 
+int mrx_cim_set_device_agent(mrx_handle h, int mode, int32_t* d_actions, int32_t* d_n_actions, int32_t* d_counts, int64_t next_key) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  if (mode != 0 && mode != 1) return set_err(MRX_ERR_INVALID_ARG, "device agent mode must be 0 (off) or 1 (random legal)");
+  if (mode && (!d_actions || !d_n_actions)) return set_err(MRX_ERR_INVALID_ARG, "null action buffers");
+  if (mode && h->plan.kp.decision_mode != 0) return set_err(MRX_ERR_UNSUPPORTED, "the device agent answers Sequential decisions only");
+  h->obs.agent_mode = mode;
+  h->obs.agent_actions = mode ? d_actions : nullptr;
+  h->obs.agent_n_actions = mode ? d_n_actions : nullptr;
+  h->obs.agent_count = mode ? d_counts : nullptr;
+  h->agent_key = next_key;
+  return MRX_OK;
+}
+
 int mrx_cim_set_step_mode(mrx_handle h, int mode) {
   if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
   if (mode < 0 || mode > 5) return set_err(MRX_ERR_INVALID_ARG, "step mode must be 0 (automatic), 1, 2, 4 or 5");
@@ -647,6 +665,7 @@ int mrx_cim_set_observation(mrx_handle h, const int32_t* port_attrs, int n_port_
   if (rc != MRX_OK) return rc;
   o.ports = d_obs_ports; o.vessel = d_obs_vessel;
   o.hist_n = h->obs.hist_n; o.hist_frames = h->obs.hist_frames; o.hist = h->obs.hist;  // (mrx_cim_set_port_history is independent of this call)
+  o.agent_mode = h->obs.agent_mode; o.agent_actions = h->obs.agent_actions; o.agent_n_actions = h->obs.agent_n_actions; o.agent_count = h->obs.agent_count;   // (so is mrx_cim_set_device_agent)
   for (int i = 0; i < 4; i++) o.hist_attr[i] = h->obs.hist_attr[i];
   if (h->spec_module && plan_defines(h->plan.kp, o) != plan_defines(h->plan.kp, h->obs)) {
     // the loaded specialised kernels have the previous observation configuration compiled in: back to the generic ones until

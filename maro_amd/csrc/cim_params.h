@@ -193,4 +193,12 @@ struct CimObs {
   int hist_n, hist_frames;
   int hist_attr[4];
   int32_t* hist;
+  // Device agent (mrx_cim_set_device_agent; runtime configuration): the step kernel ANSWERS the decision it has just raised —
+  // the random legal agent of mrx_cim_random_policy, same draw — into the action buffers the next mrx_cim_step reads, so a
+  // rollout with that agent is one launch per batch step.  agent_key >= 0: the draw is keyed on it (the step index the
+  // separate launch would be given); < 0: on the decision's own (tick, vessel).
+  int agent_mode;                 // 0 off, 1 random legal
+  long long agent_key;
+  int32_t *agent_actions, *agent_n_actions;   // [n_envs][max_actions][4], [n_envs]
+  int32_t* agent_count;           // [n_envs] decisions answered (added to), or null
 };

@@ -73,6 +73,7 @@ MRX_DEV void lds_add(int32_t* p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_
 MRX_DEV int global_add(int32_t* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // fire-and-forget OR into global memory (no return value, hence no s_waitcnt)
+MRX_DEV void global_add_nr(int32_t* p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // (result unused: no return path)
 MRX_DEV void global_or(int32_t* p, int v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // inclusive prefix sum over the lanes (lane i gets v_0 + ... + v_i): six DPP adds — shifts inside the rows of 16 lanes, then

@@ -40,15 +40,20 @@ def replay_against_oracle(engines, bufs, streams, sizes, offs, seed_base, topolo
                     rec[g]["op"][i // obs_every] = bufs[g]["obs"][0][idx[g]].reshape(len(picks[g]), -1)
                     rec[g]["ov"][i // obs_every] = bufs[g]["obs"][1][idx[g]]
 
+    # engines whose agent is answered inside the step kernel (mrx_cim_set_device_agent) are replayed in exactly that form
+    fused = [getattr(eng, "_agent_keep", (None,))[0] is not None for eng in engines]
     for g, eng in enumerate(engines):
         eng.reset(torch.arange(sizes[g], dtype=torch.int64) + seed_base + offs[g] + 1)
+        if fused[g]:
+            eng.set_device_agent(bufs[g]["actions"], bufs[g]["n_actions"], bufs[g].get("counts"), next_key=1)
         eng.step()
     record(0)
     i = 0
     while i < cap - 1:
         i += 1
         for g, eng in enumerate(engines):
-            eng.random_policy(i, bufs[g]["actions"], bufs[g]["n_actions"], None)
+            if not fused[g]:
+                eng.random_policy(i, bufs[g]["actions"], bufs[g]["n_actions"], None)
             eng.step(bufs[g]["actions"], bufs[g]["n_actions"])
         record(i)
         if i % 128 == 0:

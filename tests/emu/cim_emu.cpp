@@ -11,6 +11,7 @@ struct int4 { int x, y, z, w; };
 
 struct Emu {
   CimObs obs = {};
+  long long agent_key = -1;
   CimHostPlan plan;
   uint8_t* ws = nullptr;
   int32_t* lds = nullptr;
@@ -95,6 +96,10 @@ void emu_step(void* h, const int32_t* actions, const int32_t* n_actions, const u
   e->wave.reverse = reverse != 0;
   cim::StepBatch B = {actions, n_actions, n_answered, dec, (long long*)met, done};
   const bool obs = e->obs.np > 0 || e->obs.nv > 0;
+  if (e->obs.agent_mode) {   // as launch_step (cim_engine.hip): the device agent's key of this step
+    e->obs.agent_key = e->agent_key;
+    if (e->agent_key >= 0) e->agent_key++;
+  }
   if (mode >= 2) emu_schedule(e, mask);
   if (mode == 4) {  // split step: lane-parallel fast kernel (64 envs per wave, no LDS), then the looped full-path kernel
     for (int b0 = 0; b0 < K.n_envs; b0 += 64)
@@ -143,6 +148,7 @@ void emu_set_observation(void* h, const int32_t* pa, int np, const int32_t* va, 
   Emu* e = (Emu*)h;
   const CimObs keep = e->obs;
   memset(&e->obs, 0, sizeof(e->obs));
+  e->obs.agent_mode = keep.agent_mode; e->obs.agent_actions = keep.agent_actions; e->obs.agent_n_actions = keep.agent_n_actions; e->obs.agent_count = keep.agent_count;
   e->obs.hist_n = keep.hist_n; e->obs.hist_frames = keep.hist_frames; e->obs.hist = keep.hist;
   for (int i = 0; i < 4; i++) e->obs.hist_attr[i] = keep.hist_attr[i];
   for (int i = 0; i < np; i++) e->obs.pa[i] = pa[i];
@@ -155,6 +161,13 @@ void emu_set_observation(void* h, const int32_t* pa, int np, const int32_t* va, 
     if (pa[i] == PA_EMPTY) e->obs.i_empty = i;
     if (pa[i] == PA_TRANSFER_COST) e->obs.i_tc = i;
   }
+}
+
+void emu_set_device_agent(void* h, int mode, int32_t* actions, int32_t* n_actions, int32_t* counts, long long next_key) {
+  Emu* e = (Emu*)h;
+  e->obs.agent_mode = mode; e->obs.agent_actions = mode ? actions : nullptr; e->obs.agent_n_actions = mode ? n_actions : nullptr;
+  e->obs.agent_count = mode ? counts : nullptr;
+  e->agent_key = next_key;
 }
 
 void emu_set_port_history(void* h, const int32_t* attrs, int n, int32_t* hist, int frames) {

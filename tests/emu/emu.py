@@ -91,6 +91,7 @@ def _declare(L):
         L.emu_step.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.emu_query.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.emu_set_device_agent.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong]
         L.emu_set_port_history.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.emu_set_observation.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                           ctypes.c_void_p]
@@ -158,6 +159,13 @@ class EmuBackend:
         self._L.emu_step(self._h, _ptr(a), _ptr(na), _ptr(mk), _ptr(self._dec), _ptr(self._met), _ptr(self._done),
                        int(self.reverse), _ptr(nans), int(self.step_mode), int(self.pipe_waves))
         return self._dec.copy(), self._met.copy(), self._done.copy()
+
+    def set_device_agent(self, actions=None, n_actions=None, counts=None, next_key=-1):
+        """mrx_cim_set_device_agent: `actions` int32 [n, max_actions, 4] / `n_actions` int32 [n] / `counts` int32 [n] are written IN
+        PLACE by every step (numpy arrays the caller keeps and passes to the next step)."""
+        on = actions is not None
+        self._agent_keep = (actions, n_actions, counts)
+        self._L.emu_set_device_agent(self._h, 1 if on else 0, _ptr(actions), _ptr(n_actions), _ptr(counts), int(next_key))
 
     def set_observation(self, port_attr_ids, vessel_attr_ids):
         """Fused observation (mrx_cim_set_observation): returns (obs_ports [n, P, np], obs_vessel [n, nv]) written by step()."""

@@ -120,6 +120,7 @@ inline int readlane(int v, int src) { return shfl(v, src); }
 inline int bcast(int v, int src) { return shfl(v, src); }
 inline void global_or(int32_t* p, int v) { *p |= v; }
 inline int global_add(int32_t* p, int v) { const int o = *p; *p += v; return o; }
+inline void global_add_nr(int32_t* p, int v) { *p += v; }
 
 inline long long reduce_add(long long v) {
   rendezvous(5, v);
