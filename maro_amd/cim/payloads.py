@@ -52,6 +52,12 @@ except Exception:  # maro is not installed (e.g. the GPU box)
         """cim/common.py:72-150 (same constructor: scope / early discharge are callables evaluated lazily)."""
 
         summary_key = ["tick", "port_idx", "vessel_idx", "snapshot_list", "action_scope", "early_discharge"]
+        # (class-level defaults: an event made from an engine row — _from_row, maro_amd/csrc_host/fastobj.c — carries six instance
+        #  attributes instead of nine)
+        _action_scope = None
+        _action_scope_func = None
+        _early_discharge_func = None
+        _scope = None
 
         def __init__(self, tick, port_idx, vessel_idx, snapshot_list, action_scope_func, early_discharge_func):
             self.tick = tick
@@ -68,8 +74,8 @@ except Exception:  # maro is not installed (e.g. the GPU box)
             """The engine's decision row -> event without the two closures of the reference's constructor form (one dict literal;
             the ActionScope object is made when it is read).  Same attributes, same pickled state."""
             ev = cls.__new__(cls)
-            ev.__dict__ = {"tick": tick, "port_idx": port_idx, "vessel_idx": vessel_idx, "snapshot_list": snapshot_list, "_action_scope": None,
-                           "_early_discharge": early, "_action_scope_func": None, "_early_discharge_func": None, "_scope": (load, discharge)}
+            ev.__dict__ = {"tick": tick, "port_idx": port_idx, "vessel_idx": vessel_idx, "snapshot_list": snapshot_list, "_early_discharge": early,
+                           "_scope": (load, discharge)}
             return ev
 
         @property

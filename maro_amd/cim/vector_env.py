@@ -16,7 +16,12 @@ import numpy as np
 import torch
 
 from .engine import NODE_ATTRS, SEED_KEEP, SEED_REDRAW, CimBatchEngine
-from .payloads import _ACTION_CODE, HAVE_MARO, DecisionEvent, action_code, encode_action, make_decision_event
+from .payloads import _ACTION_CODE, HAVE_MARO, ActionType, DecisionEvent, action_code, encode_action, make_decision_event
+
+try:   # the per-env object loops of a whole-batch step in C (maro_amd/csrc_host/fastobj.c, built by __graft_entry__.build()); optional
+    from .. import _fastobj as _FO
+except ImportError:   # not built: the comprehensions below do the same work
+    _FO = None
 
 
 class InvalidActionError(AssertionError):
@@ -235,7 +240,15 @@ class GpuVectorEnv:
         acts = np.zeros((n, A, self.ACTION_WIDTH), np.int32)
         nact = np.zeros(n, np.int32)
         if action is not None:
-            if isinstance(action, list):
+            if isinstance(action, list) and _FO is not None:
+                multi = _FO.encode_actions(action, fin_before.view(np.uint8), acts, nact, A, ActionType.LOAD, ActionType.DISCHARGE)
+                for e, a in multi:
+                    if len(a) > A:
+                        raise ValueError(f"{len(a)} actions for one decision event; engine was built with max_actions={A}")
+                    for i, x in enumerate(a):
+                        acts[e, i] = self._encode_action(x)
+                    nact[e] = len(a)
+            elif isinstance(action, list):
                 rows, idx, multi = self._encode_rows(action, fin_before.tolist())
                 for e, a in multi:
                     if len(a) > A:
@@ -267,14 +280,17 @@ class GpuVectorEnv:
             self._paused = np.where(live, ~done, self._paused)
             self._finished |= live & done
             k0, k1, k2 = self.METRIC_KEYS
-            met_l, done_l, live_l = met.tolist(), done.tolist(), live.tolist()
+            met_l, live_l = (None, None) if _FO is not None else (met.tolist(), live.tolist())
             # tens of thousands of small acyclic objects at once: with the cyclic collector on, every 700th allocation walks
             # the young generation (measured: 3.5 x the construction time at 16384 envs), so it is paused for the build
             gc_was_on = gc.isenabled()
             gc.disable()
             try:
-                metrics = [{k0: m[0], k1: m[1], k2: m[2]} if lv else None for m, lv in zip(met_l, live_l)]
-                events = self._make_events(dec, extra, [lv and not d for lv, d in zip(live_l, done_l)])
+                if _FO is not None:
+                    metrics = _FO.build_metrics(np.ascontiguousarray(met, np.int64), live.view(np.uint8), k0, k1, k2)
+                else:
+                    metrics = [{k0: m[0], k1: m[1], k2: m[2]} if lv else None for m, lv in zip(met_l, live_l)]
+                events = self._make_events(dec, extra, live & ~done)
             finally:
                 if gc_was_on:
                     gc.enable()
@@ -296,11 +312,15 @@ class GpuVectorEnv:
         return sl
 
     def _make_events(self, dec, extra, want) -> list:
-        """DecisionEvents of the envs flagged in `want` (a list of bools) from the step's decision rows."""
-        rows = dec[:, :6].tolist()
+        """DecisionEvents of the envs flagged in `want` (bool array [n]) from the step's decision rows."""
         snaps = self._env_snapshots
         if None in snaps:
             snaps = self._env_snapshots = [sl if sl is not None else _SnapshotList(self, [e]) for e, sl in enumerate(snaps)]
+        if _FO is not None and not HAVE_MARO:
+            d32 = np.ascontiguousarray(dec, np.int32)
+            return _FO.build_events(DecisionEvent, d32, int(d32.shape[1]), np.ascontiguousarray(want).view(np.uint8), snaps)
+        rows = dec[:, :6].tolist()
+        want = want.tolist()
         if HAVE_MARO:
             return [make_decision_event(r, sl) if w else None for r, sl, w in zip(rows, snaps, want)]
         # (DecisionEvent._from_row spelled out in the loop: one object + one dict literal per event, no call)
@@ -309,8 +329,7 @@ class GpuVectorEnv:
         for r, sl, w in zip(rows, snaps, want):
             if w:
                 ev = new(cls)
-                ev.__dict__ = {"tick": r[0], "port_idx": r[1], "vessel_idx": r[2], "snapshot_list": sl, "_action_scope": None, "_early_discharge": r[5],
-                               "_action_scope_func": None, "_early_discharge_func": None, "_scope": (r[3], r[4])}
+                ev.__dict__ = {"tick": r[0], "port_idx": r[1], "vessel_idx": r[2], "snapshot_list": sl, "_early_discharge": r[5], "_scope": (r[3], r[4])}
                 app(ev)
             else:
                 app(None)

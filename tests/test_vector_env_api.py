@@ -331,3 +331,49 @@ def check_whole_batch_step_equals_the_per_env_path(engine_factory):
 
 def test_whole_batch_step_equals_the_per_env_path_on_emulator():
     check_whole_batch_step_equals_the_per_env_path(emu_factory)
+
+
+def test_c_object_builders_equal_the_python_comprehensions(monkeypatch):
+    """maro_amd/_fastobj.so (csrc_host/fastobj.c: actions encoded, DecisionEvents and metrics dicts built in C) and the pure-Python
+    form of the whole-batch step give the same lists; events pickle and print like the reference's; foreign action enums and
+    numpy integers are accepted by the C encoder as by the Python one."""
+    import enum
+
+    from maro_amd.cim import vector_env as ve
+    if ve._FO is None:
+        pytest.skip("maro_amd/_fastobj.so not built")
+    n = 4
+    a, b = make_env(n, emu_factory, durations=40), make_env(n, emu_factory, durations=40)
+    ra = a.step(None)
+    monkeypatch.setattr(ve, "_FO", None)
+    rb = b.step(None)
+    monkeypatch.undo()
+
+    class Foreign(enum.Enum):
+        LOAD = "l"
+        DISCHARGE = "d"
+
+    k = 0
+    while not ra[2]:
+        assert ra[0] == rb[0] and ra[2] == rb[2]
+        for x, y in zip(ra[1], rb[1]):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert repr(x) == repr(y) and vars(pickle.loads(pickle.dumps(x))) == vars(pickle.loads(pickle.dumps(y)))
+                assert (x.tick, x.port_idx, x.vessel_idx, x.early_discharge) == (y.tick, y.port_idx, y.vessel_idx, y.early_discharge)
+        acts = []
+        for e, ev in enumerate(ra[1]):
+            if ev is None or (e + k) % 4 == 0:
+                acts.append(None)
+            elif (e + k) % 4 == 1:
+                acts.append(Action(np.int64(ev.vessel_idx), np.int32(ev.port_idx), np.int64(ev.action_scope.load // 2), Foreign.LOAD))
+            elif (e + k) % 4 == 2:
+                acts.append([Action(ev.vessel_idx, ev.port_idx, ev.action_scope.discharge // 3, ActionType.DISCHARGE)])
+            else:
+                acts.append(Action(ev.vessel_idx, ev.port_idx, 0, ActionType.LOAD))
+        ra = a.step(acts)
+        monkeypatch.setattr(ve, "_FO", None)
+        rb = b.step(list(acts))
+        monkeypatch.undo()
+        k += 1
+    assert k > 8 and ra[0] == rb[0]

@@ -22,7 +22,7 @@ def one(name, d):
 
 def main():
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    one("headline", d)
+    one("headline", d) if "metric" in d else one("line", d)
     for k, v in (d.get("secondary") or {}).items():
         one("secondary." + k, v)
     print("gpu_seconds_total", d.get("gpu_seconds_total"))
