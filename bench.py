@@ -1016,7 +1016,7 @@ def main():
     ap.add_argument("--no-episode", action="store_true", help="skip the end-to-end leg (reset + one full episode of the whole batch)")
     ap.add_argument("--sustained-episodes", type=int, default=6, help="sustained leg (after the end-to-end leg): whole episodes per group run back to back, "
                     "resets overlapped with the other groups' steps (0: skip)")
-    ap.add_argument("--episode-block", type=int, default=256, help="end-to-end leg: batch steps enqueued between two 'is every env done' read-backs")
+    ap.add_argument("--episode-block", type=int, default=32, help="(kept for old command lines; the end-to-end leg polls every group every 32 batch steps without a device-wide sync)")
     ap.add_argument("--parity-envs", type=int, default=64, help="envs replayed on the CPU oracle after the run (0: off)")
     ap.add_argument("--repeats", type=int, default=5, help="the timed window (exactly --steps steps between barrier + synchronize) is run this many "
                     "times back to back; `value` is the median window, value_min / value_max the spread")
@@ -1368,15 +1368,33 @@ def bench_cim(args, dist, dev, rank, world):
         for g, eng in enumerate(engines):
             eng.reset(group_seeds(g))
         ep_reset_ms = None
-        k = 0
-        while True:
-            for _ in range(args.episode_block):
-                for g in range(G):
-                    one_step(k, g)
-                k += 1
-            torch.cuda.synchronize(dev)
-            if all(bool(e.done.all().item()) for e in engines) or k > 8 * args.durations:
-                break
+        # no device-wide synchronisation inside the episode: every group steps in blocks of 32 and polls its own done flag through a
+        # pinned word and an event (the flag of block j is read after block j + 1 was enqueued); a group stops as soon as its envs are
+        # through, the leg ends when every group has
+        blk, k = 32, 0
+        e_flags = [torch.zeros(2, dtype=torch.uint8).pin_memory() for _ in range(G)]
+        e_evs = [[torch.cuda.Event(), torch.cuda.Event()] for _ in range(G)]
+        e_pending, e_done, e_k = [None] * G, [False] * G, [0] * G
+        slot = 0
+        while not all(e_done) and k <= 8 * args.durations:
+            for g in range(G):
+                if e_done[g]:
+                    continue
+                for _ in range(blk):
+                    one_step(e_k[g], g)
+                    e_k[g] += 1
+                if e_pending[g] is not None:
+                    e_evs[g][e_pending[g]].synchronize()
+                    if e_flags[g][e_pending[g]].item():
+                        e_done[g] = True
+                        continue
+                with torch.cuda.stream(streams[g]):
+                    e_flags[g][slot].copy_(engines[g].done.min().to(torch.uint8), non_blocking=True)
+                    e_evs[g][slot].record(streams[g])
+                e_pending[g] = slot
+            slot ^= 1
+            k += blk
+        k = max(e_k)
         sync_all()
         t_ep = time.perf_counter() - t_e
         ep_steps = sum(int(b["counter"].item()) for b in bufs)

@@ -69,9 +69,18 @@ def test_bench_default_line_carries_configs_4_and_5():
         assert fr is None or 0 < fr < 1
     assert c5["parity"]["elements_checked"] > 500 and c5["parity"]["rewards_checked"] > 0 and c5["parity"]["policy_choices_checked"] > 100
     assert c5["roofline_policy"]["bound"] == "mfma" and 0 < c5["roofline_policy"]["frac"] < 1
+    # round 6: end to end and sustained on the headline (also under config), config 4 whole on one GPU, the object-API leg
+    assert j["value_end_to_end"] > 0 and j["value_sustained"] > 0 and j["config"]["value_sustained"] == j["value_sustained"]
+    assert j["sustained"]["resets"] >= 6 and j["sustained"]["seconds"] > 0.5
+    w4 = sec["citi_bike_config4_one_gpu"]
+    assert w4["config"]["envs_per_gpu"] == 32768 and w4["parity"]["ok"] is True and w4["value"] > c4["value"]
+    obj = sec["object_api"]
+    assert obj["parity"]["ok"] is True and obj["value"] > 5e4 and obj["value_default_gc"]["value"] > 0 and obj["env_view"]["value"] > 100, obj
     ref = j.get("cpu_baseline_reference")
     if os.path.exists(os.path.join(REPO, "oracle", "_ref", "maro_ref.tgz")):     # the shipped reference build: timed live on this box
         assert ref["kind"] == "reference" and ref["measured"].startswith("live") and ref["vector_env"]["value"] > 0, ref
+        assert c4["cpu_baseline"]["kind"] == "reference" and c4["cpu_baseline"]["measured"].startswith("live"), c4["cpu_baseline"]   # the reference's citi_bike Env
+        assert obj["cpu_baseline"]["kind"] == "reference"
 
 
 @pytest.mark.parametrize("scenario,world", [("cim", 2), ("citi_bike", 4), ("cim", 8), ("citi_bike", 8)])
