@@ -21,7 +21,7 @@ def run_bench(*extra):
 
 
 @pytest.mark.parametrize("extra", [("--envs", "192", "--cpu-seconds", "2"), ("--scenario", "citi_bike", "--envs", "128", "--no-cpu"),
-                                   ("--envs", "192", "--policy", "dqn", "--no-cpu")])
+                                   ("--envs", "192", "--policy", "dqn", "--no-cpu"), ("--envs", "192", "--agent", "fused", "--no-cpu")])
 def test_bench_line_contract(extra):
     j = run_bench(*extra)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -40,6 +40,8 @@ def test_bench_line_contract(extra):
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == j["unit"] and "sample" in c
     if "dqn" in extra:
         assert j["roofline_policy"]["bound"] == "mfma" and j["roofline_policy"]["unit"] == "TFLOP/s"
+    if "fused" in extra:   # the agent answered inside the step kernel: one launch per step, the unsorted form, the same parity replay
+        assert "inside the step kernel" in j["config"]["agent"] and j["config"]["step_mode"] == 1
     if extra[:2] == ("--envs", "192") and "dqn" not in extra:   # the CIM headline line: end-to-end leg + oracle parity replay
         assert j["value_end_to_end"] > 0 and j["end_to_end"]["env_steps"] > 0 and j["end_to_end"]["reset_ms_synchronised"] > 0
         assert j["parity"]["ok"] is True and j["parity"]["envs_checked"] >= 60 and j["parity"]["env_steps_checked"] > 1000
