@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from .engine import NODE_ATTRS, SEED_KEEP, SEED_REDRAW, CimBatchEngine
-from .payloads import _ACTION_CODE, HAVE_MARO, ActionType, DecisionEvent, action_code, encode_action, make_decision_event
+from .payloads import _ACTION_CODE, HAVE_MARO, ActionScope, ActionType, DecisionEvent, action_code, encode_action, make_decision_event
 
 try:   # the per-env object loops of a whole-batch step in C (maro_amd/csrc_host/fastobj.c, built by __graft_entry__.build()); optional
     from .. import _fastobj as _FO
@@ -318,7 +318,7 @@ class GpuVectorEnv:
             snaps = self._env_snapshots = [sl if sl is not None else _SnapshotList(self, [e]) for e, sl in enumerate(snaps)]
         if _FO is not None and not HAVE_MARO:
             d32 = np.ascontiguousarray(dec, np.int32)
-            return _FO.build_events(DecisionEvent, d32, int(d32.shape[1]), np.ascontiguousarray(want).view(np.uint8), snaps)
+            return _FO.build_events(DecisionEvent, d32, int(d32.shape[1]), np.ascontiguousarray(want).view(np.uint8), snaps, ActionScope)
         rows = dec[:, :6].tolist()
         want = want.tolist()
         if HAVE_MARO:

@@ -7,7 +7,7 @@
  * logic — maro_amd/cim/vector_env.py falls back to its own comprehensions when this module is not built.
  *
  *   encode_actions(actions, skip, out_acts, out_nact, A, load_obj, discharge_obj) -> list of (env, entry) the caller must encode itself
- *   build_events(cls, rows, want, snaps)                                          -> list of DecisionEvent | None
+ *   build_events(cls, rows, stride, want, snaps, scope_cls)                       -> list of DecisionEvent | None (action scope objects included)
  *   build_metrics(met, live, k0, k1, k2)                                          -> list of dict | None
  */
 #define PY_SSIZE_T_CLEAN
@@ -15,7 +15,7 @@
 #include <stdint.h>
 
 static PyObject *s_vessel_idx, *s_port_idx, *s_quantity, *s_action_type, *s_name;
-static PyObject *k_tick, *k_port, *k_vessel, *k_snap, *k_scope_obj, *k_early, *k_scope_fn, *k_early_fn, *k_scope;
+static PyObject *k_tick, *k_port, *k_vessel, *k_snap, *k_scope_obj, *k_early, *k_scope_fn, *k_early_fn, *k_scope, *k_load, *k_discharge;
 
 static int as_long(PyObject* o, long* out) {
   long v = PyLong_AsLong(o);
@@ -101,14 +101,15 @@ fail:
 
 /* rows: int32 [n][stride] C-contiguous (tick, port, vessel, load, discharge, early, ...); want: uint8 [n]; snaps: list of n objects */
 static PyObject* build_events(PyObject* self, PyObject* args) {
-  PyObject *cls, *snaps;
+  PyObject *cls, *snaps, *scope_cls;
   Py_buffer rows, want;
   int stride;
-  if (!PyArg_ParseTuple(args, "Oy*iy*O", &cls, &rows, &stride, &want, &snaps)) return NULL;
+  if (!PyArg_ParseTuple(args, "Oy*iy*OO", &cls, &rows, &stride, &want, &snaps, &scope_cls)) return NULL;
   PyObject* out = NULL;
-  if (!PyType_Check(cls) || !PyList_Check(snaps)) { PyErr_SetString(PyExc_TypeError, "build_events(cls, rows, stride, want, snaps)"); goto fail; }
+  if (!PyType_Check(cls) || !PyList_Check(snaps) || !PyType_Check(scope_cls)) { PyErr_SetString(PyExc_TypeError, "build_events(cls, rows, stride, want, snaps, scope_cls)"); goto fail; }
   {
     PyTypeObject* tp = (PyTypeObject*)cls;
+    PyTypeObject* stp = (PyTypeObject*)scope_cls;
     const Py_ssize_t n = PyList_GET_SIZE(snaps);
     if ((Py_ssize_t)want.len < n || (Py_ssize_t)rows.len < n * stride * 4 || stride < 6) { PyErr_SetString(PyExc_ValueError, "build_events: buffers smaller than the batch"); goto fail; }
     const int32_t* r = (const int32_t*)rows.buf;
@@ -127,11 +128,22 @@ static PyObject* build_events(PyObject* self, PyObject* args) {
       Py_XSETREF(*dp, d);
       PyObject *t = PyLong_FromLong(r[0]), *p = PyLong_FromLong(r[1]), *v = PyLong_FromLong(r[2]), *ed = PyLong_FromLong(r[5]);
       PyObject *ld = PyLong_FromLong(r[3]), *dc = PyLong_FromLong(r[4]);
-      PyObject* sc = (ld && dc) ? PyTuple_Pack(2, ld, dc) : NULL;
-      int bad = !t || !p || !v || !ed || !sc;
+      /* the ActionScope(load, discharge) object itself (cim/common.py:56-69: two plain attributes), so that reading event.action_scope
+         costs the agent an attribute lookup instead of a Python-level constructor call */
+      PyObject* sc = stp->tp_alloc(stp, 0);
+      int bad = !t || !p || !v || !ed || !ld || !dc || !sc;
+      if (!bad) {
+        PyObject** sdp = _PyObject_GetDictPtr(sc);
+        PyObject* sd = sdp ? _PyDict_NewPresized(2) : NULL;
+        bad = !sd;
+        if (!bad) {
+          Py_XSETREF(*sdp, sd);
+          bad = PyDict_SetItem(sd, k_load, ld) < 0 || PyDict_SetItem(sd, k_discharge, dc) < 0;
+        }
+      }
       if (!bad) {
         bad |= PyDict_SetItem(d, k_tick, t) < 0 || PyDict_SetItem(d, k_port, p) < 0 || PyDict_SetItem(d, k_vessel, v) < 0;
-        bad |= PyDict_SetItem(d, k_snap, PyList_GET_ITEM(snaps, e)) < 0 || PyDict_SetItem(d, k_early, ed) < 0 || PyDict_SetItem(d, k_scope, sc) < 0;
+        bad |= PyDict_SetItem(d, k_snap, PyList_GET_ITEM(snaps, e)) < 0 || PyDict_SetItem(d, k_early, ed) < 0 || PyDict_SetItem(d, k_scope_obj, sc) < 0;
       }
       Py_XDECREF(t); Py_XDECREF(p); Py_XDECREF(v); Py_XDECREF(ed); Py_XDECREF(ld); Py_XDECREF(dc); Py_XDECREF(sc);
       if (bad) goto fail;
@@ -191,6 +203,7 @@ PyMODINIT_FUNC PyInit__fastobj(void) {
   S(s_vessel_idx, "vessel_idx"); S(s_port_idx, "port_idx"); S(s_quantity, "quantity"); S(s_action_type, "action_type"); S(s_name, "name");
   S(k_tick, "tick"); S(k_port, "port_idx"); S(k_vessel, "vessel_idx"); S(k_snap, "snapshot_list"); S(k_scope_obj, "_action_scope");
   S(k_early, "_early_discharge"); S(k_scope_fn, "_action_scope_func"); S(k_early_fn, "_early_discharge_func"); S(k_scope, "_scope");
+  S(k_load, "load"); S(k_discharge, "discharge");
 #undef S
   return PyModule_Create(&moddef);
 }
