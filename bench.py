@@ -274,6 +274,8 @@ def bench_citi_bike(args, dist, dev, rank, world):
         ng = sizes[g]
         if args.step_budget:
             e.set_step_budget(args.step_budget)
+        if args.replay_overlap:
+            e.set_replay_overlap(True)
         bufs.append(dict(actions=torch.zeros((ng, 1, 3), dtype=torch.int32, device=dev), n_actions=torch.zeros((ng,), dtype=torch.int32, device=dev),
                          counter=torch.zeros((1,), dtype=torch.int64, device=dev),
                          q_nodes=torch.empty((ng, cap), dtype=torch.int32, device=dev) if scope_obs else None,
@@ -1003,6 +1005,7 @@ def main():
     ap.add_argument("--step-mode", type=int, default=0, help="launch form of mrx_cim_step (mrx_cim_set_step_mode): 0 default (sorted), "
                     "1 unsorted, 2 sorted, 4 split")
     ap.add_argument("--topology", default="global_trade.22p_l0.8")
+    ap.add_argument("--replay-overlap", type=int, default=0, help="citi_bike wave kernels: replay kernel beside the in-tick kernel (mrx_cb_set_replay_overlap; 0 = after it)")
     ap.add_argument("--step-budget", type=int, default=0, help="citi_bike: bounded steps for the main window (mrx_cb_set_step_budget; 0 = every call yields a decision)")
     ap.add_argument("--bounded-budget", type=int, default=24, help="citi_bike: budget of the extra bounded-steps leg (0: skip it)")
     ap.add_argument("--cb-groups", type=int, default=1, help="citi_bike: independent env groups per GPU, each engine on its own HIP stream")

@@ -155,6 +155,17 @@ int mrx_cb_set_lanes_per_wave(mrx_cb_handle h, int lanes);
 int mrx_cb_set_wave_decisions(mrx_cb_handle h, int mode);
 
 /*
+ * The two wave kernels of a batch step side by side (no reference counterpart).  With plan-specialised kernels loaded and the
+ * wave-cooperative step in effect, mrx_cb_step first reads off the state which envs leave their tick (mrx_k_cb_classify, one
+ * wave per env, writes nothing but that flag), then runs the replay kernel for those envs on a stream of the engine's own while
+ * the in-tick kernel steps all the others on the caller's stream: a batch step lasts as long as the longer of the two instead of
+ * their sum.  The engine's stream is forked from the caller's and joined back into it by events inside the call, so the caller
+ * sees one stream-ordered operation as before (also under stream capture).  on = 1 / 0 (the default): the replay kernel after
+ * the in-tick kernel, on the caller's stream.  Results do not depend on it.
+ */
+int mrx_cb_set_replay_overlap(mrx_cb_handle h, int on);
+
+/*
  * Bounded steps (no reference counterpart).  mrx_cb_step returns when EVERY env of the batch has its next decision, so a call
  * lasts as long as the batch's longest env-step — and env-steps differ by two orders of magnitude (another station deciding at
  * the same tick: nothing to simulate; the last decision of a tick: twenty ticks of trips, two snapshots, a rebalance sweep).

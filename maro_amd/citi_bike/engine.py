@@ -207,6 +207,11 @@ class CitiBikeBatchEngine:
         self._forced_wave = forced
         return on
 
+    def set_replay_overlap(self, on: bool = True) -> None:
+        """mrx_cb_set_replay_overlap: the in-tick kernel and the replay kernel of a batch step side by side (plan-specialised wave
+        kernels) or one after the other (the default).  Results unchanged."""
+        _lib.check(self._L.mrx_cb_set_replay_overlap(self._h, int(bool(on))), "mrx_cb_set_replay_overlap")
+
     def set_step_budget(self, max_records: int = 0) -> None:
         """Bounded steps: an env replays at most ~`max_records` events per `step()` call; envs that have not reached their
         next decision report `decisions[e, 5] == 0` (and `done[e] == 0`) and continue in the next call.  0 = off."""

@@ -60,10 +60,28 @@ struct Prof {
     for (int i = 0; i < 16; i++) if (acc[i]) K.prof[CB_IX(CD(aos), CD(stride), 16, i, e)] += acc[i];
   }
 };
+// ... and of a WAVE's step (the wave kernels: one env per wave), lane 0 adding each stretch straight into the env's counters
+// (tools/cb_wave_profile.py: phases 0-7 the replay kernel, 8-11 the in-tick kernel, 12 / 13 their call counts)
+struct WProf {
+  long long last;
+  __device__ __forceinline__ WProf() { last = clock64(); }
+  __device__ __forceinline__ void mark(const CbParams& K, int e, int i) {
+    const long long c = clock64();
+    if (threadIdx.x == 0) atomicAdd(&K.prof[CB_IX(CD(aos), CD(stride), 16, i, e)], (int)(c - last));
+    last = c;
+  }
+  __device__ __forceinline__ void count(const CbParams& K, int e, int i) {
+    if (threadIdx.x == 0) atomicAdd(&K.prof[CB_IX(CD(aos), CD(stride), 16, i, e)], 1);
+  }
+};
 #else
 struct Prof {
   MRX_DEVM_EARLY void mark(int) {}
   MRX_DEVM_EARLY void flush(const CbParams&, int) {}
+};
+struct WProf {
+  MRX_DEVM_EARLY void mark(const CbParams&, int, int) {}
+  MRX_DEVM_EARLY void count(const CbParams&, int, int) {}
 };
 #endif
 
@@ -761,8 +779,29 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
 enum { CBW_MAX = 128 };  // candidates ranked in registers (two per lane)
 
 // rank[a] = how many of the n candidates come before candidate (a, lane) — mode 0 / 2: (v, key) descending, 1: ascending
-MRX_DEV void cbw_rank(int n, int mode, const int* v, const int* key, int* rank) {
+MRX_DEV void cbw_rank(const CbParams& K, int n, int mode, const int* v, const int* key, int* rank) {
   rank[0] = rank[1] = 0;
+  // The usual case — values of at most 20 bits (bike counts, trip sums), keys = distinct station numbers below 2048 — packs
+  // (v, key) into ONE word that orders the same way: a broadcast, a compare and an add-with-carry per candidate and side, eight
+  // candidates per loop trip.  The wave kernels run four waves per SIMD at 4096 envs and this loop is most of their instructions.
+  // Positions >= n hold a word that comes before nobody, so the trip count rounds up freely.
+  if (CD(S) <= 2048 && !wave::ballot(((((uint32_t)v[0] | (uint32_t)v[1]) >> 20) != 0u))) {
+    const int lane = wave::lane();
+    const uint32_t flip = mode == 1 ? 0x7fffffffu : 0u;  // ascending = descending on the complemented word (31 bits: 0 stays the smallest)
+    uint32_t c[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) c[a] = a * 64 + lane < n ? (((((uint32_t)v[a] << 11) | (uint32_t)key[a]) ^ flip) + 1u) : 0u;
+    for (int j0 = 0; j0 < n; j0 += 8) {  // wave-uniform; a trip stays on one side (64 % 8 == 0)
+      const uint32_t src = j0 < 64 ? c[0] : c[1];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t cj = (uint32_t)wave::bcast((int)src, (j0 + k) & 63);
+#pragma unroll
+        for (int a = 0; a < 2; a++) rank[a] += cj > c[a] ? 1 : 0;
+      }
+    }
+    return;
+  }
   for (int j = 0; j < n; j++) {  // wave-uniform
     const int vj = wave::bcast(j < 64 ? v[0] : v[1], j & 63), kj = wave::bcast(j < 64 ? key[0] : key[1], j & 63);
 #pragma unroll
@@ -774,10 +813,10 @@ MRX_DEV void cbw_rank(int n, int mode, const int* v, const int* key, int* rank) 
 }
 
 // keep the n_out best of n candidates, best first: survivors move to position = rank through the LDS scratch (2 x CBW_MAX words)
-MRX_DEV void cbw_select(int32_t* scr, int n, int n_out, int mode, const int* v, int* key, int* val) {
+MRX_DEV void cbw_select(const CbParams& K, int32_t* scr, int n, int n_out, int mode, const int* v, int* key, int* val) {
   const int lane = wave::lane();
   int rank[2];
-  cbw_rank(n, mode, v, key, rank);
+  cbw_rank(K, n, mode, v, key, rank);
 #pragma unroll
   for (int a = 0; a < 2; a++)
     if (a * 64 + lane < n && rank[a] < n_out) { scr[rank[a]] = key[a]; scr[CBW_MAX + rank[a]] = val[a]; }
@@ -870,7 +909,7 @@ MRX_DEV int scope_wave(const CbParams& K, int s, int type, int t, int32_t* scr, 
       // (cb_plan rejects a distance filter behind a reordering one; a later prefix cut of a still distance-ordered list)
     } else if (CDA(f_type, f) == MRX_CB_FILTER_REQUIREMENTS) {
       const int v0[2] = {val[0], val[1]};
-      cbw_select(scr, n, n_out, 0, v0, key, val);
+      cbw_select(K, scr, n, n_out, 0, v0, key, val);
     } else {
       // TripsWindowFilter :88-163 — see cb::action_scope: a frame's value is frozen at the tick it was last read as the
       // current frame; the newest frame is re-read now (with windows == 0, Python's lst[-0:], only when it is new)
@@ -898,7 +937,7 @@ MRX_DEV int scope_wave(const CbParams& K, int s, int type, int t, int32_t* scr, 
           trips[a] += K.req_cum[hi + x] - K.req_cum[lo + x];
         }
       }
-      cbw_select(scr, n, n_out, type == MRX_CB_DEMAND ? 2 : 1, trips, key, val);
+      cbw_select(K, scr, n, n_out, type == MRX_CB_DEMAND ? 2 : 1, trips, key, val);
     }
     n = n_out;
   }
@@ -948,6 +987,7 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
 #endif
   int flags = LW(LDS_HDR + CH_FLAGS), t = LW(LDS_HDR + CH_TICK);
   bool finished = (flags & CFL_FINISHED) != 0;
+  WProf WP;
   if (!finished) {
     int pos = LW(LDS_HDR + CH_EV_POS);
     bool resumed = (flags & CFL_PENDING) != 0;
@@ -956,6 +996,7 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
       flags &= ~CFL_PENDING;
       wave::sync();
     }
+    WP.mark(K, e, 1);
     flags &= ~CFL_FRESH;
     int dec_s = -1, dec_type = 0;
     int left = K.step_budget > 0 ? K.step_budget : 0x7fffffff;
@@ -977,6 +1018,7 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
       const int w0 = ctl[0], ra = ctl[1];
       pos = ctl[2]; left = ctl[3];
       wave::sync();
+      WP.mark(K, e, 2);
       t = CD(start_tick) + (w0 >> 3);
       if ((w0 & 7) != CB_EV_REBAL && (w0 & 7) != CB_EV_TICK_END) break;  // budget spent between two light records
       left -= 4;
@@ -1001,6 +1043,7 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
         }
         wave::sync();
         pos++;
+        WP.mark(K, e, 3);
         continue;
       }
       if (lane == 0 && !resumed && HDR(CH_POOL_MINLAND) <= t) pool_flush_at(K, e, hd, t);
@@ -1021,7 +1064,7 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
           }
         }
       }
-      if (dec_s >= 0) break;
+      if (dec_s >= 0) { WP.mark(K, e, 4); break; }
       // ---- end_tick
       if (lane == 0 && HDR(CH_LATE) > 0) {  // DeliverBike appended to this very tick (transfer time 0)
         pool_exec_until(K, e, hd, t, CB_NO_LAND);
@@ -1044,6 +1087,7 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
         }
         wave::sync();
       }
+      WP.mark(K, e, 4);
       if (ra & 2) {
         flags |= CFL_FINISHED;
         finished = true;
@@ -1079,6 +1123,7 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
       if (lane == 0) {
         dec[0] = t; dec[1] = dec_s; dec[2] = dec_type; dec[3] = (t - CD(start_tick)) / CD(res); dec[4] = cnt; dec[5] = 1; dec[6] = 0; dec[7] = 0;
       }
+      WP.mark(K, e, 5);
     }
     if (lane == 0) { HDR(CH_EV_POS) = pos; HDR(CH_TICK) = t; HDR(CH_FLAGS) = flags; }
     wave::sync();
@@ -1106,6 +1151,7 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
     met[0] = LW(LDS_HDR + CH_TRIPS); met[1] = LW(LDS_HDR + CH_SHORT); met[2] = LW(LDS_HDR + CH_OPER);
     *done = finished ? 1 : 0;
   }
+  WP.mark(K, e, 6);
 }
 #undef LW
 #endif  // MRX_CB_LDSFRAME

@@ -98,7 +98,12 @@ struct mrx_cb_engine {
   int lanes = 64;  // envs per wave of the step kernel
   int step_budget = 0;  // mrx_cb_set_step_budget
   hipModule_t spec_module = nullptr;   // plan-specialised reset / step kernels (mrx_cb_load_step_kernels), else the generic ones
-  hipFunction_t spec_reset = nullptr, spec_step = nullptr, spec_wave = nullptr, spec_replay = nullptr;
+  hipFunction_t spec_reset = nullptr, spec_step = nullptr, spec_wave = nullptr, spec_replay = nullptr, spec_classify = nullptr;
+  // mrx_cb_set_replay_overlap: the in-tick kernel and the replay kernel of one batch step side by side (a second stream, forked
+  // from and joined back into the caller's stream by events inside mrx_cb_step)
+  bool overlap = false;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int spec_lsh = -1;  // envs-per-wave shift compiled into the loaded step kernel (MRXC_lsh_plan of its plan text); -1: a kernel argument
   int wave_mode = 0;    // mrx_cb_set_wave_decisions: 0 automatic, 1 on, -1 off
   bool obs_wave = false;  // the row layout the fused observation's buffer was sized for: scope_cap rows (wave path) or S rows (lane path)
@@ -113,9 +118,22 @@ struct mrx_cb_engine {
       if (cur != device && cur >= 0) hipSetDevice(cur);
     }
     spec_module = nullptr;
-    spec_wave = spec_replay = nullptr;
+    spec_wave = spec_replay = spec_classify = nullptr;
   }
-  ~mrx_cb_engine() { unload_spec(); }
+  ~mrx_cb_engine() {
+    unload_spec();
+    if (side) {   // (unload_spec drained the device when kernels were loaded; the side stream only ever runs those)
+      int cur = -1;
+      if (hipGetDevice(&cur) == hipSuccess) {
+        if (cur != device) hipSetDevice(device);
+        hipStreamSynchronize(side);
+        hipEventDestroy(ev_fork);
+        hipEventDestroy(ev_join);
+        hipStreamDestroy(side);
+        if (cur != device && cur >= 0) hipSetDevice(cur);
+      }
+    }
+  }
 };
 
 static int set_err(int code, const std::string& m) { return mrx_set_error_(code, m); }
@@ -220,6 +238,12 @@ int mrx_cb_set_wave_decisions(mrx_cb_handle h, int mode) {
   return cb_wave_on(h) ? 1 : 0;
 }
 
+int mrx_cb_set_replay_overlap(mrx_cb_handle h, int on) {
+  if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
+  h->overlap = on != 0;
+  return MRX_OK;
+}
+
 int mrx_cb_observation_rows(mrx_cb_handle h) {
   if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
   return cb_wave_on(h) ? h->plan.layout.scope_cap : h->plan.kp.S;
@@ -292,17 +316,48 @@ static int cb_launch_step(mrx_cb_handle h, const int32_t* d_actions, const int32
   CbParams Kc = K;
   Kc.step_budget = h->step_budget;
   if (cb_wave_on(h)) {
-    // one env per wave: the steps that stay inside their tick; everything else is flagged in K.todo for the general kernel below
     long long* metw = (long long*)d_metrics;
+    const bool replay = h->spec_replay && (int64_t)K.lds_words * 4 <= MRX_CB_LDS_BYTES;
+    if (replay && h->spec_classify && h->overlap) {
+      // The two wave kernels side by side.  Which envs leave their tick is read off the state first (mrx_k_cb_classify -> K.todo);
+      // then the replay kernel (few envs, a long sequential chain each) runs on the side stream while the in-tick kernel (all the
+      // others) runs on the caller's: a batch step costs the longer of the two instead of their sum.  Disjoint envs, no shared
+      // words; the caller's stream continues after both.
+      if (!h->side) {
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi));   // (the long pole of the step: first in line for CUs)
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+      }
+      hipStream_t main_s = (hipStream_t)stream;
+      void* pc[] = {&Kc, &d_actions, &d_n_actions, &d_env_mask};
+      HIP_TRY(hipModuleLaunchKernel(h->spec_classify, (unsigned)K.n_envs, 1, 1, 64, 1, 1, 0, main_s, pc, nullptr));
+      HIP_TRY(hipEventRecord(h->ev_fork, main_s));
+      HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+      CbParams Kr = Kc;
+      Kr.lsh = 0;
+      const uint8_t* todo = K.todo;
+      void* pr[] = {&Kr, &d_actions, &d_n_actions, &todo, &d_decisions, &d_scope, &metw, &d_done};
+      HIP_TRY(hipModuleLaunchKernel(h->spec_replay, (unsigned)K.n_envs, 1, 1, 64, 1, 1, (unsigned)(K.lds_words * 4), h->side, pr, nullptr));
+      HIP_TRY(hipEventRecord(h->ev_join, h->side));
+      int classified = 1;
+      void* pw[] = {&Kc, &d_actions, &d_n_actions, &d_env_mask, &d_decisions, &d_scope, &metw, &d_done, &classified};
+      HIP_TRY(hipModuleLaunchKernel(h->spec_wave, (unsigned)K.n_envs, 1, 1, 64, 1, 1, 0, main_s, pw, nullptr));
+      HIP_TRY(hipStreamWaitEvent(main_s, h->ev_join, 0));
+      return MRX_OK;
+    }
+    // one env per wave: the steps that stay inside their tick; everything else is flagged in K.todo for the general kernel below
+    int classified = 0;
     if (h->spec_wave) {
-      void* pw[] = {&Kc, &d_actions, &d_n_actions, &d_env_mask, &d_decisions, &d_scope, &metw, &d_done};
+      void* pw[] = {&Kc, &d_actions, &d_n_actions, &d_env_mask, &d_decisions, &d_scope, &metw, &d_done, &classified};
       HIP_TRY(hipModuleLaunchKernel(h->spec_wave, (unsigned)K.n_envs, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, pw, nullptr));
     } else {
       hipLaunchKernelGGL(mrx_k_cb_step_wave, dim3(K.n_envs), dim3(64), 0, (hipStream_t)stream, Kc, d_actions, d_n_actions, d_env_mask, d_decisions, d_scope,
-                         metw, d_done);
+                         metw, d_done, classified);
     }
     d_env_mask = K.todo;
-    if (h->spec_replay && (int64_t)K.lds_words * 4 <= MRX_CB_LDS_BYTES) {
+    if (replay) {
       // ... and the general step for the flagged envs, also one env per wave: state in the wave's LDS column (cb::step_env_wave)
       CbParams Kr = Kc;
       Kr.lsh = 0;
@@ -418,6 +473,9 @@ int mrx_cb_load_step_kernels(mrx_cb_handle h, const void* image, int64_t bytes, 
   else (void)hipGetLastError();
   hipFunction_t f_replay = nullptr;
   if (hipModuleGetFunction(&f_replay, mod, "mrx_k_cb_replay_wave") == hipSuccess && f_replay) h->spec_replay = f_replay;
+  else (void)hipGetLastError();
+  hipFunction_t f_classify = nullptr;
+  if (hipModuleGetFunction(&f_classify, mod, "mrx_k_cb_classify") == hipSuccess && f_classify) h->spec_classify = f_classify;
   else (void)hipGetLastError();
   return MRX_OK;
 }

@@ -79,13 +79,11 @@ mrx_k_cb_step(CbParams K, const int32_t* __restrict__ actions, const int32_t* __
 #endif
 }
 
-// The wave-cooperative decision step (cb_wave.h): ONE env per wave.  Handles the env-steps that stay inside their tick (apply the
-// action, next pending station, its action scope across the lanes) and writes todo[e] = 1 for every env it had to leave alone;
-// mrx_k_cb_step then runs with `todo` as its env mask.
+// Which envs of this batch step leave their tick (todo[e] = 1: the general kernel's) and which stay inside it (0: the in-tick
+// kernel's; masked-out envs too).  One wave per env, reads only: with the answer in K.todo BEFORE either kernel runs, the two
+// work on disjoint envs and mrx_cb_step launches them side by side on two streams.
 extern "C" __global__ void __launch_bounds__(64)
-mrx_k_cb_step_wave(CbParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions, const uint8_t* __restrict__ mask,
-                   int32_t* __restrict__ decisions, int32_t* __restrict__ scope, long long* __restrict__ metrics, uint8_t* __restrict__ done) {
-  __shared__ int32_t scr[2 * cb::CBW_MAX];
+mrx_k_cb_classify(CbParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions, const uint8_t* __restrict__ mask) {
   const int e = (int)blockIdx.x;
   if (mask && !mask[e]) {
     if (threadIdx.x == 0) K.todo[e] = 0;
@@ -93,9 +91,35 @@ mrx_k_cb_step_wave(CbParams K, const int32_t* __restrict__ actions, const int32_
   }
   int na = (actions && n_actions) ? n_actions[e] : 0;
   if (na > CD(max_actions)) na = CD(max_actions);
+  cb::WavePre P;
+  const bool ok = cb::decision_step_wave_pre(K, e, na, P);
+  if (threadIdx.x == 0) K.todo[e] = ok ? 0 : 1;
+}
+
+// The wave-cooperative decision step (cb_wave.h): ONE env per wave.  Handles the env-steps that stay inside their tick (apply the
+// action, next pending station, its action scope across the lanes).  classified = 0: writes todo[e] = 1 for every env it had to
+// leave alone, and the general kernel runs AFTER it with `todo` as its env mask.  classified = 1: mrx_k_cb_classify has filled
+// K.todo already; this kernel steps the envs it marked 0 and the general kernel the others, at the same time.
+extern "C" __global__ void __launch_bounds__(64)
+mrx_k_cb_step_wave(CbParams K, const int32_t* __restrict__ actions, const int32_t* __restrict__ n_actions, const uint8_t* __restrict__ mask,
+                   int32_t* __restrict__ decisions, int32_t* __restrict__ scope, long long* __restrict__ metrics, uint8_t* __restrict__ done,
+                   int classified) {
+  __shared__ int32_t scr[2 * cb::CBW_MAX];
+  const int e = (int)blockIdx.x;
+  if (mask && !mask[e]) {
+    if (threadIdx.x == 0 && !classified) K.todo[e] = 0;
+    return;
+  }
+  if (classified && K.todo[e]) return;
+  int na = (actions && n_actions) ? n_actions[e] : 0;
+  if (na > CD(max_actions)) na = CD(max_actions);
   const bool ok = cb::decision_step_wave(K, e, actions ? actions + (size_t)e * CD(max_actions) * 3 : nullptr, na, decisions + (size_t)e * 8,
                                          scope + (size_t)e * CD(scope_cap) * 2, (int64_t*)metrics + (size_t)e * 3, done + e, scr);
-  if (threadIdx.x == 0) K.todo[e] = ok ? 0 : 1;
+  if (classified) {
+    if (!ok) __builtin_trap();  // (the same question on the same state, asked twice: an env nobody steps must not pass silently)
+  } else if (threadIdx.x == 0) {
+    K.todo[e] = ok ? 0 : 1;
+  }
 }
 
 #if defined(MRX_CB_LDSFRAME) && MRXC_lsh_plan < 0   /* (the wave REPLAY kernel runs with lsh 0: a build with the envs-per-wave shift compiled in has the speculative wave kernel only — forcing wave mode on loads the runtime-shift build, citi_bike/engine.py) */
@@ -108,6 +132,8 @@ mrx_k_cb_replay_wave(CbParams K, const int32_t* __restrict__ actions, const int3
   __shared__ int32_t scr[2 * cb::CBW_MAX + 8];
   const int e = (int)blockIdx.x, lane = (int)threadIdx.x;
   if (!todo[e]) return;
+  cb::WProf WP;
+  WP.count(K, e, 12);
 #define MRX_CB_LW(w) cb::mrx_cb_lds[CB_EV_BLOCK * 4 + (w)]
   for (int w = lane; w < MRXC_FW; w += 64) MRX_CB_LW(w) = K.live[CB_IX(CD(aos), CD(stride), CD(FW), w, e)];
   for (int w = lane; w < MRXC_S; w += 64) MRX_CB_LW(LDS_CAP + w) = K.capacity[w];
@@ -121,11 +147,13 @@ mrx_k_cb_replay_wave(CbParams K, const int32_t* __restrict__ actions, const int3
   for (int w = lane; w < MRXC_w_words; w += 64) MRX_CB_LW(LDS_FUL + w) = (int32_t)K.fulfilled[CB_IX(CD(aos), CD(stride), CD(w_words), w, e)];
   for (int w = lane; w < 2 * MRXC_mask_words; w += 64) MRX_CB_LW(LDS_DMK + w) = (int32_t)K.decmask[CB_IX(CD(aos), CD(stride), (2 * CD(mask_words)), w, e)];
   __syncthreads();
+  WP.mark(K, e, 0);
   int na = (actions && n_actions) ? n_actions[e] : 0;
   if (na > CD(max_actions)) na = CD(max_actions);
   cb::step_env_wave(K, e, actions ? actions + (size_t)e * CD(max_actions) * 3 : nullptr, na, decisions + (size_t)e * 8, scope + (size_t)e * CD(scope_cap) * 2,
                     (int64_t*)metrics + (size_t)e * 3, done + e, scr);
   __syncthreads();
+  WP.mark(K, e, 15);  // (step_env_wave keeps its own clock: this stretch is the sum of its phases 1-6)
   for (int w = lane; w < MRXC_FW; w += 64) K.live[CB_IX(CD(aos), CD(stride), CD(FW), w, e)] = MRX_CB_LW(w);
   for (int w = lane; w < CH_WORDS; w += 64) K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, w, e)] = MRX_CB_LW(LDS_HDR + w);
 #ifdef MRX_CB_TWC_LDS
@@ -136,6 +164,7 @@ mrx_k_cb_replay_wave(CbParams K, const int32_t* __restrict__ actions, const int3
 #endif
   for (int w = lane; w < MRXC_w_words; w += 64) K.fulfilled[CB_IX(CD(aos), CD(stride), CD(w_words), w, e)] = (uint32_t)MRX_CB_LW(LDS_FUL + w);
   for (int w = lane; w < 2 * MRXC_mask_words; w += 64) K.decmask[CB_IX(CD(aos), CD(stride), (2 * CD(mask_words)), w, e)] = (uint32_t)MRX_CB_LW(LDS_DMK + w);
+  WP.mark(K, e, 7);
 #undef MRX_CB_LW
 }
 #endif

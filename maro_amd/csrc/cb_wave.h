@@ -30,27 +30,52 @@ namespace cb {
 #define W_BKT(i) K.bkt[CB_IX(CD(aos), CD(stride), (2 * CB_LAND_SLOTS + CB_LAND_SLOTS / 32), (i), e)]
 #define W_POOL(i, w) K.pool[CB_IX(CD(aos), CD(stride), (CD(pool_cap) * CB_POOL_WORDS), ((size_t)(i) * CB_POOL_WORDS + (w)), e)]
 
+// What a wave learns about env `e` before it commits to the in-tick step: nothing is written while this is filled in.
+struct WavePre {
+  int h;              // header word `lane` (lanes >= CH_WORDS: 0)
+  uint32_t sup, dem;  // pending-decision mask words `lane`, the answered decision already popped
+  int s0, t, s1, type;
+};
+
+// Does this Env.step of env `e` stay inside its tick, within what decision_step_wave does across the lanes?  Reads only; the
+// same answer on every lane.  mrx_k_cb_classify asks it once per env and batch step, so that the in-tick kernel and the replay
+// kernel can run side by side on disjoint envs; decision_step_wave asks it again for the values.
+MRX_DEV bool decision_step_wave_pre(const CbParams& K, int e, int n_actions, WavePre& P) {
+  const int lane = wave::lane();
+  const int MW = CD(mask_words);
+  // ---- header (lane w holds word w) and the pending-decision masks (lane w holds words w of both masks)
+  P.h = lane < CH_WORDS ? W_HDR(lane) : 0;
+  const int flags = wave::bcast(P.h, CH_FLAGS);
+  if (!(flags & CFL_PENDING) || (flags & CFL_FINISHED) || n_actions > 1 || MW > 64) return false;
+  P.sup = lane < MW ? W_DMK(lane) : 0u;
+  P.dem = lane < MW ? W_DMK(MW + lane) : 0u;
+  P.s0 = wave::bcast(P.h, CH_CUR_STATION);
+  P.t = wave::bcast(P.h, CH_TICK);
+  if (lane == (P.s0 >> 5)) { P.sup &= ~(1u << (P.s0 & 31)); P.dem &= ~(1u << (P.s0 & 31)); }  // pop the answered decision (apply_actions)
+  const uint64_t pend = wave::ballot((P.sup | P.dem) != 0u);
+  if (!pend) return false;  // last decision of the tick: events have to be replayed
+  // ---- the next decision (next_decision: lowest station index, Supply wins) and its candidate list
+  const int l1 = __builtin_ctzll(pend);
+  const uint32_t w_any = (uint32_t)wave::bcast((int)(P.sup | P.dem), l1), w_sup = (uint32_t)wave::bcast((int)P.sup, l1);
+  const int j1 = __builtin_ctz(w_any);
+  P.s1 = l1 * 32 + j1;
+  P.type = (w_sup >> j1 & 1u) ? MRX_CB_SUPPLY : MRX_CB_DEMAND;
+  return scope_wave_ok(K, P.s1, P.t);
+}
+
 // Env.step of env `e` when the step stays inside its tick.  Returns true when the env was handled (outputs written); false:
 // nothing was touched, the general path must run.
 MRX_DEV bool decision_step_wave(const CbParams& K, int e, const int32_t* actions, int n_actions, int32_t* dec, int32_t* out, int64_t* met,
                                 uint8_t* done, int32_t* scr) {
   const int lane = wave::lane();
   const int S = CD(S), MW = CD(mask_words);
-  // ---- header (lane w holds word w) and the pending-decision masks (lane w holds words w of both masks)
-  const int h = lane < CH_WORDS ? W_HDR(lane) : 0;
-  const int flags = wave::bcast(h, CH_FLAGS);
-  if (!(flags & CFL_PENDING) || (flags & CFL_FINISHED) || n_actions > 1 || MW > 64) return false;
-  uint32_t sup = lane < MW ? W_DMK(lane) : 0u, dem = lane < MW ? W_DMK(MW + lane) : 0u;
-  const int s0 = wave::bcast(h, CH_CUR_STATION), t = wave::bcast(h, CH_TICK);
-  if (lane == (s0 >> 5)) { sup &= ~(1u << (s0 & 31)); dem &= ~(1u << (s0 & 31)); }  // pop the answered decision (apply_actions)
-  const uint64_t pend = wave::ballot((sup | dem) != 0u);
-  if (!pend) return false;  // last decision of the tick: events have to be replayed
-  // ---- the next decision (next_decision: lowest station index, Supply wins) and its candidate list
-  const int l1 = __builtin_ctzll(pend);
-  const uint32_t w_any = (uint32_t)wave::bcast((int)(sup | dem), l1), w_sup = (uint32_t)wave::bcast((int)sup, l1);
-  const int j1 = __builtin_ctz(w_any), s1 = l1 * 32 + j1;
-  const int type = (w_sup >> j1 & 1u) ? MRX_CB_SUPPLY : MRX_CB_DEMAND;
-  if (!scope_wave_ok(K, s1, t)) return false;
+  WavePre P;
+  WProf WP;
+  if (!decision_step_wave_pre(K, e, n_actions, P)) return false;
+  WP.count(K, e, 13);
+  WP.mark(K, e, 8);
+  const int h = P.h, s0 = P.s0, t = P.t, s1 = P.s1, type = P.type;
+  const uint32_t sup = P.sup, dem = P.dem;
   const int fi_cur = (t - CD(start_tick)) / CD(res);
   // ---- from here on the env is handled.  The action (_on_action_received :521-559): one action at most
   int status = 0, tt_pos = wave::bcast(h, CH_TT_POS), tail = wave::bcast(h, CH_POOL_TAIL), minland = wave::bcast(h, CH_POOL_MINLAND),
@@ -109,6 +134,7 @@ MRX_DEV bool decision_step_wave(const CbParams& K, int e, const int32_t* actions
       if (status) W_HDR(CH_STATUS) = st_old | status;
     }
   }
+  WP.mark(K, e, 9);
   // ---- action scope of (s1, type) at tick t (decision_strategy.py:253-293), across the lanes; the bikes this step just took
   // from `patch_s` come out of registers (lane 0's store above is not ordered against other lanes' loads)
   const int n_rows = scope_wave(K, s1, type, t, scr, out,
@@ -119,6 +145,7 @@ MRX_DEV bool decision_step_wave(const CbParams& K, int e, const int32_t* actions
                                   if (K.obs) write_scope_observation_row(K, e, i, st, t, [&](int lv, int s2) {
                                     return (s2 == patch_s && lv == LV_BIKES) ? patch_b : (s2 == patch_s && lv == LV_MIN_BIKES) ? patch_min : (int)W_ST(lv, s2); });
                                 });
+  WP.mark(K, e, 10);
   const int m0 = wave::bcast(h, CH_TRIPS), m1 = wave::bcast(h, CH_SHORT), m2 = wave::bcast(h, CH_OPER);
   if (lane == 0) {
     dec[0] = t; dec[1] = s1; dec[2] = type; dec[3] = fi_cur; dec[4] = n_rows; dec[5] = 1; dec[6] = 0; dec[7] = 0;

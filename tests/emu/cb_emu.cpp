@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <vector>
+
 #include "wave_emu.h"   // 64-fiber wave emulation (defines MRX_DEV): only the wave-cooperative decision step (cb_wave.h) uses it
 #include "../../maro_amd/csrc/cb_layout.h"
 #include "../../maro_amd/csrc/cb_device.h"
@@ -12,6 +14,7 @@
 struct CbEmu {
   CbHostPlan plan;
   uint8_t* ws = nullptr;
+  int overlap = 1;       // cb_emu_set_replay_overlap: the split mrx_cb_step makes (classify, then the two wave kernels on disjoint envs)
   int wave_mode = 0;     // cb_emu_set_wave_decisions: 1 = steps go through cb::decision_step_wave first, like mrx_cb_step does
   bool reverse = false;  // lane order of the wave emulator (forward / reverse exposes missing syncs)
   long handled = 0, general = 0;
@@ -69,6 +72,53 @@ void cb_emu_step(void* h, const int32_t* actions, const int32_t* n_actions, cons
   CbEmu* e = (CbEmu*)h;
   const CbParams& K = e->plan.kp;
   static int32_t scr[2 * cb::CBW_MAX];
+#ifdef MRX_CB_LDSFRAME
+  if (e->wave_mode == 2 && e->overlap && K.decision_mode == 0 && K.start_tick % K.res == 0 && K.mask_words <= 64) {
+    // mrx_cb_step with the replay overlap on: mrx_k_cb_classify over every env FIRST (reads only), then the replay kernel's envs and
+    // the in-tick kernel's envs — disjoint sets, here one after the other in the order that would expose a dependence between them
+    static int32_t scr2[2 * cb::CBW_MAX + 8];
+    std::vector<uint8_t> todo((size_t)K.n_envs, 2);
+    e->wave.reverse = e->reverse;
+    auto args = [&](int env, const int32_t*& act, int& nac) {
+      const int na = n_actions ? n_actions[env] : 0;
+      nac = na < K.max_actions ? na : K.max_actions;
+      act = actions ? actions + (size_t)env * K.max_actions * 3 : nullptr;
+    };
+    for (int env = 0; env < K.n_envs; env++) {
+      if (mask && !mask[env]) continue;
+      const int32_t* act; int nac;
+      args(env, act, nac);
+      bool ok = false;
+      wave::run_wave(e->wave, [&]() {
+        cb::WavePre P;
+        const bool r = cb::decision_step_wave_pre(K, env, (actions && n_actions) ? nac : 0, P);
+        if (wave::lane() == 0) ok = r;
+      });
+      todo[env] = ok ? 0 : 1;
+    }
+    for (int pass = 0; pass < 2; pass++)
+      for (int env = 0; env < K.n_envs; env++) {
+        const int32_t* act; int nac;
+        args(env, act, nac);
+        if (pass == 0 && todo[env] == 1) {
+          e->general++;
+          wave::run_wave(e->wave, [&]() {
+            cb::step_env_wave(K, env, act, nac, dec + (size_t)env * 8, scope + (size_t)env * K.scope_cap * 2, met + (size_t)env * 3, done + env, scr2);
+          });
+        } else if (pass == 1 && todo[env] == 0) {
+          bool ok = false;
+          wave::run_wave(e->wave, [&]() {
+            const bool r = cb::decision_step_wave(K, env, act, (actions && n_actions) ? nac : 0, dec + (size_t)env * 8, scope + (size_t)env * K.scope_cap * 2,
+                                                  met + (size_t)env * 3, done + env, scr);
+            if (wave::lane() == 0) ok = r;
+          });
+          if (!ok) { fprintf(stderr, "cb_emu: env %d classified in-tick but decision_step_wave left it alone\n", env); abort(); }
+          e->handled++;
+        }
+      }
+    return;
+  }
+#endif
   for (int env = 0; env < K.n_envs; env++) {
     if (mask && !mask[env]) continue;
     const int na = n_actions ? n_actions[env] : 0;
@@ -99,6 +149,22 @@ void cb_emu_step(void* h, const int32_t* actions, const int32_t* n_actions, cons
   }
 }
 
+// cb::cbw_rank on the wave emulator: candidate i = (v[i], key[i]), i < n <= 128; rank_out[i] = how many come before it
+void cb_emu_rank(void* h, int n, int mode, const int32_t* v, const int32_t* key, int32_t* rank_out) {
+  CbEmu* e = (CbEmu*)h;
+  const CbParams& K = e->plan.kp;
+  e->wave.reverse = e->reverse;
+  wave::run_wave(e->wave, [&]() {
+    const int lane = wave::lane();
+    const int vv[2] = {v[lane], v[64 + lane]}, kk[2] = {key[lane], key[64 + lane]};
+    int rank[2];
+    cb::cbw_rank(K, n, mode, vv, kk, rank);
+    rank_out[lane] = rank[0];
+    rank_out[64 + lane] = rank[1];
+  });
+}
+
+void cb_emu_set_replay_overlap(void* h, int on) { ((CbEmu*)h)->overlap = on; }
 void cb_emu_set_wave_decisions(void* h, int on, int reverse) { ((CbEmu*)h)->wave_mode = on; ((CbEmu*)h)->reverse = reverse != 0; }
 long cb_emu_wave_handled(void* h) { return ((CbEmu*)h)->handled; }
 long cb_emu_wave_general(void* h) { return ((CbEmu*)h)->general; }

@@ -66,6 +66,8 @@ def _declare(L):
     L.cb_emu_query.argtypes = [vp, i32, vp, i32, i32, vp, i32, i32, vp, i32, vp]
     L.cb_emu_random_policy.argtypes = [vp, vp, vp, ctypes.c_int64, vp, vp]
     L.cb_emu_set_wave_decisions.argtypes = [vp, i32, i32]
+    L.cb_emu_set_replay_overlap.argtypes = [vp, i32]
+    L.cb_emu_rank.argtypes = [vp, i32, i32, vp, vp, vp]
     L.cb_emu_set_observation.argtypes = [vp, vp, i32, vp]
     L.cb_emu_wave_handled.restype = ctypes.c_long
     L.cb_emu_wave_handled.argtypes = [vp]
@@ -127,6 +129,18 @@ class CbEmuBackend:
         if wave_decisions:   # steps go through the wave-cooperative decision step first (cb_wave.h on the 64-fiber wave emulator);
             # 2 (specialised LDS-frame builds): the general step in its wave form as well (cb::step_env_wave)
             self._L.cb_emu_set_wave_decisions(ctypes.c_void_p(self._h), int(wave_decisions), int(reverse))
+
+    def rank(self, n, mode, v, key):
+        """cb::cbw_rank (the wave kernels' counting rank) on the 64-fiber emulator: positions >= n are ignored."""
+        vv, kk = np.zeros(128, np.int32), np.full(128, -1, np.int32)
+        vv[:n], kk[:n] = v, key
+        out = np.zeros(128, np.int32)
+        self._L.cb_emu_rank(ctypes.c_void_p(self._h), int(n), int(mode), _ptr(vv), _ptr(kk), _ptr(out))
+        return out[:n]
+
+    def set_replay_overlap(self, on=True):
+        """mrx_cb_set_replay_overlap on the harness: classify every env first, then the two wave kernels on disjoint envs (the default)."""
+        self._L.cb_emu_set_replay_overlap(ctypes.c_void_p(self._h), int(bool(on)))
 
     def set_observation(self, attr_ids):
         """mrx_cb_set_observation: float64 [n, rows, len(ids)] written by every step (rows: S, or scope_cap on the wave path)."""

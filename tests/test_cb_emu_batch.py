@@ -72,16 +72,19 @@ def test_batch_matches_oracle_with_wave_cooperative_decisions(topology, kwargs, 
     assert steps > 20 and handled > 0 and general > 0
 
 
+@pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("topology,kwargs,n,budget", [
     ("toy.5s_filters", dict(durations=700, snapshot_resolution=10), 5, 0),
     ("toy.3s_tight", dict(durations=900, snapshot_resolution=3, max_snapshots=9), 6, 7),
 ])
-def test_batch_matches_oracle_with_wave_form_general_step(topology, kwargs, n, budget):
+def test_batch_matches_oracle_with_wave_form_general_step(topology, kwargs, n, budget, overlap):
     """Plan-specialised LDS-frame build: decision step AND general step in their wave forms (mrx_k_cb_step_wave +
-    mrx_k_cb_replay_wave), with and without a step budget."""
+    mrx_k_cb_replay_wave), with and without a step budget; with the split mrx_cb_step makes by default (mrx_k_cb_classify over every
+    env first, then the two kernels on disjoint envs: mrx_cb_set_replay_overlap) and with the replay kernel after the in-tick one."""
     from tests.cb_batch_check import run_bounded_vs_oracle
     data = load_topology(topology)
     b = CbEmuBackend(data, n_envs=n, max_actions=1, specialized=True, wave_decisions=2, **kwargs)
+    b.set_replay_overlap(overlap)
     if budget:
         calls, unready = run_bounded_vs_oracle(b, data, kwargs, seeds=np.arange(n) + 9, budget=budget)
         assert unready > 0
@@ -151,3 +154,25 @@ def test_fused_observation_equals_the_query_on_the_emulator(topology, specialize
                 a, na = be.random_policy(dec, scope, i)
                 dec, scope, met, done = be.step(a, na)
         assert checked > 100
+
+
+@pytest.mark.parametrize("specialized", [False, True])
+def test_counting_rank_packed_and_general_forms(specialized):
+    """cb::cbw_rank — the order every filter of the wave kernels' action scope sorts by: (value, station) descending (modes 0 / 2)
+    or ascending (mode 1), as a rank per candidate.  Values of at most 20 bits take the one-word form (eight candidates per loop
+    trip, positions >= n padded); anything larger or negative takes the general two-key loop.  Both against a plain sort, at the
+    sizes around the loop's trip length and the two-per-lane register split, ties in the value included."""
+    data = load_topology("city.180s")
+    b = CbEmuBackend(data, n_envs=1, durations=60, snapshot_resolution=10, specialized=specialized, wave_decisions=2 if specialized else 1)
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 7, 8, 9, 40, 63, 64, 65, 80, 127, 128):
+        for hi in (3, 50, (1 << 20) - 1, 1 << 20, 1 << 30):
+            for mode in (0, 1, 2):
+                v = rng.integers(0, hi + 1, n).astype(np.int32)
+                if hi == 1 << 30:
+                    v[rng.integers(0, n)] = -5      # (no filter produces one; the general loop orders it like any int)
+                key = rng.permutation(data.n_stations)[:n].astype(np.int32) if n <= data.n_stations else np.arange(n, dtype=np.int32)
+                order = sorted(range(n), key=lambda i: (int(v[i]), int(key[i])), reverse=mode != 1)
+                want = np.empty(n, np.int32)
+                want[order] = np.arange(n)
+                assert np.array_equal(b.rank(n, mode, v, key), want), (n, hi, mode)

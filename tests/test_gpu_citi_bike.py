@@ -146,17 +146,58 @@ def test_city800_batch_matches_oracle():
     assert steps > 1000
 
 
-def test_city800_batch_matches_oracle_specialised():
+@pytest.mark.parametrize("overlap", [True, False])
+def test_city800_batch_matches_oracle_specialised(overlap):
     """The same batch on the plan-specialised LDS-frame kernels: decision step AND general step one env per wave
-    (mrx_k_cb_step_wave + mrx_k_cb_replay_wave), with a step budget on top — what bench.py --topology city.800s runs."""
+    (mrx_k_cb_step_wave + mrx_k_cb_replay_wave), with a step budget on top — what bench.py --topology city.800s runs.  overlap:
+    the two kernels side by side on disjoint envs (mrx_k_cb_classify first; mrx_cb_set_replay_overlap, the default) or in sequence."""
     from tests.cb_batch_check import run_bounded_vs_oracle
     from tests.cb_gpu_backend import CbGpuBackend
     data = load_topology("city.800s")
     kw = dict(start_tick=1440, durations=130, snapshot_resolution=10, max_snapshots=6)
     b = CbGpuBackend(data, n_envs=300, max_actions=1, specialize=True, **kw)
     assert b.eng.specialized and b.eng.set_wave_decisions(0)
+    b.eng.set_replay_overlap(overlap)
     calls, unready = run_bounded_vs_oracle(b, data, kw, seeds=np.arange(300) + 17, budget=96, check_envs=[0, 151, 299])
     assert calls > 1000 and unready > 0
+
+
+def test_replay_overlap_does_not_change_a_single_output():
+    """mrx_cb_set_replay_overlap on / off on two engines of the same city-size batch, under a user stream and a tight step budget (many
+    envs in the replay kernel at once): every output of every step and the final state words are equal, and the caller's stream sees
+    the step as one ordered operation (the next launch on it reads both kernels' outputs)."""
+    import torch
+
+    from maro_amd.citi_bike.engine import CitiBikeBatchEngine
+    n = 512
+    engs = [CitiBikeBatchEngine("city.180s", n, durations=400, snapshot_resolution=10, max_snapshots=8, seeds=np.arange(n) + 5, specialize=True) for _ in range(2)]
+    assert all(e.specialized and e.set_wave_decisions(0) for e in engs)
+    engs[0].set_replay_overlap(True)
+    engs[1].set_replay_overlap(False)
+    user = torch.cuda.Stream()
+    engs[0].use_stream(user)
+    for e in engs:
+        e.set_step_budget(5)
+    acts = [torch.zeros((n, 1, 3), dtype=torch.int32, device="cuda") for _ in engs]
+    nact = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in engs]
+    sums = [torch.zeros(4, dtype=torch.int64, device="cuda") for _ in engs]
+    torch.cuda.synchronize()
+    outs = [e.step() for e in engs]
+    for i in range(600):
+        for e, a, k in zip(engs, acts, nact):
+            e.random_policy(i, a, k)
+        outs = [e.step(a, k) for e, a, k in zip(engs, acts, nact)]
+        with torch.cuda.stream(user):   # stream-ordered consumer right behind the step: no host sync in between
+            sums[0] += torch.stack([o.to(torch.int64).sum() for o in outs[0]])
+        sums[1] += torch.stack([o.to(torch.int64).sum() for o in outs[1]])
+        if i % 50 == 0:
+            torch.cuda.synchronize()
+            for x, y in zip(*outs):
+                assert torch.equal(x, y), i
+    torch.cuda.synchronize()
+    assert torch.equal(sums[0], sums[1])
+    for name in ("hdr", "live", "ring", "ring_fi"):
+        assert torch.equal(getattr(engs[0], name), getattr(engs[1], name)), name
 
 
 @pytest.mark.parametrize("topology,kwargs", [("toy.5s_filters", dict(durations=1200, snapshot_resolution=10)),
