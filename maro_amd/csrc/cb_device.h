@@ -127,10 +127,12 @@ extern __shared__ int32_t mrx_cb_lds[];
 #define CB_LSH K.lsh
 #endif
 #define LF(w) mrx_cb_lds[((CB_EV_BLOCK * 4 + (w)) << CB_LSH) + threadIdx.x]
+#define LF0(w) mrx_cb_lds[CB_EV_BLOCK * 4 + (w)] /* word w of the wave's ONE column, from any lane (the wave replay kernel: K.lsh = 0) */
 #else
 static int32_t mrx_cb_lds_host[MRXC_lds_words]; /* host harness: one env at a time */
 #define LEV() mrx_cb_lds_host
 #define LF(w) mrx_cb_lds_host[CB_EV_BLOCK * 4 + (w)]
+#define LF0(w) LF(w)
 #endif
 #define LDS_CAP (MRXC_FW)
 #define LDS_FUL (LDS_CAP + MRXC_S)
@@ -155,7 +157,19 @@ static int32_t mrx_cb_lds_host[MRXC_lds_words]; /* host harness: one env at a ti
 #else
 #define LDS_TWC_WORDS 0
 #endif
-static_assert(LDS_TWC + LDS_TWC_WORDS + CB_EV_BLOCK * 4 == MRXC_lds_words, "cb_layout.h and cb_device.h disagree on the LDS column");
+// The delivery pool's hot end (env-major plans: the wave replay kernel, K.pool_stage): the landing-tick bucket table, and a copy of
+// the CB_POOL_STAGE pool entries from the ring's head on — a decision tick at the reference's size leaves ~200 deliveries in
+// flight, and walking them in HBM cost four dependent round trips per delivery (two thirds of a replay call's cycles, measured).
+#if MRXC_aos
+#define MRX_CB_POOL_LDS 1
+#define LDS_BKT (LDS_TWC + LDS_TWC_WORDS)
+#define LDS_PSA (LDS_BKT + CB_BKT_WORDS)   /* the window's anchor: pool index of ring position 0 of the copy */
+#define LDS_PST (LDS_PSA + 1)
+#define LDS_POOL_WORDS CB_POOL_STAGE_WORDS
+#else
+#define LDS_POOL_WORDS 0
+#endif
+static_assert(LDS_TWC + LDS_TWC_WORDS + LDS_POOL_WORDS + CB_EV_BLOCK * 4 == MRXC_lds_words, "cb_layout.h and cb_device.h disagree on the LDS column");
 // the env header too: as a register array that rare branches (the delivery pool) modify, every join of the replay loop copied
 // all 16 words back and forth
 #define HDR(w) LF(LDS_HDR + (w))
@@ -237,6 +251,89 @@ struct EvWin {
 #define BKT(i) K.bkt[CB_IX(CD(aos), CD(stride), (2 * CB_LAND_SLOTS + CB_LAND_SLOTS / 32), (i), e)] /* landing-tick buckets of the delivery pool */
 #define POOL(i, w) K.pool[CB_IX(CD(aos), CD(stride), (CD(pool_cap) * CB_POOL_WORDS), ((size_t)(i) * CB_POOL_WORDS + (w)), e)]
 
+// Delivery pool / bucket table accessors.  Everywhere but the wave replay kernel: the words in HBM.  There (K.pool_stage): reads
+// come out of the LDS copy — every bucket word; a pool entry when it lies within K.pool_stage (<= CB_POOL_STAGE) ring positions of the anchor —
+// and writes go to both, so HBM is current at every moment and nothing is written back.
+#ifdef MRX_CB_POOL_LDS
+MRX_DEV int pool_pos(const CbParams& K, int idx) {  // ring position of pool index idx relative to the anchor
+  const int a = LF(LDS_PSA);
+  return idx - a + (idx < a ? CD(pool_cap) : 0);
+}
+MRX_DEV int pool_rd(const CbParams& K, int e, int idx, int w) {
+  if (K.pool_stage) {
+    const int p = pool_pos(K, idx);
+    if (p < K.pool_stage) return LF(LDS_PST + p * CB_POOL_WORDS + w);
+  }
+  return POOL(idx, w);
+}
+MRX_DEV void pool_rd_entry(const CbParams& K, int e, int idx, int* out) {
+  if (K.pool_stage) {
+    const int p = pool_pos(K, idx);
+    if (p < K.pool_stage) {
+#pragma unroll
+      for (int w = 0; w < CB_POOL_WORDS; w++) out[w] = LF(LDS_PST + p * CB_POOL_WORDS + w);
+      return;
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < CB_POOL_WORDS; w++) out[w] = POOL(idx, w);
+}
+MRX_DEV void pool_wr(const CbParams& K, int e, int idx, int w, int v) {
+  POOL(idx, w) = v;
+  if (K.pool_stage) {
+    const int p = pool_pos(K, idx);
+    if (p < K.pool_stage) LF(LDS_PST + p * CB_POOL_WORDS + w) = v;
+  }
+}
+MRX_DEV int bkt_rd(const CbParams& K, int e, int i) { return K.pool_stage ? LF(LDS_BKT + i) : BKT(i); }
+MRX_DEV void bkt_wr(const CbParams& K, int e, int i, int v) {
+  BKT(i) = v;
+  if (K.pool_stage) LF(LDS_BKT + i) = v;
+}
+// Fills the copy (all lanes of the env's wave; head / tail: the env's CH_POOL_HEAD / CH_POOL_TAIL): the bucket table, and the entries
+// between the ring's head and tail that fit.  Entries pushed later land in the copy through pool_wr.
+MRX_DEV void pool_stage_load(const CbParams& K, int e, int head, int tail) {
+  const int lane = wave::lane();
+  const int a = head % CD(pool_cap);
+  int n = tail - head;
+  if (n > K.pool_stage) n = K.pool_stage;
+  // every load in flight before the first LDS write: no load sits behind a branch (positions past the table / past the ring's
+  // tail read a valid word again and are not used), a loop with a run-time trip count would wait for each trip's loads in turn
+  constexpr int NB = (CB_BKT_WORDS + 63) / 64, NP = CB_POOL_STAGE * CB_POOL_WORDS / 64;
+  int vb[NB], vp[NP];
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    const int i = k * 64 + lane;
+    vb[k] = BKT(i < CB_BKT_WORDS ? i : 0);
+  }
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    const int i = k * 64 + lane;
+    const int p = i / CB_POOL_WORDS, w = i - p * CB_POOL_WORDS;
+    int idx = a + (p < n ? p : 0);
+    if (idx >= CD(pool_cap)) idx -= CD(pool_cap);
+    vp[k] = POOL(idx, w);
+  }
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    const int i = k * 64 + lane;
+    if (i < CB_BKT_WORDS) LF0(LDS_BKT + i) = vb[k];
+  }
+#pragma unroll
+  for (int k = 0; k < NP; k++) LF0(LDS_PST + k * 64 + lane) = vp[k];
+  if (lane == 0) LF0(LDS_PSA) = a;
+}
+#else
+MRX_DEV int pool_rd(const CbParams& K, int e, int idx, int w) { return POOL(idx, w); }
+MRX_DEV void pool_rd_entry(const CbParams& K, int e, int idx, int* out) {
+#pragma unroll
+  for (int w = 0; w < CB_POOL_WORDS; w++) out[w] = POOL(idx, w);
+}
+MRX_DEV void pool_wr(const CbParams& K, int e, int idx, int w, int v) { POOL(idx, w) = v; }
+MRX_DEV int bkt_rd(const CbParams& K, int e, int i) { return BKT(i); }
+MRX_DEV void bkt_wr(const CbParams& K, int e, int i, int v) { BKT(i) = v; }
+#endif
+
 MRX_DEV void set_bikes(const CbParams& K, int e, int32_t* hd, int s, int v) {  // station.py:71-75
   ST(LV_BIKES, s) = v;
   if (v < ST(LV_MIN_BIKES, s)) ST(LV_MIN_BIKES, s) = v;
@@ -244,33 +341,59 @@ MRX_DEV void set_bikes(const CbParams& K, int e, int32_t* hd, int s, int v) {  /
 
 // decision_strategy.py:295-343 — bikes that do not fit go to the neighbours of `cur`, nearest first
 MRX_DEV void move_to_neighbor(const CbParams& K, int e, int32_t* hd, int src, int cur, int number) {
+  // Eight neighbours per trip: their numbers in one round trip (independent loads; the row is nb_stride long, -1 past the count;
+  // the first eight do not wait for the count), then their bikes / capacity / min_bikes in one (distinct stations, and nothing
+  // below writes another neighbour's), then the arithmetic.  One load after the other made every overflowing delivery a chain
+  // of a dozen dependent round trips — and a decision tick at the reference's size lands ~200 deliveries per env.
+  const int32_t* row = K.nb + (size_t)cur * CD(nb_stride);
+  int nbv[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) nbv[k] = row[k < CD(nb_stride) ? k : 0];
   const int cnt = K.nb_cnt[cur];
-  for (int i = 0; i < cnt && number > 0; i++) {
-    const int nb = K.nb[(size_t)cur * CD(nb_stride) + i];
-    const int b = ST(LV_BIKES, nb);
-    int accept = CAP(nb) - b;
-    if (accept > number) accept = number;
-    set_bikes(K, e, hd, nb, b + accept);
-    const int target = CD(extra_cost_mode) == 0 ? src : CD(extra_cost_mode) == 1 ? cur : nb;
-    ST(LV_EXTRA_COST, target) += accept * (i + 1);
-    number -= accept;
+  for (int i0 = 0; i0 < cnt && number > 0; i0 += 8) {
+    if (i0) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) nbv[k] = row[i0 + k < CD(nb_stride) ? i0 + k : i0];
+    }
+    int bv[8], cv[8], mv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int nb = i0 + k < cnt ? nbv[k] : nbv[0];
+      bv[k] = ST(LV_BIKES, nb); cv[k] = CAP(nb); mv[k] = ST(LV_MIN_BIKES, nb);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int i = i0 + k;
+      if (i < cnt && number > 0) {
+        const int nb = nbv[k];
+        int accept = cv[k] - bv[k];
+        if (accept > number) accept = number;
+        const int v = bv[k] + accept;  // set_bikes (station.py:71-75)
+        ST(LV_BIKES, nb) = v;
+        if (v < mv[k]) ST(LV_MIN_BIKES, nb) = v;
+        const int target = CD(extra_cost_mode) == 0 ? src : CD(extra_cost_mode) == 1 ? cur : nb;
+        CB_ADD(ST(LV_EXTRA_COST, target), accept * (i + 1));
+        number -= accept;
+      }
+    }
   }
 }
 
 // _on_bike_returned :439-466 (deliver = false) and _on_bike_deliver :494-519 (deliver = true)
 MRX_DEV void land_bikes(const CbParams& K, int e, int32_t* hd, bool deliver, int frm, int to, int n) {
-  const int b = ST(LV_BIKES, to);
-  int accept = CAP(to) - b;
+  const int b = ST(LV_BIKES, to), cap = CAP(to), mn = ST(LV_MIN_BIKES, to);  // (everything the landing reads, in one round trip)
+  int accept = cap - b;
   if (accept > n) accept = n;
   if (accept < n) {
-    if (!deliver) ST(LV_FAILED_RETURN, to) += n - accept;
-    move_to_neighbor(K, e, hd, frm, to, n - accept);
+    if (!deliver) CB_ADD(ST(LV_FAILED_RETURN, to), n - accept);
+    move_to_neighbor(K, e, hd, frm, to, n - accept);   // (`to` is not among its own neighbours)
   }
   if (deliver && accept > 0) {
-    ST(LV_TRANSFER_COST, to) += accept;
-    HDR(CH_OPER) += accept;
+    CB_ADD(ST(LV_TRANSFER_COST, to), accept);
+    CB_ADD(HDR(CH_OPER), accept);
   }
-  set_bikes(K, e, hd, to, b + accept);
+  ST(LV_BIKES, to) = b + accept;  // set_bikes
+  if (b + accept < mn) ST(LV_MIN_BIKES, to) = b + accept;
 }
 
 // The delivery pool: DeliverBike events in flight, appended in scheduling (= insertion) order, and — since a decision tick at the
@@ -281,23 +404,27 @@ MRX_DEV void land_bikes(const CbParams& K, int e, int32_t* hd, bool deliver, int
 // city.800s: 97 pool entries visited per trip / return event).  A slot only ever holds one landing tick: a delivery is pushed at
 // tick now with land - now < CB_LAND_SLOTS (longer transfers are flagged as MRX_CB_ENV_DELIVERY_OVERFLOW and dropped), and every
 // slot up to `now` has been flushed by then.
-#define BKT_HEAD(slot) BKT(slot)
-#define BKT_TAIL(slot) BKT(CB_LAND_SLOTS + (slot))
-#define BKT_MASK(w) BKT(2 * CB_LAND_SLOTS + (w))
+// bucket table words: [0, CB_LAND_SLOTS) first entry of a slot, [CB_LAND_SLOTS, 2 CB_LAND_SLOTS) last entry, then the occupancy mask
+#define BKT_HEAD(slot) (slot)
+#define BKT_TAIL(slot) (CB_LAND_SLOTS + (slot))
+#define BKT_MASK(w) (2 * CB_LAND_SLOTS + (w))
 
 // Executes, in insertion order, the deliveries landing at tick `t` whose scheduling tick is < sched_lt.
 MRX_DEV void pool_exec_until(const CbParams& K, int e, int32_t* hd, int t, int sched_lt) {
   const int slot = t & (CB_LAND_SLOTS - 1);
-  int idx = BKT_HEAD(slot);
-  while (idx >= 0 && POOL(idx, 0) == t && POOL(idx, 1) < sched_lt) {
-    land_bikes(K, e, hd, true, POOL(idx, 2), POOL(idx, 3), POOL(idx, 4));
-    POOL(idx, 4) = -1;
-    idx = POOL(idx, 5);
+  int idx = bkt_rd(K, e, BKT_HEAD(slot));
+  while (idx >= 0) {
+    int w[CB_POOL_WORDS];  // the whole entry in one round trip
+    pool_rd_entry(K, e, idx, w);
+    if (!(w[0] == t && w[1] < sched_lt)) break;
+    land_bikes(K, e, hd, true, w[2], w[3], w[4]);
+    pool_wr(K, e, idx, 4, -1);
+    idx = w[5];
   }
-  BKT_HEAD(slot) = idx;
+  bkt_wr(K, e, BKT_HEAD(slot), idx);
   if (idx < 0) {
-    BKT_TAIL(slot) = -1;
-    BKT_MASK(slot >> 5) &= ~(int32_t)(1u << (slot & 31));
+    bkt_wr(K, e, BKT_TAIL(slot), -1);
+    bkt_wr(K, e, BKT_MASK(slot >> 5), bkt_rd(K, e, BKT_MASK(slot >> 5)) & ~(int32_t)(1u << (slot & 31)));
   }
 }
 
@@ -306,7 +433,7 @@ MRX_DEV void pool_exec_until(const CbParams& K, int e, int32_t* hd, int t, int s
 MRX_DEV void pool_compact(const CbParams& K, int e, int32_t* hd) {
   int head = HDR(CH_POOL_HEAD);
   const int tail = HDR(CH_POOL_TAIL);
-  while (head != tail && POOL(head % CD(pool_cap), 4) < 0) head++;
+  while (head != tail && pool_rd(K, e, head % CD(pool_cap), 4) < 0) head++;
   HDR(CH_POOL_HEAD) = head;
   int m = CB_NO_LAND;
   const int from = HDR(CH_POOL_MINLAND);
@@ -314,13 +441,13 @@ MRX_DEV void pool_compact(const CbParams& K, int e, int32_t* hd) {
     const int s0 = from & (CB_LAND_SLOTS - 1);
     for (int k = 0; k <= CB_LAND_SLOTS / 32 && m == CB_NO_LAND; k++) {  // mask words from s0's word on, wrapping once
       const int w = ((s0 >> 5) + k) & (CB_LAND_SLOTS / 32 - 1);
-      uint32_t bits = (uint32_t)BKT_MASK(w);
+      uint32_t bits = (uint32_t)bkt_rd(K, e, BKT_MASK(w));
       if (k == 0) bits &= ~0u << (s0 & 31);
       if (k == CB_LAND_SLOTS / 32) bits &= (s0 & 31) ? ((1u << (s0 & 31)) - 1u) : 0u;
       if (bits) {
         int j = 0;
         while (!(bits >> j & 1u)) j++;
-        m = POOL(BKT_HEAD(w * 32 + j), 0);
+        m = pool_rd(K, e, bkt_rd(K, e, BKT_HEAD(w * 32 + j)), 0);
       }
     }
   }
@@ -335,12 +462,13 @@ MRX_DEV void pool_push(const CbParams& K, int e, int32_t* hd, int land, int sche
     return;
   }
   const int idx = tail % CD(pool_cap);
-  POOL(idx, 0) = land; POOL(idx, 1) = sched; POOL(idx, 2) = frm; POOL(idx, 3) = to; POOL(idx, 4) = n; POOL(idx, 5) = -1;
+  pool_wr(K, e, idx, 0, land); pool_wr(K, e, idx, 1, sched); pool_wr(K, e, idx, 2, frm); pool_wr(K, e, idx, 3, to); pool_wr(K, e, idx, 4, n);
+  pool_wr(K, e, idx, 5, -1);
   const int slot = land & (CB_LAND_SLOTS - 1);
-  const int last = BKT_TAIL(slot);
-  if (last >= 0) POOL(last, 5) = idx;
-  else { BKT_HEAD(slot) = idx; BKT_MASK(slot >> 5) |= (int32_t)(1u << (slot & 31)); }
-  BKT_TAIL(slot) = idx;
+  const int last = bkt_rd(K, e, BKT_TAIL(slot));
+  if (last >= 0) pool_wr(K, e, last, 5, idx);
+  else { bkt_wr(K, e, BKT_HEAD(slot), idx); bkt_wr(K, e, BKT_MASK(slot >> 5), bkt_rd(K, e, BKT_MASK(slot >> 5)) | (int32_t)(1u << (slot & 31))); }
+  bkt_wr(K, e, BKT_TAIL(slot), idx);
   HDR(CH_POOL_TAIL) = tail + 1;
   if (land < HDR(CH_POOL_MINLAND)) HDR(CH_POOL_MINLAND) = land;
 }
@@ -984,6 +1112,10 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
 #endif
   }
   wave::sync();
+#ifdef MRX_CB_POOL_LDS
+  if (K.pool_stage) pool_stage_load(K, e, GHDR(CH_POOL_HEAD), GHDR(CH_POOL_TAIL));
+  wave::sync();
+#endif
 #endif
   int flags = LW(LDS_HDR + CH_FLAGS), t = LW(LDS_HDR + CH_TICK);
   bool finished = (flags & CFL_FINISHED) != 0;
@@ -1168,7 +1300,7 @@ MRX_DEV void reset_env(const CbParams& K, int e) {
   for (int w = 0; w < 2 * CD(mask_words); w++) GDMK(w) = 0;
   for (int w = 0; w < CD(w_words); w++) GFUL(w) = 0;
   for (int i = 0; i < 2 * CB_LAND_SLOTS; i++) BKT(i) = -1;
-  for (int w = 0; w < CB_LAND_SLOTS / 32; w++) BKT_MASK(w) = 0;
+  for (int w = 0; w < CB_LAND_SLOTS / 32; w++) BKT(BKT_MASK(w)) = 0;
 }
 
 // Observation fused into the step (mrx_cb_set_observation): what `mrx_cb_query("stations", decision frame, every station, attrs)`

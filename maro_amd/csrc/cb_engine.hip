@@ -337,6 +337,7 @@ static int cb_launch_step(mrx_cb_handle h, const int32_t* d_actions, const int32
       HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
       CbParams Kr = Kc;
       Kr.lsh = 0;
+      Kr.pool_stage = CB_POOL_STAGE;
       const uint8_t* todo = K.todo;
       void* pr[] = {&Kr, &d_actions, &d_n_actions, &todo, &d_decisions, &d_scope, &metw, &d_done};
       HIP_TRY(hipModuleLaunchKernel(h->spec_replay, (unsigned)K.n_envs, 1, 1, 64, 1, 1, (unsigned)(K.lds_words * 4), h->side, pr, nullptr));
@@ -361,6 +362,7 @@ static int cb_launch_step(mrx_cb_handle h, const int32_t* d_actions, const int32
       // ... and the general step for the flagged envs, also one env per wave: state in the wave's LDS column (cb::step_env_wave)
       CbParams Kr = Kc;
       Kr.lsh = 0;
+      Kr.pool_stage = CB_POOL_STAGE;
       const uint8_t* todo = K.todo;
       void* pr[] = {&Kr, &d_actions, &d_n_actions, &todo, &d_decisions, &d_scope, &metw, &d_done};
       HIP_TRY(hipModuleLaunchKernel(h->spec_replay, (unsigned)K.n_envs, 1, 1, 64, 1, 1, (unsigned)(K.lds_words * 4), (hipStream_t)stream, pr, nullptr));

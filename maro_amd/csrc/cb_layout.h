@@ -139,7 +139,7 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
     k.w_mask = w - 1; k.w_words = w / 32;
   }
   k.lds_words = k.FW + S + k.w_words + 2 * k.mask_words + (k.aos ? 0 : 3 * S) + CH_WORDS + (k.ring_slots <= CB_TWC_LDS ? 2 * k.ring_slots : 0) +
-                CB_EV_BLOCK * 4;  // cb_device.h: LDS_CAP .. LDS_TWC + the event block (env-major plans keep the scope scratch in HBM)
+                (k.aos ? CB_POOL_STAGE_WORDS : 0) + CB_EV_BLOCK * 4;  // cb_device.h: LDS_CAP .. LDS_TWC + the event block (env-major plans keep the scope scratch in HBM)
   k.lsh_plan = -1;
   if (!k.aos && (int64_t)k.lds_words * 4 <= MRX_CB_LDS_BYTES) {  // (what mrx_cb_step's launch computes for the automatic choice)
     int lanes = cb_auto_lanes(c->n_envs);

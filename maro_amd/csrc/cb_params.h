@@ -18,6 +18,9 @@ enum { CFL_FRESH = 1, CFL_FINISHED = 2, CFL_PENDING = 4 };
 enum { CB_POOL_WORDS = 6 };  // land tick, scheduling tick, from, to, number (<0: executed), next entry landing at the same tick (-1: last)
 #define CB_LAND_SLOTS 128  /* landing-tick buckets of the delivery pool (power of two): a transfer may take at most 127 ticks */
 #define CB_NO_LAND 0x7fffffff
+#define CB_POOL_STAGE 256        /* pool entries (from the ring's head on) the wave replay kernel keeps a copy of in LDS (cb_device.h::pool_rd) */
+#define CB_BKT_WORDS (2 * CB_LAND_SLOTS + CB_LAND_SLOTS / 32)
+#define CB_POOL_STAGE_WORDS (CB_BKT_WORDS + 1 + CB_POOL_STAGE * CB_POOL_WORDS) /* env-major plans' LDS column: buckets, window anchor, entries */
 #define CB_TWC_LDS 32            /* the trip-window filter's per-slot words ride in the LDS column when the ring has at most this many slots */
 #define CB_TWC_REG 12            /* trip-window frames whose table rows are kept in registers (cb_device.h::action_scope) */
 #define CB_EV_BLOCK 8            /* event records per look-ahead block (cb_device.h::EvWin) */
@@ -54,6 +57,7 @@ struct CbParams {
                       // the LDS column) — a plan-specialised step kernel folds it into its LDS addresses and is only launched with
                       // that many envs per wave; -1: env-major plans (their wave kernels run with lsh 0), lsh stays a kernel argument
   int32_t step_budget;  // per launch: records an env may replay in one step call before it reports "no decision yet" (0: no limit)
+  int32_t pool_stage;   // per launch (mrx_k_cb_replay_wave only; else 0): the env's delivery buckets and this many entries (<= CB_POOL_STAGE) from its pool ring's head on are staged in LDS
   double supply_wm, demand_wm, scope_low_keep, scope_high;
   // ---- per-env struct-of-arrays state: X[word][stride]
   int32_t* hdr;       // [CH_WORDS]

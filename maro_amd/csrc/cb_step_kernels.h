@@ -135,17 +135,59 @@ mrx_k_cb_replay_wave(CbParams K, const int32_t* __restrict__ actions, const int3
   cb::WProf WP;
   WP.count(K, e, 12);
 #define MRX_CB_LW(w) cb::mrx_cb_lds[CB_EV_BLOCK * 4 + (w)]
-  for (int w = lane; w < MRXC_FW; w += 64) MRX_CB_LW(w) = K.live[CB_IX(CD(aos), CD(stride), CD(FW), w, e)];
-  for (int w = lane; w < MRXC_S; w += 64) MRX_CB_LW(LDS_CAP + w) = K.capacity[w];
-  for (int w = lane; w < CH_WORDS; w += 64) MRX_CB_LW(LDS_HDR + w) = K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, w, e)];
-#ifdef MRX_CB_TWC_LDS
-  for (int w = lane; w < MRXC_ring_slots; w += 64) {
-    MRX_CB_LW(LDS_TWC + w) = K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)];
-    MRX_CB_LW(LDS_TWC + MRXC_ring_slots + w) = K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)];
-  }
+#ifdef MRX_CB_POOL_LDS
+  const int pool_head = K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, CH_POOL_HEAD, e)], pool_tail = K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, CH_POOL_TAIL, e)];
 #endif
-  for (int w = lane; w < MRXC_w_words; w += 64) MRX_CB_LW(LDS_FUL + w) = (int32_t)K.fulfilled[CB_IX(CD(aos), CD(stride), CD(w_words), w, e)];
-  for (int w = lane; w < 2 * MRXC_mask_words; w += 64) MRX_CB_LW(LDS_DMK + w) = (int32_t)K.decmask[CB_IX(CD(aos), CD(stride), (2 * CD(mask_words)), w, e)];
+  // Every load of the column in flight before the first LDS write: the loops below have compile-time trip counts and no load sits
+  // behind a branch (a lane past the end reads word 0 again and drops it).  As `for (w = lane; w < N; w += 64) lds = hbm` each
+  // trip waited for its own load: thirteen round trips for the capacities alone.
+#define MRX_CB_FILL_LOAD(v, N, expr) \
+  _Pragma("unroll") for (int i_ = 0; i_ < ((N) + 63) / 64; i_++) { const int w_ = i_ * 64 + lane < (N) ? i_ * 64 + lane : 0; (v)[i_] = (int32_t)(expr); }
+#define MRX_CB_FILL_STORE(v, N, at) \
+  _Pragma("unroll") for (int i_ = 0; i_ < ((N) + 63) / 64; i_++) if (i_ * 64 + lane < (N)) MRX_CB_LW((at) + i_ * 64 + lane) = (v)[i_];
+#if MRXC_aos && MRXC_FW % 4 == 0
+  constexpr int NQ = MRXC_FW / 4, NI = (NQ + 63) / 64;  // env-major: the frame is one contiguous run — 16 bytes per lane and load
+  int4 q[NI];
+  {
+    const int4* src = (const int4*)(K.live + (size_t)e * MRXC_FW);
+#pragma unroll
+    for (int i = 0; i < NI; i++) q[i] = src[(i + 1) * 64 <= NQ || i * 64 + lane < NQ ? i * 64 + lane : 0];
+  }
+#else
+  int32_t q[(MRXC_FW + 63) / 64];
+  MRX_CB_FILL_LOAD(q, MRXC_FW, K.live[CB_IX(CD(aos), CD(stride), CD(FW), w_, e)])
+#endif
+  int32_t vcap[(MRXC_S + 63) / 64], vhdr[1], vful[(MRXC_w_words + 63) / 64], vdmk[(2 * MRXC_mask_words + 63) / 64];
+  MRX_CB_FILL_LOAD(vcap, MRXC_S, K.capacity[w_])
+  MRX_CB_FILL_LOAD(vhdr, CH_WORDS, K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, w_, e)])
+  MRX_CB_FILL_LOAD(vful, MRXC_w_words, K.fulfilled[CB_IX(CD(aos), CD(stride), CD(w_words), w_, e)])
+  MRX_CB_FILL_LOAD(vdmk, 2 * MRXC_mask_words, K.decmask[CB_IX(CD(aos), CD(stride), (2 * CD(mask_words)), w_, e)])
+#ifdef MRX_CB_TWC_LDS
+  int32_t vtf[(MRXC_ring_slots + 63) / 64], vtt[(MRXC_ring_slots + 63) / 64];
+  MRX_CB_FILL_LOAD(vtf, MRXC_ring_slots, K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), w_, e)])
+  MRX_CB_FILL_LOAD(vtt, MRXC_ring_slots, K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), w_, e)])
+#endif
+#if MRXC_aos && MRXC_FW % 4 == 0
+  {
+    int4* dst = (int4*)&MRX_CB_LW(0);
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+      if ((i + 1) * 64 <= NQ || i * 64 + lane < NQ) dst[i * 64 + lane] = q[i];
+  }
+#else
+  MRX_CB_FILL_STORE(q, MRXC_FW, 0)
+#endif
+  MRX_CB_FILL_STORE(vcap, MRXC_S, LDS_CAP)
+  MRX_CB_FILL_STORE(vhdr, CH_WORDS, LDS_HDR)
+  MRX_CB_FILL_STORE(vful, MRXC_w_words, LDS_FUL)
+  MRX_CB_FILL_STORE(vdmk, 2 * MRXC_mask_words, LDS_DMK)
+#ifdef MRX_CB_TWC_LDS
+  MRX_CB_FILL_STORE(vtf, MRXC_ring_slots, LDS_TWC)
+  MRX_CB_FILL_STORE(vtt, MRXC_ring_slots, LDS_TWC + MRXC_ring_slots)
+#endif
+#ifdef MRX_CB_POOL_LDS
+  if (K.pool_stage) cb::pool_stage_load(K, e, pool_head, pool_tail);
+#endif
   __syncthreads();
   WP.mark(K, e, 0);
   int na = (actions && n_actions) ? n_actions[e] : 0;
@@ -154,7 +196,20 @@ mrx_k_cb_replay_wave(CbParams K, const int32_t* __restrict__ actions, const int3
                     (int64_t*)metrics + (size_t)e * 3, done + e, scr);
   __syncthreads();
   WP.mark(K, e, 15);  // (step_env_wave keeps its own clock: this stretch is the sum of its phases 1-6)
+#if MRXC_aos && MRXC_FW % 4 == 0
+  {  // (all the LDS reads first, then the 16-byte stores: a read per trip made the write-back a chain of LDS round trips)
+    const int4* srcl = (const int4*)&MRX_CB_LW(0);
+    int4* dstg = (int4*)(K.live + (size_t)e * MRXC_FW);
+#pragma unroll
+    for (int i = 0; i < NI; i++) q[i] = srcl[(i + 1) * 64 <= NQ || i * 64 + lane < NQ ? i * 64 + lane : 0];
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+      if ((i + 1) * 64 <= NQ || i * 64 + lane < NQ) dstg[i * 64 + lane] = q[i];
+  }
+#else
+#pragma unroll 8
   for (int w = lane; w < MRXC_FW; w += 64) K.live[CB_IX(CD(aos), CD(stride), CD(FW), w, e)] = MRX_CB_LW(w);
+#endif
   for (int w = lane; w < CH_WORDS; w += 64) K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, w, e)] = MRX_CB_LW(LDS_HDR + w);
 #ifdef MRX_CB_TWC_LDS
   for (int w = lane; w < MRXC_ring_slots; w += 64) {
@@ -162,9 +217,13 @@ mrx_k_cb_replay_wave(CbParams K, const int32_t* __restrict__ actions, const int3
     K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), w, e)] = MRX_CB_LW(LDS_TWC + MRXC_ring_slots + w);
   }
 #endif
-  for (int w = lane; w < MRXC_w_words; w += 64) K.fulfilled[CB_IX(CD(aos), CD(stride), CD(w_words), w, e)] = (uint32_t)MRX_CB_LW(LDS_FUL + w);
+#pragma unroll
+  for (int i = 0; i < (MRXC_w_words + 63) / 64; i++)
+    if (i * 64 + lane < MRXC_w_words) K.fulfilled[CB_IX(CD(aos), CD(stride), CD(w_words), i * 64 + lane, e)] = (uint32_t)MRX_CB_LW(LDS_FUL + i * 64 + lane);
   for (int w = lane; w < 2 * MRXC_mask_words; w += 64) K.decmask[CB_IX(CD(aos), CD(stride), (2 * CD(mask_words)), w, e)] = (uint32_t)MRX_CB_LW(LDS_DMK + w);
   WP.mark(K, e, 7);
+#undef MRX_CB_FILL_LOAD
+#undef MRX_CB_FILL_STORE
 #undef MRX_CB_LW
 }
 #endif

@@ -68,6 +68,7 @@ def _declare(L):
     L.cb_emu_set_wave_decisions.argtypes = [vp, i32, i32]
     L.cb_emu_set_replay_overlap.argtypes = [vp, i32]
     L.cb_emu_rank.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.cb_emu_set_pool_stage.argtypes = [vp, i32]
     L.cb_emu_set_observation.argtypes = [vp, vp, i32, vp]
     L.cb_emu_wave_handled.restype = ctypes.c_long
     L.cb_emu_wave_handled.argtypes = [vp]
@@ -137,6 +138,11 @@ class CbEmuBackend:
         out = np.zeros(128, np.int32)
         self._L.cb_emu_rank(ctypes.c_void_p(self._h), int(n), int(mode), _ptr(vv), _ptr(kk), _ptr(out))
         return out[:n]
+
+    def set_pool_stage(self, entries):
+        """K.pool_stage of the wave replay step (env-major builds): how many pool entries from the ring's head on are read out of the LDS
+        copy (0: none, the bucket table neither; the product passes CB_POOL_STAGE = 256)."""
+        self._L.cb_emu_set_pool_stage(ctypes.c_void_p(self._h), int(entries))
 
     def set_replay_overlap(self, on=True):
         """mrx_cb_set_replay_overlap on the harness: classify every env first, then the two wave kernels on disjoint envs (the default)."""

@@ -176,3 +176,29 @@ def test_counting_rank_packed_and_general_forms(specialized):
                 want = np.empty(n, np.int32)
                 want[order] = np.arange(n)
                 assert np.array_equal(b.rank(n, mode, v, key), want), (n, hi, mode)
+
+
+@pytest.mark.parametrize("entries", [0, 2, 256])
+@pytest.mark.parametrize("topology,kwargs,budget", [
+    ("toy.5s_filters", dict(durations=700, snapshot_resolution=10, max_snapshots=7), 0),
+    ("toy.3s_tight", dict(durations=900, snapshot_resolution=3, max_snapshots=9), 7),
+    ("city.180s", dict(start_tick=1440, durations=70, snapshot_resolution=10, max_snapshots=6), 40),
+])
+def test_delivery_pool_staged_in_lds_by_the_wave_replay_step(monkeypatch, topology, kwargs, budget, entries):
+    """mrx_k_cb_replay_wave reads the env's landing-tick buckets and the first K.pool_stage entries of its delivery ring out of an LDS
+    copy (writes go to both).  The window at full size (what the product passes), at two entries (most of the ring falls outside: reads
+    mix the copy and HBM, pushes land on either side, the ring wraps past the anchor) and off — same trajectories as the oracle."""
+    from tests.cb_batch_check import run_bounded_vs_oracle
+    monkeypatch.setenv("MRX_CB_AOS", "1")
+    data = load_topology(topology)
+    n = 4
+    b = CbEmuBackend(data, n_envs=n, max_actions=1, specialized=True, wave_decisions=2, **kwargs)
+    assert b.layout.env_major == 1
+    b.set_pool_stage(entries)
+    if budget:
+        calls, unready = run_bounded_vs_oracle(b, data, kwargs, seeds=np.arange(n) + 31, budget=budget)
+        assert unready > 0
+    else:
+        assert run_batch_vs_oracle(b, data, kwargs, seeds=np.arange(n) + 31, episodes=2) > 20
+    handled, general = b.wave_counts()
+    assert handled > 0 and general > 0

@@ -56,6 +56,7 @@ def main():
     n_replay, n_step = max(c[12], 1), max(c[13], 1)
     print(f"{a.topology}, {n} envs, budget {a.step_budget}, overlap {a.replay_overlap}: {us:.1f} us per batch step (policy + step, profiling build); "
           f"per batch step {c[12] / a.steps:.1f} envs in the replay kernel, {c[13] / a.steps:.1f} in the in-tick kernel")
+    print("raw slots per replay call:", " ".join(f"[{k}]={c[k] / n_replay:.1f}" for k in range(16)))
     tot = sum(c[k] for k in (0, 15, 7))
     print(f"mrx_k_cb_replay_wave: {tot / n_replay:.0f} cycles per call")
     for k, name in enumerate(REPLAY):
