@@ -165,6 +165,8 @@ static int32_t mrx_cb_lds_host[MRXC_lds_words]; /* host harness: one env at a ti
 #define LDS_BKT (LDS_TWC + LDS_TWC_WORDS)
 #define LDS_PSA (LDS_BKT + CB_BKT_WORDS)   /* the window's anchor: pool index of ring position 0 of the copy */
 #define LDS_PST (LDS_PSA + 1)
+#define LDS_EVM (LDS_PST + CB_POOL_STAGE * CB_POOL_WORDS)   /* the event window's bounds: first stream index held, first not held */
+#define LDS_EVW ((LDS_EVM + 2 + 3) & ~3)                    /* its records (16-byte aligned: the column starts on a 16-byte boundary) */
 #define LDS_POOL_WORDS CB_POOL_STAGE_WORDS
 #else
 #define LDS_POOL_WORDS 0
@@ -237,13 +239,53 @@ struct EvWin {
       refill(K, base);
     }
   }
+  MRX_DEVM void close(const CbParams&) {}
 #else
   struct alignas(16) Rec { int32_t w0, a, b, c; };
   MRX_DEVM void open(const CbParams&, int p) { pos = p; }
   MRX_DEVM Rec rec(const CbParams& K) const { return *(const Rec*)(K.ev_rec + (size_t)pos * 4); }
   MRX_DEVM void advance(const CbParams&) { pos++; }
+  MRX_DEVM void close(const CbParams&) {}
 #endif
 };
+
+#ifdef MRX_CB_POOL_LDS
+// The wave replay kernel's window (K.pool_stage): CB_EVW_RECS records fetched by the whole wave, one per lane, together with the
+// env's state (evw_fetch / evw_put) — a step budget's worth of records without a round trip inside the sequential part.  Lane 0 consumes
+// them; past the window it refills CB_EV_BLOCK at a time.  The bounds live in LDS so that the runs of one call share the window.
+MRX_DEV EvWin::Rec evw_fetch(const CbParams& K, int pos) { return *(const EvWin::Rec*)(K.ev_rec + (size_t)(pos + wave::lane()) * 4); }
+MRX_DEV void evw_put(const CbParams& K, int pos, const EvWin::Rec& r) {  // (fetch early, put late: the load joins the state's round trip)
+  const int lane = wave::lane();
+  ((EvWin::Rec*)&LF0(LDS_EVW))[lane] = r;
+  if (lane == 0) { LF0(LDS_EVM) = pos; LF0(LDS_EVM + 1) = pos + CB_EVW_RECS; }
+}
+struct EvWinW {
+  int pos, base, lim;
+  typedef EvWin::Rec Rec;
+  MRX_DEVM void refill(const CbParams& K, int idx) {
+    Rec r[CB_EV_BLOCK];
+#pragma unroll
+    for (int k = 0; k < CB_EV_BLOCK; k++) r[k] = *(const Rec*)(K.ev_rec + (size_t)(idx + k) * 4);
+    Rec* blk = (Rec*)&LF(LDS_EVW);
+#pragma unroll
+    for (int k = 0; k < CB_EV_BLOCK; k++) blk[k] = r[k];
+    base = idx;
+    lim = idx + CB_EV_BLOCK;
+  }
+  MRX_DEVM void open(const CbParams& K, int p) {
+    pos = p;
+    base = LF(LDS_EVM);
+    lim = LF(LDS_EVM + 1);
+    if (p < base || p >= lim) refill(K, p);
+  }
+  MRX_DEVM Rec rec(const CbParams& K) const { return ((const Rec*)&LF(LDS_EVW))[pos - base]; }
+  MRX_DEVM void advance(const CbParams& K) {
+    pos++;
+    if (pos == lim) refill(K, pos);
+  }
+  MRX_DEVM void close(const CbParams& K) { LF(LDS_EVM) = base; LF(LDS_EVM + 1) = lim; }
+};
+#endif
 
 #define RINGW(slot, w) K.ring[CB_IX(CD(aos), CD(stride), ((size_t)CD(ring_slots) * (CD(FW) + 1)), ((size_t)(slot) * (CD(FW) + 1) + (size_t)(w)), e)] /* word w of ring slot `slot` (w = FW: the tick it was taken at) */
 #define GFUL(i) K.fulfilled[CB_IX(CD(aos), CD(stride), CD(w_words), (i), e)]
@@ -1113,7 +1155,7 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
   }
   wave::sync();
 #ifdef MRX_CB_POOL_LDS
-  if (K.pool_stage) pool_stage_load(K, e, GHDR(CH_POOL_HEAD), GHDR(CH_POOL_TAIL));
+  if (K.pool_stage) { pool_stage_load(K, e, GHDR(CH_POOL_HEAD), GHDR(CH_POOL_TAIL)); evw_put(K, GHDR(CH_EV_POS), evw_fetch(K, GHDR(CH_EV_POS))); }
   wave::sync();
 #endif
 #endif
@@ -1134,17 +1176,29 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
     int left = K.step_budget > 0 ? K.step_budget : 0x7fffffff;
     for (;;) {
       if (lane == 0) {  // ---- light records: strictly sequential
-        EvWin W;
-        W.open(K, pos);
-        EvWin::Rec r = W.rec(K);
-        int minland = HDR(CH_POOL_MINLAND);
-        while ((r.w0 & 7) != CB_EV_REBAL && (r.w0 & 7) != CB_EV_TICK_END && left > 0) {
-          light_event(K, e, hd, CD(start_tick) + (r.w0 >> 3), r.w0 & 7, r.a, r.b, r.c, minland);
-          W.advance(K);
-          r = W.rec(K);
-          left--;
+        auto light_run = [&](auto& W) {
+          W.open(K, pos);
+          EvWin::Rec r = W.rec(K);
+          int minland = HDR(CH_POOL_MINLAND);
+          while ((r.w0 & 7) != CB_EV_REBAL && (r.w0 & 7) != CB_EV_TICK_END && left > 0) {
+            light_event(K, e, hd, CD(start_tick) + (r.w0 >> 3), r.w0 & 7, r.a, r.b, r.c, minland);
+            W.advance(K);
+            r = W.rec(K);
+            left--;
+          }
+          W.close(K);
+          ctl[0] = r.w0; ctl[1] = r.a; ctl[2] = W.pos; ctl[3] = left;
+        };
+#ifdef MRX_CB_POOL_LDS
+        if (K.pool_stage) {
+          EvWinW W;
+          light_run(W);
+        } else
+#endif
+        {
+          EvWin W;
+          light_run(W);
         }
-        ctl[0] = r.w0; ctl[1] = r.a; ctl[2] = W.pos; ctl[3] = left;
       }
       wave::sync();
       const int w0 = ctl[0], ra = ctl[1];

@@ -182,7 +182,7 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
       if (decision_tick || frame_end || last) rec(d, CB_EV_TICK_END, (frame_end ? 1 : 0) | (last ? 2 : 0), 0, 0);
     }
     if (ev.size() / 4 > (size_t)0x7fffff00) return bad("event stream too long", MRX_ERR_UNSUPPORTED);
-    ev.resize(ev.size() + 2 * CB_EV_BLOCK * 4, (int32_t)((D << 3) | CB_EV_TICK_END));
+    ev.resize(ev.size() + (2 * CB_EV_BLOCK + CB_EVW_RECS) * 4, (int32_t)((D << 3) | CB_EV_TICK_END));   // (look-ahead reads run past the last record)
     put(&CbParams::ev_rec, ev);
   }
   {

@@ -20,7 +20,9 @@ enum { CB_POOL_WORDS = 6 };  // land tick, scheduling tick, from, to, number (<0
 #define CB_NO_LAND 0x7fffffff
 #define CB_POOL_STAGE 256        /* pool entries (from the ring's head on) the wave replay kernel keeps a copy of in LDS (cb_device.h::pool_rd) */
 #define CB_BKT_WORDS (2 * CB_LAND_SLOTS + CB_LAND_SLOTS / 32)
-#define CB_POOL_STAGE_WORDS (CB_BKT_WORDS + 1 + CB_POOL_STAGE * CB_POOL_WORDS) /* env-major plans' LDS column: buckets, window anchor, entries */
+#define CB_EVW_RECS 64           /* event records the wave replay kernel fetches ahead, one per lane (cb_device.h::EvWinW) */
+#define CB_EVW_WORDS (2 + 3 + CB_EVW_RECS * 4) /* window bounds, alignment slack, records */
+#define CB_POOL_STAGE_WORDS (CB_BKT_WORDS + 1 + CB_POOL_STAGE * CB_POOL_WORDS + CB_EVW_WORDS) /* env-major plans' LDS column: buckets, window anchor, entries; the event window */
 #define CB_TWC_LDS 32            /* the trip-window filter's per-slot words ride in the LDS column when the ring has at most this many slots */
 #define CB_TWC_REG 12            /* trip-window frames whose table rows are kept in registers (cb_device.h::action_scope) */
 #define CB_EV_BLOCK 8            /* event records per look-ahead block (cb_device.h::EvWin) */
