@@ -1075,6 +1075,19 @@ def main():
                 r4w = bench_citi_bike(a4w, dist, dev, rank, world)
                 gc.collect()
                 torch.cuda.empty_cache()
+            # citi_bike at the size the reference SHIPS (ny.*: 800 stations, filter chain 80 -> 40 -> 20): city.800s, sustained — a window
+            # that spans several decision ticks, bounded steps, the wave-cooperative kernels (the toy of configs[3] never leaves the lane kernel)
+            r8 = None
+            if world == 1:
+                a8 = copy.copy(a4)
+                a8.topology, a8.envs, a8.durations, a8.steps, a8.warmup, a8.repeats = "city.800s", 4096, 2880, 900, 300, 1
+                a8.step_budget, a8.bounded_budget, a8.specialize, a8.no_cpu = 24, 0, 1, True
+                try:
+                    r8 = bench_citi_bike(a8, dist, dev, rank, world)
+                except Exception as e:      # (a plan this size compiles for minutes when the in-tree cache misses: never a reason to fail the bench)
+                    r8 = {"error": repr(e)[:300]}
+                gc.collect()
+                torch.cuda.empty_cache()
             # BASELINE.json configs[4]: CIM 22p + the maro.rl DQN EnvSampler loop, 8192 envs per GPU (65536 over 8 GPUs), on-device inference
             a5 = copy.copy(args)
             a5.policy, a5.collect, a5.envs, a5.ring, a5.no_episode = "dqn", True, 8192, max(args.ring, 8), True
@@ -1095,11 +1108,15 @@ def main():
                     if "value" in r_obj and "cpu_baseline_reference" in out and isinstance(out["cpu_baseline_reference"].get("vector_env"), dict):
                         r_obj["cpu_baseline"] = dict(out["cpu_baseline_reference"]["vector_env"], kind="reference", note="maro.vector_env.VectorEnv on this box's cores (headline's cpu_baseline_reference.vector_env)")
                     sec["object_api"] = r_obj
+                if r8 is not None:
+                    if "config" in r8:
+                        r8["config"]["what"] = "citi_bike at the reference's own topology size (800 stations, ny filter chain), sustained over several decision ticks; cpu_baseline: see citi_bike_config4"
+                    sec["citi_bike_city800"] = r8
                 if r4w is not None:
                     r4w["config"]["what"] = "BASELINE.json configs[3] whole (32768 envs) on ONE GPU; cpu_baseline: see citi_bike_config4"
                     sec["citi_bike_config4_one_gpu"] = r4w
                 out["secondary"] = sec
-                out["gpu_seconds_total"] += sum((r or {}).get("gpu_seconds_total", 0.0) for r in (r4, r4w, r5))
+                out["gpu_seconds_total"] += sum((r or {}).get("gpu_seconds_total", 0.0) for r in (r4, r4w, r8, r5))
     if rank == 0 and out is not None:
         print(json.dumps(out))
     if dist is not None:

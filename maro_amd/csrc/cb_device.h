@@ -308,17 +308,22 @@ MRX_DEV int pool_rd(const CbParams& K, int e, int idx, int w) {
   }
   return POOL(idx, w);
 }
-MRX_DEV void pool_rd_entry(const CbParams& K, int e, int idx, int* out) {
+// Entry idx if it lands at tick t and was scheduled before sched_lt (false: out[] is not complete).  From HBM the two words
+// of the test come first — the walk ends on an entry that fails it; from the LDS copy the whole entry is one round trip.
+MRX_DEV bool pool_rd_entry(const CbParams& K, int e, int idx, int t, int sched_lt, int* out) {
   if (K.pool_stage) {
     const int p = pool_pos(K, idx);
     if (p < K.pool_stage) {
 #pragma unroll
       for (int w = 0; w < CB_POOL_WORDS; w++) out[w] = LF(LDS_PST + p * CB_POOL_WORDS + w);
-      return;
+      return out[0] == t && out[1] < sched_lt;
     }
   }
+  out[0] = POOL(idx, 0); out[1] = POOL(idx, 1);
+  if (!(out[0] == t && out[1] < sched_lt)) return false;
 #pragma unroll
-  for (int w = 0; w < CB_POOL_WORDS; w++) out[w] = POOL(idx, w);
+  for (int w = 2; w < CB_POOL_WORDS; w++) out[w] = POOL(idx, w);
+  return true;
 }
 MRX_DEV void pool_wr(const CbParams& K, int e, int idx, int w, int v) {
   POOL(idx, w) = v;
@@ -367,9 +372,12 @@ MRX_DEV void pool_stage_load(const CbParams& K, int e, int head, int tail) {
 }
 #else
 MRX_DEV int pool_rd(const CbParams& K, int e, int idx, int w) { return POOL(idx, w); }
-MRX_DEV void pool_rd_entry(const CbParams& K, int e, int idx, int* out) {
+MRX_DEV bool pool_rd_entry(const CbParams& K, int e, int idx, int t, int sched_lt, int* out) {  // (see the LDS-copy form above)
+  out[0] = POOL(idx, 0); out[1] = POOL(idx, 1);
+  if (!(out[0] == t && out[1] < sched_lt)) return false;
 #pragma unroll
-  for (int w = 0; w < CB_POOL_WORDS; w++) out[w] = POOL(idx, w);
+  for (int w = 2; w < CB_POOL_WORDS; w++) out[w] = POOL(idx, w);
+  return true;
 }
 MRX_DEV void pool_wr(const CbParams& K, int e, int idx, int w, int v) { POOL(idx, w) = v; }
 MRX_DEV int bkt_rd(const CbParams& K, int e, int i) { return BKT(i); }
@@ -381,30 +389,37 @@ MRX_DEV void set_bikes(const CbParams& K, int e, int32_t* hd, int s, int v) {  /
   if (v < ST(LV_MIN_BIKES, s)) ST(LV_MIN_BIKES, s) = v;
 }
 
+#if defined(MRX_SPECIALIZED) && MRXC_aos
+// ---- env-major plans: these run on ONE lane of the env's wave (the wave replay kernel), where every dependent read is paid in
+// full — so each reads everything it may need up front, in one round trip.  (Same arithmetic, same order of writes as the forms
+// below, which the one-env-per-lane kernels keep: there 64 lanes share the memory pipes and speculative reads cost throughput —
+// measured on toy.3s_4t, 32768 envs: 413 -> 381 M env-steps/s with these forms.)
 // decision_strategy.py:295-343 — bikes that do not fit go to the neighbours of `cur`, nearest first
+enum { CB_NB_CHUNK = MRXC_nb_stride >= 8 ? 8 : MRXC_nb_stride > 1 ? MRXC_nb_stride : 1 };
 MRX_DEV void move_to_neighbor(const CbParams& K, int e, int32_t* hd, int src, int cur, int number) {
-  // Eight neighbours per trip: their numbers in one round trip (independent loads; the row is nb_stride long, -1 past the count;
-  // the first eight do not wait for the count), then their bikes / capacity / min_bikes in one (distinct stations, and nothing
-  // below writes another neighbour's), then the arithmetic.  One load after the other made every overflowing delivery a chain
-  // of a dozen dependent round trips — and a decision tick at the reference's size lands ~200 deliveries per env.
+  // A chunk of (up to eight) neighbours per trip: their numbers in one round trip (independent loads; the row is nb_stride long,
+  // -1 past the count; the first chunk does not wait for the count), then their bikes / capacity / min_bikes in one (distinct
+  // stations, and nothing below writes another neighbour's), then the arithmetic.  One load after the other made every
+  // overflowing delivery a chain of a dozen dependent round trips — and a decision tick at the reference's size lands ~200
+  // deliveries per env.
   const int32_t* row = K.nb + (size_t)cur * CD(nb_stride);
-  int nbv[8];
+  int nbv[CB_NB_CHUNK];
 #pragma unroll
-  for (int k = 0; k < 8; k++) nbv[k] = row[k < CD(nb_stride) ? k : 0];
+  for (int k = 0; k < CB_NB_CHUNK; k++) nbv[k] = row[k < CD(nb_stride) ? k : 0];
   const int cnt = K.nb_cnt[cur];
-  for (int i0 = 0; i0 < cnt && number > 0; i0 += 8) {
+  for (int i0 = 0; i0 < cnt && number > 0; i0 += CB_NB_CHUNK) {
     if (i0) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) nbv[k] = row[i0 + k < CD(nb_stride) ? i0 + k : i0];
+      for (int k = 0; k < CB_NB_CHUNK; k++) nbv[k] = row[i0 + k < CD(nb_stride) ? i0 + k : i0];
     }
-    int bv[8], cv[8], mv[8];
+    int bv[CB_NB_CHUNK], cv[CB_NB_CHUNK], mv[CB_NB_CHUNK];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < CB_NB_CHUNK; k++) {
       const int nb = i0 + k < cnt ? nbv[k] : nbv[0];
       bv[k] = ST(LV_BIKES, nb); cv[k] = CAP(nb); mv[k] = ST(LV_MIN_BIKES, nb);
     }
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < CB_NB_CHUNK; k++) {
       const int i = i0 + k;
       if (i < cnt && number > 0) {
         const int nb = nbv[k];
@@ -438,6 +453,40 @@ MRX_DEV void land_bikes(const CbParams& K, int e, int32_t* hd, bool deliver, int
   if (b + accept < mn) ST(LV_MIN_BIKES, to) = b + accept;
 }
 
+#else
+// decision_strategy.py:295-343 — bikes that do not fit go to the neighbours of `cur`, nearest first
+MRX_DEV void move_to_neighbor(const CbParams& K, int e, int32_t* hd, int src, int cur, int number) {
+  const int cnt = K.nb_cnt[cur];
+  for (int i = 0; i < cnt && number > 0; i++) {
+    const int nb = K.nb[(size_t)cur * CD(nb_stride) + i];
+    const int b = ST(LV_BIKES, nb);
+    int accept = CAP(nb) - b;
+    if (accept > number) accept = number;
+    set_bikes(K, e, hd, nb, b + accept);
+    const int target = CD(extra_cost_mode) == 0 ? src : CD(extra_cost_mode) == 1 ? cur : nb;
+    ST(LV_EXTRA_COST, target) += accept * (i + 1);
+    number -= accept;
+  }
+}
+
+// _on_bike_returned :439-466 (deliver = false) and _on_bike_deliver :494-519 (deliver = true)
+MRX_DEV void land_bikes(const CbParams& K, int e, int32_t* hd, bool deliver, int frm, int to, int n) {
+  const int b = ST(LV_BIKES, to);
+  int accept = CAP(to) - b;
+  if (accept > n) accept = n;
+  if (accept < n) {
+    if (!deliver) ST(LV_FAILED_RETURN, to) += n - accept;
+    move_to_neighbor(K, e, hd, frm, to, n - accept);
+  }
+  if (deliver && accept > 0) {
+    ST(LV_TRANSFER_COST, to) += accept;
+    HDR(CH_OPER) += accept;
+  }
+  set_bikes(K, e, hd, to, b + accept);
+}
+
+#endif
+
 // The delivery pool: DeliverBike events in flight, appended in scheduling (= insertion) order, and — since a decision tick at the
 // reference's topology size puts ~200 of them in flight per env — threaded by LANDING tick: slot (land mod CB_LAND_SLOTS) of the
 // env's bucket table holds the first / last pool entry landing at that tick (entry word 5 = the next one), a 128-bit mask says
@@ -456,9 +505,8 @@ MRX_DEV void pool_exec_until(const CbParams& K, int e, int32_t* hd, int t, int s
   const int slot = t & (CB_LAND_SLOTS - 1);
   int idx = bkt_rd(K, e, BKT_HEAD(slot));
   while (idx >= 0) {
-    int w[CB_POOL_WORDS];  // the whole entry in one round trip
-    pool_rd_entry(K, e, idx, w);
-    if (!(w[0] == t && w[1] < sched_lt)) break;
+    int w[CB_POOL_WORDS];
+    if (!pool_rd_entry(K, e, idx, t, sched_lt, w)) break;
     land_bikes(K, e, hd, true, w[2], w[3], w[4]);
     pool_wr(K, e, idx, 4, -1);
     idx = w[5];

@@ -76,6 +76,8 @@ def test_bench_default_line_carries_configs_4_and_5():
     assert j["sustained"]["resets"] >= 6 and j["sustained"]["seconds"] > 0.5
     w4 = sec["citi_bike_config4_one_gpu"]
     assert w4["config"]["envs_per_gpu"] == 32768 and w4["parity"]["ok"] is True and w4["value"] > c4["value"]
+    c8 = sec["citi_bike_city800"]   # the reference's own topology size, sustained (its own steps / warmup: a window over several decision ticks)
+    assert "city.800s" in c8["metric"] and c8["config"]["envs_per_gpu"] == 4096 and c8["steps"] == 900 and c8["parity"]["ok"] is True and c8["value"] > 1e7, c8
     obj = sec["object_api"]
     assert obj["parity"]["ok"] is True and obj["value"] > 5e4 and obj["value_default_gc"]["value"] > 0 and obj["env_view"]["value"] > 100, obj
     ref = j.get("cpu_baseline_reference")
