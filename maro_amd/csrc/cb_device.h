@@ -249,6 +249,9 @@ struct EvWin {
 #endif
 };
 
+#ifndef CB_POOL_EVENT_COST
+#define CB_POOL_EVENT_COST 3
+#endif
 #ifdef MRX_CB_POOL_LDS
 // The wave replay kernel's window (K.pool_stage): CB_EVW_RECS records fetched by the whole wave, one per lane, together with the
 // env's state (evw_fetch / evw_put) — a step budget's worth of records without a round trip inside the sequential part.  Lane 0 consumes
@@ -1229,10 +1232,11 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
           EvWin::Rec r = W.rec(K);
           int minland = HDR(CH_POOL_MINLAND);
           while ((r.w0 & 7) != CB_EV_REBAL && (r.w0 & 7) != CB_EV_TICK_END && left > 0) {
+            const bool pooled = minland <= CD(start_tick) + (r.w0 >> 3);   // deliveries land before this record: several times a plain record's work
             light_event(K, e, hd, CD(start_tick) + (r.w0 >> 3), r.w0 & 7, r.a, r.b, r.c, minland);
             W.advance(K);
             r = W.rec(K);
-            left--;
+            left -= pooled ? 1 + CB_POOL_EVENT_COST : 1;
           }
           W.close(K);
           ctl[0] = r.w0; ctl[1] = r.a; ctl[2] = W.pos; ctl[3] = left;
