@@ -249,9 +249,6 @@ struct EvWin {
 #endif
 };
 
-#ifndef CB_POOL_EVENT_COST
-#define CB_POOL_EVENT_COST 3
-#endif
 #ifdef MRX_CB_POOL_LDS
 // The wave replay kernel's window (K.pool_stage): CB_EVW_RECS records fetched by the whole wave, one per lane, together with the
 // env's state (evw_fetch / evw_put) — a step budget's worth of records without a round trip inside the sequential part.  Lane 0 consumes
@@ -341,37 +338,43 @@ MRX_DEV void bkt_wr(const CbParams& K, int e, int i, int v) {
   if (K.pool_stage) LF(LDS_BKT + i) = v;
 }
 // Fills the copy (all lanes of the env's wave; head / tail: the env's CH_POOL_HEAD / CH_POOL_TAIL): the bucket table, and the entries
-// between the ring's head and tail that fit.  Entries pushed later land in the copy through pool_wr.
-MRX_DEV void pool_stage_load(const CbParams& K, int e, int head, int tail) {
+// between the ring's head and tail that fit.  Entries pushed later land in the copy through pool_wr.  In two halves — fetch issues
+// the loads, put writes LDS — so that the caller can have them in flight together with the rest of the env's state.
+// Every load in flight before the first LDS write: no load sits behind a branch (positions past the table / past the ring's tail
+// read a valid word again and are not used), a loop with a run-time trip count would wait for each trip's loads in turn.
+struct PoolStage {
+  enum { NB = (CB_BKT_WORDS + 63) / 64, NP = CB_POOL_STAGE * CB_POOL_WORDS / 64 };
+  int vb[NB], vp[NP], a;
+};
+MRX_DEV void pool_stage_fetch(const CbParams& K, int e, int head, int tail, PoolStage& S) {
   const int lane = wave::lane();
-  const int a = head % CD(pool_cap);
+  S.a = head % CD(pool_cap);
   int n = tail - head;
   if (n > K.pool_stage) n = K.pool_stage;
-  // every load in flight before the first LDS write: no load sits behind a branch (positions past the table / past the ring's
-  // tail read a valid word again and are not used), a loop with a run-time trip count would wait for each trip's loads in turn
-  constexpr int NB = (CB_BKT_WORDS + 63) / 64, NP = CB_POOL_STAGE * CB_POOL_WORDS / 64;
-  int vb[NB], vp[NP];
 #pragma unroll
-  for (int k = 0; k < NB; k++) {
+  for (int k = 0; k < PoolStage::NB; k++) {
     const int i = k * 64 + lane;
-    vb[k] = BKT(i < CB_BKT_WORDS ? i : 0);
+    S.vb[k] = BKT(i < CB_BKT_WORDS ? i : 0);
   }
 #pragma unroll
-  for (int k = 0; k < NP; k++) {
+  for (int k = 0; k < PoolStage::NP; k++) {
     const int i = k * 64 + lane;
     const int p = i / CB_POOL_WORDS, w = i - p * CB_POOL_WORDS;
-    int idx = a + (p < n ? p : 0);
+    int idx = S.a + (p < n ? p : 0);
     if (idx >= CD(pool_cap)) idx -= CD(pool_cap);
-    vp[k] = POOL(idx, w);
+    S.vp[k] = POOL(idx, w);
   }
+}
+MRX_DEV void pool_stage_put(const CbParams& K, const PoolStage& S) {
+  const int lane = wave::lane();
 #pragma unroll
-  for (int k = 0; k < NB; k++) {
+  for (int k = 0; k < PoolStage::NB; k++) {
     const int i = k * 64 + lane;
-    if (i < CB_BKT_WORDS) LF0(LDS_BKT + i) = vb[k];
+    if (i < CB_BKT_WORDS) LF0(LDS_BKT + i) = S.vb[k];
   }
 #pragma unroll
-  for (int k = 0; k < NP; k++) LF0(LDS_PST + k * 64 + lane) = vp[k];
-  if (lane == 0) LF0(LDS_PSA) = a;
+  for (int k = 0; k < PoolStage::NP; k++) LF0(LDS_PST + k * 64 + lane) = S.vp[k];
+  if (lane == 0) LF0(LDS_PSA) = S.a;
 }
 #else
 MRX_DEV int pool_rd(const CbParams& K, int e, int idx, int w) { return POOL(idx, w); }
@@ -1206,7 +1209,12 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
   }
   wave::sync();
 #ifdef MRX_CB_POOL_LDS
-  if (K.pool_stage) { pool_stage_load(K, e, GHDR(CH_POOL_HEAD), GHDR(CH_POOL_TAIL)); evw_put(K, GHDR(CH_EV_POS), evw_fetch(K, GHDR(CH_EV_POS))); }
+  if (K.pool_stage) {
+    PoolStage PS;
+    pool_stage_fetch(K, e, GHDR(CH_POOL_HEAD), GHDR(CH_POOL_TAIL), PS);
+    pool_stage_put(K, PS);
+    evw_put(K, GHDR(CH_EV_POS), evw_fetch(K, GHDR(CH_EV_POS)));
+  }
   wave::sync();
 #endif
 #endif
@@ -1232,11 +1240,10 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
           EvWin::Rec r = W.rec(K);
           int minland = HDR(CH_POOL_MINLAND);
           while ((r.w0 & 7) != CB_EV_REBAL && (r.w0 & 7) != CB_EV_TICK_END && left > 0) {
-            const bool pooled = minland <= CD(start_tick) + (r.w0 >> 3);   // deliveries land before this record: several times a plain record's work
             light_event(K, e, hd, CD(start_tick) + (r.w0 >> 3), r.w0 & 7, r.a, r.b, r.c, minland);
             W.advance(K);
             r = W.rec(K);
-            left -= pooled ? 1 + CB_POOL_EVENT_COST : 1;
+            left--;
           }
           W.close(K);
           ctl[0] = r.w0; ctl[1] = r.a; ctl[2] = W.pos; ctl[3] = left;

@@ -138,8 +138,6 @@ mrx_k_cb_replay_wave(CbParams K, const int32_t* __restrict__ actions, const int3
 #ifdef MRX_CB_POOL_LDS
   const int pool_head = K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, CH_POOL_HEAD, e)], pool_tail = K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, CH_POOL_TAIL, e)];
   const int ev_pos = K.hdr[CB_IX(CD(aos), CD(stride), CH_WORDS, CH_EV_POS, e)];
-  cb::EvWin::Rec ev_rec0;
-  if (K.pool_stage) ev_rec0 = cb::evw_fetch(K, ev_pos);
 #endif
   // Every load of the column in flight before the first LDS write: the loops below have compile-time trip counts and no load sits
   // behind a branch (a lane past the end reads word 0 again and drops it).  As `for (w = lane; w < N; w += 64) lds = hbm` each
@@ -170,6 +168,12 @@ mrx_k_cb_replay_wave(CbParams K, const int32_t* __restrict__ actions, const int3
   MRX_CB_FILL_LOAD(vtf, MRXC_ring_slots, K.twc_fi[CB_IX(CD(aos), CD(stride), CD(ring_slots), w_, e)])
   MRX_CB_FILL_LOAD(vtt, MRXC_ring_slots, K.twc_tick[CB_IX(CD(aos), CD(stride), CD(ring_slots), w_, e)])
 #endif
+#ifdef MRX_CB_POOL_LDS
+  // (the loads that need a header word go out last — everything above is in flight while that word arrives — and land last)
+  cb::EvWin::Rec ev_rec0;
+  cb::PoolStage PS;
+  if (K.pool_stage) { ev_rec0 = cb::evw_fetch(K, ev_pos); cb::pool_stage_fetch(K, e, pool_head, pool_tail, PS); }
+#endif
 #if MRXC_aos && MRXC_FW % 4 == 0
   {
     int4* dst = (int4*)&MRX_CB_LW(0);
@@ -189,7 +193,7 @@ mrx_k_cb_replay_wave(CbParams K, const int32_t* __restrict__ actions, const int3
   MRX_CB_FILL_STORE(vtt, MRXC_ring_slots, LDS_TWC + MRXC_ring_slots)
 #endif
 #ifdef MRX_CB_POOL_LDS
-  if (K.pool_stage) { cb::pool_stage_load(K, e, pool_head, pool_tail); cb::evw_put(K, ev_pos, ev_rec0); }
+  if (K.pool_stage) { cb::pool_stage_put(K, PS); cb::evw_put(K, ev_pos, ev_rec0); }
 #endif
   __syncthreads();
   WP.mark(K, e, 0);

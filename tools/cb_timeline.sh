@@ -1,6 +1,6 @@
 # city.800s: kernel timeline of a few batch steps (start offsets, durations) — are the two wave kernels side by side?
 export TMPDIR=/tmp; cd /tmp
-C="--scenario citi_bike --no-cpu --topology city.800s --envs 4096 --durations 2880 --steps 300 --warmup 300 --bounded-budget 0 --specialize 1 --step-budget ${BUDGET:-32}"
+C="--scenario citi_bike --no-cpu --topology city.800s --envs 4096 --durations 2880 --steps 300 --warmup 300 --bounded-budget 0 --specialize 1 --step-budget ${BUDGET:-24}"
 timeout 300 rocprofv3 --kernel-trace -d /tmp/tl -o r -- python /root/repo/bench.py $C --replay-overlap ${OV:-1} > /dev/null 2>/tmp/tl.err
 f=$(find /tmp/tl -name "r_results.db" | head -1)
 python - "$f" <<'PY'

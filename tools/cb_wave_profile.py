@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--durations", type=int, default=2880)
     ap.add_argument("--steps", type=int, default=900)
     ap.add_argument("--warmup", type=int, default=300)
-    ap.add_argument("--step-budget", type=int, default=32)
+    ap.add_argument("--step-budget", type=int, default=24)
     ap.add_argument("--replay-overlap", type=int, default=0)
     a = ap.parse_args()
     os.environ["MARO_AMD_SPEC_FLAGS"] = (os.environ.get("MARO_AMD_SPEC_FLAGS", "") + " -DMRX_CB_PROFILE").strip()
