@@ -14,6 +14,7 @@ export TMPDIR=/tmp
 tag=$1; shift
 O=gpurun_out/$tag
 mkdir -p $O
+if [ "${HEADLINE:-1}" = "1" ]; then   # (HEADLINE=0: only the optional blocks below, e.g. CB=1 after a change to the citi_bike kernels alone)
 timeout 900 python bench.py "$@" > $O/bench_line.json 2> $O/bench_line.err; echo "bench rc $?"
 [ -x tools/hbm_pattern_bench ] || hipcc -O3 --offload-arch=gfx950 -o tools/hbm_pattern_bench tools/hbm_pattern_bench.hip   # (built from source: the binary is not tracked)
 timeout 120 tools/hbm_pattern_bench --json-out $O/pattern_ceiling.json > $O/pattern_line.json 2> $O/pattern.err; echo "pattern rc $?"
@@ -23,6 +24,7 @@ timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o r -- $B > $
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o r -- $B > $O/write_line.json 2> $O/write.err; echo "write rc $?"
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/sq -o r -- $B > $O/sq_line.json 2> $O/sq.err; echo "sq rc $?"
 python tools/refresh_pmc.py $O profiles/${tag}_rocprofv3.md $O
+fi
 # ---- citi_bike (CB=1): the toy of BASELINE config 4 and city.800s (the reference's own topology size, sustained: a window that
 # spans several decision ticks, bounded steps), same passes, summarised into <tag>_citi_bike.md + latest_pmc_citi_bike.json
 if [ "${CB:-0}" = "1" ]; then
