@@ -1153,6 +1153,25 @@ MRX_DEV int scope_wave(const CbParams& K, int s, int type, int t, int32_t* scr, 
         lo_o = (w0 - CD(start_tick)) * S;
       }
       int trips[2] = {0, 0};
+      if (cnt <= CB_TWC_REG) {
+        // the usual window: every read of every frame in flight before the first sum (lanes >= cnt hold row 0 twice: + 0) — frame
+        // after frame each trip of the loop below waits for its own four reads, ten dependent round trips per decision
+        int vh[CB_TWC_REG][2], vl[CB_TWC_REG][2];
+#pragma unroll
+        for (int k = 0; k < CB_TWC_REG; k++) {
+          const int hi = wave::bcast(hi_o, k), lo = wave::bcast(lo_o, k);
+#pragma unroll
+          for (int a = 0; a < 2; a++) {
+            const int x = key[a] >= 0 ? key[a] : 0;
+            vh[k][a] = K.req_cum[hi + x];
+            vl[k][a] = K.req_cum[lo + x];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < CB_TWC_REG; k++)
+#pragma unroll
+          for (int a = 0; a < 2; a++) trips[a] += vh[k][a] - vl[k][a];
+      } else
       for (int k = 0; k < cnt; k++) {  // wave-uniform
         const int hi = wave::bcast(hi_o, k), lo = wave::bcast(lo_o, k);
 #pragma unroll
