@@ -181,12 +181,14 @@ def test_replay_overlap_does_not_change_a_single_output():
     acts = [torch.zeros((n, 1, 3), dtype=torch.int32, device="cuda") for _ in engs]
     nact = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in engs]
     sums = [torch.zeros(4, dtype=torch.int64, device="cuda") for _ in engs]
+    masks = [(torch.arange(n, device="cuda") % 3 != r).to(torch.uint8) for r in range(3)]
     torch.cuda.synchronize()
     outs = [e.step() for e in engs]
     for i in range(600):
         for e, a, k in zip(engs, acts, nact):
             e.random_policy(i, a, k)
-        outs = [e.step(a, k) for e, a, k in zip(engs, acts, nact)]
+        mask = masks[i % 3] if i % 7 == 0 else None     # (a masked step now and then: masked envs belong to neither kernel)
+        outs = [e.step(a, k, mask) for e, a, k in zip(engs, acts, nact)]
         with torch.cuda.stream(user):   # stream-ordered consumer right behind the step: no host sync in between
             sums[0] += torch.stack([o.to(torch.int64).sum() for o in outs[0]])
         sums[1] += torch.stack([o.to(torch.int64).sum() for o in outs[1]])
