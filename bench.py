@@ -208,7 +208,7 @@ print(steps, episodes, t_step, t_reset)
             "measured": "live, in this run", "reference_from": rt[3], **box_description()}
 
 
-def measured_bytes_citi_bike(topology, n, step_budget, code_key, groups=1):
+def measured_bytes_citi_bike(topology, n, step_budget, code_key, groups=1, replay_period=1):
     """HBM bytes one batch step of this citi_bike configuration really moves (profiles/latest_pmc_citi_bike.json: separate
     --pmc FETCH_SIZE / WRITE_SIZE passes, all kernels of one batch step) -> (bytes or None, basis).  An entry of another build
     (its code_object_key differs) or another batch size is NOT used: the fraction is then null, never a formula."""
@@ -217,9 +217,10 @@ def measured_bytes_citi_bike(topology, n, step_budget, code_key, groups=1):
             pmc = json.load(fp)
     except (OSError, ValueError):
         return None, "no profiles/latest_pmc_citi_bike.json"
-    state = "no PMC entry of this topology / batch size / step budget"
+    state = "no PMC entry of this topology / batch size / step budget / replay period"
     for ent in pmc.get("entries", []):
-        if ent["topology"] == topology and ent["envs_per_launch"] == n and ent.get("step_budget", 0) == step_budget and ent.get("groups_per_gpu", 1) == groups:
+        if ent["topology"] == topology and ent["envs_per_launch"] == n and ent.get("step_budget", 0) == step_budget and ent.get("groups_per_gpu", 1) == groups and \
+                ent.get("replay_period", 1) == replay_period:
             if ent.get("code_object_key") != code_key:
                 state = f"the PMC entry is of another build (code object {ent.get('code_object_key')}, running {code_key})"
                 continue
@@ -276,6 +277,8 @@ def bench_citi_bike(args, dist, dev, rank, world):
             e.set_step_budget(args.step_budget)
         if args.replay_overlap:
             e.set_replay_overlap(True)
+        if args.replay_period > 1:
+            e.set_replay_period(args.replay_period)
         bufs.append(dict(actions=torch.zeros((ng, 1, 3), dtype=torch.int32, device=dev), n_actions=torch.zeros((ng,), dtype=torch.int32, device=dev),
                          counter=torch.zeros((1,), dtype=torch.int64, device=dev),
                          q_nodes=torch.empty((ng, cap), dtype=torch.int32, device=dev) if scope_obs else None,
@@ -420,7 +423,7 @@ def bench_citi_bike(args, dist, dev, rank, world):
     ms_per_step = dt / args.steps * 1e3
     from maro_amd import _lib as mrx_lib
     code_key = f"{getattr(eng, 'code_object_key', None)}+{mrx_lib.source_hash('cb')}"   # step kernels' code object + the library's sources (policy / query kernels)
-    traffic, basis = measured_bytes_citi_bike(topology, n, args.step_budget, code_key, G)
+    traffic, basis = measured_bytes_citi_bike(topology, n, args.step_budget, code_key, G, args.replay_period)
     achieved = None if traffic is None else traffic / (ms_per_step * 1e-3) / 1e9     # per GPU: bytes of one batch step / its wall time
     out = {
         "metric": f"env-steps/sec (decision events/sec), citi_bike {topology}",
@@ -432,7 +435,7 @@ def bench_citi_bike(args, dist, dev, rank, world):
                    "envs_per_gpu": n, "groups_per_gpu": G, "host_enqueue_ms_per_step": t_issued / args.steps * 1e3, "specialized_kernels": bool(eng.specialized), "code_object_key": code_key, "wave_cooperative_step": bool(eng.set_wave_decisions(0)),
                    "env_major_state": bool(eng.layout.env_major), "ring_slots": 16, "parallelism": f"env-shard x{world} (no data-path collective); {G} independent group(s) per GPU on separate HIP streams",
                    "trajectory_gather_ms_32_steps": gather_ms, "mean_ticks_per_env_step": tbar, "envs_finished_in_window": n_done, "env_status_errors": status_bad,
-                   "step_budget": args.step_budget},
+                   "step_budget": args.step_budget, "replay_period": args.replay_period},
         "roofline": {"bound": "hbm", "kernel": "mrx_k_cb_step" if not eng.layout.env_major else "mrx_k_cb_step_wave + mrx_k_cb_replay_wave (+ query, policy)",
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None if achieved is None else achieved / HBM_PEAK_GBPS,
                      "traffic": traffic, "basis": basis, "kernel_ms": step_kernel_ms, "env_steps_per_launch": n,
@@ -1005,6 +1008,7 @@ def main():
     ap.add_argument("--step-mode", type=int, default=0, help="launch form of mrx_cim_step (mrx_cim_set_step_mode): 0 default (sorted), "
                     "1 unsorted, 2 sorted, 4 split")
     ap.add_argument("--topology", default="global_trade.22p_l0.8")
+    ap.add_argument("--replay-period", type=int, default=1, help="citi_bike wave kernels: the replay kernel on every n-th batch step (mrx_cb_set_replay_period)")
     ap.add_argument("--replay-overlap", type=int, default=0, help="citi_bike wave kernels: replay kernel beside the in-tick kernel (mrx_cb_set_replay_overlap; 0 = after it)")
     ap.add_argument("--step-budget", type=int, default=0, help="citi_bike: bounded steps for the main window (mrx_cb_set_step_budget; 0 = every call yields a decision)")
     ap.add_argument("--bounded-budget", type=int, default=24, help="citi_bike: budget of the extra bounded-steps leg (0: skip it)")
@@ -1081,7 +1085,7 @@ def main():
             if world == 1:
                 a8 = copy.copy(a4)
                 a8.topology, a8.envs, a8.durations, a8.steps, a8.warmup, a8.repeats = "city.800s", 4096, 2880, 900, 300, 3   # (value = the median window, as in profiles/*_citi_bike.md)
-                a8.step_budget, a8.bounded_budget, a8.specialize, a8.no_cpu = 24, 0, 1, True
+                a8.step_budget, a8.replay_period, a8.bounded_budget, a8.specialize, a8.no_cpu = 96, 4, 0, 1, True   # (the replay kernel on every 4th batch step, four steps' worth of records per call)
                 try:
                     r8 = bench_citi_bike(a8, dist, dev, rank, world)
                 except Exception as e:      # (a plan this size compiles for minutes when the in-tree cache misses: never a reason to fail the bench)

@@ -166,6 +166,18 @@ int mrx_cb_set_wave_decisions(mrx_cb_handle h, int mode);
 int mrx_cb_set_replay_overlap(mrx_cb_handle h, int on);
 
 /*
+ * How often the general (replay) kernel of the wave-stepped path runs (no reference counterpart; plan-specialised wave kernels, with
+ * mrx_cb_set_step_budget).  A call of the replay kernel costs a fixed part — the env's state into LDS and back, one wave's latency
+ * chain — whatever the budget; with n > 1 it runs on every n-th mrx_cb_step only, with a budget n times as large the same amount of
+ * replaying per call at 1 / n of that fixed cost.  On the calls in between an env that leaves its tick waits: the answer it was
+ * just given is kept with the env (applied when its replay runs), and its row says "no decision yet" exactly as under a step budget
+ * (decisions[e] = {tick, -1, -1, frame_index, 0, valid = 0, ..}, done as it stands); answers to such a row are ignored.  Every env
+ * still sees exactly the reference's sequence of decisions, actions and snapshots.  n = 1 (the default): every call.  Needs
+ * max_actions <= 4.  Ignored while mrx_cb_set_replay_overlap is on and on plans that are not wave-stepped.
+ */
+int mrx_cb_set_replay_period(mrx_cb_handle h, int n);
+
+/*
  * Bounded steps (no reference counterpart).  mrx_cb_step returns when EVERY env of the batch has its next decision, so a call
  * lasts as long as the batch's longest env-step — and env-steps differ by two orders of magnitude (another station deciding at
  * the same tick: nothing to simulate; the last decision of a tick: twenty ticks of trips, two snapshots, a rebalance sweep).

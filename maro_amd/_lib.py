@@ -60,7 +60,7 @@ EXPORTS = ("mrx_last_error", "mrx_version", "mrx_cim_workspace_bytes", "mrx_cim_
            # include/maro_amd_citi_bike.h
            "mrx_cb_workspace_bytes", "mrx_cb_create", "mrx_cb_destroy", "mrx_cb_get_layout", "mrx_cb_reset", "mrx_cb_step",
            "mrx_cb_query", "mrx_cb_random_policy", "mrx_cb_attr_id", "mrx_cb_attr_slots", "mrx_cb_plan_defines",
-           "mrx_cb_load_step_kernels", "mrx_cb_set_lanes_per_wave", "mrx_cb_set_step_budget", "mrx_cb_step_joint", "mrx_cb_set_wave_decisions", "mrx_cb_set_replay_overlap", "mrx_cb_set_observation", "mrx_cb_observation_rows")
+           "mrx_cb_load_step_kernels", "mrx_cb_set_lanes_per_wave", "mrx_cb_set_step_budget", "mrx_cb_step_joint", "mrx_cb_set_wave_decisions", "mrx_cb_set_replay_overlap", "mrx_cb_set_replay_period", "mrx_cb_set_observation", "mrx_cb_observation_rows")
 
 _lib = None
 
@@ -168,6 +168,8 @@ def load() -> ctypes.CDLL:
     L.mrx_cb_set_wave_decisions.argtypes = [vp, i32]
     L.mrx_cb_set_replay_overlap.restype = i32
     L.mrx_cb_set_replay_overlap.argtypes = [vp, i32]
+    L.mrx_cb_set_replay_period.restype = i32
+    L.mrx_cb_set_replay_period.argtypes = [vp, i32]
     L.mrx_cb_random_policy.restype = i32
     L.mrx_cb_random_policy.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
     L.mrx_cb_plan_defines.restype = i64

@@ -808,6 +808,14 @@ MRX_DEV int action_scope(const CbParams& K, int e, int32_t* hd, int s, int type,
 }
 
 // _on_action_received :521-559 for the pending decision of station `s` at tick t
+// The answer a deferred env was given (mrx_cb_set_replay_period: cb::defer_env_wave put it there): copies it out, returns its length
+MRX_DEV int stash_take(const CbParams& K, int e, int32_t* hd, int32_t* sa) {
+#pragma unroll
+  for (int i = 0; i < CB_STASH_MAX * 3; i++) sa[i] = K.stash[CB_IX(CD(aos), CD(stride), (CB_STASH_MAX * 3), i, e)];
+  const int n = HDR(CH_RES1);
+  return n < 0 ? 0 : n > CB_STASH_MAX ? CB_STASH_MAX : n;
+}
+
 MRX_DEV void apply_actions(const CbParams& K, int e, int32_t* hd, int t, int s, const int32_t* actions, int n_actions) {
   // pop the decision from the tick's list
   DMK(s >> 5) &= ~(1u << (s & 31));
@@ -876,7 +884,13 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
     bool resumed = (flags & CFL_PENDING) != 0;
     if (resumed) {
       if (CD(decision_mode) == 0) {
-        apply_actions(K, e, hd, t, HDR(CH_CUR_STATION), actions, n_actions);
+        if (flags & CFL_STASH) {  // the env was deferred: its answer came with an earlier call
+          int32_t sa[CB_STASH_MAX * 3];
+          const int ns = stash_take(K, e, hd, sa);
+          apply_actions(K, e, hd, t, HDR(CH_CUR_STATION), sa, ns);
+        } else {
+          apply_actions(K, e, hd, t, HDR(CH_CUR_STATION), actions, n_actions);
+        }
       } else {
         // core.py:354-366: the agent's i-th action list goes to the i-th reported event; each answered decision event runs, is
         // popped, and its action event runs right behind it, in event (= station) order.  apply_actions' "was it the last
@@ -892,7 +906,7 @@ MRX_DEV void step_env(const CbParams& K, int e, const int32_t* actions, int n_ac
         if (CD(decision_mode) == 1)  // Joint: the unanswered events are finished without effect
           for (int w = 0; w < 2 * CD(mask_words); w++) DMK(w) = 0;
       }
-      flags &= ~CFL_PENDING;
+      flags &= ~(CFL_PENDING | CFL_STASH);
       P.mark(1);
     }
     flags &= ~CFL_FRESH;
@@ -1244,8 +1258,16 @@ MRX_DEV void step_env_wave(const CbParams& K, int e, const int32_t* actions, int
     int pos = LW(LDS_HDR + CH_EV_POS);
     bool resumed = (flags & CFL_PENDING) != 0;
     if (resumed) {
-      if (lane == 0) apply_actions(K, e, hd, t, HDR(CH_CUR_STATION), actions, n_actions);
-      flags &= ~CFL_PENDING;
+      if (lane == 0) {
+        if (flags & CFL_STASH) {  // the env was deferred: its answer came with an earlier call
+          int32_t sa[CB_STASH_MAX * 3];
+          const int ns = stash_take(K, e, hd, sa);
+          apply_actions(K, e, hd, t, HDR(CH_CUR_STATION), sa, ns);
+        } else {
+          apply_actions(K, e, hd, t, HDR(CH_CUR_STATION), actions, n_actions);
+        }
+      }
+      flags &= ~(CFL_PENDING | CFL_STASH);
       wave::sync();
     }
     WP.mark(K, e, 1);

@@ -101,6 +101,8 @@ struct mrx_cb_engine {
   hipFunction_t spec_reset = nullptr, spec_step = nullptr, spec_wave = nullptr, spec_replay = nullptr, spec_classify = nullptr;
   // mrx_cb_set_replay_overlap: the in-tick kernel and the replay kernel of one batch step side by side (a second stream, forked
   // from and joined back into the caller's stream by events inside mrx_cb_step)
+  int replay_period = 1;   // mrx_cb_set_replay_period: the general (replay) kernel runs on every n-th step call
+  long long step_calls = 0;
   bool overlap = false;
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -244,6 +246,13 @@ int mrx_cb_set_replay_overlap(mrx_cb_handle h, int on) {
   return MRX_OK;
 }
 
+int mrx_cb_set_replay_period(mrx_cb_handle h, int n) {
+  if (!h || n < 1) return set_err(MRX_ERR_INVALID_ARG, "null handle or period < 1");
+  if (n > 1 && h->plan.kp.max_actions > CB_STASH_MAX) return set_err(MRX_ERR_UNSUPPORTED, "a replay period needs max_actions <= 4 (the deferred answer is kept per env)");
+  h->replay_period = n;
+  return MRX_OK;
+}
+
 int mrx_cb_observation_rows(mrx_cb_handle h) {
   if (!h) return set_err(MRX_ERR_INVALID_ARG, "null handle");
   return cb_wave_on(h) ? h->plan.layout.scope_cap : h->plan.kp.S;
@@ -348,6 +357,10 @@ static int cb_launch_step(mrx_cb_handle h, const int32_t* d_actions, const int32
       HIP_TRY(hipStreamWaitEvent(main_s, h->ev_join, 0));
       return MRX_OK;
     }
+    // mrx_cb_set_replay_period: on the calls in between the replay kernel sits out; envs that leave their tick put their answer aside
+    // and report "no decision yet" (cb::defer_env_wave)
+    const bool defer = replay && h->spec_wave && h->replay_period > 1 && (++h->step_calls % h->replay_period) != 0;
+    Kc.defer = defer ? 1 : 0;
     // one env per wave: the steps that stay inside their tick; everything else is flagged in K.todo for the general kernel below
     int classified = 0;
     if (h->spec_wave) {
@@ -357,6 +370,7 @@ static int cb_launch_step(mrx_cb_handle h, const int32_t* d_actions, const int32
       hipLaunchKernelGGL(mrx_k_cb_step_wave, dim3(K.n_envs), dim3(64), 0, (hipStream_t)stream, Kc, d_actions, d_n_actions, d_env_mask, d_decisions, d_scope,
                          metw, d_done, classified);
     }
+    if (defer) return MRX_OK;
     d_env_mask = K.todo;
     if (replay) {
       // ... and the general step for the flagged envs, also one env per wave: state in the wave's LDS column (cb::step_env_wave)

@@ -238,6 +238,7 @@ inline int cb_plan(const mrx_cb_topology* t, const mrx_cb_config* c, CbHostPlan*
   env_arr(&CbParams::fulfilled, k.w_words);
   env_arr(&CbParams::decmask, 2 * (int64_t)k.mask_words);
   L.off_prof = env_arr(&CbParams::prof, 16);
+  env_arr(&CbParams::stash, CB_STASH_MAX * 3);
   env_arr(&CbParams::todo, 1);   // (one byte per env is used: written by the wave-cooperative decision kernel, read as the general kernel's mask)
   pl->workspace_bytes = align_up(top, 256);
   L.n_envs = k.n_envs; L.env_stride = k.stride; L.env_major = k.aos; L.n_stations = S; L.frame_words = k.FW; L.ring_slots = k.ring_slots;

@@ -14,7 +14,8 @@ enum { LV_BIKES, LV_SHORTAGE, LV_TRIP_REQUIREMENT, LV_FULFILLMENT, LV_EXTRA_COST
 // Per-env header words (hdr[w][env]).
 enum { CH_TICK, CH_FLAGS, CH_CUR_STATION, CH_CUR_TYPE, CH_TT_POS, CH_TRIPS, CH_SHORT, CH_OPER, CH_POOL_HEAD, CH_POOL_TAIL,
        CH_POOL_MINLAND, CH_LATE, CH_NDEC, CH_STATUS, CH_EV_POS, CH_RES1, CH_WORDS };  // CH_EV_POS: cursor into ev_rec
-enum { CFL_FRESH = 1, CFL_FINISHED = 2, CFL_PENDING = 4 };
+enum { CFL_FRESH = 1, CFL_FINISHED = 2, CFL_PENDING = 4, CFL_STASH = 8 };  // CFL_STASH: the answer to the pending decision waits in CbParams::stash (CH_RES1 actions)
+#define CB_STASH_MAX 4           /* actions an env's stash holds (mrx_cb_set_replay_period needs max_actions <= this) */
 enum { CB_POOL_WORDS = 6 };  // land tick, scheduling tick, from, to, number (<0: executed), next entry landing at the same tick (-1: last)
 #define CB_LAND_SLOTS 128  /* landing-tick buckets of the delivery pool (power of two): a transfer may take at most 127 ticks */
 #define CB_NO_LAND 0x7fffffff
@@ -59,6 +60,7 @@ struct CbParams {
                       // the LDS column) — a plan-specialised step kernel folds it into its LDS addresses and is only launched with
                       // that many envs per wave; -1: env-major plans (their wave kernels run with lsh 0), lsh stays a kernel argument
   int32_t step_budget;  // per launch: records an env may replay in one step call before it reports "no decision yet" (0: no limit)
+  int32_t defer;        // per launch (mrx_k_cb_step_wave): no general kernel follows this call — an env that leaves its tick stashes its answer and reports "no decision yet"
   int32_t pool_stage;   // per launch (mrx_k_cb_replay_wave only; else 0): the env's delivery buckets and this many entries (<= CB_POOL_STAGE) from its pool ring's head on are staged in LDS
   double supply_wm, demand_wm, scope_low_keep, scope_high;
   // ---- per-env struct-of-arrays state: X[word][stride]
@@ -76,6 +78,7 @@ struct CbParams {
   int32_t* prof;        // [16] phase cycle counters (MRX_CB_PROFILE builds only)
   uint32_t* decmask;    // [2 * mask_words] stations with a pending Supply / Demand decision this tick
   uint8_t* todo;        // [n_envs] written by the wave-cooperative decision kernel (cb_wave.h): 1 = the general step must run for this env
+  int32_t* stash;       // [CB_STASH_MAX * 3] the actions a deferred env was answered with (mrx_cb_set_replay_period): applied when its replay runs
   // ---- observation fused into the step (mrx_cb_set_observation; runtime configuration, not part of a specialised plan):
   // obs [n_envs][S][obs_n] float64 = snapshot_list["stations"][decision frame :: obs_attr] of the env's new decision
   double* obs;

@@ -117,6 +117,10 @@ mrx_k_cb_step_wave(CbParams K, const int32_t* __restrict__ actions, const int32_
                                          scope + (size_t)e * CD(scope_cap) * 2, (int64_t*)metrics + (size_t)e * 3, done + e, scr);
   if (classified) {
     if (!ok) __builtin_trap();  // (the same question on the same state, asked twice: an env nobody steps must not pass silently)
+  } else if (!ok && K.defer) {   // mrx_cb_set_replay_period: the general kernel sits this call out
+    cb::defer_env_wave(K, e, actions ? actions + (size_t)e * CD(max_actions) * 3 : nullptr, na, decisions + (size_t)e * 8,
+                       scope + (size_t)e * CD(scope_cap) * 2, (int64_t*)metrics + (size_t)e * 3, done + e);
+    if (threadIdx.x == 0) K.todo[e] = 0;
   } else if (threadIdx.x == 0) {
     K.todo[e] = ok ? 0 : 1;
   }

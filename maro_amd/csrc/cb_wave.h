@@ -46,7 +46,7 @@ MRX_DEV bool decision_step_wave_pre(const CbParams& K, int e, int n_actions, Wav
   // ---- header (lane w holds word w) and the pending-decision masks (lane w holds words w of both masks)
   P.h = lane < CH_WORDS ? W_HDR(lane) : 0;
   const int flags = wave::bcast(P.h, CH_FLAGS);
-  if (!(flags & CFL_PENDING) || (flags & CFL_FINISHED) || n_actions > 1 || MW > 64) return false;
+  if (!(flags & CFL_PENDING) || (flags & (CFL_FINISHED | CFL_STASH)) || n_actions > 1 || MW > 64) return false;
   P.sup = lane < MW ? W_DMK(lane) : 0u;
   P.dem = lane < MW ? W_DMK(MW + lane) : 0u;
   P.s0 = wave::bcast(P.h, CH_CUR_STATION);
@@ -153,6 +153,31 @@ MRX_DEV bool decision_step_wave(const CbParams& K, int e, const int32_t* actions
     *done = 0;
   }
   return true;
+}
+
+// mrx_cb_set_replay_period: a call that the general kernel does not follow.  The env keeps its state; if it stands at a decision the
+// answer it was just given is put aside (CbParams::stash, CFL_STASH: the general step applies it when it runs), and its row says
+// "no decision yet" — exactly what a step budget's unfinished env reports.  Later answers to that row are ignored, as documented.
+MRX_DEV void defer_env_wave(const CbParams& K, int e, const int32_t* actions, int n_actions, int32_t* dec, int32_t* out, int64_t* met, uint8_t* done) {
+  const int lane = wave::lane();
+  const int h = lane < CH_WORDS ? W_HDR(lane) : 0;
+  const int flags = wave::bcast(h, CH_FLAGS), t = wave::bcast(h, CH_TICK);
+  const bool finished = (flags & CFL_FINISHED) != 0;
+  if ((flags & CFL_PENDING) && !(flags & CFL_STASH) && !finished) {
+    const int na = n_actions < 0 ? 0 : n_actions > CB_STASH_MAX ? CB_STASH_MAX : n_actions;
+    if (lane < na * 3) K.stash[CB_IX(CD(aos), CD(stride), (CB_STASH_MAX * 3), lane, e)] = actions[lane];
+    if (lane == 0) { W_HDR(CH_FLAGS) = flags | CFL_STASH; W_HDR(CH_RES1) = na; }
+  }
+  const int m0 = wave::bcast(h, CH_TRIPS), m1 = wave::bcast(h, CH_SHORT), m2 = wave::bcast(h, CH_OPER);
+  if (lane == 0) {
+    dec[0] = t; dec[1] = -1; dec[2] = -1; dec[3] = (t - CD(start_tick)) / CD(res); dec[4] = 0; dec[5] = 0; dec[6] = 0; dec[7] = 0;
+    met[0] = m0; met[1] = m1; met[2] = m2;
+    *done = finished ? 1 : 0;
+  }
+  for (int i = lane; i < CD(scope_cap); i += 64) {
+    out[2 * i] = -1; out[2 * i + 1] = -1;
+    if (K.obs) write_scope_observation_row(K, e, i, -1, t, [&](int, int) { return 0; });
+  }
 }
 
 #undef W_HDR

@@ -15,6 +15,8 @@ struct CbEmu {
   CbHostPlan plan;
   uint8_t* ws = nullptr;
   int pool_stage = CB_POOL_STAGE;   // cb_emu_set_pool_stage: step_env_wave's K.pool_stage (env-major builds) — the product launches with CB_POOL_STAGE
+  int period = 1;        // cb_emu_set_replay_period: mrx_cb_set_replay_period (the general step on every n-th call; deferred envs in between)
+  long calls = 0;
   int overlap = 1;       // cb_emu_set_replay_overlap: the split mrx_cb_step makes (classify, then the two wave kernels on disjoint envs)
   int wave_mode = 0;     // cb_emu_set_wave_decisions: 1 = steps go through cb::decision_step_wave first, like mrx_cb_step does
   bool reverse = false;  // lane order of the wave emulator (forward / reverse exposes missing syncs)
@@ -75,6 +77,14 @@ void cb_emu_step(void* h, const int32_t* actions, const int32_t* n_actions, cons
   static int32_t scr[2 * cb::CBW_MAX];
   CbParams Kr = K;          // what mrx_cb_step passes to mrx_k_cb_replay_wave: the delivery pool's hot end staged in LDS
   Kr.pool_stage = e->pool_stage;
+  // mrx_cb_set_replay_period (wave-stepped plans with the wave-form general step): on the calls in between, envs that leave their tick
+  // are deferred by cb::defer_env_wave instead of replayed
+  const bool defer = e->wave_mode == 2 && e->period > 1 && (++e->calls % e->period) != 0;
+  auto defer_env = [&](int env, const int32_t* act, int nac) {
+    wave::run_wave(e->wave, [&]() {
+      cb::defer_env_wave(K, env, act, nac, dec + (size_t)env * 8, scope + (size_t)env * K.scope_cap * 2, met + (size_t)env * 3, done + env);
+    });
+  };
 #ifdef MRX_CB_LDSFRAME
   if (e->wave_mode == 2 && e->overlap && K.decision_mode == 0 && K.start_tick % K.res == 0 && K.mask_words <= 64) {
     // mrx_cb_step with the replay overlap on: mrx_k_cb_classify over every env FIRST (reads only), then the replay kernel's envs and
@@ -103,7 +113,9 @@ void cb_emu_step(void* h, const int32_t* actions, const int32_t* n_actions, cons
       for (int env = 0; env < K.n_envs; env++) {
         const int32_t* act; int nac;
         args(env, act, nac);
-        if (pass == 0 && todo[env] == 1) {
+        if (pass == 0 && todo[env] == 1 && defer) {
+          defer_env(env, act, (actions && n_actions) ? nac : 0);
+        } else if (pass == 0 && todo[env] == 1) {
           e->general++;
           wave::run_wave(e->wave, [&]() {
             cb::step_env_wave(Kr, env, act, nac, dec + (size_t)env * 8, scope + (size_t)env * K.scope_cap * 2, met + (size_t)env * 3, done + env, scr2);
@@ -138,6 +150,7 @@ void cb_emu_step(void* h, const int32_t* actions, const int32_t* n_actions, cons
       if (ok) { e->handled++; continue; }
       e->general++;
 #ifdef MRX_CB_LDSFRAME
+      if (e->wave_mode == 2 && defer) { defer_env(env, act, (actions && n_actions) ? nac : 0); e->general--; continue; }
       if (e->wave_mode == 2) {  // the general step in its wave form too (plan-specialised LDS-frame builds: mrx_k_cb_replay_wave)
         static int32_t scr2[2 * cb::CBW_MAX + 8];
         wave::run_wave(e->wave, [&]() {
@@ -168,6 +181,7 @@ void cb_emu_rank(void* h, int n, int mode, const int32_t* v, const int32_t* key,
 }
 
 void cb_emu_set_pool_stage(void* h, int entries) { ((CbEmu*)h)->pool_stage = entries < 0 ? 0 : entries > CB_POOL_STAGE ? CB_POOL_STAGE : entries; }
+void cb_emu_set_replay_period(void* h, int n) { ((CbEmu*)h)->period = n < 1 ? 1 : n; }
 void cb_emu_set_replay_overlap(void* h, int on) { ((CbEmu*)h)->overlap = on; }
 void cb_emu_set_wave_decisions(void* h, int on, int reverse) { ((CbEmu*)h)->wave_mode = on; ((CbEmu*)h)->reverse = reverse != 0; }
 long cb_emu_wave_handled(void* h) { return ((CbEmu*)h)->handled; }

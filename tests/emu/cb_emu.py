@@ -69,6 +69,7 @@ def _declare(L):
     L.cb_emu_set_replay_overlap.argtypes = [vp, i32]
     L.cb_emu_rank.argtypes = [vp, i32, i32, vp, vp, vp]
     L.cb_emu_set_pool_stage.argtypes = [vp, i32]
+    L.cb_emu_set_replay_period.argtypes = [vp, i32]
     L.cb_emu_set_observation.argtypes = [vp, vp, i32, vp]
     L.cb_emu_wave_handled.restype = ctypes.c_long
     L.cb_emu_wave_handled.argtypes = [vp]
@@ -143,6 +144,10 @@ class CbEmuBackend:
         """K.pool_stage of the wave replay step (env-major builds): how many pool entries from the ring's head on are read out of the LDS
         copy (0: none, the bucket table neither; the product passes CB_POOL_STAGE = 256)."""
         self._L.cb_emu_set_pool_stage(ctypes.c_void_p(self._h), int(entries))
+
+    def set_replay_period(self, n):
+        """mrx_cb_set_replay_period on the harness (wave_decisions=2): the general step on every n-th call, deferred envs in between."""
+        self._L.cb_emu_set_replay_period(ctypes.c_void_p(self._h), int(n))
 
     def set_replay_overlap(self, on=True):
         """mrx_cb_set_replay_overlap on the harness: classify every env first, then the two wave kernels on disjoint envs (the default)."""

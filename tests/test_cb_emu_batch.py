@@ -202,3 +202,24 @@ def test_delivery_pool_staged_in_lds_by_the_wave_replay_step(monkeypatch, topolo
         assert run_batch_vs_oracle(b, data, kwargs, seeds=np.arange(n) + 31, episodes=2) > 20
     handled, general = b.wave_counts()
     assert handled > 0 and general > 0
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("topology,kwargs,budget,period", [
+    ("toy.5s_filters", dict(durations=700, snapshot_resolution=10, max_snapshots=7), 9, 2),
+    ("toy.3s_tight", dict(durations=900, snapshot_resolution=3, max_snapshots=9), 7, 3),
+    ("city.180s", dict(start_tick=1440, durations=70, snapshot_resolution=10, max_snapshots=6), 40, 2),
+])
+def test_replay_period_defers_envs_without_changing_trajectories(topology, kwargs, budget, period, overlap):
+    """mrx_cb_set_replay_period: the general step runs on every n-th call only; in between an env that leaves its tick keeps the answer
+    it was given (CbParams::stash, CFL_STASH) and reports "no decision yet".  Every env still follows the oracle decision by decision —
+    the deferred answers are applied when the replay runs, later answers to the invalid rows are ignored."""
+    from tests.cb_batch_check import run_bounded_vs_oracle
+    data = load_topology(topology)
+    n = 5
+    b = CbEmuBackend(data, n_envs=n, max_actions=1, specialized=True, wave_decisions=2, **kwargs)
+    b.set_replay_overlap(overlap)
+    b.set_replay_period(period)
+    calls, unready = run_bounded_vs_oracle(b, data, kwargs, seeds=np.arange(n) + 41, budget=budget)
+    handled, general = b.wave_counts()
+    assert unready > 0 and handled > 0 and general > 0

@@ -146,11 +146,11 @@ def test_city800_batch_matches_oracle():
     assert steps > 1000
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_city800_batch_matches_oracle_specialised(overlap):
+@pytest.mark.parametrize("overlap,period", [(True, 1), (False, 1), (False, 3)])
+def test_city800_batch_matches_oracle_specialised(overlap, period):
     """The same batch on the plan-specialised LDS-frame kernels: decision step AND general step one env per wave
     (mrx_k_cb_step_wave + mrx_k_cb_replay_wave), with a step budget on top — what bench.py --topology city.800s runs.  overlap:
-    the two kernels side by side on disjoint envs (mrx_k_cb_classify first; mrx_cb_set_replay_overlap, the default) or in sequence."""
+    the two kernels side by side on disjoint envs (mrx_k_cb_classify first; mrx_cb_set_replay_overlap) or in sequence; period: mrx_cb_set_replay_period."""
     from tests.cb_batch_check import run_bounded_vs_oracle
     from tests.cb_gpu_backend import CbGpuBackend
     data = load_topology("city.800s")
@@ -158,6 +158,7 @@ def test_city800_batch_matches_oracle_specialised(overlap):
     b = CbGpuBackend(data, n_envs=300, max_actions=1, specialize=True, **kw)
     assert b.eng.specialized and b.eng.set_wave_decisions(0)
     b.eng.set_replay_overlap(overlap)
+    b.eng.set_replay_period(period)   # > 1: the replay kernel on every n-th call, deferred envs (stashed answers) in between (mrx_cb_set_replay_period)
     calls, unready = run_bounded_vs_oracle(b, data, kw, seeds=np.arange(300) + 17, budget=96, check_envs=[0, 151, 299])
     assert calls > 1000 and unready > 0
 

@@ -36,14 +36,14 @@ def main():
     line = json.load(open(os.path.join(folder, "bench_line.json")))
     fetch, calls = per_step(db(folder, "fetch"), "FETCH_SIZE")
     write, _ = per_step(db(folder, "write"), "WRITE_SIZE")
-    ent = {"topology": line["metric"].split()[-1], "envs_per_launch": line["config"]["envs_per_gpu"], "step_budget": line["config"].get("step_budget", 0), "groups_per_gpu": line["config"].get("groups_per_gpu", 1),
-           "fetch_size_kib": fetch, "write_size_kib": write, "kernels": calls, "bench_value": line["value"], "bench_ms_per_step": line["ms_per_step"],
+    ent = {"topology": line["metric"].split()[-1], "envs_per_launch": line["config"]["envs_per_gpu"], "step_budget": line["config"].get("step_budget", 0), "replay_period": line["config"].get("replay_period", 1),
+           "groups_per_gpu": line["config"].get("groups_per_gpu", 1), "fetch_size_kib": fetch, "write_size_kib": write, "kernels": calls, "bench_value": line["value"], "bench_ms_per_step": line["ms_per_step"],
            "specialized_kernels": line["config"]["specialized_kernels"], "code_object_key": line["config"].get("code_object_key"), "git_head": os.environ.get("GIT_HEAD")}
     path = os.path.join(out_dir, "latest_pmc_citi_bike.json")
     rec = json.load(open(path)) if os.path.exists(path) else {
         "source": f"profiles/{os.path.basename(os.path.normpath(out_dir))}_citi_bike.md (tools/gpu_profile.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction; bytes per batch step = every mrx_k_cb_* kernel of one batch step: policy, step kernels, snapshot query)",
         "kernel": "every kernel of one batch step (mrx_k_cb_random_policy, mrx_k_cb_step | mrx_k_cb_step_wave + mrx_k_cb_replay_wave, mrx_k_cb_query*)", "entries": []}
-    rec["entries"] = [x for x in rec["entries"] if not (x["topology"] == ent["topology"] and x["envs_per_launch"] == ent["envs_per_launch"] and x.get("step_budget", 0) == ent["step_budget"] and x.get("groups_per_gpu", 1) == ent["groups_per_gpu"])] + [ent]
+    rec["entries"] = [x for x in rec["entries"] if not (x["topology"] == ent["topology"] and x["envs_per_launch"] == ent["envs_per_launch"] and x.get("step_budget", 0) == ent["step_budget"] and x.get("replay_period", 1) == ent["replay_period"] and x.get("groups_per_gpu", 1) == ent["groups_per_gpu"])] + [ent]
     json.dump(rec, open(path, "w"), indent=1)
     buf = io.StringIO()
     with redirect_stdout(buf):
