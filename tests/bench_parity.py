@@ -114,8 +114,7 @@ def replay_against_oracle(engines, bufs, streams, sizes, offs, seed_base, topolo
                 break
         if first is not None:
             break
-    return {"envs_checked": checked, "ok": first is None and status_bad == 0 and steps_checked > 0, "env_steps_checked": steps_checked, "rows_without_decision": unready,
-            "observation_checks": obs_checks,
+    return {"envs_checked": checked, "ok": first is None and status_bad == 0, "env_steps_checked": steps_checked, "observation_checks": obs_checks,
             "final_ring_frames": last, "env_status_errors": status_bad, "first_mismatch": first,
             "what": "every decision, metric, done flag, fused observation sample and the final snapshot ring of the sampled envs vs the CPU oracle "
                     "(oracle/cim_oracle.c), one complete episode of the timed configuration"}
@@ -204,7 +203,8 @@ def replay_citi_bike_against_oracle(eng, seeds, k=6, steps=600, obs_attrs=None, 
         checked += 1
         if first is not None:
             break
-    return {"envs_checked": checked, "ok": first is None and status_bad == 0, "env_steps_checked": steps_checked, "observation_checks": obs_checks,
+    return {"envs_checked": checked, "ok": first is None and status_bad == 0 and steps_checked > 0, "env_steps_checked": steps_checked, "rows_without_decision": unready,
+            "observation_checks": obs_checks,
             "env_status_errors": status_bad, "first_mismatch": first,
             "what": f"every decision event, action scope, metric triple, done flag, device-policy action and sampled stations observation of {len(picks)} envs of the "
                     f"timed engine over the first {steps} batch steps of an episode vs the pure-Python oracle (oracle/citi_bike_oracle.py)"}
