@@ -277,8 +277,8 @@ def bench_citi_bike(args, dist, dev, rank, world):
             e.set_step_budget(args.step_budget)
         if args.replay_overlap:
             e.set_replay_overlap(True)
-        if args.replay_period > 1:
-            e.set_replay_period(args.replay_period)
+        if args.replay_period > 1:   # (the groups' replay calls staggered: one group's replay kernel beside the others' in-tick kernels)
+            e.set_replay_period(args.replay_period, (g * args.replay_period) // G)
         bufs.append(dict(actions=torch.zeros((ng, 1, 3), dtype=torch.int32, device=dev), n_actions=torch.zeros((ng,), dtype=torch.int32, device=dev),
                          counter=torch.zeros((1,), dtype=torch.int64, device=dev),
                          q_nodes=torch.empty((ng, cap), dtype=torch.int32, device=dev) if scope_obs else None,
@@ -1085,7 +1085,7 @@ def main():
             if world == 1:
                 a8 = copy.copy(a4)
                 a8.topology, a8.envs, a8.durations, a8.steps, a8.warmup, a8.repeats = "city.800s", 4096, 2880, 900, 300, 3   # (value = the median window, as in profiles/*_citi_bike.md)
-                a8.step_budget, a8.replay_period, a8.bounded_budget, a8.specialize, a8.no_cpu = 96, 4, 0, 1, True   # (the replay kernel on every 4th batch step, four steps' worth of records per call)
+                a8.step_budget, a8.replay_period, a8.cb_groups, a8.bounded_budget, a8.specialize, a8.no_cpu = 96, 4, 2, 0, 1, True   # (the replay kernel on every 4th batch step, four steps' worth of records per call; two env groups on their own streams, their replay calls staggered)
                 try:
                     r8 = bench_citi_bike(a8, dist, dev, rank, world)
                 except Exception as e:      # (a plan this size compiles for minutes when the in-tree cache misses: never a reason to fail the bench)

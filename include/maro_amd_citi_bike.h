@@ -174,8 +174,11 @@ int mrx_cb_set_replay_overlap(mrx_cb_handle h, int on);
  * (decisions[e] = {tick, -1, -1, frame_index, 0, valid = 0, ..}, done as it stands); answers to such a row are ignored.  Every env
  * still sees exactly the reference's sequence of decisions, actions and snapshots.  n = 1 (the default): every call.  Needs
  * max_actions <= 4.  Ignored while mrx_cb_set_replay_overlap is on and on plans that are not wave-stepped.
+ * phase (0 .. n - 1): counting this engine's mrx_cb_step calls c = 1, 2, ... from now, the replay kernel runs when (phase + c) % n == 0 —
+ * several engines stepped in turn on streams of their own (env groups) take different phases, so that one group's replay kernel (a
+ * few hundred waves, one lane busy in each) runs beside the other groups' in-tick kernels instead of beside their replay kernels.
  */
-int mrx_cb_set_replay_period(mrx_cb_handle h, int n);
+int mrx_cb_set_replay_period(mrx_cb_handle h, int n, int phase);
 
 /*
  * Bounded steps (no reference counterpart).  mrx_cb_step returns when EVERY env of the batch has its next decision, so a call

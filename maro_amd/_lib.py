@@ -169,7 +169,7 @@ def load() -> ctypes.CDLL:
     L.mrx_cb_set_replay_overlap.restype = i32
     L.mrx_cb_set_replay_overlap.argtypes = [vp, i32]
     L.mrx_cb_set_replay_period.restype = i32
-    L.mrx_cb_set_replay_period.argtypes = [vp, i32]
+    L.mrx_cb_set_replay_period.argtypes = [vp, i32, i32]
     L.mrx_cb_random_policy.restype = i32
     L.mrx_cb_random_policy.argtypes = [vp, vp, vp, i64, vp, vp, vp, vp]
     L.mrx_cb_plan_defines.restype = i64

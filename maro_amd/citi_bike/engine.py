@@ -212,11 +212,12 @@ class CitiBikeBatchEngine:
         kernels) or one after the other (the default).  Results unchanged."""
         _lib.check(self._L.mrx_cb_set_replay_overlap(self._h, int(bool(on))), "mrx_cb_set_replay_overlap")
 
-    def set_replay_period(self, n: int = 1) -> None:
+    def set_replay_period(self, n: int = 1, phase: int = 0) -> None:
         """mrx_cb_set_replay_period: the replay kernel of the wave-stepped path on every n-th `step()` only (use a step budget n times
         as large: the same replaying per call at 1 / n of the kernel's fixed cost).  In between, envs that leave their tick keep the
-        answer they were given and report `decisions[e, 5] == 0`, as under a step budget.  Trajectories unchanged."""
-        _lib.check(self._L.mrx_cb_set_replay_period(self._h, int(n)), "mrx_cb_set_replay_period")
+        answer they were given and report `decisions[e, 5] == 0`, as under a step budget.  Trajectories unchanged.  `phase` (0 .. n - 1)
+        shifts which calls those are: env groups on streams of their own take different phases."""
+        _lib.check(self._L.mrx_cb_set_replay_period(self._h, int(n), int(phase)), "mrx_cb_set_replay_period")
 
     def set_step_budget(self, max_records: int = 0) -> None:
         """Bounded steps: an env replays at most ~`max_records` events per `step()` call; envs that have not reached their

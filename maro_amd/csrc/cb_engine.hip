@@ -246,10 +246,11 @@ int mrx_cb_set_replay_overlap(mrx_cb_handle h, int on) {
   return MRX_OK;
 }
 
-int mrx_cb_set_replay_period(mrx_cb_handle h, int n) {
-  if (!h || n < 1) return set_err(MRX_ERR_INVALID_ARG, "null handle or period < 1");
+int mrx_cb_set_replay_period(mrx_cb_handle h, int n, int phase) {
+  if (!h || n < 1 || phase < 0) return set_err(MRX_ERR_INVALID_ARG, "null handle, period < 1 or negative phase");
   if (n > 1 && h->plan.kp.max_actions > CB_STASH_MAX) return set_err(MRX_ERR_UNSUPPORTED, "a replay period needs max_actions <= 4 (the deferred answer is kept per env)");
   h->replay_period = n;
+  h->step_calls = phase % n;   // the replay kernel runs on the calls c with (phase + c) % n == 0, c = 1, 2, ...
   return MRX_OK;
 }
 

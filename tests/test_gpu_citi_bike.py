@@ -158,7 +158,7 @@ def test_city800_batch_matches_oracle_specialised(overlap, period):
     b = CbGpuBackend(data, n_envs=300, max_actions=1, specialize=True, **kw)
     assert b.eng.specialized and b.eng.set_wave_decisions(0)
     b.eng.set_replay_overlap(overlap)
-    b.eng.set_replay_period(period)   # > 1: the replay kernel on every n-th call, deferred envs (stashed answers) in between (mrx_cb_set_replay_period)
+    b.eng.set_replay_period(period, period - 1)   # > 1: the replay kernel on every n-th call, deferred envs (stashed answers) in between (mrx_cb_set_replay_period)
     calls, unready = run_bounded_vs_oracle(b, data, kw, seeds=np.arange(300) + 17, budget=96, check_envs=[0, 151, 299])
     assert calls > 1000 and unready > 0
 

@@ -40,7 +40,7 @@ if [ "${CB:-0}" = "1" ]; then
   }
   cb_pass toy3s --bounded-budget 0
   cb_pass toy3s_32768 --envs 32768 --bounded-budget 0
-  cb_pass city800 --topology city.800s --envs 4096 --durations 2880 --steps 900 --warmup 300 --bounded-budget 0 --step-budget 96 --replay-period 4 --specialize 1
+  cb_pass city800 --topology city.800s --envs 4096 --durations 2880 --steps 900 --warmup 300 --bounded-budget 0 --step-budget 96 --replay-period 4 --cb-groups 2 --specialize 1
 fi
 # ---- config 5 (COLLECT=1): the DQN collection loop at 8192 envs per GPU — kernel trace + the two PMC passes over every kernel of the loop
 if [ "${COLLECT:-0}" = "1" ]; then

@@ -71,6 +71,7 @@ def main(which="bench"):
         ts8, keep8 = topology_struct(data8)
         cap8 = data8.n_stations * (int((data8.time_mean + 6 * data8.time_std) / max(data8.resolution, 1)) + 2) + 4
         todo[("citi_bike", spec.plan_defines(ts8, MrxCbConfig(4096, 0, 0, 2880, 10, 16, 1, cap8, 0, 0), "citi_bike"))] = 1
+        todo[("citi_bike", spec.plan_defines(ts8, MrxCbConfig(2048, 0, 0, 2880, 10, 16, 1, cap8, 0, 0), "citi_bike"))] = 1   # two env groups per GPU
         todo[("citi_bike", spec.plan_defines(ts8, MrxCbConfig(300, 0, 1440, 130, 10, 6, 1, cap8, 0, 0), "citi_bike"))] = 1
         del keep8
     if which in ("goldens", "all"):   # citi_bike golden replays on the GPU (tests/test_gpu_citi_bike.py, test_gpu_specialized.py: 70 envs)

@@ -19,8 +19,9 @@ from tools.rocprof_summary import load_rows, summarise  # noqa: E402
 STEP_KERNELS = ("mrx_k_cb_step", "mrx_k_cb_step_wave", "mrx_k_cb_replay_wave")
 
 
-def per_step(path, counter):
-    """sum over the step kernels of (mean counter value per dispatch x dispatches) / dispatches of the most frequent one"""
+def per_step(path, counter, groups=1):
+    """sum over the step kernels of (mean counter value per dispatch x dispatches) / dispatches of the most frequent one, x the env groups
+    per GPU (a batch step = one launch of every group)"""
     tot, calls = 0.0, {}
     for name, s, e, gx, wx, lds, ctrs in load_rows(path):
         name = name.replace(".kd", "")
@@ -28,14 +29,15 @@ def per_step(path, counter):
             tot += ctrs[counter]
             calls[name] = calls.get(name, 0) + 1
     steps = max((v for k, v in calls.items() if k in STEP_KERNELS), default=1)
-    return tot / max(steps, 1), calls
+    return tot / max(steps, 1) * groups, calls
 
 
 def main():
     folder, name, out_dir = sys.argv[1], sys.argv[2], sys.argv[3]
     line = json.load(open(os.path.join(folder, "bench_line.json")))
-    fetch, calls = per_step(db(folder, "fetch"), "FETCH_SIZE")
-    write, _ = per_step(db(folder, "write"), "WRITE_SIZE")
+    G = line["config"].get("groups_per_gpu", 1)
+    fetch, calls = per_step(db(folder, "fetch"), "FETCH_SIZE", G)
+    write, _ = per_step(db(folder, "write"), "WRITE_SIZE", G)
     ent = {"topology": line["metric"].split()[-1], "envs_per_launch": line["config"]["envs_per_gpu"], "step_budget": line["config"].get("step_budget", 0), "replay_period": line["config"].get("replay_period", 1),
            "groups_per_gpu": line["config"].get("groups_per_gpu", 1), "fetch_size_kib": fetch, "write_size_kib": write, "kernels": calls, "bench_value": line["value"], "bench_ms_per_step": line["ms_per_step"],
            "specialized_kernels": line["config"]["specialized_kernels"], "code_object_key": line["config"].get("code_object_key"), "git_head": os.environ.get("GIT_HEAD")}
